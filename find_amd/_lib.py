@@ -1,0 +1,109 @@
+"""ctypes binding of libfind_hip.so (include/find_hip.h).  There is NO fallback: if the HIP library is
+missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'lib', 'libfind_hip.so')
+MAX_LAYERS = 8
+ABI_VERSION = 1
+
+_lib = None
+
+
+class MlpParams(Structure):
+	_fields_ = [
+		('width', c_int32), ('in_dim', c_int32), ('pe_size', c_int32), ('n_trunk', c_int32),
+		('n_disp', c_int32), ('n_col', c_int32), ('lat_disp', c_int32), ('lat_col', c_int32),
+		('B', c_void_p),
+		('trunk_w', c_void_p * MAX_LAYERS), ('trunk_b', c_void_p * MAX_LAYERS),
+		('disp_w', c_void_p * MAX_LAYERS), ('disp_b', c_void_p * MAX_LAYERS),
+		('col_w', c_void_p * MAX_LAYERS), ('col_b', c_void_p * MAX_LAYERS),
+		('avg_col', c_void_p),
+	]
+
+
+class MlpGrads(Structure):
+	_fields_ = [
+		('trunk_w', c_void_p * MAX_LAYERS), ('trunk_b', c_void_p * MAX_LAYERS),
+		('disp_w', c_void_p * MAX_LAYERS), ('disp_b', c_void_p * MAX_LAYERS),
+		('col_w', c_void_p * MAX_LAYERS), ('col_b', c_void_p * MAX_LAYERS),
+		('lat_disp', c_void_p), ('lat_col', c_void_p),
+	]
+
+
+class RenderParams(Structure):
+	_fields_ = [
+		('image_h', c_int32), ('image_w', c_int32), ('fov_deg', c_float), ('znear', c_float), ('zfar', c_float),
+		('sil_blur_radius', c_float), ('sil_sigma', c_float), ('sil_faces_per_pixel', c_int32),
+		('rgb_sigma', c_float), ('rgb_gamma', c_float), ('background', c_float * 3), ('light_pos', c_float * 3),
+		('ambient', c_float), ('diffuse', c_float), ('specular', c_float), ('shininess', c_float), ('z_clip', c_float),
+	]
+
+
+# name -> (restype, argtypes); mirrors include/find_hip.h one to one
+_P = c_void_p
+_I = c_int64
+PROTOTYPES = {
+	'find_abi_version': (c_int, []),
+	'find_last_error': (c_char_p, []),
+	'find_build_arch': (c_char_p, []),
+	'find_mlp_ws_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I, c_int]),
+	'find_mlp_fwd': (c_int, [POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, c_int, _P]),
+	'find_mlp_bwd_scratch_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I]),
+	'find_mlp_bwd': (c_int, [POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, POINTER(MlpGrads), _P]),
+	'find_register_fwd': (c_int, [_P, _I, _P, _P, _I, _I, _P, _P]),
+	'find_register_bwd_ws_bytes': (c_int64, [_I, _I]),
+	'find_register_bwd': (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
+	'find_sample_points_fwd': (c_int, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+	'find_sample_points_bwd': (c_int, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+	'find_face_areas': (c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
+	'find_nn_fwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+	'find_nn_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+	'find_smooth_ws_bytes': (c_int64, [_I, _I, _I, _I]),
+	'find_smooth_fwd': (c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+	'find_smooth_bwd': (c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+	'find_render_ws_bytes': (c_int64, [POINTER(RenderParams), _I, _I, _I, _I]),
+	'find_render_fwd': (c_int, [POINTER(RenderParams), _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+	'find_render_bwd': (c_int, [POINTER(RenderParams), _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+}
+
+
+def lib():
+	"""Load (once) and return the shared library; raise if it is missing or has the wrong ABI."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	if not os.path.exists(LIB_PATH):
+		raise RuntimeError(f'find_amd: HIP library not built: {LIB_PATH} is missing. Run `python -m find_amd.build` '
+						   '(or __graft_entry__.build()). There is no CPU fallback.')
+	L = ctypes.CDLL(LIB_PATH)
+	for name, (res, args) in PROTOTYPES.items():
+		try:
+			fn = getattr(L, name)
+		except AttributeError as e:
+			raise RuntimeError(f'find_amd: {LIB_PATH} does not export {name}; rebuild it') from e
+		fn.restype = res
+		fn.argtypes = args
+	v = L.find_abi_version()
+	if v != ABI_VERSION:
+		raise RuntimeError(f'find_amd: ABI mismatch: library {v}, binding {ABI_VERSION}; rebuild with python -m find_amd.build')
+	_lib = L
+	return L
+
+
+def check(rc, what):
+	if rc != 0:
+		msg = lib().find_last_error()
+		raise RuntimeError(f'find_amd: {what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+	"""Device pointer of a tensor (None -> NULL)."""
+	return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+	import torch
+	return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,65 @@
+"""Build libfind_hip.so (gfx950) in-tree with hipcc.  `python -m find_amd.build [-j N] [--force]`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+INCLUDE = os.path.join(ROOT, 'include')
+LIBDIR = os.path.join(PKG, 'lib')
+LIB = os.path.join(LIBDIR, 'libfind_hip.so')
+OBJDIR = os.path.join(LIBDIR, 'obj')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
+
+
+def _sources():
+	return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _deps_mtime():
+	hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+	hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith('.h')]
+	return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build(force=False, jobs=4, verbose=True):
+	"""Compile every csrc/*.hip for gfx950 and link libfind_hip.so.  Incremental on mtimes."""
+	os.makedirs(OBJDIR, exist_ok=True)
+	hdr_m = _deps_mtime()
+	todo, objs = [], []
+	for src in _sources():
+		obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + '.o')
+		objs.append(obj)
+		if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m):
+			todo.append((src, obj))
+
+	def cc(job):
+		src, obj = job
+		cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+		if verbose:
+			print('[find_amd.build]', ' '.join(cmd), flush=True)
+		r = subprocess.run(cmd, capture_output=True, text=True)
+		if r.returncode != 0:
+			raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+
+	if todo:
+		with ThreadPoolExecutor(max_workers=jobs) as ex:
+			list(ex.map(cc, todo))
+	if todo or not os.path.exists(LIB):
+		cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+		if verbose:
+			print('[find_amd.build]', ' '.join(cmd), flush=True)
+		r = subprocess.run(cmd, capture_output=True, text=True)
+		if r.returncode != 0:
+			raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+	return LIB
+
+
+if __name__ == '__main__':
+	j = 4
+	if '-j' in sys.argv:
+		j = int(sys.argv[sys.argv.index('-j') + 1])
+	print(build(force='--force' in sys.argv, jobs=j))

@@ -1,0 +1,62 @@
+// Shared helpers for libfind_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+#include "find_hip.h"
+
+namespace find {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) {
+		set_error("%s: %s", what, hipGetErrorString(e));
+		return FIND_ELAUNCH;
+	}
+	return FIND_OK;
+}
+
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bump allocator over a caller-provided workspace (256-byte aligned carves).
+struct Carver {
+	char* base;
+	int64_t off;
+	explicit Carver(void* p) : base(reinterpret_cast<char*>(p)), off(0) {}
+	template <typename T>
+	T* take(int64_t n) {
+		T* r = reinterpret_cast<T*>(base + off);
+		off += align_up(n * (int64_t)sizeof(T), 256);
+		return r;
+	}
+};
+
+}  // namespace find
+
+#define FIND_REQUIRE(cond, ...)            \
+	do {                                   \
+		if (!(cond)) {                     \
+			find::set_error(__VA_ARGS__);  \
+			return FIND_EINVAL;            \
+		}                                  \
+	} while (0)
+
+#define FIND_LAUNCH_CHECK(what)                    \
+	do {                                           \
+		int _rc = find::check_launch(what);        \
+		if (_rc != FIND_OK) return _rc;            \
+	} while (0)
+
+// Wave-level sum over 64 lanes (result valid in every lane).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+	return v;
+}

@@ -1,0 +1,502 @@
+// C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
+// Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
+#include "mlp_kernels.h"
+
+namespace find {
+namespace mlp {
+
+struct Dims {
+	int64_t pos_batch, n_feet, V;
+	bool shared;      // one set of positions evaluated for every foot: trunk computed once
+	int64_t rows_t;   // trunk rows
+	int64_t rows_h;   // head rows
+	int64_t feet_t;   // grid.y of trunk launches
+	int nchunk0;      // K chunks of trunk layer 0
+	int nkt0;         // 256-wide k tiles of trunk layer 0 (dW)
+};
+
+static int make_dims(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t V, Dims* d) {
+	FIND_REQUIRE(p != nullptr, "find_mlp: params is NULL");
+	FIND_REQUIRE(p->width == W, "find_mlp: only width=256 is supported (got %d)", p->width);
+	FIND_REQUIRE(p->in_dim == 3, "find_mlp: only in_dim=3 is supported (got %d)", p->in_dim);
+	FIND_REQUIRE(p->pe_size >= 0 && p->pe_size <= 256 && p->pe_size % 32 == 0, "find_mlp: pe_size must be a multiple of 32 in [0,256] (got %d)", p->pe_size);
+	FIND_REQUIRE(p->n_trunk >= 1 && p->n_trunk <= FIND_MAX_LAYERS, "find_mlp: n_trunk out of range (%d)", p->n_trunk);
+	FIND_REQUIRE(p->n_disp >= 1 && p->n_disp < FIND_MAX_LAYERS, "find_mlp: n_disp out of range (%d)", p->n_disp);
+	FIND_REQUIRE(p->n_col >= 1 && p->n_col < FIND_MAX_LAYERS, "find_mlp: n_col out of range (%d)", p->n_col);
+	FIND_REQUIRE(p->lat_disp >= 0 && p->lat_col >= 0, "find_mlp: negative latent size");
+	FIND_REQUIRE(n_feet >= 1 && V >= 1, "find_mlp: empty batch (n_feet=%lld, n_pts=%lld)", (long long)n_feet, (long long)V);
+	FIND_REQUIRE(pos_batch == 1 || pos_batch == n_feet, "find_mlp: pos_batch must be 1 or n_feet (got %lld vs %lld)", (long long)pos_batch, (long long)n_feet);
+	FIND_REQUIRE(V < (1ll << 31) / 256 && n_feet < (1 << 16), "find_mlp: batch too large for the launch grid");
+	d->pos_batch = pos_batch; d->n_feet = n_feet; d->V = V;
+	d->shared = (pos_batch == 1 && n_feet > 1);
+	d->rows_t = pos_batch * V;
+	d->rows_h = n_feet * V;
+	d->feet_t = pos_batch;
+	const int nsc = p->pe_size >> 4;
+	d->nchunk0 = nsc + 1;
+	d->nkt0 = (int)cdiv((nsc + 1) * 32, 256);
+	return FIND_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int check_weights(const find_mlp_params* p) {
+	FIND_REQUIRE(p->pe_size == 0 || p->B != nullptr, "find_mlp: B is NULL");
+	for (int i = 0; i < p->n_trunk; ++i) {
+		FIND_REQUIRE(p->trunk_w[i] && p->trunk_b[i], "find_mlp: trunk layer %d weight/bias NULL", i);
+		if (i > 0) FIND_REQUIRE(aligned16(p->trunk_w[i]), "find_mlp: trunk_w[%d] must be 16-byte aligned", i);
+	}
+	for (int i = 0; i <= p->n_disp; ++i) {
+		FIND_REQUIRE(p->disp_w[i] && p->disp_b[i], "find_mlp: disp layer %d weight/bias NULL", i);
+		if (i > 0) FIND_REQUIRE(aligned16(p->disp_w[i]), "find_mlp: disp_w[%d] must be 16-byte aligned", i);
+	}
+	for (int i = 0; i <= p->n_col; ++i) {
+		FIND_REQUIRE(p->col_w[i] && p->col_b[i], "find_mlp: col layer %d weight/bias NULL", i);
+		if (i > 0) FIND_REQUIRE(aligned16(p->col_w[i]), "find_mlp: col_w[%d] must be 16-byte aligned", i);
+	}
+	return FIND_OK;
+}
+
+// Forward workspace.  With save=false the hidden activations ping-pong between two buffers per stage.
+struct FwdWs {
+	float* w0p;   // (256, KP0) layer-0 weight in padded PE order
+	float* wd0;   // (256,256) main block of mlp_disp.0.weight
+	float* wc0;   // (256,256) main block of mlp_col.0.weight
+	float* fbd;   // (n_feet,256) per-foot bias of the disp head's first layer
+	float* fbc;
+	float* H[FIND_MAX_LAYERS];
+	float* D[FIND_MAX_LAYERS];
+	float* C[FIND_MAX_LAYERS];
+	float* zd;    // (rows_h,3)
+	float* zc;
+	int64_t bytes;
+};
+
+static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* ws, FwdWs* o) {
+	Carver c(ws);
+	o->w0p = c.take<float>((int64_t)W * KP0);
+	o->wd0 = c.take<float>((int64_t)W * W);
+	o->wc0 = c.take<float>((int64_t)W * W);
+	o->fbd = c.take<float>(d.n_feet * W);
+	o->fbc = c.take<float>(d.n_feet * W);
+	o->zd = c.take<float>(d.rows_h * 3);
+	o->zc = c.take<float>(d.rows_h * 3);
+	float* pt[2] = {nullptr, nullptr};
+	float* pd[2] = {nullptr, nullptr};
+	float* pc[2] = {nullptr, nullptr};
+	for (int i = 0; i < p->n_trunk; ++i) {
+		if (save || !pt[i & 1]) pt[i & 1] = c.take<float>(d.rows_t * W);
+		o->H[i] = pt[i & 1];
+	}
+	for (int i = 0; i < p->n_disp; ++i) {
+		if (save || !pd[i & 1]) pd[i & 1] = c.take<float>(d.rows_h * W);
+		o->D[i] = pd[i & 1];
+	}
+	for (int i = 0; i < p->n_col; ++i) {
+		if (save || !pc[i & 1]) pc[i & 1] = c.take<float>(d.rows_h * W);
+		o->C[i] = pc[i & 1];
+	}
+	o->bytes = c.off;
+}
+
+static int pick_bm(int64_t V, int64_t feet) {
+	if (cdiv(V, 128) * feet >= 512) return 128;
+	if (cdiv(V, 64) * feet >= 512) return 64;
+	return 32;
+}
+
+template <int AMODE, int EPI>
+static void launch_gemm_bm(int bm, const GemmArgs& a, int64_t feet, hipStream_t s) {
+	dim3 block(256);
+	if (bm == 128) {
+		dim3 grid((unsigned)cdiv(a.V, 128), (unsigned)feet);
+		hipLaunchKernelGGL((gemm_kernel<128, AMODE, EPI>), grid, block, 0, s, a);
+	} else if (bm == 64) {
+		dim3 grid((unsigned)cdiv(a.V, 64), (unsigned)feet);
+		hipLaunchKernelGGL((gemm_kernel<64, AMODE, EPI>), grid, block, 0, s, a);
+	} else {
+		dim3 grid((unsigned)cdiv(a.V, 32), (unsigned)feet);
+		hipLaunchKernelGGL((gemm_kernel<32, AMODE, EPI>), grid, block, 0, s, a);
+	}
+}
+
+static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hipStream_t s) {
+	const int bm = pick_bm(a.V, feet);
+	if (amode == AMODE_PE) launch_gemm_bm<AMODE_PE, EPI_BIAS_RELU>(bm, a, feet, s);
+	else if (epi == EPI_BIAS_RELU) launch_gemm_bm<AMODE_MAT, EPI_BIAS_RELU>(bm, a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm_bm<AMODE_MAT, EPI_MASK>(bm, a, feet, s);
+	else launch_gemm_bm<AMODE_MAT, EPI_NONE>(bm, a, feet, s);
+}
+
+static GemmArgs gemm_args_zero() {
+	GemmArgs a;
+	memset(&a, 0, sizeof(a));
+	a.nbase = 1;
+	a.nseg_per_base = 1;
+	return a;
+}
+
+// Linear + ReLU forward:  y = relu(x @ w^T + bias[foot])
+static void linear_fwd(const float* x, int64_t x_foot_stride, const float* w, int ldw, const float* bias,
+					   int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s) {
+	GemmArgs a = gemm_args_zero();
+	a.a0 = x; a.a_foot_stride = x_foot_stride; a.lda = W;
+	a.w0 = w; a.ldw = ldw; a.nchunk = W / KC;
+	a.bias = bias; a.bias_foot_stride = bias_foot_stride;
+	a.y = y; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+	launch_gemm(AMODE_MAT, EPI_BIAS_RELU, a, feet, s);
+}
+
+static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps) {
+	const int64_t cpf = cdiv(V, 32);
+	const int64_t target = 128;
+	int64_t s0 = std::max<int64_t>(1, std::min<int64_t>(cpf, cdiv(target, n_feet)));
+	*cps = (int)cdiv(cpf, s0);
+	*spf = (int)cdiv(cpf, *cps);
+}
+
+}  // namespace mlp
+}  // namespace find
+
+using namespace find;
+using namespace find::mlp;
+
+extern "C" int64_t find_mlp_ws_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts, int save_for_bwd) {
+	Dims d;
+	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;
+	FwdWs w;
+	carve_fwd(p, d, save_for_bwd != 0, nullptr, &w);
+	return w.bytes;
+}
+
+extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+							const float* lat_disp, const float* lat_col, float* disp, float* col, void* ws,
+							int64_t ws_bytes, int save_for_bwd, void* stream) {
+	Dims d;
+	int rc = make_dims(p, pos_batch, n_feet, n_pts, &d);
+	if (rc != FIND_OK) return rc;
+	rc = check_weights(p);
+	if (rc != FIND_OK) return rc;
+	FIND_REQUIRE(pos && ws, "find_mlp_fwd: pos/ws is NULL");
+	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_fwd: lat_disp pointer does not match params.lat_disp=%d", p->lat_disp);
+	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_fwd: lat_col pointer does not match params.lat_col=%d", p->lat_col);
+	FIND_REQUIRE(disp || col, "find_mlp_fwd: both outputs NULL");
+	FwdWs w;
+	carve_fwd(p, d, save_for_bwd != 0, ws, &w);
+	if (ws_bytes < w.bytes) {
+		set_error("find_mlp_fwd: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
+		return FIND_EWORKSPACE;
+	}
+	hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+	const int64_t V = d.V;
+	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
+
+	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers
+	{
+		RepackArgs ra;
+		memset(&ra, 0, sizeof(ra));
+		ra.njobs = 3;
+		ra.job[0] = RepackJob{p->trunk_w[0], w.w0p, W, KP0, p->in_dim + 2 * p->pe_size, 0, KP0, 2, p->pe_size, p->in_dim};
+		ra.job[1] = RepackJob{p->disp_w[0], w.wd0, W, W, ld_d0, 0, W, 0, 0, 0};
+		ra.job[2] = RepackJob{p->col_w[0], w.wc0, W, W, ld_c0, 0, W, 0, 0, 0};
+		hipLaunchKernelGGL(repack_kernel, dim3(96, ra.njobs), dim3(256), 0, s, ra);
+		FIND_LAUNCH_CHECK("repack_kernel");
+	}
+	// 2. per-foot latent bias (model.py:428-437 as a bias)
+	const float* bias_d0 = p->disp_b[0];
+	const float* bias_c0 = p->col_b[0];
+	int64_t bstride_d = 0, bstride_c = 0;
+	if (p->lat_disp > 0) {
+		hipLaunchKernelGGL(latent_bias_kernel, dim3((unsigned)n_feet), dim3(W), 0, s, p->disp_w[0], ld_d0, p->disp_b[0], lat_disp, p->lat_disp, w.fbd);
+		bias_d0 = w.fbd; bstride_d = W;
+	}
+	if (p->lat_col > 0) {
+		hipLaunchKernelGGL(latent_bias_kernel, dim3((unsigned)n_feet), dim3(W), 0, s, p->col_w[0], ld_c0, p->col_b[0], lat_col, p->lat_col, w.fbc);
+		bias_c0 = w.fbc; bstride_c = W;
+	}
+	FIND_LAUNCH_CHECK("latent_bias_kernel");
+
+	// 3. trunk (model.py:421-426).  Layer 0 generates the Fourier features on the fly.
+	{
+		GemmArgs a = gemm_args_zero();
+		a.pos = pos; a.pos_foot_stride = V * 3; a.Bm = p->B; a.pe = p->pe_size;
+		a.w0 = w.w0p; a.ldw = KP0; a.nchunk = d.nchunk0;
+		a.bias = p->trunk_b[0]; a.bias_foot_stride = 0;
+		a.y = w.H[0]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+		launch_gemm(AMODE_PE, EPI_BIAS_RELU, a, d.feet_t, s);
+	}
+	for (int i = 1; i < p->n_trunk; ++i)
+		linear_fwd(w.H[i - 1], V * W, p->trunk_w[i], W, p->trunk_b[i], 0, w.H[i], V, d.feet_t, s);
+	FIND_LAUNCH_CHECK("trunk gemm");
+
+	// 4. heads (model.py:439-440); the trunk rows are shared by every foot when d.shared
+	const float* hl = w.H[p->n_trunk - 1];
+	const int64_t hl_stride = d.shared ? 0 : V * W;
+	if (disp) {
+		linear_fwd(hl, hl_stride, w.wd0, W, bias_d0, bstride_d, w.D[0], V, n_feet, s);
+		for (int i = 1; i < p->n_disp; ++i) linear_fwd(w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s);
+	}
+	if (col) {
+		linear_fwd(hl, hl_stride, w.wc0, W, bias_c0, bstride_c, w.C[0], V, n_feet, s);
+		for (int i = 1; i < p->n_col; ++i) linear_fwd(w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, s);
+	}
+	FIND_LAUNCH_CHECK("head gemm");
+
+	// 5. final 256->3 layers + tanh scalings (model.py:444-449)
+	{
+		HeadOutArgs h;
+		memset(&h, 0, sizeof(h));
+		h.x[0] = w.D[p->n_disp - 1]; h.x[1] = w.C[p->n_col - 1];
+		h.w[0] = p->disp_w[p->n_disp]; h.w[1] = p->col_w[p->n_col];
+		h.b[0] = p->disp_b[p->n_disp]; h.b[1] = p->col_b[p->n_col];
+		h.z[0] = w.zd; h.z[1] = w.zc;
+		h.out[0] = disp; h.out[1] = col;
+		h.avg_col = p->avg_col;
+		h.rows = d.rows_h;
+		const unsigned gx = (unsigned)std::min<int64_t>(cdiv(d.rows_h, 4), 2048);
+		hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 2), dim3(256), 0, s, h);
+		FIND_LAUNCH_CHECK("head_out_fwd_kernel");
+	}
+	return FIND_OK;
+}
+
+// ------------------------------------------------------------------------------------------- backward
+namespace find {
+namespace mlp {
+
+struct BwdWs {
+	float* Tt[FIND_MAX_LAYERS];  // transposed trunk weights (layers >= 1)
+	float* Dt[FIND_MAX_LAYERS];  // transposed disp-head weights (layer 0: main block)
+	float* Ct[FIND_MAX_LAYERS];
+	float* dzD[2];
+	float* dzC[2];
+	float* dzT[2];
+	float* pw;    // dW partial slabs
+	float* pb;    // bias partial slabs
+	float* Sd;    // (n_feet,256) per-foot column sums of the disp head's first-layer dZ
+	float* Sc;
+	float* pwo[2];  // final-layer partials
+	float* pbo[2];
+	int nblk_out;
+	int64_t max_split;
+	int64_t bytes;
+};
+
+static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, BwdWs* o) {
+	Carver c(scratch);
+	for (int i = 1; i < p->n_trunk; ++i) o->Tt[i] = c.take<float>((int64_t)W * W);
+	for (int i = 0; i < p->n_disp; ++i) o->Dt[i] = c.take<float>((int64_t)W * W);
+	for (int i = 0; i < p->n_col; ++i) o->Ct[i] = c.take<float>((int64_t)W * W);
+	for (int i = 0; i < 2; ++i) o->dzD[i] = c.take<float>(d.rows_h * W);
+	for (int i = 0; i < 2; ++i) o->dzC[i] = c.take<float>(d.rows_h * W);
+	for (int i = 0; i < 2; ++i) o->dzT[i] = c.take<float>(d.rows_t * W);
+	int spf, cps;
+	split_policy(d.n_feet, d.V, &spf, &cps);
+	int64_t ms = d.n_feet * spf;
+	split_policy(1, d.V, &spf, &cps);
+	ms = std::max<int64_t>(ms, spf);
+	o->max_split = ms;
+	o->pw = c.take<float>(ms * W * KP0);
+	o->pb = c.take<float>(ms * W);
+	o->Sd = c.take<float>(d.n_feet * W);
+	o->Sc = c.take<float>(d.n_feet * W);
+	o->nblk_out = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(d.rows_h, 32), 1024));
+	for (int i = 0; i < 2; ++i) {
+		o->pwo[i] = c.take<float>((int64_t)o->nblk_out * 3 * W);
+		o->pbo[i] = c.take<float>((int64_t)o->nblk_out * 4);
+	}
+	o->bytes = c.off;
+}
+
+// dW / db of one Linear layer from dz (rows (foot,v)) and its input x.
+static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
+					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
+					   int k_valid, int pe_map, float* db, float* S, hipStream_t s) {
+	int spf, cps;
+	split_policy(feet, V, &spf, &cps);
+	DwArgs a;
+	memset(&a, 0, sizeof(a));
+	a.dz = dz; a.dz_foot_stride = V * W;
+	a.x = x; a.x_foot_stride = x_foot_stride; a.ldx = W;
+	a.pos = pos; a.pos_foot_stride = pos_foot_stride; a.Bm = p->B; a.pe = p->pe_size;
+	a.V = (int)V; a.spf = spf; a.cps = cps; a.Kp = nkt * 256;
+	a.pw = b.pw; a.pb = b.pb;
+	const int nsplit = (int)(feet * spf);
+	dim3 grid((unsigned)nkt, (unsigned)nsplit);
+	if (pos) hipLaunchKernelGGL((dw_kernel<AMODE_PE>), grid, dim3(512), 0, s, a);
+	else hipLaunchKernelGGL((dw_kernel<AMODE_MAT>), grid, dim3(512), 0, s, a);
+	FIND_LAUNCH_CHECK("dw_kernel");
+	ReduceWArgs r;
+	memset(&r, 0, sizeof(r));
+	r.pw = b.pw; r.nsplit = nsplit; r.Kp = a.Kp; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
+	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
+	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)cdiv((int64_t)256 * a.Kp, 256)), dim3(256), 0, s, r);
+	hipLaunchKernelGGL(reduce_b_kernel, dim3(1), dim3(256), 0, s, b.pb, (int)feet, spf, db, S);
+	FIND_LAUNCH_CHECK("reduce kernels");
+	return FIND_OK;
+}
+
+// masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
+static void linear_bwd_dx(const float* dz, const float* wt, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s) {
+	GemmArgs a = gemm_args_zero();
+	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
+	a.w0 = wt; a.ldw = W; a.nchunk = W / KC;
+	a.mask = mask; a.mask_foot_stride = V * W;
+	a.y = y; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+	launch_gemm(AMODE_MAT, EPI_MASK, a, feet, s);
+}
+
+}  // namespace mlp
+}  // namespace find
+
+extern "C" int64_t find_mlp_bwd_scratch_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts) {
+	Dims d;
+	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;
+	BwdWs b;
+	carve_bwd(p, d, nullptr, &b);
+	return b.bytes;
+}
+
+extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+							const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col,
+							const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
+							const find_mlp_grads* g, void* stream) {
+	Dims d;
+	int rc = make_dims(p, pos_batch, n_feet, n_pts, &d);
+	if (rc != FIND_OK) return rc;
+	rc = check_weights(p);
+	if (rc != FIND_OK) return rc;
+	FIND_REQUIRE(pos && ws && scratch && g, "find_mlp_bwd: NULL argument");
+	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
+	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
+	FwdWs w;
+	carve_fwd(p, d, true, const_cast<void*>(ws), &w);
+	if (ws_bytes < w.bytes) {
+		set_error("find_mlp_bwd: forward workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
+		return FIND_EWORKSPACE;
+	}
+	BwdWs b;
+	carve_bwd(p, d, scratch, &b);
+	if (scratch_bytes < b.bytes) {
+		set_error("find_mlp_bwd: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)b.bytes);
+		return FIND_EWORKSPACE;
+	}
+	hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+	const int64_t V = d.V;
+	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
+	const int K0 = p->in_dim + 2 * p->pe_size;
+	const bool act_d = d_disp != nullptr, act_c = d_col != nullptr;
+
+	// gradients of skipped parts are exact zeros
+	auto zero = [&](float* ptr, int64_t n) { if (ptr) (void)hipMemsetAsync(ptr, 0, n * sizeof(float), s); };
+	if (!act_d) {
+		zero(g->disp_w[0], (int64_t)W * ld_d0); zero(g->disp_b[0], W);
+		for (int i = 1; i < p->n_disp; ++i) { zero(g->disp_w[i], (int64_t)W * W); zero(g->disp_b[i], W); }
+		zero(g->disp_w[p->n_disp], 3 * W); zero(g->disp_b[p->n_disp], 3);
+		if (p->lat_disp) zero(g->lat_disp, n_feet * p->lat_disp);
+	}
+	if (!act_c) {
+		zero(g->col_w[0], (int64_t)W * ld_c0); zero(g->col_b[0], W);
+		for (int i = 1; i < p->n_col; ++i) { zero(g->col_w[i], (int64_t)W * W); zero(g->col_b[i], W); }
+		zero(g->col_w[p->n_col], 3 * W); zero(g->col_b[p->n_col], 3);
+		if (p->lat_col) zero(g->lat_col, n_feet * p->lat_col);
+	}
+	if (!act_d && !act_c) {
+		zero(g->trunk_w[0], (int64_t)W * K0); zero(g->trunk_b[0], W);
+		for (int i = 1; i < p->n_trunk; ++i) { zero(g->trunk_w[i], (int64_t)W * W); zero(g->trunk_b[i], W); }
+		return FIND_OK;
+	}
+
+	// 1. transposed weights for the dX GEMMs
+	{
+		RepackArgs ra;
+		memset(&ra, 0, sizeof(ra));
+		int n = 0;
+		for (int i = 1; i < p->n_trunk; ++i) ra.job[n++] = RepackJob{p->trunk_w[i], b.Tt[i], W, W, W, 0, W, 1, 0, 0};
+		ra.job[n++] = RepackJob{p->disp_w[0], b.Dt[0], W, W, ld_d0, 0, W, 1, 0, 0};
+		for (int i = 1; i < p->n_disp; ++i) ra.job[n++] = RepackJob{p->disp_w[i], b.Dt[i], W, W, W, 0, W, 1, 0, 0};
+		ra.job[n++] = RepackJob{p->col_w[0], b.Ct[0], W, W, ld_c0, 0, W, 1, 0, 0};
+		for (int i = 1; i < p->n_col; ++i) ra.job[n++] = RepackJob{p->col_w[i], b.Ct[i], W, W, W, 0, W, 1, 0, 0};
+		ra.njobs = n;
+		hipLaunchKernelGGL(repack_kernel, dim3(64, n), dim3(256), 0, s, ra);
+		FIND_LAUNCH_CHECK("repack_kernel(T)");
+	}
+
+	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
+	int cd = 0, cc = 0;  // current ping-pong index per head
+	{
+		HeadOutBwdArgs h;
+		memset(&h, 0, sizeof(h));
+		h.y[0] = w.D[p->n_disp - 1]; h.y[1] = w.C[p->n_col - 1];
+		h.w[0] = p->disp_w[p->n_disp]; h.w[1] = p->col_w[p->n_col];
+		h.z[0] = w.zd; h.z[1] = w.zc;
+		h.gout[0] = d_disp; h.gout[1] = d_col;
+		h.dy[0] = b.dzD[cd]; h.dy[1] = b.dzC[cc];
+		h.pw[0] = b.pwo[0]; h.pw[1] = b.pwo[1];
+		h.pb[0] = b.pbo[0]; h.pb[1] = b.pbo[1];
+		h.rows = d.rows_h;
+		hipLaunchKernelGGL(head_out_bwd_kernel, dim3((unsigned)b.nblk_out, 2), dim3(256), 0, s, h);
+		if (act_d) hipLaunchKernelGGL(head_out_reduce_kernel, dim3(1), dim3(256), 0, s, b.pwo[0], b.pbo[0], b.nblk_out, g->disp_w[p->n_disp], g->disp_b[p->n_disp]);
+		if (act_c) hipLaunchKernelGGL(head_out_reduce_kernel, dim3(1), dim3(256), 0, s, b.pwo[1], b.pbo[1], b.nblk_out, g->col_w[p->n_col], g->col_b[p->n_col]);
+		FIND_LAUNCH_CHECK("head_out_bwd");
+	}
+
+	const float* hl = w.H[p->n_trunk - 1];
+	const int64_t hl_stride = d.shared ? 0 : V * W;
+
+	// 3. heads, last hidden layer down to the first
+	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
+						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat) -> int {
+		for (int l = nl - 1; l >= 1; --l) {
+			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, s);
+			if (r != FIND_OK) return r;
+			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur ^ 1], V, n_feet, s);
+			cur ^= 1;
+		}
+		int r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, s);
+		if (r != FIND_OK) return r;
+		if (L > 0) {
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(128), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
+			FIND_LAUNCH_CHECK("latent_grad_kernel");
+		}
+		return FIND_OK;
+	};
+	if (act_d) {
+		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp);
+		if (rc != FIND_OK) return rc;
+	}
+	if (act_c) {
+		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col);
+		if (rc != FIND_OK) return rc;
+	}
+
+	// 4. gradient wrt the trunk output: both heads (and, for a shared trunk, every foot) summed in the K loop
+	int ct = 0;
+	{
+		GemmArgs a = gemm_args_zero();
+		const float* A[2]; const float* Wt[2]; int nb = 0;
+		if (act_d) { A[nb] = b.dzD[cd]; Wt[nb] = b.Dt[0]; ++nb; }
+		if (act_c) { A[nb] = b.dzC[cc]; Wt[nb] = b.Ct[0]; ++nb; }
+		a.nbase = nb; a.a0 = A[0]; a.w0 = Wt[0];
+		if (nb > 1) { a.a1 = A[1]; a.w1 = Wt[1]; }
+		a.lda = W; a.ldw = W; a.nchunk = W / KC;
+		if (d.shared) { a.nseg_per_base = (int)n_feet; a.a_seg_stride = V * W; a.a_foot_stride = 0; }
+		else { a.nseg_per_base = 1; a.a_seg_stride = 0; a.a_foot_stride = V * W; }
+		a.mask = hl; a.mask_foot_stride = V * W;
+		a.y = b.dzT[ct]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+		launch_gemm(AMODE_MAT, EPI_MASK, a, d.feet_t, s);
+		FIND_LAUNCH_CHECK("trunk-out dX gemm");
+	}
+
+	// 5. trunk
+	for (int l = p->n_trunk - 1; l >= 1; --l) {
+		rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, b, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, s);
+		if (rc != FIND_OK) return rc;
+		linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct ^ 1], V, d.feet_t, s);
+		ct ^= 1;
+	}
+	rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, s);
+	if (rc != FIND_OK) return rc;
+	FIND_LAUNCH_CHECK("find_mlp_bwd");
+	return FIND_OK;
+}

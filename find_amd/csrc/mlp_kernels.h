@@ -1,0 +1,600 @@
+// fp32-MFMA kernels of the FIND MLP path (gfx950).  Included once by mlp.hip.
+//
+// Data layout in HBM: every activation is a row-major (rows, 256) fp32 matrix whose rows are
+// (foot, vertex) pairs, foot-major.  Workgroup tiles never straddle two feet, so the per-foot latent
+// contribution of the first head layer is a workgroup-uniform bias ("algebraically a
+// per-foot bias") and the shared-template trunk is evaluated once for all feet.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/issue/SIMD, 157.3 TF peak).  Operand maps
+// (cdna_hip_programming.md §3):  A lane l = A[i=l&31][k=l>>5],  B lane l = B[k=l>>5][j=l&31],
+// D lane l reg r = D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31].
+#pragma once
+#include "common.h"
+
+namespace find {
+namespace mlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int W = 256;      // hidden width (reference default, model.py:207)
+constexpr int KC = 32;      // K chunk staged through LDS per step
+constexpr int LDSLD = 36;   // padded LDS row stride (floats): ds_read_b128 of 16 rows hits 16 distinct 16-B slots
+constexpr int KP0 = 768;    // padded K of the first trunk layer's repacked weight (3 k-tiles of 256)
+
+// ---------------------------------------------------------------------------------------------
+// Positional encoding in the PADDED K order used by layer 0:
+//   chunk c (32 columns) for c < pe/16: even c -> sin(2*pi*t_f), odd c -> cos(2*pi*t_f), f = (c/2)*32 + j
+//   then [x, y, z, 0...].   t_f = pos . B[:, f]   (fourier_feature_transform.py:44-52)
+// sinpif/cospif do exact range reduction, so the result is at least as accurate as the reference's
+// sin(fl(2*pi*fl(t))).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pe_value(int kp, int pe, float x, float y, float z, const float* Bl) {
+	const int c = kp >> 5, j = kp & 31;
+	const int nsc = pe >> 4;
+	if (c < nsc) {
+		const int f = (c >> 1) * 32 + j;
+		float t = fmaf(z, Bl[2 * pe + f], fmaf(y, Bl[pe + f], x * Bl[f]));
+		t = 2.0f * t;
+		return (c & 1) ? cospif(t) : sinpif(t);
+	}
+	const int q = kp - nsc * 32;
+	return q == 0 ? x : (q == 1 ? y : (q == 2 ? z : 0.0f));
+}
+
+// padded column -> column of the reference weight base.0.weight (width, in_dim + 2*pe), or -1 for padding
+__host__ __device__ __forceinline__ int pe_col_to_orig(int kp, int pe, int in_dim) {
+	const int c = kp >> 5, j = kp & 31;
+	const int nsc = pe >> 4;
+	if (c < nsc) {
+		const int f = (c >> 1) * 32 + j;
+		return in_dim + ((c & 1) ? pe : 0) + f;
+	}
+	const int q = kp - nsc * 32;
+	return q < in_dim ? q : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  Y[(foot,v), n] = epi( sum_seg sum_k A_seg[(foot,v), k] * Wseg[n, k] ),  n in [0,256)
+// Used for every forward Linear (EPI_BIAS_RELU) and every backward dX (EPI_MASK, W pre-transposed).
+// Segments let the backward sum the contributions of both heads and -- when the trunk is shared by
+// all feet -- of every foot, inside the K loop (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+	const float* a0;  // A base for segments [0, nseg_per_base)
+	const float* a1;  // A base for segments [nseg_per_base, 2*nseg_per_base) (nbase == 2)
+	int nbase;
+	int nseg_per_base;
+	int64_t a_seg_stride;   // elements between consecutive segments of one base
+	int64_t a_foot_stride;  // elements between feet (blockIdx.y); 0 = rows shared by all feet
+	int lda;
+	const float* pos;       // AMODE_PE: (pos_batch, V, 3)
+	int64_t pos_foot_stride;
+	const float* Bm;        // AMODE_PE: (3, pe)
+	int pe;
+	const float* w0;        // (256, ldw), K contiguous
+	const float* w1;
+	int ldw;
+	int nchunk;             // 32-wide K chunks per segment
+	const float* bias;      // EPI_BIAS_RELU: (.., 256)
+	int64_t bias_foot_stride;
+	const float* mask;      // EPI_MASK: same layout as y; output zeroed where mask <= 0
+	int64_t mask_foot_stride;
+	float* y;
+	int64_t y_foot_stride;
+	int ldy;
+	int V;                  // rows per foot
+};
+
+enum { AMODE_MAT = 0, AMODE_PE = 1 };
+enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2 };
+
+template <int BM, int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+	constexpr int WM = (BM >= 64) ? 2 : 1;
+	constexpr int WN = 4 / WM;
+	constexpr int MI = BM / (32 * WM);
+	constexpr int NI = W / (32 * WN);
+	constexpr int AV = BM / 32;  // float4 A loads per thread per chunk
+
+	__shared__ __attribute__((aligned(16))) float As[BM * LDSLD];
+	__shared__ __attribute__((aligned(16))) float Bs[W * LDSLD];
+	__shared__ float Bl[(AMODE == AMODE_PE) ? 3 * 256 : 4];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	const int wm = wave / WN, wn = wave % WN;
+	const int foot = blockIdx.y;
+	const int v0 = blockIdx.x * BM;
+	const int lr = tid >> 3;          // loader row within a 32-row group
+	const int lc = (tid & 7) * 4;     // loader column (float4)
+
+	float px[AV], py[AV], pz[AV];
+	if constexpr (AMODE == AMODE_PE) {
+		for (int i = tid; i < 3 * g.pe; i += 256) Bl[i] = g.Bm[i];
+		const float* pp = g.pos + (int64_t)foot * g.pos_foot_stride;
+#pragma unroll
+		for (int i = 0; i < AV; ++i) {
+			const int v = v0 + lr + 32 * i;
+			const bool ok = v < g.V;
+			px[i] = ok ? pp[(int64_t)v * 3 + 0] : 0.f;
+			py[i] = ok ? pp[(int64_t)v * 3 + 1] : 0.f;
+			pz[i] = ok ? pp[(int64_t)v * 3 + 2] : 0.f;
+		}
+		__syncthreads();
+	}
+
+	f32x16 acc[MI][NI];
+#pragma unroll
+	for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+		for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+	float4 ra[AV], rb[8];
+	const int total = g.nbase * g.nseg_per_base * g.nchunk;
+
+	auto load_chunk = [&](int tc) {
+		const int seg = tc / g.nchunk;
+		const int c = tc - seg * g.nchunk;
+		const int base = seg / g.nseg_per_base;
+		const int s = seg - base * g.nseg_per_base;
+		const float* wp = (base ? g.w1 : g.w0) + c * KC + lc;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(lr + 32 * i) * g.ldw);
+		if constexpr (AMODE == AMODE_MAT) {
+			const float* ap = (base ? g.a1 : g.a0) + (int64_t)s * g.a_seg_stride + (int64_t)foot * g.a_foot_stride + c * KC + lc;
+#pragma unroll
+			for (int i = 0; i < AV; ++i) {
+				const int v = v0 + lr + 32 * i;
+				ra[i] = (v < g.V) ? *reinterpret_cast<const float4*>(ap + (int64_t)v * g.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < AV; ++i) {
+				const int kp = c * KC + lc;
+				ra[i].x = pe_value(kp + 0, g.pe, px[i], py[i], pz[i], Bl);
+				ra[i].y = pe_value(kp + 1, g.pe, px[i], py[i], pz[i], Bl);
+				ra[i].z = pe_value(kp + 2, g.pe, px[i], py[i], pz[i], Bl);
+				ra[i].w = pe_value(kp + 3, g.pe, px[i], py[i], pz[i], Bl);
+			}
+		}
+	};
+
+	load_chunk(0);
+	for (int tc = 0; tc < total; ++tc) {
+		__syncthreads();  // previous chunk's LDS reads are done
+#pragma unroll
+		for (int i = 0; i < AV; ++i) *reinterpret_cast<float4*>(&As[(lr + 32 * i) * LDSLD + lc]) = ra[i];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&Bs[(lr + 32 * i) * LDSLD + lc]) = rb[i];
+		__syncthreads();
+		if (tc + 1 < total) load_chunk(tc + 1);  // global loads fly under the MFMAs below
+
+		const int arow = (wm * MI * 32 + (lane & 31)) * LDSLD + (lane >> 5) * 4;
+		const int brow = (wn * NI * 32 + (lane & 31)) * LDSLD + (lane >> 5) * 4;
+#pragma unroll
+		for (int j = 0; j < KC / 8; ++j) {
+			float4 af[MI], bf[NI];
+#pragma unroll
+			for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const float4*>(&As[arow + mi * 32 * LDSLD + j * 8]);
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const float4*>(&Bs[brow + ni * 32 * LDSLD + j * 8]);
+#pragma unroll
+			for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+				for (int ni = 0; ni < NI; ++ni) {
+					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+				}
+		}
+	}
+
+	// epilogue: lane holds column (lane&31) of 16 rows per 32x32 block
+	float* yp = g.y + (int64_t)foot * g.y_foot_stride;
+	const float* mp = (EPI == EPI_MASK) ? g.mask + (int64_t)foot * g.mask_foot_stride : nullptr;
+#pragma unroll
+	for (int ni = 0; ni < NI; ++ni) {
+		const int col = wn * NI * 32 + ni * 32 + (lane & 31);
+		float bv = 0.f;
+		if constexpr (EPI == EPI_BIAS_RELU) bv = g.bias[(int64_t)foot * g.bias_foot_stride + col];
+#pragma unroll
+		for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int row = wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+				const int v = v0 + row;
+				if (v < g.V) {
+					float val = acc[mi][ni][r];
+					const int64_t o = (int64_t)v * g.ldy + col;
+					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv, 0.f);
+					if constexpr (EPI == EPI_MASK) val = (mp[o] > 0.f) ? val : 0.f;
+					yp[o] = val;
+				}
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient  dW[n, k] = sum_rows dZ[row, n] * X[row, k]   (split over rows; partial slabs)
+// One 512-thread workgroup owns a full 256(n) x 256(k) tile so dZ and X are each read once.
+// k-tile 0 also produces the column sums of dZ (bias gradient / per-foot sums for the latent grads).
+// ---------------------------------------------------------------------------------------------
+struct DwArgs {
+	const float* dz;        // rows (foot, v), ld 256
+	int64_t dz_foot_stride;
+	const float* x;         // AMODE_MAT: rows (foot, v) or shared (x_foot_stride 0)
+	int64_t x_foot_stride;
+	int ldx;
+	const float* pos;       // AMODE_PE
+	int64_t pos_foot_stride;
+	const float* Bm;
+	int pe;
+	int V;
+	int spf;                // splits per foot
+	int cps;                // 32-row chunks per split
+	int Kp;                 // padded K = 256 * gridDim.x
+	float* pw;              // [n_feet*spf][256][Kp]
+	float* pb;              // [n_feet*spf][256] or nullptr
+};
+
+template <int AMODE>
+__global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
+	__shared__ __attribute__((aligned(16))) float Zs[32 * 256];
+	__shared__ __attribute__((aligned(16))) float Xs[32 * 256];
+	__shared__ float Bl[(AMODE == AMODE_PE) ? 3 * 256 : 4];
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	const int wn = wave >> 2;  // n rows wn*128 .. +127 (4 blocks)
+	const int wk = wave & 3;   // k cols wk*64 .. +63   (2 blocks)
+	const int kt = blockIdx.x;
+	const int split = blockIdx.y;
+	const int foot = split / g.spf;
+	const int sidx = split - foot * g.spf;
+	const int cpf = (g.V + 31) / 32;
+	const int q0 = sidx * g.cps;
+	const int q1 = min(q0 + g.cps, cpf);
+	const int lr = tid >> 6;         // loader row within an 8-row group
+	const int lc = (tid & 63) * 4;   // loader column
+
+	if constexpr (AMODE == AMODE_PE) {
+		for (int i = tid; i < 3 * g.pe; i += 512) Bl[i] = g.Bm[i];
+		__syncthreads();
+	}
+
+	f32x16 acc[4][2];
+#pragma unroll
+	for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+		for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+	float4 rz[4], rx[4];
+	float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+	const bool do_bias = (g.pb != nullptr) && (kt == 0);
+	const float* dzp = g.dz + (int64_t)foot * g.dz_foot_stride + lc;
+	const float* xp = (AMODE == AMODE_MAT) ? g.x + (int64_t)foot * g.x_foot_stride + kt * 256 + lc : nullptr;
+	const float* pp = (AMODE == AMODE_PE) ? g.pos + (int64_t)foot * g.pos_foot_stride : nullptr;
+
+	auto load_chunk = [&](int q) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int v = q * 32 + lr + 8 * i;
+			const bool ok = v < g.V;
+			rz[i] = ok ? *reinterpret_cast<const float4*>(dzp + (int64_t)v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+			if constexpr (AMODE == AMODE_MAT) {
+				rx[i] = ok ? *reinterpret_cast<const float4*>(xp + (int64_t)v * g.ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+			} else {
+				if (ok) {
+					const float x = pp[(int64_t)v * 3 + 0], y = pp[(int64_t)v * 3 + 1], z = pp[(int64_t)v * 3 + 2];
+					const int kp = kt * 256 + lc;
+					rx[i].x = pe_value(kp + 0, g.pe, x, y, z, Bl);
+					rx[i].y = pe_value(kp + 1, g.pe, x, y, z, Bl);
+					rx[i].z = pe_value(kp + 2, g.pe, x, y, z, Bl);
+					rx[i].w = pe_value(kp + 3, g.pe, x, y, z, Bl);
+				} else {
+					rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+				}
+			}
+		}
+	};
+
+	if (q0 < q1) load_chunk(q0);
+	for (int q = q0; q < q1; ++q) {
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			*reinterpret_cast<float4*>(&Zs[(lr + 8 * i) * 256 + lc]) = rz[i];
+			*reinterpret_cast<float4*>(&Xs[(lr + 8 * i) * 256 + lc]) = rx[i];
+			if (do_bias) {
+				bsum.x += rz[i].x; bsum.y += rz[i].y; bsum.z += rz[i].z; bsum.w += rz[i].w;
+			}
+		}
+		__syncthreads();
+		if (q + 1 < q1) load_chunk(q + 1);
+
+		const int zo = (lane >> 5) * 256 + wn * 128 + (lane & 31);
+		const int xo = (lane >> 5) * 256 + wk * 64 + (lane & 31);
+#pragma unroll
+		for (int t = 0; t < 16; ++t) {
+			float a[4], b[2];
+#pragma unroll
+			for (int mi = 0; mi < 4; ++mi) a[mi] = Zs[zo + t * 512 + mi * 32];
+#pragma unroll
+			for (int ni = 0; ni < 2; ++ni) b[ni] = Xs[xo + t * 512 + ni * 32];
+#pragma unroll
+			for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+				for (int ni = 0; ni < 2; ++ni)
+					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+		}
+	}
+
+	float* pw = g.pw + (int64_t)split * 256 * g.Kp + kt * 256;
+#pragma unroll
+	for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+		for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int n = wn * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+				const int k = wk * 64 + ni * 32 + (lane & 31);
+				pw[(int64_t)n * g.Kp + k] = acc[mi][ni][r];
+			}
+
+	if (do_bias) {
+		__syncthreads();
+		float* red = Zs;  // [8][256]
+		*reinterpret_cast<float4*>(&red[lr * 256 + lc]) = bsum;
+		__syncthreads();
+		if (tid < 256) {
+			float s = 0.f;
+#pragma unroll
+			for (int w = 0; w < 8; ++w) s += red[w * 256 + tid];
+			g.pb[(int64_t)split * 256 + tid] = s;
+		}
+	}
+}
+
+// dW[n, map(k)] = sum_split pw[split][n][k]
+struct ReduceWArgs {
+	const float* pw;
+	int nsplit;
+	int Kp;
+	float* out;
+	int ld_out;
+	int K_valid;   // identity map: columns [0, K_valid) are written
+	int pe_map;    // 1: padded PE layout -> reference column order
+	int pe;
+	int in_dim;
+};
+
+__global__ void reduce_w_kernel(const ReduceWArgs g) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (int64_t)256 * g.Kp) return;
+	const int n = (int)(i / g.Kp), k = (int)(i - (int64_t)n * g.Kp);
+	int ko;
+	if (g.pe_map) ko = pe_col_to_orig(k, g.pe, g.in_dim);
+	else ko = (k < g.K_valid) ? k : -1;
+	if (ko < 0) return;
+	float s = 0.f;
+	const float* p = g.pw + i;
+	const int64_t stride = (int64_t)256 * g.Kp;
+	for (int sidx = 0; sidx < g.nsplit; ++sidx) s += p[sidx * stride];
+	g.out[(int64_t)n * g.ld_out + ko] = s;
+}
+
+// db[n] = sum_split pb[split][n];  S[foot][n] = sum over that foot's splits (optional)
+__global__ void reduce_b_kernel(const float* pb, int n_feet, int spf, float* db, float* S) {
+	const int n = threadIdx.x;  // 256
+	float tot = 0.f;
+	for (int f = 0; f < n_feet; ++f) {
+		float s = 0.f;
+		for (int k = 0; k < spf; ++k) s += pb[((int64_t)f * spf + k) * 256 + n];
+		if (S) S[(int64_t)f * 256 + n] = s;
+		tot += s;
+	}
+	if (db) db[n] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight repacking (one launch, grid.y = job): copy a column block / transpose / PE permutation.
+// ---------------------------------------------------------------------------------------------
+struct RepackJob {
+	const float* src;
+	float* dst;
+	int rows, cols;   // extent of the source block
+	int ld_src, coff; // source row stride and first column
+	int ld_dst;
+	int mode;         // 0 copy, 1 transpose (dst[c][r]), 2 PE permute into KP0 padded columns
+	int pe, in_dim;
+};
+constexpr int MAX_REPACK = 28;
+struct RepackArgs {
+	RepackJob job[MAX_REPACK];
+	int njobs;
+};
+
+__global__ void repack_kernel(const RepackArgs a) {
+	const RepackJob& j = a.job[blockIdx.y];
+	if (j.mode == 2) {
+		const int64_t total = (int64_t)j.rows * KP0;
+		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+			const int r = (int)(i / KP0), kp = (int)(i - (int64_t)r * KP0);
+			const int ko = pe_col_to_orig(kp, j.pe, j.in_dim);
+			j.dst[(int64_t)r * j.ld_dst + kp] = (ko >= 0) ? j.src[(int64_t)r * j.ld_src + ko] : 0.f;
+		}
+		return;
+	}
+	const int64_t total = (int64_t)j.rows * j.cols;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+		const int r = (int)(i / j.cols), c = (int)(i - (int64_t)r * j.cols);
+		const float v = j.src[(int64_t)r * j.ld_src + j.coff + c];
+		if (j.mode == 0) j.dst[(int64_t)r * j.ld_dst + c] = v;
+		else j.dst[(int64_t)c * j.ld_dst + r] = v;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-foot latent bias of a head's first layer (model.py:428-437 folded into a bias):
+//   fb[foot][n] = b[n] + sum_j Wfull[n][256 + j] * lat[foot][j]
+// ---------------------------------------------------------------------------------------------
+__global__ void latent_bias_kernel(const float* Wfull, int ldw, const float* b, const float* lat, int L, float* fb) {
+	const int n = threadIdx.x, foot = blockIdx.x;
+	float s = b[n];
+	const float* wr = Wfull + (int64_t)n * ldw + W;
+	const float* lv = lat + (int64_t)foot * L;
+	for (int j = 0; j < L; ++j) s = fmaf(wr[j], lv[j], s);
+	fb[(int64_t)foot * W + n] = s;
+}
+
+// latent gradients from S[foot][n] = sum_v dZ0[(foot,v)][n]:
+//   dlat[foot][j] = sum_n S[foot][n] * Wfull[n][256+j];   dWfull[n][256+j] = sum_foot S[foot][n] * lat[foot][j]
+__global__ void latent_grad_kernel(const float* Wfull, int ldw, const float* lat, int L, const float* S, int n_feet,
+								   float* dlat, float* dWfull) {
+	const int b = blockIdx.x;
+	if (b < n_feet) {
+		if (dlat == nullptr) return;
+		for (int j = threadIdx.x; j < L; j += blockDim.x) {
+			float s = 0.f;
+			for (int n = 0; n < W; ++n) s = fmaf(S[(int64_t)b * W + n], Wfull[(int64_t)n * ldw + W + j], s);
+			dlat[(int64_t)b * L + j] = s;
+		}
+	} else {
+		const int n = b - n_feet;  // 0..255
+		for (int j = threadIdx.x; j < L; j += blockDim.x) {
+			float s = 0.f;
+			for (int f = 0; f < n_feet; ++f) s = fmaf(S[(int64_t)f * W + n], lat[(int64_t)f * L + j], s);
+			dWfull[(int64_t)n * ldw + W + j] = s;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final 256->3 layers of both heads + output activations (model.py:439-451).  One wave per row.
+//   head 0: disp = 0.1*tanh(z)        head 1: col = 0.5*(1+tanh(z)) [+ avg_col]
+// ---------------------------------------------------------------------------------------------
+struct HeadOutArgs {
+	const float* x[2];    // (rows, 256) last hidden activation of each head
+	const float* w[2];    // (3, 256)
+	const float* b[2];    // (3)
+	float* z[2];          // (rows, 3) pre-activation, saved for backward (may be null)
+	float* out[2];        // (rows, 3)
+	const float* avg_col; // or null
+	int64_t rows;
+};
+
+__global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) {
+	const int head = blockIdx.y;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const float* x = head ? g.x[1] : g.x[0];
+	const float* w = head ? g.w[1] : g.w[0];
+	const float* b = head ? g.b[1] : g.b[0];
+	float* z = head ? g.z[1] : g.z[0];
+	float* out = head ? g.out[1] : g.out[0];
+	if (out == nullptr) return;
+	const float4 w0 = *reinterpret_cast<const float4*>(w + 0 * W + lane * 4);
+	const float4 w1 = *reinterpret_cast<const float4*>(w + 1 * W + lane * 4);
+	const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * W + lane * 4);
+	const float b0 = b[0], b1 = b[1], b2 = b[2];
+	float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+	if (head && g.avg_col) { a0 = g.avg_col[0]; a1 = g.avg_col[1]; a2 = g.avg_col[2]; }
+	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < g.rows; row += (int64_t)gridDim.x * 4) {
+		const float4 xv = *reinterpret_cast<const float4*>(x + row * W + lane * 4);
+		float s0 = xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
+		float s1 = xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
+		float s2 = xv.x * w2.x + xv.y * w2.y + xv.z * w2.z + xv.w * w2.w;
+		s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+		if (lane < 3) {
+			const float zz = (lane == 0 ? s0 + b0 : (lane == 1 ? s1 + b1 : s2 + b2));
+			const float t = tanhf(zz);
+			if (z) z[row * 3 + lane] = zz;
+			const float av = (lane == 0 ? a0 : (lane == 1 ? a1 : a2));
+			out[row * 3 + lane] = head ? (av + 0.5f * (1.0f + t)) : 0.1f * t;
+		}
+	}
+}
+
+// Backward of the final layers: dz = g * act'(z);  dY[row][k] = (sum_c dz_c W[c][k]) * (Y[row][k] > 0);
+// partial dW[c][k] = sum_rows dz_c * Y[row][k], partial db[c] = sum_rows dz_c   (per workgroup slabs).
+struct HeadOutBwdArgs {
+	const float* y[2];     // (rows,256) last hidden activation
+	const float* w[2];     // (3,256)
+	const float* z[2];     // (rows,3)
+	const float* gout[2];  // (rows,3) upstream gradient, null -> head skipped
+	float* dy[2];          // (rows,256) masked gradient wrt last hidden pre-activation
+	float* pw[2];          // [gridDim.x][3][256]
+	float* pb[2];          // [gridDim.x][4]
+	int64_t rows;
+};
+
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs g) {
+	const int head = blockIdx.y;
+	const float* gout = head ? g.gout[1] : g.gout[0];
+	if (gout == nullptr) return;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const float* y = head ? g.y[1] : g.y[0];
+	const float* w = head ? g.w[1] : g.w[0];
+	const float* z = head ? g.z[1] : g.z[0];
+	float* dy = head ? g.dy[1] : g.dy[0];
+	float* pw = head ? g.pw[1] : g.pw[0];
+	float* pb = head ? g.pb[1] : g.pb[0];
+	const float4 w0 = *reinterpret_cast<const float4*>(w + 0 * W + lane * 4);
+	const float4 w1 = *reinterpret_cast<const float4*>(w + 1 * W + lane * 4);
+	const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * W + lane * 4);
+	const float scale = head ? 0.5f : 0.1f;
+	float4 aw0 = make_float4(0, 0, 0, 0), aw1 = aw0, aw2 = aw0;
+	float ab0 = 0.f, ab1 = 0.f, ab2 = 0.f;
+	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < g.rows; row += (int64_t)gridDim.x * 4) {
+		const float t0 = tanhf(z[row * 3 + 0]), t1 = tanhf(z[row * 3 + 1]), t2 = tanhf(z[row * 3 + 2]);
+		const float d0 = gout[row * 3 + 0] * scale * (1.f - t0 * t0);
+		const float d1 = gout[row * 3 + 1] * scale * (1.f - t1 * t1);
+		const float d2 = gout[row * 3 + 2] * scale * (1.f - t2 * t2);
+		const float4 yv = *reinterpret_cast<const float4*>(y + row * W + lane * 4);
+		float4 o;
+		o.x = (yv.x > 0.f) ? d0 * w0.x + d1 * w1.x + d2 * w2.x : 0.f;
+		o.y = (yv.y > 0.f) ? d0 * w0.y + d1 * w1.y + d2 * w2.y : 0.f;
+		o.z = (yv.z > 0.f) ? d0 * w0.z + d1 * w1.z + d2 * w2.z : 0.f;
+		o.w = (yv.w > 0.f) ? d0 * w0.w + d1 * w1.w + d2 * w2.w : 0.f;
+		*reinterpret_cast<float4*>(dy + row * W + lane * 4) = o;
+		aw0.x += d0 * yv.x; aw0.y += d0 * yv.y; aw0.z += d0 * yv.z; aw0.w += d0 * yv.w;
+		aw1.x += d1 * yv.x; aw1.y += d1 * yv.y; aw1.z += d1 * yv.z; aw1.w += d1 * yv.w;
+		aw2.x += d2 * yv.x; aw2.y += d2 * yv.y; aw2.z += d2 * yv.z; aw2.w += d2 * yv.w;
+		ab0 += d0; ab1 += d1; ab2 += d2;
+	}
+	__shared__ __attribute__((aligned(16))) float red[4][3][256];
+	__shared__ float redb[4][4];
+	*reinterpret_cast<float4*>(&red[wave][0][lane * 4]) = aw0;
+	*reinterpret_cast<float4*>(&red[wave][1][lane * 4]) = aw1;
+	*reinterpret_cast<float4*>(&red[wave][2][lane * 4]) = aw2;
+	if (lane == 0) { redb[wave][0] = ab0; redb[wave][1] = ab1; redb[wave][2] = ab2; }
+	__syncthreads();
+	const int k = threadIdx.x;
+	for (int c = 0; c < 3; ++c)
+		pw[((int64_t)blockIdx.x * 3 + c) * 256 + k] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
+	if (k < 3) pb[(int64_t)blockIdx.x * 4 + k] = redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k];
+}
+
+__global__ void head_out_reduce_kernel(const float* pw, const float* pb, int nblk, float* dw, float* db) {
+	const int k = threadIdx.x;  // 256
+	for (int c = 0; c < 3; ++c) {
+		float s = 0.f;
+		for (int i = 0; i < nblk; ++i) s += pw[((int64_t)i * 3 + c) * 256 + k];
+		dw[c * 256 + k] = s;
+	}
+	if (k < 3) {
+		float s = 0.f;
+		for (int i = 0; i < nblk; ++i) s += pb[(int64_t)i * 4 + k];
+		db[k] = s;
+	}
+}
+
+}  // namespace mlp
+}  // namespace find

@@ -1,0 +1,372 @@
+"""FIND model API on the MI355X hot path.
+
+Host-side mirror of reference src/model/model.py: same class names, constructor keywords, state_dict keys,
+parameter groups and forward()/get_meshes()/get_meshes_from_batch() signatures, so src/train and src/eval call it
+unchanged.  All arithmetic runs in libfind_hip.so (find_amd.functional); nothing here computes the
+network on the CPU."""
+import os
+
+import numpy as np
+import torch
+
+from . import functional as FN
+from .structures import Meshes, TexturesVertex, extend_template
+
+nn = torch.nn
+
+
+def make_params_list(*params):
+	"""Flatten modules / parameters / None into a list of parameters (reference model.py:47-60)."""
+	out = []
+	for prm in params:
+		if prm is None:
+			continue
+		if isinstance(prm, nn.Parameter):
+			out.append(prm)
+		elif hasattr(prm, 'parameters'):
+			out.extend(prm.parameters())
+		else:
+			raise ValueError(f'Param type {type(prm)} not understood.')
+	return out
+
+
+class FourierFeatureTransform(nn.Module):
+	"""Holder of the Gaussian Fourier matrix B (reference src/utils/fourier_feature_transform.py:17-26).
+
+	Quirks kept on purpose: construction reseeds the *global* torch RNG to 1 (so every later nn.Linear init is
+	deterministic), the `num_input_channels` ROWS of B are sorted by L2 norm, and `_B` is a plain attribute --
+	not a buffer, not in the state_dict.  The encoding itself is fused into the first GEMM of the HIP MLP kernel
+	(csrc/mlp_kernels.h: pe_value), so this module has no forward of its own."""
+
+	def __init__(self, num_input_channels, mapping_size=256, scale=10, exclude=0):
+		super().__init__()
+		self._num_input_channels = num_input_channels
+		self._mapping_size = mapping_size
+		self.exclude = exclude
+		torch.manual_seed(1)
+		B = torch.randn((num_input_channels, mapping_size)) * scale
+		order = sorted(range(num_input_channels), key=lambda i: float(torch.norm(B[i], p=2)))
+		self._B = torch.stack([B[i] for i in order])
+		self._B_dev = {}
+
+	def B(self, device):
+		device = torch.device(device)
+		t = self._B_dev.get(device)
+		if t is None:
+			t = self._B.to(device=device, dtype=torch.float32).contiguous()
+			self._B_dev[device] = t
+		return t
+
+	def forward(self, x):
+		raise NotImplementedError('FourierFeatureTransform is fused into find_amd.functional.mlp (HIP); call the model instead')
+
+
+class LatentVector(nn.Module):
+	"""Table of learned per-item vectors addressed by int / tensor / label / list (reference model.py:92-152)."""
+
+	def __init__(self, dataset_size=None, vec_size=512, name='', device='cuda', key=None, labels: list = None, init_values=None):
+		super().__init__()
+		self.dataset_size = dataset_size
+		self.vec_size = vec_size
+		if labels is not None:
+			dataset_size = len(labels)
+		self.labels = labels
+		self.key = key
+		init = torch.zeros(dataset_size, vec_size)
+		if init_values is not None:
+			if not isinstance(init_values, np.ndarray):
+				raise NotImplementedError
+			init[:] = torch.from_numpy(init_values).unsqueeze(0).float()
+		self.data = nn.Parameter(init.to(device))
+		self.name = name
+
+	def __len__(self):
+		return self.dataset_size
+
+	def _index_of(self, label):
+		assert self.labels is not None, f'Tried to access item {label} from LatentVector {self.name}, LV does not have labels'
+		return self.labels.index(label)
+
+	def __getitem__(self, idx):
+		if isinstance(idx, (int, torch.Tensor)):
+			return self.data[idx]
+		if isinstance(idx, str):
+			return self.data[self._index_of(idx)]
+		if isinstance(idx, list):
+			if isinstance(idx[0], int):
+				return self.data[idx]
+			if isinstance(idx[0], str):
+				return self.data[[self._index_of(o) for o in idx]]
+			return None  # the reference falls through here as well (model.py:142-149)
+		raise NotImplementedError(f"Didn't understand indexing of LatentVector {self.name}, type {type(idx)}")
+
+
+class Model(nn.Module):
+	"""save / load / freeze (reference model.py:155-196); checkpoints are {'state_dict', 'params'} dicts."""
+
+	def save_model(self, out_dir='models/tmp', fname='model_tmp'):
+		os.makedirs(out_dir, exist_ok=True)
+		torch.save({'state_dict': self.state_dict(), 'params': self.params}, os.path.join(out_dir, fname + '.pth'))
+
+	def freeze(self):
+		for prm in self.parameters():
+			prm.requires_grad = False
+
+	@classmethod
+	def load(cls, file, device='cuda', opts=None, **kwargs):
+		ext = os.path.splitext(file)[-1]
+		assert ext == '.pth', f'Generic models can only load from .pth files - received `{ext}` file.'
+		data = torch.load(file, map_location=device, weights_only=False)
+		skip_latents = opts is not None and getattr(opts, 'dont_load_latents', False)
+		if skip_latents:
+			data['params']['train_size'] = kwargs.get('train_size', 1)
+			data['params']['val_size'] = kwargs.get('val_size', 1)
+			data['params']['latent_labels'] = kwargs.get('latent_labels', None)
+		state_dict = data['state_dict']
+		model = cls(**data['params'], device=device, opts=opts)
+		model.configure_template(state_dict, device=device)
+		if skip_latents:
+			latent_keys = {f + '.data' for f in ['shapevec', 'shapevec_val', 'texvec', 'texvec_val', 'posevec', 'posevec_val', 'reg', 'reg_val']}
+			state_dict = {k: v for k, v in state_dict.items() if k not in latent_keys}
+		model.load_state_dict(state_dict, strict=False)
+		return model
+
+
+def _read_obj(path):
+	"""Vertices / triangle faces / optional per-vertex RGB of a Wavefront OBJ (polygons are fan-triangulated)."""
+	verts, cols, faces = [], [], []
+	with open(path, 'r') as f:
+		for line in f:
+			if line.startswith('v '):
+				p = line.split()
+				verts.append([float(p[1]), float(p[2]), float(p[3])])
+				if len(p) >= 7:
+					cols.append([float(p[4]), float(p[5]), float(p[6])])
+			elif line.startswith('f '):
+				idx = [int(tok.split('/')[0]) for tok in line.split()[1:]]
+				idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+				for k in range(1, len(idx) - 1):
+					faces.append([idx[0], idx[k], idx[k + 1]])
+	v = torch.tensor(verts, dtype=torch.float32)
+	fc = torch.tensor(faces, dtype=torch.int64)
+	c = torch.tensor(cols, dtype=torch.float32) if len(cols) == len(verts) and cols else None
+	return v, fc, c
+
+
+class NeuralDisplacementField(Model):
+	"""Template mesh + Fourier PE + trunk MLP + displacement / colour heads + per-instance latent tables
+	(reference model.py:206-534)."""
+
+	def __init__(self, sigma=10, depth=4, width=256, encoding='gaussian', dispdepth=3, coldepth=3, normratio=0.1,
+				 clamp=None, normclamp=None, niter=6000, input_dim=3, positional_encoding=True, progressive_encoding=False,
+				 exclude=0,
+				 use_shapevec=False, train_size=None, val_size=None, shapevec_size=256,
+				 use_texvec=False, texvec_size=256, use_posevec=False, posevec_size=256,
+				 template_mesh_loc=None, device='cuda',
+				 restyle_features_per_vertex=False, restyle_cluster_per_vertex=False,
+				 use_avg_colour=False, opts=None,
+				 latent_labels: dict = None):
+		super().__init__()
+		self.params = dict(sigma=sigma, depth=depth, width=width, encoding=encoding, dispdepth=dispdepth, coldepth=coldepth,
+						   progressive_encoding=progressive_encoding, positional_encoding=positional_encoding,
+						   train_size=train_size, val_size=val_size,
+						   use_shapevec=use_shapevec, shapevec_size=shapevec_size, use_texvec=use_texvec,
+						   texvec_size=texvec_size, use_posevec=use_posevec, posevec_size=posevec_size,
+						   restyle_features_per_vertex=restyle_features_per_vertex,
+						   restyle_cluster_per_vertex=restyle_cluster_per_vertex,
+						   use_avg_colour=use_avg_colour, latent_labels=latent_labels)
+		if progressive_encoding:
+			raise NotImplementedError('progressive_encoding is flagged untested in the reference (opts.py:49-50) and is out of scope')
+		if restyle_features_per_vertex or restyle_cluster_per_vertex:
+			raise NotImplementedError('restyle per-vertex features are out of scope (need the absent restyle_encoder submodule)')
+		if width != 256 or input_dim != 3:
+			raise NotImplementedError('the HIP kernels are specialised for width=256, input_dim=3 (the reference setting, model.py:207)')
+		self.clamp, self.normclamp, self.normratio = clamp, normclamp, normratio
+		self.width, self.input_dim = width, input_dim
+
+		# --- construction order matters: FFT reseeds the global RNG, then Linear layers draw from it in this order
+		enc = []
+		use_pe = (encoding == 'gaussian') and positional_encoding
+		if use_pe:
+			enc.append(FourierFeatureTransform(input_dim, width, sigma, exclude))
+		input_size = width * 2 + input_dim if use_pe else input_dim
+		layers = [nn.Linear(input_size, width), nn.ReLU()]
+		for _ in range(depth):
+			layers += [nn.Linear(width, width), nn.ReLU()]
+		self.encoder = nn.ModuleList(enc)
+		self.base = nn.ModuleList(layers)
+
+		# --- template (centred at its centroid, model.py:274-275)
+		if template_mesh_loc is not None:
+			verts, faces, cols = _read_obj(template_mesh_loc)
+			verts = verts - verts.mean(dim=0)
+			avg_col = cols.mean(dim=0) if cols is not None else torch.zeros(3)
+		else:
+			verts = torch.zeros((1, 3), dtype=torch.float32)
+			faces = torch.ones((1, 3), dtype=torch.int)
+			avg_col = torch.zeros(3, dtype=torch.float32)
+		self.template_verts = nn.Parameter(verts.unsqueeze(0).float().to(device), requires_grad=False)
+		self.template_faces = nn.Parameter(faces.unsqueeze(0).to(device), requires_grad=False)
+		self.avg_col = nn.Parameter(avg_col.to(device), requires_grad=False)
+		self._rebuild_template_mesh()
+
+		# --- latent tables (model.py:299-348).  NB posevec tables are sized with shapevec_size (model.py:320-322).
+		self.latent_vectors_train, self.latent_vectors_val = [], []
+		ll = latent_labels or {}
+
+		def table(n, size, name, key, lab, **kw):
+			return LatentVector(n, vec_size=size, name=name, key=key, labels=ll.get(lab, None), device=device, **kw)
+
+		self.shapevec_size, self.use_shapevec = shapevec_size, use_shapevec
+		self.shapevec = self.shapevec_val = None
+		if use_shapevec:
+			self.shapevec = table(train_size, shapevec_size, 'shapevec_train', 'shape', 'shape')
+			self.shapevec_val = table(val_size, shapevec_size, 'shapevec_val', 'shape', 'shape_val')
+			self.latent_vectors_train.append(self.shapevec)
+			self.latent_vectors_val.append(self.shapevec_val)
+		self.posevec_size, self.use_posevec = posevec_size, use_posevec
+		self.posevec = self.posevec_val = None
+		if use_posevec:
+			self.posevec = table(train_size, shapevec_size, 'posevec_train', 'pose', 'pose')
+			self.posevec_val = table(val_size, shapevec_size, 'posevec_val', 'pose', 'pose_val')
+			self.latent_vectors_train.append(self.posevec)
+			self.latent_vectors_val.append(self.posevec_val)
+		self.texvec_size, self.use_texvec = texvec_size, use_texvec
+		self.texvec = self.texvec_val = None
+		if use_texvec:
+			self.texvec = table(train_size, texvec_size, 'texvec_train', 'tex', 'tex')
+			self.texvec_val = table(val_size, texvec_size, 'texvec_val', 'tex', 'tex_val')
+			self.latent_vectors_train.append(self.texvec)
+			self.latent_vectors_val.append(self.texvec_val)
+		ident = np.array([0] * 6 + [1] * 3)
+		self.reg = table(train_size, 9, 'reg_train', 'reg', 'reg', init_values=ident)
+		self.reg_val = table(val_size, 9, 'reg_val', 'reg', 'reg_val', init_values=ident)
+		self.latent_vectors_train.append(self.reg)
+		self.latent_vectors_val.append(self.reg_val)
+
+		# --- heads.  The disp-head input counts the shape code only if use_texvec (reference quirk, model.py:352).
+		self._lat_disp = self.shapevec_size * self.use_texvec + self.posevec_size * self.use_posevec
+		self._lat_col = self.texvec_size * self.use_texvec
+		disp_layers = []
+		for i in range(dispdepth):
+			disp_layers += [nn.Linear(width + self._lat_disp if i == 0 else width, width), nn.ReLU()]
+		disp_layers.append(nn.Linear(width, 3))
+		self.mlp_disp = nn.Sequential(*disp_layers)
+		col_layers = []
+		for i in range(coldepth):
+			col_layers += [nn.Linear(width + self._lat_col if i == 0 else width, width), nn.ReLU()]
+		self.use_avg_colour = use_avg_colour
+		col_layers.append(nn.Linear(width, 3))
+		self.mlp_col = nn.Sequential(*col_layers)
+
+		self.restyle_features_per_vertex = restyle_features_per_vertex
+		self.per_vertex_features = None
+		if opts is not None and getattr(opts, 'template_features_pth', None) is not None:
+			raise NotImplementedError('template_features_pth (per-vertex restyle classes) is out of scope')
+
+		# --- parameter groups read by train.py:161-168
+		self.main_params = make_params_list(self.base, self.mlp_disp, self.mlp_col, self.shapevec, self.texvec, self.posevec)
+		self.templ_params = make_params_list(self.template_verts, self.reg)
+		self.val_params = make_params_list(self.shapevec_val, self.texvec_val, self.posevec_val)
+		self.reg_params = make_params_list(self.reg, self.reg_val)
+		self.latent_params = make_params_list(self.shapevec, self.shapevec_val, self.texvec, self.texvec_val, self.posevec, self.posevec_val)
+
+		if dispdepth < 1 or coldepth < 1:
+			raise NotImplementedError('dispdepth/coldepth must be >= 1')
+		self._spec = FN.MLPSpec(n_trunk=depth + 1, n_disp=dispdepth, n_col=coldepth, pe_size=width if use_pe else 0,
+								lat_disp=self._lat_disp, lat_col=self._lat_col, in_dim=input_dim, width=width)
+		self.reset_weights()
+		self.onnx_mode = False
+
+	# ------------------------------------------------------------------ helpers
+	def _rebuild_template_mesh(self):
+		self.template_mesh = Meshes(verts=self.template_verts.data, faces=self.template_faces.data[0])
+
+	def _weights(self):
+		ws = []
+		for seq in (self.base, self.mlp_disp, self.mlp_col):
+			for layer in seq:
+				if isinstance(layer, nn.Linear):
+					ws += [layer.weight, layer.bias]
+		return ws
+
+	@staticmethod
+	def _cat_latents(*vecs):
+		vecs = [v for v in vecs if v is not None]
+		if not vecs:
+			return None
+		return vecs[0] if len(vecs) == 1 else torch.cat(vecs, dim=-1)
+
+	# ------------------------------------------------------------------ reference API
+	def forward(self, pos, shapevec=None, texvec=None, posevec=None):
+		"""pos [B|1, V, 3]; shapevec/texvec/posevec [B, L] -> dict(disp [B,V,3], col [B,V,3])   (model.py:393-453).
+		A batch-1 `pos` with batched latents is evaluated once through the trunk and shared by every foot."""
+		if self.onnx_mode:
+			raise NotImplementedError('onnx_mode (web export) is out of scope')
+		if pos.dim() != 3 or pos.shape[-1] != self.input_dim:
+			raise ValueError(f'pos must be [B, V, {self.input_dim}], got {tuple(pos.shape)}')
+		lat_disp = self._cat_latents(shapevec, posevec)
+		lat_col = self._cat_latents(texvec)
+		got_d = 0 if lat_disp is None else lat_disp.shape[-1]
+		got_c = 0 if lat_col is None else lat_col.shape[-1]
+		if got_d != self._lat_disp or got_c != self._lat_col:
+			raise RuntimeError(f'latent widths do not match the head input sizes: disp head expects {self._lat_disp} latent columns '
+							   f'(got {got_d}), col head expects {self._lat_col} (got {got_c}); cf. model.py:352,361')
+		enc = self.encoder[0] if len(self.encoder) else None
+		B = enc.B(pos.device) if enc is not None else None
+		avg = self.avg_col if self.use_avg_colour else None
+		disp, col = FN.mlp(self._spec, pos, lat_disp, lat_col, B, avg, self._weights())
+		return {'disp': disp, 'col': col}
+
+	def get_meshes(self, shapevec=None, reg=None, texvec=None, posevec=None, no_displacement=False, include_texture=True):
+		"""Evaluate the field at every template vertex, apply the learned similarity registration and return
+		dict(meshes, offsets, verts, disp, col)   (model.py:455-504)."""
+		N = 0 if shapevec is None else shapevec.shape[0]
+		meshes = extend_template(self.template_mesh, N=N)
+		tv = self.template_verts.data  # (1, V, 3): the trunk is evaluated once for all N feet
+		res = self(tv, shapevec=shapevec, texvec=texvec, posevec=posevec)
+		offsets, col = res['disp'], res['col']
+		if reg is not None:
+			X = FN.register_points(tv, offsets, reg)
+		else:
+			X = tv + offsets
+		if not no_displacement:
+			meshes = meshes.update_padded(X)
+		if self.use_texvec:
+			meshes.textures = TexturesVertex(col[..., :3])
+		else:
+			raise NotImplementedError('use_texvec=False needs the template UV texture (template_tex), which is out of scope')
+		return dict(meshes=meshes, offsets=offsets, verts=X, **res)
+
+	def get_meshes_from_batch(self, batch, is_train=True, no_displacement=False):
+		sfx = 'train' if is_train else 'val'
+		return self.get_meshes(shapevec=batch.get(f'shapevec_{sfx}', None), reg=batch.get(f'reg_{sfx}', None),
+							   texvec=batch.get(f'texvec_{sfx}', None), posevec=batch.get(f'posevec_{sfx}', None),
+							   include_texture=True, no_displacement=no_displacement)
+
+	def reset_weights(self):
+		"""Zero the last displacement layer so the initial mesh equals the template (model.py:516-518)."""
+		self.mlp_disp[-1].weight.data.zero_()
+		self.mlp_disp[-1].bias.data.zero_()
+
+	def configure_template(self, state_dict, device='cuda'):
+		self.template_verts = nn.Parameter(state_dict['template_verts'].float().to(device), requires_grad=False)
+		self.template_faces = nn.Parameter(state_dict['template_faces'].to(device), requires_grad=False)
+		self._rebuild_template_mesh()
+		if 'avg_col' in state_dict:
+			self.avg_col = nn.Parameter(state_dict['avg_col'].to(device), requires_grad=False)
+
+	def set_template(self, verts, faces):
+		"""Install an in-memory template (verts (V,3) float, faces (F,3) int); used by synthetic benchmarks/tests."""
+		dev = self.template_verts.device
+		self.configure_template({'template_verts': verts.reshape(1, -1, 3), 'template_faces': faces.reshape(1, -1, 3)}, device=dev)
+
+	def to(self, device):
+		out = super().to(device)
+		self._rebuild_template_mesh()
+		return out
+
+	def _apply(self, fn, *a, **kw):
+		out = super()._apply(fn, *a, **kw)
+		self._rebuild_template_mesh()
+		return out

@@ -1,0 +1,212 @@
+/* find_hip.h -- C ABI of libfind_hip.so: the MI355X (gfx950) hot path of FIND.
+ *
+ * The reference (OllieBoyne/FIND) is pure Python; its "FFI" for this path is the PyTorch / PyTorch3D
+ * operator surface.  Each entry point below names the reference call site(s) it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (PyTorch-allocated); the library allocates
+ *     nothing and keeps no state.  Scratch is passed in as `ws` + `ws_bytes`; query sizes with *_ws_bytes().
+ *   - All tensors are contiguous row-major fp32 unless stated; indices are int32 or int64 as stated.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and performs no device synchronisation.
+ *   - Return value: 0 on success, negative FIND_E* code otherwise; find_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI.
+ *   - Threading: call from the thread that owns the stream; one process per GPU under data parallelism.
+ */
+#ifndef FIND_HIP_H
+#define FIND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIND_ABI_VERSION 1
+
+#define FIND_OK 0
+#define FIND_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define FIND_EWORKSPACE (-2) /* workspace too small */
+#define FIND_ELAUNCH (-3)  /* HIP launch or runtime error */
+
+#define FIND_MAX_LAYERS 8
+
+int find_abi_version(void);
+const char* find_last_error(void);
+/* Name of the code-object architecture the library was built for ("gfx950"). */
+const char* find_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * MLP: Fourier positional encoding + trunk + displacement head + colour head.
+ * Replaces NeuralDisplacementField.forward  (src/model/model.py:393-453)
+ *      and FourierFeatureTransform.forward  (src/utils/fourier_feature_transform.py:28-55),
+ * plus their autograd backward (reached from src/train/trainer.py:121).
+ *
+ * Weight pointers use the reference state_dict tensors directly:
+ *   trunk_w[i] = base.{2i}.weight   (width, in_i) ; in_0 = in_dim + 2*pe_size (or in_dim), else width
+ *   disp_w[0]  = mlp_disp.0.weight  (width, width + lat_disp)  ... disp_w[n_disp] = final (3, width)
+ *   col_w[0]   = mlp_col.0.weight   (width, width + lat_col)   ... col_w[n_col]   = final (3, width)
+ * Only width == 256 and in_dim == 3 are supported (the reference's fixed setting, model.py:207).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct find_mlp_params {
+	int32_t width;      /* hidden width (256) */
+	int32_t in_dim;     /* 3 */
+	int32_t pe_size;    /* Fourier mapping size (256); 0 = positional encoding disabled */
+	int32_t n_trunk;    /* number of trunk Linear layers (depth + 1) */
+	int32_t n_disp;     /* hidden Linear layers in the displacement head (dispdepth); final 3-wide layer is extra */
+	int32_t n_col;      /* hidden Linear layers in the colour head (coldepth) */
+	int32_t lat_disp;   /* latent columns appended to the disp-head input ([shapevec, posevec]) */
+	int32_t lat_col;    /* latent columns appended to the col-head input (texvec) */
+	const float* B;     /* (in_dim, pe_size) Fourier matrix (_B; not in the state_dict) */
+	const float* trunk_w[FIND_MAX_LAYERS];
+	const float* trunk_b[FIND_MAX_LAYERS];
+	const float* disp_w[FIND_MAX_LAYERS];
+	const float* disp_b[FIND_MAX_LAYERS];
+	const float* col_w[FIND_MAX_LAYERS];
+	const float* col_b[FIND_MAX_LAYERS];
+	const float* avg_col; /* (3) added to the colour output when non-NULL (use_avg_colour, model.py:446-447) */
+} find_mlp_params;
+
+/* Gradient outputs, same shapes as the corresponding weights; every buffer is OVERWRITTEN. */
+typedef struct find_mlp_grads {
+	float* trunk_w[FIND_MAX_LAYERS];
+	float* trunk_b[FIND_MAX_LAYERS];
+	float* disp_w[FIND_MAX_LAYERS];
+	float* disp_b[FIND_MAX_LAYERS];
+	float* col_w[FIND_MAX_LAYERS];
+	float* col_b[FIND_MAX_LAYERS];
+	float* lat_disp; /* (n_feet, lat_disp) or NULL */
+	float* lat_col;  /* (n_feet, lat_col) or NULL */
+} find_mlp_grads;
+
+/* Bytes of workspace find_mlp_fwd needs.  `pos_batch` is 1 (positions shared by every foot: the template,
+ * model.py:404-406 / pytorch3d_tools.py:7-16) or n_feet.  With save_for_bwd the same buffer must be passed,
+ * untouched, to find_mlp_bwd. */
+int64_t find_mlp_ws_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts, int save_for_bwd);
+
+/* pos (pos_batch, n_pts, 3); lat_disp (n_feet, lat_disp) or NULL; lat_col (n_feet, lat_col) or NULL;
+ * out: disp (n_feet, n_pts, 3) = 0.1*tanh(.), col (n_feet, n_pts, 3) = 0.5*(1+tanh(.)) [+avg_col]. */
+int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+				 const float* lat_disp, const float* lat_col, float* disp, float* col,
+				 void* ws, int64_t ws_bytes, int save_for_bwd, void* stream);
+
+/* Backward of find_mlp_fwd.  d_disp, d_col: (n_feet, n_pts, 3) upstream gradients (either may be NULL = zero).
+ * `ws` is the forward workspace (save_for_bwd=1); `scratch` is extra space of find_mlp_bwd_scratch_bytes(). */
+int64_t find_mlp_bwd_scratch_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts);
+int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+				 const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col,
+				 const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
+				 const find_mlp_grads* grads, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Similarity registration  X = ((v + disp) * S) @ R(euler 'XYZ') + t.
+ * Replaces euler_angles_to_matrix + Transform3d().scale().rotate().translate().transform_points
+ * in NeuralDisplacementField.get_meshes (src/model/model.py:481-491).
+ * reg (n_feet, 9) = [t(3), euler(3), S(3)]; verts (verts_batch in {1, n_feet}, n_pts, 3).
+ * ---------------------------------------------------------------------------------------------- */
+int find_register_fwd(const float* verts, int64_t verts_batch, const float* disp, const float* reg,
+					  int64_t n_feet, int64_t n_pts, float* out, void* stream);
+/* d_out (n_feet,n_pts,3) -> d_disp (n_feet,n_pts,3), d_reg (n_feet,9).  ws: find_register_bwd_ws_bytes(). */
+int64_t find_register_bwd_ws_bytes(int64_t n_feet, int64_t n_pts);
+int find_register_bwd(const float* verts, int64_t verts_batch, const float* disp, const float* reg,
+					  const float* d_out, int64_t n_feet, int64_t n_pts, float* d_disp, float* d_reg,
+					  void* ws, int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Surface sampling gather.  Replaces the gather/lerp half of pytorch3d.ops.sample_points_from_meshes
+ * (call sites src/model/losses.py:39-41,63,67; src/eval/eval_3d.py:149-150); the random draws
+ * (face index, u, v) are INPUTS so CPU and GPU runs see identical samples.
+ * verts (n_meshes, n_verts, 3); faces (n_faces, 3) int32 shared topology when faces_batch == 1, else
+ * (n_meshes, n_faces, 3); face_idx (n_meshes, n_samples) int32; uv (n_meshes, n_samples, 2).
+ * out (n_meshes, n_samples, 3) = w0*v0 + w1*v1 + w2*v2,  (w0,w1,w2) = (1-sqrt(u), sqrt(u)(1-v), sqrt(u)v).
+ * `attr` (optional, same layout as verts, n_attr channels=3) is sampled into attr_out with the same weights.
+ * ---------------------------------------------------------------------------------------------- */
+int find_sample_points_fwd(const float* verts, const int32_t* faces, int64_t faces_batch, const int32_t* face_idx,
+						   const float* uv, int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_samples,
+						   float* out, const float* attr, float* attr_out, void* stream);
+/* d_out (n_meshes,n_samples,3) scattered to d_verts (n_meshes,n_verts,3), which must be zero-initialised. */
+int find_sample_points_bwd(const int32_t* faces, int64_t faces_batch, const int32_t* face_idx, const float* uv,
+						   const float* d_out, int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_samples,
+						   float* d_verts, void* stream);
+/* Face areas 0.5*|(v1-v0)x(v2-v0)| (n_meshes, n_faces): the multinomial weights of the sampler. */
+int find_face_areas(const float* verts, const int32_t* faces, int64_t faces_batch, int64_t n_meshes, int64_t n_verts,
+					int64_t n_faces, float* areas, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Chamfer nearest neighbour (K=1, squared L2, brute force).
+ * Replaces pytorch3d.ops.knn_points inside pytorch3d.loss.chamfer_distance
+ * (call sites src/model/losses.py:77,85,88; src/eval/eval_3d.py:151,159).
+ * x (n, p1_max, 3) with per-cloud lengths x_len (n) int32 (NULL = all p1_max); same for y.
+ * Outputs for every valid x_i: dist (n,p1_max) = min_j |x_i-y_j|^2, idx (n,p1_max) int32 = argmin_j
+ * (lowest j on ties); padding rows get dist 0 / idx -1.
+ * ---------------------------------------------------------------------------------------------- */
+int find_nn_fwd(const float* x, const int32_t* x_len, const float* y, const int32_t* y_len, int64_t n,
+				int64_t p1_max, int64_t p2_max, float* dist, int32_t* idx, void* stream);
+/* Chamfer gradient for one direction: for valid i, g = 2*w[n,i]*(x_i - y_idx);  d_x[n,i] += g ; d_y[n,idx] -= g.
+ * w (n,p1_max) is the upstream gradient of dist.  d_x / d_y must be zero-initialised (or hold the other
+ * direction's contribution); either may be NULL. */
+int find_nn_bwd(const float* x, const int32_t* x_len, const float* y, const int32_t* idx, const float* w, int64_t n,
+				int64_t p1_max, int64_t p2_max, float* d_x, float* d_y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mesh smoothness: mesh_edge_loss(target 0) and mesh_laplacian_smoothing('cot').
+ * Replaces pytorch3d.loss.mesh_edge_loss / mesh_laplacian_smoothing (call site src/model/losses.py:95-97).
+ * Topology is shared by every mesh in the batch (one template): edges (n_edges,2) int32 unique undirected,
+ * faces (n_faces,3) int32.  verts (n_meshes,n_verts,3).
+ * Outputs: loss_edge, loss_lap: 1-element device scalars (batch means, as PyTorch3D).
+ * ws: find_smooth_ws_bytes();  the forward leaves what the backward needs in ws.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t find_smooth_ws_bytes(int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_edges);
+int find_smooth_fwd(const float* verts, const int32_t* faces, const int32_t* edges, int64_t n_meshes, int64_t n_verts,
+					int64_t n_faces, int64_t n_edges, float* loss_edge, float* loss_lap, void* ws, int64_t ws_bytes,
+					void* stream);
+/* d_verts (n_meshes,n_verts,3) OVERWRITTEN with g_edge*dLedge/dV + g_lap*dLlap/dV; g_* are device scalars. */
+int find_smooth_bwd(const float* verts, const int32_t* faces, const int32_t* edges, int64_t n_meshes, int64_t n_verts,
+					int64_t n_faces, int64_t n_edges, const float* g_edge, const float* g_lap, const void* ws,
+					int64_t ws_bytes, float* d_verts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Differentiable mesh render: world->view->NDC transform, rasterisation, fused shading.
+ * Replaces FootRenderer.forward / rasterize (src/model/renderer.py:208-245, 247-383), i.e. PyTorch3D's
+ * FoVPerspectiveCameras + rasterize_meshes (naive and binned) + SoftSilhouetteShader + SoftPhongShader +
+ * softmax_rgb_blend (in-repo mirror src/model/renderer.py:23-72), and their backward.
+ *
+ * Image index = mesh*n_views + view (renderer.py:271-277).  verts (n_meshes, n_verts, 3) world space;
+ * faces (n_faces,3) int32 shared when faces_batch==1 else (n_meshes,n_faces,3); R (n_views,3,3), T (n_views,3)
+ * in PyTorch3D row-vector convention (p_view = p_world @ R + T).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct find_render_params {
+	int32_t image_h, image_w;
+	float fov_deg;        /* 60 */
+	float znear, zfar;    /* 0.02, 100 (renderer.py:274; PyTorch3D default zfar) */
+	float sil_blur_radius;/* log(1/1e-4 - 1) * 1e-4 (renderer.py:127) */
+	float sil_sigma;      /* 1e-4 (renderer.py:124) */
+	int32_t sil_faces_per_pixel; /* 100 (renderer.py:128); the soft mask uses the K nearest-in-depth faces */
+	float rgb_sigma, rgb_gamma;  /* 1e-4, 1e-4 BlendParams defaults */
+	float background[3];  /* (1,1,1) renderer.py:109,118 */
+	float light_pos[3];   /* (0,0,100) renderer.py:114 */
+	float ambient, diffuse, specular, shininess; /* 0.5, 0.3, 0.2, 64 (PyTorch3D PointLights/Materials defaults) */
+	float z_clip;         /* znear/2 (renderer.py:231-234) */
+} find_render_params;
+
+int64_t find_render_ws_bytes(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t n_verts,
+							 int64_t n_faces);
+/* Outputs (any may be NULL to skip): mask (n_meshes,n_views,H,W) soft silhouette; image (n_meshes,n_views,H,W,3)
+ * Phong RGB; pix_to_face (n_meshes,n_views,H,W) int32 nearest face (K=1, blur 0) packed id mesh*n_faces+f or -1;
+ * zbuf (n_meshes,n_views,H,W) depth of that face (-1 where empty).  vert_colors (n_meshes,n_verts,3) needed for image. */
+int find_render_fwd(const find_render_params* rp, const float* verts, const int32_t* faces, int64_t faces_batch,
+					const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
+					int64_t n_verts, int64_t n_faces, float* mask, float* image, int32_t* pix_to_face, float* zbuf,
+					void* ws, int64_t ws_bytes, void* stream);
+/* d_mask / d_image upstream grads (either NULL).  d_verts (n_meshes,n_verts,3) and d_vert_colors (same) are
+ * OVERWRITTEN.  ws must be the forward workspace. */
+int find_render_bwd(const find_render_params* rp, const float* verts, const int32_t* faces, int64_t faces_batch,
+					const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
+					int64_t n_verts, int64_t n_faces, const float* d_mask, const float* d_image,
+					float* d_verts, float* d_vert_colors, void* ws, int64_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIND_HIP_H */

@@ -1,0 +1,227 @@
+"""GPU parity: HIP MLP / registration (through the C-ABI) vs the golden vectors captured from the reference and
+vs the torch-CPU oracle.  Tolerance: the north_star's 1e-4 (fp32); observed errors are ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mlp_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _model_from_golden(g, dev='cuda'):
+	from find_amd.model import NeuralDisplacementField
+	m = NeuralDisplacementField(template_mesh_loc=None, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True,
+								train_size=4, val_size=2, shapevec_size=100, texvec_size=100, posevec_size=100)
+	sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('sd/')}
+	m.load_state_dict(sd, strict=True)
+	np.testing.assert_array_equal(m.encoder[0]._B.numpy(), g['B'])
+	return m.to(dev)
+
+
+def _t(a, dev='cuda'):
+	return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_library_loads_and_reports_gfx950():
+	from find_amd import _lib
+	L = _lib.lib()
+	assert L.find_abi_version() == _lib.ABI_VERSION
+	assert L.find_build_arch() == b'gfx950'
+
+
+@pytest.mark.parametrize('case', list('abcde'))
+def test_forward_matches_reference_golden(golden_main, case):
+	m = _model_from_golden(golden_main)
+	g = {k: _t(golden_main[f'fwd/{case}/{k}']) for k in ['pos', 'shapevec', 'texvec', 'posevec', 'disp', 'col']}
+	with torch.no_grad():
+		res = m(g['pos'], shapevec=g['shapevec'], texvec=g['texvec'], posevec=g['posevec'])
+	assert res['disp'].shape == g['disp'].shape and res['col'].shape == g['col'].shape
+	ed = (res['disp'] - g['disp']).abs().max().item()
+	ec = (res['col'] - g['col']).abs().max().item()
+	assert ed < TOL and ec < TOL, (case, ed, ec)
+	assert ed < 2e-5 and ec < 2e-5, f'fp32 MFMA path unexpectedly loose: {ed} {ec}'
+
+
+@pytest.mark.parametrize('case', list('abd'))
+def test_backward_matches_reference_golden(golden_main, case):
+	m = _model_from_golden(golden_main)
+	lat = {k: _t(golden_main[f'fwd/{case}/{k}']).requires_grad_(True) for k in ['shapevec', 'texvec', 'posevec']}
+	res = m(_t(golden_main[f'fwd/{case}/pos']), **lat)
+	loss = (res['disp'] ** 2).sum() + (res['col'] ** 2).sum()
+	loss.backward()
+	ref_loss = float(golden_main[f'grad/{case}/loss'])
+	assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss)
+	for k in lat:
+		ref = golden_main[f'grad/{case}/{k}']
+		err = np.abs(lat[k].grad.cpu().numpy() - ref).max()
+		assert err < TOL * max(1.0, np.abs(ref).max()), (case, k, err)
+	for k, prm in m.named_parameters():
+		key = f'grad/{case}/sd/{k}'
+		if key not in golden_main:
+			assert prm.grad is None or k.split('.')[0] in ('shapevec', 'texvec', 'posevec', 'reg', 'shapevec_val', 'texvec_val', 'posevec_val', 'reg_val'), k
+			continue
+		got = prm.grad.cpu().numpy()
+		ref = golden_main[key]
+		if ref.shape != got.shape:  # strided subsample (tests/golden/make_golden_mlp.py GRAD_STRIDE)
+			got = got.reshape(-1)[::17]
+		scale = max(1.0, float(np.abs(ref).max()))
+		err = float(np.abs(got - ref).max())
+		assert err < TOL * scale, (case, k, err, scale)
+
+
+def test_variants_match_reference_golden(golden_variants):
+	from find_amd.model import NeuralDisplacementField
+	kws = {
+		'ttf': dict(use_shapevec=True, use_texvec=True, use_posevec=False, shapevec_size=100, texvec_size=100, posevec_size=100),
+		'fff': dict(use_shapevec=False, use_texvec=False, use_posevec=False, shapevec_size=100, texvec_size=100, posevec_size=100),
+		'sizes': dict(use_shapevec=True, use_texvec=True, use_posevec=True, shapevec_size=64, texvec_size=32, posevec_size=64),
+		'depth2': dict(use_shapevec=True, use_texvec=True, use_posevec=True, shapevec_size=100, texvec_size=100, posevec_size=100,
+					   depth=2, dispdepth=2, coldepth=1, sigma=5),
+		'avgcol': dict(use_shapevec=True, use_texvec=True, use_posevec=True, shapevec_size=100, texvec_size=100, posevec_size=100,
+					   use_avg_colour=True),
+	}
+	for name, kw in kws.items():
+		m = NeuralDisplacementField(template_mesh_loc=None, device='cpu', train_size=3, val_size=1, **kw)
+		gen = torch.Generator().manual_seed(1234)
+		with torch.no_grad():
+			m.mlp_disp[-1].weight.copy_(torch.randn(m.mlp_disp[-1].weight.shape, generator=gen) * 0.01)
+			m.mlp_disp[-1].bias.copy_(torch.randn(m.mlp_disp[-1].bias.shape, generator=gen) * 0.01)
+			if kw.get('use_avg_colour'):
+				m.avg_col.copy_(torch.tensor([0.1, -0.2, 0.05]))
+		m = m.to('cuda')
+		lat = {k: _t(golden_variants[f'{name}/{k}']) for k in ['shapevec', 'texvec', 'posevec'] if f'{name}/{k}' in golden_variants}
+		with torch.no_grad():
+			res = m(_t(golden_variants[f'{name}/pos']), **lat)
+		ed = (res['disp'].cpu() - torch.from_numpy(golden_variants[f'{name}/disp'])).abs().max().item()
+		ec = (res['col'].cpu() - torch.from_numpy(golden_variants[f'{name}/col'])).abs().max().item()
+		assert ed < TOL and ec < TOL, (name, ed, ec)
+
+
+def test_latent_width_mismatch_raises(golden_main):
+	m = _model_from_golden(golden_main)
+	pos = torch.zeros(2, 8, 3, device='cuda')
+	with pytest.raises(RuntimeError):
+		m(pos, shapevec=torch.zeros(2, 100, device='cuda'))  # tex/pose missing: the reference fails on the matmul shape too
+
+
+def test_cpu_tensors_fail_loudly(golden_main):
+	m = _model_from_golden(golden_main, dev='cpu')
+	with pytest.raises(RuntimeError, match='no CPU fallback'):
+		m(torch.zeros(1, 4, 3), shapevec=torch.zeros(1, 100), texvec=torch.zeros(1, 100), posevec=torch.zeros(1, 100))
+
+
+def test_shared_trunk_equals_general_path_full_size(golden_main):
+	"""C2-size property (16 feet x 6890 vertices): evaluating a batch-1 template through the shared trunk gives the
+	same outputs and gradients as expanding it to one copy per foot (what the reference executes)."""
+	m = _model_from_golden(golden_main)
+	gen = torch.Generator().manual_seed(3)
+	N, V = 16, 6890
+	ext = torch.tensor([0.12, 0.045, 0.04])
+	pos1 = ((torch.rand(1, V, 3, generator=gen) * 2 - 1) * ext).cuda()
+	lat = [(torch.randn(N, 100, generator=gen) * 0.1).cuda() for _ in range(3)]
+	outs, grads = [], []
+	for pos in (pos1, pos1.expand(N, -1, -1).contiguous()):
+		m.zero_grad()
+		l3 = [x.clone().requires_grad_(True) for x in lat]
+		res = m(pos, shapevec=l3[0], texvec=l3[1], posevec=l3[2])
+		w = torch.linspace(0.5, 1.5, N * V * 3, device='cuda').reshape(N, V, 3)
+		((res['disp'] * w).sum() * 10 + (res['col'] * w).sum()).backward()
+		outs.append((res['disp'].detach(), res['col'].detach()))
+		grads.append([x.grad.clone() for x in l3] + [prm.grad.clone() for prm in m._weights()])
+	assert (outs[0][0] - outs[1][0]).abs().max() < 1e-5
+	assert (outs[0][1] - outs[1][1]).abs().max() < 1e-5
+	for a, b in zip(grads[0], grads[1]):
+		scale = max(1.0, b.abs().max().item())
+		assert (a - b).abs().max().item() < 2e-4 * scale
+
+
+def test_backward_is_linear_in_upstream_gradient(golden_main):
+	m = _model_from_golden(golden_main)
+	pos = _t(golden_main['fwd/a/pos'])
+	lat = {k: _t(golden_main[f'fwd/a/{k}']) for k in ['shapevec', 'texvec', 'posevec']}
+	gen = torch.Generator().manual_seed(5)
+	g1 = torch.randn(2, 1000, 3, generator=gen).cuda()
+	g2 = torch.randn(2, 1000, 3, generator=gen).cuda()
+
+	def grads(gd, gc):
+		m.zero_grad()
+		res = m(pos, **lat)
+		torch.autograd.backward([res['disp'], res['col']], [gd, gc])
+		return [prm.grad.clone() for prm in m._weights()]
+
+	a = grads(g1, g2)
+	b = grads(2 * g1, 2 * g2)
+	c = grads(g1, torch.zeros_like(g2))
+	d = grads(torch.zeros_like(g1), g2)
+	for x, y, u, v in zip(a, b, c, d):
+		s = max(1.0, x.abs().max().item())
+		assert (2 * x - y).abs().max().item() < 1e-4 * s
+		assert (u + v - x).abs().max().item() < 1e-4 * s
+
+
+def test_only_col_gradient_skips_disp_head(golden_main):
+	"""TextureLossGTSpace (losses.py:51-57) back-propagates through `col` only."""
+	m = _model_from_golden(golden_main)
+	pos = _t(golden_main['fwd/d/pos'])
+	lat = {k: _t(golden_main[f'fwd/d/{k}']).requires_grad_(True) for k in ['shapevec', 'texvec', 'posevec']}
+	res = m(pos, **lat)
+	(res['col'] ** 2).sum().backward()
+	assert m.mlp_disp[0].weight.grad.abs().max().item() == 0.0
+	assert lat['shapevec'].grad.abs().max().item() == 0.0
+	assert m.mlp_col[0].weight.grad.abs().max().item() > 0.0
+	# oracle check of the col-only gradient
+	sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and k.split('.')[0] in ('base', 'mlp_col'))
+		  for k, v in m.state_dict().items()}
+	r = mlp_ref.mlp_forward(sd, m.encoder[0]._B, pos.cpu(), *(lat[k].detach().cpu() for k in ['shapevec', 'texvec', 'posevec']))
+	(r['col'] ** 2).sum().backward()
+	for k in ['base.0.weight', 'base.8.bias', 'mlp_col.0.weight', 'mlp_col.6.weight']:
+		ref = sd[k].grad
+		got = dict(m.named_parameters())[k].grad.cpu()
+		assert (got - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item()), k
+
+
+def test_registration_forward_backward_vs_oracle():
+	from find_amd import functional as FN
+	gen = torch.Generator().manual_seed(9)
+	for vb, N, V in [(1, 3, 1500), (3, 3, 257), (1, 1, 1)]:
+		verts = torch.randn(vb, V, 3, generator=gen) * 0.1
+		disp = (torch.randn(N, V, 3, generator=gen) * 0.01).requires_grad_(True)
+		reg = torch.cat([torch.rand(N, 3, generator=gen) * 0.02 - 0.01, torch.rand(N, 3, generator=gen) * 0.6 - 0.3,
+						 torch.rand(N, 3, generator=gen) * 0.2 + 0.9], dim=1).requires_grad_(True)
+		gout = torch.randn(N, V, 3, generator=gen)
+		ref = mlp_ref.registration(verts.expand(N, -1, -1), disp, reg)
+		ref.backward(gout)
+		d2 = disp.detach().cuda().requires_grad_(True)
+		r2 = reg.detach().cuda().requires_grad_(True)
+		out = FN.register_points(verts.cuda(), d2, r2)
+		out.backward(gout.cuda())
+		assert (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-6
+		assert (d2.grad.cpu() - disp.grad).abs().max().item() < 1e-5
+		scale = max(1.0, reg.grad.abs().max().item())
+		assert (r2.grad.cpu() - reg.grad).abs().max().item() < 1e-4 * scale, (r2.grad.cpu(), reg.grad)
+
+
+def test_get_meshes_matches_oracle(golden_main):
+	m = _model_from_golden(golden_main)
+	gen = torch.Generator().manual_seed(4)
+	V = 333
+	tv = (torch.rand(V, 3, generator=gen) * 2 - 1) * torch.tensor([0.12, 0.045, 0.04])
+	faces = torch.randint(0, V, (600, 3), generator=gen)
+	m.set_template(tv.cuda(), faces.cuda())
+	N = 4
+	sv, tx, pv = [(torch.randn(N, 100, generator=gen) * 0.1) for _ in range(3)]
+	reg = torch.cat([torch.rand(N, 3, generator=gen) * 0.02 - 0.01, torch.rand(N, 3, generator=gen) * 0.2 - 0.1,
+					 torch.rand(N, 3, generator=gen) * 0.2 + 0.9], dim=1)
+	with torch.no_grad():
+		res = m.get_meshes(shapevec=sv.cuda(), reg=reg.cuda(), texvec=tx.cuda(), posevec=pv.cuda())
+		sd = {k: v.cpu() for k, v in m.state_dict().items()}
+		ref = mlp_ref.get_meshes_verts(sd, m.encoder[0]._B, tv[None], sv, reg, tx, pv)
+	assert set(res) >= {'meshes', 'offsets', 'verts', 'disp', 'col'}
+	assert (res['verts'].cpu() - ref['verts']).abs().max().item() < TOL
+	assert (res['col'].cpu() - ref['col']).abs().max().item() < TOL
+	assert len(res['meshes']) == N
+	assert res['meshes'].verts_padded().shape == (N, V, 3)
+	assert torch.equal(res['meshes'].faces_padded()[2].cpu(), faces)
+	assert (res['meshes'].textures.verts_features_padded() - res['col']).abs().max().item() == 0
