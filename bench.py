@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the FIND hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Metric (BASELINE.json): deformed vertices x rendered views / second, forward+backward.
+Workload at every N: BASELINE.json configs[1] per GPU -- a batch of 16 feet x 6890-vertex template through
+Fourier PE + trunk + displacement/colour heads + similarity registration, loss = sum(verts^2)+sum(col^2), full
+backward to every weight, latent row and registration row (views := 1: nothing is rendered in this config).
+Weak scaling: every rank owns 16 distinct feet; gradients of the replicated parameters are averaged with one
+RCCL all-reduce per step.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant kernel (256x256 Linear+ReLU fp32-MFMA GEMM over all 110 240 rows) timed live with
+                  HIP events on the launch stream; achieved = 2*rows*256*256 flop / average duration.
+  cpu_baseline -- oracle/mlp_ref.py (the reference's op sequence on torch-CPU) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FEET = 16
+N_VERTS = 6890
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MAC counts per vertex evaluation: reference-equivalent fwd+bwd, and what this build executes when the
+# trunk is shared by the 16 feet of a batch (trunk fwd+bwd once per template vertex instead of once per foot-vertex).
+MAC_FWD_REF = 866304
+MAC_FWDBWD_REF = 2465536
+MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
+MAC_HEADS_FWD = (456 + 356) * 256 + 4 * 256 * 256 + 2 * 3 * 256
+
+
+def executed_flops_per_step(n_feet, n_verts):
+	"""fwd+bwd flops this build executes for one batch with a shared template (per-foot latent columns folded into a bias)."""
+	trunk_fwd = MAC_TRUNK_FWD
+	trunk_bwd = 2 * MAC_TRUNK_FWD - 515 * 256  # dW + dX, no dX through layer 0
+	heads_main_fwd = 2 * 256 * 256 + 4 * 256 * 256 + 2 * 3 * 256  # latent columns become a bias
+	heads_bwd = 2 * heads_main_fwd
+	return 2.0 * (n_verts * (trunk_fwd + trunk_bwd) + n_feet * n_verts * (heads_main_fwd + heads_bwd))
+
+
+def build_step(device, seed):
+	from find_amd import synthetic
+	model = synthetic.make_model(N_VERTS, train_size=N_FEET, val_size=2, device=device)
+	lat = synthetic.latents(N_FEET, seed=seed, device=device)
+	# latent rows live in the model's tables (LatentVector); the step gathers them like trainer.sample_latent_vectors
+	with torch.no_grad():
+		model.shapevec.data.copy_(lat['shapevec'])
+		model.texvec.data.copy_(lat['texvec'])
+		model.posevec.data.copy_(lat['posevec'])
+		model.reg.data.copy_(lat['reg'])
+	idx = torch.arange(N_FEET, device=device)
+	params = [p for p in model.parameters() if p.requires_grad]
+
+	def step():
+		for p in params:
+			p.grad = None
+		batch = dict(shapevec_train=model.shapevec[idx], texvec_train=model.texvec[idx], posevec_train=model.posevec[idx],
+					 reg_train=model.reg[idx])
+		res = model.get_meshes_from_batch(batch, is_train=True)
+		loss = (res['verts'] ** 2).sum() + (res['col'] ** 2).sum()
+		loss.backward()
+		return loss
+
+	return model, params, step
+
+
+def time_dominant_kernel(device, iters=30):
+	"""Average duration of the dominant kernel (Linear 256->256 + ReLU over all head rows), HIP events on the launch stream."""
+	import ctypes
+	from find_amd import _lib
+	L = _lib.lib()
+	rows = N_FEET * N_VERTS
+	g = torch.Generator().manual_seed(0)
+	x = torch.randn(rows, 256, generator=g).to(device)
+	w = (torch.randn(256, 256, generator=g) / 16).to(device)
+	b = torch.randn(256, generator=g).to(device)
+	y = torch.empty_like(x)
+	stream = torch.cuda.current_stream(device)
+
+	def launch():
+		_lib.check(L.find_linear_relu_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), N_FEET, N_VERTS, _lib.ptr(y),
+										  ctypes.c_void_p(stream.cuda_stream)), 'find_linear_relu_fwd')
+
+	for _ in range(5):
+		launch()
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	e0.record(stream)
+	for _ in range(iters):
+		launch()
+	e1.record(stream)
+	e1.synchronize()
+	ms = e0.elapsed_time(e1) / iters
+	flops = 2.0 * rows * 256 * 256
+	return ms, flops
+
+
+def cpu_baseline(sample_feet=2, steps=2):
+	"""oracle/mlp_ref.py = the reference's op sequence (no trunk sharing, latents concatenated per vertex) on host cores."""
+	from find_amd import synthetic
+	from oracle import mlp_ref
+	cores = os.cpu_count() or 1
+	torch.set_num_threads(cores)
+	model = synthetic.make_model(N_VERTS, train_size=N_FEET, val_size=2, device='cpu')
+	lat = synthetic.latents(sample_feet, seed=0, device='cpu')
+	sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
+		  for k, v in model.state_dict().items()}
+	B = model.encoder[0]._B
+	tv = model.template_verts.data
+	best = float('inf')
+	for i in range(steps + 1):
+		lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+		t0 = time.perf_counter()
+		res = mlp_ref.get_meshes_verts(sd, B, tv, lv['shapevec'], lv['reg'], lv['texvec'], lv['posevec'])
+		loss = (res['verts'] ** 2).sum() + (res['col'] ** 2).sum()
+		loss.backward()
+		dt = time.perf_counter() - t0
+		if i > 0:
+			best = min(best, dt)
+	return dict(value=sample_feet * N_VERTS / best, unit='vertices*views/s', cores=cores, kind='port',
+				sample=f'{sample_feet} of {N_FEET} feet x {N_VERTS} verts, fwd+bwd, best of {steps} after 1 warm-up, torch-CPU {cores} threads')
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument('--gpus', type=int, default=1)
+	ap.add_argument('--steps', type=int, default=30)
+	ap.add_argument('--warmup', type=int, default=5)
+	ap.add_argument('--no-cpu-baseline', action='store_true')
+	args = ap.parse_args()
+
+	import torch.distributed as dist
+	from find_amd import distributed as fdist
+	rank, world, local = fdist.init_from_env()
+	if world != args.gpus:
+		raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run --nproc-per-node {args.gpus}')
+	if not torch.cuda.is_available():
+		raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+	torch.cuda.set_device(local)
+	device = torch.device('cuda', local)
+
+	model, params, step = build_step(device, seed=rank)
+	bucket = None
+	if world > 1:
+		fdist.broadcast_parameters([p for p in model.parameters() if p.is_floating_point()])
+		bucket = fdist.GradBucket(params)
+
+	def full_step():
+		step()
+		if bucket is not None:
+			bucket.allreduce_()
+
+	for _ in range(args.warmup):
+		full_step()
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		full_step()
+	torch.cuda.synchronize()
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	elapsed = time.perf_counter() - t0
+	if world > 1:
+		t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t.item())
+
+	if rank == 0:
+		ms_step = elapsed / args.steps * 1e3
+		verts_per_step = world * N_FEET * N_VERTS
+		value = verts_per_step * args.steps / elapsed
+		kms, kflops = time_dominant_kernel(device)
+		ach = kflops / (kms * 1e-3) / 1e12
+		fl_exec = executed_flops_per_step(N_FEET, N_VERTS)
+		fl_ref = 2.0 * MAC_FWDBWD_REF * N_FEET * N_VERTS
+		out = {
+			'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': value, 'unit': 'vertices*views/s',
+			'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
+			'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+			'config': {'workload': f'C2: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
+					   'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{world}',
+					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
+					   'step_tflops_executed': fl_exec / (ms_step * 1e-3) / 1e12,
+					   'step_tflops_reference_equiv': fl_ref / (ms_step * 1e-3) / 1e12},
+			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm_kernel<128,MAT,BIAS_RELU> (Linear 256->256 + ReLU, 110240 rows)',
+						 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
+						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': None},
+		}
+		if world == 1 and not args.no_cpu_baseline:
+			out['cpu_baseline'] = cpu_baseline()
+		print(json.dumps(out), flush=True)
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+	main()

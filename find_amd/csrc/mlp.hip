@@ -260,6 +260,15 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	return FIND_OK;
 }
 
+extern "C" int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream) {
+	FIND_REQUIRE(x && w && b && y, "find_linear_relu_fwd: NULL argument");
+	FIND_REQUIRE(n_feet >= 1 && n_pts >= 1 && n_feet < (1 << 16), "find_linear_relu_fwd: bad sizes");
+	FIND_REQUIRE(aligned16(w) && aligned16(x), "find_linear_relu_fwd: x and w must be 16-byte aligned");
+	linear_fwd(x, n_pts * W, w, W, b, 0, y, n_pts, n_feet, reinterpret_cast<hipStream_t>(stream));
+	FIND_LAUNCH_CHECK("find_linear_relu_fwd");
+	return FIND_OK;
+}
+
 // ------------------------------------------------------------------------------------------- backward
 namespace find {
 namespace mlp {

@@ -1,0 +1,102 @@
+"""Seeded synthetic inputs of the FIND hot path: there is no Foot3D dataset or checkpoint in the
+build / GPU containers, so benchmarks, smoke and parity tests use these generators.  Host-side numpy/torch only."""
+import math
+
+import numpy as np
+import torch
+
+TEMPLATE_GRIDS = {1002: (25, 40), 6890: (84, 82), 10002: (100, 100), 50002: (200, 250)}
+
+
+def ellipsoid_mesh(rings, segs, axes=(0.12, 0.045, 0.04)):
+	"""Closed lat-long ellipsoid centred at the origin: V = rings*segs + 2, F = 2*(V - 2).
+	Returns verts (V,3) float32, faces (F,3) int64 (outward orientation)."""
+	th = (np.arange(1, rings + 1) / (rings + 1)) * math.pi          # polar angle, poles excluded
+	ph = (np.arange(segs) / segs) * 2 * math.pi
+	T, P = np.meshgrid(th, ph, indexing='ij')
+	x = np.sin(T) * np.cos(P)
+	y = np.sin(T) * np.sin(P)
+	z = np.cos(T)
+	grid = np.stack([x, y, z], -1).reshape(-1, 3)
+	verts = np.concatenate([[[0, 0, 1.0]], grid, [[0, 0, -1.0]]], 0) * np.asarray(axes)[None]
+	top, bot = 0, rings * segs + 1
+
+	def vid(r, s):
+		return 1 + r * segs + (s % segs)
+
+	faces = []
+	for s in range(segs):
+		faces.append([top, vid(0, s), vid(0, s + 1)])
+		faces.append([bot, vid(rings - 1, s + 1), vid(rings - 1, s)])
+	for r in range(rings - 1):
+		for s in range(segs):
+			a, b, c, d = vid(r, s), vid(r + 1, s), vid(r + 1, s + 1), vid(r, s + 1)
+			faces.append([a, b, c])
+			faces.append([a, c, d])
+	return torch.from_numpy(verts.astype(np.float32)), torch.tensor(faces, dtype=torch.int64)
+
+
+def template(n_verts=6890):
+	rings, segs = TEMPLATE_GRIDS[n_verts]
+	return ellipsoid_mesh(rings, segs)
+
+
+def make_model(n_verts=6890, train_size=16, val_size=2, device='cuda', latent_size=100, nonzero_disp_head=True, **kw):
+	"""NeuralDisplacementField at FIND's training settings (train.py:148-157) with an ellipsoid template.
+	The last disp layer is re-drawn N(0, 0.01^2) (generator seed 1234) so the displacement head carries gradient:
+	at the reference's zero init (model.py:516-518) most of that head's backward is identically zero."""
+	from .model import NeuralDisplacementField
+	m = NeuralDisplacementField(template_mesh_loc=None, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True,
+								train_size=train_size, val_size=val_size, shapevec_size=latent_size, texvec_size=latent_size,
+								posevec_size=latent_size, **kw)
+	if nonzero_disp_head:
+		g = torch.Generator().manual_seed(1234)
+		with torch.no_grad():
+			m.mlp_disp[-1].weight.copy_(torch.randn(m.mlp_disp[-1].weight.shape, generator=g) * 0.01)
+			m.mlp_disp[-1].bias.copy_(torch.randn(m.mlp_disp[-1].bias.shape, generator=g) * 0.01)
+	m = m.to(device)
+	v, f = template(n_verts)
+	m.set_template(v.to(device), f.to(device))
+	return m
+
+
+def latents(n_feet, latent_size=100, seed=0, device='cuda'):
+	"""shape / tex / pose codes ~ N(0, 0.1^2); reg: t~U(-0.01,0.01), euler~U(-0.1,0.1), S~U(0.9,1.1)."""
+	g = torch.Generator().manual_seed(seed)
+	sv, tv, pv = [(torch.randn(n_feet, latent_size, generator=g) * 0.1) for _ in range(3)]
+	reg = torch.cat([torch.rand(n_feet, 3, generator=g) * 0.02 - 0.01, torch.rand(n_feet, 3, generator=g) * 0.2 - 0.1,
+					 torch.rand(n_feet, 3, generator=g) * 0.2 + 0.9], dim=1)
+	return dict(shapevec=sv.to(device), texvec=tv.to(device), posevec=pv.to(device), reg=reg.to(device))
+
+
+def gt_feet(n_feet, n_verts=10002, seed=0, device='cuda'):
+	"""Per-foot GT scans: ellipsoid with axes scaled U(0.9,1.1) plus three low-frequency sinusoidal bumps (3 mm),
+	per-vertex RGB.  Returns verts (N,V,3), faces (F,3) int64 (shared topology), colours (N,V,3)."""
+	rng = np.random.RandomState(seed)
+	rings, segs = TEMPLATE_GRIDS[n_verts]
+	base, faces = ellipsoid_mesh(rings, segs, axes=(1.0, 1.0, 1.0))
+	base = base.numpy()
+	verts, cols = [], []
+	for _ in range(n_feet):
+		ax = np.array([0.12, 0.045, 0.04]) * rng.uniform(0.9, 1.1, 3)
+		r = np.ones(len(base))
+		for _k in range(3):
+			w = rng.uniform(1.0, 3.0, 3)
+			ph = rng.uniform(0, 2 * np.pi)
+			r = r + (0.003 / 0.04) * np.sin(base @ w + ph)
+		v = base * r[:, None] * ax[None]
+		verts.append(v.astype(np.float32))
+		c = 0.5 + 0.4 * np.sin(base * rng.uniform(2, 6, 3)[None] + rng.uniform(0, 6, 3)[None])
+		cols.append(c.astype(np.float32))
+	return (torch.from_numpy(np.stack(verts)).to(device), faces.to(device), torch.from_numpy(np.stack(cols)).to(device))
+
+
+def surface_draws(n_meshes, n_samples, n_faces, seed=0, device='cuda', areas=None):
+	"""Pre-drawn sampler inputs (face index, u, v): face ~ multinomial(areas) if given else uniform."""
+	g = torch.Generator().manual_seed(seed)
+	if areas is not None:
+		face = torch.multinomial(areas.detach().cpu().float(), n_samples, replacement=True, generator=g)
+	else:
+		face = torch.randint(0, n_faces, (n_meshes, n_samples), generator=g)
+	uv = torch.rand(n_meshes, n_samples, 2, generator=g)
+	return face.to(torch.int32).to(device), uv.to(device)

@@ -99,6 +99,11 @@ int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, 
 				 const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
 				 const find_mlp_grads* grads, void* stream);
 
+/* One hidden layer  y = relu(x @ w^T + b)  with x (n_feet*n_pts, 256), w (256,256), b (256): the dominant kernel
+ * of the path (nn.Linear + nn.ReLU pairs built at src/model/model.py:255-257, 353-356, 362-365).  Exposed so the
+ * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
+int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Similarity registration  X = ((v + disp) * S) @ R(euler 'XYZ') + t.
  * Replaces euler_angles_to_matrix + Transform3d().scale().rotate().translate().transform_points
