@@ -284,6 +284,10 @@ struct BwdWs {
 	float* pb;    // bias partial slabs
 	float* Sd;    // (n_feet,256) per-foot column sums of the disp head's first-layer dZ
 	float* Sc;
+	float* zsD;   // shared template: (V,256) sum over feet of the disp head's first-layer dZ
+	float* zsC;
+	float* pS;    // [nblk_fs][n_feet][256] partial per-foot column sums
+	int nblk_fs;
 	float* pwo[2];  // final-layer partials
 	float* pbo[2];
 	int nblk_out;
@@ -309,7 +313,15 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	o->pb = c.take<float>(ms * W);
 	o->Sd = c.take<float>(d.n_feet * W);
 	o->Sc = c.take<float>(d.n_feet * W);
-	o->nblk_out = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(d.rows_h, 32), 1024));
+	o->nblk_fs = (int)cdiv(d.V, FS_ROWS);
+	if (d.shared) {
+		o->zsD = c.take<float>(d.V * W);
+		o->zsC = c.take<float>(d.V * W);
+		o->pS = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
+	} else {
+		o->zsD = o->zsC = o->pS = nullptr;
+	}
+	o->nblk_out = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(d.rows_h, 64), 512));
 	for (int i = 0; i < 2; ++i) {
 		o->pwo[i] = c.take<float>((int64_t)o->nblk_out * 3 * W);
 		o->pbo[i] = c.take<float>((int64_t)o->nblk_out * 4);
@@ -329,7 +341,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 	a.x = x; a.x_foot_stride = x_foot_stride; a.ldx = W;
 	a.pos = pos; a.pos_foot_stride = pos_foot_stride; a.Bm = p->B; a.pe = p->pe_size;
 	a.V = (int)V; a.spf = spf; a.cps = cps; a.Kp = nkt * 256;
-	a.pw = b.pw; a.pb = b.pb;
+	a.pw = b.pw; a.pb = (db || S) ? b.pb : nullptr;
 	const int nsplit = (int)(feet * spf);
 	dim3 grid((unsigned)nkt, (unsigned)nsplit);
 	if (pos) hipLaunchKernelGGL((dw_kernel<AMODE_PE>), grid, dim3(512), 0, s, a);
@@ -339,9 +351,10 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 	memset(&r, 0, sizeof(r));
 	r.pw = b.pw; r.nsplit = nsplit; r.Kp = a.Kp; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
-	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)cdiv((int64_t)256 * a.Kp, 256)), dim3(256), 0, s, r);
-	hipLaunchKernelGGL(reduce_b_kernel, dim3(1), dim3(256), 0, s, b.pb, (int)feet, spf, db, S);
-	FIND_LAUNCH_CHECK("reduce kernels");
+	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
+	r.nwblk = (int)cdiv((int64_t)256 * a.Kp / 4, 256);
+	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)r.nwblk + 1), dim3(256), 0, s, r);
+	FIND_LAUNCH_CHECK("reduce_w_kernel");
 	return FIND_OK;
 }
 
@@ -445,8 +458,13 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		h.pb[0] = b.pbo[0]; h.pb[1] = b.pbo[1];
 		h.rows = d.rows_h;
 		hipLaunchKernelGGL(head_out_bwd_kernel, dim3((unsigned)b.nblk_out, 2), dim3(256), 0, s, h);
-		if (act_d) hipLaunchKernelGGL(head_out_reduce_kernel, dim3(1), dim3(256), 0, s, b.pwo[0], b.pbo[0], b.nblk_out, g->disp_w[p->n_disp], g->disp_b[p->n_disp]);
-		if (act_c) hipLaunchKernelGGL(head_out_reduce_kernel, dim3(1), dim3(256), 0, s, b.pwo[1], b.pbo[1], b.nblk_out, g->col_w[p->n_col], g->col_b[p->n_col]);
+		HeadOutReduceArgs hr;
+		memset(&hr, 0, sizeof(hr));
+		hr.pw[0] = b.pwo[0]; hr.pw[1] = b.pwo[1]; hr.pb[0] = b.pbo[0]; hr.pb[1] = b.pbo[1];
+		hr.dw[0] = act_d ? g->disp_w[p->n_disp] : nullptr; hr.db[0] = g->disp_b[p->n_disp];
+		hr.dw[1] = act_c ? g->col_w[p->n_col] : nullptr; hr.db[1] = g->col_b[p->n_col];
+		hr.nblk = b.nblk_out;
+		hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(256), 0, s, hr);
 		FIND_LAUNCH_CHECK("head_out_bwd");
 	}
 
@@ -455,14 +473,24 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 
 	// 3. heads, last hidden layer down to the first
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
-						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat) -> int {
+						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs) -> int {
 		for (int l = nl - 1; l >= 1; --l) {
 			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, s);
 			if (r != FIND_OK) return r;
 			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur ^ 1], V, n_feet, s);
 			cur ^= 1;
 		}
-		int r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, s);
+		int r;
+		if (d.shared) {
+			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, b.pS);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(256), 0, s, b.pS, b.nblk_fs, (int)n_feet, S, (float*)nullptr);
+			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
+			FIND_LAUNCH_CHECK("footsum");
+			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, s);
+		} else {
+			r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, s);
+		}
 		if (r != FIND_OK) return r;
 		if (L > 0) {
 			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(128), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
@@ -471,11 +499,11 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		return FIND_OK;
 	};
 	if (act_d) {
-		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp);
+		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD);
 		if (rc != FIND_OK) return rc;
 	}
 	if (act_c) {
-		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col);
+		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC);
 		if (rc != FIND_OK) return rc;
 	}
 
@@ -484,13 +512,13 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	{
 		GemmArgs a = gemm_args_zero();
 		const float* A[2]; const float* Wt[2]; int nb = 0;
-		if (act_d) { A[nb] = b.dzD[cd]; Wt[nb] = b.Dt[0]; ++nb; }
-		if (act_c) { A[nb] = b.dzC[cc]; Wt[nb] = b.Ct[0]; ++nb; }
+		if (act_d) { A[nb] = d.shared ? b.zsD : b.dzD[cd]; Wt[nb] = b.Dt[0]; ++nb; }
+		if (act_c) { A[nb] = d.shared ? b.zsC : b.dzC[cc]; Wt[nb] = b.Ct[0]; ++nb; }
 		a.nbase = nb; a.a0 = A[0]; a.w0 = Wt[0];
 		if (nb > 1) { a.a1 = A[1]; a.w1 = Wt[1]; }
 		a.lda = W; a.ldw = W; a.nchunk = W / KC;
-		if (d.shared) { a.nseg_per_base = (int)n_feet; a.a_seg_stride = V * W; a.a_foot_stride = 0; }
-		else { a.nseg_per_base = 1; a.a_seg_stride = 0; a.a_foot_stride = V * W; }
+		a.nseg_per_base = 1; a.a_seg_stride = 0;
+		a.a_foot_stride = d.shared ? 0 : V * W;  // shared: the foot-summed (V,256) matrices
 		a.mask = hl; a.mask_foot_stride = V * W;
 		a.y = b.dzT[ct]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
 		launch_gemm(AMODE_MAT, EPI_MASK, a, d.feet_t, s);

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 	}
 }
 
-// dW[n, map(k)] = sum_split pw[split][n][k]
+// dW[n, map(k)] = sum_split pw[split][n][k]   (blocks [0, nwblk));   bias / per-foot sums in the last block.
 struct ReduceWArgs {
 	const float* pw;
 	int nsplit;
@@ -374,34 +374,110 @@ struct ReduceWArgs {
 	int pe_map;    // 1: padded PE layout -> reference column order
 	int pe;
 	int in_dim;
+	const float* pb;  // [n_feet*spf][256] or nullptr
+	int n_feet, spf;
+	float* db;        // (256) or nullptr
+	float* S;         // (n_feet,256) or nullptr
+	int nwblk;
 };
 
-__global__ void reduce_w_kernel(const ReduceWArgs g) {
-	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= (int64_t)256 * g.Kp) return;
-	const int n = (int)(i / g.Kp), k = (int)(i - (int64_t)n * g.Kp);
-	int ko;
-	if (g.pe_map) ko = pe_col_to_orig(k, g.pe, g.in_dim);
-	else ko = (k < g.K_valid) ? k : -1;
-	if (ko < 0) return;
-	float s = 0.f;
-	const float* p = g.pw + i;
+__global__ __launch_bounds__(256) void reduce_w_kernel(const ReduceWArgs g) {
+	if ((int)blockIdx.x >= g.nwblk) {
+		// bias: db[n] = sum_split pb[split][n];  S[foot][n] = sum over that foot's splits
+		if (g.pb == nullptr) return;
+		const int n = threadIdx.x;
+		float tot = 0.f;
+		for (int f = 0; f < g.n_feet; ++f) {
+			float s = 0.f;
+			const float* p = g.pb + (int64_t)f * g.spf * 256 + n;
+#pragma unroll 4
+			for (int k = 0; k < g.spf; ++k) s += p[(int64_t)k * 256];
+			if (g.S) g.S[(int64_t)f * 256 + n] = s;
+			tot += s;
+		}
+		if (g.db) g.db[n] = tot;
+		return;
+	}
+	const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+	if (i4 >= (int64_t)256 * g.Kp) return;
+	const int n = (int)(i4 / g.Kp), k = (int)(i4 - (int64_t)n * g.Kp);
+	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+	const float* p = g.pw + i4;
 	const int64_t stride = (int64_t)256 * g.Kp;
-	for (int sidx = 0; sidx < g.nsplit; ++sidx) s += p[sidx * stride];
-	g.out[(int64_t)n * g.ld_out + ko] = s;
+	int sidx = 0;
+	for (; sidx + 4 <= g.nsplit; sidx += 4) {
+		const float4 a = *reinterpret_cast<const float4*>(p + (sidx + 0) * stride);
+		const float4 b = *reinterpret_cast<const float4*>(p + (sidx + 1) * stride);
+		const float4 c = *reinterpret_cast<const float4*>(p + (sidx + 2) * stride);
+		const float4 d = *reinterpret_cast<const float4*>(p + (sidx + 3) * stride);
+		s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+		s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
+	}
+	for (; sidx < g.nsplit; ++sidx) {
+		const float4 a = *reinterpret_cast<const float4*>(p + sidx * stride);
+		s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+	}
+	const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		int ko;
+		if (g.pe_map) ko = pe_col_to_orig(k + j, g.pe, g.in_dim);
+		else ko = (k + j < g.K_valid) ? k + j : -1;
+		if (ko >= 0) g.out[(int64_t)n * g.ld_out + ko] = v[j];
+	}
 }
 
-// db[n] = sum_split pb[split][n];  S[foot][n] = sum over that foot's splits (optional)
-__global__ void reduce_b_kernel(const float* pb, int n_feet, int spf, float* db, float* S) {
-	const int n = threadIdx.x;  // 256
-	float tot = 0.f;
-	for (int f = 0; f < n_feet; ++f) {
-		float s = 0.f;
-		for (int k = 0; k < spf; ++k) s += pb[((int64_t)f * spf + k) * 256 + n];
-		if (S) S[(int64_t)f * 256 + n] = s;
-		tot += s;
+// Shared-template backward of a head's first layer: because every foot multiplies the SAME trunk rows,
+//   sum_b dZ0[b,v,:] @ W  ==  (sum_b dZ0[b,v,:]) @ W      and      dW0 = (sum_b dZ0[b])^T @ H.
+// One pass over dZ0 (n_feet, V, 256) produces  zsum[v] = sum_b dZ0[b,v]  and partial per-foot column sums.
+constexpr int FS_ROWS = 16;  // rows of v per block
+__global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ dz, int n_feet, int V, float* __restrict__ zsum,
+													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */) {
+	__shared__ __attribute__((aligned(16))) float red[4][256];
+	const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+	const int v0 = blockIdx.x * FS_ROWS;
+	float4 zs[FS_ROWS / 4];
+#pragma unroll
+	for (int i = 0; i < FS_ROWS / 4; ++i) zs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (int b = 0; b < n_feet; ++b) {
+		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+		const float* base = dz + ((int64_t)b * V) * 256 + cg * 4;
+#pragma unroll
+		for (int i = 0; i < FS_ROWS / 4; ++i) {
+			const int v = v0 + rl + 4 * i;
+			if (v < V) {
+				const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)v * 256);
+				zs[i].x += x.x; zs[i].y += x.y; zs[i].z += x.z; zs[i].w += x.w;
+				acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+			}
+		}
+		__syncthreads();
+		*reinterpret_cast<float4*>(&red[rl][cg * 4]) = acc;
+		__syncthreads();
+		pS[((int64_t)blockIdx.x * n_feet + b) * 256 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 	}
-	if (db) db[n] = tot;
+#pragma unroll
+	for (int i = 0; i < FS_ROWS / 4; ++i) {
+		const int v = v0 + rl + 4 * i;
+		if (v < V) *reinterpret_cast<float4*>(zsum + (int64_t)v * 256 + cg * 4) = zs[i];
+	}
+}
+
+// S[b][n] = sum_blk pS[blk][b][n];  db[n] = sum_b S[b][n]
+__global__ __launch_bounds__(256) void footsum_reduce_kernel(const float* __restrict__ pS, int nblk, int n_feet, float* __restrict__ S, float* __restrict__ db_partial) {
+	const int b = blockIdx.x, n = threadIdx.x;
+	float s = 0.f;
+	const float* p = pS + (int64_t)b * 256 + n;
+#pragma unroll 8
+	for (int k = 0; k < nblk; ++k) s += p[(int64_t)k * n_feet * 256];
+	S[(int64_t)b * 256 + n] = s;
+}
+
+__global__ void colsum_small_kernel(const float* __restrict__ S, int n_feet, float* __restrict__ db) {
+	const int n = threadIdx.x;
+	float s = 0.f;
+	for (int b = 0; b < n_feet; ++b) s += S[(int64_t)b * 256 + n];
+	db[n] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -552,22 +628,37 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 	const float scale = head ? 0.5f : 0.1f;
 	float4 aw0 = make_float4(0, 0, 0, 0), aw1 = aw0, aw2 = aw0;
 	float ab0 = 0.f, ab1 = 0.f, ab2 = 0.f;
-	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < g.rows; row += (int64_t)gridDim.x * 4) {
-		const float t0 = tanhf(z[row * 3 + 0]), t1 = tanhf(z[row * 3 + 1]), t2 = tanhf(z[row * 3 + 2]);
-		const float d0 = gout[row * 3 + 0] * scale * (1.f - t0 * t0);
-		const float d1 = gout[row * 3 + 1] * scale * (1.f - t1 * t1);
-		const float d2 = gout[row * 3 + 2] * scale * (1.f - t2 * t2);
-		const float4 yv = *reinterpret_cast<const float4*>(y + row * W + lane * 4);
-		float4 o;
-		o.x = (yv.x > 0.f) ? d0 * w0.x + d1 * w1.x + d2 * w2.x : 0.f;
-		o.y = (yv.y > 0.f) ? d0 * w0.y + d1 * w1.y + d2 * w2.y : 0.f;
-		o.z = (yv.z > 0.f) ? d0 * w0.z + d1 * w1.z + d2 * w2.z : 0.f;
-		o.w = (yv.w > 0.f) ? d0 * w0.w + d1 * w1.w + d2 * w2.w : 0.f;
-		*reinterpret_cast<float4*>(dy + row * W + lane * 4) = o;
-		aw0.x += d0 * yv.x; aw0.y += d0 * yv.y; aw0.z += d0 * yv.z; aw0.w += d0 * yv.w;
-		aw1.x += d1 * yv.x; aw1.y += d1 * yv.y; aw1.z += d1 * yv.z; aw1.w += d1 * yv.w;
-		aw2.x += d2 * yv.x; aw2.y += d2 * yv.y; aw2.z += d2 * yv.z; aw2.w += d2 * yv.w;
-		ab0 += d0; ab1 += d1; ab2 += d2;
+	constexpr int U = 4;  // rows in flight per wave
+	for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * U; r0 < g.rows; r0 += (int64_t)gridDim.x * 4 * U) {
+		float4 yv[U];
+		float d[U][3];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t row = r0 + u;
+			const bool ok = row < g.rows;
+			yv[u] = ok ? *reinterpret_cast<const float4*>(y + row * W + lane * 4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				const float t = ok ? tanhf(z[row * 3 + c]) : 0.f;
+				d[u][c] = ok ? gout[row * 3 + c] * scale * (1.f - t * t) : 0.f;
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t row = r0 + u;
+			if (row >= g.rows) break;
+			const float d0 = d[u][0], d1 = d[u][1], d2 = d[u][2];
+			float4 o;
+			o.x = (yv[u].x > 0.f) ? d0 * w0.x + d1 * w1.x + d2 * w2.x : 0.f;
+			o.y = (yv[u].y > 0.f) ? d0 * w0.y + d1 * w1.y + d2 * w2.y : 0.f;
+			o.z = (yv[u].z > 0.f) ? d0 * w0.z + d1 * w1.z + d2 * w2.z : 0.f;
+			o.w = (yv[u].w > 0.f) ? d0 * w0.w + d1 * w1.w + d2 * w2.w : 0.f;
+			*reinterpret_cast<float4*>(dy + row * W + lane * 4) = o;
+			aw0.x += d0 * yv[u].x; aw0.y += d0 * yv[u].y; aw0.z += d0 * yv[u].z; aw0.w += d0 * yv[u].w;
+			aw1.x += d1 * yv[u].x; aw1.y += d1 * yv[u].y; aw1.z += d1 * yv[u].z; aw1.w += d1 * yv[u].w;
+			aw2.x += d2 * yv[u].x; aw2.y += d2 * yv[u].y; aw2.z += d2 * yv[u].z; aw2.w += d2 * yv[u].w;
+			ab0 += d0; ab1 += d1; ab2 += d2;
+		}
 	}
 	__shared__ __attribute__((aligned(16))) float red[4][3][256];
 	__shared__ float redb[4][4];
@@ -582,17 +673,34 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 	if (k < 3) pb[(int64_t)blockIdx.x * 4 + k] = redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k];
 }
 
-__global__ void head_out_reduce_kernel(const float* pw, const float* pb, int nblk, float* dw, float* db) {
-	const int k = threadIdx.x;  // 256
-	for (int c = 0; c < 3; ++c) {
-		float s = 0.f;
-		for (int i = 0; i < nblk; ++i) s += pw[((int64_t)i * 3 + c) * 256 + k];
-		dw[c * 256 + k] = s;
-	}
-	if (k < 3) {
-		float s = 0.f;
-		for (int i = 0; i < nblk; ++i) s += pb[(int64_t)i * 4 + k];
-		db[k] = s;
+// grid (12, 2 heads): block handles 64 of the 768 dW outputs; 4 partial-groups per output, LDS-combined.
+struct HeadOutReduceArgs {
+	const float* pw[2];
+	const float* pb[2];
+	float* dw[2];
+	float* db[2];
+	int nblk;
+};
+__global__ __launch_bounds__(256) void head_out_reduce_kernel(const HeadOutReduceArgs g) {
+	const int head = blockIdx.y;
+	float* dw = head ? g.dw[1] : g.dw[0];
+	if (dw == nullptr) return;
+	const float* pw = head ? g.pw[1] : g.pw[0];
+	const float* pb = head ? g.pb[1] : g.pb[0];
+	float* db = head ? g.db[1] : g.db[0];
+	__shared__ float red[4][64];
+	const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+	const int o = blockIdx.x * 64 + j;  // 0..767
+	float s = 0.f;
+#pragma unroll 8
+	for (int i = q; i < g.nblk; i += 4) s += pw[(int64_t)i * 768 + o];
+	red[q][j] = s;
+	__syncthreads();
+	if (q == 0) dw[o] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+	if (blockIdx.x == 0 && threadIdx.x < 3) {
+		float t = 0.f;
+		for (int i = 0; i < g.nblk; ++i) t += pb[(int64_t)i * 4 + threadIdx.x];
+		db[threadIdx.x] = t;
 	}
 }
 
