@@ -1,6 +1,6 @@
 // C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
-#include "mlp_kernels.h"
+#include "mlp_gemm2.h"
 
 namespace find {
 namespace mlp {
@@ -120,7 +120,56 @@ static void launch_gemm_bm(int bm, const GemmArgs& a, int64_t feet, hipStream_t 
 	}
 }
 
+// tuning: 0 = register-staged tiles (gemm_kernel), 64 / 128 = persistent LDS-DMA kernel (gemm2_kernel) with that BM
+static int g_gemm_mode = 64;
+static int g_num_cus = 0;
+
+static int num_cus() {
+	if (g_num_cus == 0) {
+		int dev = 0, n = 0;
+		(void)hipGetDevice(&dev);
+		(void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+		g_num_cus = n > 0 ? n : 256;
+	}
+	return g_num_cus;
+}
+
+template <int BM, int AMODE, int EPI>
+static void launch_gemm2_t(Gemm2Args a, int64_t feet, hipStream_t s) {
+	static bool attr_set = false;
+	constexpr int lds = gemm2_lds_bytes<BM>();
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		attr_set = true;
+	}
+	a.tiles_per_foot = (int)cdiv(a.V, BM);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	const int grid = std::min(a.ntiles, num_cus());
+	hipLaunchKernelGGL((gemm2_kernel<BM, AMODE, EPI>), dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int BM>
+static void launch_gemm2(int amode, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (amode == AMODE_PE) launch_gemm2_t<BM, AMODE_PE, EPI_BIAS_RELU>(a, feet, s);
+	else if (epi == EPI_BIAS_RELU) launch_gemm2_t<BM, AMODE_MAT, EPI_BIAS_RELU>(a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm2_t<BM, AMODE_MAT, EPI_MASK>(a, feet, s);
+	else launch_gemm2_t<BM, AMODE_MAT, EPI_NONE>(a, feet, s);
+}
+
 static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hipStream_t s) {
+	if (g_gemm_mode != 0 && a.nseg_per_base == 1) {
+		Gemm2Args b;
+		memset(&b, 0, sizeof(b));
+		b.a0 = a.a0; b.a1 = a.a1; b.nseg = a.nbase; b.a_foot_stride = a.a_foot_stride; b.lda = a.lda;
+		b.pos = a.pos; b.pos_foot_stride = a.pos_foot_stride; b.Bm = a.Bm; b.pe = a.pe;
+		b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk;
+		b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
+		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V;
+		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
+		if (g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus()) launch_gemm2<128>(amode, epi, b, feet, s);
+		else launch_gemm2<64>(amode, epi, b, feet, s);
+		return;
+	}
 	const int bm = pick_bm(a.V, feet);
 	if (amode == AMODE_PE) launch_gemm_bm<AMODE_PE, EPI_BIAS_RELU>(bm, a, feet, s);
 	else if (epi == EPI_BIAS_RELU) launch_gemm_bm<AMODE_MAT, EPI_BIAS_RELU>(bm, a, feet, s);
@@ -536,4 +585,16 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	if (rc != FIND_OK) return rc;
 	FIND_LAUNCH_CHECK("find_mlp_bwd");
 	return FIND_OK;
+}
+
+// Tuning hook (not part of the reference surface): "gemm" -> 0 register-staged tiles, 64 / 128 persistent LDS-DMA tiles.
+extern "C" int find_set_tuning(const char* key, int64_t value) {
+	FIND_REQUIRE(key != nullptr, "find_set_tuning: NULL key");
+	if (strcmp(key, "gemm") == 0) {
+		FIND_REQUIRE(value == 0 || value == 64 || value == 128, "find_set_tuning: gemm must be 0, 64 or 128");
+		g_gemm_mode = (int)value;
+		return FIND_OK;
+	}
+	set_error("find_set_tuning: unknown key %s", key);
+	return FIND_EINVAL;
 }

@@ -104,6 +104,10 @@ int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, 
  * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
 int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
 
+/* Tuning hook (no reference counterpart).  key "gemm": 0 = register-staged tiles, 64 / 128 = persistent LDS-DMA
+ * kernel with that tile height (default 64). */
+int find_set_tuning(const char* key, int64_t value);
+
 /* ------------------------------------------------------------------------------------------------
  * Similarity registration  X = ((v + disp) * S) @ R(euler 'XYZ') + t.
  * Replaces euler_angles_to_matrix + Transform3d().scale().rotate().translate().transform_points

@@ -14,6 +14,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n_feet = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n_pts = int(sys.argv[3]) if len(sys.argv) > 3 else 6890
 L = _lib.lib()
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+_lib.check(L.find_set_tuning(b'gemm', mode), 'tuning')
 rows = n_feet * n_pts
 g = torch.Generator().manual_seed(0)
 x = torch.randn(rows, 256, generator=g).cuda()
@@ -32,4 +34,6 @@ e1.synchronize()
 ms = e0.elapsed_time(e1) / iters
 ref = torch.relu(x[:4096] @ w.t() + b)
 err = (y[:4096] - ref).abs().max().item()
-print(f'linear_relu {n_feet}x{n_pts}: {ms*1e3:.1f} us  {2.0*rows*65536/ms/1e9:.1f} TF/s  max_err_vs_torch {err:.2e}')
+ref_all = torch.relu(x @ w.t() + b)
+err = (y - ref_all).abs().max().item()
+print(f'mode {mode} linear_relu {n_feet}x{n_pts}: {ms*1e3:.1f} us  {2.0*rows*65536/ms/1e9:.1f} TF/s  max_err_vs_torch {err:.2e}')
