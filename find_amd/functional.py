@@ -175,3 +175,221 @@ class _Register(torch.autograd.Function):
 
 def register_points(verts, disp, reg):
 	return _Register.apply(verts, disp, reg)
+
+
+# ----------------------------------------------------------------------------------------------- surface sampling
+def _faces_i32(faces):
+	f = faces if faces.dtype == torch.int32 else faces.to(torch.int32)
+	return f.contiguous()
+
+
+def face_areas(verts, faces):
+	"""0.5*|(v1-v0)x(v2-v0)| per face, no gradient (the sampler's multinomial weights; PyTorch3D computes them under
+	no_grad too).  verts (N,V,3); faces (F,3) shared or (N,F,3) (-1 padded)."""
+	_require_gpu(verts)
+	L = _lib.lib()
+	verts = _c(verts.detach())
+	faces = _faces_i32(faces)
+	N, V, _ = verts.shape
+	fb = 1 if faces.dim() == 2 else faces.shape[0]
+	F = faces.shape[-2]
+	out = torch.empty(N, F, device=verts.device, dtype=torch.float32)
+	check(L.find_face_areas(ptr(verts), ptr(faces), fb, N, V, F, ptr(out), current_stream(verts.device)), 'find_face_areas')
+	return out
+
+
+class _SamplePoints(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, verts, faces, face_idx, uv, attr):
+		_require_gpu(verts, uv, attr)
+		L = _lib.lib()
+		verts, uv, attr = _c(verts), _c(uv), _c(attr)
+		faces = _faces_i32(faces)
+		face_idx = face_idx.to(torch.int32).contiguous()
+		N, V, _ = verts.shape
+		S = face_idx.shape[1]
+		fb = 1 if faces.dim() == 2 else faces.shape[0]
+		F = faces.shape[-2]
+		out = torch.empty(N, S, 3, device=verts.device, dtype=torch.float32)
+		aout = torch.empty_like(out) if attr is not None else None
+		check(L.find_sample_points_fwd(ptr(verts), ptr(faces), fb, ptr(face_idx), ptr(uv), N, V, F, S, ptr(out), ptr(attr), ptr(aout),
+									   current_stream(verts.device)), 'find_sample_points_fwd')
+		ctx.save_for_backward(faces, face_idx, uv)
+		ctx.dims = (N, V, F, S, fb)
+		ctx.has_attr = attr is not None
+		if attr is None:
+			return out
+		return out, aout
+
+	@staticmethod
+	def backward(ctx, g_out, g_attr=None):
+		L = _lib.lib()
+		faces, face_idx, uv = ctx.saved_tensors
+		N, V, F, S, fb = ctx.dims
+
+		def scatter(g):
+			if g is None:
+				return None
+			d = torch.zeros(N, V, 3, device=g.device, dtype=torch.float32)
+			check(L.find_sample_points_bwd(ptr(faces), fb, ptr(face_idx), ptr(uv), ptr(_c(g)), N, V, F, S, ptr(d), current_stream(g.device)),
+				  'find_sample_points_bwd')
+			return d
+
+		d_verts = scatter(g_out) if ctx.needs_input_grad[0] else None
+		d_attr = scatter(g_attr) if (ctx.has_attr and ctx.needs_input_grad[4]) else None
+		return d_verts, None, None, None, d_attr
+
+
+def sample_points(verts, faces, face_idx, uv, attr=None):
+	"""Gather half of sample_points_from_meshes with the draws (face_idx (N,S), uv (N,S,2)) given.
+	Returns points (N,S,3) [and attr sampled with the same barycentric weights]."""
+	return _SamplePoints.apply(verts, faces, face_idx, uv, attr)
+
+
+# ----------------------------------------------------------------------------------------------- Chamfer / KNN
+class _NN(torch.autograd.Function):
+	"""dist[n,i] = min_j |x_i - y_j|^2 (K=1 knn_points); gradient flows to both x and the selected y."""
+
+	@staticmethod
+	def forward(ctx, x, y, x_len, y_len):
+		_require_gpu(x, y)
+		L = _lib.lib()
+		x, y = _c(x), _c(y)
+		N, P1, _ = x.shape
+		P2 = y.shape[1]
+		if y.shape[0] != N:
+			raise RuntimeError('find_amd.nn: batch mismatch')
+		xl = None if x_len is None else x_len.to(device=x.device, dtype=torch.int32).contiguous()
+		yl = None if y_len is None else y_len.to(device=x.device, dtype=torch.int32).contiguous()
+		dist = torch.empty(N, P1, device=x.device, dtype=torch.float32)
+		idx = torch.empty(N, P1, device=x.device, dtype=torch.int32)
+		check(L.find_nn_fwd(ptr(x), ptr(xl), ptr(y), ptr(yl), N, P1, P2, ptr(dist), ptr(idx), current_stream(x.device)), 'find_nn_fwd')
+		ctx.save_for_backward(x, y, idx, xl if xl is not None else torch.empty(0, device=x.device, dtype=torch.int32))
+		ctx.has_xl = xl is not None
+		ctx.mark_non_differentiable(idx)
+		return dist, idx
+
+	@staticmethod
+	def backward(ctx, g_dist, _g_idx):
+		L = _lib.lib()
+		x, y, idx, xl = ctx.saved_tensors
+		N, P1, _ = x.shape
+		P2 = y.shape[1]
+		d_x = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+		d_y = torch.zeros_like(y) if ctx.needs_input_grad[1] else None
+		if d_x is not None or d_y is not None:
+			check(L.find_nn_bwd(ptr(x), ptr(xl) if ctx.has_xl else None, ptr(y), ptr(idx), ptr(_c(g_dist)), N, P1, P2, ptr(d_x), ptr(d_y),
+								current_stream(x.device)), 'find_nn_bwd')
+		return d_x, d_y, None, None
+
+
+def knn1(x, y, x_len=None, y_len=None):
+	"""Nearest neighbour in y of every x: (squared distance (N,P1), index (N,P1) int32)."""
+	return _NN.apply(x, y, x_len, y_len)
+
+
+def chamfer_distance(x, y, x_lengths=None, y_lengths=None):
+	"""pytorch3d.loss.chamfer_distance with its defaults (bidirectional, squared L2, point mean, batch mean).
+	Returns (loss, None) like PyTorch3D (the second value is the normals term, never used by FIND: losses.py:77,85,88)."""
+	N = x.shape[0]
+	dx, _ = knn1(x, y, x_lengths, y_lengths)
+	dy, _ = knn1(y, x, y_lengths, x_lengths)
+	if x_lengths is None:
+		cx = dx.sum(1) / float(x.shape[1])
+	else:
+		cx = dx.sum(1) / x_lengths.to(dx.device).clamp(min=1).to(dx.dtype)
+	if y_lengths is None:
+		cy = dy.sum(1) / float(y.shape[1])
+	else:
+		cy = dy.sum(1) / y_lengths.to(dy.device).clamp(min=1).to(dy.dtype)
+	return (cx.sum() + cy.sum()) / max(N, 1), None
+
+
+# ----------------------------------------------------------------------------------------------- smoothness
+class MeshTopology:
+	"""Static per-template tables for the smoothness kernels: unique undirected edges, vertex->incident-corner CSR and
+	vertex->neighbour CSR (host-built once, cached per faces tensor)."""
+	_cache = {}
+
+	def __init__(self, faces, n_verts):
+		import numpy as np
+		f = faces.detach().cpu().numpy().astype(np.int64).reshape(-1, 3)
+		self.n_verts, self.n_faces = int(n_verts), int(f.shape[0])
+		e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+		e.sort(axis=1)
+		e = np.unique(e, axis=0)
+		self.n_edges = int(e.shape[0])
+		# vertex -> corners
+		vid = f.reshape(-1)
+		order = np.argsort(vid, kind='stable')
+		vf_items = order.astype(np.int32)  # item = face*3 + corner
+		vf_off = np.zeros(self.n_verts + 1, np.int32)
+		np.add.at(vf_off, vid + 1, 1)
+		vf_off = np.cumsum(vf_off).astype(np.int32)
+		# vertex -> neighbours
+		a = np.concatenate([e[:, 0], e[:, 1]])
+		b = np.concatenate([e[:, 1], e[:, 0]])
+		o2 = np.argsort(a, kind='stable')
+		nbr_idx = b[o2].astype(np.int32)
+		nbr_off = np.zeros(self.n_verts + 1, np.int32)
+		np.add.at(nbr_off, a + 1, 1)
+		nbr_off = np.cumsum(nbr_off).astype(np.int32)
+		dev = faces.device
+		self.faces = torch.from_numpy(f.astype(np.int32)).to(dev)
+		self.edges = torch.from_numpy(e.astype(np.int32)).to(dev)
+		self.vf_off = torch.from_numpy(vf_off).to(dev)
+		self.vf_items = torch.from_numpy(vf_items).to(dev)
+		self.nbr_off = torch.from_numpy(nbr_off).to(dev)
+		self.nbr_idx = torch.from_numpy(nbr_idx).to(dev)
+
+	@classmethod
+	def get(cls, faces, n_verts):
+		key = (faces.data_ptr(), tuple(faces.shape), str(faces.device), int(n_verts), int(faces._version))
+		t = cls._cache.get(key)
+		if t is None:
+			if len(cls._cache) > 16:
+				cls._cache.clear()
+			t = cls(faces, n_verts)
+			cls._cache[key] = t
+		return t
+
+
+class _Smooth(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, verts, topo):
+		_require_gpu(verts)
+		L = _lib.lib()
+		verts = _c(verts)
+		N, V, _ = verts.shape
+		if V != topo.n_verts:
+			raise RuntimeError(f'find_amd.smooth: verts have {V} vertices, topology {topo.n_verts}')
+		ws = _ws(L.find_smooth_ws_bytes(N, V, topo.n_faces), verts.device)
+		out = torch.empty(2, device=verts.device, dtype=torch.float32)
+		check(L.find_smooth_fwd(ptr(verts), ptr(topo.faces), ptr(topo.vf_off), ptr(topo.vf_items), ptr(topo.nbr_off), ptr(topo.nbr_idx),
+								N, V, topo.n_faces, topo.n_edges, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(out.data_ptr() + 4),
+								ptr(ws), ws.numel(), current_stream(verts.device)), 'find_smooth_fwd')
+		ctx.topo, ctx.ws = topo, ws
+		ctx.save_for_backward(verts)
+		return out[0], out[1]
+
+	@staticmethod
+	def backward(ctx, g_edge, g_lap):
+		L = _lib.lib()
+		(verts,) = ctx.saved_tensors
+		topo = ctx.topo
+		N, V, _ = verts.shape
+		g = torch.zeros(2, device=verts.device, dtype=torch.float32)
+		if g_edge is not None:
+			g[0] = g_edge
+		if g_lap is not None:
+			g[1] = g_lap
+		d = torch.empty_like(verts)
+		check(L.find_smooth_bwd(ptr(verts), ptr(topo.faces), ptr(topo.vf_off), ptr(topo.vf_items), ptr(topo.nbr_off), ptr(topo.nbr_idx),
+								N, V, topo.n_faces, topo.n_edges, ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(g.data_ptr() + 4),
+								ptr(ctx.ws), ctx.ws.numel(), ptr(d), current_stream(verts.device)), 'find_smooth_bwd')
+		return d, None
+
+
+def mesh_edge_and_laplacian(verts, topo):
+	"""(mesh_edge_loss(target 0), mesh_laplacian_smoothing('cot')) for a batch sharing one topology."""
+	return _Smooth.apply(verts, topo)

@@ -161,19 +161,22 @@ int find_nn_bwd(const float* x, const int32_t* x_len, const float* y, const int3
 /* ------------------------------------------------------------------------------------------------
  * Mesh smoothness: mesh_edge_loss(target 0) and mesh_laplacian_smoothing('cot').
  * Replaces pytorch3d.loss.mesh_edge_loss / mesh_laplacian_smoothing (call site src/model/losses.py:95-97).
- * Topology is shared by every mesh in the batch (one template): edges (n_edges,2) int32 unique undirected,
- * faces (n_faces,3) int32.  verts (n_meshes,n_verts,3).
+ * Topology is shared by every mesh in the batch (one template) and static, so the host builds two CSR tables once:
+ *   vf_off (n_verts+1), vf_items (3*n_faces): for every vertex the incident corners, item = face*3 + corner;
+ *   nbr_off (n_verts+1), nbr_idx (2*n_edges): for every vertex its neighbours over the unique undirected edges.
+ * faces (n_faces,3) int32; verts (n_meshes,n_verts,3).  All kernels are deterministic gathers (no float atomics).
  * Outputs: loss_edge, loss_lap: 1-element device scalars (batch means, as PyTorch3D).
  * ws: find_smooth_ws_bytes();  the forward leaves what the backward needs in ws.
  * ---------------------------------------------------------------------------------------------- */
-int64_t find_smooth_ws_bytes(int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_edges);
-int find_smooth_fwd(const float* verts, const int32_t* faces, const int32_t* edges, int64_t n_meshes, int64_t n_verts,
-					int64_t n_faces, int64_t n_edges, float* loss_edge, float* loss_lap, void* ws, int64_t ws_bytes,
-					void* stream);
+int64_t find_smooth_ws_bytes(int64_t n_meshes, int64_t n_verts, int64_t n_faces);
+int find_smooth_fwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
+					const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
+					int64_t n_edges, float* loss_edge, float* loss_lap, void* ws, int64_t ws_bytes, void* stream);
 /* d_verts (n_meshes,n_verts,3) OVERWRITTEN with g_edge*dLedge/dV + g_lap*dLlap/dV; g_* are device scalars. */
-int find_smooth_bwd(const float* verts, const int32_t* faces, const int32_t* edges, int64_t n_meshes, int64_t n_verts,
-					int64_t n_faces, int64_t n_edges, const float* g_edge, const float* g_lap, const void* ws,
-					int64_t ws_bytes, float* d_verts, void* stream);
+int find_smooth_bwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
+					const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
+					int64_t n_edges, const float* g_edge, const float* g_lap, void* ws, int64_t ws_bytes, float* d_verts,
+					void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Differentiable mesh render: world->view->NDC transform, rasterisation, fused shading.
