@@ -68,7 +68,8 @@ PROTOTYPES = {
 	'find_smooth_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
 	'find_render_ws_bytes': (c_int64, [POINTER(RenderParams), _I, _I, _I, _I]),
 	'find_render_fwd': (c_int, [POINTER(RenderParams), _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
-	'find_render_bwd': (c_int, [POINTER(RenderParams), _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P]),
+	'find_render_bwd': (c_int, [POINTER(RenderParams), _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+	'find_render_flags': (c_int, [_P, _P, _P]),
 }
 
 

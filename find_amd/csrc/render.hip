@@ -1,0 +1,763 @@
+// Differentiable mesh render for FIND on gfx950: projection, tile rasteriser fused with the soft-silhouette and
+// Phong/softmax-blend shaders, and the backward passes.
+//
+// Replaces FootRenderer.forward / rasterize (reference src/model/renderer.py:208-245, 247-383): PyTorch3D's
+// FoVPerspectiveCameras transform, rasterize_meshes (K=100 soft-silhouette pass + K=1 RGB pass), SoftSilhouetteShader,
+// SoftPhongShader + softmax_rgb_blend (math restated in-repo at renderer.py:23-72).
+//
+// Design (HBM/VALU-bound, no MFMA): the K=100 fragment buffers PyTorch3D materialises (2.8 kB/pixel) never exist.
+//   1. project_kernel   : world -> (x_ndc, y_ndc, z_view) per (image, vertex)                       [coalesced stream]
+//   2. face_setup_kernel: per (image, face) cull + 48-B face record + tile-bbox packed in one uint32
+//   3. raster_tile_kernel: one 16x16-pixel tile per workgroup.  The packed bboxes are scanned 256 faces at a time
+//      (4 B/face, L2-resident), hits are ballot-compacted IN FACE ORDER into LDS (deterministic), their records staged in
+//      LDS and broadcast to the 256 pixel threads, which keep the silhouette product and the nearest inside fragment
+//      in registers.  The tail shades the nearest fragment (Phong + blend) and writes mask / image.
+//   4. backward: silhouette gradient is FACE-centric (one thread walks the blurred bbox of its face and accumulates the
+//      six NDC gradients in registers: no per-fragment atomics); projection backward is a deterministic sum over views.
+// Conventions: SURVEY.md Appendix A.2-A.4 (row-vector transforms, NDC +x left / +y up, image = mesh*n_views + view).
+#include "common.h"
+
+namespace find {
+namespace render {
+
+constexpr int TS = 16;          // tile edge in pixels
+constexpr int BATCH = 256;      // candidates shaded per LDS batch
+constexpr float KEPS = 1e-8f;
+constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
+
+struct Ws {
+	float* vproj;     // (n_img, V, 3)
+	float4* frec;     // (n_img, F, 3) float4: [x0 y0 x1 y1][x2 y2 z0 z1][z2 - - -]
+	uint32_t* tb;     // (n_img, F) packed tile bbox
+	float* normals;   // (n_meshes, V, 3) area-weighted vertex normals (world)
+	int32_t* p2f;     // (n_img, H, W) nearest inside face (local id) or -1   [saved for backward]
+	float* bary;      // (n_img, H, W, 3) its perspective-correct barycentrics
+	float* d_vproj;   // (n_img, V, 3) backward accumulator
+	float* d_normals; // (n_meshes, V, 3) backward accumulator
+	float* raw_normals; // (n_meshes, V, 3) un-normalised vertex-normal sums (backward)
+	int32_t* flags;   // [0] straddling faces seen, [1] pixels with more than K silhouette candidates
+	int64_t bytes;
+};
+
+static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t V, int64_t F, void* ws, Ws* o) {
+	Carver c(ws);
+	const int64_t n_img = n_meshes * n_views;
+	const int64_t px = n_img * rp->image_h * rp->image_w;
+	o->flags = c.take<int32_t>(64);
+	o->vproj = c.take<float>(n_img * V * 3);
+	o->frec = c.take<float4>(n_img * F * 3);
+	o->tb = c.take<uint32_t>(n_img * F);
+	o->normals = c.take<float>(n_meshes * V * 3);
+	o->p2f = c.take<int32_t>(px);
+	o->bary = c.take<float>(px * 3);
+	o->d_vproj = c.take<float>(n_img * V * 3);
+	o->d_normals = c.take<float>(n_meshes * V * 3);
+	o->raw_normals = c.take<float>(n_meshes * V * 3);
+	o->bytes = c.off;
+}
+
+// ------------------------------------------------------------------------------------------------ 1. projection
+__global__ void project_kernel(const float* __restrict__ verts, const float* __restrict__ R, const float* __restrict__ T, float s,
+							   int n_views, int V, float* __restrict__ vproj) {
+	const int img = blockIdx.y;
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V) return;
+	const int mesh = img / n_views, view = img - mesh * n_views;
+	const float* Rm = R + view * 9;
+	const float* Tm = T + view * 3;
+	const float* p = verts + ((int64_t)mesh * V + v) * 3;
+	const float x = p[0] * Rm[0] + p[1] * Rm[3] + p[2] * Rm[6] + Tm[0];
+	const float y = p[0] * Rm[1] + p[1] * Rm[4] + p[2] * Rm[7] + Tm[1];
+	const float z = p[0] * Rm[2] + p[1] * Rm[5] + p[2] * Rm[8] + Tm[2];
+	float* o = vproj + ((int64_t)img * V + v) * 3;
+	o[0] = s * x / z;
+	o[1] = s * y / z;
+	o[2] = z;
+}
+
+// d_vproj (dx_ndc, dy_ndc, dz_view) -> d_verts (world), summed over the views of each mesh (deterministic, no atomics)
+__global__ void project_bwd_kernel(const float* __restrict__ verts, const float* __restrict__ R, const float* __restrict__ T, float s,
+								   int n_views, int V, const float* __restrict__ d_vproj, float* __restrict__ d_verts, int accumulate) {
+	const int mesh = blockIdx.y;
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= V) return;
+	const float* p = verts + ((int64_t)mesh * V + v) * 3;
+	float gx = 0.f, gy = 0.f, gz = 0.f;
+	for (int m = 0; m < n_views; ++m) {
+		const float* Rm = R + m * 9;
+		const float* Tm = T + m * 3;
+		const float x = p[0] * Rm[0] + p[1] * Rm[3] + p[2] * Rm[6] + Tm[0];
+		const float y = p[0] * Rm[1] + p[1] * Rm[4] + p[2] * Rm[7] + Tm[1];
+		const float z = p[0] * Rm[2] + p[1] * Rm[5] + p[2] * Rm[8] + Tm[2];
+		const float* g = d_vproj + (((int64_t)mesh * n_views + m) * V + v) * 3;
+		const float iz = 1.0f / z;
+		const float dvx = g[0] * s * iz, dvy = g[1] * s * iz;
+		const float dvz = g[2] - (g[0] * s * x + g[1] * s * y) * iz * iz;
+		gx += dvx * Rm[0] + dvy * Rm[1] + dvz * Rm[2];
+		gy += dvx * Rm[3] + dvy * Rm[4] + dvz * Rm[5];
+		gz += dvx * Rm[6] + dvy * Rm[7] + dvz * Rm[8];
+	}
+	float* o = d_verts + ((int64_t)mesh * V + v) * 3;
+	if (accumulate) { o[0] += gx; o[1] += gy; o[2] += gz; }
+	else { o[0] = gx; o[1] = gy; o[2] = gz; }
+}
+
+// ------------------------------------------------------------------------------------------------ 2. face setup
+__device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
+	return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+}
+
+// pixel index range [lo, hi] whose centres 1-(2i+1)/S may fall in NDC [cmin, cmax] (one pixel of slack; exact test per pixel)
+__device__ __forceinline__ void pix_range(float cmin, float cmax, int S, int* lo, int* hi) {
+	const float a = ((1.0f - cmax) * S - 1.0f) * 0.5f;
+	const float b = ((1.0f - cmin) * S - 1.0f) * 0.5f;
+	*lo = max((int)floorf(a) - 1, 0);
+	*hi = min((int)ceilf(b) + 1, S - 1);
+}
+
+__global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
+								  float4* __restrict__ frec, uint32_t* __restrict__ tb, int32_t* __restrict__ flags) {
+	const int img = blockIdx.y;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= F) return;
+	const int mesh = img / n_views;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
+	uint32_t packed = TB_EMPTY;
+	const int64_t o = (int64_t)img * F + f;
+	if (fp[0] >= 0) {
+		const float* vp = vproj + (int64_t)img * V * 3;
+		const float x0 = vp[3 * fp[0]], y0 = vp[3 * fp[0] + 1], z0 = vp[3 * fp[0] + 2];
+		const float x1 = vp[3 * fp[1]], y1 = vp[3 * fp[1] + 1], z1 = vp[3 * fp[1] + 2];
+		const float x2 = vp[3 * fp[2]], y2 = vp[3 * fp[2] + 1], z2 = vp[3 * fp[2] + 2];
+		frec[o * 3 + 0] = make_float4(x0, y0, x1, y1);
+		frec[o * 3 + 1] = make_float4(x2, y2, z0, z1);
+		frec[o * 3 + 2] = make_float4(z2, 0.f, 0.f, 0.f);
+		const bool all_behind = z0 < z_clip && z1 < z_clip && z2 < z_clip;
+		const bool any_behind = z0 < z_clip || z1 < z_clip || z2 < z_clip;
+		if (any_behind && !all_behind) atomicAdd(&flags[0], 1);  // straddling the clip plane: PyTorch3D would clip it (clip.py)
+		const float zmax = fmaxf(z0, fmaxf(z1, z2));
+		const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+		const bool degenerate = area <= KEPS && area >= -KEPS;
+		if (!all_behind && !(zmax < 0.f) && !degenerate) {
+			const float br = sqrtf(blur_radius);
+			int xlo, xhi, ylo, yhi;
+			pix_range(fminf(x0, fminf(x1, x2)) - br, fmaxf(x0, fmaxf(x1, x2)) + br, W, &xlo, &xhi);
+			pix_range(fminf(y0, fminf(y1, y2)) - br, fmaxf(y0, fmaxf(y1, y2)) + br, H, &ylo, &yhi);
+			if (xlo <= xhi && ylo <= yhi)
+				packed = (uint32_t)(xlo / TS) | ((uint32_t)(xhi / TS) << 8) | ((uint32_t)(ylo / TS) << 16) | ((uint32_t)(yhi / TS) << 24);
+		}
+	}
+	tb[o] = packed;
+}
+
+// ------------------------------------------------------------------------------------------------ shared fragment math
+struct FaceRec {  // staged in LDS, one per candidate
+	float x0, y0, x1, y1, x2, y2, z0, z1, z2;
+	float xmin, xmax, ymin, ymax;  // blurred NDC bbox
+	float inv_area;
+	int f;
+	int pad;
+};
+
+__device__ __forceinline__ void make_rec(const float4* fr, int f, float br, FaceRec* r) {
+	const float4 a = fr[0], b = fr[1], c = fr[2];
+	r->x0 = a.x; r->y0 = a.y; r->x1 = a.z; r->y1 = a.w; r->x2 = b.x; r->y2 = b.y; r->z0 = b.z; r->z1 = b.w; r->z2 = c.x;
+	r->xmin = fminf(a.x, fminf(a.z, b.x)) - br; r->xmax = fmaxf(a.x, fmaxf(a.z, b.x)) + br;
+	r->ymin = fminf(a.y, fminf(a.w, b.y)) - br; r->ymax = fmaxf(a.y, fmaxf(a.w, b.y)) + br;
+	r->inv_area = 1.0f / (edge_fn(b.x, b.y, a.x, a.y, a.z, a.w) + KEPS);
+	r->f = f;
+	r->pad = 0;
+}
+
+// squared distance to segment ab; also returns the clamped parameter (PointLineDistanceForward)
+__device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float* t_out) {
+	const float bax = bx - ax, bay = by - ay;
+	const float l2 = bax * bax + bay * bay;
+	float t = 1.0f;
+	if (l2 > KEPS) t = fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) / l2, 0.f), 1.f);
+	const float qx = ax + t * bax - px, qy = ay + t * bay - py;
+	*t_out = t;
+	return qx * qx + qy * qy;
+}
+
+struct Frag {
+	float w0, w1, w2;     // perspective-correct barycentrics, unclipped
+	float pz_clip;        // depth from clipped barycentrics (silhouette pass)
+	float pz;             // depth from unclipped barycentrics (RGB pass)
+	float dist;           // unsigned squared distance to the triangle outline
+	bool inside;
+	int edge;             // nearest edge: 0 = v0v1, 1 = v0v2, 2 = v1v2
+	float t;              // its clamped projection parameter
+};
+
+// geometry_utils: barycentric, perspective correction, clip, depth, point-triangle distance.  Returns false when the
+// pixel is outside the blurred bbox.
+__device__ __forceinline__ bool eval_frag(const FaceRec& r, float px, float py, Frag* o) {
+	if (px > r.xmax || px < r.xmin || py > r.ymax || py < r.ymin) return false;
+	float w0 = edge_fn(px, py, r.x1, r.y1, r.x2, r.y2) * r.inv_area;
+	float w1 = edge_fn(px, py, r.x2, r.y2, r.x0, r.y0) * r.inv_area;
+	float w2 = edge_fn(px, py, r.x0, r.y0, r.x1, r.y1) * r.inv_area;
+	const float t0 = w0 * r.z1 * r.z2, t1 = r.z0 * w1 * r.z2, t2 = r.z0 * r.z1 * w2;
+	const float den = fmaxf(t0 + t1 + t2, KEPS);
+	w0 = t0 / den; w1 = t1 / den; w2 = t2 / den;
+	o->w0 = w0; o->w1 = w1; o->w2 = w2;
+	o->inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
+	float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
+	const float sum = fmaxf(c0 + c1 + c2, 1e-5f);
+	c0 /= sum; c1 /= sum; c2 /= sum;
+	o->pz_clip = c0 * r.z0 + c1 * r.z1 + c2 * r.z2;
+	o->pz = w0 * r.z0 + w1 * r.z1 + w2 * r.z2;
+	float ta, tb, tc;
+	const float e01 = seg_dist(px, py, r.x0, r.y0, r.x1, r.y1, &ta);
+	const float e02 = seg_dist(px, py, r.x0, r.y0, r.x2, r.y2, &tb);
+	const float e12 = seg_dist(px, py, r.x1, r.y1, r.x2, r.y2, &tc);
+	if (e01 <= e02 && e01 <= e12) { o->dist = e01; o->edge = 0; o->t = ta; }
+	else if (e02 <= e01 && e02 <= e12) { o->dist = e02; o->edge = 1; o->t = tb; }
+	else { o->dist = e12; o->edge = 2; o->t = tc; }
+	return true;
+}
+
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+	const float l = fmaxf(sqrtf(x * x + y * y + z * z), 1e-6f);
+	x /= l; y /= l; z /= l;
+}
+
+// ------------------------------------------------------------------------------------------------ vertex normals
+__global__ void normals_scatter_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+									   int V, int F, float* __restrict__ normals) {
+	const int mesh = blockIdx.y;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= F) return;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
+	if (fp[0] < 0) return;
+	const float* vp = verts + (int64_t)mesh * V * 3;
+	const float* a = vp + 3 * fp[0]; const float* b = vp + 3 * fp[1]; const float* c = vp + 3 * fp[2];
+	const float ux = c[0] - b[0], uy = c[1] - b[1], uz = c[2] - b[2];
+	const float wx = a[0] - b[0], wy = a[1] - b[1], wz = a[2] - b[2];
+	const float nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx;
+	float* np_ = normals + (int64_t)mesh * V * 3;
+	for (int k = 0; k < 3; ++k) {
+		atomicAdd(np_ + 3 * fp[k] + 0, nx); atomicAdd(np_ + 3 * fp[k] + 1, ny); atomicAdd(np_ + 3 * fp[k] + 2, nz);
+	}
+}
+
+__global__ void normals_normalize_kernel(float* __restrict__ normals, int64_t n) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float x = normals[i * 3], y = normals[i * 3 + 1], z = normals[i * 3 + 2];
+	normalize3(x, y, z);
+	normals[i * 3] = x; normals[i * 3 + 1] = y; normals[i * 3 + 2] = z;
+}
+
+// ------------------------------------------------------------------------------------------------ 3. tile rasteriser
+struct TileArgs {
+	find_render_params rp;
+	const float4* frec;
+	const uint32_t* tb;
+	const int32_t* faces;
+	int64_t faces_mesh_stride;
+	const float* verts;      // world (n_meshes,V,3)
+	const float* normals;    // world
+	const float* colors;     // (n_meshes,V,3) or null
+	const float* cam;        // (n_views,3) camera centres
+	int n_views, V, F, tiles_x;
+	float* mask;             // (n_img,H,W) or null
+	float* image;            // (n_img,H,W,3) or null
+	int32_t* p2f_out;        // user-visible packed ids or null
+	float* zbuf_out;         // or null
+	int32_t* p2f_ws;         // local ids for backward
+	float* bary_ws;
+	int32_t* flags;
+};
+
+__global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
+	__shared__ int list[2 * BATCH];
+	__shared__ FaceRec rec[BATCH];
+	__shared__ int wcount[4];
+	__shared__ int n_list;
+
+	const int H = a.rp.image_h, W = a.rp.image_w;
+	const int img = blockIdx.y;
+	const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int xi = tile_x * TS + (tid & (TS - 1)), yi = tile_y * TS + (tid >> 4);
+	const bool in_img = xi < W && yi < H;
+	const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
+	const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+	const float blur = a.rp.sil_blur_radius, br = sqrtf(blur);
+	const float inv_sigma = 1.0f / a.rp.sil_sigma;
+	const bool want_sil = a.mask != nullptr;
+	const bool want_rgb = a.image != nullptr || a.p2f_out != nullptr || a.zbuf_out != nullptr;
+
+	float alpha = 1.0f;
+	int cnt = 0;
+	float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+	int bf = -1;
+
+	if (tid == 0) n_list = 0;
+	__syncthreads();
+
+	const uint32_t* tbp = a.tb + (int64_t)img * a.F;
+	const float4* frp = a.frec + (int64_t)img * a.F * 3;
+
+	auto shade_batch = [&](int nb) {
+		// stage the records of list[0 .. nb) in LDS
+		if (tid < nb) make_rec(frp + (int64_t)list[tid] * 3, list[tid], br, &rec[tid]);
+		__syncthreads();
+		if (in_img) {
+			for (int k = 0; k < nb; ++k) {
+				Frag fr;
+				if (!eval_frag(rec[k], px, py, &fr)) continue;
+				if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
+					const float sd = fr.inside ? -fr.dist : fr.dist;
+					const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
+					alpha *= (1.0f - prob);
+					++cnt;
+				}
+				if (want_rgb && fr.inside && fr.pz >= 0.f && fr.pz < bz) {
+					bz = fr.pz; bf = rec[k].f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
+				}
+			}
+		}
+		__syncthreads();
+	};
+
+	for (int base = 0; base < a.F; base += 256) {
+		const int f = base + tid;
+		bool hit = false;
+		if (f < a.F) {
+			const uint32_t t = tbp[f];
+			const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
+			hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;
+		}
+		// ordered compaction: ballot per wave, exclusive offsets across waves through LDS
+		const unsigned long long m = __ballot(hit);
+		if (lane == 0) wcount[wave] = __popcll(m);
+		__syncthreads();
+		int off = n_list;
+		for (int w = 0; w < wave; ++w) off += wcount[w];
+		if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = f;
+		__syncthreads();
+		if (tid == 0) n_list += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+		__syncthreads();
+		if (n_list >= BATCH) {  // uniform
+			shade_batch(BATCH);
+			const int rest = n_list - BATCH;
+			int moved = 0;
+			if (tid < rest) moved = list[BATCH + tid];
+			__syncthreads();
+			if (tid < rest) list[tid] = moved;
+			if (tid == 0) n_list = rest;
+			__syncthreads();
+		}
+	}
+	if (n_list > 0) shade_batch(n_list);
+
+	if (!in_img) return;
+	const int64_t pix = ((int64_t)img * H + yi) * W + xi;
+	if (want_sil) {
+		a.mask[pix] = 1.0f - alpha;
+		if (cnt > a.rp.sil_faces_per_pixel) atomicAdd(&a.flags[1], 1);
+	}
+	if (!want_rgb) return;
+	if (a.p2f_ws) {
+		a.p2f_ws[pix] = bf;
+		a.bary_ws[pix * 3 + 0] = bw0; a.bary_ws[pix * 3 + 1] = bw1; a.bary_ws[pix * 3 + 2] = bw2;
+	}
+	if (a.p2f_out) a.p2f_out[pix] = bf < 0 ? -1 : img * a.F + bf;
+	if (a.zbuf_out) a.zbuf_out[pix] = bf < 0 ? -1.0f : bz;
+	if (!a.image) return;
+	float* o = a.image + pix * 3;
+	if (bf < 0) { o[0] = a.rp.background[0]; o[1] = a.rp.background[1]; o[2] = a.rp.background[2]; return; }
+	const int mesh = img / a.n_views, view = img - mesh * a.n_views;
+	const int32_t* fp = a.faces + (int64_t)mesh * a.faces_mesh_stride + (int64_t)bf * 3;
+	const float bw[3] = {bw0, bw1, bw2};
+	float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
+	for (int k = 0; k < 3; ++k) {
+		const int64_t vo = ((int64_t)mesh * a.V + fp[k]) * 3;
+		for (int c = 0; c < 3; ++c) {
+			pos[c] += bw[k] * a.verts[vo + c];
+			nrm[c] += bw[k] * a.normals[vo + c];
+			tex[c] += bw[k] * a.colors[vo + c];
+		}
+	}
+	float nx = nrm[0], ny = nrm[1], nz = nrm[2];
+	normalize3(nx, ny, nz);
+	float lx = a.rp.light_pos[0] - pos[0], ly = a.rp.light_pos[1] - pos[1], lz = a.rp.light_pos[2] - pos[2];
+	normalize3(lx, ly, lz);
+	const float cosang = nx * lx + ny * ly + nz * lz;
+	const float diff = a.rp.diffuse * fmaxf(cosang, 0.f);
+	float vx = a.cam[view * 3] - pos[0], vy = a.cam[view * 3 + 1] - pos[1], vz = a.cam[view * 3 + 2] - pos[2];
+	normalize3(vx, vy, vz);
+	const float rx = -lx + 2.f * cosang * nx, ry = -ly + 2.f * cosang * ny, rz = -lz + 2.f * cosang * nz;
+	const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+	const float spec = a.rp.specular * powf(al, a.rp.shininess);
+	const float eps = 1e-10f;
+	const float prob = 1.0f / (1.0f + __expf(bd / a.rp.rgb_sigma));
+	const float z_inv = (a.rp.zfar - bz) / (a.rp.zfar - a.rp.znear);
+	const float z_inv_max = fmaxf(z_inv, eps);
+	const float wnum = prob * __expf((z_inv - z_inv_max) / a.rp.rgb_gamma);
+	const float delta = fmaxf(__expf((eps - z_inv_max) / a.rp.rgb_gamma), eps);
+	const float den = wnum + delta;
+	for (int c = 0; c < 3; ++c) {
+		const float col = (a.rp.ambient + diff) * tex[c] + spec;
+		o[c] = (wnum * col + delta * a.rp.background[c]) / den;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ 4. silhouette backward
+// mask = 1 - prod_k (1 - p_k),  p_k = sigmoid(-d_k / sigma)   =>   d mask / d d_k = -alpha * p_k / sigma.
+// One thread per (image, face): walks the blurred bbox, accumulates the gradients of its three NDC vertices in registers
+// (PointTriangleDistanceBackward: nearest edge only, projection parameter treated as constant), six atomics at the end.
+__global__ void sil_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
+							   const int32_t* __restrict__ faces, int64_t faces_mesh_stride, int n_views, int V, int F,
+							   const float* __restrict__ mask, const float* __restrict__ d_mask, float* __restrict__ d_vproj) {
+	const int img = blockIdx.y;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= F) return;
+	const int64_t o = (int64_t)img * F + f;
+	if (tb[o] == TB_EMPTY) return;
+	const int H = rp.image_h, W = rp.image_w;
+	const float blur = rp.sil_blur_radius, br = sqrtf(blur);
+	FaceRec r;
+	make_rec(frec + o * 3, f, br, &r);
+	int xlo, xhi, ylo, yhi;
+	pix_range(r.xmin, r.xmax, W, &xlo, &xhi);
+	pix_range(r.ymin, r.ymax, H, &ylo, &yhi);
+	float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
+	const float inv_sigma = 1.0f / rp.sil_sigma;
+	for (int yi = ylo; yi <= yhi; ++yi) {
+		const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+		for (int xi = xlo; xi <= xhi; ++xi) {
+			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
+			const float g = d_mask[pix];
+			if (g == 0.f) continue;
+			const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
+			Frag fr;
+			if (!eval_frag(r, px, py, &fr)) continue;
+			if (!(fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur))) continue;
+			const float sd = fr.inside ? -fr.dist : fr.dist;
+			const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
+			const float alpha = 1.0f - mask[pix];
+			// gradient w.r.t. the UNSIGNED distance: sign * dmask/dd
+			const float gd = (fr.inside ? -1.0f : 1.0f) * (-g * alpha * prob * inv_sigma);
+			// nearest edge (a,b), q = a + t (b - a):  d = |q - p|^2,  dd/da = 2 (1-t) (q - p),  dd/db = 2 t (q - p)
+			float ax, ay, bx, by;
+			if (fr.edge == 0) { ax = r.x0; ay = r.y0; bx = r.x1; by = r.y1; }
+			else if (fr.edge == 1) { ax = r.x0; ay = r.y0; bx = r.x2; by = r.y2; }
+			else { ax = r.x1; ay = r.y1; bx = r.x2; by = r.y2; }
+			const float qx = ax + fr.t * (bx - ax) - px, qy = ay + fr.t * (by - ay) - py;
+			const float ga = gd * 2.0f * (1.0f - fr.t), gb = gd * 2.0f * fr.t;
+			if (fr.edge == 0) { g0x += ga * qx; g0y += ga * qy; g1x += gb * qx; g1y += gb * qy; }
+			else if (fr.edge == 1) { g0x += ga * qx; g0y += ga * qy; g2x += gb * qx; g2y += gb * qy; }
+			else { g1x += ga * qx; g1y += ga * qy; g2x += gb * qx; g2y += gb * qy; }
+		}
+	}
+	const int mesh = img / n_views;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
+	float* dv = d_vproj + (int64_t)img * V * 3;
+	if (g0x != 0.f || g0y != 0.f) { atomicAdd(dv + 3 * fp[0], g0x); atomicAdd(dv + 3 * fp[0] + 1, g0y); }
+	if (g1x != 0.f || g1y != 0.f) { atomicAdd(dv + 3 * fp[1], g1x); atomicAdd(dv + 3 * fp[1] + 1, g1y); }
+	if (g2x != 0.f || g2y != 0.f) { atomicAdd(dv + 3 * fp[2], g2x); atomicAdd(dv + 3 * fp[2] + 1, g2y); }
+}
+
+// ------------------------------------------------------------------------------------------------ RGB backward
+// Pixel-centric (K = 1): image = (amb + diff) * tex + spec at the nearest inside fragment (the blend weight cancels to
+// within 1e-10).  Gradients flow to vertex colours (tex), world vertices (pos), vertex normals (nrm) and,
+// through the perspective-correct barycentrics, to the NDC vertices (x, y, z_view).
+__global__ __launch_bounds__(256) void rgb_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec,
+													   const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+													   const float* __restrict__ verts, const float* __restrict__ normals,
+													   const float* __restrict__ colors, const float* __restrict__ cam, int n_views,
+													   int V, int F, const int32_t* __restrict__ p2f, const float* __restrict__ bary,
+													   const float* __restrict__ d_image, float* __restrict__ d_vproj,
+													   float* __restrict__ d_verts, float* __restrict__ d_normals,
+													   float* __restrict__ d_colors) {
+	const int H = rp.image_h, W = rp.image_w;
+	const int img = blockIdx.y;
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= H * W) return;
+	const int64_t pix = (int64_t)img * H * W + p;
+	const int bf = p2f[pix];
+	if (bf < 0) return;
+	const float g[3] = {d_image[pix * 3], d_image[pix * 3 + 1], d_image[pix * 3 + 2]};
+	if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) return;
+	const int mesh = img / n_views, view = img - mesh * n_views;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)bf * 3;
+	const float bw[3] = {bary[pix * 3], bary[pix * 3 + 1], bary[pix * 3 + 2]};
+	float P[3][3], N[3][3], C[3][3];
+	float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
+	for (int k = 0; k < 3; ++k) {
+		const int64_t vo = ((int64_t)mesh * V + fp[k]) * 3;
+		for (int c = 0; c < 3; ++c) {
+			P[k][c] = verts[vo + c]; N[k][c] = normals[vo + c]; C[k][c] = colors[vo + c];
+			pos[c] += bw[k] * P[k][c]; nrm[c] += bw[k] * N[k][c]; tex[c] += bw[k] * C[k][c];
+		}
+	}
+	// ---- forward recompute
+	const float nl = fmaxf(sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), 1e-6f);
+	const float n[3] = {nrm[0] / nl, nrm[1] / nl, nrm[2] / nl};
+	float Lv[3] = {rp.light_pos[0] - pos[0], rp.light_pos[1] - pos[1], rp.light_pos[2] - pos[2]};
+	const float ll = fmaxf(sqrtf(Lv[0] * Lv[0] + Lv[1] * Lv[1] + Lv[2] * Lv[2]), 1e-6f);
+	const float l[3] = {Lv[0] / ll, Lv[1] / ll, Lv[2] / ll};
+	const float cosang = n[0] * l[0] + n[1] * l[1] + n[2] * l[2];
+	float Vv[3] = {cam[view * 3] - pos[0], cam[view * 3 + 1] - pos[1], cam[view * 3 + 2] - pos[2]};
+	const float vl = fmaxf(sqrtf(Vv[0] * Vv[0] + Vv[1] * Vv[1] + Vv[2] * Vv[2]), 1e-6f);
+	const float vd[3] = {Vv[0] / vl, Vv[1] / vl, Vv[2] / vl};
+	const float r[3] = {-l[0] + 2.f * cosang * n[0], -l[1] + 2.f * cosang * n[1], -l[2] + 2.f * cosang * n[2]};
+	const float vr = vd[0] * r[0] + vd[1] * r[1] + vd[2] * r[2];
+	const bool lit = cosang > 0.f;
+	const float al = (lit && vr > 0.f) ? vr : 0.f;
+	const float shade = rp.ambient + rp.diffuse * fmaxf(cosang, 0.f);
+	// ---- backward: col_c = shade * tex_c + spec
+	float d_tex[3], d_shade = 0.f, d_spec = 0.f;
+	for (int c = 0; c < 3; ++c) { d_tex[c] = g[c] * shade; d_shade += g[c] * tex[c]; d_spec += g[c]; }
+	float d_cos = lit ? d_shade * rp.diffuse : 0.f;
+	const float d_al = (al > 0.f) ? d_spec * rp.specular * rp.shininess * powf(al, rp.shininess - 1.0f) : 0.f;
+	// al = vd . r
+	float d_vd[3], d_r[3];
+	for (int c = 0; c < 3; ++c) { d_vd[c] = d_al * r[c]; d_r[c] = d_al * vd[c]; }
+	// r = -l + 2 cos n
+	float d_l[3], d_n[3];
+	float dot_rn = 0.f;
+	for (int c = 0; c < 3; ++c) { d_l[c] = -d_r[c]; d_n[c] = 2.f * cosang * d_r[c]; dot_rn += d_r[c] * n[c]; }
+	d_cos += 2.f * dot_rn;
+	// cos = n . l
+	for (int c = 0; c < 3; ++c) { d_n[c] += d_cos * l[c]; d_l[c] += d_cos * n[c]; }
+	// normalisations  x/|x|:  d_x = (d_u - u (u . d_u)) / |x|
+	auto unnorm = [](const float* u, const float* du, float len, float* dx) {
+		const float dot = u[0] * du[0] + u[1] * du[1] + u[2] * du[2];
+		for (int c = 0; c < 3; ++c) dx[c] = (du[c] - u[c] * dot) / len;
+	};
+	float d_nrm[3], d_Lv[3], d_Vv[3];
+	unnorm(n, d_n, nl, d_nrm);
+	unnorm(l, d_l, ll, d_Lv);
+	unnorm(vd, d_vd, vl, d_Vv);
+	float d_pos[3];
+	for (int c = 0; c < 3; ++c) d_pos[c] = -d_Lv[c] - d_Vv[c];
+	// ---- interpolation: x = sum_k bw_k X_k
+	float d_bw[3] = {0, 0, 0};
+	for (int k = 0; k < 3; ++k) {
+		const int64_t vo = ((int64_t)mesh * V + fp[k]) * 3;
+		for (int c = 0; c < 3; ++c) {
+			d_bw[k] += d_pos[c] * P[k][c] + d_nrm[c] * N[k][c] + d_tex[c] * C[k][c];
+			atomicAdd(d_verts + vo + c, bw[k] * d_pos[c]);
+			atomicAdd(d_normals + vo + c, bw[k] * d_nrm[c]);
+			if (d_colors) atomicAdd(d_colors + vo + c, bw[k] * d_tex[c]);
+		}
+	}
+	// ---- barycentrics -> NDC vertices.  w'_i = t_i / sum t,  t_0 = w0 z1 z2, t_1 = z0 w1 z2, t_2 = z0 z1 w2,
+	// w_i = edge_i(p) / area  (BarycentricPerspectiveCorrectionBackward + BarycentricCoordsBackward)
+	const float4 fa = frec[((int64_t)img * F + bf) * 3], fb = frec[((int64_t)img * F + bf) * 3 + 1], fc = frec[((int64_t)img * F + bf) * 3 + 2];
+	const float x0 = fa.x, y0 = fa.y, x1 = fa.z, y1 = fa.w, x2 = fb.x, y2 = fb.y, z0 = fb.z, z1 = fb.w, z2 = fc.x;
+	const int xi = p % W, yi = p / W;
+	const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W, py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+	const float area = edge_fn(x2, y2, x0, y0, x1, y1) + KEPS;
+	const float e0 = edge_fn(px, py, x1, y1, x2, y2), e1 = edge_fn(px, py, x2, y2, x0, y0), e2 = edge_fn(px, py, x0, y0, x1, y1);
+	const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+	const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+	const float den = t0 + t1 + t2;
+	if (!(den > KEPS)) return;
+	const float sdb = (d_bw[0] * t0 + d_bw[1] * t1 + d_bw[2] * t2) / den;
+	const float d_t0 = (d_bw[0] - sdb) / den, d_t1 = (d_bw[1] - sdb) / den, d_t2 = (d_bw[2] - sdb) / den;
+	const float d_w0 = d_t0 * z1 * z2, d_w1 = d_t1 * z0 * z2, d_w2 = d_t2 * z0 * z1;
+	const float d_z0 = d_t1 * w1 * z2 + d_t2 * z1 * w2;
+	const float d_z1 = d_t0 * w0 * z2 + d_t2 * z0 * w2;
+	const float d_z2 = d_t0 * w0 * z1 + d_t1 * z0 * w1;
+	// w_i = e_i / area
+	const float d_e0 = d_w0 / area, d_e1 = d_w1 / area, d_e2 = d_w2 / area;
+	const float d_area = -(d_w0 * w0 + d_w1 * w1 + d_w2 * w2) / area;
+	// edge(p,a,b) = (px-ax)(by-ay) - (py-ay)(bx-ax):  d/da = (-(by-ay)+(py-ay), (px-ax)-(bx-ax)) ... written out per vertex
+	float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f;
+	auto edge_bwd = [](float qx, float qy, float ax, float ay, float bx, float by, float ge, float& gax, float& gay, float& gbx, float& gby) {
+		gax += ge * (-(by - ay) + (qy - ay));
+		gay += ge * (-(qx - ax) + (bx - ax));
+		gbx += ge * (-(qy - ay));
+		gby += ge * (qx - ax);
+	};
+	edge_bwd(px, py, x1, y1, x2, y2, d_e0, gx1, gy1, gx2, gy2);
+	edge_bwd(px, py, x2, y2, x0, y0, d_e1, gx2, gy2, gx0, gy0);
+	edge_bwd(px, py, x0, y0, x1, y1, d_e2, gx0, gy0, gx1, gy1);
+	// area = edge(v2; v0, v1): the query point is v2 itself
+	{
+		const float ge = d_area;
+		gx2 += ge * (y1 - y0); gy2 += ge * (-(x1 - x0));
+		gx0 += ge * (-(y1 - y0) + (y2 - y0)); gy0 += ge * (-(x2 - x0) + (x1 - x0));
+		gx1 += ge * (-(y2 - y0)); gy1 += ge * (x2 - x0);
+	}
+	float* dv = d_vproj + (int64_t)img * V * 3;
+	atomicAdd(dv + 3 * fp[0], gx0); atomicAdd(dv + 3 * fp[0] + 1, gy0); atomicAdd(dv + 3 * fp[0] + 2, d_z0);
+	atomicAdd(dv + 3 * fp[1], gx1); atomicAdd(dv + 3 * fp[1] + 1, gy1); atomicAdd(dv + 3 * fp[1] + 2, d_z1);
+	atomicAdd(dv + 3 * fp[2], gx2); atomicAdd(dv + 3 * fp[2] + 1, gy2); atomicAdd(dv + 3 * fp[2] + 2, d_z2);
+}
+
+// vertex-normal backward: n_v = normalize(sum_f fn_f), fn_f = (v2 - v1) x (v0 - v1).  d_normals holds dL/dn_v.
+__global__ void normals_bwd_prepare_kernel(const float* __restrict__ raw, const float* __restrict__ unit, float* __restrict__ d_normals, int64_t n) {
+	// in place: dL/d(raw sum) from dL/d(unit normal)
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float rx = raw[i * 3], ry = raw[i * 3 + 1], rz = raw[i * 3 + 2];
+	const float len = sqrtf(rx * rx + ry * ry + rz * rz);
+	const float ux = unit[i * 3], uy = unit[i * 3 + 1], uz = unit[i * 3 + 2];
+	float dx = d_normals[i * 3], dy = d_normals[i * 3 + 1], dz = d_normals[i * 3 + 2];
+	if (len > 1e-6f) {
+		const float dot = ux * dx + uy * dy + uz * dz;
+		dx = (dx - ux * dot) / len; dy = (dy - uy * dot) / len; dz = (dz - uz * dot) / len;
+	} else {
+		dx /= 1e-6f; dy /= 1e-6f; dz /= 1e-6f;
+	}
+	d_normals[i * 3] = dx; d_normals[i * 3 + 1] = dy; d_normals[i * 3 + 2] = dz;
+}
+
+__global__ void normals_bwd_faces_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+										 int V, int F, const float* __restrict__ d_raw, float* __restrict__ d_verts) {
+	const int mesh = blockIdx.y;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= F) return;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
+	if (fp[0] < 0) return;
+	const float* vp = verts + (int64_t)mesh * V * 3;
+	const float* dr = d_raw + (int64_t)mesh * V * 3;
+	// every corner received the same face normal: G = sum of the three vertices' raw-normal gradients
+	float G[3];
+	for (int c = 0; c < 3; ++c) G[c] = dr[3 * fp[0] + c] + dr[3 * fp[1] + c] + dr[3 * fp[2] + c];
+	const float* a = vp + 3 * fp[0]; const float* b = vp + 3 * fp[1]; const float* c3 = vp + 3 * fp[2];
+	const float u[3] = {c3[0] - b[0], c3[1] - b[1], c3[2] - b[2]};   // v2 - v1
+	const float w[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};      // v0 - v1
+	// fn = u x w:  d_u = w x G,  d_w = G x u
+	const float du[3] = {w[1] * G[2] - w[2] * G[1], w[2] * G[0] - w[0] * G[2], w[0] * G[1] - w[1] * G[0]};
+	const float dw[3] = {G[1] * u[2] - G[2] * u[1], G[2] * u[0] - G[0] * u[2], G[0] * u[1] - G[1] * u[0]};
+	float* dv = d_verts + (int64_t)mesh * V * 3;
+	for (int c = 0; c < 3; ++c) {
+		atomicAdd(dv + 3 * fp[2] + c, du[c]);
+		atomicAdd(dv + 3 * fp[0] + c, dw[c]);
+		atomicAdd(dv + 3 * fp[1] + c, -du[c] - dw[c]);
+	}
+}
+
+__global__ void cam_center_kernel(const float* __restrict__ R, const float* __restrict__ T, int n_views, float* __restrict__ cam) {
+	const int m = threadIdx.x;
+	if (m >= n_views) return;
+	const float* Rm = R + m * 9;
+	const float* Tm = T + m * 3;
+	for (int i = 0; i < 3; ++i) cam[m * 3 + i] = -(Tm[0] * Rm[i * 3 + 0] + Tm[1] * Rm[i * 3 + 1] + Tm[2] * Rm[i * 3 + 2]);
+}
+
+}  // namespace render
+}  // namespace find
+
+using namespace find;
+using namespace find::render;
+
+static int check_params(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t V, int64_t F) {
+	FIND_REQUIRE(rp != nullptr, "find_render: params is NULL");
+	FIND_REQUIRE(rp->image_h >= 1 && rp->image_w >= 1 && rp->image_h <= 4096 && rp->image_w <= 4096, "find_render: image size out of range");
+	FIND_REQUIRE(n_meshes >= 1 && n_views >= 1 && n_views <= 256 && n_meshes * n_views < 65536, "find_render: bad batch (%lld meshes x %lld views)", (long long)n_meshes, (long long)n_views);
+	FIND_REQUIRE(V >= 1 && F >= 1 && V < (1ll << 28) && F < (1ll << 28), "find_render: bad mesh size");
+	FIND_REQUIRE(rp->sil_sigma > 0.f && rp->rgb_sigma > 0.f && rp->rgb_gamma > 0.f && rp->zfar > rp->znear, "find_render: bad blend parameters");
+	return FIND_OK;
+}
+
+extern "C" int64_t find_render_ws_bytes(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t n_verts, int64_t n_faces) {
+	if (check_params(rp, n_meshes, n_views, n_verts, n_faces) != FIND_OK) return -1;
+	Ws w;
+	carve(rp, n_meshes, n_views, n_verts, n_faces, nullptr, &w);
+	return w.bytes + 256 * 3 * (int64_t)sizeof(float);  // + camera centres
+}
+
+extern "C" int find_render_fwd(const find_render_params* rp, const float* verts, const int32_t* faces, int64_t faces_batch,
+							   const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
+							   int64_t n_verts, int64_t n_faces, float* mask, float* image, int32_t* pix_to_face, float* zbuf,
+							   void* ws, int64_t ws_bytes, void* stream) {
+	int rc = check_params(rp, n_meshes, n_views, n_verts, n_faces);
+	if (rc != FIND_OK) return rc;
+	FIND_REQUIRE(verts && faces && R && T && ws, "find_render_fwd: NULL argument");
+	FIND_REQUIRE(faces_batch == 1 || faces_batch == n_meshes, "find_render_fwd: faces_batch must be 1 or n_meshes");
+	FIND_REQUIRE(mask || image || pix_to_face || zbuf, "find_render_fwd: no output requested");
+	FIND_REQUIRE(!image || vert_colors, "find_render_fwd: image requested without vertex colours");
+	Ws w;
+	carve(rp, n_meshes, n_views, n_verts, n_faces, ws, &w);
+	if (ws_bytes < find_render_ws_bytes(rp, n_meshes, n_views, n_verts, n_faces)) { set_error("find_render_fwd: workspace too small"); return FIND_EWORKSPACE; }
+	float* cam = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + w.bytes);
+	hipStream_t s = (hipStream_t)stream;
+	const int64_t n_img = n_meshes * n_views;
+	const int V = (int)n_verts, F = (int)n_faces, H = rp->image_h, W = rp->image_w;
+	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
+	const float sc = 1.0f / tanf(rp->fov_deg * 3.14159265358979323846f / 180.0f * 0.5f);
+	(void)hipMemsetAsync(w.flags, 0, 64 * sizeof(int32_t), s);
+	hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv(V, 256), (unsigned)n_img), dim3(256), 0, s, verts, R, T, sc, (int)n_views, V, w.vproj);
+	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one scan serves both
+	const float blur = mask ? rp->sil_blur_radius : 0.0f;
+	hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, w.vproj, faces, fstride, (int)n_views, V, F, H, W,
+					   blur, rp->z_clip, w.frec, w.tb, w.flags);
+	if (image) {
+		(void)hipMemsetAsync(w.normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
+		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.normals);
+		// keep the raw sums for the backward in d_normals' slot until then? no: recomputed there. Normalise in place.
+		hipLaunchKernelGGL(normals_normalize_kernel, dim3((unsigned)cdiv(n_meshes * n_verts, 256)), dim3(256), 0, s, w.normals, n_meshes * n_verts);
+		hipLaunchKernelGGL(cam_center_kernel, dim3(1), dim3(256), 0, s, R, T, (int)n_views, cam);
+	}
+	TileArgs a;
+	memset(&a, 0, sizeof(a));
+	a.rp = *rp;
+	a.frec = w.frec; a.tb = w.tb; a.faces = faces; a.faces_mesh_stride = fstride;
+	a.verts = verts; a.normals = w.normals; a.colors = vert_colors; a.cam = cam;
+	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = (int)cdiv(W, TS);
+	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
+	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
+	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)(a.tiles_x * cdiv(H, TS)), (unsigned)n_img), dim3(256), 0, s, a);
+	FIND_LAUNCH_CHECK("find_render_fwd");
+	return FIND_OK;
+}
+
+extern "C" int find_render_bwd(const find_render_params* rp, const float* verts, const int32_t* faces, int64_t faces_batch,
+							   const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
+							   int64_t n_verts, int64_t n_faces, const float* mask, const float* d_mask, const float* d_image,
+							   float* d_verts, float* d_vert_colors, void* ws, int64_t ws_bytes, void* stream) {
+	int rc = check_params(rp, n_meshes, n_views, n_verts, n_faces);
+	if (rc != FIND_OK) return rc;
+	FIND_REQUIRE(verts && faces && R && T && ws && d_verts, "find_render_bwd: NULL argument");
+	FIND_REQUIRE(faces_batch == 1 || faces_batch == n_meshes, "find_render_bwd: faces_batch must be 1 or n_meshes");
+	FIND_REQUIRE(!d_image || vert_colors, "find_render_bwd: d_image given without vertex colours");
+	FIND_REQUIRE(!d_mask || mask, "find_render_bwd: d_mask given without the forward mask");
+	Ws w;
+	carve(rp, n_meshes, n_views, n_verts, n_faces, ws, &w);
+	if (ws_bytes < find_render_ws_bytes(rp, n_meshes, n_views, n_verts, n_faces)) { set_error("find_render_bwd: workspace too small"); return FIND_EWORKSPACE; }
+	const float* cam = reinterpret_cast<const float*>(reinterpret_cast<char*>(ws) + w.bytes);
+	hipStream_t s = (hipStream_t)stream;
+	const int64_t n_img = n_meshes * n_views;
+	const int V = (int)n_verts, F = (int)n_faces, H = rp->image_h, W = rp->image_w;
+	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
+	const float sc = 1.0f / tanf(rp->fov_deg * 3.14159265358979323846f / 180.0f * 0.5f);
+	(void)hipMemsetAsync(w.d_vproj, 0, n_img * n_verts * 3 * sizeof(float), s);
+	(void)hipMemsetAsync(d_verts, 0, n_meshes * n_verts * 3 * sizeof(float), s);
+	if (d_vert_colors) (void)hipMemsetAsync(d_vert_colors, 0, n_meshes * n_verts * 3 * sizeof(float), s);
+	if (d_mask) {
+		hipLaunchKernelGGL(sil_bwd_kernel, dim3((unsigned)cdiv(F, 128), (unsigned)n_img), dim3(128), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
+						   mask, d_mask, w.d_vproj);
+	}
+	if (d_image) {
+		(void)hipMemsetAsync(w.d_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
+		hipLaunchKernelGGL(rgb_bwd_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, faces, fstride, verts,
+						   w.normals, vert_colors, cam, (int)n_views, V, F, w.p2f, w.bary, d_image, w.d_vproj, d_verts, w.d_normals, d_vert_colors);
+		// unit normals -> raw area-weighted sums -> face cross products -> vertices
+		(void)hipMemsetAsync(w.raw_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
+		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.raw_normals);
+		hipLaunchKernelGGL(normals_bwd_prepare_kernel, dim3((unsigned)cdiv(n_meshes * n_verts, 256)), dim3(256), 0, s, w.raw_normals, w.normals, w.d_normals, n_meshes * n_verts);
+		hipLaunchKernelGGL(normals_bwd_faces_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.d_normals, d_verts);
+	}
+	hipLaunchKernelGGL(project_bwd_kernel, dim3((unsigned)cdiv(V, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, R, T, sc, (int)n_views, V, w.d_vproj, d_verts, 1);
+	FIND_LAUNCH_CHECK("find_render_bwd");
+	return FIND_OK;
+}
+
+/* Diagnostics of the last forward that used `ws`: flags[0] = faces straddling the z-clip plane (left unclipped),
+ * flags[1] = pixels with more silhouette candidates than faces_per_pixel (all of them were blended).  Device->host copy. */
+extern "C" int find_render_flags(const void* ws, int32_t* out2, void* stream) {
+	FIND_REQUIRE(ws && out2, "find_render_flags: NULL argument");
+	hipError_t e = hipMemcpyAsync(out2, ws, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+	if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+	if (e != hipSuccess) { set_error("find_render_flags: %s", hipGetErrorString(e)); return FIND_ELAUNCH; }
+	return FIND_OK;
+}

@@ -1,0 +1,89 @@
+"""torch.autograd binding of the HIP renderer (find_render_fwd / find_render_bwd).  GPU only, no fallback."""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import RenderParams, check, current_stream, ptr
+from .functional import _c, _faces_i32, _require_gpu, _ws
+
+
+def make_params(image_size=256, faces_per_pixel=100, background=(1., 1., 1.), light_pos=(0., 0., 100.), znear=0.02, zfar=100.0,
+				fov_deg=60.0, sil_sigma=1e-4, z_clip=None):
+	"""FootRenderer's fixed settings (renderer.py:113-128, 274) + PyTorch3D defaults for BlendParams / PointLights / Materials."""
+	p = RenderParams()
+	if isinstance(image_size, (tuple, list)):
+		p.image_h, p.image_w = int(image_size[0]), int(image_size[1])
+	else:
+		p.image_h = p.image_w = int(image_size)
+	p.fov_deg, p.znear, p.zfar = fov_deg, znear, zfar
+	p.sil_sigma = sil_sigma
+	p.sil_blur_radius = float(math.log(1. / 1e-4 - 1.) * sil_sigma)
+	p.sil_faces_per_pixel = faces_per_pixel
+	p.rgb_sigma, p.rgb_gamma = 1e-4, 1e-4
+	p.background[:] = list(background)
+	p.light_pos[:] = list(light_pos)
+	p.ambient, p.diffuse, p.specular, p.shininess = 0.5, 0.3, 0.2, 64.0
+	p.z_clip = znear / 2 if z_clip is None else z_clip
+	return p
+
+
+class _Render(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, verts, colors, faces, R, T, params, want_mask, want_image, want_frags):
+		_require_gpu(verts, colors, R, T)
+		L = _lib.lib()
+		verts, colors, R, T = _c(verts), _c(colors), _c(R), _c(T)
+		faces = _faces_i32(faces)
+		N, V, _ = verts.shape
+		M = R.shape[0]
+		fb = 1 if faces.dim() == 2 else faces.shape[0]
+		F = faces.shape[-2]
+		H, W = params.image_h, params.image_w
+		dev = verts.device
+		nbytes = L.find_render_ws_bytes(ctypes.byref(params), N, M, V, F)
+		if nbytes < 0:
+			check(-1, 'find_render_ws_bytes')
+		ws = _ws(nbytes, dev)
+		mask = torch.empty(N, M, H, W, device=dev) if want_mask else None
+		image = torch.empty(N, M, H, W, 3, device=dev) if want_image else None
+		p2f = torch.empty(N, M, H, W, device=dev, dtype=torch.int32) if want_frags else None
+		zbuf = torch.empty(N, M, H, W, device=dev) if want_frags else None
+		check(L.find_render_fwd(ctypes.byref(params), ptr(verts), ptr(faces), fb, ptr(colors), ptr(R), ptr(T), N, M, V, F, ptr(mask), ptr(image),
+								ptr(p2f), ptr(zbuf), ptr(ws), ws.numel(), current_stream(dev)), 'find_render_fwd')
+		ctx.params, ctx.ws, ctx.dims = params, ws, (N, M, V, F, fb)
+		ctx.save_for_backward(verts, colors, faces, R, T, mask)
+		ctx.mark_non_differentiable(*[t for t in (p2f, zbuf) if t is not None])
+		return mask, image, p2f, zbuf
+
+	@staticmethod
+	def backward(ctx, g_mask, g_image, _gp, _gz):
+		L = _lib.lib()
+		verts, colors, faces, R, T, mask = ctx.saved_tensors
+		N, M, V, F, fb = ctx.dims
+		if g_mask is None and g_image is None:
+			return (None,) * 9
+		g_mask, g_image = _c(g_mask), _c(g_image)
+		d_verts = torch.empty_like(verts)
+		d_colors = torch.empty_like(colors) if (colors is not None and g_image is not None and ctx.needs_input_grad[1]) else None
+		check(L.find_render_bwd(ctypes.byref(ctx.params), ptr(verts), ptr(faces), fb, ptr(colors), ptr(R), ptr(T), N, M, V, F, ptr(mask),
+								ptr(g_mask), ptr(g_image), ptr(d_verts), ptr(d_colors), ptr(ctx.ws), ctx.ws.numel(),
+								current_stream(verts.device)), 'find_render_bwd')
+		return d_verts, d_colors, None, None, None, None, None, None, None
+
+
+def render(verts, colors, faces, R, T, params, want_mask=True, want_image=True, want_frags=False):
+	"""verts (N,V,3), colors (N,V,3)|None, faces (F,3)|(N,F,3), R (M,3,3), T (M,3)  ->  mask (N,M,H,W), image (N,M,H,W,3),
+	pix_to_face (N,M,H,W) int32, zbuf (N,M,H,W)   (entries not requested are None)."""
+	if want_image and colors is None:
+		raise RuntimeError('find_amd.render: an RGB image needs per-vertex colours')
+	return _Render.apply(verts, colors, faces, R, T, params, want_mask, want_image, want_frags)
+
+
+def render_flags(ws):
+	"""(faces straddling the clip plane, pixels with more than K silhouette candidates) of the forward that used ws."""
+	L = _lib.lib()
+	out = (ctypes.c_int32 * 2)()
+	check(L.find_render_flags(ptr(ws), ctypes.cast(out, ctypes.c_void_p), current_stream(ws.device)), 'find_render_flags')
+	return int(out[0]), int(out[1])

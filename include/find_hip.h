@@ -211,12 +211,17 @@ int find_render_fwd(const find_render_params* rp, const float* verts, const int3
 					const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
 					int64_t n_verts, int64_t n_faces, float* mask, float* image, int32_t* pix_to_face, float* zbuf,
 					void* ws, int64_t ws_bytes, void* stream);
-/* d_mask / d_image upstream grads (either NULL).  d_verts (n_meshes,n_verts,3) and d_vert_colors (same) are
- * OVERWRITTEN.  ws must be the forward workspace. */
+/* d_mask / d_image upstream grads (either NULL); `mask` is the forward's soft silhouette (required with d_mask).
+ * d_verts (n_meshes,n_verts,3) and d_vert_colors (same, may be NULL) are OVERWRITTEN.  ws must be the forward workspace,
+ * untouched since find_render_fwd (it holds the projected faces and the nearest-fragment buffers). */
 int find_render_bwd(const find_render_params* rp, const float* verts, const int32_t* faces, int64_t faces_batch,
 					const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
-					int64_t n_verts, int64_t n_faces, const float* d_mask, const float* d_image,
+					int64_t n_verts, int64_t n_faces, const float* mask, const float* d_mask, const float* d_image,
 					float* d_verts, float* d_vert_colors, void* ws, int64_t ws_bytes, void* stream);
+/* Diagnostics of the last forward that used `ws` (synchronises the stream): out2[0] = faces straddling the z-clip
+ * plane (PyTorch3D would clip them; they are rasterised whole here -- none exists on FIND's camera set-up),
+ * out2[1] = pixels with more silhouette candidates than sil_faces_per_pixel (all of them were blended). */
+int find_render_flags(const void* ws, int32_t* out2, void* stream);
 
 #ifdef __cplusplus
 }
