@@ -1,0 +1,129 @@
+"""FootRenderer on the MI355X hot path: host-side mirror of reference src/model/renderer.py (same class name, constructor
+keywords, view helpers and forward() keywords / outputs); all rendering arithmetic runs in libfind_hip.so
+(find_amd.functional_render).  Keypoint splatting and the N-channel feature shader are out of scope."""
+from typing import Union
+
+import numpy as np
+import torch
+
+from . import functional_render as FR
+from .cameras import look_at_view_transform
+from .structures import Meshes, TexturesVertex
+
+nn = torch.nn
+
+
+class FootRenderer(nn.Module):
+	def __init__(self, image_size, device='cuda', background_color=(1., 1., 1.), bin_size=None, z_clip_value=None, max_faces_per_bin=None):
+		"""bin_size / max_faces_per_bin are accepted for signature compatibility: binning is an acceleration structure of
+		PyTorch3D's CUDA rasteriser and must not change results; the HIP rasteriser tiles internally."""
+		super().__init__()
+		self.image_size = image_size
+		self.device = device
+		self.background_color = tuple(float(c) for c in background_color)
+		self.bin_size, self.max_faces_per_bin = bin_size, max_faces_per_bin
+		self.light_location = (0., 0., 100.)  # PointLights(location=[[0, 0, 100]])  (renderer.py:114)
+		self.params = FR.make_params(image_size, faces_per_pixel=100, background=self.background_color, light_pos=self.light_location,
+									 znear=0.02, z_clip=z_clip_value)
+
+	# ------------------------------------------------------------------ view helpers (numpy RNG, as the reference)
+	def sample_views(self, nviews=1, dist_mean=.25, dist_std=0.05, elev_min=-90, elev_max=90, azim_min=0, azim_max=360, seed: int = None):
+		if seed:
+			np.random.seed(seed)
+		distances = np.random.normal(dist_mean, dist_std, (nviews))
+		elev = np.random.uniform(elev_min, elev_max, (nviews))
+		azim = np.random.uniform(azim_min, azim_max, (nviews))
+		return look_at_view_transform(dist=distances, elev=elev, azim=azim, up=((1, 0, 0),))
+
+	def linspace_views(self, nviews=1, dist=.3, dist_min=None, dist_max=None, elev_min=None, elev_max=None, azim_min=None, azim_max=None,
+					   at=((0, 0, 0),)):
+		if dist_min is not None:
+			dist = np.linspace(dist_min, dist_max, nviews)
+		elev = 0 if elev_min is None else np.linspace(elev_min, elev_max, nviews)
+		azim = 0 if azim_min is None else np.linspace(azim_min, azim_max, nviews)
+		return look_at_view_transform(dist=dist, elev=elev, azim=azim, up=((1, 0, 0),), at=at)
+
+	def view_from(self, view_kw='topdown'):
+		kws = ['topdown', 'side1', 'side2', 'toes', '45', '60']
+		if isinstance(view_kw, str):
+			view_kw = [view_kw]
+		N = len(view_kw)
+		R, T = torch.empty((N, 3, 3)), torch.empty((N, 3))
+		for n, v in enumerate(view_kw):
+			assert v in kws, f'View description `{view_kw}` not understood'
+			dist, elev, azim, point = 0.3, 0, 0, ((0, 0, 0),)
+			if v == 'side1':
+				elev, dist = 90, 0.35
+			if v == 'side2':
+				elev, azim, dist = -90, 180, 0.35
+			if v == 'toes':
+				point, dist = ((0.1, 0, 0),), 0.1
+			if v == '45':
+				dist, elev = 0.35, -45
+			if v == '60':
+				dist, elev = 0.35, -60
+			_R, _T = look_at_view_transform(dist=dist, elev=elev, azim=azim, up=((1, 0, 0),), at=point)
+			R[n], T[n] = _R, _T
+		return R, T
+
+	def combine_views(self, R1, T1, R2, T2):
+		return torch.cat([R1, R2], dim=0), torch.cat([T1, T2], dim=0)
+
+	# ------------------------------------------------------------------ render
+	def forward(self, input_meshes: Meshes, R, T, return_images=True, return_depth=False, return_mask=False, mask_with_grad=True,
+				mask_out_faces=False, masked_faces=None, keypoints=None, keypoints_blend=False, lights=None, return_mask_out_masks=False,
+				return_features=False, features=None) -> dict:
+		"""Render N meshes from M views: image [N,M,H,W,3], mask [N,M,H,W] (soft silhouette when mask_with_grad), optional
+		depth and mask-out masks (reference renderer.py:247-383).  Image index = mesh*M + view."""
+		if keypoints is not None or keypoints_blend:
+			raise NotImplementedError('keypoint splatting (points renderer) is visualisation-only and out of scope')
+		if return_features or features is not None:
+			raise NotImplementedError('per-vertex feature rendering needs the restyle encoder and is out of scope')
+		if lights is not None:
+			raise NotImplementedError('custom lights are not used on the FIND path; the renderer keeps PointLights((0,0,100))')
+		dev = input_meshes.device
+		R, T = R.to(dev).float(), T.to(dev).float()
+		N, M = len(input_meshes), R.shape[0]
+		verts = input_meshes.verts_padded()
+		faces = input_meshes.faces_shared()
+		if faces is None:
+			faces = input_meshes.faces_padded()
+		F = faces.shape[-2]
+		colors = None
+		if return_images:
+			tex = input_meshes.textures
+			if not isinstance(tex, TexturesVertex):
+				raise NotImplementedError('return_images needs per-vertex colours (TexturesVertex); TexturesUV sampling is SURVEY §8(f1)')
+			colors = tex.verts_features_padded()[..., :3]
+		want_soft = return_mask and (mask_with_grad or not return_images)
+		want_frags = mask_out_faces or return_depth
+		if not (return_images or want_soft or want_frags):
+			return dict()
+		mask, renders, p2f, zbuf = FR.render(verts, colors, faces, R, T, self.params, want_mask=want_soft, want_image=return_images,
+											 want_frags=want_frags)
+		out = dict()
+		if return_depth:
+			out['depth'] = zbuf
+		if return_mask and not want_soft:  # hard mask from the image render (renderer.py:313)
+			mask = torch.any(renders < 1, dim=-1).float()
+
+		mask_out = torch.zeros((N, M, self.params.image_h, self.params.image_w), dtype=torch.bool, device=dev)
+		if mask_out_faces and masked_faces is not None:
+			img = torch.arange(N * M, device=dev, dtype=torch.int32).view(N, M, 1, 1)
+			local = torch.where(p2f >= 0, p2f - img * F, p2f)  # face count within the mesh (renderer.py:322-327)
+			for n in range(N):
+				mf = masked_faces[n] if isinstance(masked_faces, list) else masked_faces
+				mask_out[n] = torch.isin(local[n], mf.to(dev).to(local.dtype))
+			if return_images:
+				renders = torch.where(mask_out.unsqueeze(-1), torch.ones_like(renders), renders)
+			if return_mask:
+				mask = torch.where(mask_out, torch.zeros_like(mask), mask)
+		# (masks derived from a "u=v=0" UV vertex need TexturesUV -- SURVEY §8(f1); without them nothing is masked out)
+
+		if return_images:
+			out['image'] = renders
+		if return_mask:
+			out['mask'] = mask
+		if return_mask_out_masks:
+			out['mask_out_masks'] = mask_out
+		return out

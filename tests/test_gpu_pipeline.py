@@ -1,0 +1,175 @@
+"""End-to-end GPU parity: ModelWithLoss.forward (reference src/model/model.py:1001-1163) with the train_3d.yaml loss set
+(chamf + smooth + texture) and with the render losses (sil + pix), against the oracle composed from the same inputs.
+The sampler's random draws are recorded on the GPU run and replayed in the oracle (draws are inputs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom_ref, mlp_ref, render_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_feet=3, n_verts=1002, gt_verts=1002, seed=0):
+	from find_amd import synthetic
+	from find_amd.model_with_loss import ModelWithLoss
+	from find_amd.opts import Opts
+	from find_amd.structures import Meshes, TexturesVertex
+	opts = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True, num_views=2)
+	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=n_feet, val_size=1,
+						shapevec_size=100, texvec_size=100, posevec_size=100, template_mesh_loc=None)
+	g = torch.Generator().manual_seed(1234)
+	with torch.no_grad():
+		mwl.model.mlp_disp[-1].weight.copy_(torch.randn(mwl.model.mlp_disp[-1].weight.shape, generator=g) * 0.01)
+		mwl.model.mlp_disp[-1].bias.copy_(torch.randn(3, generator=g) * 0.01)
+	mwl = mwl.to('cuda')
+	v, f = synthetic.template(n_verts)
+	mwl.model.set_template(v.cuda(), f.cuda())
+	lat = synthetic.latents(n_feet, seed=seed, device='cuda')
+	with torch.no_grad():
+		mwl.model.shapevec.data.copy_(lat['shapevec']); mwl.model.texvec.data.copy_(lat['texvec'])
+		mwl.model.posevec.data.copy_(lat['posevec']); mwl.model.reg.data.copy_(lat['reg'])
+	gv, gf, gc = synthetic.gt_feet(n_feet, gt_verts, seed=seed, device='cuda')
+	gc = gc.clamp(0.05, 0.95)
+	gc[:, ::7] = 1.0  # some pure-white GT samples: masked out of the texture loss (losses.py:43)
+	batch = dict(mesh=Meshes(gv, gf, TexturesVertex(gc)), idx=torch.arange(n_feet, device='cuda'), name=[f'{i:04d}' for i in range(n_feet)])
+	from find_amd.train_utils import sample_latent_vectors
+	batch.update(sample_latent_vectors(batch, mwl.model.latent_vectors_train))
+	return mwl, opts, batch, (gv, gf, gc)
+
+
+class DrawRecorder:
+	"""Wraps find_amd.losses.sample_points_from_meshes: draws on the GPU exactly as the product does, but keeps them."""
+
+	def __init__(self):
+		import find_amd.losses as L
+		self.L = L
+		self.orig = L.sample_points_from_meshes
+		self.draws = []
+
+	def __enter__(self):
+		from find_amd import functional as FN
+
+		def wrapped(meshes, num_samples=10000, return_textures=False, generator=None, draws=None):
+			verts = meshes.verts_padded()
+			faces = meshes.faces_shared() if meshes.faces_shared() is not None else meshes.faces_padded()
+			with torch.no_grad():
+				areas = FN.face_areas(verts, faces)
+				fi = torch.multinomial(areas, num_samples, replacement=True)
+				uv = torch.rand(verts.shape[0], num_samples, 2, device=verts.device)
+			self.draws.append((fi.cpu(), uv.cpu()))
+			return self.orig(meshes, num_samples, return_textures, draws=(fi, uv))
+
+		self.L.sample_points_from_meshes = wrapped
+		return self
+
+	def __exit__(self, *a):
+		self.L.sample_points_from_meshes = self.orig
+
+
+def _oracle_model(mwl, batch):
+	m = mwl.model
+	sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
+		  for k, v in m.state_dict().items()}
+	lat = {k: batch[f'{k}_train'].detach().cpu().clone().requires_grad_(True) for k in ['shapevec', 'texvec', 'posevec', 'reg']}
+	return sd, lat, m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
+
+
+def test_train_3d_loss_set_matches_oracle():
+	mwl, opts, batch, (gv, gf, gc) = _setup()
+	with DrawRecorder() as rec:
+		loss, losses = mwl(batch, 0, opts, chamf=True, smooth=True, texture=True)
+	assert set(losses) == {'loss_chamf', 'loss_smooth', 'loss_tex'}
+	loss.backward()
+	# ---- oracle with the recorded draws: order of sampler calls = GT (chamf), pred (chamf), GT+tex (texture)
+	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = rec.draws
+	sd, lat, B, tv, tf = _oracle_model(mwl, batch)
+	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	gvc, gfc, gcc = gv.cpu(), gf.cpu(), gc.cpu()
+	gt_s = geom_ref.sample_points(gvc, gfc, fi_gt, uv_gt)
+	pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
+	l_ch = geom_ref.chamfer_distance(pr_s, gt_s)
+	l_sm = geom_ref.mesh_smoothness(res['verts'], tf)
+	tx_p, tx_c = geom_ref.sample_points(gvc, gfc, fi_tx, uv_tx, attr=gcc)
+	col = mlp_ref.mlp_forward(sd, B, tx_p, lat['shapevec'], lat['texvec'], lat['posevec'])['col']
+	mask = (tx_c < 1).any(dim=-1, keepdim=True).expand(-1, -1, 3)
+	l_tx = (torch.nn.functional.mse_loss(col, tx_c, reduction='none') * mask).mean()
+	ref = {'loss_chamf': l_ch * 10000., 'loss_smooth': l_sm * 1000., 'loss_tex': l_tx * 1.}  # opts.py:97-99
+	for k in ref:
+		assert abs(losses[k].item() - ref[k].item()) < 1e-4 * max(1.0, abs(ref[k].item())), (k, losses[k].item(), ref[k].item())
+	assert float((~mask).float().mean()) > 0.05  # the white-sample mask is exercised
+	rl = sum(ref.values())
+	assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
+	rl.backward()
+	for k, name in [('shapevec', 'shapevec'), ('texvec', 'texvec'), ('posevec', 'posevec'), ('reg', 'reg')]:
+		got = getattr(mwl.model, name).data.grad.cpu()
+		want = lat[k].grad
+		s = max(1e-3, want.abs().max().item())
+		assert (got - want).abs().max().item() < 2e-3 * s, (k, (got - want).abs().max().item(), s)
+	for k in ['base.0.weight', 'base.4.bias', 'mlp_disp.2.weight', 'mlp_disp.6.weight', 'mlp_col.0.weight', 'mlp_col.6.bias']:
+		got = dict(mwl.model.named_parameters())[k].grad.cpu()
+		want = sd[k].grad
+		s = max(1e-3, want.abs().max().item())
+		assert (got - want).abs().max().item() < 2e-3 * s, (k, (got - want).abs().max().item(), s)
+
+
+def test_z_cutoff_variants_match_oracle():
+	mwl, opts, batch, (gv, gf, gc) = _setup(seed=2)
+	for kw in [dict(use_z_cutoff=True), dict(gt_z_cutoff=0.01)]:
+		with DrawRecorder() as rec:
+			loss, losses = mwl(batch, 0, opts, chamf=True, **kw)
+		(fi_gt, uv_gt), (fi_pr, uv_pr) = rec.draws
+		sd, lat, B, tv, tf = _oracle_model(mwl, batch)
+		with torch.no_grad():
+			res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+			gt_s = geom_ref.sample_points(gv.cpu(), gf.cpu(), fi_gt, uv_gt)
+			pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
+			tot = 0.0
+			for b in range(gt_s.shape[0]):  # ragged clouds, one at a time, exactly as losses.py:69-85 builds them
+				if 'use_z_cutoff' in kw:
+					p, q = pr_s[b][pr_s[b, :, 2] <= 0.07], gt_s[b][gt_s[b, :, 2] <= 0.07]
+				else:
+					p, q = pr_s[b], gt_s[b][gt_s[b, :, 2] <= 0.01]
+				tot = tot + geom_ref.chamfer_distance(p[None], q[None])
+			ref = tot / gt_s.shape[0] * 10000.
+		assert abs(losses['loss_chamf'].item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item())), kw
+
+
+def test_render_losses_match_oracle():
+	mwl, opts, batch, (gv, gf, gc) = _setup(n_feet=2, seed=3)
+	mwl.rdr = type(mwl.rdr)(image_size=64, device='cuda')
+	np.random.seed(11)
+	R, T = mwl.rdr.sample_views(nviews=2, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+	out = mwl(batch, 0, opts, sil=True, pix=True, render_foot=True, return_renders=True, views=(R, T))
+	loss, losses, renders = out
+	assert set(losses) == {'loss_pix', 'loss_sil'} and set(renders) == {'pred', 'gt'}
+	assert renders['pred']['image'].shape == (2, 2, 64, 64, 3) and renders['gt']['mask'].shape == (2, 2, 64, 64)
+	loss.backward()
+	# oracle forward
+	sd, lat, B, tv, tf = _oracle_model(mwl, batch)
+	with torch.no_grad():
+		res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	gt = render_ref.render(gv.cpu().numpy(), gf.cpu().numpy(), gc.cpu().numpy(), R.numpy(), T.numpy(), image_size=64)
+	pr = render_ref.render(res['verts'].numpy(), tf.numpy(), res['col'].numpy(), R.numpy(), T.numpy(), image_size=64)
+	sil = float(((pr['mask'] - gt['mask']) ** 2).mean()) * 5.0
+	pix = float(((pr['image'] * pr['mask'][..., None] - gt['image'] * gt['mask'][..., None]) ** 2).mean()) * 1.0
+	assert abs(losses['loss_sil'].item() - sil) < 1e-4 * max(1.0, sil), (losses['loss_sil'].item(), sil)
+	assert abs(losses['loss_pix'].item() - pix) < 2e-4 * max(1.0, pix), (losses['loss_pix'].item(), pix)
+	# gradients reach the registration, the latents and the network through both render losses
+	for name in ['reg', 'shapevec', 'texvec', 'posevec']:
+		g = getattr(mwl.model, name).data.grad
+		assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0, name
+	assert mwl.model.base[0].weight.grad.abs().max().item() > 0
+
+
+def test_loss_weights_are_applied_and_flags_respected():
+	mwl, opts, batch, _ = _setup(n_feet=2, seed=4)
+	l0, d0 = mwl(batch, 0, opts)
+	assert d0 == {} and l0 == 0  # no loss enabled -> sum of nothing (trainer.py:108 `if loss == 0: continue`)
+	torch.manual_seed(0)
+	l1, d1 = mwl(batch, 0, opts, smooth=True)
+	opts.weight_smooth = 2000.
+	l2, d2 = mwl(batch, 0, opts, smooth=True)
+	assert abs(l2.item() - 2 * l1.item()) < 1e-5 * abs(l2.item())
+	with pytest.raises(NotImplementedError):
+		mwl(batch, 0, opts, vgg_perc=True)

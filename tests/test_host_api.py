@@ -1,0 +1,228 @@
+"""CPU tests of the host-side mirror of the reference API (no compute calls): state_dict compatibility, LatentVector (golden
+G5), parameter groups, containers, cameras, options, and that libfind_hip.so exports every symbol include/find_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(**kw):
+	from find_amd.model import NeuralDisplacementField
+	base = dict(template_mesh_loc=None, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=4, val_size=2,
+				shapevec_size=100, texvec_size=100, posevec_size=100)
+	base.update(kw)
+	return NeuralDisplacementField(**base)
+
+
+def test_state_dict_keys_shapes_and_init_match_reference(golden_main):
+	m = _model()
+	sd = m.state_dict()
+	ref = {k[3:]: v for k, v in golden_main.items() if k.startswith('sd/')}
+	assert set(sd) == set(ref)
+	for k, v in ref.items():
+		assert tuple(sd[k].shape) == v.shape, k
+	# identical seeded initialisation (FFT reseeds the global RNG to 1): every tensor except the re-drawn last disp layer
+	for k, v in ref.items():
+		if k.startswith('mlp_disp.6'):
+			assert float(sd[k].abs().max()) == 0.0  # reference zero-init (model.py:516-518)
+		else:
+			np.testing.assert_array_equal(sd[k].numpy(), v, err_msg=k)
+	assert sum(p.numel() for p in m.parameters()) == 870221
+	np.testing.assert_array_equal(m.encoder[0]._B.numpy(), golden_main['B'])
+	assert not any(k.startswith('encoder') for k in sd)  # _B is not saved
+
+
+def test_latent_vector_golden(golden_latent):
+	from find_amd.model import LatentVector
+	labels = [str(s) for s in golden_latent['labels']]
+	L = LatentVector(None, vec_size=5, name='shapevec_train', device='cpu', key='shape', labels=labels)
+	with torch.no_grad():
+		L.data.copy_(torch.from_numpy(golden_latent['data']))
+	np.testing.assert_array_equal(L[2].detach().numpy(), golden_latent['int_2'])
+	np.testing.assert_array_equal(L[torch.tensor([3, 0])].detach().numpy(), golden_latent['tensor_3_0'])
+	np.testing.assert_array_equal(L['0005-B'].detach().numpy(), golden_latent['str_0005-B'])
+	np.testing.assert_array_equal(L[[1, 1, 2]].detach().numpy(), golden_latent['list_int_1_1_2'])
+	np.testing.assert_array_equal(L[['0007-A', '0003-A']].detach().numpy(), golden_latent['list_str'])
+	R = LatentVector(3, vec_size=9, name='reg_train', device='cpu', key='reg', init_values=np.array([0] * 6 + [1] * 3))
+	np.testing.assert_array_equal(R.data.detach().numpy(), golden_latent['reg_init'])
+	assert len(R) == int(golden_latent['len_unlabelled'][0])
+	with pytest.raises(AssertionError):
+		R['x']
+	with pytest.raises(NotImplementedError):
+		L[1.5]
+	# gradients reach only the gathered rows
+	L[[1, 2]].sum().backward()
+	assert L.data.grad[0].abs().sum() == 0 and L.data.grad[1].abs().sum() > 0
+
+
+def test_param_groups_and_save_load(tmp_path):
+	m = _model()
+	n = lambda ps: sum(p.numel() for p in ps)
+	assert n(m.main_params) == 868358 + 3 * 4 * 100
+	assert n(m.reg_params) == 6 * 9 and n(m.latent_params) == 3 * 6 * 100 and n(m.val_params) == 3 * 2 * 100
+	assert [v.name for v in m.latent_vectors_train] == ['shapevec_train', 'posevec_train', 'texvec_train', 'reg_train']
+	assert [v.name for v in m.latent_vectors_val] == ['shapevec_val', 'posevec_val', 'texvec_val', 'reg_val']
+	v = torch.randn(50, 3)
+	f = torch.randint(0, 50, (80, 3))
+	m.set_template(v, f)
+	with torch.no_grad():
+		m.shapevec.data.normal_()
+	m.save_model(str(tmp_path), 'ckpt')
+	from find_amd.model import NeuralDisplacementField
+	from find_amd.opts import Opts
+	m2 = NeuralDisplacementField.load(str(tmp_path / 'ckpt.pth'), device='cpu', opts=Opts())
+	for (k1, a), (k2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+		assert k1 == k2 and torch.equal(a, b), k1
+	assert m2.template_mesh.verts_padded().shape == (1, 50, 3)
+	m3 = NeuralDisplacementField.load(str(tmp_path / 'ckpt.pth'), device='cpu', opts=Opts(dont_load_latents=True), train_size=7, val_size=3)
+	assert m3.shapevec.data.shape == (7, 100) and float(m3.shapevec.data.abs().max()) == 0.0
+	assert torch.equal(m3.base[0].weight, m.base[0].weight)
+	m.freeze()
+	assert not any(p.requires_grad for p in m.parameters())
+
+
+def test_quirks_of_head_sizes():
+	# posevec tables are sized by shapevec_size (model.py:320-322); disp head counts the shape code only if use_texvec (:352)
+	m = _model(shapevec_size=64, texvec_size=32, posevec_size=64)
+	assert m.posevec.data.shape == (4, 64) and m.mlp_disp[0].weight.shape == (256, 256 + 64 + 64) and m.mlp_col[0].weight.shape == (256, 256 + 32)
+	m = _model(use_texvec=False, use_posevec=False)
+	assert m.mlp_disp[0].weight.shape == (256, 256) and m.mlp_col[0].weight.shape == (256, 256)
+	with pytest.raises(NotImplementedError):
+		_model(width=128)
+
+
+def test_forward_on_cpu_fails_loudly_without_fallback():
+	m = _model()
+	with pytest.raises(RuntimeError, match='no CPU fallback'):
+		m(torch.zeros(1, 4, 3), shapevec=torch.zeros(1, 100), texvec=torch.zeros(1, 100), posevec=torch.zeros(1, 100))
+
+
+def test_c_abi_exports_every_declared_symbol():
+	from find_amd import _lib
+	hdr = open(os.path.join(ROOT, 'include', 'find_hip.h')).read()
+	hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+	declared = set(re.findall(r'\b(find_[a-z0-9_]+)\s*\(', hdr))
+	assert len(declared) >= 24
+	assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+	L = _lib.lib()  # dlopen; raises if any symbol is missing or the ABI version differs
+	for name in declared:
+		assert hasattr(L, name), name
+	assert L.find_abi_version() == _lib.ABI_VERSION
+	assert L.find_build_arch() == b'gfx950'
+	assert ctypes.sizeof(_lib.MlpParams) == 8 * 4 + 8 + 6 * 8 * 8 + 8
+	assert ctypes.sizeof(_lib.RenderParams) == 21 * 4
+
+
+def test_error_reporting_without_gpu():
+	"""Argument validation happens before any launch, so it can be exercised on the CPU-only builder."""
+	from find_amd import _lib
+	L = _lib.lib()
+	assert L.find_register_fwd(None, 1, None, None, 1, 1, None, None) == -1
+	assert b'NULL' in L.find_last_error()
+	p = _lib.MlpParams()
+	p.width = 128
+	assert L.find_mlp_ws_bytes(ctypes.byref(p), 1, 1, 10, 1) == -1
+	assert b'width=256' in L.find_last_error()
+	assert L.find_set_tuning(b'nope', 1) == -1
+
+
+def test_meshes_container_subset():
+	from find_amd.structures import Meshes, TexturesVertex, extend_template, join_meshes_as_batch
+	v = torch.randn(1, 10, 3)
+	f = torch.randint(0, 10, (12, 3))
+	t = Meshes(v, f)
+	m = extend_template(t, N=3)
+	assert len(m) == 3 and m.verts_padded().shape == (3, 10, 3) and m.faces_padded().shape == (3, 12, 3)
+	assert m.verts_padded().data_ptr() == v.data_ptr()  # expanded, not copied (pytorch3d_tools.py:9)
+	assert m.faces_shared() is not None and m.faces_shared().dtype == torch.int32
+	m2 = m.update_padded(torch.zeros(3, 10, 3))
+	assert float(m2.verts_padded().abs().sum()) == 0 and float(m.verts_padded().abs().sum()) > 0
+	m2.textures = TexturesVertex(torch.rand(3, 10, 3))
+	e = m2.extend(2)
+	assert len(e) == 6 and torch.equal(e.textures.verts_features_padded()[0], e.textures.verts_features_padded()[1])
+	assert torch.equal(e.textures.verts_features_padded()[2], m2.textures.verts_features_padded()[1])
+	assert m.verts_packed().shape == (30, 3) and m.faces_packed().shape == (36, 3)
+	assert int(m.faces_packed()[12:24].min()) >= 10  # offsets into the packed vertices
+	assert m.num_verts_per_mesh().tolist() == [10, 10, 10] and m.num_faces_per_mesh().tolist() == [12, 12, 12]
+	r = Meshes([torch.randn(5, 3), torch.randn(8, 3)], [torch.randint(0, 5, (4, 3)), torch.randint(0, 8, (9, 3))])
+	assert r.verts_padded().shape == (2, 8, 3) and r.faces_padded().shape == (2, 9, 3) and int(r.faces_padded()[0, 4:].max()) == -1
+	assert r.verts_packed().shape == (13, 3) and not r.is_homogeneous()
+	j = join_meshes_as_batch([r[0], r[1]])
+	assert len(j) == 2 and torch.equal(j.verts_padded(), r.verts_padded())
+	assert len(m[1:3]) == 2 and len(m.clone()) == 3
+
+
+def test_cameras_and_view_helpers_match_oracle():
+	from find_amd.cameras import look_at_view_transform
+	from find_amd.renderer import FootRenderer
+	from oracle import camera_ref
+	rng = np.random.RandomState(0)
+	d, e, a = rng.uniform(0.2, 0.4, 6), rng.uniform(-90, 90, 6), rng.uniform(-180, 180, 6)
+	R, T = look_at_view_transform(dist=d, elev=e, azim=a, up=((1, 0, 0),))
+	R2, T2 = camera_ref.look_at_view_transform(dist=d, elev=e, azim=a, up=((1, 0, 0),))
+	np.testing.assert_array_equal(R.numpy(), R2)
+	np.testing.assert_array_equal(T.numpy(), T2)
+	rdr = FootRenderer(image_size=64, device='cpu')
+	np.random.seed(7)
+	Rs, Ts = rdr.sample_views(nviews=4, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+	np.random.seed(7)
+	dist = np.random.normal(0.3, 0, 4)
+	el = np.random.uniform(-90, 90, 4)
+	az = np.random.uniform(-90, 90, 4)
+	R3, _ = camera_ref.look_at_view_transform(dist=dist, elev=el, azim=az, up=((1, 0, 0),))
+	np.testing.assert_array_equal(Rs.numpy(), R3)
+	# `if seed:` in the reference: seed=5 reseeds numpy's global RNG
+	a1 = rdr.sample_views(nviews=2, seed=5)[0]
+	a2 = rdr.sample_views(nviews=2, seed=5)[0]
+	assert torch.equal(a1, a2)
+	Rv, Tv = rdr.view_from(['topdown', 'side1', 'side2', 'toes', '45', '60'])
+	assert Rv.shape == (6, 3, 3) and abs(float(Tv[0, 2]) - 0.3) < 1e-6
+	Rc, Tc = rdr.combine_views(Rv, Tv, Rs, Ts)
+	assert Rc.shape == (10, 3, 3)
+	Rl, Tl = rdr.linspace_views(nviews=5, dist=0.3, elev_min=-90, elev_max=90)
+	assert Rl.shape == (5, 3, 3)
+	assert abs(rdr.params.sil_blur_radius - np.log(1. / 1e-4 - 1.) * 1e-4) < 1e-9 and rdr.params.sil_faces_per_pixel == 100
+	assert abs(rdr.params.z_clip - 0.01) < 1e-9
+
+
+def test_opts_defaults_and_weights():
+	from find_amd.opts import Opts
+	o = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True)
+	assert (o.weight_chamf, o.weight_smooth, o.weight_tex, o.weight_sil, o.weight_pix) == (10000., 1000., 1., 5., 1.)  # opts.py:97-99
+	assert o.num_views == 5 and o.net_train_kwargs()['chamf'] and not o.net_train_kwargs()['render_foot']
+	with pytest.raises(AssertionError):
+		o.set_option('not_a_flag', 1)
+	assert not o.use_restyle()
+
+
+def test_topology_tables_cpu():
+	from find_amd import synthetic
+	from find_amd.functional import MeshTopology
+	from oracle import geom_ref
+	v, f = synthetic.ellipsoid_mesh(6, 8)
+	t = MeshTopology(f, v.shape[0])
+	assert t.n_edges == geom_ref.unique_edges(f).shape[0] == 3 * (v.shape[0] - 2)  # closed genus-0 surface: E = 3V - 6
+	deg = (t.nbr_off[1:] - t.nbr_off[:-1])
+	assert int(deg.sum()) == 2 * t.n_edges and int(deg.min()) >= 3
+	cnt = (t.vf_off[1:] - t.vf_off[:-1])
+	assert int(cnt.sum()) == 3 * f.shape[0] and torch.equal(cnt, deg)  # closed manifold: #faces == #edges at every vertex
+	items = t.vf_items.long()
+	vid = f.reshape(-1)[items]
+	assert torch.equal(vid, torch.repeat_interleave(torch.arange(v.shape[0]), cnt.long()))
+
+
+def test_sample_latent_vectors_by_label_and_index():
+	from find_amd.train_utils import sample_latent_vectors
+	m = _model(latent_labels={'shape': ['a', 'b', 'c', 'd'], 'tex': ['a', 'b', 'c', 'd']})
+	with torch.no_grad():
+		m.shapevec.data.copy_(torch.arange(400.).reshape(4, 100))
+	batch = {'idx': torch.tensor([2, 0]), 'shape': ['d', 'a'], 'tex': ['b', 'b']}
+	out = sample_latent_vectors(batch, m.latent_vectors_train)
+	assert set(out) == {'shapevec_train', 'posevec_train', 'texvec_train', 'reg_train'}
+	assert torch.equal(out['shapevec_train'][:, 0], torch.tensor([300., 0.]))  # by label
+	assert out['reg_train'].shape == (2, 9)  # by index
