@@ -107,26 +107,38 @@ def cpu_baseline(sample_feet=2, steps=2):
 	"""oracle/mlp_ref.py = the reference's op sequence (no trunk sharing, latents concatenated per vertex) on host cores."""
 	from find_amd import synthetic
 	from oracle import mlp_ref
-	cores = os.cpu_count() or 1
-	torch.set_num_threads(cores)
+	try:
+		avail = len(os.sched_getaffinity(0))
+	except AttributeError:
+		avail = os.cpu_count() or 1
 	model = synthetic.make_model(N_VERTS, train_size=N_FEET, val_size=2, device='cpu')
-	lat = synthetic.latents(sample_feet, seed=0, device='cpu')
 	sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
 		  for k, v in model.state_dict().items()}
 	B = model.encoder[0]._B
 	tv = model.template_verts.data
-	best = float('inf')
-	for i in range(steps + 1):
+
+	def one_step(n_feet):
+		lat = synthetic.latents(n_feet, seed=0, device='cpu')
 		lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
 		t0 = time.perf_counter()
 		res = mlp_ref.get_meshes_verts(sd, B, tv, lv['shapevec'], lv['reg'], lv['texvec'], lv['posevec'])
 		loss = (res['verts'] ** 2).sum() + (res['col'] ** 2).sum()
 		loss.backward()
-		dt = time.perf_counter() - t0
-		if i > 0:
-			best = min(best, dt)
+		return time.perf_counter() - t0
+
+	# torch-CPU does not scale to every hardware thread of a big host on GEMMs this small: pick the best thread count
+	# from a short probe (1 foot), then time the sample with it
+	probe = {}
+	for t in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
+		torch.set_num_threads(t)
+		one_step(1)
+		probe[t] = one_step(1)
+	cores = min(probe, key=probe.get)
+	torch.set_num_threads(cores)
+	best = min(one_step(sample_feet) for _ in range(steps))
 	return dict(value=sample_feet * N_VERTS / best, unit='vertices*views/s', cores=cores, kind='port',
-				sample=f'{sample_feet} of {N_FEET} feet x {N_VERTS} verts, fwd+bwd, best of {steps} after 1 warm-up, torch-CPU {cores} threads')
+				sample=f'{sample_feet} of {N_FEET} feet x {N_VERTS} verts, fwd+bwd, best of {steps}, torch-CPU with {cores} threads '
+					   f'(best of a {sorted(probe)}-thread probe; host exposes {avail} hardware threads)')
 
 
 def main():
@@ -193,7 +205,7 @@ def main():
 					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
 					   'step_tflops_executed': fl_exec / (ms_step * 1e-3) / 1e12,
 					   'step_tflops_reference_equiv': fl_ref / (ms_step * 1e-3) / 1e12},
-			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm_kernel<128,MAT,BIAS_RELU> (Linear 256->256 + ReLU, 110240 rows)',
+			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm2_kernel<64,0,1> (Linear 256->256 + ReLU over 110240 rows, fp32 MFMA)',
 						 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
 						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': None},
 		}
