@@ -1,6 +1,6 @@
 // C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
-#include "mlp_gemm2.h"
+#include "mlp_gemm3.h"
 
 namespace find {
 namespace mlp {
@@ -122,6 +122,9 @@ static void launch_gemm_bm(int bm, const GemmArgs& a, int64_t feet, hipStream_t 
 
 // tuning: 0 = register-staged tiles (gemm_kernel), 64 / 128 = persistent LDS-DMA kernel (gemm2_kernel) with that BM
 static int g_gemm_mode = 64;
+static int g_ablate = 0;
+static unsigned long long* g_dbg = nullptr;
+static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
 static int g_num_cus = 0;
 
 static int num_cus() {
@@ -148,6 +151,27 @@ static void launch_gemm2_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	hipLaunchKernelGGL((gemm2_kernel<BM, AMODE, EPI>), dim3(grid), dim3(256), lds, s, a);
 }
 
+template <int BM, int EPI>
+static void launch_gemm3_t(Gemm2Args a, int64_t feet, hipStream_t s) {
+	static bool attr_set = false;
+	constexpr int lds = gemm2_lds_bytes<BM>();
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		attr_set = true;
+	}
+	a.tiles_per_foot = (int)cdiv(a.V, BM);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	const int grid = std::min(a.ntiles, num_cus());
+	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int BM>
+static void launch_gemm3(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) launch_gemm3_t<BM, EPI_BIAS_RELU>(a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm3_t<BM, EPI_MASK>(a, feet, s);
+	else launch_gemm3_t<BM, EPI_NONE>(a, feet, s);
+}
+
 template <int BM>
 static void launch_gemm2(int amode, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (amode == AMODE_PE) launch_gemm2_t<BM, AMODE_PE, EPI_BIAS_RELU>(a, feet, s);
@@ -164,9 +188,12 @@ static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hip
 		b.pos = a.pos; b.pos_foot_stride = a.pos_foot_stride; b.Bm = a.Bm; b.pe = a.pe;
 		b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk;
 		b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
-		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V;
+		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = g_ablate; b.dbg = g_dbg;
 		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
-		if (g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus()) launch_gemm2<128>(amode, epi, b, feet, s);
+		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
+		if (g_gemm3 && amode == AMODE_MAT && !big) {
+			launch_gemm3<64>(epi, b, feet, s);  // (the 128-row instantiation of gemm3 spills; 128-row tiles stay on gemm2)
+		} else if (big) launch_gemm2<128>(amode, epi, b, feet, s);
 		else launch_gemm2<64>(amode, epi, b, feet, s);
 		return;
 	}
@@ -590,6 +617,18 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 // Tuning hook (not part of the reference surface): "gemm" -> 0 register-staged tiles, 64 / 128 persistent LDS-DMA tiles.
 extern "C" int find_set_tuning(const char* key, int64_t value) {
 	FIND_REQUIRE(key != nullptr, "find_set_tuning: NULL key");
+	if (strcmp(key, "dbg") == 0) {  // device pointer to >= 4*grid uint64 (profiling only)
+		g_dbg = reinterpret_cast<unsigned long long*>(value);
+		return FIND_OK;
+	}
+	if (strcmp(key, "ablate") == 0) {
+		g_ablate = (int)value;
+		return FIND_OK;
+	}
+	if (strcmp(key, "gemm3") == 0) {
+		g_gemm3 = value != 0;
+		return FIND_OK;
+	}
 	if (strcmp(key, "gemm") == 0) {
 		FIND_REQUIRE(value == 0 || value == 64 || value == 128, "find_set_tuning: gemm must be 0, 64 or 128");
 		g_gemm_mode = (int)value;

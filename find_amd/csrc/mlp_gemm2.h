@@ -47,6 +47,8 @@ struct Gemm2Args {
 	int V;                  // rows per foot
 	int tiles_per_foot;
 	int ntiles;
+	int ablate;             // profiling only: bit0 skip DMA issue, bit1 skip epilogue stores, bit2 skip MFMAs
+	unsigned long long* dbg; // profiling only: per-workgroup [total, wait+barrier, epilogue, lgkm-wait] shader cycles (wave 0)
 };
 
 #define FIND_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")

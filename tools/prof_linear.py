@@ -15,7 +15,9 @@ n_feet = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n_pts = int(sys.argv[3]) if len(sys.argv) > 3 else 6890
 L = _lib.lib()
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 64
-_lib.check(L.find_set_tuning(b'gemm', mode), 'tuning')
+_lib.check(L.find_set_tuning(b'gemm', mode if mode in (0, 64, 128) else 64), 'tuning')
+_lib.check(L.find_set_tuning(b'gemm3', 1 if mode == 3 else 0), 'tuning')
+_lib.check(L.find_set_tuning(b'ablate', int(sys.argv[5]) if len(sys.argv) > 5 else 0), 'tuning')
 rows = n_feet * n_pts
 g = torch.Generator().manual_seed(0)
 x = torch.randn(rows, 256, generator=g).cuda()
@@ -34,6 +36,16 @@ e1.synchronize()
 ms = e0.elapsed_time(e1) / iters
 ref = torch.relu(x[:4096] @ w.t() + b)
 err = (y[:4096] - ref).abs().max().item()
+if os.environ.get('FIND_DBG'):
+	dbg = torch.zeros(256 * 4, dtype=torch.int64, device='cuda')
+	_lib.check(L.find_set_tuning(b'dbg', dbg.data_ptr()), 'tuning')
+	_lib.check(L.find_linear_relu_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), n_feet, n_pts, _lib.ptr(y), ctypes.c_void_p(s.cuda_stream)), 'lin')
+	torch.cuda.synchronize()
+	_lib.check(L.find_set_tuning(b'dbg', 0), 'tuning')
+	d = dbg.view(256, 4).double().cpu()
+	print('cycles per WG: total %.0f  wait+barrier %.0f (%.1f%%)  epilogue %.0f (%.1f%%)  lgkm %.0f (%.1f%%)' % (
+		d[:, 0].mean(), d[:, 1].mean(), 100 * d[:, 1].sum() / d[:, 0].sum(), d[:, 2].mean(), 100 * d[:, 2].sum() / d[:, 0].sum(),
+		d[:, 3].mean(), 100 * d[:, 3].sum() / d[:, 0].sum()), ' max total %.0f min total %.0f' % (d[:, 0].max(), d[:, 0].min()))
 ref_all = torch.relu(x @ w.t() + b)
 err = (y - ref_all).abs().max().item()
 print(f'mode {mode} linear_relu {n_feet}x{n_pts}: {ms*1e3:.1f} us  {2.0*rows*65536/ms/1e9:.1f} TF/s  max_err_vs_torch {err:.2e}')
