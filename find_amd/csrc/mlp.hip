@@ -1,6 +1,6 @@
 // C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
-#include "mlp_gemm3.h"
+#include "mlp_dw2.h"
 
 namespace find {
 namespace mlp {
@@ -125,6 +125,7 @@ static int g_gemm_mode = 64;
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
+static int g_dw2 = 1;    // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
 static int g_num_cus = 0;
 
 static int num_cus() {
@@ -385,8 +386,10 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	split_policy(1, d.V, &spf, &cps);
 	ms = std::max<int64_t>(ms, spf);
 	o->max_split = ms;
-	o->pw = c.take<float>(ms * W * KP0);
-	o->pb = c.take<float>(ms * W);
+	// dw2 policy: up to max(#CUs, feet) main slabs + one tail slab per foot, each 256x256
+	const int64_t ms2 = std::max<int64_t>(512, d.n_feet) + d.n_feet + 16;
+	o->pw = c.take<float>(std::max<int64_t>(ms * W * KP0, ms2 * W * W));
+	o->pb = c.take<float>(std::max<int64_t>(ms, ms2) * W);
 	o->Sd = c.take<float>(d.n_feet * W);
 	o->Sc = c.take<float>(d.n_feet * W);
 	o->nblk_fs = (int)cdiv(d.V, FS_ROWS);
@@ -409,6 +412,49 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
 					   int k_valid, int pe_map, float* db, float* S, hipStream_t s) {
+	if (!pos && g_dw2) {
+		// LDS-DMA kernel over the full 16-row chunks of every foot; the <= 15 leftover rows per foot go through dw_kernel
+		const int cpf16 = (int)(V / 16);
+		int spf2 = 0, cps2 = 1;
+		if (cpf16 > 0) {
+			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(num_cus(), feet)));
+			cps2 = (int)cdiv(cpf16, want);
+			spf2 = (int)cdiv(cpf16, cps2);
+		}
+		const int nmain = (int)(feet * spf2);
+		const bool tail = (V % 16) != 0;
+		float* pbuf = (db || S) ? b.pb : nullptr;
+		if (nmain > 0) {
+			static bool attr_set = false;
+			if (!attr_set) {
+				(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS);
+				attr_set = true;
+			}
+			Dw2Args d2;
+			memset(&d2, 0, sizeof(d2));
+			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
+			d2.chunks_per_foot = cpf16; d2.spf = spf2; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
+			hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), DW2_LDS, s, d2);
+			FIND_LAUNCH_CHECK("dw2_kernel");
+		}
+		if (tail) {
+			DwArgs t;
+			memset(&t, 0, sizeof(t));
+			t.dz = dz; t.dz_foot_stride = V * W; t.x = x; t.x_foot_stride = x_foot_stride; t.ldx = W;
+			t.V = (int)V; t.spf = 1; t.cps = 1; t.Kp = 256; t.v_begin = cpf16 * 16;
+			t.pw = b.pw + (int64_t)nmain * 65536; t.pb = pbuf ? pbuf + (int64_t)nmain * 256 : nullptr;
+			hipLaunchKernelGGL((dw_kernel<AMODE_MAT>), dim3(1, (unsigned)feet), dim3(512), 0, s, t);
+			FIND_LAUNCH_CHECK("dw_kernel(tail)");
+		}
+		ReduceWArgs r;
+		memset(&r, 0, sizeof(r));
+		r.pw = b.pw; r.nsplit = nmain + (tail ? (int)feet : 0); r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
+		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf2; r.db = db; r.S = S; r.tail_base = tail ? nmain : -1;
+		r.nwblk = (int)cdiv((int64_t)256 * 256 / 4, 256);
+		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)r.nwblk + 1), dim3(256), 0, s, r);
+		FIND_LAUNCH_CHECK("reduce_w_kernel");
+		return FIND_OK;
+	}
 	int spf, cps;
 	split_policy(feet, V, &spf, &cps);
 	DwArgs a;
@@ -427,7 +473,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 	memset(&r, 0, sizeof(r));
 	r.pw = b.pw; r.nsplit = nsplit; r.Kp = a.Kp; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
-	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
+	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S; r.tail_base = -1;
 	r.nwblk = (int)cdiv((int64_t)256 * a.Kp / 4, 256);
 	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)r.nwblk + 1), dim3(256), 0, s, r);
 	FIND_LAUNCH_CHECK("reduce_w_kernel");
@@ -623,6 +669,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "ablate") == 0) {
 		g_ablate = (int)value;
+		return FIND_OK;
+	}
+	if (strcmp(key, "dw2") == 0) {
+		g_dw2 = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm3") == 0) {

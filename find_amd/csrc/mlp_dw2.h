@@ -1,0 +1,182 @@
+// dw2_kernel: weight gradient  dW[n,k] = sum_rows dZ[row,n] * X[row,k]  (256 x 256 output, fp32 MFMA) on the LDS-DMA
+// pipeline.  One 4-wave workgroup owns a full 256x256 output tile over a contiguous range of 16-row chunks of ONE foot
+// (so dZ and X are each read from HBM exactly once and per-foot bias sums fall out for free); the partial tile goes to a
+// slab reduced by reduce_w_kernel (deterministic, no atomics).
+//
+//   * chunk = 16 rows of dZ (16 KB) + 16 rows of X (16 KB), each row one 1-KB global_load_lds_dwordx4; 3-stage ring;
+//   * MFMA operands come from LDS with ONE ds_read_b128 per operand per k-pair: lane l reads columns 4(l&31)..+3 of row
+//     2t+(l>>5); component j feeds accumulator j, so accumulator (ja,jb) holds the outputs n = 4i+ja, k = 4j+jb
+//     (i, j = MFMA row/col).  A 128x128 wave tile therefore needs 2 LDS reads per 16 MFMAs (the 32-row GEMM needs 5), and
+//     the epilogue recombines jb = 0..3 into one coalesced 16-byte store;
+//   * schedule as gemm3: early barrier before the last MFMA step of a chunk, DMA issue interleaved, hoisted arguments.
+// Rows [16*floor(V/16), V) of every foot (at most 15) are handled by dw_kernel through extra slabs (mlp.hip).
+#pragma once
+#include "mlp_gemm3.h"
+
+namespace find {
+namespace mlp {
+
+struct Dw2Args {
+	const float* dz;         // rows (foot, v), ld 256
+	int64_t dz_foot_stride;
+	const float* x;          // rows (foot, v) or shared (x_foot_stride 0), ld 256
+	int64_t x_foot_stride;
+	int chunks_per_foot;     // floor(V / 16)
+	int spf;                 // splits per foot
+	int cps;                 // chunks per split
+	float* pw;               // [n_feet*spf][256][256]
+	float* pb;               // [n_feet*spf][256] or nullptr
+};
+
+constexpr int DW2_STAGE = 2 * 16 * 1024;                // dZ rows then X rows
+constexpr int DW2_LDS = 3 * DW2_STAGE + 4 * 256 * 4;    // + bias reduction scratch
+
+__global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const unsigned lds_base = (unsigned)(uintptr_t)smem;
+	float* red = reinterpret_cast<float*>(smem + 3 * DW2_STAGE);
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wn = wave >> 1, wk = wave & 1;
+	const int fh = lane >> 5;
+	const int split = blockIdx.x;
+	const int foot = split / g.spf;
+	const int sidx = split - foot * g.spf;
+	const int q0 = sidx * g.cps;
+	const int q1 = min(q0 + g.cps, g.chunks_per_foot);
+	const int total = max(q1 - q0, 0);
+	float* const pw = g.pw + (int64_t)split * 65536;
+	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
+
+	f32x16 acc[4][4];
+#pragma unroll
+	for (int a = 0; a < 4; ++a)
+#pragma unroll
+		for (int b = 0; b < 4; ++b)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+	float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+	if (total > 0) {
+		const float* zb = g.dz + (int64_t)foot * g.dz_foot_stride + (int64_t)q0 * 16 * 256;
+		const float* xb = g.x + (int64_t)foot * g.x_foot_stride + (int64_t)q0 * 16 * 256;
+		// DMA: wave w moves rows 4w..4w+3 of both operands; lane i the 16 bytes at column 4i
+		unsigned doff[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) doff[j] = (unsigned)(((wave * 4 + j) * 256 + lane * 4) * 4);
+		const unsigned d_dst = (wave * 4) * 1024;
+		int issued = 0, consumed = 0, ps = 0;
+		const float* iz = nullptr;
+		const float* ix = nullptr;
+		unsigned idst = 0;
+		auto issue_prepare = [&]() {
+			iz = uniform_ptr(zb + (int64_t)issued * 4096);
+			ix = uniform_ptr(xb + (int64_t)issued * 4096);
+			idst = __builtin_amdgcn_readfirstlane(lds_base + ps * DW2_STAGE + d_dst);
+		};
+		auto issue_z = [&]() { dma4(iz, idst, doff[0], doff[1], doff[2], doff[3]); };
+		auto issue_x = [&]() { dma4(ix, idst + 16384, doff[0], doff[1], doff[2], doff[3]); };
+		auto issue_advance = [&]() { ++issued; ps = (ps == 2) ? 0 : ps + 1; };
+
+		for (int k = 0; k < 3 && issued < total; ++k) { issue_prepare(); issue_z(); issue_x(); issue_advance(); }
+		if (issued >= 3) FIND_WAIT_VMCNT(16);
+		else if (issued == 2) FIND_WAIT_VMCNT(8);
+		else FIND_WAIT_VMCNT(0);
+		__builtin_amdgcn_s_barrier();
+
+		// fragment addresses: row 2t + fh, 16 B at column 4*(lane&31) of this wave's 128-column block
+		const int za = fh * 1024 + (wn * 128 + 4 * (lane & 31)) * 4;
+		const int xa = 16384 + fh * 1024 + (wk * 128 + 4 * (lane & 31)) * 4;
+		const int ba = (wave * 4) * 1024 + lane * 16;  // bias partial: rows 4w..4w+3, column 4*lane
+		float4 a0, b0, a1, b1;
+		auto load_frag = [&](const char* sb, int t, float4& a, float4& b) {
+			a = *reinterpret_cast<const float4*>(sb + za + t * 2048);
+			b = *reinterpret_cast<const float4*>(sb + xa + t * 2048);
+		};
+		auto mfma_ja = [&](const float4& a, const float4& b, int ja) {
+			const float av = ja == 0 ? a.x : (ja == 1 ? a.y : (ja == 2 ? a.z : a.w));
+			acc[ja][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.x, acc[ja][0], 0, 0, 0);
+			acc[ja][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.y, acc[ja][1], 0, 0, 0);
+			acc[ja][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.z, acc[ja][2], 0, 0, 0);
+			acc[ja][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.w, acc[ja][3], 0, 0, 0);
+		};
+		auto mfma_step = [&](const float4& a, const float4& b) { mfma_ja(a, b, 0); mfma_ja(a, b, 1); mfma_ja(a, b, 2); mfma_ja(a, b, 3); };
+
+		load_frag(smem, 0, a0, b0);
+		int cs = 0;
+		for (int c = 0; c < total; ++c) {
+			const char* sb = smem + cs * DW2_STAGE;
+			load_frag(sb, 1, a1, b1); mfma_step(a0, b0);
+			load_frag(sb, 2, a0, b0); mfma_step(a1, b1);
+			load_frag(sb, 3, a1, b1); mfma_step(a0, b0);
+			if (pb) {  // column sums of dZ (bias gradient / per-foot sums): 4 rows x 4 columns per thread per chunk
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const float4 z = *reinterpret_cast<const float4*>(sb + ba + j * 1024);
+					bsum.x += z.x; bsum.y += z.y; bsum.z += z.z; bsum.w += z.w;
+				}
+			}
+			load_frag(sb, 4, a0, b0); mfma_step(a1, b1);
+			load_frag(sb, 5, a1, b1); mfma_step(a0, b0);
+			load_frag(sb, 6, a0, b0); mfma_step(a1, b1);
+			load_frag(sb, 7, a1, b1);
+			const bool more = consumed + 1 < total;
+			const bool do_issue = more && issued < total;
+			if (do_issue) issue_prepare();
+			const int ns = (cs == 2) ? 0 : cs + 1;
+			const char* nsb = smem + ns * DW2_STAGE;
+			const int ahead = issued - (consumed + 2);
+			mfma_step(a0, b0);
+			if (more) {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				if (ahead <= 0) FIND_WAIT_VMCNT(0);
+				else FIND_WAIT_VMCNT(8);
+				__builtin_amdgcn_s_barrier();
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			mfma_ja(a1, b1, 0);
+			__builtin_amdgcn_sched_barrier(0);
+			load_frag(nsb, 0, a0, b0);  // stale stage at the very end; never used
+			if (do_issue) issue_z();
+			__builtin_amdgcn_sched_barrier(0);
+			mfma_ja(a1, b1, 1);
+			__builtin_amdgcn_sched_barrier(0);
+			if (do_issue) issue_x();
+			__builtin_amdgcn_sched_barrier(0);
+			mfma_ja(a1, b1, 2);
+			mfma_ja(a1, b1, 3);
+			if (do_issue) issue_advance();
+			cs = ns;
+			++consumed;
+		}
+	}
+
+	// ---- epilogue: accumulator (ja, jb) element (i, j) is output n = 4i + ja, k = 4j + jb (within the wave's 128x128 block)
+	{
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(pw)), 0, 65536 * 4, 0x00020000);
+		const int voff = ((wn * 128 + 16 * fh) * 256 + wk * 128 + 4 * (lane & 31)) * 4;
+#pragma unroll
+		for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int nrow = 4 * ((r & 3) + 8 * (r >> 2)) + ja;
+				typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+				u32x4 v;
+				// (value copies: __builtin_bit_cast on a vector-element lvalue reads element 0)
+				const float f0 = acc[ja][0][r], f1 = acc[ja][1][r], f2 = acc[ja][2][r], f3 = acc[ja][3][r];
+				v.x = __float_as_uint(f0); v.y = __float_as_uint(f1); v.z = __float_as_uint(f2); v.w = __float_as_uint(f3);
+				__builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, nrow * 1024, 0);
+			}
+	}
+	if (pb) {
+		__syncthreads();
+		*reinterpret_cast<float4*>(&red[wave * 256 + lane * 4]) = bsum;
+		__syncthreads();
+		pb[tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+	}
+}
+
+}  // namespace mlp
+}  // namespace find

@@ -237,6 +237,7 @@ struct DwArgs {
 	int V;
 	int spf;                // splits per foot
 	int cps;                // 32-row chunks per split
+	int v_begin;            // first row of every foot handled by this launch (0, or 16*floor(V/16) for the tail pass)
 	int Kp;                 // padded K = 256 * gridDim.x
 	float* pw;              // [n_feet*spf][256][Kp]
 	float* pb;              // [n_feet*spf][256] or nullptr
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 	const int split = blockIdx.y;
 	const int foot = split / g.spf;
 	const int sidx = split - foot * g.spf;
-	const int cpf = (g.V + 31) / 32;
+	const int cpf = (g.V - g.v_begin + 31) / 32;
 	const int q0 = sidx * g.cps;
 	const int q1 = min(q0 + g.cps, cpf);
 	const int lr = tid >> 6;         // loader row within an 8-row group
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 	auto load_chunk = [&](int q) {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const int v = q * 32 + lr + 8 * i;
+			const int v = g.v_begin + q * 32 + lr + 8 * i;
 			const bool ok = v < g.V;
 			rz[i] = ok ? *reinterpret_cast<const float4*>(dzp + (int64_t)v * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
 			if constexpr (AMODE == AMODE_MAT) {
@@ -376,6 +377,7 @@ struct ReduceWArgs {
 	int in_dim;
 	const float* pb;  // [n_feet*spf][256] or nullptr
 	int n_feet, spf;
+	int tail_base;    // index of the first per-foot tail slab (one per foot) or -1
 	float* db;        // (256) or nullptr
 	float* S;         // (n_feet,256) or nullptr
 	int nwblk;
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(256) void reduce_w_kernel(const ReduceWArgs g) {
 			const float* p = g.pb + (int64_t)f * g.spf * 256 + n;
 #pragma unroll 4
 			for (int k = 0; k < g.spf; ++k) s += p[(int64_t)k * 256];
+			if (g.tail_base >= 0) s += g.pb[((int64_t)g.tail_base + f) * 256 + n];
 			if (g.S) g.S[(int64_t)f * 256 + n] = s;
 			tot += s;
 		}
@@ -635,14 +638,21 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const int64_t row = r0 + u;
-			const bool ok = row < g.rows;
-			yv[u] = ok ? *reinterpret_cast<const float4*>(y + row * W + lane * 4) : make_float4(0, 0, 0, 0);
-#pragma unroll
-			for (int c = 0; c < 3; ++c) {
-				const float t = ok ? tanhf(z[row * 3 + c]) : 0.f;
-				d[u][c] = ok ? gout[row * 3 + c] * scale * (1.f - t * t) : 0.f;
+			yv[u] = (row < g.rows) ? *reinterpret_cast<const float4*>(y + row * W + lane * 4) : make_float4(0, 0, 0, 0);
+		}
+		// the U*3 output gradients of these rows are computed once (lanes 0..U*3-1: one tanh each) and broadcast
+		float dmine = 0.f;
+		if (lane < U * 3) {
+			const int64_t e = r0 * 3 + lane;  // rows are contiguous: element (u, c) = r0*3 + u*3 + c
+			if (e < g.rows * 3) {
+				const float t = tanhf(z[e]);
+				dmine = gout[e] * scale * (1.f - t * t);
 			}
 		}
+#pragma unroll
+		for (int u = 0; u < U; ++u)
+#pragma unroll
+			for (int c = 0; c < 3; ++c) d[u][c] = __shfl(dmine, u * 3 + c, 64);
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const int64_t row = r0 + u;
