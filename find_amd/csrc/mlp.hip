@@ -284,11 +284,11 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	const float* bias_c0 = p->col_b[0];
 	int64_t bstride_d = 0, bstride_c = 0;
 	if (p->lat_disp > 0) {
-		hipLaunchKernelGGL(latent_bias_kernel, dim3((unsigned)n_feet), dim3(W), 0, s, p->disp_w[0], ld_d0, p->disp_b[0], lat_disp, p->lat_disp, w.fbd);
+		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4), dim3(256), 0, s, p->disp_w[0], ld_d0, p->disp_b[0], lat_disp, p->lat_disp, w.fbd, (int)n_feet);
 		bias_d0 = w.fbd; bstride_d = W;
 	}
 	if (p->lat_col > 0) {
-		hipLaunchKernelGGL(latent_bias_kernel, dim3((unsigned)n_feet), dim3(W), 0, s, p->col_w[0], ld_c0, p->col_b[0], lat_col, p->lat_col, w.fbc);
+		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4), dim3(256), 0, s, p->col_w[0], ld_c0, p->col_b[0], lat_col, p->lat_col, w.fbc, (int)n_feet);
 		bias_c0 = w.fbc; bstride_c = W;
 	}
 	FIND_LAUNCH_CHECK("latent_bias_kernel");
@@ -330,7 +330,7 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 		h.out[0] = disp; h.out[1] = col;
 		h.avg_col = p->avg_col;
 		h.rows = d.rows_h;
-		const unsigned gx = (unsigned)std::min<int64_t>(cdiv(d.rows_h, 4), 2048);
+		const unsigned gx = (unsigned)std::min<int64_t>(cdiv(d.rows_h, 32), 2048);
 		hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 2), dim3(256), 0, s, h);
 		FIND_LAUNCH_CHECK("head_out_fwd_kernel");
 	}
@@ -413,45 +413,34 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
 					   int k_valid, int pe_map, float* db, float* S, hipStream_t s) {
 	if (!pos && g_dw2) {
-		// LDS-DMA kernel over the full 16-row chunks of every foot; the <= 15 leftover rows per foot go through dw_kernel
+		// LDS-DMA kernel: every foot's rows cut into spf2 contiguous runs of 16-row chunks, the <= 15 leftover rows
+		// folded into the foot's last run
 		const int cpf16 = (int)(V / 16);
-		int spf2 = 0, cps2 = 1;
+		int spf2 = 1, cps2 = 1;
 		if (cpf16 > 0) {
 			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(num_cus(), feet)));
 			cps2 = (int)cdiv(cpf16, want);
 			spf2 = (int)cdiv(cpf16, cps2);
 		}
 		const int nmain = (int)(feet * spf2);
-		const bool tail = (V % 16) != 0;
 		float* pbuf = (db || S) ? b.pb : nullptr;
-		if (nmain > 0) {
-			static bool attr_set = false;
-			if (!attr_set) {
-				(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS);
-				attr_set = true;
-			}
-			Dw2Args d2;
-			memset(&d2, 0, sizeof(d2));
-			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
-			d2.chunks_per_foot = cpf16; d2.spf = spf2; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
-			hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), DW2_LDS, s, d2);
-			FIND_LAUNCH_CHECK("dw2_kernel");
+		static bool attr_set = false;
+		if (!attr_set) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS);
+			attr_set = true;
 		}
-		if (tail) {
-			DwArgs t;
-			memset(&t, 0, sizeof(t));
-			t.dz = dz; t.dz_foot_stride = V * W; t.x = x; t.x_foot_stride = x_foot_stride; t.ldx = W;
-			t.V = (int)V; t.spf = 1; t.cps = 1; t.Kp = 256; t.v_begin = cpf16 * 16;
-			t.pw = b.pw + (int64_t)nmain * 65536; t.pb = pbuf ? pbuf + (int64_t)nmain * 256 : nullptr;
-			hipLaunchKernelGGL((dw_kernel<AMODE_MAT>), dim3(1, (unsigned)feet), dim3(512), 0, s, t);
-			FIND_LAUNCH_CHECK("dw_kernel(tail)");
-		}
+		Dw2Args d2;
+		memset(&d2, 0, sizeof(d2));
+		d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
+		d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf2; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
+		hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), DW2_LDS, s, d2);
+		FIND_LAUNCH_CHECK("dw2_kernel");
 		ReduceWArgs r;
 		memset(&r, 0, sizeof(r));
-		r.pw = b.pw; r.nsplit = nmain + (tail ? (int)feet : 0); r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
-		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf2; r.db = db; r.S = S; r.tail_base = tail ? nmain : -1;
-		r.nwblk = (int)cdiv((int64_t)256 * 256 / 4, 256);
-		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)r.nwblk + 1), dim3(256), 0, s, r);
+		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
+		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf2; r.db = db; r.S = S;
+		r.nwblk = 256 * 256 / 4 / 64;
+		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, s, r);
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
@@ -473,9 +462,9 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 	memset(&r, 0, sizeof(r));
 	r.pw = b.pw; r.nsplit = nsplit; r.Kp = a.Kp; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
-	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S; r.tail_base = -1;
-	r.nwblk = (int)cdiv((int64_t)256 * a.Kp / 4, 256);
-	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)r.nwblk + 1), dim3(256), 0, s, r);
+	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
+	r.nwblk = 256 * a.Kp / 4 / 64;
+	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), 0, s, r);
 	FIND_LAUNCH_CHECK("reduce_w_kernel");
 	return FIND_OK;
 }
@@ -586,7 +575,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		hr.dw[0] = act_d ? g->disp_w[p->n_disp] : nullptr; hr.db[0] = g->disp_b[p->n_disp];
 		hr.dw[1] = act_c ? g->col_w[p->n_col] : nullptr; hr.db[1] = g->col_b[p->n_col];
 		hr.nblk = b.nblk_out;
-		hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(256), 0, s, hr);
+		hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(1024), 0, s, hr);
 		FIND_LAUNCH_CHECK("head_out_bwd");
 	}
 
@@ -606,8 +595,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
 			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, b.pS);
-			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(256), 0, s, b.pS, b.nblk_fs, (int)n_feet, S, (float*)nullptr);
-			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet + 1), dim3(1024), 0, s, b.pS, b.nblk_fs, (int)n_feet, S, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
 			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, s);
 		} else {
@@ -615,7 +603,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		}
 		if (r != FIND_OK) return r;
 		if (L > 0) {
-			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(128), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
 			FIND_LAUNCH_CHECK("latent_grad_kernel");
 		}
 		return FIND_OK;

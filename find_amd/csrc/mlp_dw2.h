@@ -9,7 +9,7 @@
 //     (i, j = MFMA row/col).  A 128x128 wave tile therefore needs 2 LDS reads per 16 MFMAs (the 32-row GEMM needs 5), and
 //     the epilogue recombines jb = 0..3 into one coalesced 16-byte store;
 //   * schedule as gemm3: early barrier before the last MFMA step of a chunk, DMA issue interleaved, hoisted arguments.
-// Rows [16*floor(V/16), V) of every foot (at most 15) are handled by dw_kernel through extra slabs (mlp.hip).
+// Rows [16*floor(V/16), V) of every foot (at most 15) are one extra, un-pipelined chunk of the foot's last split.
 #pragma once
 #include "mlp_gemm3.h"
 
@@ -22,7 +22,8 @@ struct Dw2Args {
 	const float* x;          // rows (foot, v) or shared (x_foot_stride 0), ld 256
 	int64_t x_foot_stride;
 	int chunks_per_foot;     // floor(V / 16)
-	int spf;                 // splits per foot
+	int tail_rows;           // V % 16: leftover rows of every foot, folded in by the foot's last split
+	int spf;                 // splits per foot (>= 1)
 	int cps;                 // chunks per split
 	float* pw;               // [n_feet*spf][256][256]
 	float* pb;               // [n_feet*spf][256] or nullptr
@@ -47,8 +48,11 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 	const int q0 = sidx * g.cps;
 	const int q1 = min(q0 + g.cps, g.chunks_per_foot);
 	const int total = max(q1 - q0, 0);
+	const int tail = (sidx == g.spf - 1) ? g.tail_rows : 0;
 	float* const pw = g.pw + (int64_t)split * 65536;
 	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
+	const float* const zfoot = g.dz + (int64_t)foot * g.dz_foot_stride;
+	const float* const xfoot = g.x + (int64_t)foot * g.x_foot_stride;
 
 	f32x16 acc[4][4];
 #pragma unroll
@@ -59,14 +63,39 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 	float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
+	// DMA: wave w moves rows 4w..4w+3 of both operands; lane i the 16 bytes at column 4i
+	const unsigned d_dst = (wave * 4) * 1024;
+	// fragment addresses: row 2t + fh, 16 B at column 4*(lane&31) of this wave's 128-column block
+	const int za = fh * 1024 + (wn * 128 + 4 * (lane & 31)) * 4;
+	const int xa = 16384 + fh * 1024 + (wk * 128 + 4 * (lane & 31)) * 4;
+	const int ba = (wave * 4) * 1024 + lane * 16;  // bias partial: rows 4w..4w+3, column 4*lane
+	float4 a0, b0, a1, b1;
+	auto load_frag = [&](const char* sb, int t, float4& a, float4& b) {
+		a = *reinterpret_cast<const float4*>(sb + za + t * 2048);
+		b = *reinterpret_cast<const float4*>(sb + xa + t * 2048);
+	};
+	auto mfma_ja = [&](const float4& a, const float4& b, int ja) {
+		const float av = ja == 0 ? a.x : (ja == 1 ? a.y : (ja == 2 ? a.z : a.w));
+		acc[ja][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.x, acc[ja][0], 0, 0, 0);
+		acc[ja][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.y, acc[ja][1], 0, 0, 0);
+		acc[ja][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.z, acc[ja][2], 0, 0, 0);
+		acc[ja][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.w, acc[ja][3], 0, 0, 0);
+	};
+	auto mfma_step = [&](const float4& a, const float4& b) { mfma_ja(a, b, 0); mfma_ja(a, b, 1); mfma_ja(a, b, 2); mfma_ja(a, b, 3); };
+	auto bias_rows = [&](const char* sb) {  // column sums of dZ: 4 rows x 4 columns per thread per chunk
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float4 z = *reinterpret_cast<const float4*>(sb + ba + j * 1024);
+			bsum.x += z.x; bsum.y += z.y; bsum.z += z.z; bsum.w += z.w;
+		}
+	};
+
 	if (total > 0) {
-		const float* zb = g.dz + (int64_t)foot * g.dz_foot_stride + (int64_t)q0 * 16 * 256;
-		const float* xb = g.x + (int64_t)foot * g.x_foot_stride + (int64_t)q0 * 16 * 256;
-		// DMA: wave w moves rows 4w..4w+3 of both operands; lane i the 16 bytes at column 4i
+		const float* zb = zfoot + (int64_t)q0 * 16 * 256;
+		const float* xb = xfoot + (int64_t)q0 * 16 * 256;
 		unsigned doff[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) doff[j] = (unsigned)(((wave * 4 + j) * 256 + lane * 4) * 4);
-		const unsigned d_dst = (wave * 4) * 1024;
 		int issued = 0, consumed = 0, ps = 0;
 		const float* iz = nullptr;
 		const float* ix = nullptr;
@@ -86,24 +115,6 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 		else FIND_WAIT_VMCNT(0);
 		__builtin_amdgcn_s_barrier();
 
-		// fragment addresses: row 2t + fh, 16 B at column 4*(lane&31) of this wave's 128-column block
-		const int za = fh * 1024 + (wn * 128 + 4 * (lane & 31)) * 4;
-		const int xa = 16384 + fh * 1024 + (wk * 128 + 4 * (lane & 31)) * 4;
-		const int ba = (wave * 4) * 1024 + lane * 16;  // bias partial: rows 4w..4w+3, column 4*lane
-		float4 a0, b0, a1, b1;
-		auto load_frag = [&](const char* sb, int t, float4& a, float4& b) {
-			a = *reinterpret_cast<const float4*>(sb + za + t * 2048);
-			b = *reinterpret_cast<const float4*>(sb + xa + t * 2048);
-		};
-		auto mfma_ja = [&](const float4& a, const float4& b, int ja) {
-			const float av = ja == 0 ? a.x : (ja == 1 ? a.y : (ja == 2 ? a.z : a.w));
-			acc[ja][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.x, acc[ja][0], 0, 0, 0);
-			acc[ja][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.y, acc[ja][1], 0, 0, 0);
-			acc[ja][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.z, acc[ja][2], 0, 0, 0);
-			acc[ja][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.w, acc[ja][3], 0, 0, 0);
-		};
-		auto mfma_step = [&](const float4& a, const float4& b) { mfma_ja(a, b, 0); mfma_ja(a, b, 1); mfma_ja(a, b, 2); mfma_ja(a, b, 3); };
-
 		load_frag(smem, 0, a0, b0);
 		int cs = 0;
 		for (int c = 0; c < total; ++c) {
@@ -111,13 +122,7 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 			load_frag(sb, 1, a1, b1); mfma_step(a0, b0);
 			load_frag(sb, 2, a0, b0); mfma_step(a1, b1);
 			load_frag(sb, 3, a1, b1); mfma_step(a0, b0);
-			if (pb) {  // column sums of dZ (bias gradient / per-foot sums): 4 rows x 4 columns per thread per chunk
-#pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					const float4 z = *reinterpret_cast<const float4*>(sb + ba + j * 1024);
-					bsum.x += z.x; bsum.y += z.y; bsum.z += z.z; bsum.w += z.w;
-				}
-			}
+			if (pb) bias_rows(sb);
 			load_frag(sb, 4, a0, b0); mfma_step(a1, b1);
 			load_frag(sb, 5, a1, b1); mfma_step(a0, b0);
 			load_frag(sb, 6, a0, b0); mfma_step(a1, b1);
@@ -150,6 +155,33 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 			if (do_issue) issue_advance();
 			cs = ns;
 			++consumed;
+		}
+	}
+
+	// ---- leftover rows [16*chunks_per_foot, V) of the foot (last split only): one un-pipelined chunk through stage 0.
+	// Row addresses are clamped to the last valid row (finite data); the dZ rows past the end are then zeroed in LDS.
+	if (tail > 0) {
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();  // every wave is done reading the ring
+		unsigned toff[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) toff[j] = (unsigned)((min(wave * 4 + j, tail - 1) * 256 + lane * 4) * 4);
+		const float* tz = uniform_ptr(zfoot + (int64_t)g.chunks_per_foot * 4096);
+		const float* tx = uniform_ptr(xfoot + (int64_t)g.chunks_per_foot * 4096);
+		const unsigned tdst = __builtin_amdgcn_readfirstlane(lds_base + d_dst);
+		dma4(tz, tdst, toff[0], toff[1], toff[2], toff[3]);
+		dma4(tx, tdst + 16384, toff[0], toff[1], toff[2], toff[3]);
+		FIND_WAIT_VMCNT(0);
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			if (wave * 4 + j >= tail) *reinterpret_cast<float4*>(smem + d_dst + j * 1024 + lane * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		if (pb) bias_rows(smem);
+		const int steps = (tail + 1) >> 1;  // k-pairs that contain a valid row
+		for (int t = 0; t < steps; ++t) {
+			load_frag(smem, t, a0, b0);
+			mfma_step(a0, b0);
 		}
 	}
 

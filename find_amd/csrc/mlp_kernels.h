@@ -364,7 +364,9 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 	}
 }
 
-// dW[n, map(k)] = sum_split pw[split][n][k]   (blocks [0, nwblk));   bias / per-foot sums in the last block.
+// dW[n, map(k)] = sum_split pw[split][n][k]: blocks [0, nwblk), 64 float4 outputs each, the slab range cut 16 ways
+// across the 1024 threads and combined through LDS in a fixed order (deterministic).  Bias / per-foot sums: block
+// nwblk + f -> S[f][:], block nwblk + n_feet -> db.
 struct ReduceWArgs {
 	const float* pw;
 	int nsplit;
@@ -377,87 +379,111 @@ struct ReduceWArgs {
 	int in_dim;
 	const float* pb;  // [n_feet*spf][256] or nullptr
 	int n_feet, spf;
-	int tail_base;    // index of the first per-foot tail slab (one per foot) or -1
 	float* db;        // (256) or nullptr
 	float* S;         // (n_feet,256) or nullptr
-	int nwblk;
+	int nwblk;        // 256*Kp/4/64
 };
 
-__global__ __launch_bounds__(256) void reduce_w_kernel(const ReduceWArgs g) {
+__global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) {
+	__shared__ __attribute__((aligned(16))) float red[16 * 256];
+	const int tid = threadIdx.x;
 	if ((int)blockIdx.x >= g.nwblk) {
-		// bias: db[n] = sum_split pb[split][n];  S[foot][n] = sum over that foot's splits
+		// bias: S[foot][n] = sum over that foot's splits;  db[n] = sum over every split
 		if (g.pb == nullptr) return;
-		const int n = threadIdx.x;
-		float tot = 0.f;
-		for (int f = 0; f < g.n_feet; ++f) {
-			float s = 0.f;
-			const float* p = g.pb + (int64_t)f * g.spf * 256 + n;
-#pragma unroll 4
-			for (int k = 0; k < g.spf; ++k) s += p[(int64_t)k * 256];
-			if (g.tail_base >= 0) s += g.pb[((int64_t)g.tail_base + f) * 256 + n];
-			if (g.S) g.S[(int64_t)f * 256 + n] = s;
-			tot += s;
+		const int f = (int)blockIdx.x - g.nwblk;
+		const int n = tid & 255, q = tid >> 8;
+		const bool all = f >= g.n_feet;
+		if (!all && g.S == nullptr) return;
+		if (all && g.db == nullptr) return;
+		const int lo = all ? 0 : f * g.spf, hi = all ? g.n_feet * g.spf : (f + 1) * g.spf;
+		float s0 = 0.f, s1 = 0.f;
+		int k = lo + q;
+		for (; k + 4 < hi; k += 8) { s0 += g.pb[(int64_t)k * 256 + n]; s1 += g.pb[(int64_t)(k + 4) * 256 + n]; }
+		if (k < hi) s0 += g.pb[(int64_t)k * 256 + n];
+		red[q * 256 + n] = s0 + s1;
+		__syncthreads();
+		if (q == 0) {
+			const float t = (red[n] + red[256 + n]) + (red[512 + n] + red[768 + n]);
+			if (all) g.db[n] = t;
+			else g.S[(int64_t)f * 256 + n] = t;
 		}
-		if (g.db) g.db[n] = tot;
 		return;
 	}
-	const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-	if (i4 >= (int64_t)256 * g.Kp) return;
+	const int o = tid & 63, q = tid >> 6;  // output float4 within the block, slab slice
+	const int64_t i4 = ((int64_t)blockIdx.x * 64 + o) * 4;
 	const int n = (int)(i4 / g.Kp), k = (int)(i4 - (int64_t)n * g.Kp);
 	float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 	const float* p = g.pw + i4;
 	const int64_t stride = (int64_t)256 * g.Kp;
-	int sidx = 0;
-	for (; sidx + 4 <= g.nsplit; sidx += 4) {
+	int sidx = q;
+	for (; sidx + 48 < g.nsplit; sidx += 64) {
 		const float4 a = *reinterpret_cast<const float4*>(p + (sidx + 0) * stride);
-		const float4 b = *reinterpret_cast<const float4*>(p + (sidx + 1) * stride);
-		const float4 c = *reinterpret_cast<const float4*>(p + (sidx + 2) * stride);
-		const float4 d = *reinterpret_cast<const float4*>(p + (sidx + 3) * stride);
+		const float4 b = *reinterpret_cast<const float4*>(p + (sidx + 16) * stride);
+		const float4 c = *reinterpret_cast<const float4*>(p + (sidx + 32) * stride);
+		const float4 d = *reinterpret_cast<const float4*>(p + (sidx + 48) * stride);
 		s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
 		s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
 	}
-	for (; sidx < g.nsplit; ++sidx) {
+	for (; sidx < g.nsplit; sidx += 16) {
 		const float4 a = *reinterpret_cast<const float4*>(p + sidx * stride);
 		s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
 	}
-	const float v[4] = {s.x, s.y, s.z, s.w};
+	*reinterpret_cast<float4*>(&red[(q * 64 + o) * 4]) = s;
+	__syncthreads();
+	if (tid < 256) {
+		// thread -> scalar output (o2, j): conflict-free LDS columns
+		const int o2 = tid >> 2, j = tid & 3;
+		float t = 0.f;
 #pragma unroll
-	for (int j = 0; j < 4; ++j) {
+		for (int qq = 0; qq < 16; ++qq) t += red[(qq * 64 + o2) * 4 + j];
+		const int64_t e = ((int64_t)blockIdx.x * 64 + o2) * 4 + j;
+		const int nn = (int)(e / g.Kp), kk = (int)(e - (int64_t)nn * g.Kp);
 		int ko;
-		if (g.pe_map) ko = pe_col_to_orig(k + j, g.pe, g.in_dim);
-		else ko = (k + j < g.K_valid) ? k + j : -1;
-		if (ko >= 0) g.out[(int64_t)n * g.ld_out + ko] = v[j];
+		if (g.pe_map) ko = pe_col_to_orig(kk, g.pe, g.in_dim);
+		else ko = (kk < g.K_valid) ? kk : -1;
+		if (ko >= 0) g.out[(int64_t)nn * g.ld_out + ko] = t;
 	}
+	(void)n; (void)k;
 }
 
 // Shared-template backward of a head's first layer: because every foot multiplies the SAME trunk rows,
 //   sum_b dZ0[b,v,:] @ W  ==  (sum_b dZ0[b,v,:]) @ W      and      dW0 = (sum_b dZ0[b])^T @ H.
 // One pass over dZ0 (n_feet, V, 256) produces  zsum[v] = sum_b dZ0[b,v]  and partial per-foot column sums.
 constexpr int FS_ROWS = 16;  // rows of v per block
+constexpr int FS_FEET = 8;   // feet per LDS round
 __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ dz, int n_feet, int V, float* __restrict__ zsum,
 													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */) {
-	__shared__ __attribute__((aligned(16))) float red[4][256];
+	__shared__ __attribute__((aligned(16))) float red[FS_FEET][4][256];
 	const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
 	const int v0 = blockIdx.x * FS_ROWS;
 	float4 zs[FS_ROWS / 4];
 #pragma unroll
 	for (int i = 0; i < FS_ROWS / 4; ++i) zs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-	for (int b = 0; b < n_feet; ++b) {
-		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-		const float* base = dz + ((int64_t)b * V) * 256 + cg * 4;
+	for (int b0 = 0; b0 < n_feet; b0 += FS_FEET) {
+		const int nb = min(FS_FEET, n_feet - b0);
+		// all loads of the round are independent: FS_FEET x 4 float4 in flight per thread
 #pragma unroll
-		for (int i = 0; i < FS_ROWS / 4; ++i) {
-			const int v = v0 + rl + 4 * i;
-			if (v < V) {
-				const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)v * 256);
-				zs[i].x += x.x; zs[i].y += x.y; zs[i].z += x.z; zs[i].w += x.w;
-				acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+		for (int bb = 0; bb < FS_FEET; ++bb) {
+			if (bb < nb) {
+				float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+				const float* base = dz + ((int64_t)(b0 + bb) * V) * 256 + cg * 4;
+#pragma unroll
+				for (int i = 0; i < FS_ROWS / 4; ++i) {
+					const int v = v0 + rl + 4 * i;
+					if (v < V) {
+						const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)v * 256);
+						zs[i].x += x.x; zs[i].y += x.y; zs[i].z += x.z; zs[i].w += x.w;
+						acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+					}
+				}
+				*reinterpret_cast<float4*>(&red[bb][rl][cg * 4]) = acc;
 			}
 		}
 		__syncthreads();
-		*reinterpret_cast<float4*>(&red[rl][cg * 4]) = acc;
+		for (int bb = 0; bb < nb; ++bb)
+			pS[((int64_t)blockIdx.x * n_feet + b0 + bb) * 256 + threadIdx.x] =
+				(red[bb][0][threadIdx.x] + red[bb][1][threadIdx.x]) + (red[bb][2][threadIdx.x] + red[bb][3][threadIdx.x]);
 		__syncthreads();
-		pS[((int64_t)blockIdx.x * n_feet + b) * 256 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 	}
 #pragma unroll
 	for (int i = 0; i < FS_ROWS / 4; ++i) {
@@ -466,21 +492,33 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 	}
 }
 
-// S[b][n] = sum_blk pS[blk][b][n];  db[n] = sum_b S[b][n]
-__global__ __launch_bounds__(256) void footsum_reduce_kernel(const float* __restrict__ pS, int nblk, int n_feet, float* __restrict__ S, float* __restrict__ db_partial) {
-	const int b = blockIdx.x, n = threadIdx.x;
-	float s = 0.f;
-	const float* p = pS + (int64_t)b * 256 + n;
-#pragma unroll 8
-	for (int k = 0; k < nblk; ++k) s += p[(int64_t)k * n_feet * 256];
-	S[(int64_t)b * 256 + n] = s;
-}
-
-__global__ void colsum_small_kernel(const float* __restrict__ S, int n_feet, float* __restrict__ db) {
-	const int n = threadIdx.x;
-	float s = 0.f;
-	for (int b = 0; b < n_feet; ++b) s += S[(int64_t)b * 256 + n];
-	db[n] = s;
+// S[b][n] = sum_blk pS[blk][b][n] (block b < n_feet);  db[n] = sum_b S[b][n] (block n_feet, same summation tree per foot,
+// so db == sum of the S rows bit for bit).  1024 threads: 4 slices of the block range per column.
+__global__ __launch_bounds__(1024) void footsum_reduce_kernel(const float* __restrict__ pS, int nblk, int n_feet, float* __restrict__ S, float* __restrict__ db) {
+	__shared__ float red[4][256];
+	const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
+	const bool all = (int)blockIdx.x >= n_feet;
+	const int f_lo = all ? 0 : blockIdx.x, f_hi = all ? n_feet : blockIdx.x + 1;
+	float tot = 0.f;
+	for (int f = f_lo; f < f_hi; ++f) {
+		const float* p = pS + (int64_t)f * 256 + n;
+		float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+		int k = q;
+		for (; k + 12 < nblk; k += 16) {
+			s0 += p[(int64_t)k * n_feet * 256];
+			s1 += p[(int64_t)(k + 4) * n_feet * 256];
+			s2 += p[(int64_t)(k + 8) * n_feet * 256];
+			s3 += p[(int64_t)(k + 12) * n_feet * 256];
+		}
+		for (; k < nblk; k += 4) s0 += p[(int64_t)k * n_feet * 256];
+		red[q][n] = (s0 + s1) + (s2 + s3);
+		__syncthreads();
+		const float t = (red[0][n] + red[1][n]) + (red[2][n] + red[3][n]);
+		__syncthreads();
+		if (!all && q == 0) S[(int64_t)f * 256 + n] = t;
+		tot += t;
+	}
+	if (all && q == 0 && db) db[n] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -525,26 +563,50 @@ __global__ void repack_kernel(const RepackArgs a) {
 // Per-foot latent bias of a head's first layer (model.py:428-437 folded into a bias):
 //   fb[foot][n] = b[n] + sum_j Wfull[n][256 + j] * lat[foot][j]
 // ---------------------------------------------------------------------------------------------
-__global__ void latent_bias_kernel(const float* Wfull, int ldw, const float* b, const float* lat, int L, float* fb) {
-	const int n = threadIdx.x, foot = blockIdx.x;
-	float s = b[n];
+// grid 64 x 256 threads: wave -> output n, lanes over the latent dimension (coalesced row of Wfull), loop over feet.
+__global__ __launch_bounds__(256) void latent_bias_kernel(const float* Wfull, int ldw, const float* b, const float* lat, int L, float* fb, int n_feet) {
+	const int lane = threadIdx.x & 63;
+	const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
 	const float* wr = Wfull + (int64_t)n * ldw + W;
-	const float* lv = lat + (int64_t)foot * L;
-	for (int j = 0; j < L; ++j) s = fmaf(wr[j], lv[j], s);
-	fb[(int64_t)foot * W + n] = s;
+	const float bn = b[n];
+	for (int foot = 0; foot < n_feet; ++foot) {
+		const float* lv = lat + (int64_t)foot * L;
+		float s = 0.f;
+		for (int j = lane; j < L; j += 64) s = fmaf(wr[j], lv[j], s);
+		s = wave_sum(s);
+		if (lane == 0) fb[(int64_t)foot * W + n] = bn + s;
+	}
 }
 
 // latent gradients from S[foot][n] = sum_v dZ0[(foot,v)][n]:
 //   dlat[foot][j] = sum_n S[foot][n] * Wfull[n][256+j];   dWfull[n][256+j] = sum_foot S[foot][n] * lat[foot][j]
-__global__ void latent_grad_kernel(const float* Wfull, int ldw, const float* lat, int L, const float* S, int n_feet,
-								   float* dlat, float* dWfull) {
+// 256 threads.  Blocks [0, n_feet): 4 groups of 64 lanes split n, lanes over j (coalesced), LDS-combined.
+// Blocks [n_feet, n_feet + 256): one output row n of dWfull's latent columns.
+__global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, int ldw, const float* lat, int L, const float* S, int n_feet,
+														   float* dlat, float* dWfull) {
+	__shared__ float red[4][64];
 	const int b = blockIdx.x;
+	const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
 	if (b < n_feet) {
 		if (dlat == nullptr) return;
-		for (int j = threadIdx.x; j < L; j += blockDim.x) {
-			float s = 0.f;
-			for (int n = 0; n < W; ++n) s = fmaf(S[(int64_t)b * W + n], Wfull[(int64_t)n * ldw + W + j], s);
-			dlat[(int64_t)b * L + j] = s;
+		for (int j0 = 0; j0 < L; j0 += 64) {
+			const int j = j0 + lane;
+			float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+			if (j < L) {
+				const float* wp = Wfull + (int64_t)(q * 64) * ldw + W + j;
+				const float* sp = S + (int64_t)b * W + q * 64;
+#pragma unroll 4
+				for (int n = 0; n < 64; n += 4) {
+					s0 = fmaf(sp[n + 0], wp[(int64_t)(n + 0) * ldw], s0);
+					s1 = fmaf(sp[n + 1], wp[(int64_t)(n + 1) * ldw], s1);
+					s2 = fmaf(sp[n + 2], wp[(int64_t)(n + 2) * ldw], s2);
+					s3 = fmaf(sp[n + 3], wp[(int64_t)(n + 3) * ldw], s3);
+				}
+			}
+			red[q][lane] = (s0 + s1) + (s2 + s3);
+			__syncthreads();
+			if (q == 0 && j < L) dlat[(int64_t)b * L + j] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+			__syncthreads();
 		}
 	} else {
 		const int n = b - n_feet;  // 0..255
@@ -570,6 +632,7 @@ struct HeadOutArgs {
 	int64_t rows;
 };
 
+// 16 lanes per row (4 rows per wave, 2 row groups in flight): lane part p holds columns 4p + 64i, i = 0..3.
 __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) {
 	const int head = blockIdx.y;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -579,24 +642,43 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) 
 	float* z = head ? g.z[1] : g.z[0];
 	float* out = head ? g.out[1] : g.out[0];
 	if (out == nullptr) return;
-	const float4 w0 = *reinterpret_cast<const float4*>(w + 0 * W + lane * 4);
-	const float4 w1 = *reinterpret_cast<const float4*>(w + 1 * W + lane * 4);
-	const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * W + lane * 4);
-	const float b0 = b[0], b1 = b[1], b2 = b[2];
-	float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-	if (head && g.avg_col) { a0 = g.avg_col[0]; a1 = g.avg_col[1]; a2 = g.avg_col[2]; }
-	for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < g.rows; row += (int64_t)gridDim.x * 4) {
-		const float4 xv = *reinterpret_cast<const float4*>(x + row * W + lane * 4);
-		float s0 = xv.x * w0.x + xv.y * w0.y + xv.z * w0.z + xv.w * w0.w;
-		float s1 = xv.x * w1.x + xv.y * w1.y + xv.z * w1.z + xv.w * w1.w;
-		float s2 = xv.x * w2.x + xv.y * w2.y + xv.z * w2.z + xv.w * w2.w;
-		s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-		if (lane < 3) {
-			const float zz = (lane == 0 ? s0 + b0 : (lane == 1 ? s1 + b1 : s2 + b2));
-			const float t = tanhf(zz);
-			if (z) z[row * 3 + lane] = zz;
-			const float av = (lane == 0 ? a0 : (lane == 1 ? a1 : a2));
-			out[row * 3 + lane] = head ? (av + 0.5f * (1.0f + t)) : 0.1f * t;
+	const int part = lane & 15, sub = lane >> 4;
+	float4 wv[3][4];
+#pragma unroll
+	for (int c = 0; c < 3; ++c)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) wv[c][i] = *reinterpret_cast<const float4*>(w + c * W + part * 4 + 64 * i);
+	const int c3 = part < 3 ? part : 0;
+	const float bc = b[c3];
+	const float av = (head && g.avg_col) ? g.avg_col[c3] : 0.f;
+	constexpr int U = 2;
+	for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * (4 * U); r0 < g.rows; r0 += (int64_t)gridDim.x * 4 * (4 * U)) {
+		float4 xv[U][4];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t row = r0 + u * 4 + sub;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				xv[u][i] = (row < g.rows) ? *reinterpret_cast<const float4*>(x + row * W + part * 4 + 64 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t row = r0 + u * 4 + sub;
+			float sc[3];
+#pragma unroll
+			for (int c = 0; c < 3; ++c) {
+				float t = 0.f;
+#pragma unroll
+				for (int i = 0; i < 4; ++i) t += xv[u][i].x * wv[c][i].x + xv[u][i].y * wv[c][i].y + xv[u][i].z * wv[c][i].z + xv[u][i].w * wv[c][i].w;
+				t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+				sc[c] = t;
+			}
+			if (part < 3 && row < g.rows) {
+				const float zz = (part == 0 ? sc[0] : (part == 1 ? sc[1] : sc[2])) + bc;
+				const float t = tanhf(zz);
+				if (z) z[row * 3 + part] = zz;
+				out[row * 3 + part] = head ? (av + 0.5f * (1.0f + t)) : 0.1f * t;
+			}
 		}
 	}
 }
@@ -683,7 +765,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 	if (k < 3) pb[(int64_t)blockIdx.x * 4 + k] = redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k];
 }
 
-// grid (12, 2 heads): block handles 64 of the 768 dW outputs; 4 partial-groups per output, LDS-combined.
+// grid (12, 2 heads) x 1024 threads: block handles 64 of the 768 dW outputs, the partial range cut 16 ways, LDS-combined.
 struct HeadOutReduceArgs {
 	const float* pw[2];
 	const float* pb[2];
@@ -691,26 +773,39 @@ struct HeadOutReduceArgs {
 	float* db[2];
 	int nblk;
 };
-__global__ __launch_bounds__(256) void head_out_reduce_kernel(const HeadOutReduceArgs g) {
+__global__ __launch_bounds__(1024) void head_out_reduce_kernel(const HeadOutReduceArgs g) {
 	const int head = blockIdx.y;
 	float* dw = head ? g.dw[1] : g.dw[0];
 	if (dw == nullptr) return;
 	const float* pw = head ? g.pw[1] : g.pw[0];
 	const float* pb = head ? g.pb[1] : g.pb[0];
 	float* db = head ? g.db[1] : g.db[0];
-	__shared__ float red[4][64];
+	__shared__ float red[16][64];
+	__shared__ float redb[16][4];
 	const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
 	const int o = blockIdx.x * 64 + j;  // 0..767
-	float s = 0.f;
-#pragma unroll 8
-	for (int i = q; i < g.nblk; i += 4) s += pw[(int64_t)i * 768 + o];
-	red[q][j] = s;
-	__syncthreads();
-	if (q == 0) dw[o] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-	if (blockIdx.x == 0 && threadIdx.x < 3) {
+	float s0 = 0.f, s1 = 0.f;
+	int i = q;
+	for (; i + 16 < g.nblk; i += 32) { s0 += pw[(int64_t)i * 768 + o]; s1 += pw[(int64_t)(i + 16) * 768 + o]; }
+	if (i < g.nblk) s0 += pw[(int64_t)i * 768 + o];
+	red[q][j] = s0 + s1;
+	if (blockIdx.x == 0 && j < 3) {
 		float t = 0.f;
-		for (int i = 0; i < g.nblk; ++i) t += pb[(int64_t)i * 4 + threadIdx.x];
-		db[threadIdx.x] = t;
+		for (int k = q; k < g.nblk; k += 16) t += pb[(int64_t)k * 4 + j];
+		redb[q][j] = t;
+	}
+	__syncthreads();
+	if (q == 0) {
+		float t = 0.f;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) t += red[k][j];
+		dw[o] = t;
+		if (blockIdx.x == 0 && j < 3) {
+			float u = 0.f;
+#pragma unroll
+			for (int k = 0; k < 16; ++k) u += redb[k][j];
+			db[j] = u;
+		}
 	}
 }
 
