@@ -125,7 +125,8 @@ static int g_gemm_mode = 64;
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
-static int g_dw2 = 1;    // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
+static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
+static int g_dw2_min_cps = 8;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
 static int g_num_cus = 0;
 
 static int num_cus() {
@@ -419,7 +420,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 		int spf2 = 1, cps2 = 1;
 		if (cpf16 > 0) {
 			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(num_cus(), feet)));
-			cps2 = (int)cdiv(cpf16, want);
+			cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(g_dw2_min_cps, cpf16));  // few, long runs: slab traffic
 			spf2 = (int)cdiv(cpf16, cps2);
 		}
 		const int nmain = (int)(feet * spf2);
@@ -595,7 +596,8 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
 			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, b.pS);
-			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet + 1), dim3(1024), 0, s, b.pS, b.nblk_fs, (int)n_feet, S, gb[0]);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, s, b.pS, b.nblk_fs, (int)n_feet, S);
+			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
 			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, s);
 		} else {
@@ -657,6 +659,11 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "ablate") == 0) {
 		g_ablate = (int)value;
+		return FIND_OK;
+	}
+	if (strcmp(key, "dw2_min_cps") == 0) {
+		FIND_REQUIRE(value >= 1, "find_set_tuning: dw2_min_cps must be >= 1");
+		g_dw2_min_cps = (int)value;
 		return FIND_OK;
 	}
 	if (strcmp(key, "dw2") == 0) {

@@ -492,33 +492,32 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 	}
 }
 
-// S[b][n] = sum_blk pS[blk][b][n] (block b < n_feet);  db[n] = sum_b S[b][n] (block n_feet, same summation tree per foot,
-// so db == sum of the S rows bit for bit).  1024 threads: 4 slices of the block range per column.
-__global__ __launch_bounds__(1024) void footsum_reduce_kernel(const float* __restrict__ pS, int nblk, int n_feet, float* __restrict__ S, float* __restrict__ db) {
+// S[b][n] = sum_blk pS[blk][b][n]: block per foot, 1024 threads = 4 slices of the block range per column.
+__global__ __launch_bounds__(1024) void footsum_reduce_kernel(const float* __restrict__ pS, int nblk, int n_feet, float* __restrict__ S) {
 	__shared__ float red[4][256];
 	const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
-	const bool all = (int)blockIdx.x >= n_feet;
-	const int f_lo = all ? 0 : blockIdx.x, f_hi = all ? n_feet : blockIdx.x + 1;
-	float tot = 0.f;
-	for (int f = f_lo; f < f_hi; ++f) {
-		const float* p = pS + (int64_t)f * 256 + n;
-		float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-		int k = q;
-		for (; k + 12 < nblk; k += 16) {
-			s0 += p[(int64_t)k * n_feet * 256];
-			s1 += p[(int64_t)(k + 4) * n_feet * 256];
-			s2 += p[(int64_t)(k + 8) * n_feet * 256];
-			s3 += p[(int64_t)(k + 12) * n_feet * 256];
-		}
-		for (; k < nblk; k += 4) s0 += p[(int64_t)k * n_feet * 256];
-		red[q][n] = (s0 + s1) + (s2 + s3);
-		__syncthreads();
-		const float t = (red[0][n] + red[1][n]) + (red[2][n] + red[3][n]);
-		__syncthreads();
-		if (!all && q == 0) S[(int64_t)f * 256 + n] = t;
-		tot += t;
+	const int f = blockIdx.x;
+	const float* p = pS + (int64_t)f * 256 + n;
+	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+	int k = q;
+	for (; k + 12 < nblk; k += 16) {
+		s0 += p[(int64_t)k * n_feet * 256];
+		s1 += p[(int64_t)(k + 4) * n_feet * 256];
+		s2 += p[(int64_t)(k + 8) * n_feet * 256];
+		s3 += p[(int64_t)(k + 12) * n_feet * 256];
 	}
-	if (all && q == 0 && db) db[n] = tot;
+	for (; k < nblk; k += 4) s0 += p[(int64_t)k * n_feet * 256];
+	red[q][n] = (s0 + s1) + (s2 + s3);
+	__syncthreads();
+	if (q == 0) S[(int64_t)f * 256 + n] = (red[0][n] + red[1][n]) + (red[2][n] + red[3][n]);
+}
+
+// db[n] = sum_b S[b][n]
+__global__ void colsum_small_kernel(const float* __restrict__ S, int n_feet, float* __restrict__ db) {
+	const int n = threadIdx.x;
+	float s = 0.f;
+	for (int b = 0; b < n_feet; ++b) s += S[(int64_t)b * 256 + n];
+	db[n] = s;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -140,6 +140,38 @@ def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights):
 
 
 # ----------------------------------------------------------------------------------------------- registration
+class _LatentGather(torch.autograd.Function):
+	"""rows = table[idx]   (LatentVector.__getitem__, model.py:131-152); deterministic scatter backward."""
+
+	@staticmethod
+	def forward(ctx, table, idx):
+		_require_gpu(table, idx)
+		L = _lib.lib()
+		if table.dim() != 2 or idx.dim() != 1 or idx.dtype != torch.int64:
+			raise RuntimeError(f'find_amd.latent_gather: table (rows, dim) and int64 idx (n) expected, got {tuple(table.shape)} / {tuple(idx.shape)} {idx.dtype}')
+		table, idx = _c(table), _c(idx)
+		out = torch.empty(idx.shape[0], table.shape[1], device=table.device, dtype=torch.float32)
+		check(L.find_latent_gather_fwd(ptr(table), table.shape[0], table.shape[1], ptr(idx), idx.shape[0], ptr(out), current_stream(table.device)),
+			  'find_latent_gather_fwd')
+		ctx.save_for_backward(idx)
+		ctx.shape = tuple(table.shape)
+		return out
+
+	@staticmethod
+	def backward(ctx, g):
+		L = _lib.lib()
+		idx, = ctx.saved_tensors
+		g = _c(g)
+		d_table = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+		check(L.find_latent_gather_bwd(ptr(g), ptr(idx), idx.shape[0], ctx.shape[0], ctx.shape[1], ptr(d_table), current_stream(g.device)),
+			  'find_latent_gather_bwd')
+		return d_table, None
+
+
+def latent_gather(table, idx):
+	return _LatentGather.apply(table, idx)
+
+
 class _Register(torch.autograd.Function):
 	"""X = ((verts + disp) * S) @ R(euler XYZ) + t     (model.py:481-491)."""
 

@@ -88,9 +88,10 @@ class LatentVector(nn.Module):
 		return self.labels.index(label)
 
 	def __getitem__(self, idx):
-		if isinstance(idx, torch.Tensor) and idx.dim() == 1 and idx.dtype in (torch.int64, torch.int32):
-			# same rows as self.data[idx]; index_select's backward is an index_add instead of a sort-based index_put
-			return self.data.index_select(0, idx.to(self.data.device))
+		if isinstance(idx, torch.Tensor) and idx.dim() == 1 and idx.dtype in (torch.int64, torch.int32) and self.data.is_cuda \
+				and self.data.dtype == torch.float32:
+			# same rows as self.data[idx]; the backward is a deterministic scatter kernel instead of a sort-based index_put
+			return FN.latent_gather(self.data, idx.to(device=self.data.device, dtype=torch.int64))
 		if isinstance(idx, (int, torch.Tensor)):
 			return self.data[idx]
 		if isinstance(idx, str):

@@ -109,6 +109,16 @@ int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t
 int find_set_tuning(const char* key, int64_t value);
 
 /* ------------------------------------------------------------------------------------------------
+ * Latent-table lookup.  Replaces LatentVector.__getitem__ with a tensor of indices (src/model/model.py:131-152;
+ * call sites src/model/model.py:360-372 get_meshes_from_batch) and the index_put its autograd runs backward.
+ * table (n_rows, dim) fp32; idx (n_idx) int64, negative values count from the end; an out-of-range index yields a
+ * NaN row (no host synchronisation here).  The backward owns every table element by one thread and sums the
+ * matching rows in index order: deterministic with duplicates, untouched rows come out zero.
+ * ---------------------------------------------------------------------------------------------- */
+int find_latent_gather_fwd(const float* table, int64_t n_rows, int64_t dim, const int64_t* idx, int64_t n_idx, float* out, void* stream);
+int find_latent_gather_bwd(const float* d_out, const int64_t* idx, int64_t n_idx, int64_t n_rows, int64_t dim, float* d_table, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Similarity registration  X = ((v + disp) * S) @ R(euler 'XYZ') + t.
  * Replaces euler_angles_to_matrix + Transform3d().scale().rotate().translate().transform_points
  * in NeuralDisplacementField.get_meshes (src/model/model.py:481-491).

@@ -225,3 +225,29 @@ def test_get_meshes_matches_oracle(golden_main):
 	assert res['meshes'].verts_padded().shape == (N, V, 3)
 	assert torch.equal(res['meshes'].faces_padded()[2].cpu(), faces)
 	assert (res['meshes'].textures.verts_features_padded() - res['col']).abs().max().item() == 0
+
+
+@pytest.mark.gpu
+def test_latent_gather_matches_indexing_and_scatters_deterministically():
+	"""LatentVector lookup (model.py:131-152): rows and gradient identical to table[idx], duplicates and negatives included."""
+	from find_amd import functional as FN
+	dev = torch.device('cuda:0')
+	g = torch.Generator().manual_seed(3)
+	table = torch.randn(37, 100, generator=g).to(dev).requires_grad_(True)
+	idx = torch.tensor([5, 0, 36, 5, -1, 17, 5, 0], device=dev)
+	out = FN.latent_gather(table, idx)
+	ref_t = table.detach().clone().requires_grad_(True)
+	ref = ref_t[idx]
+	assert torch.equal(out, ref)
+	w = torch.randn(out.shape, generator=g).to(dev)
+	(out * w).sum().backward()
+	(ref * w).sum().backward()
+	# sums of <= 3 terms in index order: equal to fp32 rounding of any order within 1 ulp; compare tightly
+	assert torch.allclose(table.grad, ref_t.grad, rtol=1e-6, atol=1e-7)
+	assert torch.count_nonzero(table.grad[1]) == 0
+	g1 = table.grad.clone()
+	table.grad = None
+	(FN.latent_gather(table, idx) * w).sum().backward()
+	assert torch.equal(g1, table.grad)
+	bad = FN.latent_gather(table.detach(), torch.tensor([40], device=dev))
+	assert torch.isnan(bad).all()
