@@ -126,7 +126,7 @@ static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
 static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
 static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
-static int g_dw2_min_cps = 8;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
+static int g_dw2_min_cps = 4;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
 static int g_num_cus = 0;
 
 static int num_cus() {
@@ -285,11 +285,11 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	const float* bias_c0 = p->col_b[0];
 	int64_t bstride_d = 0, bstride_c = 0;
 	if (p->lat_disp > 0) {
-		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4), dim3(256), 0, s, p->disp_w[0], ld_d0, p->disp_b[0], lat_disp, p->lat_disp, w.fbd, (int)n_feet);
+		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4, (unsigned)n_feet), dim3(256), 0, s, p->disp_w[0], ld_d0, p->disp_b[0], lat_disp, p->lat_disp, w.fbd);
 		bias_d0 = w.fbd; bstride_d = W;
 	}
 	if (p->lat_col > 0) {
-		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4), dim3(256), 0, s, p->col_w[0], ld_c0, p->col_b[0], lat_col, p->lat_col, w.fbc, (int)n_feet);
+		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4, (unsigned)n_feet), dim3(256), 0, s, p->col_w[0], ld_c0, p->col_b[0], lat_col, p->lat_col, w.fbc);
 		bias_c0 = w.fbc; bstride_c = W;
 	}
 	FIND_LAUNCH_CHECK("latent_bias_kernel");

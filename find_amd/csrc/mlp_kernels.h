@@ -562,19 +562,17 @@ __global__ void repack_kernel(const RepackArgs a) {
 // Per-foot latent bias of a head's first layer (model.py:428-437 folded into a bias):
 //   fb[foot][n] = b[n] + sum_j Wfull[n][256 + j] * lat[foot][j]
 // ---------------------------------------------------------------------------------------------
-// grid 64 x 256 threads: wave -> output n, lanes over the latent dimension (coalesced row of Wfull), loop over feet.
-__global__ __launch_bounds__(256) void latent_bias_kernel(const float* Wfull, int ldw, const float* b, const float* lat, int L, float* fb, int n_feet) {
+// grid (64, n_feet) x 256 threads: wave -> output n of one foot, lanes over the latent dimension (coalesced row of Wfull).
+__global__ __launch_bounds__(256) void latent_bias_kernel(const float* Wfull, int ldw, const float* b, const float* lat, int L, float* fb) {
 	const int lane = threadIdx.x & 63;
 	const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const int foot = blockIdx.y;
 	const float* wr = Wfull + (int64_t)n * ldw + W;
-	const float bn = b[n];
-	for (int foot = 0; foot < n_feet; ++foot) {
-		const float* lv = lat + (int64_t)foot * L;
-		float s = 0.f;
-		for (int j = lane; j < L; j += 64) s = fmaf(wr[j], lv[j], s);
-		s = wave_sum(s);
-		if (lane == 0) fb[(int64_t)foot * W + n] = bn + s;
-	}
+	const float* lv = lat + (int64_t)foot * L;
+	float s = 0.f;
+	for (int j = lane; j < L; j += 64) s = fmaf(wr[j], lv[j], s);
+	s = wave_sum(s);
+	if (lane == 0) fb[(int64_t)foot * W + n] = b[n] + s;
 }
 
 // latent gradients from S[foot][n] = sum_v dZ0[(foot,v)][n]:
