@@ -1,6 +1,7 @@
 // C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
 #include "mlp_dw2.h"
+#include "mlp_gemm4.h"
 
 namespace find {
 namespace mlp {
@@ -124,6 +125,8 @@ static void launch_gemm_bm(int bm, const GemmArgs& a, int64_t feet, hipStream_t 
 static int g_gemm_mode = 64;
 static int g_ablate = 0;
 static unsigned long long* g_dbg = nullptr;
+static int g_gemm4 = 1;  // 1: K=256 single-segment MAT launches use gemm4_kernel (W resident in LDS, 2 waves per SIMD)
+static int64_t g_gemm4_min_units = 1024;
 static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
 static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
 static int g_dw2_min_cps = 4;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
@@ -167,6 +170,25 @@ static void launch_gemm3_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), lds, s, a);
 }
 
+template <int EPI>
+static void launch_gemm4_t(Gemm2Args a, int64_t feet, hipStream_t s) {
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM4_LDS);
+		attr_set = true;
+	}
+	a.tiles_per_foot = (int)cdiv(a.V, 32);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	const int grid = std::max(16, (num_cus() / 16) * 16);  // pairs of column halves, mates 8 blocks apart (same XCD)
+	hipLaunchKernelGGL((gemm4_kernel<EPI>), dim3(grid), dim3(512), GEMM4_LDS, s, a);
+}
+
+static void launch_gemm4(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU>(a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK>(a, feet, s);
+	else launch_gemm4_t<EPI_NONE>(a, feet, s);
+}
+
 template <int BM>
 static void launch_gemm3(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (epi == EPI_BIAS_RELU) launch_gemm3_t<BM, EPI_BIAS_RELU>(a, feet, s);
@@ -193,6 +215,11 @@ static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hip
 		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = g_ablate; b.dbg = g_dbg;
 		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
 		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
+		// K = 256, one segment, enough 32-row units to give every SIMD of the chip work: W-resident kernel
+		if (g_gemm4 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet * 2 >= g_gemm4_min_units) {
+			launch_gemm4(epi, b, feet, s);
+			return;
+		}
 		if (g_gemm3 && amode == AMODE_MAT && !big) {
 			launch_gemm3<64>(epi, b, feet, s);  // (the 128-row instantiation of gemm3 spills; 128-row tiles stay on gemm2)
 		} else if (big) launch_gemm2<128>(amode, epi, b, feet, s);
@@ -668,6 +695,14 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "dw2") == 0) {
 		g_dw2 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "gemm4") == 0) {
+		g_gemm4 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "gemm4_min_units") == 0) {
+		g_gemm4_min_units = value;
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm3") == 0) {
