@@ -17,6 +17,7 @@ L = _lib.lib()
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 _lib.check(L.find_set_tuning(b'gemm', mode if mode in (0, 64, 128) else 64), 'tuning')
 _lib.check(L.find_set_tuning(b'gemm3', 1 if mode == 3 else 0), 'tuning')
+_lib.check(L.find_set_tuning(b'gemm4', 1 if mode == 4 else 0), 'tuning')
 _lib.check(L.find_set_tuning(b'ablate', int(sys.argv[5]) if len(sys.argv) > 5 else 0), 'tuning')
 rows = n_feet * n_pts
 g = torch.Generator().manual_seed(0)
