@@ -38,6 +38,11 @@ MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 MAC_HEADS_FWD = (456 + 356) * 256 + 4 * 256 * 256 + 2 * 3 * 256
 
 
+# HBM-side traffic of one launch of the dominant kernel, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes (tools/profile_round.sh; profiles/r01_gemm4_pmc_summary.txt): 2 x 71.04 MB fetched + 112.9 MB written.
+GEMM_TRAFFIC_BYTES = 255.0e6
+
+
 def executed_flops_per_step(n_feet, n_verts):
 	"""fwd+bwd flops this build executes for one batch with a shared template (per-foot latent columns folded into a bias)."""
 	trunk_fwd = MAC_TRUNK_FWD
@@ -205,9 +210,11 @@ def main():
 					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
 					   'step_tflops_executed': fl_exec / (ms_step * 1e-3) / 1e12,
 					   'step_tflops_reference_equiv': fl_ref / (ms_step * 1e-3) / 1e12},
-			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm2_kernel<64,0,1> (Linear 256->256 + ReLU over 110240 rows, fp32 MFMA)',
+			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm4_kernel<1> (Linear 256->256 + bias + ReLU over 110240 rows, fp32 MFMA)',
 						 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
-						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': None},
+						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES,
+						 'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
+										 'profiles/r01_gemm4_pmc_summary.txt; algorithmic 226.0e6'},
 		}
 		if world == 1 and not args.no_cpu_baseline:
 			out['cpu_baseline'] = cpu_baseline()

@@ -12,7 +12,7 @@ LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'libfind_hip.so')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC] + os.environ.get('FIND_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def _sources():

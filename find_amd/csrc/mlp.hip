@@ -216,9 +216,7 @@ static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hip
 		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
 		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
 		// K = 256, one segment, enough 32-row units to give every SIMD of the chip work: W-resident kernel
-		const int64_t g4_pairs = std::max(16, (num_cus() / 16) * 16) / 2;
-		const bool g4_span_ok = cdiv(cdiv(a.V, 32) * feet, g4_pairs) / cdiv(a.V, 32) + 2 <= GEMM4_MAX_FEET;  // feet per workgroup
-		if (g_gemm4 && g4_span_ok && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet * 2 >= g_gemm4_min_units) {
+		if (g_gemm4 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet * 2 >= g_gemm4_min_units) {
 			launch_gemm4(epi, b, feet, s);
 			return;
 		}

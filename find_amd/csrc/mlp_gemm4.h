@@ -14,23 +14,22 @@
 // LDS layout of the W half: row R = 4*(n & 31) + (n >> 5) (so the four 32-column blocks of a lane are 1 KB apart: immediate
 // offsets), 1 KB per row, 16-B slot index XORed with (n & 15): any 16 consecutive lanes of a ds_read_b128 hit 16 distinct
 // slots of a 256-B bank row.  The swizzle is applied on the DMA source address; the LDS side stays lane-linear.
+//
+// Measured (profiles/r01_gemm4_notes.md): 315-300 K shader cycles per launch at the C2 shape against 221 K for the MFMAs alone
+// (SQ_VALU_MFMA_BUSY_CYCLES / cycles = 0.74), s_waitcnt stalls ~4%.  Variants tried and dropped, all within +-3% of this one:
+// hand-counted vmcnt for the A loads (asm-issued) so the next unit never waits for the previous unit's stores; 16-byte stores
+// with the operand roles swapped and the bias folded into the accumulator init; one wave per SIMD with 64x128 wave tiles (main
+// loop at 96% of the MFMA issue bound in isolation, but the epilogue is then dead time) and the same with two accumulator sets
+// draining the previous unit under the MFMAs (the slices are not absorbed: every non-MFMA instruction of the wave costs
+// matrix-pipe issue time).  What is left is instruction issue: ~0.6 non-MFMA instructions per MFMA.
 #pragma once
 #include "mlp_gemm3.h"
 
 namespace find {
 namespace mlp {
 
-constexpr int GEMM4_MAX_FEET = 32;   // feet a workgroup's row range may span (their bias rows are staged in LDS)
-constexpr int GEMM4_LDS = 128 * 1024 + GEMM4_MAX_FEET * 128 * 4;
+constexpr int GEMM4_LDS = 128 * 1024;
 constexpr int GEMM4_PD = 3;  // A prefetch distance in 32-k chunks (ring of 4)
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// A-fragment load issued from inline asm so that ITS completion is tracked by hand (see the vmcnt notes in the kernel):
-// the waitcnt pass would otherwise wait for every epilogue store of the previous unit before the first MFMA of the next.
-__device__ __forceinline__ void aload16(f32x4& dst, const float4* p) {
-	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
-}
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
@@ -46,11 +45,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 	const int pair = (b >> 4) * 8 + (b & 7);
 	const int half = (b >> 3) & 1;
 	const int V = g.V, lda = g.lda, ldy = g.ldy, upf = g.tiles_per_foot;
-#ifdef FIND_GEMM4_ABLATE
-	const int ablate = g.ablate;  // profiling builds only: bit0 no A loads, bit1 no epilogue stores, bit2 no B fragment reads
-#else
-	constexpr int ablate = 0;     // (run-time branches around the loads make the waitcnt pass drain vmcnt)
-#endif
 
 	// ---- prologue: this half of W -> LDS (wave w: rows n with (n & 31) in [4w, 4w+4), i.e. LDS rows 16w .. 16w+15)
 	{
@@ -63,20 +57,12 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 			for (int ni = 0; ni < 4; ++ni) o[ni] = (unsigned)(((half * 128 + ni * 32 + l2) * g.ldw + ((lane ^ (l2 & 15)) * 4)) * 4);
 			dma4(wb, __builtin_amdgcn_readfirstlane(lds_base + (l2 * 4) * 1024), o[0], o[1], o[2], o[3]);
 		}
+		FIND_WAIT_VMCNT(0);
+		__syncthreads();
 	}
+
 	const int u0 = (int)((int64_t)pair * g.ntiles / npairs);
 	const int u1 = (int)((int64_t)(pair + 1) * g.ntiles / npairs);
-	// bias rows of the feet this workgroup touches -> LDS (read back with ds_read: the accumulators start at the bias, and a
-	// GLOBAL load there would sit behind the previous unit's stores in the in-order vmcnt queue)
-	float* const bias_lds = reinterpret_cast<float*>(smem + 128 * 1024);
-	const int f_lo = (g.bias_foot_stride != 0 && u1 > u0) ? u0 / upf : 0;
-	if constexpr (EPI == EPI_BIAS_RELU) {
-		const int f_hi = (g.bias_foot_stride != 0 && u1 > u0) ? (u1 - 1) / upf : 0;
-		const int nb = (f_hi - f_lo + 1) * 128;  // launcher guarantees <= GEMM4_MAX_FEET feet
-		for (int i = tid; i < nb; i += 512) bias_lds[i] = g.bias[(int64_t)(f_lo + (i >> 7)) * g.bias_foot_stride + half * 128 + (i & 127)];
-	}
-	FIND_WAIT_VMCNT(0);
-	__syncthreads();
 	int u = u0 + wave;
 	if (u >= u1) return;
 
@@ -96,17 +82,11 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 
 	int foot, v0;
 	const float4* cur = unit_rows(u, foot, v0);
-	// vmcnt bookkeeping (VMEM operations of a wave complete in order, stores included): the loads of chunk c are followed
-	// by those of chunks c+1..c+3 (12 operations) before chunk c is multiplied -> s_waitcnt vmcnt(12).  For chunks 0..2 of a
-	// unit the previous unit's 16 epilogue stores sit in between as well -> vmcnt(28), which does NOT wait for those
-	// stores.  The first unit's three chunks are simply waited for outright (there vmcnt(28) is a no-op).  Operations the
-	// compiler adds (bias / mask loads, stores) are only ever NEWER, which makes every count here conservative.
-	f32x4 areg[4][4];
+	float4 areg[4][4];
 #pragma unroll
 	for (int c = 0; c < GEMM4_PD; ++c)
 #pragma unroll
-		for (int q = 0; q < 4; ++q) aload16(areg[c][q], cur + c * 8 + q);
-	FIND_WAIT_VMCNT(0);
+		for (int q = 0; q < 4; ++q) areg[c][q] = cur[c * 8 + q];
 
 	float4 bf[2][4];
 	auto load_b = [&](int c, int q, float4 (&f)[4]) {
@@ -119,24 +99,17 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 		int nfoot = foot, nv0 = v0;
 		const float4* nxt = (u + 8 < u1) ? unit_rows(u + 8, nfoot, nv0) : cur;
 
-		// accumulators start at the bias (element r of block ni = output column 32ni + 8(r>>2) + 4fh + (r&3) of row li:
-		// W is the MFMA's A operand, so a lane owns 4 CONSECUTIVE columns of its row -> 16-byte stores / mask loads)
-		f32x16 acc[4];
+		float bv[4];
 		if constexpr (EPI == EPI_BIAS_RELU) {
-			const float* bp = bias_lds + ((g.bias_foot_stride != 0 ? foot - f_lo : 0) * 128 + 4 * fh);
 #pragma unroll
-			for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-				for (int gq = 0; gq < 4; ++gq) {
-					const float4 t = *reinterpret_cast<const float4*>(bp + ni * 32 + 8 * gq);
-					acc[ni][4 * gq + 0] = t.x; acc[ni][4 * gq + 1] = t.y; acc[ni][4 * gq + 2] = t.z; acc[ni][4 * gq + 3] = t.w;
-				}
-		} else {
-#pragma unroll
-			for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-				for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+			for (int ni = 0; ni < 4; ++ni) bv[ni] = g.bias[(int64_t)foot * g.bias_foot_stride + half * 128 + ni * 32 + li];
 		}
+
+		f32x16 acc[4];
+#pragma unroll
+		for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
@@ -144,21 +117,16 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 			{
 				const int pc = c + GEMM4_PD;
 				const float4* src = (pc < 8) ? cur + pc * 8 : nxt + (pc - 8) * 8;
-				if (!(ablate & 1)) {
 #pragma unroll
-					for (int q = 0; q < 4; ++q) aload16(areg[pc & 3][q], src + q);
-				}
+				for (int q = 0; q < 4; ++q) areg[pc & 3][q] = src[q];
 			}
-			if (c < GEMM4_PD) FIND_WAIT_VMCNT(28);  // chunks c+1..c+3 (12) + the previous unit's 16 stores
-			else FIND_WAIT_VMCNT(12);
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int q = 0; q < 4; ++q) {
 				const int s = c * 4 + q;
 				// B fragments of the next k-group (wraps to (0,0): the next unit multiplies the same W)
-				if (!(ablate & 4)) load_b(((s + 1) >> 2) & 7, (s + 1) & 3, bf[(s + 1) & 1]);
-				__builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of this group's MFMAs (the scheduler sinks them otherwise)
-				const f32x4 a = areg[c & 3][q];
+				load_b(((s + 1) >> 2) & 7, (s + 1) & 3, bf[(s + 1) & 1]);
+				const float4 a = areg[c & 3][q];
 				const float4(&f)[4] = bf[s & 1];
 #pragma unroll
 				for (int kk = 0; kk < 4; ++kk) {
@@ -166,48 +134,39 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 #pragma unroll
 					for (int ni = 0; ni < 4; ++ni) {
 						const float bvv = kk == 0 ? f[ni].x : (kk == 1 ? f[ni].y : (kk == 2 ? f[ni].z : f[ni].w));
-						acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bvv, av, acc[ni], 0, 0, 0);
+						acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc[ni], 0, 0, 0);
 					}
 				}
 				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
 
-		// ---- epilogue: 16-byte buffer stores; the SRD's size is the number of valid bytes of the unit, so rows past the end
-		// of a foot are dropped by the bounds check.
+		// ---- epilogue: buffer stores; the SRD's size is the number of valid bytes of the unit, so rows past the end of a
+		// foot are dropped by the bounds check.  Element (r, lane) of block ni = row (r&3) + 8(r>>2) + 4fh, column 32ni + li.
 		{
 			const int valid_rows = min(32, V - v0);
 			float* ytile = g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy;
 			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ytile)), 0, valid_rows * ldy * 4, 0x00020000);
-			const int voff = (li * ldy + half * 128 + 4 * fh) * 4;
+			const int voff = ((4 * fh) * ldy + half * 128 + li) * 4;
 			__amdgpu_buffer_rsrc_t msrc = rsrc;
 			if constexpr (EPI == EPI_MASK) {
 				const float* mtile = g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy;
 				msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(mtile)), 0, valid_rows * ldy * 4, 0x00020000);
 			}
-			typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
 			for (int ni = 0; ni < 4; ++ni) {
-				u32x4 mv[4];
+				float mv[16];
 				if constexpr (EPI == EPI_MASK) {
 #pragma unroll
-					for (int gq = 0; gq < 4; ++gq) mv[gq] = __builtin_amdgcn_raw_buffer_load_b128(msrc, voff, (ni * 32 + 8 * gq) * 4, 0);
+					for (int r = 0; r < 16; ++r)
+						mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0));
 				}
 #pragma unroll
-				for (int gq = 0; gq < 4; ++gq) {
-					float v[4];
-#pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						v[e] = acc[ni][4 * gq + e];
-						if constexpr (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
-					}
-					if constexpr (EPI == EPI_MASK) {
-						v[0] = (__uint_as_float(mv[gq].x) > 0.f) ? v[0] : 0.f; v[1] = (__uint_as_float(mv[gq].y) > 0.f) ? v[1] : 0.f;
-						v[2] = (__uint_as_float(mv[gq].z) > 0.f) ? v[2] : 0.f; v[3] = (__uint_as_float(mv[gq].w) > 0.f) ? v[3] : 0.f;
-					}
-					u32x4 o;
-					o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
-					if (!(ablate & 2)) __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, voff, (ni * 32 + 8 * gq) * 4, 0);
+				for (int r = 0; r < 16; ++r) {
+					float val = acc[ni][r];
+					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv[ni], 0.f);
+					if constexpr (EPI == EPI_MASK) val = (mv[r] > 0.f) ? val : 0.f;
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0);
 				}
 			}
 		}

@@ -1,0 +1,13 @@
+"""python tools/run_with_tuning.py key=value [key=value ...] -- <pytest args>: set find_set_tuning knobs, then run pytest in-process."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pytest
+import torch
+torch.cuda.init(); torch.zeros(1, device="cuda")
+from find_amd import _lib
+
+sep = sys.argv.index('--')
+for kv in sys.argv[1:sep]:
+	k, v = kv.split('=')
+	_lib.check(_lib.lib().find_set_tuning(k.encode(), int(v)), 'tuning')
+sys.exit(pytest.main(sys.argv[sep + 1:]))
