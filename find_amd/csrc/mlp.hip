@@ -622,7 +622,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		int r;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
-			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, b.pS);
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, b.pS);
 			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, s, b.pS, b.nblk_fs, (int)n_feet, S);
 			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");

@@ -450,46 +450,39 @@ __global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) {
 //   sum_b dZ0[b,v,:] @ W  ==  (sum_b dZ0[b,v,:]) @ W      and      dW0 = (sum_b dZ0[b])^T @ H.
 // One pass over dZ0 (n_feet, V, 256) produces  zsum[v] = sum_b dZ0[b,v]  and partial per-foot column sums.
 constexpr int FS_ROWS = 16;  // rows of v per block
-constexpr int FS_FEET = 8;   // feet per LDS round
+constexpr int FS_FEET = 16;  // feet per round: that many independent 16-byte loads in flight per thread
+// grid (ceil(V/16), 4): block = 16 rows x 64 columns; thread (row r = tid>>4, column group cg = tid&15) walks the feet.
 __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ dz, int n_feet, int V, float* __restrict__ zsum,
 													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */) {
-	__shared__ __attribute__((aligned(16))) float red[FS_FEET][4][256];
-	const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
-	const int v0 = blockIdx.x * FS_ROWS;
-	float4 zs[FS_ROWS / 4];
-#pragma unroll
-	for (int i = 0; i < FS_ROWS / 4; ++i) zs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	__shared__ __attribute__((aligned(16))) float red[4][FS_FEET][64];
+	const int cg = threadIdx.x & 15, r = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+	const int v = blockIdx.x * FS_ROWS + r;
+	const int c0 = blockIdx.y * 64 + cg * 4;
+	const bool live = v < V;
+	float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
 	for (int b0 = 0; b0 < n_feet; b0 += FS_FEET) {
 		const int nb = min(FS_FEET, n_feet - b0);
-		// all loads of the round are independent: FS_FEET x 4 float4 in flight per thread
+		float4 x[FS_FEET];
+#pragma unroll
+		for (int bb = 0; bb < FS_FEET; ++bb)
+			x[bb] = (live && bb < nb) ? *reinterpret_cast<const float4*>(dz + ((int64_t)(b0 + bb) * V + v) * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 		for (int bb = 0; bb < FS_FEET; ++bb) {
-			if (bb < nb) {
-				float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-				const float* base = dz + ((int64_t)(b0 + bb) * V) * 256 + cg * 4;
-#pragma unroll
-				for (int i = 0; i < FS_ROWS / 4; ++i) {
-					const int v = v0 + rl + 4 * i;
-					if (v < V) {
-						const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)v * 256);
-						zs[i].x += x.x; zs[i].y += x.y; zs[i].z += x.z; zs[i].w += x.w;
-						acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
-					}
-				}
-				*reinterpret_cast<float4*>(&red[bb][rl][cg * 4]) = acc;
-			}
+			zs.x += x[bb].x; zs.y += x[bb].y; zs.z += x[bb].z; zs.w += x[bb].w;
+			// per-foot column sums: the 4 rows of this wave by shuffles (lanes 16 apart), the 4 waves through LDS
+			float4 a = x[bb];
+			a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
+			a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
+			if ((threadIdx.x & 63) < 16) *reinterpret_cast<float4*>(&red[wave][bb][cg * 4]) = a;
 		}
 		__syncthreads();
-		for (int bb = 0; bb < nb; ++bb)
-			pS[((int64_t)blockIdx.x * n_feet + b0 + bb) * 256 + threadIdx.x] =
-				(red[bb][0][threadIdx.x] + red[bb][1][threadIdx.x]) + (red[bb][2][threadIdx.x] + red[bb][3][threadIdx.x]);
+		for (int i = threadIdx.x; i < nb * 64; i += 256) {
+			const int bb = i >> 6, c = i & 63;
+			pS[((int64_t)blockIdx.x * n_feet + b0 + bb) * 256 + blockIdx.y * 64 + c] = (red[0][bb][c] + red[1][bb][c]) + (red[2][bb][c] + red[3][bb][c]);
+		}
 		__syncthreads();
 	}
-#pragma unroll
-	for (int i = 0; i < FS_ROWS / 4; ++i) {
-		const int v = v0 + rl + 4 * i;
-		if (v < V) *reinterpret_cast<float4*>(zsum + (int64_t)v * 256 + cg * 4) = zs[i];
-	}
+	if (live) *reinterpret_cast<float4*>(zsum + (int64_t)v * 256 + c0) = zs;
 }
 
 // S[b][n] = sum_blk pS[blk][b][n]: block per foot, 1024 threads = 4 slices of the block range per column.
