@@ -132,6 +132,30 @@ static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers u
 static int g_dw2_min_cps = 4;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
 static int g_num_cus = 0;
 
+// Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
+// the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
+static int g_bwd_streams = 1;
+struct SideStream {
+	hipStream_t q = nullptr;
+	hipEvent_t ev[64];
+	int n = 0;      // events created
+	int next = 0;   // round-robin cursor
+};
+static SideStream g_side[16];
+
+static SideStream* side_stream() {
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+	SideStream* ss = &g_side[dev];
+	if (!ss->q) {
+		if (hipStreamCreateWithFlags(&ss->q, hipStreamNonBlocking) != hipSuccess) { ss->q = nullptr; return nullptr; }
+		for (ss->n = 0; ss->n < 64; ++ss->n)
+			if (hipEventCreateWithFlags(&ss->ev[ss->n], hipEventDisableTiming) != hipSuccess) break;
+		if (ss->n < 64) return nullptr;
+	}
+	return ss;
+}
+
 static int num_cus() {
 	if (g_num_cus == 0) {
 		int dev = 0, n = 0;
@@ -548,6 +572,26 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	const int K0 = p->in_dim + 2 * p->pe_size;
 	const bool act_d = d_disp != nullptr, act_c = d_col != nullptr;
 
+	// weight-gradient work goes to the side stream q: fork() makes q wait for everything issued on s so far; side_done()
+	// returns an event that fires when q has finished what was issued so far (waited for by s before it overwrites a
+	// buffer q reads, and once at the end so the caller's stream sees every gradient)
+	SideStream* ss = g_bwd_streams ? side_stream() : nullptr;
+	hipStream_t q = ss ? ss->q : s;
+	auto next_event = [&]() -> hipEvent_t { hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63; return e; };
+	auto fork = [&]() {
+		if (!ss) return;
+		hipEvent_t e = next_event();
+		(void)hipEventRecord(e, s);
+		(void)hipStreamWaitEvent(q, e, 0);
+	};
+	auto side_done = [&]() -> hipEvent_t {
+		if (!ss) return nullptr;
+		hipEvent_t e = next_event();
+		(void)hipEventRecord(e, q);
+		return e;
+	};
+	auto wait_side = [&](hipEvent_t e) { if (ss && e) (void)hipStreamWaitEvent(s, e, 0); };
+
 	// gradients of skipped parts are exact zeros
 	auto zero = [&](float* ptr, int64_t n) { if (ptr) (void)hipMemsetAsync(ptr, 0, n * sizeof(float), s); };
 	if (!act_d) {
@@ -613,9 +657,13 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	// 3. heads, last hidden layer down to the first
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs) -> int {
+		hipEvent_t reads[2] = {nullptr, nullptr};  // last side-stream reader of each ping-pong buffer
 		for (int l = nl - 1; l >= 1; --l) {
-			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, s);
+			fork();
+			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
 			if (r != FIND_OK) return r;
+			reads[cur] = side_done();
+			wait_side(reads[cur ^ 1]);
 			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur ^ 1], V, n_feet, s);
 			cur ^= 1;
 		}
@@ -626,13 +674,15 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, s, b.pS, b.nblk_fs, (int)n_feet, S);
 			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
-			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, s);
+			fork();
+			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, q);
 		} else {
-			r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, s);
+			fork();
+			r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, q);
 		}
 		if (r != FIND_OK) return r;
 		if (L > 0) {
-			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, q, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
 			FIND_LAUNCH_CHECK("latent_grad_kernel");
 		}
 		return FIND_OK;
@@ -665,14 +715,22 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	}
 
 	// 5. trunk
-	for (int l = p->n_trunk - 1; l >= 1; --l) {
-		rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, b, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, s);
+	{
+		hipEvent_t reads[2] = {nullptr, nullptr};
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			fork();
+			rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, b, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, q);
+			if (rc != FIND_OK) return rc;
+			reads[ct] = side_done();
+			wait_side(reads[ct ^ 1]);
+			linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct ^ 1], V, d.feet_t, s);
+			ct ^= 1;
+		}
+		fork();
+		rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, q);
 		if (rc != FIND_OK) return rc;
-		linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct ^ 1], V, d.feet_t, s);
-		ct ^= 1;
+		wait_side(side_done());  // join: the caller's stream continues only after every gradient is written
 	}
-	rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, s);
-	if (rc != FIND_OK) return rc;
 	FIND_LAUNCH_CHECK("find_mlp_bwd");
 	return FIND_OK;
 }
@@ -695,6 +753,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "dw2") == 0) {
 		g_dw2 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "bwd_streams") == 0) {
+		g_bwd_streams = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm4") == 0) {
