@@ -251,3 +251,29 @@ def test_latent_gather_matches_indexing_and_scatters_deterministically():
 	assert torch.equal(g1, table.grad)
 	bad = FN.latent_gather(table.detach(), torch.tensor([40], device=dev))
 	assert torch.isnan(bad).all()
+
+
+@pytest.mark.gpu
+def test_c5_dense_template_shared_equals_general(golden_main):
+	"""C5-size property (50 002-vertex dense template, fp32): shared-trunk evaluation == one template copy per foot, outputs
+	and every gradient, at a row count where the long-row-range kernels (gemm4 units, dw2 runs) take their large-V paths."""
+	m = _model_from_golden(golden_main)
+	gen = torch.Generator().manual_seed(8)
+	N, V = 3, 50002
+	ext = torch.tensor([0.12, 0.045, 0.04])
+	pos1 = ((torch.rand(1, V, 3, generator=gen) * 2 - 1) * ext).cuda()
+	lat = [(torch.randn(N, 100, generator=gen) * 0.1).cuda() for _ in range(3)]
+	outs, grads = [], []
+	for pos in (pos1, pos1.expand(N, -1, -1).contiguous()):
+		m.zero_grad()
+		l3 = [x.clone().requires_grad_(True) for x in lat]
+		res = m(pos, shapevec=l3[0], texvec=l3[1], posevec=l3[2])
+		w = torch.linspace(0.5, 1.5, N * V * 3, device='cuda').reshape(N, V, 3)
+		((res['disp'] * w).sum() * 10 + (res['col'] * w).sum()).backward()
+		outs.append((res['disp'].detach(), res['col'].detach()))
+		grads.append([x.grad.clone() for x in l3] + [prm.grad.clone() for prm in m._weights()])
+	assert (outs[0][0] - outs[1][0]).abs().max() < 1e-5
+	assert (outs[0][1] - outs[1][1]).abs().max() < 1e-5
+	for a, b in zip(grads[0], grads[1]):
+		scale = max(1.0, b.abs().max().item())
+		assert (a - b).abs().max().item() < 2e-4 * scale

@@ -126,3 +126,32 @@ def test_c3_size_properties():
 	m2, i2, _, _ = FR.render(verts[perm.cuda()], cols[perm.cuda()], f.cuda(), R, T, params)
 	assert torch.equal(m2, mask[perm.cuda()])
 	assert (i2 - image[perm.cuda()]).abs().max().item() < 1e-5  # normals are accumulated with float atomics
+
+
+def test_c4_rank_share_properties():
+	"""C4 per-rank share (16 of the 128 feet x 4 views @512^2, 6890-vertex template): resolution consistency -- the 512^2
+	silhouette area fraction agrees with the 256^2 one, masks stay in [0,1], the render is batch-order invariant, and the
+	silhouette loss gradient is finite and non-zero only on vertices."""
+	from find_amd import functional_render as FR
+	from find_amd import synthetic
+	v, f = synthetic.template(6890)
+	g = torch.Generator().manual_seed(2)
+	verts = (v[None] * (1 + 0.1 * torch.rand(16, 1, 3, generator=g))).cuda().requires_grad_(True)
+	cols = torch.rand(16, v.shape[0], 3, generator=g).cuda()
+	rng = np.random.RandomState(11)
+	R, T = camera_ref.look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
+	R, T = torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda()
+	m512, i512, _, _ = FR.render(verts, cols, f.cuda(), R, T, FR.make_params(512))
+	m256, _, _, _ = FR.render(verts.detach(), cols, f.cuda(), R, T, FR.make_params(256))
+	assert m512.shape == (16, 4, 512, 512) and i512.shape == (16, 4, 512, 512, 3)
+	assert m512.min().item() >= 0.0 and m512.max().item() <= 1.0
+	a512 = (m512 > 0.5).float().mean(dim=(2, 3))
+	a256 = (m256 > 0.5).float().mean(dim=(2, 3))
+	assert (a512 - a256).abs().max().item() < 0.01  # same silhouettes, finer grid
+	perm = torch.randperm(16, generator=torch.Generator().manual_seed(3)).cuda()
+	m2, _, _, _ = FR.render(verts.detach()[perm], cols[perm], f.cuda(), R, T, FR.make_params(512))
+	assert torch.equal(m2, m512.detach()[perm])
+	target = (m256.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) > 0.5).float()
+	loss = ((m512 - target) ** 2).mean()
+	loss.backward()
+	assert torch.isfinite(verts.grad).all() and verts.grad.abs().max().item() > 0
