@@ -78,7 +78,7 @@ def build_step(device, seed):
 	return model, params, step
 
 
-def time_dominant_kernel(device, iters=30):
+def time_dominant_kernel(device, iters=100, warm=150):
 	"""Average duration of the dominant kernel (Linear 256->256 + ReLU over all head rows), HIP events on the launch stream."""
 	import ctypes
 	from find_amd import _lib
@@ -95,7 +95,8 @@ def time_dominant_kernel(device, iters=30):
 		_lib.check(L.find_linear_relu_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), N_FEET, N_VERTS, _lib.ptr(y),
 										  ctypes.c_void_p(stream.cuda_stream)), 'find_linear_relu_fwd')
 
-	for _ in range(5):
+	# the GPU idled while the inputs were generated on the host: launch long enough for the clock to come back up before timing
+	for _ in range(warm):
 		launch()
 	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 	e0.record(stream)
