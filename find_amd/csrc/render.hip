@@ -152,30 +152,41 @@ __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t
 }
 
 // ------------------------------------------------------------------------------------------------ shared fragment math
-struct FaceRec {  // staged in LDS, one per candidate
+struct FaceRec {  // staged in LDS, one per candidate (80 bytes)
 	float x0, y0, x1, y1, x2, y2, z0, z1, z2;
 	float xmin, xmax, ymin, ymax;  // blurred NDC bbox
 	float inv_area;
+	float il01, il02, il12;        // 1 / |edge|^2 (0 for a degenerate edge: the projection parameter is then 1, as PyTorch3D)
 	int f;
-	int pad;
+	int pad[2];
 };
 
+__device__ __forceinline__ float edge_inv_len2(float ax, float ay, float bx, float by) {
+	const float dx = bx - ax, dy = by - ay;
+	const float l2 = dx * dx + dy * dy;
+	return l2 > KEPS ? 1.0f / l2 : 0.0f;
+}
+
+// Everything that is per face (not per pixel) is computed here, once: the per-pixel fragment math below then has no IEEE
+// division left (a v_rcp_f32 for the two normalisations).
 __device__ __forceinline__ void make_rec(const float4* fr, int f, float br, FaceRec* r) {
 	const float4 a = fr[0], b = fr[1], c = fr[2];
 	r->x0 = a.x; r->y0 = a.y; r->x1 = a.z; r->y1 = a.w; r->x2 = b.x; r->y2 = b.y; r->z0 = b.z; r->z1 = b.w; r->z2 = c.x;
 	r->xmin = fminf(a.x, fminf(a.z, b.x)) - br; r->xmax = fmaxf(a.x, fmaxf(a.z, b.x)) + br;
 	r->ymin = fminf(a.y, fminf(a.w, b.y)) - br; r->ymax = fmaxf(a.y, fmaxf(a.w, b.y)) + br;
 	r->inv_area = 1.0f / (edge_fn(b.x, b.y, a.x, a.y, a.z, a.w) + KEPS);
+	r->il01 = edge_inv_len2(a.x, a.y, a.z, a.w);
+	r->il02 = edge_inv_len2(a.x, a.y, b.x, b.y);
+	r->il12 = edge_inv_len2(a.z, a.w, b.x, b.y);
 	r->f = f;
-	r->pad = 0;
+	r->pad[0] = r->pad[1] = 0;
 }
 
-// squared distance to segment ab; also returns the clamped parameter (PointLineDistanceForward)
-__device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float* t_out) {
+// squared distance to segment ab; also returns the clamped parameter (PointLineDistanceForward); il = 1/|ab|^2 or 0
+__device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float il, float* t_out) {
 	const float bax = bx - ax, bay = by - ay;
-	const float l2 = bax * bax + bay * bay;
 	float t = 1.0f;
-	if (l2 > KEPS) t = fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) / l2, 0.f), 1.f);
+	if (il > 0.f) t = fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) * il, 0.f), 1.f);
 	const float qx = ax + t * bax - px, qy = ay + t * bay - py;
 	*t_out = t;
 	return qx * qx + qy * qy;
@@ -199,19 +210,19 @@ __device__ __forceinline__ bool eval_frag(const FaceRec& r, float px, float py, 
 	float w1 = edge_fn(px, py, r.x2, r.y2, r.x0, r.y0) * r.inv_area;
 	float w2 = edge_fn(px, py, r.x0, r.y0, r.x1, r.y1) * r.inv_area;
 	const float t0 = w0 * r.z1 * r.z2, t1 = r.z0 * w1 * r.z2, t2 = r.z0 * r.z1 * w2;
-	const float den = fmaxf(t0 + t1 + t2, KEPS);
-	w0 = t0 / den; w1 = t1 / den; w2 = t2 / den;
+	const float iden = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, KEPS));
+	w0 = t0 * iden; w1 = t1 * iden; w2 = t2 * iden;
 	o->w0 = w0; o->w1 = w1; o->w2 = w2;
 	o->inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
 	float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
-	const float sum = fmaxf(c0 + c1 + c2, 1e-5f);
-	c0 /= sum; c1 /= sum; c2 /= sum;
+	const float isum = __builtin_amdgcn_rcpf(fmaxf(c0 + c1 + c2, 1e-5f));
+	c0 *= isum; c1 *= isum; c2 *= isum;
 	o->pz_clip = c0 * r.z0 + c1 * r.z1 + c2 * r.z2;
 	o->pz = w0 * r.z0 + w1 * r.z1 + w2 * r.z2;
 	float ta, tb, tc;
-	const float e01 = seg_dist(px, py, r.x0, r.y0, r.x1, r.y1, &ta);
-	const float e02 = seg_dist(px, py, r.x0, r.y0, r.x2, r.y2, &tb);
-	const float e12 = seg_dist(px, py, r.x1, r.y1, r.x2, r.y2, &tc);
+	const float e01 = seg_dist(px, py, r.x0, r.y0, r.x1, r.y1, r.il01, &ta);
+	const float e02 = seg_dist(px, py, r.x0, r.y0, r.x2, r.y2, r.il02, &tb);
+	const float e12 = seg_dist(px, py, r.x1, r.y1, r.x2, r.y2, r.il12, &tc);
 	if (e01 <= e02 && e01 <= e12) { o->dist = e01; o->edge = 0; o->t = ta; }
 	else if (e02 <= e01 && e02 <= e12) { o->dist = e02; o->edge = 1; o->t = tb; }
 	else { o->dist = e12; o->edge = 2; o->t = tc; }
@@ -281,10 +292,15 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	const int img = blockIdx.y;
 	const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int xi = tile_x * TS + (tid & (TS - 1)), yi = tile_y * TS + (tid >> 4);
+	// wave w owns the 8x8-pixel quadrant (w&1, w>>1) of the tile: faces are culled per wave against that quadrant
+	const int qx0 = tile_x * TS + (wave & 1) * 8, qy0 = tile_y * TS + (wave >> 1) * 8;
+	const int xi = qx0 + (lane & 7), yi = qy0 + (lane >> 3);
 	const bool in_img = xi < W && yi < H;
 	const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
 	const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+	// NDC extent of the quadrant's pixel centres (x and y decrease with the pixel index)
+	const float q_xhi = 1.0f - (2.0f * qx0 + 1.0f) / (float)W, q_xlo = 1.0f - (2.0f * (qx0 + 7) + 1.0f) / (float)W;
+	const float q_yhi = 1.0f - (2.0f * qy0 + 1.0f) / (float)H, q_ylo = 1.0f - (2.0f * (qy0 + 7) + 1.0f) / (float)H;
 	const float blur = a.rp.sil_blur_radius, br = sqrtf(blur);
 	const float inv_sigma = 1.0f / a.rp.sil_sigma;
 	const bool want_sil = a.mask != nullptr;
@@ -305,10 +321,20 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 		// stage the records of list[0 .. nb) in LDS
 		if (tid < nb) make_rec(frp + (int64_t)list[tid] * 3, list[tid], br, &rec[tid]);
 		__syncthreads();
-		if (in_img) {
-			for (int k = 0; k < nb; ++k) {
+		// candidates of this wave's quadrant: bbox-vs-quadrant test by 64 lanes at a time, then a scalar loop over the set
+		// bits (increasing k: the order of the alpha product is that of the face list)
+		for (int kb = 0; kb < nb; kb += 64) {
+			bool ov = false;
+			if (kb + lane < nb) {
+				const FaceRec& rr = rec[kb + lane];
+				ov = !(q_xlo > rr.xmax || q_xhi < rr.xmin || q_ylo > rr.ymax || q_yhi < rr.ymin);
+			}
+			unsigned long long qm = __ballot(ov);
+			while (qm) {
+				const int k = kb + __builtin_ctzll(qm);
+				qm &= qm - 1;
 				Frag fr;
-				if (!eval_frag(rec[k], px, py, &fr)) continue;
+				if (!in_img || !eval_frag(rec[k], px, py, &fr)) continue;
 				if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
 					const float sd = fr.inside ? -fr.dist : fr.dist;
 					const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Sub-path measurements of SURVEY.md §8(d) that bench.py's headline line does not carry: the rasteriser + silhouette /
+Phong shaders (C3 and the per-rank share of C4), Chamfer at the training and eval sizes, the smoothness terms -- each timed
+on the GPU (HIP events on the launch stream, inputs resident in HBM) with the CPU oracle timed beside it on a bounded sample.
+One JSON line per sub-path.   python tools/bench_paths.py [--no-cpu]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from find_amd import functional as FN            # noqa: E402
+from find_amd import functional_render as FR     # noqa: E402
+from find_amd import synthetic                   # noqa: E402
+from oracle import camera_ref, geom_ref, render_ref  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def gpu_ms(fn, warm=3, iters=10):
+	for _ in range(warm):
+		fn()
+	torch.cuda.synchronize()
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	e0.record()
+	for _ in range(iters):
+		fn()
+	e1.record()
+	e1.synchronize()
+	return e0.elapsed_time(e1) / iters
+
+
+def views(m, seed=7):
+	rng = np.random.RandomState(seed)
+	R, T = camera_ref.look_at_view_transform(dist=np.full(m, 0.3), elev=rng.uniform(-90, 90, m), azim=rng.uniform(-90, 90, m), up=((1, 0, 0),))
+	return torch.from_numpy(R), torch.from_numpy(T)
+
+
+def bench_render(n_feet, n_views, size, want_image, cpu):
+	v, f = synthetic.template(6890)
+	g = torch.Generator().manual_seed(0)
+	verts = (v[None] * (1 + 0.1 * torch.rand(n_feet, 1, 3, generator=g))).cuda()
+	cols = torch.rand(n_feet, v.shape[0], 3, generator=g).cuda()
+	R, T = views(n_views)
+	Rc, Tc, fc = R.cuda(), T.cuda(), f.cuda()
+	params = FR.make_params(size)
+	gt = torch.rand(n_feet, n_views, size, size, generator=g).cuda()
+	gti = torch.rand(n_feet, n_views, size, size, 3, generator=g).cuda() if want_image else None
+
+	def fwd():
+		return FR.render(verts, cols if want_image else None, fc, Rc, Tc, params, want_image=want_image)
+
+	def fwdbwd():
+		vg = verts.detach().requires_grad_(True)
+		cg = cols.detach().requires_grad_(True) if want_image else None
+		mask, image, _, _ = FR.render(vg, cg, fc, Rc, Tc, params, want_image=want_image)
+		loss = ((mask - gt) ** 2).mean()
+		if want_image:
+			loss = loss + ((image - gti) ** 2).mean()
+		loss.backward()
+
+	ms_f, ms_fb = gpu_ms(fwd), gpu_ms(fwdbwd)
+	px = n_feet * n_views * size * size
+	images = n_feet * n_views
+	F = f.shape[0]
+	alg = px * (8 + (24 if want_image else 0)) + images * 36 * F
+	out = dict(path=f'render+{"phong+" if want_image else ""}silhouette fwd+bwd', workload=f'{n_feet} feet x {n_views} views @{size}^2, V=6890 F={F}',
+			   ms_fwd=ms_f, ms_fwd_bwd=ms_fb, vertices_views_per_s=n_feet * 6890 * n_views / (ms_fb * 1e-3), mpix_per_s_fwd=px / ms_f / 1e3,
+			   bytes_algorithmic=alg, achieved_GBs_fwd=alg / (ms_f * 1e-3) / 1e9, hbm_frac_fwd=alg / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+			   bound='VALU/LDS (pixel x candidate-face tests); HBM floor %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
+	if cpu:
+		t0 = time.perf_counter()
+		render_ref.render(verts[:1].cpu().numpy(), f.numpy(), cols[:1].cpu().numpy(), R[:1].numpy(), T[:1].numpy(), image_size=size, want_image=want_image)
+		dt = time.perf_counter() - t0
+		out['cpu_oracle'] = dict(ms_per_image_fwd=dt * 1e3, sample='1 foot x 1 view forward, oracle/raster_ref.c (OpenMP, all host threads)',
+								 gpu_speedup_fwd=(dt * 1e3) / (ms_f / images))
+	return out
+
+
+def bench_chamfer(n_feet, p1, p2, cpu, label):
+	g = torch.Generator().manual_seed(1)
+	x = (torch.rand(n_feet, p1, 3, generator=g) * 0.2).cuda()
+	y = (torch.rand(n_feet, p2, 3, generator=g) * 0.2).cuda()
+
+	def fwdbwd():
+		xg = x.detach().requires_grad_(True)
+		loss, _ = FN.chamfer_distance(xg, y)
+		loss.backward()
+
+	ms = gpu_ms(fwdbwd)
+	pairs = n_feet * p1 * p2
+	out = dict(path='chamfer fwd+bwd', workload=f'{label}: {n_feet} feet, {p1} x {p2} points', ms=ms, gpairs_per_s=pairs / (ms * 1e-3) / 1e9,
+			   gflops=8.0 * pairs / (ms * 1e-3) / 1e9, bytes_algorithmic=24 * (p1 + p2) * n_feet, bound='VALU (3-D distances); not MFMA-shaped')
+	if cpu:
+		t0 = time.perf_counter()
+		geom_ref.chamfer_distance(x[:1].cpu(), y[:1].cpu())
+		dt = time.perf_counter() - t0
+		out['cpu_oracle'] = dict(ms_per_foot_fwd=dt * 1e3, sample='1 foot forward, oracle/geom_ref.py (torch-CPU cdist)', gpu_speedup=(dt * 1e3) / (ms / n_feet))
+	return out
+
+
+def bench_smooth(n_feet, cpu):
+	v, f = synthetic.template(6890)
+	topo = FN.MeshTopology(f.cuda(), v.shape[0])
+	g = torch.Generator().manual_seed(2)
+	verts = (v[None] + 0.001 * torch.randn(n_feet, v.shape[0], 3, generator=g)).cuda()
+
+	def fwdbwd():
+		vg = verts.detach().requires_grad_(True)
+		e, l = FN.mesh_edge_and_laplacian(vg, topo)
+		(e + l).backward()
+
+	ms = gpu_ms(fwdbwd)
+	out = dict(path='mesh_edge_loss + cot-Laplacian smoothing fwd+bwd', workload=f'{n_feet} feet, V=6890 F={f.shape[0]}', ms=ms,
+			   vertices_per_s=n_feet * 6890 / (ms * 1e-3), bound='gather latency (CSR tables), HBM floor trivial')
+	if cpu:
+		t0 = time.perf_counter()
+		geom_ref.mesh_smoothness(verts[:1].cpu(), f)
+		dt = time.perf_counter() - t0
+		out['cpu_oracle'] = dict(ms_per_foot_fwd=dt * 1e3, sample='1 foot forward, oracle/geom_ref.py', gpu_speedup=(dt * 1e3) / (ms / n_feet))
+	return out
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument('--no-cpu', action='store_true')
+	args = ap.parse_args()
+	cpu = not args.no_cpu
+	if not torch.cuda.is_available():
+		raise SystemExit('bench_paths.py needs an MI355X')
+	for r in (bench_render(16, 4, 256, False, cpu), bench_render(16, 4, 256, True, cpu), bench_render(16, 4, 512, True, cpu),
+			  bench_chamfer(16, 5000, 5000, cpu, 'train (losses.py:61)'), bench_chamfer(16, 10000, 10000, cpu, 'eval (eval_3d.py:148)'),
+			  bench_smooth(16, cpu)):
+		print(json.dumps(r), flush=True)
+
+
+if __name__ == '__main__':
+	main()
