@@ -8,13 +8,18 @@
 // Design (HBM/VALU-bound, no MFMA): the K=100 fragment buffers PyTorch3D materialises (2.8 kB/pixel) never exist.
 //   1. project_kernel   : world -> (x_ndc, y_ndc, z_view) per (image, vertex)                       [coalesced stream]
 //   2. face_setup_kernel: per (image, face) cull + 48-B face record + tile-bbox packed in one uint32
-//   3. raster_tile_kernel: one 16x16-pixel tile per workgroup.  The packed bboxes are scanned 256 faces at a time
-//      (4 B/face, L2-resident), hits are ballot-compacted IN FACE ORDER into LDS (deterministic), their records staged in
-//      LDS and broadcast to the 256 pixel threads, which keep the silhouette product and the nearest inside fragment
-//      in registers.  The tail shades the nearest fragment (Phong + blend) and writes mask / image.
+//   3. raster_tile_kernel: persistent workgroups take 16x16-pixel tiles from an atomic counter (covered tiles cost far more
+//      than empty ones).  The packed bboxes are scanned 256 faces at a time (4 B/face, L2-resident), hits are
+//      ballot-compacted IN FACE ORDER into LDS (deterministic), their records staged in LDS; each wave owns an 8x8-pixel
+//      quadrant and evaluates only the faces whose blurred bbox touches it; pixels keep the silhouette product and the
+//      nearest inside fragment in registers.  Silhouette candidates are also appended to a per-workgroup scratch so that a
+//      pixel with more than faces_per_pixel of them keeps exactly the K nearest in depth (lane-parallel bisection; the
+//      K-th depth is saved for the backward).  The tail shades the nearest fragment (Phong + blend), writes mask / image.
 //   4. backward: silhouette gradient is FACE-centric (one thread walks the blurred bbox of its face and accumulates the
 //      six NDC gradients in registers: no per-fragment atomics); projection backward is a deterministic sum over views.
 // Conventions: SURVEY.md Appendix A.2-A.4 (row-vector transforms, NDC +x left / +y up, image = mesh*n_views + view).
+#include <type_traits>
+
 #include "common.h"
 
 namespace find {
@@ -24,6 +29,8 @@ constexpr int TS = 16;          // tile edge in pixels
 constexpr int BATCH = 256;      // candidates shaded per LDS batch
 constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
+constexpr int KN_CAP = 1024;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1])
+constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 per CU); each owns KN_CAP x 256 x 8 B of scratch
 
 struct Ws {
 	float* vproj;     // (n_img, V, 3)
@@ -35,7 +42,10 @@ struct Ws {
 	float* d_vproj;   // (n_img, V, 3) backward accumulator
 	float* d_normals; // (n_meshes, V, 3) backward accumulator
 	float* raw_normals; // (n_meshes, V, 3) un-normalised vertex-normal sums (backward)
-	int32_t* flags;   // [0] straddling faces seen, [1] pixels with more than K silhouette candidates
+	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tile counter
+	float* zthr;      // (n_img, H, W) depth of the K-th nearest silhouette candidate (+inf: every candidate counts)  [backward]
+	float2* scratch;  // (raster workgroups, KN_CAP, 256) per-pixel candidate lists (depth, 1 - p) of the tile in flight
+	int64_t raster_wgs;
 	int64_t bytes;
 };
 
@@ -53,6 +63,10 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->d_vproj = c.take<float>(n_img * V * 3);
 	o->d_normals = c.take<float>(n_meshes * V * 3);
 	o->raw_normals = c.take<float>(n_meshes * V * 3);
+	o->zthr = c.take<float>(px);
+	const int64_t tiles = n_img * cdiv(rp->image_w, TS) * cdiv(rp->image_h, TS);
+	o->raster_wgs = std::min<int64_t>(tiles, RASTER_WGS);
+	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
 	o->bytes = c.off;
 }
 
@@ -280,155 +294,234 @@ struct TileArgs {
 	int32_t* p2f_ws;         // local ids for backward
 	float* bary_ws;
 	int32_t* flags;
+	float* zthr;
+	float2* scratch;
+	int tiles_per_img, total_tiles;
 };
 
+// Persistent: workgroups take (image, tile) pairs from an atomic counter.  Silhouette candidates of every pixel are also
+// appended, in face order, to the workgroup's scratch (depth, 1 - p): a pixel that ends with more than faces_per_pixel
+// candidates is resolved at the end of its tile by its own wave -- rank by depth, ties to the earlier face (PyTorch3D's
+// insertion into the per-pixel K-buffer), blend the K nearest, record the K-th depth for the backward pass.
 __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	__shared__ int list[2 * BATCH];
 	__shared__ FaceRec rec[BATCH];
 	__shared__ int wcount[4];
 	__shared__ int n_list;
+	__shared__ int s_tile;
 
 	const int H = a.rp.image_h, W = a.rp.image_w;
-	const int img = blockIdx.y;
-	const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	// wave w owns the 8x8-pixel quadrant (w&1, w>>1) of the tile: faces are culled per wave against that quadrant
-	const int qx0 = tile_x * TS + (wave & 1) * 8, qy0 = tile_y * TS + (wave >> 1) * 8;
-	const int xi = qx0 + (lane & 7), yi = qy0 + (lane >> 3);
-	const bool in_img = xi < W && yi < H;
-	const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
-	const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
-	// NDC extent of the quadrant's pixel centres (x and y decrease with the pixel index)
-	const float q_xhi = 1.0f - (2.0f * qx0 + 1.0f) / (float)W, q_xlo = 1.0f - (2.0f * (qx0 + 7) + 1.0f) / (float)W;
-	const float q_yhi = 1.0f - (2.0f * qy0 + 1.0f) / (float)H, q_ylo = 1.0f - (2.0f * (qy0 + 7) + 1.0f) / (float)H;
 	const float blur = a.rp.sil_blur_radius, br = sqrtf(blur);
 	const float inv_sigma = 1.0f / a.rp.sil_sigma;
+	const int K = a.rp.sil_faces_per_pixel;
 	const bool want_sil = a.mask != nullptr;
 	const bool want_rgb = a.image != nullptr || a.p2f_out != nullptr || a.zbuf_out != nullptr;
+	float2* const scr = a.scratch + (int64_t)blockIdx.x * KN_CAP * 256;
 
-	float alpha = 1.0f;
-	int cnt = 0;
-	float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
-	int bf = -1;
+	for (;;) {
+		if (tid == 0) s_tile = atomicAdd(&a.flags[3], 1);
+		__syncthreads();
+		const int t_id = s_tile;
+		__syncthreads();
+		if (t_id >= a.total_tiles) break;
+		const int img = t_id / a.tiles_per_img, tile = t_id - img * a.tiles_per_img;
+		const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+		// wave w owns the 8x8-pixel quadrant (w&1, w>>1) of the tile: faces are culled per wave against that quadrant
+		const int qx0 = tile_x * TS + (wave & 1) * 8, qy0 = tile_y * TS + (wave >> 1) * 8;
+		const int xi = qx0 + (lane & 7), yi = qy0 + (lane >> 3);
+		const bool in_img = xi < W && yi < H;
+		const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
+		const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+		// NDC extent of the quadrant's pixel centres (x and y decrease with the pixel index)
+		const float q_xhi = 1.0f - (2.0f * qx0 + 1.0f) / (float)W, q_xlo = 1.0f - (2.0f * (qx0 + 7) + 1.0f) / (float)W;
+		const float q_yhi = 1.0f - (2.0f * qy0 + 1.0f) / (float)H, q_ylo = 1.0f - (2.0f * (qy0 + 7) + 1.0f) / (float)H;
 
-	if (tid == 0) n_list = 0;
-	__syncthreads();
+		float alpha = 1.0f, z_lo = INFINITY, z_hi = 0.0f;
+		int cnt = 0;
+		float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
+		int bf = -1;
 
-	const uint32_t* tbp = a.tb + (int64_t)img * a.F;
-	const float4* frp = a.frec + (int64_t)img * a.F * 3;
+		if (tid == 0) n_list = 0;
+		__syncthreads();
 
-	auto shade_batch = [&](int nb) {
-		// stage the records of list[0 .. nb) in LDS
-		if (tid < nb) make_rec(frp + (int64_t)list[tid] * 3, list[tid], br, &rec[tid]);
-		__syncthreads();
-		// candidates of this wave's quadrant: bbox-vs-quadrant test by 64 lanes at a time, then a scalar loop over the set
-		// bits (increasing k: the order of the alpha product is that of the face list)
-		for (int kb = 0; kb < nb; kb += 64) {
-			bool ov = false;
-			if (kb + lane < nb) {
-				const FaceRec& rr = rec[kb + lane];
-				ov = !(q_xlo > rr.xmax || q_xhi < rr.xmin || q_ylo > rr.ymax || q_yhi < rr.ymin);
-			}
-			unsigned long long qm = __ballot(ov);
-			while (qm) {
-				const int k = kb + __builtin_ctzll(qm);
-				qm &= qm - 1;
-				Frag fr;
-				if (!in_img || !eval_frag(rec[k], px, py, &fr)) continue;
-				if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
-					const float sd = fr.inside ? -fr.dist : fr.dist;
-					const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
-					alpha *= (1.0f - prob);
-					++cnt;
-				}
-				if (want_rgb && fr.inside && fr.pz >= 0.f && fr.pz < bz) {
-					bz = fr.pz; bf = rec[k].f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
-				}
-			}
-		}
-		__syncthreads();
-	};
+		const uint32_t* tbp = a.tb + (int64_t)img * a.F;
+		const float4* frp = a.frec + (int64_t)img * a.F * 3;
 
-	for (int base = 0; base < a.F; base += 256) {
-		const int f = base + tid;
-		bool hit = false;
-		if (f < a.F) {
-			const uint32_t t = tbp[f];
-			const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
-			hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;
-		}
-		// ordered compaction: ballot per wave, exclusive offsets across waves through LDS
-		const unsigned long long m = __ballot(hit);
-		if (lane == 0) wcount[wave] = __popcll(m);
-		__syncthreads();
-		int off = n_list;
-		for (int w = 0; w < wave; ++w) off += wcount[w];
-		if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = f;
-		__syncthreads();
-		if (tid == 0) n_list += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-		__syncthreads();
-		if (n_list >= BATCH) {  // uniform
-			shade_batch(BATCH);
-			const int rest = n_list - BATCH;
-			int moved = 0;
-			if (tid < rest) moved = list[BATCH + tid];
+		auto shade_batch = [&](int nb) {
+			// stage the records of list[0 .. nb) in LDS
+			if (tid < nb) make_rec(frp + (int64_t)list[tid] * 3, list[tid], br, &rec[tid]);
 			__syncthreads();
-			if (tid < rest) list[tid] = moved;
-			if (tid == 0) n_list = rest;
+			// candidates of this wave's quadrant: bbox-vs-quadrant test by 64 lanes at a time, then a scalar loop over the set
+			// bits (increasing k: the order of the alpha product and of the candidate lists is that of the face list)
+			for (int kb = 0; kb < nb; kb += 64) {
+				bool ov = false;
+				if (kb + lane < nb) {
+					const FaceRec& rr = rec[kb + lane];
+					ov = !(q_xlo > rr.xmax || q_xhi < rr.xmin || q_ylo > rr.ymax || q_yhi < rr.ymin);
+				}
+				unsigned long long qm = __ballot(ov);
+				while (qm) {
+					const int k = kb + __builtin_ctzll(qm);
+					qm &= qm - 1;
+					Frag fr;
+					if (!in_img || !eval_frag(rec[k], px, py, &fr)) continue;
+					if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
+						const float sd = fr.inside ? -fr.dist : fr.dist;
+						const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
+						alpha *= (1.0f - prob);
+						if (cnt < KN_CAP) scr[cnt * 256 + tid] = make_float2(fr.pz_clip, 1.0f - prob);
+						++cnt;
+						z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bisection bounds)
+					}
+					if (want_rgb && fr.inside && fr.pz >= 0.f && fr.pz < bz) {
+						bz = fr.pz; bf = rec[k].f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
+					}
+				}
+			}
 			__syncthreads();
-		}
-	}
-	if (n_list > 0) shade_batch(n_list);
+		};
 
-	if (!in_img) return;
-	const int64_t pix = ((int64_t)img * H + yi) * W + xi;
-	if (want_sil) {
-		a.mask[pix] = 1.0f - alpha;
-		if (cnt > a.rp.sil_faces_per_pixel) atomicAdd(&a.flags[1], 1);
-	}
-	if (!want_rgb) return;
-	if (a.p2f_ws) {
-		a.p2f_ws[pix] = bf;
-		a.bary_ws[pix * 3 + 0] = bw0; a.bary_ws[pix * 3 + 1] = bw1; a.bary_ws[pix * 3 + 2] = bw2;
-	}
-	if (a.p2f_out) a.p2f_out[pix] = bf < 0 ? -1 : img * a.F + bf;
-	if (a.zbuf_out) a.zbuf_out[pix] = bf < 0 ? -1.0f : bz;
-	if (!a.image) return;
-	float* o = a.image + pix * 3;
-	if (bf < 0) { o[0] = a.rp.background[0]; o[1] = a.rp.background[1]; o[2] = a.rp.background[2]; return; }
-	const int mesh = img / a.n_views, view = img - mesh * a.n_views;
-	const int32_t* fp = a.faces + (int64_t)mesh * a.faces_mesh_stride + (int64_t)bf * 3;
-	const float bw[3] = {bw0, bw1, bw2};
-	float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
-	for (int k = 0; k < 3; ++k) {
-		const int64_t vo = ((int64_t)mesh * a.V + fp[k]) * 3;
-		for (int c = 0; c < 3; ++c) {
-			pos[c] += bw[k] * a.verts[vo + c];
-			nrm[c] += bw[k] * a.normals[vo + c];
-			tex[c] += bw[k] * a.colors[vo + c];
+		for (int base = 0; base < a.F; base += 256) {
+			const int f = base + tid;
+			bool hit = false;
+			if (f < a.F) {
+				const uint32_t t = tbp[f];
+				const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
+				hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;
+			}
+			// ordered compaction: ballot per wave, exclusive offsets across waves through LDS
+			const unsigned long long m = __ballot(hit);
+			if (lane == 0) wcount[wave] = __popcll(m);
+			__syncthreads();
+			int off = n_list;
+			for (int w = 0; w < wave; ++w) off += wcount[w];
+			if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = f;
+			__syncthreads();
+			if (tid == 0) n_list += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+			__syncthreads();
+			if (n_list >= BATCH) {  // uniform
+				shade_batch(BATCH);
+				const int rest = n_list - BATCH;
+				int moved = 0;
+				if (tid < rest) moved = list[BATCH + tid];
+				__syncthreads();
+				if (tid < rest) list[tid] = moved;
+				if (tid == 0) n_list = rest;
+				__syncthreads();
+			}
 		}
-	}
-	float nx = nrm[0], ny = nrm[1], nz = nrm[2];
-	normalize3(nx, ny, nz);
-	float lx = a.rp.light_pos[0] - pos[0], ly = a.rp.light_pos[1] - pos[1], lz = a.rp.light_pos[2] - pos[2];
-	normalize3(lx, ly, lz);
-	const float cosang = nx * lx + ny * ly + nz * lz;
-	const float diff = a.rp.diffuse * fmaxf(cosang, 0.f);
-	float vx = a.cam[view * 3] - pos[0], vy = a.cam[view * 3 + 1] - pos[1], vz = a.cam[view * 3 + 2] - pos[2];
-	normalize3(vx, vy, vz);
-	const float rx = -lx + 2.f * cosang * nx, ry = -ly + 2.f * cosang * ny, rz = -lz + 2.f * cosang * nz;
-	const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
-	const float spec = a.rp.specular * powf(al, a.rp.shininess);
-	const float eps = 1e-10f;
-	const float prob = 1.0f / (1.0f + __expf(bd / a.rp.rgb_sigma));
-	const float z_inv = (a.rp.zfar - bz) / (a.rp.zfar - a.rp.znear);
-	const float z_inv_max = fmaxf(z_inv, eps);
-	const float wnum = prob * __expf((z_inv - z_inv_max) / a.rp.rgb_gamma);
-	const float delta = fmaxf(__expf((eps - z_inv_max) / a.rp.rgb_gamma), eps);
-	const float den = wnum + delta;
-	for (int c = 0; c < 3; ++c) {
-		const float col = (a.rp.ambient + diff) * tex[c] + spec;
-		o[c] = (wnum * col + delta * a.rp.background[c]) / den;
+		if (n_list > 0) shade_batch(n_list);
+
+		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
+		// lane finds the K-th smallest depth of its OWN list (reads scr[i*256 + tid]: coalesced across the wave) by bisection
+		// on the integer image of the depth (non-negative floats order like their bit patterns) with one counting pass per
+		// step, then blends, in face order, the candidates in front of it and as many of those AT it as still fit.
+		float thr = INFINITY;
+		if (want_sil) {
+			const bool over = in_img && cnt > K;
+			const unsigned long long ov_all = __ballot(over);
+			if (ov_all) {
+				// agent-scope fence: this wave's scratch stores are complete and the L1 is invalidated (the slot is rewritten for
+				// every tile, a line read for an earlier tile would be stale), so plain loads below see this tile's lists
+				__threadfence();
+				const unsigned long long trunc = __ballot(over && cnt > KN_CAP);
+				int wave_max_cnt = cnt;  // diagnostics: [5] largest candidate count seen
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) wave_max_cnt = max(wave_max_cnt, __shfl_xor(wave_max_cnt, d, 64));
+				if (lane == 0) {  // diagnostics: [4] pixels with more than K candidates; [1] of those, left unresolved
+					atomicAdd(&a.flags[4], (int)__popcll(ov_all));
+					atomicMax(&a.flags[5], wave_max_cnt);
+					if (trunc) atomicAdd(&a.flags[1], (int)__popcll(trunc));
+				}
+				if (over && cnt <= KN_CAP) {
+					const float2* mp = scr + tid;
+					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
+					while (lo < hi) {
+						const unsigned mid = lo + ((hi - lo) >> 1);
+						int c = 0, i = 0;
+						for (; i + 4 <= cnt; i += 4) {
+							const float z0 = mp[(i + 0) * 256].x, z1 = mp[(i + 1) * 256].x, z2 = mp[(i + 2) * 256].x, z3 = mp[(i + 3) * 256].x;
+							c += (__float_as_uint(z0 + 0.0f) <= mid) + (__float_as_uint(z1 + 0.0f) <= mid) + (__float_as_uint(z2 + 0.0f) <= mid) +
+								 (__float_as_uint(z3 + 0.0f) <= mid);
+						}
+						for (; i < cnt; ++i) c += __float_as_uint(mp[i * 256].x + 0.0f) <= mid;
+						if (c >= K) hi = mid; else lo = mid + 1;
+					}
+					// lo = bits of the K-th smallest depth
+					int c_lt = 0;
+					for (int i = 0; i < cnt; ++i) c_lt += __float_as_uint(mp[i * 256].x + 0.0f) < lo;
+					int ties = K - c_lt;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
+					float asel = 1.0f;
+					for (int i = 0; i < cnt; ++i) {
+						const float2 c = mp[i * 256];
+						const unsigned zb = __float_as_uint(c.x + 0.0f);
+						if (zb < lo) asel *= c.y;
+						else if (zb == lo && ties > 0) { asel *= c.y; --ties; }
+					}
+					alpha = asel;
+					thr = __uint_as_float(lo);
+				}
+			}
+		}
+
+		if (in_img) {
+			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
+			if (want_sil) {
+				a.mask[pix] = 1.0f - alpha;
+				a.zthr[pix] = thr;
+			}
+			if (want_rgb) {
+				if (a.p2f_ws) {
+					a.p2f_ws[pix] = bf;
+					a.bary_ws[pix * 3 + 0] = bw0; a.bary_ws[pix * 3 + 1] = bw1; a.bary_ws[pix * 3 + 2] = bw2;
+				}
+				if (a.p2f_out) a.p2f_out[pix] = bf < 0 ? -1 : img * a.F + bf;
+				if (a.zbuf_out) a.zbuf_out[pix] = bf < 0 ? -1.0f : bz;
+				if (a.image) {
+					float* o = a.image + pix * 3;
+					if (bf < 0) {
+						o[0] = a.rp.background[0]; o[1] = a.rp.background[1]; o[2] = a.rp.background[2];
+					} else {
+						const int mesh = img / a.n_views, view = img - mesh * a.n_views;
+						const int32_t* fp = a.faces + (int64_t)mesh * a.faces_mesh_stride + (int64_t)bf * 3;
+						const float bw[3] = {bw0, bw1, bw2};
+						float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
+						for (int k = 0; k < 3; ++k) {
+							const int64_t vo = ((int64_t)mesh * a.V + fp[k]) * 3;
+							for (int c = 0; c < 3; ++c) {
+								pos[c] += bw[k] * a.verts[vo + c];
+								nrm[c] += bw[k] * a.normals[vo + c];
+								tex[c] += bw[k] * a.colors[vo + c];
+							}
+						}
+						float nx = nrm[0], ny = nrm[1], nz = nrm[2];
+						normalize3(nx, ny, nz);
+						float lx = a.rp.light_pos[0] - pos[0], ly = a.rp.light_pos[1] - pos[1], lz = a.rp.light_pos[2] - pos[2];
+						normalize3(lx, ly, lz);
+						const float cosang = nx * lx + ny * ly + nz * lz;
+						const float diff = a.rp.diffuse * fmaxf(cosang, 0.f);
+						float vx = a.cam[view * 3] - pos[0], vy = a.cam[view * 3 + 1] - pos[1], vz = a.cam[view * 3 + 2] - pos[2];
+						normalize3(vx, vy, vz);
+						const float rx = -lx + 2.f * cosang * nx, ry = -ly + 2.f * cosang * ny, rz = -lz + 2.f * cosang * nz;
+						const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+						const float spec = a.rp.specular * powf(al, a.rp.shininess);
+						const float eps = 1e-10f;
+						const float prob = 1.0f / (1.0f + __expf(bd / a.rp.rgb_sigma));
+						const float z_inv = (a.rp.zfar - bz) / (a.rp.zfar - a.rp.znear);
+						const float z_inv_max = fmaxf(z_inv, eps);
+						const float wnum = prob * __expf((z_inv - z_inv_max) / a.rp.rgb_gamma);
+						const float delta = fmaxf(__expf((eps - z_inv_max) / a.rp.rgb_gamma), eps);
+						const float den = wnum + delta;
+						for (int c = 0; c < 3; ++c) {
+							const float col = (a.rp.ambient + diff) * tex[c] + spec;
+							o[c] = (wnum * col + delta * a.rp.background[c]) / den;
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();  // the next tile reuses list / rec / scratch
 	}
 }
 
@@ -438,7 +531,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 // (PointTriangleDistanceBackward: nearest edge only, projection parameter treated as constant), six atomics at the end.
 __global__ void sil_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
 							   const int32_t* __restrict__ faces, int64_t faces_mesh_stride, int n_views, int V, int F,
-							   const float* __restrict__ mask, const float* __restrict__ d_mask, float* __restrict__ d_vproj) {
+							   const float* __restrict__ mask, const float* __restrict__ d_mask, const float* __restrict__ zthr,
+							   float* __restrict__ d_vproj) {
 	const int img = blockIdx.y;
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= F) return;
@@ -463,6 +557,7 @@ __global__ void sil_bwd_kernel(const find_render_params rp, const float4* __rest
 			Frag fr;
 			if (!eval_frag(r, px, py, &fr)) continue;
 			if (!(fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur))) continue;
+			if (fr.pz_clip > zthr[pix]) continue;  // pixel with more than K candidates: this one is not among the K nearest
 			const float sd = fr.inside ? -fr.dist : fr.dist;
 			const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
 			const float alpha = 1.0f - mask[pix];
@@ -732,7 +827,9 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = (int)cdiv(W, TS);
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
-	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)(a.tiles_x * cdiv(H, TS)), (unsigned)n_img), dim3(256), 0, s, a);
+	a.zthr = w.zthr; a.scratch = w.scratch;
+	a.tiles_per_img = (int)(a.tiles_x * cdiv(H, TS)); a.total_tiles = (int)(a.tiles_per_img * n_img);
+	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)w.raster_wgs), dim3(256), 0, s, a);
 	FIND_LAUNCH_CHECK("find_render_fwd");
 	return FIND_OK;
 }
@@ -761,7 +858,7 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 	if (d_vert_colors) (void)hipMemsetAsync(d_vert_colors, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 	if (d_mask) {
 		hipLaunchKernelGGL(sil_bwd_kernel, dim3((unsigned)cdiv(F, 128), (unsigned)n_img), dim3(128), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-						   mask, d_mask, w.d_vproj);
+						   mask, d_mask, w.zthr, w.d_vproj);
 	}
 	if (d_image) {
 		(void)hipMemsetAsync(w.d_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
@@ -779,7 +876,8 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 }
 
 /* Diagnostics of the last forward that used `ws`: flags[0] = faces straddling the z-clip plane (left unclipped),
- * flags[1] = pixels with more silhouette candidates than faces_per_pixel (all of them were blended).  Device->host copy. */
+ * flags[1] = pixels with more than KN_CAP silhouette candidates (the K-nearest rule could not be applied: all of them were
+ * blended).  Device->host copy. */
 extern "C" int find_render_flags(const void* ws, int32_t* out2, void* stream) {
 	FIND_REQUIRE(ws && out2, "find_render_flags: NULL argument");
 	hipError_t e = hipMemcpyAsync(out2, ws, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);

@@ -82,7 +82,8 @@ def render(verts, colors, faces, R, T, params, want_mask=True, want_image=True, 
 
 
 def render_flags(ws):
-	"""(faces straddling the clip plane, pixels with more than K silhouette candidates) of the forward that used ws."""
+	"""(faces straddling the clip plane, pixels with more than 1024 silhouette candidates -- the only ones the K-nearest rule
+	leaves unresolved) of the forward that used ws."""
 	L = _lib.lib()
 	out = (ctypes.c_int32 * 2)()
 	check(L.find_render_flags(ptr(ws), ctypes.cast(out, ctypes.c_void_p), current_stream(ws.device)), 'find_render_flags')

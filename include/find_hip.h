@@ -230,7 +230,9 @@ int find_render_bwd(const find_render_params* rp, const float* verts, const int3
 					float* d_verts, float* d_vert_colors, void* ws, int64_t ws_bytes, void* stream);
 /* Diagnostics of the last forward that used `ws` (synchronises the stream): out2[0] = faces straddling the z-clip
  * plane (PyTorch3D would clip them; they are rasterised whole here -- none exists on FIND's camera set-up),
- * out2[1] = pixels with more silhouette candidates than sil_faces_per_pixel (all of them were blended). */
+ * out2[1] = pixels left UNRESOLVED by the K-nearest rule: a pixel with more silhouette candidates than
+ * sil_faces_per_pixel keeps the K nearest in depth (ties to the earlier face, as PyTorch3D's per-pixel K-buffer);
+ * only a pixel with more than 1024 candidates is not resolved -- all of its candidates stay blended. */
 int find_render_flags(const void* ws, int32_t* out2, void* stream);
 
 #ifdef __cplusplus

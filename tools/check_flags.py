@@ -1,0 +1,25 @@
+"""Count pixels with more than faces_per_pixel silhouette candidates at C3 / C4-share sizes (find_render_flags)."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from find_amd import functional_render as FR, synthetic, _lib
+from find_amd.functional import _ws, _c, _faces_i32
+from find_amd._lib import ptr, check, current_stream
+from oracle import camera_ref
+for size in (256, 512):
+	v, f = synthetic.template(6890)
+	g = torch.Generator().manual_seed(0)
+	verts = (v[None] * (1 + 0.1 * torch.rand(16, 1, 3, generator=g))).cuda()
+	rng = np.random.RandomState(7)
+	R, T = camera_ref.look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
+	R, T = torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda()
+	params = FR.make_params(size)
+	L = _lib.lib()
+	faces = _faces_i32(f.cuda())
+	N, V, M, F = 16, v.shape[0], 4, f.shape[0]
+	ws = _ws(L.find_render_ws_bytes(ctypes.byref(params), N, M, V, F), verts.device)
+	mask = torch.empty(N, M, size, size, device='cuda')
+	check(L.find_render_fwd(ctypes.byref(params), ptr(verts), ptr(faces), 1, None, ptr(R), ptr(T), N, M, V, F, ptr(mask), None, None, None, ptr(ws), ws.numel(), current_stream(verts.device)), 'fwd')
+	torch.cuda.synchronize()
+	fl = ws[:256].view(torch.int32).cpu().tolist()
+	print(size, 'flags (z-straddlers, unresolved overflow pixels):', FR.render_flags(ws), 'of', N * M * size * size, 'pixels; overflow pixels', fl[4], 'max candidates per pixel', fl[5])
