@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	const int K = a.rp.sil_faces_per_pixel;
 	const bool want_sil = a.mask != nullptr;
 	const bool want_rgb = a.image != nullptr || a.p2f_out != nullptr || a.zbuf_out != nullptr;
-	float2* const scr = a.scratch + (int64_t)blockIdx.x * KN_CAP * 256;
+	float* const scr_z = reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256);  // [KN_CAP][256] depths
+	float* const scr_q = scr_z + KN_CAP * 256;                                                        // [KN_CAP][256] 1 - p
 
 	for (;;) {
 		if (tid == 0) s_tile = atomicAdd(&a.flags[3], 1);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						const float sd = fr.inside ? -fr.dist : fr.dist;
 						const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
 						alpha *= (1.0f - prob);
-						if (cnt < KN_CAP) scr[cnt * 256 + tid] = make_float2(fr.pz_clip, 1.0f - prob);
+						if (cnt < KN_CAP) { scr_z[cnt * 256 + tid] = fr.pz_clip; scr_q[cnt * 256 + tid] = 1.0f - prob; }
 						++cnt;
 						z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bisection bounds)
 					}
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 		if (n_list > 0) shade_batch(n_list);
 
 		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
-		// lane finds the K-th smallest depth of its OWN list (reads scr[i*256 + tid]: coalesced across the wave) by bisection
+		// lane finds the K-th smallest depth of its OWN list (reads scr_z[i*256 + tid]: coalesced across the wave) by bisection
 		// on the integer image of the depth (non-negative floats order like their bit patterns) with one counting pass per
 		// step, then blends, in face order, the candidates in front of it and as many of those AT it as still fit.
 		float thr = INFINITY;
@@ -435,29 +436,40 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					if (trunc) atomicAdd(&a.flags[1], (int)__popcll(trunc));
 				}
 				if (over && cnt <= KN_CAP) {
-					const float2* mp = scr + tid;
+					const float* zp = scr_z + tid;
+					const float* qp = scr_q + tid;
 					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
+					// invariant: count(z <= lo - 1) < K <= count(z <= hi); three pivots per counting pass
 					while (lo < hi) {
-						const unsigned mid = lo + ((hi - lo) >> 1);
-						int c = 0, i = 0;
+						const unsigned span = hi - lo;
+						const unsigned m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + (span >> 1) + (span >> 2);
+						int c1 = 0, c2 = 0, c3 = 0, i = 0;
 						for (; i + 4 <= cnt; i += 4) {
-							const float z0 = mp[(i + 0) * 256].x, z1 = mp[(i + 1) * 256].x, z2 = mp[(i + 2) * 256].x, z3 = mp[(i + 3) * 256].x;
-							c += (__float_as_uint(z0 + 0.0f) <= mid) + (__float_as_uint(z1 + 0.0f) <= mid) + (__float_as_uint(z2 + 0.0f) <= mid) +
-								 (__float_as_uint(z3 + 0.0f) <= mid);
+							const unsigned b0 = __float_as_uint(zp[(i + 0) * 256] + 0.0f), b1 = __float_as_uint(zp[(i + 1) * 256] + 0.0f);
+							const unsigned b2 = __float_as_uint(zp[(i + 2) * 256] + 0.0f), b3 = __float_as_uint(zp[(i + 3) * 256] + 0.0f);
+							c1 += (b0 <= m1) + (b1 <= m1) + (b2 <= m1) + (b3 <= m1);
+							c2 += (b0 <= m2) + (b1 <= m2) + (b2 <= m2) + (b3 <= m2);
+							c3 += (b0 <= m3) + (b1 <= m3) + (b2 <= m3) + (b3 <= m3);
 						}
-						for (; i < cnt; ++i) c += __float_as_uint(mp[i * 256].x + 0.0f) <= mid;
-						if (c >= K) hi = mid; else lo = mid + 1;
+						for (; i < cnt; ++i) {
+							const unsigned b0 = __float_as_uint(zp[i * 256] + 0.0f);
+							c1 += b0 <= m1; c2 += b0 <= m2; c3 += b0 <= m3;
+						}
+						if (c1 >= K) hi = m1;
+						else if (c2 >= K) { lo = m1 + 1; hi = m2; }
+						else if (c3 >= K) { lo = m2 + 1; hi = m3; }
+						else lo = m3 + 1;
 					}
 					// lo = bits of the K-th smallest depth
 					int c_lt = 0;
-					for (int i = 0; i < cnt; ++i) c_lt += __float_as_uint(mp[i * 256].x + 0.0f) < lo;
+					for (int i = 0; i < cnt; ++i) c_lt += __float_as_uint(zp[i * 256] + 0.0f) < lo;
 					int ties = K - c_lt;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
 					float asel = 1.0f;
 					for (int i = 0; i < cnt; ++i) {
-						const float2 c = mp[i * 256];
-						const unsigned zb = __float_as_uint(c.x + 0.0f);
-						if (zb < lo) asel *= c.y;
-						else if (zb == lo && ties > 0) { asel *= c.y; --ties; }
+						const unsigned zb = __float_as_uint(zp[i * 256] + 0.0f);
+						const float qi = qp[i * 256];
+						if (zb < lo) asel *= qi;
+						else if (zb == lo && ties > 0) { asel *= qi; --ties; }
 					}
 					alpha = asel;
 					thr = __uint_as_float(lo);
