@@ -147,13 +147,38 @@ def cpu_baseline(sample_feet=2, steps=2):
 					   f'(best of a {sorted(probe)}-thread probe; host exposes {avail} hardware threads)')
 
 
+def subpaths(with_cpu):
+	"""Sub-path lines (tools/bench_paths.py workloads).  The CPU leg times the oracle on one foot / one image of the same inputs."""
+	sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+	import bench_paths
+
+	def cpu(kind, **kw):
+		from oracle import geom_ref, render_ref
+		t0 = time.perf_counter()
+		if kind == 'render':
+			render_ref.render(kw['verts'], kw['faces'], kw['colors'], kw['R'], kw['T'], image_size=kw['size'], want_image=kw['want_image'])
+		elif kind == 'chamfer':
+			geom_ref.chamfer_distance(kw['x'], kw['y'])
+		else:
+			geom_ref.mesh_smoothness(kw['verts'], kw['faces'])
+		return time.perf_counter() - t0
+
+	if not torch.cuda.is_available():
+		raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+	for r in bench_paths.run_all(cpu if with_cpu else None):
+		print(json.dumps(r), flush=True)
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument('--gpus', type=int, default=1)
 	ap.add_argument('--steps', type=int, default=30)
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
+	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
 	args = ap.parse_args()
+	if args.subpaths:
+		return subpaths(not args.no_cpu_baseline)
 
 	import torch.distributed as dist
 	from find_amd import distributed as fdist

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Sub-path measurements of SURVEY.md §8(d) that bench.py's headline line does not carry: the rasteriser + silhouette /
 Phong shaders (C3 and the per-rank share of C4), Chamfer at the training and eval sizes, the smoothness terms -- each timed
-on the GPU (HIP events on the launch stream, inputs resident in HBM) with the CPU oracle timed beside it on a bounded sample.
-One JSON line per sub-path.   python tools/bench_paths.py [--no-cpu]"""
-import argparse
+on the GPU (HIP events on the launch stream, inputs resident in HBM).  One JSON line per sub-path.
+`python bench.py --subpaths` runs the same workloads and times the CPU oracle beside each of them (the oracle is only ever
+touched from tests/, smoke() and bench.py's CPU-baseline leg); `python tools/bench_paths.py` prints the GPU side alone."""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from find_amd import functional as FN            # noqa: E402
 from find_amd import functional_render as FR     # noqa: E402
 from find_amd import synthetic                   # noqa: E402
-from oracle import camera_ref, geom_ref, render_ref  # noqa: E402
+from find_amd.cameras import look_at_view_transform  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
 
@@ -36,11 +36,10 @@ def gpu_ms(fn, warm=3, iters=10):
 
 def views(m, seed=7):
 	rng = np.random.RandomState(seed)
-	R, T = camera_ref.look_at_view_transform(dist=np.full(m, 0.3), elev=rng.uniform(-90, 90, m), azim=rng.uniform(-90, 90, m), up=((1, 0, 0),))
-	return torch.from_numpy(R), torch.from_numpy(T)
+	return look_at_view_transform(dist=np.full(m, 0.3), elev=rng.uniform(-90, 90, m), azim=rng.uniform(-90, 90, m), up=((1, 0, 0),))
 
 
-def bench_render(n_feet, n_views, size, want_image, cpu):
+def bench_render(n_feet, n_views, size, want_image, cpu=None):
 	v, f = synthetic.template(6890)
 	g = torch.Generator().manual_seed(0)
 	verts = (v[None] * (1 + 0.1 * torch.rand(n_feet, 1, 3, generator=g))).cuda()
@@ -73,15 +72,14 @@ def bench_render(n_feet, n_views, size, want_image, cpu):
 			   bytes_algorithmic=alg, achieved_GBs_fwd=alg / (ms_f * 1e-3) / 1e9, hbm_frac_fwd=alg / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			   bound='VALU/LDS (pixel x candidate-face tests); HBM floor %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
 	if cpu:
-		t0 = time.perf_counter()
-		render_ref.render(verts[:1].cpu().numpy(), f.numpy(), cols[:1].cpu().numpy(), R[:1].numpy(), T[:1].numpy(), image_size=size, want_image=want_image)
-		dt = time.perf_counter() - t0
+		dt = cpu('render', verts=verts[:1].cpu().numpy(), faces=f.numpy(), colors=cols[:1].cpu().numpy(), R=R[:1].numpy(), T=T[:1].numpy(), size=size,
+				 want_image=want_image)
 		out['cpu_oracle'] = dict(ms_per_image_fwd=dt * 1e3, sample='1 foot x 1 view forward, oracle/raster_ref.c (OpenMP, all host threads)',
 								 gpu_speedup_fwd=(dt * 1e3) / (ms_f / images))
 	return out
 
 
-def bench_chamfer(n_feet, p1, p2, cpu, label):
+def bench_chamfer(n_feet, p1, p2, label, cpu=None):
 	g = torch.Generator().manual_seed(1)
 	x = (torch.rand(n_feet, p1, 3, generator=g) * 0.2).cuda()
 	y = (torch.rand(n_feet, p2, 3, generator=g) * 0.2).cuda()
@@ -96,14 +94,12 @@ def bench_chamfer(n_feet, p1, p2, cpu, label):
 	out = dict(path='chamfer fwd+bwd', workload=f'{label}: {n_feet} feet, {p1} x {p2} points', ms=ms, gpairs_per_s=pairs / (ms * 1e-3) / 1e9,
 			   gflops=8.0 * pairs / (ms * 1e-3) / 1e9, bytes_algorithmic=24 * (p1 + p2) * n_feet, bound='VALU (3-D distances); not MFMA-shaped')
 	if cpu:
-		t0 = time.perf_counter()
-		geom_ref.chamfer_distance(x[:1].cpu(), y[:1].cpu())
-		dt = time.perf_counter() - t0
+		dt = cpu('chamfer', x=x[:1].cpu(), y=y[:1].cpu())
 		out['cpu_oracle'] = dict(ms_per_foot_fwd=dt * 1e3, sample='1 foot forward, oracle/geom_ref.py (torch-CPU cdist)', gpu_speedup=(dt * 1e3) / (ms / n_feet))
 	return out
 
 
-def bench_smooth(n_feet, cpu):
+def bench_smooth(n_feet, cpu=None):
 	v, f = synthetic.template(6890)
 	topo = FN.MeshTopology(f.cuda(), v.shape[0])
 	g = torch.Generator().manual_seed(2)
@@ -118,23 +114,22 @@ def bench_smooth(n_feet, cpu):
 	out = dict(path='mesh_edge_loss + cot-Laplacian smoothing fwd+bwd', workload=f'{n_feet} feet, V=6890 F={f.shape[0]}', ms=ms,
 			   vertices_per_s=n_feet * 6890 / (ms * 1e-3), bound='gather latency (CSR tables), HBM floor trivial')
 	if cpu:
-		t0 = time.perf_counter()
-		geom_ref.mesh_smoothness(verts[:1].cpu(), f)
-		dt = time.perf_counter() - t0
+		dt = cpu('smooth', verts=verts[:1].cpu(), faces=f)
 		out['cpu_oracle'] = dict(ms_per_foot_fwd=dt * 1e3, sample='1 foot forward, oracle/geom_ref.py', gpu_speedup=(dt * 1e3) / (ms / n_feet))
 	return out
 
 
+def run_all(cpu=None):
+	"""cpu: None, or a callable (kind, **inputs) -> seconds that times the CPU oracle on that sample (supplied by bench.py)."""
+	return [bench_render(16, 4, 256, False, cpu), bench_render(16, 4, 256, True, cpu), bench_render(16, 4, 512, True, cpu),
+			bench_chamfer(16, 5000, 5000, 'train (losses.py:61)', cpu), bench_chamfer(16, 10000, 10000, 'eval (eval_3d.py:148)', cpu),
+			bench_smooth(16, cpu)]
+
+
 def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument('--no-cpu', action='store_true')
-	args = ap.parse_args()
-	cpu = not args.no_cpu
 	if not torch.cuda.is_available():
 		raise SystemExit('bench_paths.py needs an MI355X')
-	for r in (bench_render(16, 4, 256, False, cpu), bench_render(16, 4, 256, True, cpu), bench_render(16, 4, 512, True, cpu),
-			  bench_chamfer(16, 5000, 5000, cpu, 'train (losses.py:61)'), bench_chamfer(16, 10000, 10000, cpu, 'eval (eval_3d.py:148)'),
-			  bench_smooth(16, cpu)):
+	for r in run_all(None):
 		print(json.dumps(r), flush=True)
 
 

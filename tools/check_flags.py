@@ -5,14 +5,14 @@ import numpy as np, torch
 from find_amd import functional_render as FR, synthetic, _lib
 from find_amd.functional import _ws, _c, _faces_i32
 from find_amd._lib import ptr, check, current_stream
-from oracle import camera_ref
+from find_amd.cameras import look_at_view_transform
 for size in (256, 512):
 	v, f = synthetic.template(6890)
 	g = torch.Generator().manual_seed(0)
 	verts = (v[None] * (1 + 0.1 * torch.rand(16, 1, 3, generator=g))).cuda()
 	rng = np.random.RandomState(7)
-	R, T = camera_ref.look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
-	R, T = torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda()
+	R, T = look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
+	R, T = R.cuda(), T.cuda()
 	params = FR.make_params(size)
 	L = _lib.lib()
 	faces = _faces_i32(f.cuda())

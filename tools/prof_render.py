@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from find_amd import functional_render as FR, synthetic
-from oracle import camera_ref
+from find_amd.cameras import look_at_view_transform
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 want_image = (sys.argv[2] != '0') if len(sys.argv) > 2 else True
 v, f = synthetic.template(6890)
@@ -11,8 +11,8 @@ g = torch.Generator().manual_seed(0)
 verts = (v[None] * (1 + 0.1 * torch.rand(16, 1, 3, generator=g))).cuda()
 cols = torch.rand(16, v.shape[0], 3, generator=g).cuda()
 rng = np.random.RandomState(7)
-R, T = camera_ref.look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
-R, T, fc = torch.from_numpy(R).cuda(), torch.from_numpy(T).cuda(), f.cuda()
+R, T = look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
+R, T, fc = R.cuda(), T.cuda(), f.cuda()
 params = FR.make_params(size)
 gt = torch.rand(16, 4, size, size, generator=g).cuda()
 for _ in range(6):
