@@ -235,6 +235,20 @@ int find_render_bwd(const find_render_params* rp, const float* verts, const int3
  * only a pixel with more than 1024 candidates is not resolved -- all of its candidates stay blended. */
 int find_render_flags(const void* ws, int32_t* out2, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor optimiser steps.  Replace torch.optim.Adam / torch.optim.SGD(momentum=0.9)
+ * as constructed by the reference (src/train/train.py:161-168) and stepped once per batch
+ * (src/train/trainer.py:121-123).  `param`, `grad`, moment arrays: HOST arrays of n_tensors DEVICE pointers (fp32,
+ * contiguous); `numel`: host array.  Dense updates, torch's single-tensor arithmetic operation for operation;
+ * amsgrad / maximize / foreach-only options are not provided.
+ * find_adam_step: `step` is the 1-based count INCLUDING this update (torch's state['step'] after it).
+ * find_sgd_step: `first_step` != 0 initialises the momentum buffers to the gradient (torch clones it).
+ * ---------------------------------------------------------------------------------------------- */
+int find_adam_step(int64_t n_tensors, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+				   const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+int find_sgd_step(int64_t n_tensors, float* const* param, const float* const* grad, float* const* momentum_buf, const int64_t* numel,
+				  float lr, float momentum, float dampening, float weight_decay, int nesterov, int first_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,73 @@
+"""Fused optimisers (C-ABI find_adam_step / find_sgd_step behind find_amd.optim) against the oracle's golden trajectories and
+against torch.optim running on the same device: the three optimisers of the reference's step (train.py:161-168)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_optim import CASES, GOLD, SHAPES, STEPS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gold():
+	return np.load(GOLD)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_fused_step_matches_golden_trajectory(gold, name):
+	from find_amd import optim
+	kind, kw = CASES[name]
+	ps = [torch.nn.Parameter(torch.from_numpy(gold[f'p0/{i}']).cuda()) for i in range(SHAPES)]
+	opt = (optim.Adam if kind == 'adam' else optim.SGD)(ps, **kw)
+	for k in range(STEPS):
+		for i, p in enumerate(ps):
+			p.grad = torch.from_numpy(gold[f'grad/{k}/{i}']).cuda()
+		opt.step()
+		for i, p in enumerate(ps):
+			ref = gold[f'{name}/{k}/{i}']
+			assert np.allclose(p.detach().cpu().numpy(), ref, rtol=2e-6, atol=1e-7), (name, k, i)
+
+
+def test_find_parameter_set_matches_torch_optim_and_state_dict_is_compatible():
+	"""The real parameter set (MLP + latent tables + registration, 16 training feet): 5 steps of the reference's three optimisers,
+	fused vs torch.optim on the same GPU; the state_dict of one loads into the other."""
+	from find_amd import optim, synthetic
+	g = torch.Generator().manual_seed(0)
+	models = [synthetic.make_model(1002, train_size=16, val_size=2, device='cuda') for _ in range(2)]
+	models[1].load_state_dict(models[0].state_dict())
+
+	def groups(m):
+		return [p for p in m.main_params], [p for p in m.reg_params], [p for p in m.latent_params]
+
+	(n0, r0, l0), (n1, r1, l1) = groups(models[0]), groups(models[1])
+	fused = [optim.Adam(n0, lr=5e-4), optim.SGD(r0, lr=1e-2, momentum=0.9), optim.Adam(l0, lr=1e-3)]
+	ref = [torch.optim.Adam(n1, lr=5e-4), torch.optim.SGD(r1, lr=1e-2, momentum=0.9), torch.optim.Adam(l1, lr=1e-3)]
+	for k in range(5):
+		for pa, pb in zip(n0 + r0 + l0, n1 + r1 + l1):
+			gr = torch.randn(pa.shape, generator=g).cuda() * 0.1
+			pa.grad, pb.grad = gr.clone(), gr.clone()
+		for o in fused + ref:
+			o.step()
+	for pa, pb in zip(n0 + r0 + l0, n1 + r1 + l1):
+		assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-7)
+	# state round trip: torch's optimiser continues from the fused one's state and vice versa
+	sd = fused[0].state_dict()
+	t2 = torch.optim.Adam(n1, lr=5e-4)
+	t2.load_state_dict(sd)
+	f2 = optim.Adam(n0, lr=5e-4)
+	f2.load_state_dict(ref[0].state_dict())
+	for pa, pb in zip(n0, n1):
+		gr = torch.randn(pa.shape, generator=g).cuda() * 0.1
+		pa.grad, pb.grad = gr.clone(), gr.clone()
+	f2.step(); t2.step()
+	for pa, pb in zip(n0, n1):
+		assert torch.allclose(pa, pb, rtol=4e-6, atol=2e-7)
+
+
+def test_optimiser_rejects_cpu_parameters():
+	from find_amd import optim
+	p = torch.nn.Parameter(torch.zeros(4))
+	p.grad = torch.ones(4)
+	with pytest.raises(RuntimeError, match='no CPU fallback'):
+		optim.Adam([p]).step()
