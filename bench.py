@@ -147,6 +147,112 @@ def cpu_baseline(sample_feet=2, steps=2):
 					   f'(best of a {sorted(probe)}-thread probe; host exposes {avail} hardware threads)')
 
 
+def train3d(with_cpu, steps, warmup, n_feet=16):
+	"""The reference's own training configuration (cfgs/train_3d.yaml: losses chamf + smooth + texture, nothing rendered in the
+	timed loop, so views := 1): ModelWithLoss.forward on a batch of `n_feet` feet (6890-vertex template, 10 002-vertex GT scans,
+	5000 / 1000 surface samples as losses.py:27,61), backward, and the step of the three optimisers (train.py:161-168).  One
+	JSON line; the CPU leg runs the oracle's composition of the same step on a bounded sample of feet."""
+	from find_amd import optim, synthetic
+	from find_amd.model_with_loss import ModelWithLoss
+	from find_amd.opts import Opts
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.train_utils import sample_latent_vectors
+	if not torch.cuda.is_available():
+		raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+	dev = torch.device('cuda', 0)
+	opts = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True)
+	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=n_feet, val_size=2,
+						shapevec_size=100, texvec_size=100, posevec_size=100, template_mesh_loc=None)
+	g = torch.Generator().manual_seed(1234)
+	with torch.no_grad():
+		mwl.model.mlp_disp[-1].weight.copy_(torch.randn(mwl.model.mlp_disp[-1].weight.shape, generator=g) * 0.01)
+		mwl.model.mlp_disp[-1].bias.copy_(torch.randn(3, generator=g) * 0.01)
+	mwl = mwl.to(dev)
+	v, f = synthetic.template(N_VERTS)
+	mwl.model.set_template(v.to(dev), f.to(dev))
+	lat = synthetic.latents(n_feet, seed=0, device=dev)
+	with torch.no_grad():
+		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+			getattr(mwl.model, k).data.copy_(lat[k])
+	gv, gf, gc = synthetic.gt_feet(n_feet, 10002, seed=0, device=dev)
+	batch = dict(mesh=Meshes(gv, gf, TexturesVertex(gc.clamp(0.05, 0.95))), idx=torch.arange(n_feet, device=dev), name=[f'{i:04d}' for i in range(n_feet)])
+	m = mwl.model
+	optims = [optim.Adam(m.main_params, lr=5e-4), optim.SGD(m.reg_params, lr=1e-3, momentum=0.9), optim.Adam(m.latent_params, lr=1e-3)]
+
+	def step():
+		for o in optims:
+			o.zero_grad(set_to_none=True)
+		b = dict(batch)
+		b.update(sample_latent_vectors(b, m.latent_vectors_train))
+		loss, _ = mwl(b, 0, opts, chamf=True, smooth=True, texture=True)
+		loss.backward()
+		for o in optims:
+			o.step()
+		return loss
+
+	for _ in range(warmup):
+		step()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		step()
+	torch.cuda.synchronize()
+	ms = (time.perf_counter() - t0) / steps * 1e3
+	out = {'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': n_feet * N_VERTS / (ms * 1e-3), 'unit': 'vertices*views/s', 'n_gpus': 1,
+		   'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+		   'data': 'synthetic',
+		   'config': {'workload': f'train_3d.yaml: {n_feet} feet x {N_VERTS}-vertex template, GT 10002-vertex scans, losses chamf(5000 samples) + smooth + '
+								  f'texture(1000 samples), backward, Adam/SGD/Adam steps; nothing rendered, views:=1', 'feet_per_gpu': n_feet}}
+	if with_cpu:
+		out['cpu_baseline'] = train3d_cpu(mwl, batch, gv, gf, gc)
+	print(json.dumps(out), flush=True)
+
+
+def train3d_cpu(mwl, batch, gv, gf, gc, sample_feet=1):
+	"""Oracle composition of the same step (tests/test_gpu_pipeline.py::test_train_3d_loss_set_matches_oracle) on `sample_feet` feet."""
+	from oracle import geom_ref, mlp_ref
+	m = mwl.model
+	nf = sample_feet
+	sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
+		  for k, v in m.state_dict().items()}
+	B, tv, tf = m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
+	lat = {k: getattr(m, k).data.detach().cpu()[:nf].clone().requires_grad_(True) for k in ('shapevec', 'texvec', 'posevec', 'reg')}
+	gvc, gfc, gcc = gv.cpu()[:nf], gf.cpu(), gc.cpu()[:nf].clamp(0.05, 0.95)
+	g = torch.Generator().manual_seed(0)
+
+	def draws(verts, faces, n):
+		areas = geom_ref.face_areas(verts, faces)
+		return torch.multinomial(areas, n, replacement=True, generator=g), torch.rand(verts.shape[0], n, 2, generator=g)
+
+	def one():
+		t0 = time.perf_counter()
+		res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+		fi, uv = draws(gvc, gfc, 5000)
+		gt_s = geom_ref.sample_points(gvc, gfc, fi, uv)
+		fi, uv = draws(res['verts'].detach(), tf, 5000)
+		pr_s = geom_ref.sample_points(res['verts'], tf, fi, uv)
+		l_ch = geom_ref.chamfer_distance(pr_s, gt_s)
+		l_sm = geom_ref.mesh_smoothness(res['verts'], tf)
+		fi, uv = draws(gvc, gfc, 1000)
+		tx_p, tx_c = geom_ref.sample_points(gvc, gfc, fi, uv, attr=gcc)
+		col = mlp_ref.mlp_forward(sd, B, tx_p, lat['shapevec'], lat['texvec'], lat['posevec'])['col']
+		mask = (tx_c < 1).any(dim=-1, keepdim=True).expand(-1, -1, 3)
+		l_tx = (torch.nn.functional.mse_loss(col, tx_c, reduction='none') * mask).mean()
+		(l_ch * 10000. + l_sm * 1000. + l_tx).backward()
+		return time.perf_counter() - t0
+
+	try:
+		avail = len(os.sched_getaffinity(0))
+	except AttributeError:
+		avail = os.cpu_count() or 1
+	cores = min(avail, 16)
+	torch.set_num_threads(cores)
+	one()
+	best = min(one() for _ in range(2))
+	return dict(value=nf * N_VERTS / best, unit='vertices*views/s', cores=cores, kind='port',
+				sample=f'{nf} of the feet, same step without the optimiser update, best of 2, oracle (torch-CPU / numpy) with {cores} threads')
+
+
 def subpaths(with_cpu):
 	"""Sub-path lines (tools/bench_paths.py workloads).  The CPU leg times the oracle on one foot / one image of the same inputs."""
 	sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
@@ -175,10 +281,13 @@ def main():
 	ap.add_argument('--steps', type=int, default=30)
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
+	ap.add_argument('--train3d', action='store_true', help='instead of the headline line: the reference training configuration (train_3d.yaml losses + optimiser steps)')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
 	args = ap.parse_args()
 	if args.subpaths:
 		return subpaths(not args.no_cpu_baseline)
+	if args.train3d:
+		return train3d(not args.no_cpu_baseline, args.steps, args.warmup)
 
 	import torch.distributed as dist
 	from find_amd import distributed as fdist
