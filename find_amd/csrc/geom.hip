@@ -89,8 +89,11 @@ __global__ void sample_bwd_kernel(const int32_t* __restrict__ faces, int64_t fac
 }
 
 // ------------------------------------------------------------------------------------------- nearest neighbour
-// One thread owns NQ query points; target points stream through LDS in tiles of NN_TILE (x,y,z,pad float4 so a
-// wave-uniform ds_read_b128 broadcasts one target to all lanes).  Strict '<' on ascending j keeps the lowest index on ties.
+// A lane owns NQ query points; the four waves of a block own the SAME 64*NQ queries and each scans one quarter of every
+// target tile (targets stream through LDS in tiles of NN_TILE, x,y,z,pad float4, a wave-uniform ds_read_b128 broadcasts one
+// target to all lanes), so that FIND's small clouds (5-10 k points x 16 feet) still put more than two waves on every SIMD.
+// Strict '<' on ascending j keeps the lowest index on ties inside a wave; the four partial results are merged through LDS by
+// (distance, index), which is the same rule.
 constexpr int NN_TILE = 1024;
 constexpr int NQ = 2;
 
@@ -98,7 +101,10 @@ __global__ __launch_bounds__(256) void nn_fwd_kernel(const float* __restrict__ x
 													  const float* __restrict__ y, const int32_t* __restrict__ y_len, int p1_max,
 													  int p2_max, float* __restrict__ dist, int32_t* __restrict__ idx) {
 	__shared__ float4 ty[NN_TILE];
+	__shared__ float pbest[4][64 * NQ];
+	__shared__ int pidx[4][64 * NQ];
 	const int n = blockIdx.y;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int p1 = x_len ? x_len[n] : p1_max;
 	const int p2 = y_len ? y_len[n] : p2_max;
 	const float* xp = x + (int64_t)n * p1_max * 3;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void nn_fwd_kernel(const float* __restrict__ x
 	int bi[NQ], qi[NQ];
 #pragma unroll
 	for (int k = 0; k < NQ; ++k) {
-		qi[k] = (blockIdx.x * NQ + k) * 256 + threadIdx.x;
+		qi[k] = (blockIdx.x * NQ + k) * 64 + lane;
 		const int i = min(qi[k], p1_max - 1);
 		qx[k] = xp[i * 3 + 0]; qy[k] = xp[i * 3 + 1]; qz[k] = xp[i * 3 + 2];
 		best[k] = INFINITY; bi[k] = -1;
@@ -120,8 +126,9 @@ __global__ __launch_bounds__(256) void nn_fwd_kernel(const float* __restrict__ x
 			ty[j] = make_float4(s[0], s[1], s[2], 0.f);
 		}
 		__syncthreads();
+		const int ja = wave * (NN_TILE / 4), jb = min(cnt, ja + NN_TILE / 4);
 #pragma unroll 4
-		for (int j = 0; j < cnt; ++j) {
+		for (int j = ja; j < jb; ++j) {
 			const float4 t = ty[j];
 #pragma unroll
 			for (int k = 0; k < NQ; ++k) {
@@ -132,11 +139,24 @@ __global__ __launch_bounds__(256) void nn_fwd_kernel(const float* __restrict__ x
 		}
 	}
 #pragma unroll
-	for (int k = 0; k < NQ; ++k) {
-		if (qi[k] < p1_max) {
-			const bool valid = qi[k] < p1 && p2 > 0;
-			dist[(int64_t)n * p1_max + qi[k]] = valid ? best[k] : 0.f;
-			idx[(int64_t)n * p1_max + qi[k]] = valid ? bi[k] : -1;
+	for (int k = 0; k < NQ; ++k) { pbest[wave][k * 64 + lane] = best[k]; pidx[wave][k * 64 + lane] = bi[k]; }
+	__syncthreads();
+	if (wave == 0) {
+#pragma unroll
+		for (int k = 0; k < NQ; ++k) {
+			float b = best[k];
+			int ib = bi[k];
+#pragma unroll
+			for (int w = 1; w < 4; ++w) {
+				const float ob = pbest[w][k * 64 + lane];
+				const int oi = pidx[w][k * 64 + lane];
+				if (oi >= 0 && (ib < 0 || ob < b || (ob == b && oi < ib))) { b = ob; ib = oi; }
+			}
+			if (qi[k] < p1_max) {
+				const bool valid = qi[k] < p1 && p2 > 0;
+				dist[(int64_t)n * p1_max + qi[k]] = valid ? b : 0.f;
+				idx[(int64_t)n * p1_max + qi[k]] = valid ? ib : -1;
+			}
 		}
 	}
 }
@@ -371,7 +391,7 @@ extern "C" int find_nn_fwd(const float* x, const int32_t* x_len, const float* y,
 						   int64_t p2_max, float* dist, int32_t* idx, void* stream) {
 	FIND_REQUIRE(x && y && dist && idx, "find_nn_fwd: NULL argument");
 	FIND_REQUIRE(!bad_dims(n, p1_max) && p2_max >= 1 && p2_max < (1ll << 30), "find_nn_fwd: bad sizes");
-	hipLaunchKernelGGL(nn_fwd_kernel, dim3((unsigned)cdiv(p1_max, 256 * NQ), (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, x_len, y, y_len,
+	hipLaunchKernelGGL(nn_fwd_kernel, dim3((unsigned)cdiv(p1_max, 64 * NQ), (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, x_len, y, y_len,
 					   (int)p1_max, (int)p2_max, dist, idx);
 	FIND_LAUNCH_CHECK("nn_fwd_kernel");
 	return FIND_OK;
