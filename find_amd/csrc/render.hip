@@ -897,3 +897,86 @@ extern "C" int find_render_flags(const void* ws, int32_t* out2, void* stream) {
 	if (e != hipSuccess) { set_error("find_render_flags: %s", hipGetErrorString(e)); return FIND_ELAUNCH; }
 	return FIND_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ UV textures
+// TexturesUV.sample_textures (PyTorch3D, used by the reference for GT scans: src/data/dataset.py:263-271, losses.py:39-43,
+// renderer.py:329-346): the UV of a surface point is the barycentric mix of its face's three UV vertices; the map is flipped
+// vertically and read with grid_sample(mode='bilinear', align_corners=True, padding_mode='border'), i.e. at
+// x = u (W-1), y = (1-v) (H-1), clamped to the border.
+namespace find {
+namespace render {
+
+__global__ void uv_sample_kernel(const float* __restrict__ maps, int Ht, int Wt, const float* __restrict__ verts_uvs, int Vt,
+								 const int32_t* __restrict__ faces_uvs, int64_t faces_mesh_stride, int F, const int32_t* __restrict__ face_idx,
+								 const float* __restrict__ bary, int64_t P, int64_t rows_per_map, float* __restrict__ out) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t row = blockIdx.y;
+	if (i >= P) return;
+	const int64_t o = row * P + i;
+	const int f = face_idx[o];
+	float* op = out + o * 3;
+	if (f < 0 || f >= F) { op[0] = op[1] = op[2] = 0.f; return; }
+	const int64_t mesh = row / rows_per_map;
+	const int32_t* fu = faces_uvs + mesh * faces_mesh_stride + (int64_t)f * 3;
+	const float* uvp = verts_uvs + mesh * (int64_t)Vt * 2;
+	float u = 0.f, v = 0.f;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const float w = bary[o * 3 + k];
+		u += w * uvp[2 * fu[k]];
+		v += w * uvp[2 * fu[k] + 1];
+	}
+	// grid_sample, align_corners=True, on the vertically flipped map; border padding = clamp of the source coordinate
+	float x = u * (float)(Wt - 1), y = (1.0f - v) * (float)(Ht - 1);
+	x = fminf(fmaxf(x, 0.f), (float)(Wt - 1));
+	y = fminf(fmaxf(y, 0.f), (float)(Ht - 1));
+	const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+	const int x1 = min(x0 + 1, Wt - 1), y1 = min(y0 + 1, Ht - 1);
+	const float tx = x - (float)x0, ty = y - (float)y0;
+	const float* mp = maps + mesh * (int64_t)Ht * Wt * 3;
+	const float* p00 = mp + ((int64_t)y0 * Wt + x0) * 3;
+	const float* p01 = mp + ((int64_t)y0 * Wt + x1) * 3;
+	const float* p10 = mp + ((int64_t)y1 * Wt + x0) * 3;
+	const float* p11 = mp + ((int64_t)y1 * Wt + x1) * 3;
+	const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) op[c] = w00 * p00[c] + w01 * p01[c] + w10 * p10[c] + w11 * p11[c];
+}
+
+}  // namespace render
+}  // namespace find
+
+extern "C" int find_uv_sample(const float* maps, int64_t n_maps, int64_t map_h, int64_t map_w, const float* verts_uvs, int64_t n_uv_verts,
+							  const int32_t* faces_uvs, int64_t faces_batch, int64_t n_faces, const int32_t* face_idx, const float* bary,
+							  int64_t n_rows, int64_t n_points, float* out, void* stream) {
+	FIND_REQUIRE(maps && verts_uvs && faces_uvs && face_idx && bary && out, "find_uv_sample: NULL argument");
+	FIND_REQUIRE(n_maps >= 1 && map_h >= 1 && map_w >= 1 && map_h < (1 << 15) && map_w < (1 << 15) && n_uv_verts >= 1 && n_faces >= 1,
+				 "find_uv_sample: bad map / topology sizes");
+	FIND_REQUIRE(faces_batch == 1 || faces_batch == n_maps, "find_uv_sample: faces_batch must be 1 or n_maps");
+	FIND_REQUIRE(n_rows >= 1 && n_rows < 65536 && n_rows % n_maps == 0 && n_points >= 0, "find_uv_sample: n_rows must be a multiple of n_maps (rows of one map are consecutive)");
+	if (n_points == 0) return FIND_OK;
+	hipLaunchKernelGGL(render::uv_sample_kernel, dim3((unsigned)cdiv(n_points, 256), (unsigned)n_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), maps,
+					   (int)map_h, (int)map_w, verts_uvs, (int)n_uv_verts, faces_uvs, faces_batch == 1 ? 0 : n_faces * 3, (int)n_faces, face_idx, bary, n_points,
+					   n_rows / n_maps, out);
+	FIND_LAUNCH_CHECK("uv_sample_kernel");
+	return FIND_OK;
+}
+
+/* Nearest-fragment buffers of the forward that used `ws`: local face id (-1 = background) and perspective-correct
+ * barycentrics per pixel -- the inputs of find_uv_sample for a UV-textured render. */
+extern "C" int find_render_frags(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t n_verts, int64_t n_faces, const void* ws,
+								 int32_t* face_local, float* bary, void* stream) {
+	int rc = check_params(rp, n_meshes, n_views, n_verts, n_faces);
+	if (rc != FIND_OK) return rc;
+	FIND_REQUIRE(ws && face_local && bary, "find_render_frags: NULL argument");
+	Ws w;
+	carve(rp, n_meshes, n_views, n_verts, n_faces, const_cast<void*>(ws), &w);
+	const int64_t px = n_meshes * n_views * rp->image_h * rp->image_w;
+	hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+	if (hipMemcpyAsync(face_local, w.p2f, px * sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+		hipMemcpyAsync(bary, w.bary, px * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+		set_error("find_render_frags: copy failed");
+		return FIND_ELAUNCH;
+	}
+	return FIND_OK;
+}

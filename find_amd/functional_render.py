@@ -88,3 +88,57 @@ def render_flags(ws):
 	out = (ctypes.c_int32 * 2)()
 	check(L.find_render_flags(ptr(ws), ctypes.cast(out, ctypes.c_void_p), current_stream(ws.device)), 'find_render_flags')
 	return int(out[0]), int(out[1])
+
+
+def uv_sample(maps, verts_uvs, faces_uvs, face_idx, bary):
+	"""Colours of surface points from UV maps (TexturesUV.sample_textures): maps (Nm,H,W,3), verts_uvs (Nm,Vt,2), faces_uvs (Nm|1,F,3),
+	face_idx (R,P) local face ids (-1 -> zeros), bary (R,P,3), R a multiple of Nm with the rows of one map consecutive.  No gradient
+	(the reference only ever samples GT scans)."""
+	_require_gpu(maps, verts_uvs, bary)
+	L = _lib.lib()
+	maps, verts_uvs, bary = _c(maps.detach()), _c(verts_uvs.detach()), _c(bary.detach())
+	fu = _faces_i32(faces_uvs)
+	fi = face_idx if face_idx.dtype == torch.int32 else face_idx.to(torch.int32)
+	fi = fi.contiguous()
+	fb = 1 if fu.dim() == 2 else fu.shape[0]
+	Rr, P = fi.shape
+	out = torch.empty(Rr, P, 3, device=maps.device, dtype=torch.float32)
+	check(L.find_uv_sample(ptr(maps), maps.shape[0], maps.shape[1], maps.shape[2], ptr(verts_uvs), verts_uvs.shape[1], ptr(fu), fb, fu.shape[-2], ptr(fi), ptr(bary),
+						   Rr, P, ptr(out), current_stream(maps.device)), 'find_uv_sample')
+	return out
+
+
+def render_frags(ws, params, n_meshes, n_views, n_verts, n_faces):
+	"""(local face id (N,M,H,W) int32, perspective-correct barycentrics (N,M,H,W,3)) of the forward that used `ws`."""
+	L = _lib.lib()
+	H, W = params.image_h, params.image_w
+	f = torch.empty(n_meshes, n_views, H, W, device=ws.device, dtype=torch.int32)
+	b = torch.empty(n_meshes, n_views, H, W, 3, device=ws.device, dtype=torch.float32)
+	check(L.find_render_frags(ctypes.byref(params), n_meshes, n_views, n_verts, n_faces, ptr(ws), ptr(f), ptr(b), current_stream(ws.device)), 'find_render_frags')
+	return f, b
+
+
+def render_uv(verts, tex, faces, R, T, params, want_mask=True, want_frags=False):
+	"""FootRenderer image of UV-textured meshes (GT scans; no gradient): the Phong + softmax blend is linear in the texture colour, so
+	image = o0 + (o1 - o0) * texel with o0 / o1 the renders with black / white vertex colours and texel the map read at every pixel's
+	nearest fragment.  Returns (mask, image, pix_to_face, zbuf)."""
+	with torch.no_grad():
+		N, V, _ = verts.shape
+		M = R.shape[0]
+		Fn = faces.shape[-2]
+		ones = torch.ones(N, V, 3, device=verts.device)
+		L = _lib.lib()
+		mask, o1, p2f, zbuf = _Render.apply(verts, ones, faces, R, T, params, want_mask, True, True)
+		# the fragments of that forward (its workspace is not exposed by autograd.Function: run the raster once more for the buffers)
+		vv, ff = _c(verts), _faces_i32(faces)
+		fb = 1 if ff.dim() == 2 else ff.shape[0]
+		ws = _ws(L.find_render_ws_bytes(ctypes.byref(params), N, M, V, Fn), verts.device)
+		o0 = torch.empty_like(o1)
+		zeros = torch.zeros_like(ones)
+		check(L.find_render_fwd(ctypes.byref(params), ptr(vv), ptr(ff), fb, ptr(zeros), ptr(_c(R)), ptr(_c(T)), N, M, V, Fn, None, ptr(o0), None, None,
+								ptr(ws), ws.numel(), current_stream(verts.device)), 'find_render_fwd')
+		fl, bary = render_frags(ws, params, N, M, V, Fn)
+		H, W = params.image_h, params.image_w
+		texel = uv_sample(tex.maps_padded(), tex.verts_uvs_padded(), tex.faces_uvs_padded(), fl.reshape(N, M * H * W), bary.reshape(N, M * H * W, 3))
+		image = o0 + (o1 - o0) * texel.reshape(N, M, H, W, 3)
+	return mask, image, (p2f if want_frags else None), (zbuf if want_frags else None)

@@ -8,7 +8,8 @@ import torch
 from torch.nn import functional as F
 
 from . import functional as FN
-from .structures import Meshes, TexturesVertex
+from . import functional_render as FR
+from .structures import Meshes, TexturesUV, TexturesVertex
 
 nn = torch.nn
 
@@ -31,8 +32,14 @@ def sample_points_from_meshes(meshes: Meshes, num_samples: int = 10000, return_t
 		face_idx, uv = draws
 	if return_textures:
 		tex = meshes.textures
+		if isinstance(tex, TexturesUV):
+			# PyTorch3D: barycentrics of the sample (w0 = 1 - sqrt(u), w1 = sqrt(u)(1 - v), w2 = sqrt(u) v), then TexturesUV.sample_textures
+			pts = FN.sample_points(verts, faces, face_idx, uv)
+			su = uv[..., 0].sqrt()
+			bary = torch.stack([1.0 - su, su * (1.0 - uv[..., 1]), su * uv[..., 1]], dim=-1)
+			return pts, FR.uv_sample(tex.maps_padded(), tex.verts_uvs_padded(), tex.faces_uvs_padded(), face_idx, bary)
 		if not isinstance(tex, TexturesVertex):
-			raise NotImplementedError('return_textures needs per-vertex colours (TexturesVertex); TexturesUV sampling is SURVEY §8(f1)')
+			raise NotImplementedError('return_textures needs TexturesVertex or TexturesUV')
 		return FN.sample_points(verts, faces, face_idx, uv, tex.verts_features_padded()[..., :3].contiguous())
 	return FN.sample_points(verts, faces, face_idx, uv)
 

@@ -8,7 +8,7 @@ import torch
 
 from . import functional_render as FR
 from .cameras import look_at_view_transform
-from .structures import Meshes, TexturesVertex
+from .structures import Meshes, TexturesUV, TexturesVertex
 
 nn = torch.nn
 
@@ -90,17 +90,24 @@ class FootRenderer(nn.Module):
 			faces = input_meshes.faces_padded()
 		F = faces.shape[-2]
 		colors = None
-		if return_images:
-			tex = input_meshes.textures
+		tex = input_meshes.textures
+		uv_tex = isinstance(tex, TexturesUV)
+		if return_images and not uv_tex:
 			if not isinstance(tex, TexturesVertex):
-				raise NotImplementedError('return_images needs per-vertex colours (TexturesVertex); TexturesUV sampling is SURVEY §8(f1)')
+				raise NotImplementedError('return_images needs TexturesVertex or TexturesUV textures')
 			colors = tex.verts_features_padded()[..., :3]
 		want_soft = return_mask and (mask_with_grad or not return_images)
 		want_frags = mask_out_faces or return_depth
 		if not (return_images or want_soft or want_frags):
 			return dict()
-		mask, renders, p2f, zbuf = FR.render(verts, colors, faces, R, T, self.params, want_mask=want_soft, want_image=return_images,
-											 want_frags=want_frags)
+		if return_images and uv_tex:
+			# GT scans (dataset.py:263-271): no gradient flows to a UV-textured mesh anywhere in the reference
+			if verts.requires_grad:
+				raise NotImplementedError('UV-textured meshes are rendered without gradient (GT scans); use TexturesVertex for predicted meshes')
+			mask, renders, p2f, zbuf = FR.render_uv(verts, tex, faces, R, T, self.params, want_mask=want_soft, want_frags=want_frags)
+		else:
+			mask, renders, p2f, zbuf = FR.render(verts, colors, faces, R, T, self.params, want_mask=want_soft, want_image=return_images,
+												 want_frags=want_frags)
 		out = dict()
 		if return_depth:
 			out['depth'] = zbuf
@@ -108,17 +115,24 @@ class FootRenderer(nn.Module):
 			mask = torch.any(renders < 1, dim=-1).float()
 
 		mask_out = torch.zeros((N, M, self.params.image_h, self.params.image_w), dtype=torch.bool, device=dev)
-		if mask_out_faces and masked_faces is not None:
+		if mask_out_faces and (masked_faces is not None or uv_tex):
 			img = torch.arange(N * M, device=dev, dtype=torch.int32).view(N, M, 1, 1)
 			local = torch.where(p2f >= 0, p2f - img * F, p2f)  # face count within the mesh (renderer.py:322-327)
 			for n in range(N):
-				mf = masked_faces[n] if isinstance(masked_faces, list) else masked_faces
+				if masked_faces is not None:
+					mf = masked_faces[n] if isinstance(masked_faces, list) else masked_faces
+				else:
+					# TexturesUV convention (renderer.py:340-349): a final UV vertex at (0, 0) marks faces to mask out -- those whose three
+					# UV indices all point at it; the first mesh without the marker ends the search, as the reference's `break`
+					vu, fu = tex.verts_uvs_padded()[n], tex.faces_uvs_padded()[n]
+					if not bool((vu[-1] == 0).all()):
+						break
+					mf = torch.argwhere(torch.all(fu == vu.shape[0] - 1, dim=-1)).flatten()
 				mask_out[n] = torch.isin(local[n], mf.to(dev).to(local.dtype))
 			if return_images:
 				renders = torch.where(mask_out.unsqueeze(-1), torch.ones_like(renders), renders)
 			if return_mask:
 				mask = torch.where(mask_out, torch.zeros_like(mask), mask)
-		# (masks derived from a "u=v=0" UV vertex need TexturesUV -- SURVEY §8(f1); without them nothing is masked out)
 
 		if return_images:
 			out['image'] = renders

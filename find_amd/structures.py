@@ -42,6 +42,53 @@ class TexturesVertex:
 		return self._feat.shape[0]
 
 
+class TexturesUV:
+	"""UV-mapped textures -- pytorch3d.renderer.TexturesUV subset used by the reference for GT scans (src/data/dataset.py:263-271):
+	maps (N, H, W, 3), faces_uvs (N, F, 3) indices into verts_uvs (N, Vt, 2).  Sampling = find_amd.functional_render.uv_sample
+	(flip + grid_sample(align_corners=True, padding_mode='border'), PyTorch3D's defaults)."""
+
+	def __init__(self, maps, faces_uvs, verts_uvs):
+		if isinstance(maps, (list, tuple)):
+			maps = torch.stack(list(maps))
+		if isinstance(faces_uvs, (list, tuple)):
+			faces_uvs = _pad_list(list(faces_uvs), -1)[0]
+		if isinstance(verts_uvs, (list, tuple)):
+			verts_uvs = _pad_list(list(verts_uvs), 0.0)[0]
+		if maps.dim() != 4 or maps.shape[-1] != 3 or faces_uvs.dim() != 3 or verts_uvs.dim() != 3 or verts_uvs.shape[-1] != 2:
+			raise ValueError('TexturesUV expects maps (N,H,W,3), faces_uvs (N,F,3), verts_uvs (N,Vt,2)')
+		if not (maps.shape[0] == faces_uvs.shape[0] == verts_uvs.shape[0]):
+			raise ValueError('TexturesUV: batch sizes differ')
+		self._maps, self._faces_uvs, self._verts_uvs = maps.float(), faces_uvs, verts_uvs.float()
+
+	def maps_padded(self):
+		return self._maps
+
+	def faces_uvs_padded(self):
+		return self._faces_uvs
+
+	def verts_uvs_padded(self):
+		return self._verts_uvs
+
+	def extend(self, M):
+		return TexturesUV(self._maps.repeat_interleave(M, dim=0), self._faces_uvs.repeat_interleave(M, dim=0), self._verts_uvs.repeat_interleave(M, dim=0))
+
+	def clone(self):
+		return TexturesUV(self._maps.clone(), self._faces_uvs.clone(), self._verts_uvs.clone())
+
+	def detach(self):
+		return TexturesUV(self._maps.detach(), self._faces_uvs, self._verts_uvs.detach())
+
+	def to(self, device):
+		return TexturesUV(self._maps.to(device), self._faces_uvs.to(device), self._verts_uvs.to(device))
+
+	def __getitem__(self, idx):
+		sl = (lambda t: t[idx].unsqueeze(0) if isinstance(idx, int) else t[idx])
+		return TexturesUV(sl(self._maps), sl(self._faces_uvs), sl(self._verts_uvs))
+
+	def __len__(self):
+		return self._maps.shape[0]
+
+
 def _pad_list(tensors, pad_value):
 	n = max(int(t.shape[0]) for t in tensors)
 	out = tensors[0].new_full((len(tensors), n) + tuple(tensors[0].shape[1:]), pad_value)

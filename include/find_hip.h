@@ -236,6 +236,21 @@ int find_render_bwd(const find_render_params* rp, const float* verts, const int3
 int find_render_flags(const void* ws, int32_t* out2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * UV textures.  Replaces pytorch3d TexturesUV.sample_textures as the reference uses it for GT scans
+ * (src/data/dataset.py:263-271 builds TexturesUV(img, faces_uvs, verts_uvs); losses.py:39-43 samples GT surface colours;
+ * renderer.py:329-346 renders GT images): colour at a surface point = bilinear read of the vertically flipped map at the
+ * barycentric mix of the face's three UV vertices (grid_sample align_corners=True, padding_mode='border').
+ * maps (n_maps,H,W,3); verts_uvs (n_maps,Vt,2); faces_uvs (1|n_maps, F, 3) int32; face_idx / bary (n_rows,P[,3]) with
+ * n_rows a multiple of n_maps (rows of one map consecutive: feet x views); face_idx < 0 -> zeros.
+ * find_render_frags copies out the nearest-fragment buffers (local face id, barycentrics) of the forward that used `ws`.
+ * ---------------------------------------------------------------------------------------------- */
+int find_uv_sample(const float* maps, int64_t n_maps, int64_t map_h, int64_t map_w, const float* verts_uvs, int64_t n_uv_verts,
+				   const int32_t* faces_uvs, int64_t faces_batch, int64_t n_faces, const int32_t* face_idx, const float* bary,
+				   int64_t n_rows, int64_t n_points, float* out, void* stream);
+int find_render_frags(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t n_verts, int64_t n_faces, const void* ws,
+					  int32_t* face_local, float* bary, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused multi-tensor optimiser steps.  Replace torch.optim.Adam / torch.optim.SGD(momentum=0.9)
  * as constructed by the reference (src/train/train.py:161-168) and stepped once per batch
  * (src/train/trainer.py:121-123).  `param`, `grad`, moment arrays: HOST arrays of n_tensors DEVICE pointers (fp32,
