@@ -81,3 +81,37 @@ def test_uv_textured_render_equals_vertex_colour_render_on_a_linear_map_and_mask
 	assert (c['image'][mo] == 1).all() and (c['mask'][mo] == 0).all()
 	d = rdr(Meshes(verts.cuda(), f.cuda(), tv.to('cuda')), R, T, return_mask=True, mask_out_faces=True, masked_faces=marked, return_mask_out_masks=True)
 	assert torch.equal(d['mask_out_masks'], mo)
+
+
+def test_dataset_batch_feeds_texture_loss_and_gt_render(tmp_path):
+	"""End to end for f1 + f2: OBJ/PNG/JSON folder -> Foot3DDataset -> BatchCollator (ragged Meshes + TexturesUV) -> the texture loss of
+	the hot path (UV-sampled GT colours) and a UV-textured GT render."""
+	import json, os
+	from tests.test_host_dataset import CFG_POSE, _write_scan
+	from find_amd import synthetic
+	from find_amd.dataset import BatchCollator, Foot3DDataset
+	from find_amd.losses import TextureLossGTSpace
+	from find_amd.renderer import FootRenderer
+	root = str(tmp_path)
+	data = []
+	for k, fid in enumerate(['0005', '0006']):
+		rel = f'{fid}/A/{fid}-A'
+		_write_scan(os.path.join(root, 'Meshes_sliced'), rel + '.obj', rel + '.png', 6 + k, (0.0, 0.0, 0.0))
+		data.append({'Foot ID': fid, 'Scan ID': 'A', 'footedness': 'Left', 'pose': ['T-Pose'], 'keypoints': None, 'OBJ file': rel + '.obj', 'PNG file': rel + '.png'})
+	jpath = os.path.join(root, 'index.json')
+	with open(jpath, 'w') as fh:
+		json.dump({'keypoint_labels': ['a'], 'data': data}, fh)
+	cfg = {'DATASET_FOLDER': root, 'DATASET_JSON': jpath, 'DATASET_NAME': 'Meshes_sliced', 'LOWPOLY_DATASET_NAME': 'x', 'VAL_FEET': [], 'TEMPLATE_FEET': [],
+		   'POSE_VECTOR': CFG_POSE}
+	ds = Foot3DDataset(cfg, device='cpu')
+	batch = BatchCollator(device='cuda').collate_batches([ds[0], ds[1]])
+	model = synthetic.make_model(1002, train_size=2, val_size=1, device='cuda')
+	lat = synthetic.latents(2, seed=0, device='cuda')
+	loss = TextureLossGTSpace()(model, batch, num_samples=300, shapevec=lat['shapevec'], texvec=lat['texvec'], posevec=lat['posevec'])
+	assert torch.isfinite(loss) and loss.item() > 0
+	loss.backward()
+	assert any(p.grad is not None and p.grad.abs().max() > 0 for p in model.mlp_col.parameters())
+	rdr = FootRenderer(image_size=48, device='cuda')
+	R, T = rdr.sample_views(nviews=2, dist_mean=0.3, dist_std=0, elev_min=20, elev_max=70, azim_min=-30, azim_max=30) if hasattr(rdr, 'sample_views') else None
+	out = rdr(batch['mesh'], R, T, return_mask=True)
+	assert out['image'].shape == (2, 2, 48, 48, 3) and torch.isfinite(out['image']).all() and (out['image'] < 1).any()

@@ -1,0 +1,110 @@
+"""find_amd.dataset on a synthetic Foot3D-shaped folder: OBJ + PNG + JSON index, the reference's filters, item
+keys and quirks (src/data/dataset.py:116-299), the collator's ragged Meshes + joined TexturesUV."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+CFG_POSE = {'SIZE': 8, 0: ['T-Pose'], 1: ['Plantarflex', 'Dorsiflex'], 2: ['Inversion', 'Eversion'], 3: ['Lateral', 'Medial'],
+			4: ['Toe Flexion', 'Toe Extension'], 5: ['Toe Abduction', 'Toe Adduction'], 6: ['Standing on Floor'], 7: ['Tiptoes']}
+
+
+def _write_scan(folder, rel_obj, rel_png, n_side, offset, quad=False):
+	from PIL import Image
+	os.makedirs(os.path.dirname(os.path.join(folder, rel_obj)), exist_ok=True)
+	g = np.random.RandomState(n_side)
+	lines = []
+	for i in range(n_side):
+		for j in range(n_side):
+			lines.append(f'v {i * 0.01 + offset[0]:.6f} {j * 0.01 + offset[1]:.6f} {0.002 * ((i * j) % 3) + offset[2]:.6f}')
+	for i in range(n_side):
+		for j in range(n_side):
+			lines.append(f'vt {i / (n_side - 1):.6f} {j / (n_side - 1):.6f}')
+	idx = lambda i, j: i * n_side + j + 1
+	for i in range(n_side - 1):
+		for j in range(n_side - 1):
+			a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+			if quad:
+				lines.append(f'f {a}/{a} {b}/{b} {c}/{c} {d}/{d}')
+			else:
+				lines.append(f'f {a}/{a} {b}/{b} {c}/{c}')
+				lines.append(f'f {a}/{a} {c}/{c} {d}/{d}')
+	with open(os.path.join(folder, rel_obj), 'w') as fh:
+		fh.write('# synthetic scan\nmtllib none.mtl\n' + '\n'.join(lines) + '\n')
+	img = (g.rand(8, 6, 3) * 255).astype(np.uint8)
+	Image.fromarray(img).save(os.path.join(folder, rel_png))
+	return img
+
+
+@pytest.fixture()
+def foot3d(tmp_path):
+	root = str(tmp_path)
+	mesh_dir = os.path.join(root, 'Meshes_sliced')
+	scans = [('0003', 'A', 'Left', ['T-Pose'], None), ('0005', 'A', 'Left', ['T-Pose'], [1, 2, 3]), ('0005', 'B', 'Left', ['Strong Dorsiflex', 'Eversion'], None),
+			 ('0007', 'A', 'Right', ['Tiptoes'], [4, 5, 6]), ('0021', 'A', 'Left', ['T-Pose'], None)]
+	data, imgs = [], {}
+	for k, (fid, sid, side, pose, kps) in enumerate(scans):
+		rel = f'{fid}/{sid}/{fid}-{sid}'
+		imgs[f'{fid}-{sid}'] = _write_scan(mesh_dir, rel + '.obj', rel + '.png', 4 + k, (0.1 * k, -0.05, 0.02), quad=(k == 2))
+		data.append({'Foot ID': fid, 'Scan ID': sid, 'footedness': side, 'pose': pose, 'keypoints': kps, 'OBJ file': rel + '.obj', 'PNG file': rel + '.png'})
+	jpath = os.path.join(root, 'index.json')
+	with open(jpath, 'w') as fh:
+		json.dump({'keypoint_labels': ['a', 'b', 'c'], 'data': data}, fh)
+	cfg = {'DATASET_FOLDER': root, 'DATASET_JSON': jpath, 'DATASET_NAME': 'Meshes_sliced', 'LOWPOLY_DATASET_NAME': 'Meshes_sliced_simplified',
+		   'VAL_FEET': ['0021'], 'TEMPLATE_FEET': ['0003'], 'POSE_VECTOR': CFG_POSE}
+	return cfg, imgs
+
+
+def test_filters_keys_and_items(foot3d):
+	from find_amd.dataset import Foot3DDataset
+	cfg, imgs = foot3d
+	tr = Foot3DDataset(cfg, device='cpu')
+	assert [f'{a}-{b}' for a, b in zip(tr.foot_ids, tr.scan_ids)] == ['0005-A', '0005-B']      # template, val and right feet dropped
+	assert len(Foot3DDataset(cfg, device='cpu', left_only=False)) == 3
+	assert Foot3DDataset(cfg, device='cpu', is_train=False).foot_ids == ['0021']
+	assert Foot3DDataset(cfg, device='cpu', tpose_only=True).scan_ids == ['A']
+	assert Foot3DDataset(cfg, device='cpu', specific_feet=['0003']).foot_ids == ['0003']
+	assert tr.get_all_keys() == {'shape': ['0005'], 'pose': ['0005-A', '0005-B'], 'tex': ['0005'], 'reg': ['0005-A', '0005-B']}
+	it = tr[1]
+	assert set(it) == {'faces', 'verts', 'textures', 'idx', 'name', 'has_keypoints', 'kp_idxs', 'is_tpose', 'orig_footedness', 'pose_descr', 'pose_code',
+					   'shape', 'pose', 'tex', 'reg'}
+	assert it['name'] == '0005-B' and not it['has_keypoints'] and (it['kp_idxs'] == 0).all() and not it['is_tpose']
+	assert it['pose_descr'] == 'Strong Dorsiflex,Eversion'
+	assert it['pose_code'].tolist() == [0, 1, 1, 0, 0, 0, 0, 0]                                  # 'Strong ' stripped; second entries are +1
+	assert it['verts'].shape == (36, 3) and it['faces'].shape == (50, 3)                         # 5x5 quads fan-triangulated
+	assert it['verts'].mean(0).abs().max() < 1e-6                                                # centred
+	assert torch.equal(it['textures'].maps_padded()[0], torch.from_numpy(imgs['0005-B'].astype(np.float32) / 255))
+	assert it['textures'].faces_uvs_padded().shape == (1, 50, 3) and it['textures'].verts_uvs_padded().shape == (1, 36, 2)
+	assert tr[0]['has_keypoints'] and tr[0]['kp_idxs'].tolist() == [1, 2, 3]
+	with pytest.raises(LookupError):
+		from find_amd.dataset import get_pose_code
+		get_pose_code(['Moonwalk'], cfg)
+
+
+def test_right_feet_are_mirrored_and_caching_and_no_texture(foot3d):
+	from find_amd.dataset import Foot3DDataset, NoTextureLoading, load_obj
+	cfg, _ = foot3d
+	ds = Foot3DDataset(cfg, device='cpu', left_only=False, full_caching=True)
+	i = ds.scan_ids.index('A', 2) if ds.foot_ids[2] == '0007' else [n for n, f in enumerate(ds.foot_ids) if f == '0007'][0]
+	raw, _, _ = load_obj(os.path.join(ds.folder, ds.data[i]['OBJ file']))
+	want = raw.clone(); want[:, 1] = -want[:, 1]; want = want - want.mean(0)
+	assert torch.allclose(ds[i]['verts'], want) and torch.allclose(ds[i]['verts'], want)          # second read comes from the cache, unflipped twice
+	with NoTextureLoading(ds):
+		assert ds[0]['textures'] is None
+	assert ds[0]['textures'] is not None
+
+
+def test_collator_builds_ragged_meshes_with_joined_uv_textures(foot3d):
+	from find_amd.dataset import BatchCollator, Foot3DDataset
+	cfg, _ = foot3d
+	ds = Foot3DDataset(cfg, device='cpu')
+	batch = BatchCollator(device='cpu').collate_batches([ds[0], ds[1]])
+	m = batch['mesh']
+	assert len(m) == 2 and m.num_verts_per_mesh().tolist() == [25, 36] and m.num_faces_per_mesh().tolist() == [32, 50]
+	assert m.verts_padded().shape == (2, 36, 3) and m.faces_padded().shape == (2, 50, 3) and (m.faces_padded()[0, 32:] == -1).all()
+	t = m.textures
+	assert t.maps_padded().shape == (2, 8, 6, 3) and t.faces_uvs_padded().shape == (2, 50, 3) and t.verts_uvs_padded().shape == (2, 36, 2)
+	assert batch['name'] == ['0005-A', '0005-B'] and batch['idx'].tolist() == [0, 1] and batch['pose_code'].shape == (2, 8)
+	assert batch['shape'] == ['0005', '0005'] and batch['reg'] == ['0005-A', '0005-B']
