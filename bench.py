@@ -47,9 +47,9 @@ def executed_flops_per_step(n_feet, n_verts):
 	"""fwd+bwd flops this build executes for one batch with a shared template (per-foot latent columns folded into a bias)."""
 	trunk_fwd = MAC_TRUNK_FWD
 	trunk_bwd = 2 * MAC_TRUNK_FWD - 515 * 256  # dW + dX, no dX through layer 0
-	heads_main_fwd = 2 * 256 * 256 + 4 * 256 * 256 + 2 * 3 * 256  # latent columns become a bias
-	heads_bwd = 2 * heads_main_fwd
-	return 2.0 * (n_verts * (trunk_fwd + trunk_bwd) + n_feet * n_verts * (heads_main_fwd + heads_bwd))
+	heads_in = 2 * 256 * 256                      # first layer of both heads: the latent columns are a bias, and the trunk rows are shared,
+	heads_rest = 4 * 256 * 256 + 2 * 3 * 256      # so H W^T (forward), dW and dH (backward, after the sum over feet) run once per TEMPLATE vertex
+	return 2.0 * (n_verts * (trunk_fwd + trunk_bwd + 3 * heads_in) + n_feet * n_verts * 3 * heads_rest)
 
 
 def build_step(device, seed):

@@ -70,6 +70,7 @@ struct FwdWs {
 	float* C[FIND_MAX_LAYERS];
 	float* zd;    // (rows_h,3)
 	float* zc;
+	float* hp;    // shared template: (V,256) product of the trunk output with a head's first-layer weight (no bias), reused per head
 	int64_t bytes;
 };
 
@@ -82,6 +83,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 	o->fbc = c.take<float>(d.n_feet * W);
 	o->zd = c.take<float>(d.rows_h * 3);
 	o->zc = c.take<float>(d.rows_h * 3);
+	o->hp = (d.shared && d.n_feet > 1) ? c.take<float>(d.V * W) : nullptr;
 	float* pt[2] = {nullptr, nullptr};
 	float* pd[2] = {nullptr, nullptr};
 	float* pc[2] = {nullptr, nullptr};
@@ -361,12 +363,28 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	// 4. heads (model.py:439-440); the trunk rows are shared by every foot when d.shared
 	const float* hl = w.H[p->n_trunk - 1];
 	const int64_t hl_stride = d.shared ? 0 : V * W;
+	// first layer of a head.  Shared template: every foot multiplies the SAME trunk rows, so  H W^T  is formed once on V rows
+	// and each foot only adds its (latent-folded) bias and applies the ReLU -- a bandwidth-bound broadcast instead of a GEMM
+	// over n_feet * V rows.  (The backward has always used the same fact: footsum_kernel.)
+	auto head_first = [&](const float* w0, const float* bias, int64_t bstride, float* out) {
+		if (w.hp) {
+			GemmArgs a = gemm_args_zero();
+			a.a0 = hl; a.a_foot_stride = 0; a.lda = W;
+			a.w0 = w0; a.ldw = W; a.nchunk = W / KC;
+			a.y = w.hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+			launch_gemm(AMODE_MAT, EPI_NONE, a, 1, s);
+			const int64_t n4 = n_feet * V * (W / 4);
+			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 8192)), dim3(256), 0, s, w.hp, bias, bstride, (int)n_feet, V, out);
+		} else {
+			linear_fwd(hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, s);
+		}
+	};
 	if (disp) {
-		linear_fwd(hl, hl_stride, w.wd0, W, bias_d0, bstride_d, w.D[0], V, n_feet, s);
+		head_first(w.wd0, bias_d0, bstride_d, w.D[0]);
 		for (int i = 1; i < p->n_disp; ++i) linear_fwd(w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s);
 	}
 	if (col) {
-		linear_fwd(hl, hl_stride, w.wc0, W, bias_c0, bstride_c, w.C[0], V, n_feet, s);
+		head_first(w.wc0, bias_c0, bstride_c, w.C[0]);
 		for (int i = 1; i < p->n_col; ++i) linear_fwd(w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, s);
 	}
 	FIND_LAUNCH_CHECK("head gemm");

@@ -608,6 +608,22 @@ __global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, in
 	}
 }
 
+// out[foot][v][:] = relu(P[v][:] + bias[foot][:]) : first head layer with a shared template (P = H W^T computed once on V rows)
+__global__ __launch_bounds__(256) void bias_relu_bcast_kernel(const float* __restrict__ P, const float* __restrict__ bias, int64_t bias_foot_stride,
+															   int n_feet, int64_t V, float* __restrict__ out) {
+	const int64_t per_foot = V * (W / 4);
+	const int64_t total = per_foot * n_feet;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t foot = i / per_foot, r = i - foot * per_foot;
+		const int c4 = (int)(r & (W / 4 - 1));
+		const float4 p = reinterpret_cast<const float4*>(P)[r];
+		const float4 b = *reinterpret_cast<const float4*>(bias + foot * bias_foot_stride + c4 * 4);
+		float4 o;
+		o.x = fmaxf(p.x + b.x, 0.f); o.y = fmaxf(p.y + b.y, 0.f); o.z = fmaxf(p.z + b.z, 0.f); o.w = fmaxf(p.w + b.w, 0.f);
+		reinterpret_cast<float4*>(out)[i] = o;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // Final 256->3 layers of both heads + output activations (model.py:439-451).  One wave per row.
 //   head 0: disp = 0.1*tanh(z)        head 1: col = 0.5*(1+tanh(z)) [+ avg_col]
