@@ -439,37 +439,63 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					const float* zp = scr_z + tid;
 					const float* qp = scr_q + tid;
 					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
-					// invariant: count(z <= lo - 1) < K <= count(z <= hi); three pivots per counting pass
-					while (lo < hi) {
+					// invariant: c_lo = count(z < lo) < K <= count(z <= hi) = c_hi.  Each pass counts against three pivots.  Odd
+					// passes guess the K-th depth by interpolating the counts over [lo, hi] and bracket the guess tightly (depths of
+					// the candidates of a pixel are spread fairly evenly, so this lands within a few candidates of the answer);
+					// even passes use the quartiles, which bounds the number of passes whatever the distribution.
+					int c_lo = 0, c_hi = cnt;
+					for (int pass = 0; lo < hi; ++pass) {
 						const unsigned span = hi - lo;
-						const unsigned m1 = lo + (span >> 2), m2 = lo + (span >> 1), m3 = lo + (span >> 1) + (span >> 2);
+						unsigned m1, m2, m3;
+						if (pass & 1) {
+							m1 = lo + (span >> 2); m2 = lo + (span >> 1); m3 = lo + (span >> 1) + (span >> 2);
+						} else {
+							const float t = (float)(K - c_lo) / (float)(c_hi - c_lo);                 // in (0, 1]
+							const unsigned g = lo + (unsigned)fminf((float)span * t, (float)(span - 1));
+							const unsigned w = max(span >> 5, 1u);
+							m2 = min(g, hi - 1);
+							m1 = (m2 - lo > w) ? m2 - w : lo;
+							m3 = (hi - 1 - m2 > w) ? m2 + w : hi - 1;
+						}
 						int c1 = 0, c2 = 0, c3 = 0, i = 0;
-						for (; i + 4 <= cnt; i += 4) {
-							const unsigned b0 = __float_as_uint(zp[(i + 0) * 256] + 0.0f), b1 = __float_as_uint(zp[(i + 1) * 256] + 0.0f);
-							const unsigned b2 = __float_as_uint(zp[(i + 2) * 256] + 0.0f), b3 = __float_as_uint(zp[(i + 3) * 256] + 0.0f);
-							c1 += (b0 <= m1) + (b1 <= m1) + (b2 <= m1) + (b3 <= m1);
-							c2 += (b0 <= m2) + (b1 <= m2) + (b2 <= m2) + (b3 <= m2);
-							c3 += (b0 <= m3) + (b1 <= m3) + (b2 <= m3) + (b3 <= m3);
+						for (; i + 8 <= cnt; i += 8) {
+							unsigned bz[8];
+#pragma unroll
+							for (int u = 0; u < 8; ++u) bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f);
+#pragma unroll
+							for (int u = 0; u < 8; ++u) { c1 += bz[u] <= m1; c2 += bz[u] <= m2; c3 += bz[u] <= m3; }
 						}
 						for (; i < cnt; ++i) {
 							const unsigned b0 = __float_as_uint(zp[i * 256] + 0.0f);
 							c1 += b0 <= m1; c2 += b0 <= m2; c3 += b0 <= m3;
 						}
-						if (c1 >= K) hi = m1;
-						else if (c2 >= K) { lo = m1 + 1; hi = m2; }
-						else if (c3 >= K) { lo = m2 + 1; hi = m3; }
-						else lo = m3 + 1;
+						if (c1 >= K) { hi = m1; c_hi = c1; }
+						else if (c2 >= K) { lo = m1 + 1; c_lo = c1; hi = m2; c_hi = c2; }
+						else if (c3 >= K) { lo = m2 + 1; c_lo = c2; hi = m3; c_hi = c3; }
+						else { lo = m3 + 1; c_lo = c3; }
 					}
-					// lo = bits of the K-th smallest depth
-					int c_lt = 0;
-					for (int i = 0; i < cnt; ++i) c_lt += __float_as_uint(zp[i * 256] + 0.0f) < lo;
-					int ties = K - c_lt;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
+					// lo = bits of the K-th smallest depth, c_lo = candidates strictly in front of it
+					int ties = K - c_lo;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
 					float asel = 1.0f;
-					for (int i = 0; i < cnt; ++i) {
-						const unsigned zb = __float_as_uint(zp[i * 256] + 0.0f);
-						const float qi = qp[i * 256];
-						if (zb < lo) asel *= qi;
-						else if (zb == lo && ties > 0) { asel *= qi; --ties; }
+					{
+						int i = 0;
+						for (; i + 8 <= cnt; i += 8) {
+							unsigned bz[8];
+							float qv[8];
+#pragma unroll
+							for (int u = 0; u < 8; ++u) { bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f); qv[u] = qp[(i + u) * 256]; }
+#pragma unroll
+							for (int u = 0; u < 8; ++u) {
+								if (bz[u] < lo) asel *= qv[u];
+								else if (bz[u] == lo && ties > 0) { asel *= qv[u]; --ties; }
+							}
+						}
+						for (; i < cnt; ++i) {
+							const unsigned zb = __float_as_uint(zp[i * 256] + 0.0f);
+							const float qi = qp[i * 256];
+							if (zb < lo) asel *= qi;
+							else if (zb == lo && ties > 0) { asel *= qi; --ties; }
+						}
 					}
 					alpha = asel;
 					thr = __uint_as_float(lo);
