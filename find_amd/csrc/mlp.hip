@@ -373,8 +373,8 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 			a.w0 = w0; a.ldw = W; a.nchunk = W / KC;
 			a.y = w.hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
 			launch_gemm(AMODE_MAT, EPI_NONE, a, 1, s);
-			const int64_t n4 = n_feet * V * (W / 4);
-			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n4, 256), 8192)), dim3(256), 0, s, w.hp, bias, bstride, (int)n_feet, V, out);
+			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, s, w.hp, bias,
+							   bstride, (int)n_feet, V, out);
 		} else {
 			linear_fwd(hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, s);
 		}

@@ -608,19 +608,26 @@ __global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, in
 	}
 }
 
-// out[foot][v][:] = relu(P[v][:] + bias[foot][:]) : first head layer with a shared template (P = H W^T computed once on V rows)
+// out[foot][v][:] = relu(P[v][:] + bias[foot][:]) : first head layer with a shared template (P = H W^T computed once on V rows).
+// grid (ceil(V*64/256), n_feet-groups): a thread keeps its float4 of P in registers and writes it for FEET_PER feet (P is read
+// once per group instead of once per foot; the writes are the traffic: n_feet * V * 1 KB).
+constexpr int BCAST_FEET = 4;
 __global__ __launch_bounds__(256) void bias_relu_bcast_kernel(const float* __restrict__ P, const float* __restrict__ bias, int64_t bias_foot_stride,
 															   int n_feet, int64_t V, float* __restrict__ out) {
 	const int64_t per_foot = V * (W / 4);
-	const int64_t total = per_foot * n_feet;
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-		const int64_t foot = i / per_foot, r = i - foot * per_foot;
-		const int c4 = (int)(r & (W / 4 - 1));
-		const float4 p = reinterpret_cast<const float4*>(P)[r];
+	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= per_foot) return;
+	const int c4 = (int)(r & (W / 4 - 1));
+	const float4 p = reinterpret_cast<const float4*>(P)[r];
+	const int f0 = blockIdx.y * BCAST_FEET;
+#pragma unroll
+	for (int k = 0; k < BCAST_FEET; ++k) {
+		const int foot = f0 + k;
+		if (foot >= n_feet) break;
 		const float4 b = *reinterpret_cast<const float4*>(bias + foot * bias_foot_stride + c4 * 4);
 		float4 o;
 		o.x = fmaxf(p.x + b.x, 0.f); o.y = fmaxf(p.y + b.y, 0.f); o.z = fmaxf(p.z + b.z, 0.f); o.w = fmaxf(p.w + b.w, 0.f);
-		reinterpret_cast<float4*>(out)[i] = o;
+		reinterpret_cast<float4*>(out)[foot * per_foot + r] = o;
 	}
 }
 
