@@ -253,6 +253,105 @@ def train3d_cpu(mwl, batch, gv, gf, gc, sample_feet=1):
 				sample=f'{nf} of the feet, same step without the optimiser update, best of 2, oracle (torch-CPU / numpy) with {cores} threads')
 
 
+def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256):
+	"""BASELINE.json configs[2]: a batch of 16 feet x 4 views @256^2 with the silhouette render loss, end to end -- MLP query,
+	registration, GT and predicted renders (the GT is re-rendered every step, as the reference does), silhouette loss, backward
+	through rasteriser and MLP, optimiser steps.  One JSON line; the CPU leg runs the oracle's composition on one foot x one view."""
+	import numpy as np
+	from find_amd import optim, synthetic
+	from find_amd.model_with_loss import ModelWithLoss
+	from find_amd.opts import Opts
+	from find_amd.renderer import FootRenderer
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.train_utils import sample_latent_vectors
+	if not torch.cuda.is_available():
+		raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+	dev = torch.device('cuda', 0)
+	opts = Opts(sil_loss=True, num_views=n_views)
+	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=n_feet, val_size=2,
+						shapevec_size=100, texvec_size=100, posevec_size=100, template_mesh_loc=None)
+	g = torch.Generator().manual_seed(1234)
+	with torch.no_grad():
+		mwl.model.mlp_disp[-1].weight.copy_(torch.randn(mwl.model.mlp_disp[-1].weight.shape, generator=g) * 0.01)
+		mwl.model.mlp_disp[-1].bias.copy_(torch.randn(3, generator=g) * 0.01)
+	mwl = mwl.to(dev)
+	mwl.rdr = FootRenderer(image_size=size, device=dev)
+	v, f = synthetic.template(N_VERTS)
+	mwl.model.set_template(v.to(dev), f.to(dev))
+	lat = synthetic.latents(n_feet, seed=0, device=dev)
+	with torch.no_grad():
+		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+			getattr(mwl.model, k).data.copy_(lat[k])
+	gv, gf, gc = synthetic.gt_feet(n_feet, 10002, seed=0, device=dev)
+	batch = dict(mesh=Meshes(gv, gf, TexturesVertex(gc.clamp(0.05, 0.95))), idx=torch.arange(n_feet, device=dev), name=[f'{i:04d}' for i in range(n_feet)])
+	np.random.seed(7)
+	R, T = mwl.rdr.sample_views(nviews=n_views, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+	m = mwl.model
+	optims = [optim.Adam(m.main_params, lr=5e-4), optim.SGD(m.reg_params, lr=1e-3, momentum=0.9), optim.Adam(m.latent_params, lr=1e-3)]
+
+	def step():
+		for o in optims:
+			o.zero_grad(set_to_none=True)
+		b = dict(batch)
+		b.update(sample_latent_vectors(b, m.latent_vectors_train))
+		loss, _ = mwl(b, 0, opts, sil=True, render_foot=True, views=(R, T))
+		loss.backward()
+		for o in optims:
+			o.step()
+		return loss
+
+	for _ in range(warmup):
+		step()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(steps):
+		step()
+	torch.cuda.synchronize()
+	ms = (time.perf_counter() - t0) / steps * 1e3
+	out = {'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': n_feet * N_VERTS * n_views / (ms * 1e-3), 'unit': 'vertices*views/s',
+		   'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+		   'dtype': 'f32', 'data': 'synthetic',
+		   'config': {'workload': f'C3: {n_feet} feet x {n_views} views @{size}^2, {N_VERTS}-vertex template (13776 faces), 10002-vertex GT scans re-rendered every '
+								  f'step, silhouette loss, backward through rasteriser + MLP, optimiser steps', 'feet_per_gpu': n_feet, 'views': n_views}}
+	if with_cpu:
+		out['cpu_baseline'] = c3_cpu(mwl, gv, gf, R, T, size)
+	print(json.dumps(out), flush=True)
+
+
+def c3_cpu(mwl, gv, gf, R, T, size):
+	"""Oracle composition of the C3 step on one foot x one view: MLP (torch-CPU), C rasteriser for both meshes, torch restatement of the
+	soft silhouette for the gradient, backward to the MLP weights."""
+	from oracle import mlp_ref, render_ref
+	m = mwl.model
+	sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
+		  for k, v in m.state_dict().items()}
+	B, tv, tf = m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
+	lat = {k: getattr(m, k).data.detach().cpu()[:1].clone().requires_grad_(True) for k in ('shapevec', 'texvec', 'posevec', 'reg')}
+	Rc, Tc = R[:1].cpu(), T[:1].cpu()
+	rp = render_ref.default_params(size)
+	try:
+		avail = len(os.sched_getaffinity(0))
+	except AttributeError:
+		avail = os.cpu_count() or 1
+	cores = min(avail, 16)
+	torch.set_num_threads(cores)
+
+	def one():
+		t0 = time.perf_counter()
+		res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+		gt = render_ref.render(gv[:1].cpu().numpy(), gf.cpu().numpy(), None, Rc.numpy(), Tc.numpy(), image_size=size, want_image=False)['mask']
+		vproj = render_ref.project(rp, res['verts'].detach().numpy(), Rc.numpy(), Tc.numpy())
+		p2f, _, _, _ = render_ref.rasterize(vproj, tf.numpy(), 1, size, size, 100, rp.sil_blur_radius)
+		mask = render_ref.torch_mask(rp, res['verts'], tf, Rc, Tc, torch.from_numpy(p2f).long(), 1)
+		((mask - torch.from_numpy(gt)) ** 2).mean().backward()
+		return time.perf_counter() - t0
+
+	best = min(one() for _ in range(2))
+	return dict(value=N_VERTS / best, unit='vertices*views/s', cores=cores, kind='port',
+				sample=f'1 foot x 1 view of the same step without the optimiser update, best of 2, oracle (torch-CPU MLP + oracle/raster_ref.c OpenMP + '
+					   f'torch autograd through the K=100 fragments) with {cores} torch threads')
+
+
 def subpaths(with_cpu):
 	"""Sub-path lines (tools/bench_paths.py workloads).  The CPU leg times the oracle on one foot / one image of the same inputs."""
 	sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
@@ -282,12 +381,15 @@ def main():
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
 	ap.add_argument('--train3d', action='store_true', help='instead of the headline line: the reference training configuration (train_3d.yaml losses + optimiser steps)')
+	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
 	args = ap.parse_args()
 	if args.subpaths:
 		return subpaths(not args.no_cpu_baseline)
 	if args.train3d:
 		return train3d(not args.no_cpu_baseline, args.steps, args.warmup)
+	if args.c3:
+		return c3(not args.no_cpu_baseline, args.steps, args.warmup)
 
 	import torch.distributed as dist
 	from find_amd import distributed as fdist
