@@ -423,9 +423,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			const bool over = in_img && cnt > K;
 			const unsigned long long ov_all = __ballot(over);
 			if (ov_all) {
-				// agent-scope fence: this wave's scratch stores are complete and the L1 is invalidated (the slot is rewritten for
-				// every tile, a line read for an earlier tile would be stale), so plain loads below see this tile's lists
-				__threadfence();
+				// (no fence: every lane reads back only the list it wrote itself -- same thread, same addresses, program order.  An
+				// agent-scope fence here costs 0.6 ms per C3 render: L2 write-back + L1 invalidate on a multi-XCD part.)
 				const unsigned long long trunc = __ballot(over && cnt > KN_CAP);
 				int wave_max_cnt = cnt;  // diagnostics: [5] largest candidate count seen
 #pragma unroll
@@ -439,40 +438,73 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					const float* zp = scr_z + tid;
 					const float* qp = scr_q + tid;
 					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
-					// invariant: c_lo = count(z < lo) < K <= count(z <= hi) = c_hi.  Each pass counts against three pivots.  Odd
-					// passes guess the K-th depth by interpolating the counts over [lo, hi] and bracket the guess tightly (depths of
-					// the candidates of a pixel are spread fairly evenly, so this lands within a few candidates of the answer);
-					// even passes use the quartiles, which bounds the number of passes whatever the distribution.
-					int c_lo = 0, c_hi = cnt;
-					for (int pass = 0; lo < hi; ++pass) {
+					// Radix search for the K-th smallest depth.  Invariant: every candidate lies in [lo, hi] or was counted in c_lo
+					// (candidates in front of lo) or lies behind hi; the K-th smallest is inside [lo, hi].  A level histograms
+					// (z - lo) >> shift into 16 bins (16-bit counters packed in 8 registers) in ONE read of the list and keeps the bin
+					// that holds the K-th; once that bin has at most 4 candidates they are fetched and ranked directly.
+					int c_lo = 0;
+					while (lo < hi) {
 						const unsigned span = hi - lo;
-						unsigned m1, m2, m3;
-						if (pass & 1) {
-							m1 = lo + (span >> 2); m2 = lo + (span >> 1); m3 = lo + (span >> 1) + (span >> 2);
-						} else {
-							const float t = (float)(K - c_lo) / (float)(c_hi - c_lo);                 // in (0, 1]
-							const unsigned g = lo + (unsigned)fminf((float)span * t, (float)(span - 1));
-							const unsigned w = max(span >> 5, 1u);
-							m2 = min(g, hi - 1);
-							m1 = (m2 - lo > w) ? m2 - w : lo;
-							m3 = (hi - 1 - m2 > w) ? m2 + w : hi - 1;
-						}
-						int c1 = 0, c2 = 0, c3 = 0, i = 0;
+						const int shift = span < 16u ? 0 : (28 - __builtin_clz(span));  // (span >> shift) <= 15
+						unsigned h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
+						auto tally = [&](unsigned zb) {
+							if (zb < lo || zb > hi) return;
+							const unsigned bin = (zb - lo) >> shift;
+							const unsigned inc = 1u << ((bin & 1u) * 16u);
+							const unsigned w = bin >> 1;
+							h0 += w == 0 ? inc : 0u; h1 += w == 1 ? inc : 0u; h2 += w == 2 ? inc : 0u; h3 += w == 3 ? inc : 0u;
+							h4 += w == 4 ? inc : 0u; h5 += w == 5 ? inc : 0u; h6 += w == 6 ? inc : 0u; h7 += w == 7 ? inc : 0u;
+						};
+						int i = 0;
 						for (; i + 8 <= cnt; i += 8) {
 							unsigned bz[8];
 #pragma unroll
 							for (int u = 0; u < 8; ++u) bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f);
 #pragma unroll
-							for (int u = 0; u < 8; ++u) { c1 += bz[u] <= m1; c2 += bz[u] <= m2; c3 += bz[u] <= m3; }
+							for (int u = 0; u < 8; ++u) tally(bz[u]);
 						}
-						for (; i < cnt; ++i) {
-							const unsigned b0 = __float_as_uint(zp[i * 256] + 0.0f);
-							c1 += b0 <= m1; c2 += b0 <= m2; c3 += b0 <= m3;
+						for (; i < cnt; ++i) tally(__float_as_uint(zp[i * 256] + 0.0f));
+						// the bin that holds the (K - c_lo)-th candidate of the range
+						const unsigned hw[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+						const int need = K - c_lo;
+						int acc = 0, sel = 15, in_sel = 0;
+						bool found = false;
+#pragma unroll
+						for (int bb = 0; bb < 16; ++bb) {
+							const int cb = (int)((hw[bb >> 1] >> ((bb & 1) * 16)) & 0xFFFFu);
+							if (!found) {
+								if (acc + cb >= need) { sel = bb; in_sel = cb; found = true; }
+								else acc += cb;
+							}
 						}
-						if (c1 >= K) { hi = m1; c_hi = c1; }
-						else if (c2 >= K) { lo = m1 + 1; c_lo = c1; hi = m2; c_hi = c2; }
-						else if (c3 >= K) { lo = m2 + 1; c_lo = c2; hi = m3; c_hi = c3; }
-						else { lo = m3 + 1; c_lo = c3; }
+						c_lo += acc;
+						lo = lo + ((unsigned)sel << shift);
+						hi = min(hi, lo + ((1u << shift) - 1u));
+						if (shift == 0) break;  // a single depth value is left
+						if (in_sel <= 4) {
+							// fetch the (at most 4) candidates of the bin and take the (K - c_lo)-th smallest of them
+							unsigned c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
+							int m = 0;
+							for (int j = 0; j < cnt; ++j) {
+								const unsigned zb = __float_as_uint(zp[j * 256] + 0.0f);
+								if (zb >= lo && zb <= hi) {
+									if (m == 0) c0 = zb; else if (m == 1) c1 = zb; else if (m == 2) c2 = zb; else c3 = zb;
+									++m;
+								}
+							}
+							// sort the four (absent ones are +max) and index
+							unsigned t;
+							if (c0 > c1) { t = c0; c0 = c1; c1 = t; }
+							if (c2 > c3) { t = c2; c2 = c3; c3 = t; }
+							if (c0 > c2) { t = c0; c0 = c2; c2 = t; }
+							if (c1 > c3) { t = c1; c1 = c3; c3 = t; }
+							if (c1 > c2) { t = c1; c1 = c2; c2 = t; }
+							const int rnk = K - c_lo;  // 1-based rank inside the bin
+							const unsigned T = rnk == 1 ? c0 : (rnk == 2 ? c1 : (rnk == 3 ? c2 : c3));
+							c_lo += (c0 < T) + (c1 < T) + (c2 < T) + (c3 < T);
+							lo = hi = T;
+							break;
+						}
 					}
 					// lo = bits of the K-th smallest depth, c_lo = candidates strictly in front of it
 					int ties = K - c_lo;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
