@@ -45,6 +45,7 @@ struct Ws {
 	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tile counter
 	float* zthr;      // (n_img, H, W) depth of the K-th nearest silhouette candidate (+inf: every candidate counts)  [backward]
 	float2* scratch;  // (raster workgroups, KN_CAP, 256) per-pixel candidate lists (depth, 1 - p) of the tile in flight
+	int32_t* tile_any; // (n_img, tiles) 1 = some face's blurred bbox touches the tile
 	int64_t raster_wgs;
 	int64_t bytes;
 };
@@ -67,6 +68,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	const int64_t tiles = n_img * cdiv(rp->image_w, TS) * cdiv(rp->image_h, TS);
 	o->raster_wgs = std::min<int64_t>(tiles, RASTER_WGS);
 	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
+	o->tile_any = c.take<int32_t>(tiles);
 	o->bytes = c.off;
 }
 
@@ -131,7 +133,8 @@ __device__ __forceinline__ void pix_range(float cmin, float cmax, int S, int* lo
 
 __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
 								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
-								  float4* __restrict__ frec, uint32_t* __restrict__ tb, int32_t* __restrict__ flags) {
+								  float4* __restrict__ frec, uint32_t* __restrict__ tb, int32_t* __restrict__ flags,
+								  int32_t* __restrict__ tile_any, int tiles_x, int tiles_per_img) {
 	const int img = blockIdx.y;
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= F) return;
@@ -158,8 +161,15 @@ __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t
 			int xlo, xhi, ylo, yhi;
 			pix_range(fminf(x0, fminf(x1, x2)) - br, fmaxf(x0, fmaxf(x1, x2)) + br, W, &xlo, &xhi);
 			pix_range(fminf(y0, fminf(y1, y2)) - br, fmaxf(y0, fmaxf(y1, y2)) + br, H, &ylo, &yhi);
-			if (xlo <= xhi && ylo <= yhi)
+			if (xlo <= xhi && ylo <= yhi) {
 				packed = (uint32_t)(xlo / TS) | ((uint32_t)(xhi / TS) << 8) | ((uint32_t)(ylo / TS) << 16) | ((uint32_t)(yhi / TS) << 24);
+				// mark the tiles this face can touch: the rasteriser skips the scan of a tile nobody marked (most of an image)
+				for (int ty = ylo / TS; ty <= yhi / TS; ++ty)
+					for (int tx = xlo / TS; tx <= xhi / TS; ++tx) {
+						int32_t* t = tile_any + (int64_t)img * tiles_per_img + ty * tiles_x + tx;
+						if (*t == 0) *t = 1;  // benign race: every writer stores 1
+					}
+			}
 		}
 	}
 	tb[o] = packed;
@@ -296,6 +306,7 @@ struct TileArgs {
 	int32_t* flags;
 	float* zthr;
 	float2* scratch;
+	const int32_t* tile_any;
 	int tiles_per_img, total_tiles;
 };
 
@@ -383,10 +394,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			__syncthreads();
 		};
 
-		for (int base = 0; base < a.F; base += 256) {
+		const int nF = a.tile_any[t_id] ? a.F : 0;  // nothing can touch this tile: straight to the background write
+		for (int base = 0; base < nF; base += 256) {
 			const int f = base + tid;
 			bool hit = false;
-			if (f < a.F) {
+			if (f < nF) {
 				const uint32_t t = tbp[f];
 				const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
 				hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;
@@ -880,8 +892,10 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv(V, 256), (unsigned)n_img), dim3(256), 0, s, verts, R, T, sc, (int)n_views, V, w.vproj);
 	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one scan serves both
 	const float blur = mask ? rp->sil_blur_radius : 0.0f;
+	const int tiles_x = (int)cdiv(W, TS), tiles_per_img = tiles_x * (int)cdiv(H, TS);
+	(void)hipMemsetAsync(w.tile_any, 0, n_img * (int64_t)tiles_per_img * sizeof(int32_t), s);
 	hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, w.vproj, faces, fstride, (int)n_views, V, F, H, W,
-					   blur, rp->z_clip, w.frec, w.tb, w.flags);
+					   blur, rp->z_clip, w.frec, w.tb, w.flags, w.tile_any, tiles_x, tiles_per_img);
 	if (image) {
 		(void)hipMemsetAsync(w.normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.normals);
@@ -897,7 +911,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = (int)cdiv(W, TS);
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
-	a.zthr = w.zthr; a.scratch = w.scratch;
+	a.zthr = w.zthr; a.scratch = w.scratch; a.tile_any = w.tile_any;
 	a.tiles_per_img = (int)(a.tiles_x * cdiv(H, TS)); a.total_tiles = (int)(a.tiles_per_img * n_img);
 	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)w.raster_wgs), dim3(256), 0, s, a);
 	FIND_LAUNCH_CHECK("find_render_fwd");
