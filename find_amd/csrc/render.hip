@@ -609,17 +609,20 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 
 // ------------------------------------------------------------------------------------------------ 4. silhouette backward
 // mask = 1 - prod_k (1 - p_k),  p_k = sigmoid(-d_k / sigma)   =>   d mask / d d_k = -alpha * p_k / sigma.
-// One thread per (image, face): walks the blurred bbox, accumulates the gradients of its three NDC vertices in registers
-// (PointTriangleDistanceBackward: nearest edge only, projection parameter treated as constant), six atomics at the end.
-__global__ void sil_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
-							   const int32_t* __restrict__ faces, int64_t faces_mesh_stride, int n_views, int V, int F,
-							   const float* __restrict__ mask, const float* __restrict__ d_mask, const float* __restrict__ zthr,
-							   float* __restrict__ d_vproj) {
+// LPF lanes per (image, face) (8 for small blurred bboxes, 32 for large ones): they stride over the pixels of the face's blurred bbox (coalesced rows of d_mask / mask / zthr, no
+// divergence between faces with different bbox sizes), accumulate the gradients of its three NDC vertices in registers
+// (PointTriangleDistanceBackward: nearest edge only, projection parameter treated as constant), butterfly-reduce them, and
+// lane 0 issues the six atomics.
+template <int LPF>
+__global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
+													   const int32_t* __restrict__ faces, int64_t faces_mesh_stride, int n_views, int V, int F,
+													   const float* __restrict__ mask, const float* __restrict__ d_mask, const float* __restrict__ zthr,
+													   float* __restrict__ d_vproj) {
 	const int img = blockIdx.y;
-	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= F) return;
-	const int64_t o = (int64_t)img * F + f;
-	if (tb[o] == TB_EMPTY) return;
+	const int sub = threadIdx.x & (LPF - 1);
+	const int f = blockIdx.x * (256 / LPF) + threadIdx.x / LPF;
+	const int64_t o = (int64_t)img * F + min(f, F - 1);
+	const bool act = f < F && tb[o] != TB_EMPTY;
 	const int H = rp.image_h, W = rp.image_w;
 	const float blur = rp.sil_blur_radius, br = sqrtf(blur);
 	FaceRec r;
@@ -627,11 +630,15 @@ __global__ void sil_bwd_kernel(const find_render_params rp, const float4* __rest
 	int xlo, xhi, ylo, yhi;
 	pix_range(r.xmin, r.xmax, W, &xlo, &xhi);
 	pix_range(r.ymin, r.ymax, H, &ylo, &yhi);
+	const int bw = xhi - xlo + 1;
+	const int npx = act ? max(bw, 0) * max(yhi - ylo + 1, 0) : 0;
 	float g0x = 0.f, g0y = 0.f, g1x = 0.f, g1y = 0.f, g2x = 0.f, g2y = 0.f;
 	const float inv_sigma = 1.0f / rp.sil_sigma;
-	for (int yi = ylo; yi <= yhi; ++yi) {
+	for (int pi = sub; pi < npx; pi += LPF) {
+		const int ry = pi / bw;
+		const int yi = ylo + ry, xi = xlo + (pi - ry * bw);
 		const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
-		for (int xi = xlo; xi <= xhi; ++xi) {
+		{
 			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
 			const float g = d_mask[pix];
 			if (g == 0.f) continue;
@@ -657,6 +664,12 @@ __global__ void sil_bwd_kernel(const find_render_params rp, const float4* __rest
 			else { g1x += ga * qx; g1y += ga * qy; g2x += gb * qx; g2y += gb * qy; }
 		}
 	}
+#pragma unroll
+	for (int d = 1; d < LPF; d <<= 1) {
+		g0x += __shfl_xor(g0x, d, 64); g0y += __shfl_xor(g0y, d, 64); g1x += __shfl_xor(g1x, d, 64);
+		g1y += __shfl_xor(g1y, d, 64); g2x += __shfl_xor(g2x, d, 64); g2y += __shfl_xor(g2y, d, 64);
+	}
+	if (!act || sub != 0) return;
 	const int mesh = img / n_views;
 	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
 	float* dv = d_vproj + (int64_t)img * V * 3;
@@ -941,7 +954,13 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 	(void)hipMemsetAsync(d_verts, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 	if (d_vert_colors) (void)hipMemsetAsync(d_vert_colors, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 	if (d_mask) {
-		hipLaunchKernelGGL(sil_bwd_kernel, dim3((unsigned)cdiv(F, 128), (unsigned)n_img), dim3(128), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
+		// lanes per face by the size of a typical blurred bbox (a face of ~1 px plus the blur margin on both sides)
+		const float side = 2.0f * sqrtf(rp->sil_blur_radius) * 0.5f * (float)std::max(H, W) + 2.0f;
+		if (side * side > 160.0f)
+			hipLaunchKernelGGL(sil_bwd_kernel<32>, dim3((unsigned)cdiv(F, 8), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
+							   mask, d_mask, w.zthr, w.d_vproj);
+		else
+			hipLaunchKernelGGL(sil_bwd_kernel<8>, dim3((unsigned)cdiv(F, 32), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
 						   mask, d_mask, w.zthr, w.d_vproj);
 	}
 	if (d_image) {
