@@ -682,26 +682,39 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 // Pixel-centric (K = 1): image = (amb + diff) * tex + spec at the nearest inside fragment (the blend weight cancels to
 // within 1e-10).  Gradients flow to vertex colours (tex), world vertices (pos), vertex normals (nrm) and,
 // through the perspective-correct barycentrics, to the NDC vertices (x, y, z_view).
-__global__ __launch_bounds__(256) void rgb_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec,
-													   const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
-													   const float* __restrict__ verts, const float* __restrict__ normals,
-													   const float* __restrict__ colors, const float* __restrict__ cam, int n_views,
-													   int V, int F, const int32_t* __restrict__ p2f, const float* __restrict__ bary,
-													   const float* __restrict__ d_image, float* __restrict__ d_vproj,
-													   float* __restrict__ d_verts, float* __restrict__ d_normals,
-													   float* __restrict__ d_colors) {
+struct RgbGrad {  // gradients of one face's three vertices: world position, vertex normal, vertex colour, NDC (x, y, z_view)
+	float dP[3][3], dN[3][3], dC[3][3], g[9];
+};
+
+__device__ __forceinline__ void rgb_grad_zero(RgbGrad& o) {
+#pragma unroll
+	for (int k = 0; k < 3; ++k)
+#pragma unroll
+		for (int c = 0; c < 3; ++c) { o.dP[k][c] = 0.f; o.dN[k][c] = 0.f; o.dC[k][c] = 0.f; }
+#pragma unroll
+	for (int i = 0; i < 9; ++i) o.g[i] = 0.f;
+}
+
+__device__ __forceinline__ void rgb_grad_commit(const RgbGrad& o, const int32_t* fp, int64_t mesh, int64_t img, int V, float* d_vproj, float* d_verts,
+												float* d_normals, float* d_colors) {
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const int64_t vo = (mesh * V + fp[k]) * 3;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			atomicAdd(d_verts + vo + c, o.dP[k][c]);
+			atomicAdd(d_normals + vo + c, o.dN[k][c]);
+			if (d_colors) atomicAdd(d_colors + vo + c, o.dC[k][c]);
+			atomicAdd(d_vproj + (img * V + fp[k]) * 3 + c, o.g[3 * k + c]);
+		}
+	}
+}
+
+// gradient contribution of ONE pixel whose nearest fragment is face bf (barycentrics bw, upstream gradient g), added into o
+__device__ __forceinline__ void rgb_pixel_grad(const find_render_params& rp, const float4* __restrict__ frec, const int32_t* fp, const float* __restrict__ verts,
+											   const float* __restrict__ normals, const float* __restrict__ colors, const float* __restrict__ cam, int mesh,
+											   int view, int64_t img, int V, int F, int bf, int xi, int yi, const float* g, const float* bw, RgbGrad& o) {
 	const int H = rp.image_h, W = rp.image_w;
-	const int img = blockIdx.y;
-	const int p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= H * W) return;
-	const int64_t pix = (int64_t)img * H * W + p;
-	const int bf = p2f[pix];
-	if (bf < 0) return;
-	const float g[3] = {d_image[pix * 3], d_image[pix * 3 + 1], d_image[pix * 3 + 2]};
-	if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) return;
-	const int mesh = img / n_views, view = img - mesh * n_views;
-	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)bf * 3;
-	const float bw[3] = {bary[pix * 3], bary[pix * 3 + 1], bary[pix * 3 + 2]};
 	float P[3][3], N[3][3], C[3][3];
 	float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
 	for (int k = 0; k < 3; ++k) {
@@ -758,23 +771,22 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(const find_render_params r
 		const int64_t vo = ((int64_t)mesh * V + fp[k]) * 3;
 		for (int c = 0; c < 3; ++c) {
 			d_bw[k] += d_pos[c] * P[k][c] + d_nrm[c] * N[k][c] + d_tex[c] * C[k][c];
-			atomicAdd(d_verts + vo + c, bw[k] * d_pos[c]);
-			atomicAdd(d_normals + vo + c, bw[k] * d_nrm[c]);
-			if (d_colors) atomicAdd(d_colors + vo + c, bw[k] * d_tex[c]);
+			o.dP[k][c] += bw[k] * d_pos[c];
+			o.dN[k][c] += bw[k] * d_nrm[c];
+			o.dC[k][c] += bw[k] * d_tex[c];
 		}
 	}
 	// ---- barycentrics -> NDC vertices.  w'_i = t_i / sum t,  t_0 = w0 z1 z2, t_1 = z0 w1 z2, t_2 = z0 z1 w2,
 	// w_i = edge_i(p) / area  (BarycentricPerspectiveCorrectionBackward + BarycentricCoordsBackward)
 	const float4 fa = frec[((int64_t)img * F + bf) * 3], fb = frec[((int64_t)img * F + bf) * 3 + 1], fc = frec[((int64_t)img * F + bf) * 3 + 2];
 	const float x0 = fa.x, y0 = fa.y, x1 = fa.z, y1 = fa.w, x2 = fb.x, y2 = fb.y, z0 = fb.z, z1 = fb.w, z2 = fc.x;
-	const int xi = p % W, yi = p / W;
 	const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W, py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
 	const float area = edge_fn(x2, y2, x0, y0, x1, y1) + KEPS;
 	const float e0 = edge_fn(px, py, x1, y1, x2, y2), e1 = edge_fn(px, py, x2, y2, x0, y0), e2 = edge_fn(px, py, x0, y0, x1, y1);
 	const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
 	const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
 	const float den = t0 + t1 + t2;
-	if (!(den > KEPS)) return;
+	if (!(den > KEPS)) return;  // (degenerate fragment: only the interpolation part contributes)
 	const float sdb = (d_bw[0] * t0 + d_bw[1] * t1 + d_bw[2] * t2) / den;
 	const float d_t0 = (d_bw[0] - sdb) / den, d_t1 = (d_bw[1] - sdb) / den, d_t2 = (d_bw[2] - sdb) / den;
 	const float d_w0 = d_t0 * z1 * z2, d_w1 = d_t1 * z0 * z2, d_w2 = d_t2 * z0 * z1;
@@ -802,10 +814,73 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(const find_render_params r
 		gx0 += ge * (-(y1 - y0) + (y2 - y0)); gy0 += ge * (-(x2 - x0) + (x1 - x0));
 		gx1 += ge * (-(y2 - y0)); gy1 += ge * (x2 - x0);
 	}
-	float* dv = d_vproj + (int64_t)img * V * 3;
-	atomicAdd(dv + 3 * fp[0], gx0); atomicAdd(dv + 3 * fp[0] + 1, gy0); atomicAdd(dv + 3 * fp[0] + 2, d_z0);
-	atomicAdd(dv + 3 * fp[1], gx1); atomicAdd(dv + 3 * fp[1] + 1, gy1); atomicAdd(dv + 3 * fp[1] + 2, d_z1);
-	atomicAdd(dv + 3 * fp[2], gx2); atomicAdd(dv + 3 * fp[2] + 1, gy2); atomicAdd(dv + 3 * fp[2] + 2, d_z2);
+	o.g[0] += gx0; o.g[1] += gy0; o.g[2] += d_z0; o.g[3] += gx1; o.g[4] += gy1; o.g[5] += d_z1; o.g[6] += gx2; o.g[7] += gy2; o.g[8] += d_z2;
+}
+
+// Pixel-centric (K = 1): image = (amb + diff) * tex + spec at the nearest inside fragment (the blend weight cancels to
+// within 1e-10).  One thread per pixel, 36 atomics per covered pixel: right when a face covers about a pixel.
+__global__ __launch_bounds__(256) void rgb_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec,
+													   const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+													   const float* __restrict__ verts, const float* __restrict__ normals,
+													   const float* __restrict__ colors, const float* __restrict__ cam, int n_views,
+													   int V, int F, const int32_t* __restrict__ p2f, const float* __restrict__ bary,
+													   const float* __restrict__ d_image, float* __restrict__ d_vproj,
+													   float* __restrict__ d_verts, float* __restrict__ d_normals,
+													   float* __restrict__ d_colors) {
+	const int H = rp.image_h, W = rp.image_w;
+	const int img = blockIdx.y;
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= H * W) return;
+	const int64_t pix = (int64_t)img * H * W + p;
+	const int bf = p2f[pix];
+	if (bf < 0) return;
+	const float g[3] = {d_image[pix * 3], d_image[pix * 3 + 1], d_image[pix * 3 + 2]};
+	if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) return;
+	const int mesh = img / n_views, view = img - mesh * n_views;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)bf * 3;
+	const float bw[3] = {bary[pix * 3], bary[pix * 3 + 1], bary[pix * 3 + 2]};
+	RgbGrad o;
+	rgb_grad_zero(o);
+	rgb_pixel_grad(rp, frec, fp, verts, normals, colors, cam, mesh, view, img, V, F, bf, p % W, p / W, g, bw, o);
+	rgb_grad_commit(o, fp, mesh, img, V, d_vproj, d_verts, d_normals, d_colors);
+}
+
+// Face-centric variant for large images (a visible face covers several pixels): one thread per (image, face) walks the
+// face's pixel bbox, sums the contributions of the pixels whose nearest fragment it is, and issues its 36 atomics ONCE.
+__global__ __launch_bounds__(256) void rgb_bwd_faces_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
+															 const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+															 const float* __restrict__ verts, const float* __restrict__ normals,
+															 const float* __restrict__ colors, const float* __restrict__ cam, int n_views,
+															 int V, int F, const int32_t* __restrict__ p2f, const float* __restrict__ bary,
+															 const float* __restrict__ d_image, float* __restrict__ d_vproj,
+															 float* __restrict__ d_verts, float* __restrict__ d_normals,
+															 float* __restrict__ d_colors) {
+	const int H = rp.image_h, W = rp.image_w;
+	const int img = blockIdx.y;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= F) return;
+	const int64_t fo = (int64_t)img * F + f;
+	if (tb[fo] == TB_EMPTY) return;
+	const float4 fa = frec[fo * 3], fb = frec[fo * 3 + 1];
+	int xlo, xhi, ylo, yhi;
+	pix_range(fminf(fa.x, fminf(fa.z, fb.x)), fmaxf(fa.x, fmaxf(fa.z, fb.x)), W, &xlo, &xhi);
+	pix_range(fminf(fa.y, fminf(fa.w, fb.y)), fmaxf(fa.y, fmaxf(fa.w, fb.y)), H, &ylo, &yhi);
+	const int mesh = img / n_views, view = img - mesh * n_views;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
+	RgbGrad o;
+	rgb_grad_zero(o);
+	bool any = false;
+	for (int yi = ylo; yi <= yhi; ++yi)
+		for (int xi = xlo; xi <= xhi; ++xi) {
+			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
+			if (p2f[pix] != f) continue;
+			const float g[3] = {d_image[pix * 3], d_image[pix * 3 + 1], d_image[pix * 3 + 2]};
+			if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;
+			const float bw[3] = {bary[pix * 3], bary[pix * 3 + 1], bary[pix * 3 + 2]};
+			rgb_pixel_grad(rp, frec, fp, verts, normals, colors, cam, mesh, view, img, V, F, f, xi, yi, g, bw, o);
+			any = true;
+		}
+	if (any) rgb_grad_commit(o, fp, mesh, img, V, d_vproj, d_verts, d_normals, d_colors);
 }
 
 // vertex-normal backward: n_v = normalize(sum_f fn_f), fn_f = (v2 - v1) x (v0 - v1).  d_normals holds dL/dn_v.
@@ -965,7 +1040,12 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 	}
 	if (d_image) {
 		(void)hipMemsetAsync(w.d_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
-		hipLaunchKernelGGL(rgb_bwd_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, faces, fstride, verts,
+		// a visible face covers ~ (covered pixels) / (half the faces) pixels: above a few, sum per face before the atomics
+		if ((int64_t)H * W * 2 >= 12 * (int64_t)F)
+			hipLaunchKernelGGL(rgb_bwd_faces_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, verts, w.normals,
+							   vert_colors, cam, (int)n_views, V, F, w.p2f, w.bary, d_image, w.d_vproj, d_verts, w.d_normals, d_vert_colors);
+		else
+			hipLaunchKernelGGL(rgb_bwd_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, faces, fstride, verts,
 						   w.normals, vert_colors, cam, (int)n_views, V, F, w.p2f, w.bary, d_image, w.d_vproj, d_verts, w.d_normals, d_vert_colors);
 		// unit normals -> raw area-weighted sums -> face cross products -> vertices
 		(void)hipMemsetAsync(w.raw_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);

@@ -81,9 +81,10 @@ def test_silhouette_backward_vs_oracle_autograd():
 	assert err < 2e-3 * scale, (err, scale)
 
 
-def test_image_backward_vs_oracle_autograd():
-	size = 48
-	verts, faces, cols, R, T = _scene(n_meshes=2, rings=8, segs=10, seed=4)
+@pytest.mark.parametrize('rings,segs,size', [(8, 10, 48), (24, 30, 40)])
+def test_image_backward_vs_oracle_autograd(rings, segs, size):
+	"""(8, 10) @48: few large faces -> the face-centric RGB backward; (24, 30) @40: faces about a pixel -> the pixel-centric one."""
+	verts, faces, cols, R, T = _scene(n_meshes=2, rings=rings, segs=segs, seed=4)
 	vg = verts.clone().cuda().requires_grad_(True)
 	cg = cols.clone().cuda().requires_grad_(True)
 	(_, image, p2f, _), params = _render_gpu(vg, faces, cg, R, T, size, want_mask=False, want_frags=True)
