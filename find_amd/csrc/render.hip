@@ -1040,8 +1040,8 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 	}
 	if (d_image) {
 		(void)hipMemsetAsync(w.d_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
-		// a visible face covers ~ (covered pixels) / (half the faces) pixels: above a few, sum per face before the atomics
-		if ((int64_t)H * W * 2 >= 12 * (int64_t)F)
+		// sum per face before the atomics unless faces vastly outnumber pixels (measured: faster even at about one pixel per visible face)
+		if ((int64_t)H * W * 2 >= (int64_t)F)
 			hipLaunchKernelGGL(rgb_bwd_faces_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, verts, w.normals,
 							   vert_colors, cam, (int)n_views, V, F, w.p2f, w.bary, d_image, w.d_vproj, d_verts, w.d_normals, d_vert_colors);
 		else
