@@ -253,8 +253,10 @@ def train3d_cpu(mwl, batch, gv, gf, gc, sample_feet=1):
 				sample=f'{nf} of the feet, same step without the optimiser update, best of 2, oracle (torch-CPU / numpy) with {cores} threads')
 
 
-def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256):
-	"""BASELINE.json configs[2]: a batch of 16 feet x 4 views @256^2 with the silhouette render loss, end to end -- MLP query,
+def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256, c4=False):
+	"""BASELINE.json configs[2] (and, with c4=True, the per-rank share of configs[3]: 16 of the 128 feet, 4 views @512^2, silhouette + pixel +
+	Chamfer losses; under torch.distributed.run every rank takes 16 feet and the gradients are all-reduced, as in the headline run).
+	configs[2]: a batch of 16 feet x 4 views @256^2 with the silhouette render loss, end to end -- MLP query,
 	registration, GT and predicted renders (the GT is re-rendered every step, as the reference does), silhouette loss, backward
 	through rasteriser and MLP, optimiser steps.  One JSON line; the CPU leg runs the oracle's composition on one foot x one view."""
 	import numpy as np
@@ -266,8 +268,14 @@ def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256):
 	from find_amd.train_utils import sample_latent_vectors
 	if not torch.cuda.is_available():
 		raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
-	dev = torch.device('cuda', 0)
-	opts = Opts(sil_loss=True, num_views=n_views)
+	import torch.distributed as dist
+	from find_amd import distributed as fdist
+	rank, world, local = fdist.init_from_env()
+	torch.cuda.set_device(local)
+	dev = torch.device('cuda', local)
+	if c4:
+		size = 512
+	opts = Opts(sil_loss=True, pix_loss=c4, chamf_loss=c4, num_views=n_views)
 	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=n_feet, val_size=2,
 						shapevec_size=100, texvec_size=100, posevec_size=100, template_mesh_loc=None)
 	g = torch.Generator().manual_seed(1234)
@@ -278,44 +286,70 @@ def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256):
 	mwl.rdr = FootRenderer(image_size=size, device=dev)
 	v, f = synthetic.template(N_VERTS)
 	mwl.model.set_template(v.to(dev), f.to(dev))
-	lat = synthetic.latents(n_feet, seed=0, device=dev)
+	lat = synthetic.latents(n_feet, seed=rank, device=dev)
 	with torch.no_grad():
 		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
 			getattr(mwl.model, k).data.copy_(lat[k])
-	gv, gf, gc = synthetic.gt_feet(n_feet, 10002, seed=0, device=dev)
+	gv, gf, gc = synthetic.gt_feet(n_feet, 10002, seed=rank, device=dev)
 	batch = dict(mesh=Meshes(gv, gf, TexturesVertex(gc.clamp(0.05, 0.95))), idx=torch.arange(n_feet, device=dev), name=[f'{i:04d}' for i in range(n_feet)])
 	np.random.seed(7)
 	R, T = mwl.rdr.sample_views(nviews=n_views, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
 	m = mwl.model
 	optims = [optim.Adam(m.main_params, lr=5e-4), optim.SGD(m.reg_params, lr=1e-3, momentum=0.9), optim.Adam(m.latent_params, lr=1e-3)]
+	bucket = None
+	if world > 1:
+		trainable = [p for p in m.parameters() if p.requires_grad]
+		fdist.broadcast_parameters([p for p in m.parameters() if p.is_floating_point()])
+		bucket = fdist.GradBucket(trainable)
 
 	def step():
 		for o in optims:
 			o.zero_grad(set_to_none=True)
 		b = dict(batch)
 		b.update(sample_latent_vectors(b, m.latent_vectors_train))
-		loss, _ = mwl(b, 0, opts, sil=True, render_foot=True, views=(R, T))
+		loss, _ = mwl(b, 0, opts, sil=True, pix=c4, chamf=c4, render_foot=True, views=(R, T))
 		loss.backward()
+		if bucket is not None:
+			bucket.allreduce_()
 		for o in optims:
 			o.step()
 		return loss
 
 	for _ in range(warmup):
 		step()
+	if world > 1:
+		dist.barrier()
 	torch.cuda.synchronize()
 	t0 = time.perf_counter()
 	for _ in range(steps):
 		step()
 	torch.cuda.synchronize()
-	ms = (time.perf_counter() - t0) / steps * 1e3
-	out = {'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': n_feet * N_VERTS * n_views / (ms * 1e-3), 'unit': 'vertices*views/s',
-		   'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+	if world > 1:
+		dist.barrier()
+	torch.cuda.synchronize()
+	elapsed = time.perf_counter() - t0
+	if world > 1:
+		t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t.item())
+	ms = elapsed / steps * 1e3
+	if rank != 0:
+		dist.barrier()
+		dist.destroy_process_group()
+		return
+	n_feet_total = n_feet * world
+	out = {'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': n_feet_total * N_VERTS * n_views / (ms * 1e-3), 'unit': 'vertices*views/s',
+		   'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
 		   'dtype': 'f32', 'data': 'synthetic',
-		   'config': {'workload': f'C3: {n_feet} feet x {n_views} views @{size}^2, {N_VERTS}-vertex template (13776 faces), 10002-vertex GT scans re-rendered every '
-								  f'step, silhouette loss, backward through rasteriser + MLP, optimiser steps', 'feet_per_gpu': n_feet, 'views': n_views}}
-	if with_cpu:
+		   'config': {'workload': f'{"C4 rank share" if c4 else "C3"}: {n_feet} feet x {n_views} views @{size}^2 per GPU, {N_VERTS}-vertex template (13776 faces), 10002-vertex GT '
+								  f'scans re-rendered every step, {"silhouette + pixel + Chamfer losses" if c4 else "silhouette loss"}, backward through rasteriser + MLP, '
+								  f'optimiser steps', 'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{world}'}}
+	if with_cpu and world == 1 and not c4:
 		out['cpu_baseline'] = c3_cpu(mwl, gv, gf, R, T, size)
 	print(json.dumps(out), flush=True)
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
 
 
 def c3_cpu(mwl, gv, gf, R, T, size):
@@ -382,14 +416,15 @@ def main():
 	ap.add_argument('--no-cpu-baseline', action='store_true')
 	ap.add_argument('--train3d', action='store_true', help='instead of the headline line: the reference training configuration (train_3d.yaml losses + optimiser steps)')
 	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
+	ap.add_argument('--c4', action='store_true', help='per-rank share of BASELINE configs[3]: 16 feet x 4 views @512^2, silhouette + pixel + Chamfer losses; works under torch.distributed.run')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
 	args = ap.parse_args()
 	if args.subpaths:
 		return subpaths(not args.no_cpu_baseline)
 	if args.train3d:
 		return train3d(not args.no_cpu_baseline, args.steps, args.warmup)
-	if args.c3:
-		return c3(not args.no_cpu_baseline, args.steps, args.warmup)
+	if args.c3 or args.c4:
+		return c3(not args.no_cpu_baseline, args.steps, args.warmup, c4=args.c4)
 
 	import torch.distributed as dist
 	from find_amd import distributed as fdist
