@@ -416,9 +416,13 @@ def main():
 	ap.add_argument('--no-cpu-baseline', action='store_true')
 	ap.add_argument('--train3d', action='store_true', help='instead of the headline line: the reference training configuration (train_3d.yaml losses + optimiser steps)')
 	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
+	ap.add_argument('--c5', action='store_true', help='BASELINE configs[4] geometry in fp32: the headline workload on the 50 002-vertex dense template (the fp16 variant is not built)')
 	ap.add_argument('--c4', action='store_true', help='per-rank share of BASELINE configs[3]: 16 feet x 4 views @512^2, silhouette + pixel + Chamfer losses; works under torch.distributed.run')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
 	args = ap.parse_args()
+	if args.c5:
+		global N_VERTS
+		N_VERTS = 50002
 	if args.subpaths:
 		return subpaths(not args.no_cpu_baseline)
 	if args.train3d:
@@ -477,14 +481,14 @@ def main():
 			'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': value, 'unit': 'vertices*views/s',
 			'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
 			'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-			'config': {'workload': f'C2: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
+			'config': {'workload': f'{"C5 geometry, fp32" if N_VERTS == 50002 else "C2"}: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
 					   'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{world}',
 					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
 					   'step_tflops_executed': fl_exec / (ms_step * 1e-3) / 1e12,
 					   'step_tflops_reference_equiv': fl_ref / (ms_step * 1e-3) / 1e12},
 			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm4_kernel<1> (Linear 256->256 + bias + ReLU over 110240 rows, fp32 MFMA)',
 						 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
-						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES,
+						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES if N_VERTS == 6890 else None,
 						 'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
 										 'profiles/r01_gemm4_pmc_summary.txt; algorithmic 226.0e6'},
 		}
