@@ -426,7 +426,7 @@ struct BwdWs {
 	float* Ct[FIND_MAX_LAYERS];
 	float* dzD[2];
 	float* dzC[2];
-	float* dzT[2];
+	float* dzT[FIND_MAX_LAYERS];  // one per trunk layer: the dX chain never waits for the side stream's readers
 	float* pw;    // dW partial slabs
 	float* pb;    // bias partial slabs
 	float* Sd;    // (n_feet,256) per-foot column sums of the disp head's first-layer dZ
@@ -449,7 +449,7 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	for (int i = 0; i < p->n_col; ++i) o->Ct[i] = c.take<float>((int64_t)W * W);
 	for (int i = 0; i < 2; ++i) o->dzD[i] = c.take<float>(d.rows_h * W);
 	for (int i = 0; i < 2; ++i) o->dzC[i] = c.take<float>(d.rows_h * W);
-	for (int i = 0; i < 2; ++i) o->dzT[i] = c.take<float>(d.rows_t * W);
+	for (int i = 0; i < std::max(p->n_trunk, 1); ++i) o->dzT[i] = c.take<float>(d.rows_t * W);
 	int spf, cps;
 	split_policy(d.n_feet, d.V, &spf, &cps);
 	int64_t ms = d.n_feet * spf;
@@ -734,15 +734,14 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 
 	// 5. trunk
 	{
-		hipEvent_t reads[2] = {nullptr, nullptr};
+		// every layer's dZ has its own buffer (the trunk is small): the dX chain runs back to back on the caller's stream while the
+		// weight gradients follow on the side stream -- a cross-stream wait costs ~10 us here even when it is already satisfied
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
 			fork();
 			rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, b, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, q);
 			if (rc != FIND_OK) return rc;
-			reads[ct] = side_done();
-			wait_side(reads[ct ^ 1]);
-			linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct ^ 1], V, d.feet_t, s);
-			ct ^= 1;
+			linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s);
+			ct += 1;
 		}
 		fork();
 		rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, q);
