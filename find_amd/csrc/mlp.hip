@@ -424,8 +424,8 @@ struct BwdWs {
 	float* Tt[FIND_MAX_LAYERS];  // transposed trunk weights (layers >= 1)
 	float* Dt[FIND_MAX_LAYERS];  // transposed disp-head weights (layer 0: main block)
 	float* Ct[FIND_MAX_LAYERS];
-	float* dzD[2];
-	float* dzC[2];
+	float* dzD[FIND_MAX_LAYERS];  // one per head layer (as dzT)
+	float* dzC[FIND_MAX_LAYERS];
 	float* dzT[FIND_MAX_LAYERS];  // one per trunk layer: the dX chain never waits for the side stream's readers
 	float* pw;    // dW partial slabs
 	float* pb;    // bias partial slabs
@@ -447,8 +447,8 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	for (int i = 1; i < p->n_trunk; ++i) o->Tt[i] = c.take<float>((int64_t)W * W);
 	for (int i = 0; i < p->n_disp; ++i) o->Dt[i] = c.take<float>((int64_t)W * W);
 	for (int i = 0; i < p->n_col; ++i) o->Ct[i] = c.take<float>((int64_t)W * W);
-	for (int i = 0; i < 2; ++i) o->dzD[i] = c.take<float>(d.rows_h * W);
-	for (int i = 0; i < 2; ++i) o->dzC[i] = c.take<float>(d.rows_h * W);
+	for (int i = 0; i < std::max(p->n_disp, 1); ++i) o->dzD[i] = c.take<float>(d.rows_h * W);
+	for (int i = 0; i < std::max(p->n_col, 1); ++i) o->dzC[i] = c.take<float>(d.rows_h * W);
 	for (int i = 0; i < std::max(p->n_trunk, 1); ++i) o->dzT[i] = c.take<float>(d.rows_t * W);
 	int spf, cps;
 	split_policy(d.n_feet, d.V, &spf, &cps);
@@ -675,15 +675,12 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	// 3. heads, last hidden layer down to the first
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs) -> int {
-		hipEvent_t reads[2] = {nullptr, nullptr};  // last side-stream reader of each ping-pong buffer
-		for (int l = nl - 1; l >= 1; --l) {
+		for (int l = nl - 1; l >= 1; --l) {  // (one dZ buffer per layer: the dX chain never waits for the weight gradients)
 			fork();
 			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
 			if (r != FIND_OK) return r;
-			reads[cur] = side_done();
-			wait_side(reads[cur ^ 1]);
-			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur ^ 1], V, n_feet, s);
-			cur ^= 1;
+			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s);
+			cur += 1;
 		}
 		int r;
 		if (d.shared) {
