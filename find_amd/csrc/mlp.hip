@@ -137,8 +137,10 @@ static int g_num_cus = 0;
 // Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
 // the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
 static int g_bwd_streams = 1;
+constexpr int N_SIDE = 3;
 struct SideStream {
-	hipStream_t q = nullptr;
+	hipStream_t q = nullptr;          // weight gradients of the (large) head layers
+	hipStream_t qt[N_SIDE] = {nullptr, nullptr, nullptr};  // trunk layers, round-robin: small independent kernels that overlap each other
 	hipEvent_t ev[64];
 	int n = 0;      // events created
 	int next = 0;   // round-robin cursor
@@ -151,6 +153,9 @@ static SideStream* side_stream() {
 	SideStream* ss = &g_side[dev];
 	if (!ss->q) {
 		if (hipStreamCreateWithFlags(&ss->q, hipStreamNonBlocking) != hipSuccess) { ss->q = nullptr; return nullptr; }
+		ss->qt[0] = ss->q;
+		for (int i = 1; i < N_SIDE; ++i)
+			if (hipStreamCreateWithFlags(&ss->qt[i], hipStreamNonBlocking) != hipSuccess) { ss->qt[i] = ss->q; }
 		for (ss->n = 0; ss->n < 64; ++ss->n)
 			if (hipEventCreateWithFlags(&ss->ev[ss->n], hipEventDisableTiming) != hipSuccess) break;
 		if (ss->n < 64) return nullptr;
@@ -429,6 +434,8 @@ struct BwdWs {
 	float* dzT[FIND_MAX_LAYERS];  // one per trunk layer: the dX chain never waits for the side stream's readers
 	float* pw;    // dW partial slabs
 	float* pb;    // bias partial slabs
+	float* pw_t[3];  // slab sets of the trunk's side streams ([0] aliases pw / pb)
+	float* pb_t[3];
 	float* Sd;    // (n_feet,256) per-foot column sums of the disp head's first-layer dZ
 	float* Sc;
 	float* zsD;   // shared template: (V,256) sum over feet of the disp head's first-layer dZ
@@ -460,6 +467,11 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	const int64_t ms2 = std::max<int64_t>(512, d.n_feet) + d.n_feet + 16;
 	o->pw = c.take<float>(std::max<int64_t>(ms * W * KP0, ms2 * W * W));
 	o->pb = c.take<float>(std::max<int64_t>(ms, ms2) * W);
+	o->pw_t[0] = o->pw; o->pb_t[0] = o->pb;
+	for (int i = 1; i < 3; ++i) {  // trunk layers have matrix inputs (dw2 slabs) except layer 0, which always uses set 0
+		o->pw_t[i] = c.take<float>(ms2 * W * W);
+		o->pb_t[i] = c.take<float>(ms2 * W);
+	}
 	o->Sd = c.take<float>(d.n_feet * W);
 	o->Sc = c.take<float>(d.n_feet * W);
 	o->nblk_fs = (int)cdiv(d.V, FS_ROWS);
@@ -596,12 +608,13 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	SideStream* ss = g_bwd_streams ? side_stream() : nullptr;
 	hipStream_t q = ss ? ss->q : s;
 	auto next_event = [&]() -> hipEvent_t { hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63; return e; };
-	auto fork = [&]() {
+	auto fork_to = [&](hipStream_t target) {
 		if (!ss) return;
 		hipEvent_t e = next_event();
 		(void)hipEventRecord(e, s);
-		(void)hipStreamWaitEvent(q, e, 0);
+		(void)hipStreamWaitEvent(target, e, 0);
 	};
+	auto fork = [&]() { fork_to(q); };
 	auto side_done = [&]() -> hipEvent_t {
 		if (!ss) return nullptr;
 		hipEvent_t e = next_event();
@@ -733,9 +746,15 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	{
 		// every layer's dZ has its own buffer (the trunk is small): the dX chain runs back to back on the caller's stream while the
 		// weight gradients follow on the side stream -- a cross-stream wait costs ~10 us here even when it is already satisfied
+		// the layers' weight gradients are independent of each other and each fills a fraction of the chip: round-robin over the side
+		// streams (own slab set each) so that they overlap; set 0 / stream q stays in order behind the heads' work
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			fork();
-			rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, b, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, q);
+			const int k = ss ? l % N_SIDE : 0;
+			hipStream_t qk = ss ? ss->qt[k] : s;
+			BwdWs bk = b;
+			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
+			fork_to(qk);
+			rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, qk);
 			if (rc != FIND_OK) return rc;
 			linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s);
 			ct += 1;
@@ -743,7 +762,15 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		fork();
 		rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, q);
 		if (rc != FIND_OK) return rc;
-		wait_side(side_done());  // join: the caller's stream continues only after every gradient is written
+		// join: the caller's stream continues only after every gradient is written
+		if (ss) {
+			for (int i = 0; i < N_SIDE; ++i) {
+				if (i > 0 && ss->qt[i] == ss->q) continue;
+				hipEvent_t e = next_event();
+				(void)hipEventRecord(e, ss->qt[i]);
+				(void)hipStreamWaitEvent(s, e, 0);
+			}
+		}
 	}
 	FIND_LAUNCH_CHECK("find_mlp_bwd");
 	return FIND_OK;
