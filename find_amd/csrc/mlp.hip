@@ -131,6 +131,8 @@ static int g_gemm4 = 1;  // 1: K=256 single-segment MAT launches use gemm4_kerne
 static int64_t g_gemm4_min_units = 1024;
 static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
 static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
+static int g_gemm4_small = 64;   // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
+static int g_dw_pe_target = 384;
 static int g_dw2_min_cps = 4;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
 static int g_num_cus = 0;
 
@@ -201,23 +203,26 @@ static void launch_gemm3_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), lds, s, a);
 }
 
-template <int EPI>
+template <int EPI, int NI>
 static void launch_gemm4_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	static bool attr_set = false;
+	constexpr int lds = NI * 32 * 1024;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM4_LDS);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		attr_set = true;
 	}
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
-	const int grid = std::max(16, (num_cus() / 16) * 16);  // pairs of column halves, mates 8 blocks apart (same XCD)
-	hipLaunchKernelGGL((gemm4_kernel<EPI>), dim3(grid), dim3(512), GEMM4_LDS, s, a);
+	constexpr int G = 8 * (8 / NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
+	const int grid = std::max(G, (num_cus() / G) * G);
+	hipLaunchKernelGGL((gemm4_kernel<EPI, NI>), dim3(grid), dim3(512), lds, s, a);
 }
 
+template <int NI>
 static void launch_gemm4(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU>(a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK>(a, feet, s);
-	else launch_gemm4_t<EPI_NONE>(a, feet, s);
+	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU, NI>(a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK, NI>(a, feet, s);
+	else launch_gemm4_t<EPI_NONE, NI>(a, feet, s);
 }
 
 template <int BM>
@@ -248,7 +253,12 @@ static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hip
 		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
 		// K = 256, one segment, enough 32-row units to give every SIMD of the chip work: W-resident kernel
 		if (g_gemm4 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet * 2 >= g_gemm4_min_units) {
-			launch_gemm4(epi, b, feet, s);
+			launch_gemm4<4>(epi, b, feet, s);
+			return;
+		}
+		// the same kernel on column quarters for launches of a few hundred 32-row units (the shared trunk: V rows)
+		if (g_gemm4 && g_gemm4_small && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet >= g_gemm4_small) {
+			launch_gemm4<2>(epi, b, feet, s);
 			return;
 		}
 		if (g_gemm3 && amode == AMODE_MAT && !big) {
@@ -283,9 +293,8 @@ static void linear_fwd(const float* x, int64_t x_foot_stride, const float* w, in
 	launch_gemm(AMODE_MAT, EPI_BIAS_RELU, a, feet, s);
 }
 
-static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps) {
+static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t target = 128) {
 	const int64_t cpf = cdiv(V, 32);
-	const int64_t target = 128;
 	int64_t s0 = std::max<int64_t>(1, std::min<int64_t>(cpf, cdiv(target, n_feet)));
 	*cps = (int)cdiv(cpf, s0);
 	*spf = (int)cdiv(cpf, *cps);
@@ -440,7 +449,8 @@ struct BwdWs {
 	float* Sc;
 	float* zsD;   // shared template: (V,256) sum over feet of the disp head's first-layer dZ
 	float* zsC;
-	float* pS;    // [nblk_fs][n_feet][256] partial per-foot column sums
+	float* pS;    // [nblk_fs][n_feet][256] partial per-foot column sums (disp head)
+	float* pS2;   // same for the colour head: the reduces run on the side stream, so the heads cannot share one
 	int nblk_fs;
 	float* pwo[2];  // final-layer partials
 	float* pbo[2];
@@ -479,8 +489,9 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 		o->zsD = c.take<float>(d.V * W);
 		o->zsC = c.take<float>(d.V * W);
 		o->pS = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
+		o->pS2 = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
 	} else {
-		o->zsD = o->zsC = o->pS = nullptr;
+		o->zsD = o->zsC = o->pS = o->pS2 = nullptr;
 	}
 	o->nblk_out = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(d.rows_h, 64), 512));
 	for (int i = 0; i < 2; ++i) {
@@ -527,7 +538,8 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 		return FIND_OK;
 	}
 	int spf, cps;
-	split_policy(feet, V, &spf, &cps);
+	// (Fourier layer: nkt k-tiles per split -- keep the launch within one round of workgroups over the chip)
+	split_policy(feet, V, &spf, &cps, pos ? std::min<int64_t>(128, std::max<int64_t>(16, g_dw_pe_target / nkt)) : 128);
 	DwArgs a;
 	memset(&a, 0, sizeof(a));
 	a.dz = dz; a.dz_foot_stride = V * W;
@@ -687,7 +699,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 
 	// 3. heads, last hidden layer down to the first
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
-						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs) -> int {
+						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps) -> int {
 		for (int l = nl - 1; l >= 1; --l) {  // (one dZ buffer per layer: the dX chain never waits for the weight gradients)
 			fork();
 			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
@@ -698,11 +710,14 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		int r;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
-			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, b.pS);
-			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, s, b.pS, b.nblk_fs, (int)n_feet, S);
-			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
+			// (only the side stream's kernels read the per-foot column sums: the dX chain goes on with zs alone)
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps);
+			hipStream_t qf = g_bwd_streams == 2 ? q : s;
+			if (g_bwd_streams == 2) fork();
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, qf, ps, b.nblk_fs, (int)n_feet, S);
+			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, qf, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
-			fork();
+			if (g_bwd_streams != 2) fork();
 			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, q);
 		} else {
 			fork();
@@ -716,11 +731,11 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		return FIND_OK;
 	};
 	if (act_d) {
-		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD);
+		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS);
 		if (rc != FIND_OK) return rc;
 	}
 	if (act_c) {
-		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC);
+		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2);
 		if (rc != FIND_OK) return rc;
 	}
 
@@ -787,6 +802,15 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 		g_ablate = (int)value;
 		return FIND_OK;
 	}
+	if (strcmp(key, "gemm4_small") == 0) {
+		g_gemm4_small = (int)value;
+		return FIND_OK;
+	}
+	if (strcmp(key, "dw_pe_target") == 0) {
+		FIND_REQUIRE(value >= 16, "find_set_tuning: dw_pe_target must be >= 16");
+		g_dw_pe_target = (int)value;
+		return FIND_OK;
+	}
 	if (strcmp(key, "dw2_min_cps") == 0) {
 		FIND_REQUIRE(value >= 1, "find_set_tuning: dw2_min_cps must be >= 1");
 		g_dw2_min_cps = (int)value;
@@ -797,7 +821,7 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 		return FIND_OK;
 	}
 	if (strcmp(key, "bwd_streams") == 0) {
-		g_bwd_streams = value != 0;
+		g_bwd_streams = (int)value;
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm4") == 0) {

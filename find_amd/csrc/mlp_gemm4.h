@@ -31,8 +31,11 @@ namespace mlp {
 constexpr int GEMM4_LDS = 128 * 1024;
 constexpr int GEMM4_PD = 3;  // A prefetch distance in 32-k chunks (ring of 4)
 
-template <int EPI>
+// NI = 32-column blocks per wave unit: 4 (column halves, the large launches) or 2 (column quarters, 64 KB of W per workgroup:
+// launches of a few hundred units -- the shared trunk's V rows -- spread over four times as many SIMDs as gemm3's 64-row tiles)
+template <int EPI, int NI>
 __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
+	constexpr int NCG = 8 / NI;  // column groups
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const unsigned lds_base = (unsigned)(uintptr_t)smem;
 
@@ -41,21 +44,24 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
 	const int li = lane & 31, fh = lane >> 5;
 	const int b = blockIdx.x;
-	const int npairs = gridDim.x >> 1;
-	const int pair = (b >> 4) * 8 + (b & 7);
-	const int half = (b >> 3) & 1;
+	const int npairs = gridDim.x / NCG;
+	const int pair = (b / (8 * NCG)) * 8 + (b & 7);   // the column groups of the same rows are 8 blocks apart: same XCD
+	const int col0 = ((b >> 3) % NCG) * (NI * 32);
 	const int V = g.V, lda = g.lda, ldy = g.ldy, upf = g.tiles_per_foot;
 
-	// ---- prologue: this half of W -> LDS (wave w: rows n with (n & 31) in [4w, 4w+4), i.e. LDS rows 16w .. 16w+15)
+	// ---- prologue: this column group of W -> LDS (LDS row R = NI * (n & 31) + (n >> 5); wave w: rows 4 NI w .. 4 NI (w+1) - 1)
 	{
 		const float* wb = uniform_ptr(g.w0);
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const int l2 = wave * 4 + j;  // n & 31
+		for (int j = 0; j < NI; ++j) {
+			const int r0 = wave * 4 * NI + 4 * j;
 			unsigned o[4];
 #pragma unroll
-			for (int ni = 0; ni < 4; ++ni) o[ni] = (unsigned)(((half * 128 + ni * 32 + l2) * g.ldw + ((lane ^ (l2 & 15)) * 4)) * 4);
-			dma4(wb, __builtin_amdgcn_readfirstlane(lds_base + (l2 * 4) * 1024), o[0], o[1], o[2], o[3]);
+			for (int i = 0; i < 4; ++i) {
+				const int l2 = (r0 + i) / NI, ni = (r0 + i) % NI;  // n & 31, n >> 5
+				o[i] = (unsigned)(((col0 + ni * 32 + l2) * g.ldw + ((lane ^ (l2 & 15)) * 4)) * 4);
+			}
+			dma4(wb, __builtin_amdgcn_readfirstlane(lds_base + r0 * 1024), o[0], o[1], o[2], o[3]);
 		}
 		FIND_WAIT_VMCNT(0);
 		__syncthreads();
@@ -66,12 +72,12 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 	int u = u0 + wave;
 	if (u >= u1) return;
 
-	// B fragment byte offsets: LDS row 4*li (+ni), slot ((c&1)*8 + fh*4 + q) ^ (li & 15); (c>>1)*256 and ni*1024 are immediates
+	// B fragment byte offsets: LDS row NI*li (+ni), slot ((c&1)*8 + fh*4 + q) ^ (li & 15); (c>>1)*256 and ni*1024 are immediates
 	unsigned boff[2][4];
 #pragma unroll
 	for (int c1 = 0; c1 < 2; ++c1)
 #pragma unroll
-		for (int q = 0; q < 4; ++q) boff[c1][q] = (unsigned)((li * 4) * 1024 + (((c1 * 8 + fh * 4 + q) ^ (li & 15)) * 16));
+		for (int q = 0; q < 4; ++q) boff[c1][q] = (unsigned)((li * NI) * 1024 + (((c1 * 8 + fh * 4 + q) ^ (li & 15)) * 16));
 
 	auto unit_rows = [&](int uu, int& foot, int& v0) -> const float4* {
 		foot = uu / upf;
@@ -88,10 +94,10 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 #pragma unroll
 		for (int q = 0; q < 4; ++q) areg[c][q] = cur[c * 8 + q];
 
-	float4 bf[2][4];
-	auto load_b = [&](int c, int q, float4 (&f)[4]) {
+	float4 bf[2][NI];
+	auto load_b = [&](int c, int q, float4 (&f)[NI]) {
 #pragma unroll
-		for (int ni = 0; ni < 4; ++ni) f[ni] = *reinterpret_cast<const float4*>(smem + boff[c & 1][q] + (c >> 1) * 256 + ni * 1024);
+		for (int ni = 0; ni < NI; ++ni) f[ni] = *reinterpret_cast<const float4*>(smem + boff[c & 1][q] + (c >> 1) * 256 + ni * 1024);
 	};
 	load_b(0, 0, bf[0]);
 
@@ -99,15 +105,15 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 		int nfoot = foot, nv0 = v0;
 		const float4* nxt = (u + 8 < u1) ? unit_rows(u + 8, nfoot, nv0) : cur;
 
-		float bv[4];
+		float bv[NI];
 		if constexpr (EPI == EPI_BIAS_RELU) {
 #pragma unroll
-			for (int ni = 0; ni < 4; ++ni) bv[ni] = g.bias[(int64_t)foot * g.bias_foot_stride + half * 128 + ni * 32 + li];
+			for (int ni = 0; ni < NI; ++ni) bv[ni] = g.bias[(int64_t)foot * g.bias_foot_stride + col0 + ni * 32 + li];
 		}
 
-		f32x16 acc[4];
+		f32x16 acc[NI];
 #pragma unroll
-		for (int ni = 0; ni < 4; ++ni)
+		for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
@@ -127,12 +133,12 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 				// B fragments of the next k-group (wraps to (0,0): the next unit multiplies the same W)
 				load_b(((s + 1) >> 2) & 7, (s + 1) & 3, bf[(s + 1) & 1]);
 				const float4 a = areg[c & 3][q];
-				const float4(&f)[4] = bf[s & 1];
+				const float4(&f)[NI] = bf[s & 1];
 #pragma unroll
 				for (int kk = 0; kk < 4; ++kk) {
 					const float av = kk == 0 ? a.x : (kk == 1 ? a.y : (kk == 2 ? a.z : a.w));
 #pragma unroll
-					for (int ni = 0; ni < 4; ++ni) {
+					for (int ni = 0; ni < NI; ++ni) {
 						const float bvv = kk == 0 ? f[ni].x : (kk == 1 ? f[ni].y : (kk == 2 ? f[ni].z : f[ni].w));
 						acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, acc[ni], 0, 0, 0);
 					}
@@ -147,14 +153,14 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 			const int valid_rows = min(32, V - v0);
 			float* ytile = g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy;
 			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ytile)), 0, valid_rows * ldy * 4, 0x00020000);
-			const int voff = ((4 * fh) * ldy + half * 128 + li) * 4;
+			const int voff = ((4 * fh) * ldy + col0 + li) * 4;
 			__amdgpu_buffer_rsrc_t msrc = rsrc;
 			if constexpr (EPI == EPI_MASK) {
 				const float* mtile = g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy;
 				msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(mtile)), 0, valid_rows * ldy * 4, 0x00020000);
 			}
 #pragma unroll
-			for (int ni = 0; ni < 4; ++ni) {
+			for (int ni = 0; ni < NI; ++ni) {
 				float mv[16];
 				if constexpr (EPI == EPI_MASK) {
 #pragma unroll

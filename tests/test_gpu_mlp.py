@@ -277,3 +277,24 @@ def test_c5_dense_template_shared_equals_general(golden_main):
 	for a, b in zip(grads[0], grads[1]):
 		scale = max(1.0, b.abs().max().item())
 		assert (a - b).abs().max().item() < 2e-4 * scale
+
+
+@pytest.mark.parametrize('n_feet,n_pts', [(1, 70), (1, 2100), (1, 6890), (3, 1000), (16, 6890)])
+def test_linear_relu_kernel_every_routing(n_feet, n_pts):
+	"""find_linear_relu_fwd (the bench's dominant kernel; model.py:421-426 `Linear` + `ReLU`) at row counts that route to each of
+	the tile kernels -- 64-row LDS-DMA tiles, W-resident column quarters, W-resident column halves -- against a float64 matmul."""
+	import ctypes
+	from find_amd import _lib
+	L = _lib.lib()
+	gen = torch.Generator().manual_seed(n_feet * 7919 + n_pts)
+	x = torch.randn(n_feet * n_pts, 256, generator=gen)
+	w = torch.randn(256, 256, generator=gen) / 16
+	b = torch.randn(256, generator=gen)
+	xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+	y = torch.full_like(xd, float('nan'))
+	_lib.check(L.find_linear_relu_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), n_feet, n_pts, _lib.ptr(y),
+									  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'find_linear_relu_fwd')
+	want = np.maximum(x.numpy().astype(np.float64) @ w.numpy().astype(np.float64).T + b.numpy().astype(np.float64), 0.0)
+	got = y.cpu().numpy()
+	assert np.isfinite(got).all()
+	assert np.abs(got - want).max() < TOL
