@@ -132,7 +132,7 @@ static int64_t g_gemm4_min_units = 1024;
 static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
 static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
 static int g_gemm4_small = 64;   // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
-static int g_dw_pe_target = 384;
+static int g_dw_pe_target = 256;  // workgroups of the Fourier layer's weight-gradient launch (one round over the chip)
 static int g_dw2_min_cps = 4;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
 static int g_num_cus = 0;
 
@@ -203,26 +203,26 @@ static void launch_gemm3_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), lds, s, a);
 }
 
-template <int EPI, int NI>
+template <int EPI, int NI, int NW = 8>
 static void launch_gemm4_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	static bool attr_set = false;
 	constexpr int lds = NI * 32 * 1024;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, NI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		attr_set = true;
 	}
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	constexpr int G = 8 * (8 / NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
 	const int grid = std::max(G, (num_cus() / G) * G);
-	hipLaunchKernelGGL((gemm4_kernel<EPI, NI>), dim3(grid), dim3(512), lds, s, a);
+	hipLaunchKernelGGL((gemm4_kernel<EPI, NI, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
 }
 
-template <int NI>
+template <int NI, int NW = 8>
 static void launch_gemm4(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU, NI>(a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK, NI>(a, feet, s);
-	else launch_gemm4_t<EPI_NONE, NI>(a, feet, s);
+	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU, NI, NW>(a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK, NI, NW>(a, feet, s);
+	else launch_gemm4_t<EPI_NONE, NI, NW>(a, feet, s);
 }
 
 template <int BM>

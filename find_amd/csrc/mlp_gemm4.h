@@ -21,7 +21,8 @@
 // with the operand roles swapped and the bias folded into the accumulator init; one wave per SIMD with 64x128 wave tiles (main
 // loop at 96% of the MFMA issue bound in isolation, but the epilogue is then dead time) and the same with two accumulator sets
 // draining the previous unit under the MFMAs (the slices are not absorbed: every non-MFMA instruction of the wave costs
-// matrix-pipe issue time).  What is left is instruction issue: ~0.6 non-MFMA instructions per MFMA.
+// matrix-pipe issue time); column quarters (NI = 2) on the large launches at two and at three waves per SIMD (123 / 127 us
+// against 121).  What is left is instruction issue: ~0.6 non-MFMA instructions per MFMA.
 #pragma once
 #include "mlp_gemm3.h"
 
@@ -33,8 +34,8 @@ constexpr int GEMM4_PD = 3;  // A prefetch distance in 32-k chunks (ring of 4)
 
 // NI = 32-column blocks per wave unit: 4 (column halves, the large launches) or 2 (column quarters, 64 KB of W per workgroup:
 // launches of a few hundred units -- the shared trunk's V rows -- spread over four times as many SIMDs as gemm3's 64-row tiles)
-template <int EPI, int NI>
-__global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
+template <int EPI, int NI, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 	constexpr int NCG = 8 / NI;  // column groups
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const unsigned lds_base = (unsigned)(uintptr_t)smem;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 	// ---- prologue: this column group of W -> LDS (LDS row R = NI * (n & 31) + (n >> 5); wave w: rows 4 NI w .. 4 NI (w+1) - 1)
 	{
 		const float* wb = uniform_ptr(g.w0);
+		if (wave < 8)
 #pragma unroll
 		for (int j = 0; j < NI; ++j) {
 			const int r0 = wave * 4 * NI + 4 * j;
@@ -101,9 +103,9 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const Gemm2Args g) {
 	};
 	load_b(0, 0, bf[0]);
 
-	for (; u < u1; u += 8) {
+	for (; u < u1; u += NW) {
 		int nfoot = foot, nv0 = v0;
-		const float4* nxt = (u + 8 < u1) ? unit_rows(u + 8, nfoot, nv0) : cur;
+		const float4* nxt = (u + NW < u1) ? unit_rows(u + NW, nfoot, nv0) : cur;
 
 		float bv[NI];
 		if constexpr (EPI == EPI_BIAS_RELU) {
