@@ -418,6 +418,7 @@ def main():
 	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
 	ap.add_argument('--c5', action='store_true', help='BASELINE configs[4] geometry in fp32: the headline workload on the 50 002-vertex dense template (the fp16 variant is not built)')
 	ap.add_argument('--c4', action='store_true', help='per-rank share of BASELINE configs[3]: 16 feet x 4 views @512^2, silhouette + pixel + Chamfer losses; works under torch.distributed.run')
+	ap.add_argument('--dp-overhead', action='store_true', help='diagnostic: run the headline step on ONE GPU through the data-parallel code path (one-rank RCCL group, gradient bucket + all-reduce) to see what the N>1 bookkeeping costs per step')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
 	args = ap.parse_args()
 	if args.c5:
@@ -442,6 +443,9 @@ def main():
 
 	model, params, step = build_step(device, seed=rank)
 	bucket = None
+	if args.dp_overhead and world == 1:
+		dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1)
+		bucket = fdist.GradBucket(params)
 	if world > 1:
 		fdist.broadcast_parameters([p for p in model.parameters() if p.is_floating_point()])
 		bucket = fdist.GradBucket(params)
@@ -482,11 +486,11 @@ def main():
 			'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
 			'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
 			'config': {'workload': f'{"C5 geometry, fp32" if N_VERTS == 50002 else "C2"}: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
-					   'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{world}',
+					   'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{world}' + (' through the one-rank bucket + RCCL path (diagnostic)' if bucket is not None and world == 1 else ''),
 					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
 					   'step_tflops_executed': fl_exec / (ms_step * 1e-3) / 1e12,
 					   'step_tflops_reference_equiv': fl_ref / (ms_step * 1e-3) / 1e12},
-			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm4_kernel<1> (Linear 256->256 + bias + ReLU over 110240 rows, fp32 MFMA)',
+			'roofline': {'bound': 'mfma', 'kernel': 'find::mlp::gemm4_kernel<1, 4, 8> (Linear 256->256 + bias + ReLU over 110240 rows, fp32 MFMA)',
 						 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
 						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES if N_VERTS == 6890 else None,
 						 'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
@@ -497,6 +501,7 @@ def main():
 		print(json.dumps(out), flush=True)
 	if world > 1:
 		dist.barrier()
+	if dist.is_initialized():
 		dist.destroy_process_group()
 
 

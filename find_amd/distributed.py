@@ -35,34 +35,77 @@ def shard_range(n_items, rank, world):
 class GradBucket:
 	"""Flat gradient bucket for a fixed parameter list.  `allreduce_()` averages .grad over ranks in ONE collective
 	(MLP grads || latent-table grads, ~3.6 MB fp32).  Parameters without a gradient contribute zeros, so every rank
-	issues an identically-shaped collective even when its shard touched different latent rows."""
+	issues an identically-shaped collective even when its shard touched different latent rows.
 
-	def __init__(self, params, group=None):
+	On a GPU the bucket registers its slots as the gradient arena of find_amd.functional: the backward kernels write each
+	parameter's gradient straight into its slot and autograd adopts that view as `.grad`, so a step costs the collective alone
+	(RCCL averages in place) -- no gather into the bucket and no scatter back.  A gradient that did not come out of the arena
+	(second backward of the same parameter in one step, CPU tensors, foreign autograd nodes) takes the copy path."""
+
+	def __init__(self, params, group=None, arena=None):
 		self.params = [p for p in params if p.requires_grad]
 		self.group = group
-		self.numel = sum(p.numel() for p in self.params)
 		p0 = self.params[0]
-		self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-		self.views, o = [], 0
+		self.offsets, o = [], 0
 		for p in self.params:
-			self.views.append(self.flat[o:o + p.numel()].view_as(p))
-			o += p.numel()
+			self.offsets.append(o)
+			o += (p.numel() + 3) & ~3  # 16-byte aligned slots; the padding stays zero
+		self.numel = o
+		self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+		self.views = [self._view(i) for i in range(len(self.params))]
+		self.taken = [False] * len(self.params)
+		self.arena = p0.is_cuda if arena is None else arena
+		if self.arena:
+			from . import functional
+			functional.register_grad_arena(self, self.params)
+
+	def _view(self, i):
+		p = self.params[i]
+		return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+
+	def take(self, i, shape, device):
+		"""Arena request from a backward kernel wrapper: a FRESH view of slot i (autograd adopts a gradient tensor only when nothing
+		else references it), or None when the slot was handed out already this step or still backs a live .grad."""
+		p = self.params[i]
+		if self.taken[i] or tuple(shape) != tuple(p.shape) or device != self.flat.device:
+			return None
+		g = p.grad
+		if g is not None and g.data_ptr() == self.views[i].data_ptr():
+			return None
+		self.taken[i] = True
+		return self._view(i)
+
+	def close(self):
+		if self.arena:
+			from . import functional
+			functional.unregister_grad_arena(self)
+			self.arena = False
 
 	def allreduce_(self):
-		if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+		self.taken = [False] * len(self.params)
+		if not (dist.is_available() and dist.is_initialized()):
 			return
 		world = dist.get_world_size(self.group)
-		have = [p.grad is not None for p in self.params]
-		if not all(have):
-			self.flat.zero_()
-		torch._foreach_copy_([v for v, h in zip(self.views, have) if h], [p.grad for p, h in zip(self.params, have) if h])
-		dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-		self.flat.div_(world)
-		# copy back in one multi-tensor launch (a per-parameter loop is ~30 tiny kernels per step)
-		torch._foreach_copy_([p.grad for p, h in zip(self.params, have) if h], [v for v, h in zip(self.views, have) if h])
-		for p, v, h in zip(self.params, self.views, have):
-			if not h:
-				p.grad = v.clone()
+		missing, src, dst = [], [], []
+		for p, v in zip(self.params, self.views):
+			if p.grad is None:
+				missing.append((p, v))
+			elif p.grad.data_ptr() != v.data_ptr():
+				src.append(p.grad)
+				dst.append(v)
+		if missing:
+			torch._foreach_zero_([v for _, v in missing])
+		if src:
+			torch._foreach_copy_(dst, src)
+		if dist.get_backend(self.group) == 'nccl':
+			dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+		else:
+			dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+			self.flat.div_(world)
+		if src:  # copy back in one multi-tensor launch (a per-parameter loop is ~30 tiny kernels per step)
+			torch._foreach_copy_(src, dst)
+		for p, v in missing:
+			p.grad = v.clone()
 
 
 def broadcast_parameters(params, src=0, group=None):

@@ -28,6 +28,57 @@ def _ws(nbytes, device):
 	return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ----------------------------------------------------------------------------------------------- gradient arena
+# distributed.GradBucket registers the parameters it reduces here: the backward kernels then write those gradients straight into
+# the bucket's flat buffer (autograd adopts the returned views as .grad), so the all-reduce needs no gather / scatter copies.
+_GRAD_ARENA = {}   # (data_ptr, numel) of a parameter -> (bucket, slot)
+
+
+def register_grad_arena(bucket, params):
+	for i, prm in enumerate(params):
+		_GRAD_ARENA[(prm.data_ptr(), prm.numel())] = (bucket, i)
+
+
+def unregister_grad_arena(bucket):
+	for k in [k for k, (b, _) in _GRAD_ARENA.items() if b is bucket]:
+		del _GRAD_ARENA[k]
+
+
+def _grad_for(key, shape, device):
+	"""Uninitialised gradient buffer for the input with arena key (data_ptr, numel): its slot of a registered bucket when that slot
+	is free this step, else a fresh tensor."""
+	if _GRAD_ARENA:
+		ent = _GRAD_ARENA.get(key)
+		if ent is not None:
+			v = ent[0].take(ent[1], shape, device)
+			if v is not None:
+				return v
+	return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+def _grads_like(tensors):
+	"""Gradient buffers for a list of inputs: arena slots where registered, otherwise views of ONE fresh allocation."""
+	out = [None] * len(tensors)
+	rest = []
+	if _GRAD_ARENA:
+		for i, t in enumerate(tensors):
+			ent = _GRAD_ARENA.get((t.data_ptr(), t.numel()))
+			out[i] = ent[0].take(ent[1], t.shape, t.device) if ent is not None else None
+	for i, t in enumerate(tensors):
+		if out[i] is None:
+			rest.append(i)
+	if rest:
+		# 16-byte aligned slots (the slab reduce stores float4)
+		offs, n = [], 0
+		for i in rest:
+			offs.append(n)
+			n += (tensors[i].numel() + 3) & ~3
+		flat = torch.empty(n, dtype=tensors[rest[0]].dtype, device=tensors[rest[0]].device)
+		for i, o in zip(rest, offs):
+			out[i] = flat[o:o + tensors[i].numel()].view(tensors[i].shape)
+	return out
+
+
 # ----------------------------------------------------------------------------------------------- MLP
 class MLPSpec:
 	"""Static description of the network (layer counts / sizes) shared by forward and backward."""
@@ -108,7 +159,7 @@ class _MLP(torch.autograd.Function):
 		pos_batch, n_feet, V = ctx.dims
 		g_disp, g_col = _c(g_disp), _c(g_col)
 		p = _fill_params(spec, B, avg_col, weights)
-		grads = [torch.empty_like(w) for w in weights]
+		grads = _grads_like(weights)
 		g_lat_disp = torch.empty_like(lat_disp) if lat_disp is not None else None
 		g_lat_col = torch.empty_like(lat_col) if lat_col is not None else None
 		G = MlpGrads()
@@ -155,6 +206,7 @@ class _LatentGather(torch.autograd.Function):
 			  'find_latent_gather_fwd')
 		ctx.save_for_backward(idx)
 		ctx.shape = tuple(table.shape)
+		ctx.table_key = (table.data_ptr(), table.numel())
 		return out
 
 	@staticmethod
@@ -162,7 +214,7 @@ class _LatentGather(torch.autograd.Function):
 		L = _lib.lib()
 		idx, = ctx.saved_tensors
 		g = _c(g)
-		d_table = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+		d_table = _grad_for(ctx.table_key, ctx.shape, g.device)
 		check(L.find_latent_gather_bwd(ptr(g), ptr(idx), idx.shape[0], ctx.shape[0], ctx.shape[1], ptr(d_table), current_stream(g.device)),
 			  'find_latent_gather_bwd')
 		return d_table, None

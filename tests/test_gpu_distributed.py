@@ -1,0 +1,110 @@
+"""GPU side of the data-parallel step: the gradient arena -- backward kernels writing straight into the flat
+all-reduce bucket -- and the RCCL collective itself on a one-rank `nccl` group (the multi-rank arithmetic is covered on CPU with
+`gloo`, tests/test_distributed_cpu.py)."""
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_step(n_feet=4, n_verts=1002, seed=0):
+	from find_amd import synthetic
+	dev = torch.device('cuda:0')
+	model = synthetic.make_model(n_verts, train_size=n_feet, val_size=2, device=dev)
+	lat = synthetic.latents(n_feet, seed=seed, device=dev)
+	with torch.no_grad():
+		model.shapevec.data.copy_(lat['shapevec'])
+		model.texvec.data.copy_(lat['texvec'])
+		model.posevec.data.copy_(lat['posevec'])
+		model.reg.data.copy_(lat['reg'])
+	idx = torch.arange(n_feet, device=dev)
+	params = [p for p in model.parameters() if p.requires_grad]
+
+	def backward_once(scale=1.0):
+		batch = dict(shapevec_train=model.shapevec[idx], texvec_train=model.texvec[idx], posevec_train=model.posevec[idx], reg_train=model.reg[idx])
+		res = model.get_meshes_from_batch(batch, is_train=True)
+		(scale * ((res['verts'] ** 2).sum() + (res['col'] ** 2).sum())).backward()
+
+	return model, params, backward_once
+
+
+def _grads(params):
+	return [None if p.grad is None else p.grad.detach().clone() for p in params]
+
+
+def test_backward_writes_into_the_bucket_and_matches_plain_gradients():
+	from find_amd import distributed as fd
+	model, params, backward_once = _model_and_step()
+	backward_once()
+	plain = _grads(params)
+	for p in params:
+		p.grad = None
+	bucket = fd.GradBucket(params)
+	try:
+		assert bucket.arena
+		backward_once()
+		aliased = 0
+		for p, v, g0 in zip(params, bucket.views, plain):
+			assert (p.grad is None) == (g0 is None)
+			if p.grad is None:
+				continue
+			assert torch.equal(p.grad, g0)
+			aliased += int(p.grad.data_ptr() == v.data_ptr())
+		# every MLP weight and every latent table gets its gradient from a HIP backward: all of them must live in the bucket
+		assert aliased == sum(g is not None for g in plain), f'{aliased} gradients in the bucket'
+		# the flat buffer holds exactly those values (padding between slots stays zero)
+		total = sum(float(g.double().sum()) for g in plain if g is not None)
+		assert abs(float(bucket.flat.double().sum()) - total) <= 1e-6 * max(1.0, abs(total))
+		# second backward before the step ends: slots are handed out once, autograd accumulates in place
+		backward_once(0.5)
+		for p, g0 in zip(params, plain):
+			if g0 is not None:
+				assert torch.allclose(p.grad, 1.5 * g0, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
+		# next step without clearing .grad: the live gradients must not be overwritten by the kernels
+		bucket.allreduce_()   # no process group: ends the step only
+		backward_once(0.5)
+		for p, g0 in zip(params, plain):
+			if g0 is not None:
+				assert torch.allclose(p.grad, 2.0 * g0, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
+	finally:
+		bucket.close()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_one_rank_allreduce_in_place():
+	import torch.distributed as dist
+	from find_amd import distributed as fd
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	torch.cuda.set_device(0)
+	dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+	try:
+		model, params, backward_once = _model_and_step(seed=1)
+		extra = torch.nn.Parameter(torch.ones(5, device='cuda'))  # never receives a gradient
+		bucket = fd.GradBucket(params + [extra])
+		try:
+			backward_once()
+			want = _grads(params)
+			bucket.allreduce_()   # RCCL average over one rank, in place on the bucket
+			torch.cuda.synchronize()
+			for p, g0 in zip(params, want):  # (tables the step never read -- the validation latents -- come back as zeros)
+				assert torch.equal(p.grad, g0 if g0 is not None else torch.zeros_like(p))
+			assert torch.equal(extra.grad, torch.zeros(5, device='cuda'))
+			# a gradient that did not come out of the arena takes the copy path
+			for p in params:
+				p.grad = None
+			extra.grad = torch.full((5,), 3.0, device='cuda')
+			backward_once()
+			bucket.allreduce_()
+			torch.cuda.synchronize()
+			assert torch.equal(extra.grad, torch.full((5,), 3.0, device='cuda'))
+			for p, g0 in zip(params, want):
+				assert torch.equal(p.grad, g0 if g0 is not None else torch.zeros_like(p))
+		finally:
+			bucket.close()
+	finally:
+		dist.destroy_process_group()
