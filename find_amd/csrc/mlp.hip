@@ -708,6 +708,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 			cur += 1;
 		}
 		int r;
+		float* db_late = nullptr;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
 			// (only the side stream's kernels read the per-foot column sums: the dX chain goes on with zs alone)
@@ -715,7 +716,9 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 			hipStream_t qf = g_bwd_streams == 2 ? q : s;
 			if (g_bwd_streams == 2) fork();
 			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, qf, ps, b.nblk_fs, (int)n_feet, S);
-			hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, qf, S, (int)n_feet, gb[0]);
+			// (the bias gradient -- S summed over feet -- rides along with the latent-gradient launch when there is one)
+			if (L > 0) db_late = gb[0];
+			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, qf, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
 			if (g_bwd_streams != 2) fork();
 			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, q);
@@ -725,7 +728,8 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		}
 		if (r != FIND_OK) return r;
 		if (L > 0) {
-			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, q, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0]);
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W + (db_late ? 1 : 0))), dim3(256), 0, q, w0full, ld0, lat, L, S, (int)n_feet, glat,
+							   gw[0], db_late);
 			FIND_LAUNCH_CHECK("latent_grad_kernel");
 		}
 		return FIND_OK;

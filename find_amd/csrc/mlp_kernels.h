@@ -491,15 +491,21 @@ __global__ __launch_bounds__(1024) void footsum_reduce_kernel(const float* __res
 	const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
 	const int f = blockIdx.x;
 	const float* p = pS + (int64_t)f * 256 + n;
-	float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+	// latency-bound (a few hundred strided loads per thread): 16 independent loads in flight per iteration
+	float acc[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 	int k = q;
-	for (; k + 12 < nblk; k += 16) {
-		s0 += p[(int64_t)k * n_feet * 256];
-		s1 += p[(int64_t)(k + 4) * n_feet * 256];
-		s2 += p[(int64_t)(k + 8) * n_feet * 256];
-		s3 += p[(int64_t)(k + 12) * n_feet * 256];
+	for (; k + 60 < nblk; k += 64) {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) acc[i] += p[(int64_t)(k + 4 * i) * n_feet * 256];
 	}
-	for (; k < nblk; k += 4) s0 += p[(int64_t)k * n_feet * 256];
+	for (; k < nblk; k += 4) acc[0] += p[(int64_t)k * n_feet * 256];
+#pragma unroll
+	for (int i = 8; i >= 1; i >>= 1)
+#pragma unroll
+		for (int j = 0; j < i; ++j) acc[j] += acc[j + i];
+	const float s0 = acc[0], s1 = 0.f, s2 = 0.f, s3 = 0.f;
 	red[q][n] = (s0 + s1) + (s2 + s3);
 	__syncthreads();
 	if (q == 0) S[(int64_t)f * 256 + n] = (red[0][n] + red[1][n]) + (red[2][n] + red[3][n]);
@@ -572,11 +578,18 @@ __global__ __launch_bounds__(256) void latent_bias_kernel(const float* Wfull, in
 //   dlat[foot][j] = sum_n S[foot][n] * Wfull[n][256+j];   dWfull[n][256+j] = sum_foot S[foot][n] * lat[foot][j]
 // 256 threads.  Blocks [0, n_feet): 4 groups of 64 lanes split n, lanes over j (coalesced), LDS-combined.
 // Blocks [n_feet, n_feet + 256): one output row n of dWfull's latent columns.
+// Block n_feet + 256 (launched only when db != nullptr): db[n] = sum_foot S[foot][n].
 __global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, int ldw, const float* lat, int L, const float* S, int n_feet,
-														   float* dlat, float* dWfull) {
+														   float* dlat, float* dWfull, float* db) {
 	__shared__ float red[4][64];
 	const int b = blockIdx.x;
 	const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+	if (b == n_feet + W) {
+		float s = 0.f;
+		for (int f = 0; f < n_feet; ++f) s += S[(int64_t)f * W + threadIdx.x];
+		db[threadIdx.x] = s;
+		return;
+	}
 	if (b < n_feet) {
 		if (dlat == nullptr) return;
 		for (int j0 = 0; j0 < L; j0 += 64) {
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, in
 			if (j < L) {
 				const float* wp = Wfull + (int64_t)(q * 64) * ldw + W + j;
 				const float* sp = S + (int64_t)b * W + q * 64;
-#pragma unroll 4
+#pragma unroll
 				for (int n = 0; n < 64; n += 4) {
 					s0 = fmaf(sp[n + 0], wp[(int64_t)(n + 0) * ldw], s0);
 					s1 = fmaf(sp[n + 1], wp[(int64_t)(n + 1) * ldw], s1);
