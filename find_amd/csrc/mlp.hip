@@ -806,6 +806,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 		g_ablate = (int)value;
 		return FIND_OK;
 	}
+	if (strcmp(key, "raster_ablate") == 0) {
+		find::g_raster_ablate = (int)value;
+		return FIND_OK;
+	}
 	if (strcmp(key, "gemm4_small") == 0) {
 		g_gemm4_small = (int)value;
 		return FIND_OK;

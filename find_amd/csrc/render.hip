@@ -23,14 +23,16 @@
 #include "common.h"
 
 namespace find {
+int g_raster_ablate = 0;
 namespace render {
 
 constexpr int TS = 16;          // tile edge in pixels
 constexpr int BATCH = 256;      // candidates shaded per LDS batch
 constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
+constexpr int KU = 16;            // list entries in flight per lane in the K-nearest passes (they are L2-latency-bound)
 constexpr int KN_CAP = 1024;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1])
-constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 per CU); each owns KN_CAP x 256 x 8 B of scratch
+constexpr int RASTER_WGS = 1280;  // persistent rasteriser workgroups (5 per CU: 95 VGPRs, 22 KB LDS; 6 per CU spills and is slower); each owns KN_CAP x 256 x 8 B of scratch
 
 struct Ws {
 	float* vproj;     // (n_img, V, 3)
@@ -308,6 +310,7 @@ struct TileArgs {
 	float2* scratch;
 	const int32_t* tile_any;
 	int tiles_per_img, total_tiles;
+	int ablate;              // profiling only (find_set_tuning "raster_ablate"): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math
 };
 
 // Persistent: workgroups take (image, tile) pairs from an atomic counter.  Silhouette candidates of every pixel are also
@@ -377,12 +380,12 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					const int k = kb + __builtin_ctzll(qm);
 					qm &= qm - 1;
 					Frag fr;
-					if (!in_img || !eval_frag(rec[k], px, py, &fr)) continue;
+					if ((a.ablate & 4) || !in_img || !eval_frag(rec[k], px, py, &fr)) continue;
 					if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
 						const float sd = fr.inside ? -fr.dist : fr.dist;
 						const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
 						alpha *= (1.0f - prob);
-						if (cnt < KN_CAP) { scr_z[cnt * 256 + tid] = fr.pz_clip; scr_q[cnt * 256 + tid] = 1.0f - prob; }
+						if (cnt < KN_CAP && !(a.ablate & 1)) { scr_z[cnt * 256 + tid] = fr.pz_clip; scr_q[cnt * 256 + tid] = 1.0f - prob; }
 						++cnt;
 						z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bisection bounds)
 					}
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 		// step, then blends, in face order, the candidates in front of it and as many of those AT it as still fit.
 		float thr = INFINITY;
 		if (want_sil) {
-			const bool over = in_img && cnt > K;
+			const bool over = in_img && cnt > K && !(a.ablate & 2);
 			const unsigned long long ov_all = __ballot(over);
 			if (ov_all) {
 				// (no fence: every lane reads back only the list it wrote itself -- same thread, same addresses, program order.  An
@@ -446,47 +449,57 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					atomicMax(&a.flags[5], wave_max_cnt);
 					if (trunc) atomicAdd(&a.flags[1], (int)__popcll(trunc));
 				}
+				const long long kt0 = (a.ablate & 64) ? wall_clock64() : 0;
+				if ((a.ablate & 64) && lane == 0) {  // profiling: waves by their longest list, [8 + log2 bucket]; [20] sum of longest lists
+					atomicAdd(&a.flags[8 + min(7, max(0, 31 - __builtin_clz(max(wave_max_cnt, 1)) - 6))], 1);
+					atomicAdd(&a.flags[20], wave_max_cnt);
+					atomicAdd(&a.flags[21], (int)__popcll(ov_all));
+				}
 				if (over && cnt <= KN_CAP) {
 					const float* zp = scr_z + tid;
 					const float* qp = scr_q + tid;
 					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
 					// Radix search for the K-th smallest depth.  Invariant: every candidate lies in [lo, hi] or was counted in c_lo
 					// (candidates in front of lo) or lies behind hi; the K-th smallest is inside [lo, hi].  A level histograms
-					// (z - lo) >> shift into 16 bins (16-bit counters packed in 8 registers) in ONE read of the list and keeps the bin
+					// (z - lo) >> shift into 32 bins in ONE read of the list and keeps the bin
 					// that holds the K-th; once that bin has at most 4 candidates they are fetched and ranked directly.
 					int c_lo = 0;
+					// the lane's 32 counters (16 bits each) live in LDS, on top of the face records nobody needs any more in this tile:
+					// hist[w * 256 + tid], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
+					unsigned* const hist = reinterpret_cast<unsigned*>(rec) + tid;
 					while (lo < hi) {
 						const unsigned span = hi - lo;
-						const int shift = span < 16u ? 0 : (28 - __builtin_clz(span));  // (span >> shift) <= 15
-						unsigned h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0;
+						const int shift = span < 32u ? 0 : (27 - __builtin_clz(span));  // (span >> shift) <= 31
+#pragma unroll
+						for (int w = 0; w < 16; ++w) hist[w * 256] = 0u;
 						auto tally = [&](unsigned zb) {
 							if (zb < lo || zb > hi) return;
 							const unsigned bin = (zb - lo) >> shift;
-							const unsigned inc = 1u << ((bin & 1u) * 16u);
-							const unsigned w = bin >> 1;
-							h0 += w == 0 ? inc : 0u; h1 += w == 1 ? inc : 0u; h2 += w == 2 ? inc : 0u; h3 += w == 3 ? inc : 0u;
-							h4 += w == 4 ? inc : 0u; h5 += w == 5 ? inc : 0u; h6 += w == 6 ? inc : 0u; h7 += w == 7 ? inc : 0u;
+							__hip_atomic_fetch_add(hist + (bin >> 1) * 256, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						};
 						int i = 0;
-						for (; i + 8 <= cnt; i += 8) {
-							unsigned bz[8];
+						for (; i + KU <= cnt; i += KU) {
+							unsigned bz[KU];
 #pragma unroll
-							for (int u = 0; u < 8; ++u) bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f);
+							for (int u = 0; u < KU; ++u) bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f);
 #pragma unroll
-							for (int u = 0; u < 8; ++u) tally(bz[u]);
+							for (int u = 0; u < KU; ++u) tally(bz[u]);
 						}
 						for (; i < cnt; ++i) tally(__float_as_uint(zp[i * 256] + 0.0f));
 						// the bin that holds the (K - c_lo)-th candidate of the range
-						const unsigned hw[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
 						const int need = K - c_lo;
-						int acc = 0, sel = 15, in_sel = 0;
+						int acc = 0, sel = 31, in_sel = 0;
 						bool found = false;
 #pragma unroll
-						for (int bb = 0; bb < 16; ++bb) {
-							const int cb = (int)((hw[bb >> 1] >> ((bb & 1) * 16)) & 0xFFFFu);
-							if (!found) {
-								if (acc + cb >= need) { sel = bb; in_sel = cb; found = true; }
-								else acc += cb;
+						for (int w = 0; w < 16; ++w) {
+							const unsigned hw = hist[w * 256];
+#pragma unroll
+							for (int h = 0; h < 2; ++h) {
+								const int cb = (int)((hw >> (h * 16)) & 0xFFFFu);
+								if (!found) {
+									if (acc + cb >= need) { sel = 2 * w + h; in_sel = cb; found = true; }
+									else acc += cb;
+								}
 							}
 						}
 						c_lo += acc;
@@ -523,13 +536,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					float asel = 1.0f;
 					{
 						int i = 0;
-						for (; i + 8 <= cnt; i += 8) {
-							unsigned bz[8];
-							float qv[8];
+						for (; i + KU <= cnt; i += KU) {
+							unsigned bz[KU];
+							float qv[KU];
 #pragma unroll
-							for (int u = 0; u < 8; ++u) { bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f); qv[u] = qp[(i + u) * 256]; }
+							for (int u = 0; u < KU; ++u) { bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f); qv[u] = qp[(i + u) * 256]; }
 #pragma unroll
-							for (int u = 0; u < 8; ++u) {
+							for (int u = 0; u < KU; ++u) {
 								if (bz[u] < lo) asel *= qv[u];
 								else if (bz[u] == lo && ties > 0) { asel *= qv[u]; --ties; }
 							}
@@ -544,6 +557,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					alpha = asel;
 					thr = __uint_as_float(lo);
 				}
+				if ((a.ablate & 64) && lane == 0) atomicAdd(&a.flags[22], (int)((wall_clock64() - kt0) >> 4));  // K-pass time of the wave, 16-tick units (100 MHz)
 			}
 		}
 
@@ -1001,6 +1015,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
 	a.zthr = w.zthr; a.scratch = w.scratch; a.tile_any = w.tile_any;
 	a.tiles_per_img = (int)(a.tiles_x * cdiv(H, TS)); a.total_tiles = (int)(a.tiles_per_img * n_img);
+	a.ablate = find::g_raster_ablate;
 	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)w.raster_wgs), dim3(256), 0, s, a);
 	FIND_LAUNCH_CHECK("find_render_fwd");
 	return FIND_OK;

@@ -6,6 +6,7 @@ from find_amd import functional_render as FR, synthetic, _lib
 from find_amd.functional import _ws, _c, _faces_i32
 from find_amd._lib import ptr, check, current_stream
 from find_amd.cameras import look_at_view_transform
+_lib.check(_lib.lib().find_set_tuning(b'raster_ablate', 64), 'tune')
 for size in (256, 512):
 	v, f = synthetic.template(6890)
 	g = torch.Generator().manual_seed(0)
@@ -23,3 +24,5 @@ for size in (256, 512):
 	torch.cuda.synchronize()
 	fl = ws[:256].view(torch.int32).cpu().tolist()
 	print(size, 'flags (z-straddlers, unresolved overflow pixels):', FR.render_flags(ws), 'of', N * M * size * size, 'pixels; overflow pixels', fl[4], 'max candidates per pixel', fl[5])
+	print('   waves in the K pass by longest list [64,128) [128,256) [256,512) [512,1024) >=1024:', fl[8:13], ' sum of longest lists', fl[20], ' over-lanes', fl[21],
+		  ' K-pass wave time %.1f ms summed over waves (100 MHz ticks x16)' % (fl[22] * 16 / 100e6 * 1e3))
