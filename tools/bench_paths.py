@@ -21,10 +21,19 @@ from find_amd.cameras import look_at_view_transform  # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
-def gpu_ms(fn, warm=3, iters=10):
-	for _ in range(warm):
+def gpu_ms(fn, warm_s=0.3, min_iters=10, min_s=0.1):
+	"""Average GPU time of fn() in ms.  The GPU idles while the CPU oracle of the previous sub-path runs, so warm up by wall time
+	(the clock needs a few hundred ms of work to come back up), then time enough iterations to cover min_s."""
+	t0 = time.perf_counter()
+	n = 0
+	while n < 3 or time.perf_counter() - t0 < warm_s:
 		fn()
+		n += 1
+		if n % 4 == 0:
+			torch.cuda.synchronize()
 	torch.cuda.synchronize()
+	per = max((time.perf_counter() - t0) / n, 1e-5)
+	iters = max(min_iters, int(min_s / per))
 	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 	e0.record()
 	for _ in range(iters):
