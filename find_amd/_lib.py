@@ -99,6 +99,11 @@ def lib():
 	if v != ABI_VERSION:
 		raise RuntimeError(f'find_amd: ABI mismatch: library {v}, binding {ABI_VERSION}; rebuild with python -m find_amd.build')
 	_lib = L
+	# profiling aid: FIND_TUNING="key=value,key=value" applies find_set_tuning knobs at load time (tools/, bench.py experiments)
+	for kv in filter(None, os.environ.get('FIND_TUNING', '').split(',')):
+		k, v = kv.split('=')
+		if L.find_set_tuning(k.strip().encode(), int(v)) != 0:
+			raise RuntimeError(f'find_amd: FIND_TUNING: bad knob {kv!r}')
 	return L
 
 

@@ -212,3 +212,47 @@ def test_silhouette_backward_with_k_overflow_vs_oracle_autograd():
 	err = (vg.grad.cpu() - vr.grad).abs()
 	print('grad: max err %.2e of scale %.2e' % (err.max().item(), scale))
 	assert err.max().item() < 2e-2 * scale, (err.max().item(), scale)
+
+
+def test_forward_edge_cases_vs_oracle():
+	"""What PyTorch3D's rasteriser handles at the edges (rasterize_meshes.cu / FootRenderer, renderer.py:208-245): per-mesh ragged
+	face lists (-1 padding), a zero-area face, a mesh wholly behind the camera, a view that sees nothing, an image size that is
+	not a multiple of the 16-pixel tile.  Same checks as the regular forward test."""
+	size = 40
+	verts, faces, cols, R, T = _scene(n_meshes=3, rings=7, segs=9, seed=11, n_views=3)
+	F = faces.shape[0]
+	fr = faces[None].expand(3, -1, -1).clone()
+	fr[1, F - 9:] = -1                      # mesh 1 has 9 faces fewer (ragged batch)
+	fr[0, 5] = torch.tensor([3, 3, 7])      # degenerate (zero-area) face
+	verts = verts.clone()
+	R, T = R.clone(), T.clone()
+	# view 2 looks the other way: flip its view-space y and z (row-vector convention X_view = X R + T  ->  R' = R D, T' = T D)
+	D = torch.tensor([1.0, -1.0, -1.0])
+	R[2] = R[2] * D[None, :]
+	T[2] = T[2] * D
+	# mesh 2 sits 0.7 m behind the camera of view 0: move it 1 m against the world direction that maps to view 0's z axis
+	verts[2] = verts[2] - 1.0 * R[0][:, 2]
+	(mask, image, p2f, zbuf), _ = _render_gpu(verts, fr, cols, R, T, size, want_frags=True)
+	ref = render_ref.render(verts.numpy(), fr.numpy(), cols.numpy(), R.numpy(), T.numpy(), image_size=size)
+	m = mask.cpu().numpy()
+	assert np.abs(m - ref['mask']).max() < TOL
+	same = (p2f.cpu().numpy() == ref['pix_to_face'])
+	assert same.mean() > 0.999, same.mean()
+	assert np.abs(image.cpu().numpy() - ref['image'])[same].max() < TOL
+	assert np.abs(zbuf.cpu().numpy() - ref['zbuf'])[same].max() < 1e-5
+	# the scene really contains the cases: an empty view, a mesh behind a camera, covered pixels elsewhere
+	assert ref['mask'][0, 2].max() == 0.0 and m[0, 2].max() == 0.0
+	assert (p2f.cpu().numpy()[0, 2] == -1).all()
+	assert ref['mask'][2, 0].max() == 0.0 and m[2, 0].max() == 0.0
+	assert ref['mask'][0, 0].max() > 0.99 and ref['mask'][1, 1].max() > 0.99
+	# the padded / degenerate faces are never picked
+	ids = p2f.cpu().numpy()
+	F3 = fr.shape[1]
+	local = np.where(ids >= 0, ids % F3, -1)
+	assert not (local[1] >= F - 9).any()
+	assert not (local[0] == 5).any()
+	# gradients flow through the ragged batch without touching the padding
+	vg = verts.clone().cuda().requires_grad_(True)
+	(mk, _, _, _), _ = _render_gpu(vg, fr, None, R, T, size, want_image=False)
+	mk.sum().backward()
+	assert torch.isfinite(vg.grad).all() and vg.grad[0].abs().max() > 0 and vg.grad[2].abs().max() >= 0
