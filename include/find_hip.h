@@ -104,8 +104,18 @@ int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, 
  * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
 int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
 
-/* Tuning hook (no reference counterpart).  key "gemm": 0 = register-staged tiles, 64 / 128 = persistent LDS-DMA
- * kernel with that tile height (default 64). */
+/* Tuning / profiling hook (no reference counterpart); process-wide, not thread-safe.  Results do not depend on any knob.
+ *   "gemm"            0 = register-staged tiles, 64 / 128 = persistent LDS-DMA kernel with that tile height (default 64)
+ *   "gemm3", "gemm4"  0 / 1: early-barrier LDS-DMA kernel; W-resident kernel for K = 256 layers (defaults 1)
+ *   "gemm4_min_units" launches with at least this many 32-row x 128-column units use gemm4 on column halves (default 1024)
+ *   "gemm4_small"     ... and launches of at least this many 32-row units use it on column quarters (default 64; 0 = never)
+ *   "dw2", "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: LDS-DMA kernel on/off, shortest row run per workgroup,
+ *                     workgroups of the Fourier layer's launch
+ *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on side streams (default)
+ *   "raster_ablate"   profiling bits of the rasteriser (1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 K-pass
+ *                     statistics in the flags): any non-zero value other than 64 makes the render WRONG
+ *   "ablate", "dbg"   profiling switches of the GEMM kernels
+ * The Python binding applies FIND_TUNING="key=value,..." from the environment when it loads the library. */
 int find_set_tuning(const char* key, int64_t value);
 
 /* ------------------------------------------------------------------------------------------------
