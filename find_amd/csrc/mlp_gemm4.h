@@ -22,7 +22,8 @@
 // loop at 96% of the MFMA issue bound in isolation, but the epilogue is then dead time) and the same with two accumulator sets
 // draining the previous unit under the MFMAs (the slices are not absorbed: every non-MFMA instruction of the wave costs
 // matrix-pipe issue time); column quarters (NI = 2) on the large launches at two and at three waves per SIMD (123 / 127 us
-// against 121).  What is left is instruction issue: ~0.6 non-MFMA instructions per MFMA.
+// against 121); delaying the second wave of every SIMD by 8-64 K cycles so that the two waves' epilogues cannot coincide (+1 us).
+// What is left is instruction issue: ~0.6 non-MFMA instructions per MFMA.
 #pragma once
 #include "mlp_gemm3.h"
 
