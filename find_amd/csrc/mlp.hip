@@ -699,7 +699,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 
 	// 3. heads, last hidden layer down to the first
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
-						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps) -> int {
+						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
 		for (int l = nl - 1; l >= 1; --l) {  // (one dZ buffer per layer: the dX chain never waits for the weight gradients)
 			fork();
 			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
@@ -709,37 +709,41 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		}
 		int r;
 		float* db_late = nullptr;
+		hipStream_t q0 = q;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
-			// (only the side stream's kernels read the per-foot column sums: the dX chain goes on with zs alone)
+			// (the per-foot column sums stay on the caller's stream: moved behind the weight gradients they measured 0.08 ms slower)
 			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps);
-			hipStream_t qf = g_bwd_streams == 2 ? q : s;
-			if (g_bwd_streams == 2) fork();
-			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, qf, ps, b.nblk_fs, (int)n_feet, S);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, s, ps, b.nblk_fs, (int)n_feet, S);
 			// (the bias gradient -- S summed over feet -- rides along with the latent-gradient launch when there is one)
 			if (L > 0) db_late = gb[0];
-			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, qf, S, (int)n_feet, gb[0]);
+			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
-			if (g_bwd_streams != 2) fork();
-			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, b, gw[0], ld0, W, 0, nullptr, nullptr, q);
+			// the foot-summed first layer is a small launch: its own side stream and slab set, so that it does not queue behind the
+			// large weight-gradient launches on q
+			q0 = ss ? ss->qt[side] : s;
+			BwdWs bk = b;
+			bk.pw = b.pw_t[side]; bk.pb = b.pb_t[side];
+			fork_to(q0);
+			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0);
 		} else {
 			fork();
 			r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, q);
 		}
 		if (r != FIND_OK) return r;
 		if (L > 0) {
-			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W + (db_late ? 1 : 0))), dim3(256), 0, q, w0full, ld0, lat, L, S, (int)n_feet, glat,
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W + (db_late ? 1 : 0))), dim3(256), 0, q0, w0full, ld0, lat, L, S, (int)n_feet, glat,
 							   gw[0], db_late);
 			FIND_LAUNCH_CHECK("latent_grad_kernel");
 		}
 		return FIND_OK;
 	};
 	if (act_d) {
-		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS);
+		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS, 1);
 		if (rc != FIND_OK) return rc;
 	}
 	if (act_c) {
-		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2);
+		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2, 2);
 		if (rc != FIND_OK) return rc;
 	}
 
@@ -768,7 +772,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		// the layers' weight gradients are independent of each other and each fills a fraction of the chip: round-robin over the side
 		// streams (own slab set each) so that they overlap; set 0 / stream q stays in order behind the heads' work
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			const int k = ss ? l % N_SIDE : 0;
+			const int k = ss ? 1 + (l & 1) : 0;  // (q / set 0 keeps the heads' large launches and the Fourier layer)
 			hipStream_t qk = ss ? ss->qt[k] : s;
 			BwdWs bk = b;
 			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
@@ -829,7 +833,7 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 		return FIND_OK;
 	}
 	if (strcmp(key, "bwd_streams") == 0) {
-		g_bwd_streams = (int)value;
+		g_bwd_streams = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm4") == 0) {

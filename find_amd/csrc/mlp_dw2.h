@@ -2,6 +2,9 @@
 // pipeline.  One 4-wave workgroup owns a full 256x256 output tile over a contiguous range of 16-row chunks of ONE foot
 // (so dZ and X are each read from HBM exactly once and per-foot bias sums fall out for free); the partial tile goes to a
 // slab reduced by reduce_w_kernel (deterministic, no atomics).
+// (Tried for the launches with few rows -- the shared trunk's V rows, the texture pass: 64x64 output blocks over 16-64 row splits
+// with both MFMA operands loaded straight from global memory in operand layout, no LDS; 20 us against 25 us in isolation, but no
+// faster inside the step, where these launches overlap the large ones: dropped.)
 //
 //   * chunk = 16 rows of dZ (16 KB) + 16 rows of X (16 KB), each row one 1-KB global_load_lds_dwordx4; 3-stage ring;
 //   * MFMA operands come from LDS with ONE ds_read_b128 per operand per k-pair: lane l reads columns 4(l&31)..+3 of row
