@@ -139,6 +139,7 @@ static int g_num_cus = 0;
 // Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
 // the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
 static int g_bwd_streams = 1;
+static int g_lds_exclusive = 1;  // 1: the LDS-DMA ring kernels reserve the whole LDS of their CU (see CU_LDS_BYTES)
 constexpr int N_SIDE = 3;
 struct SideStream {
 	hipStream_t q = nullptr;          // weight gradients of the (large) head layers
@@ -175,18 +176,29 @@ static int num_cus() {
 	return g_num_cus;
 }
 
+// The LDS-DMA ring kernels (dw2, gemm3, gemm2) are launched with the WHOLE 160 KB of a CU's LDS although their rings need 100-120 KB.
+// With a second LDS-using workgroup of another stream resident on the same CU (the 16-KB slab reduce of a side stream is enough)
+// dw2 produced rare wrong partial tiles: one wave reads one 128-byte piece of one staged row with other contents, a rank-1 error of
+// ~1 % in a handful of dW elements -- 3 % of the backward passes at 4 x 1002 rows, 13 % at 16 x 6890, every pass with the dX GEMMs
+// on gemm3 -- with every vmcnt / barrier of the ring in place, and equally with vmcnt(0) everywhere, a one-stage ring, sleeps
+// between the wait and the read, poisoned inputs (no stale global data) or device-wide syncs around the call.  Alone on the CU's
+// LDS it never happens (tools/check_determinism.py: 0 of 500 passes, 144 KB is not enough, 160 KB is).  The reservation takes
+// nothing these kernels use -- they run one workgroup per CU anyway -- and costs 0.03 ms/step of overlap with the small kernels.
+constexpr int CU_LDS_BYTES = 160 * 1024;
+
 template <int BM, int AMODE, int EPI>
 static void launch_gemm2_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	static bool attr_set = false;
 	constexpr int lds = gemm2_lds_bytes<BM>();
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
 		attr_set = true;
 	}
 	a.tiles_per_foot = (int)cdiv(a.V, BM);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	const int grid = std::min(a.ntiles, num_cus());
-	hipLaunchKernelGGL((gemm2_kernel<BM, AMODE, EPI>), dim3(grid), dim3(256), lds, s, a);
+	static_assert(lds <= CU_LDS_BYTES, "ring larger than a CU's LDS");
+	hipLaunchKernelGGL((gemm2_kernel<BM, AMODE, EPI>), dim3(grid), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : lds, s, a);
 }
 
 template <int BM, int EPI>
@@ -194,13 +206,14 @@ static void launch_gemm3_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	static bool attr_set = false;
 	constexpr int lds = gemm2_lds_bytes<BM>();
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
 		attr_set = true;
 	}
 	a.tiles_per_foot = (int)cdiv(a.V, BM);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	const int grid = std::min(a.ntiles, num_cus());
-	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), lds, s, a);
+	static_assert(lds <= CU_LDS_BYTES, "ring larger than a CU's LDS");
+	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : lds, s, a);
 }
 
 template <int EPI, int NI, int NW = 8>
@@ -519,14 +532,14 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 		float* pbuf = (db || S) ? b.pb : nullptr;
 		static bool attr_set = false;
 		if (!attr_set) {
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
 			attr_set = true;
 		}
 		Dw2Args d2;
 		memset(&d2, 0, sizeof(d2));
 		d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
 		d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf2; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
-		hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), DW2_LDS, s, d2);
+		hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : DW2_LDS, s, d2);
 		FIND_LAUNCH_CHECK("dw2_kernel");
 		ReduceWArgs r;
 		memset(&r, 0, sizeof(r));
@@ -830,6 +843,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "dw2") == 0) {
 		g_dw2 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "lds_exclusive") == 0) {  // 0 reproduces the co-residence fault described at CU_LDS_BYTES (diagnosis only)
+		g_lds_exclusive = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "bwd_streams") == 0) {

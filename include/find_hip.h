@@ -104,7 +104,7 @@ int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, 
  * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
 int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
 
-/* Tuning / profiling hook (no reference counterpart); process-wide, not thread-safe.  Results do not depend on any knob.
+/* Tuning / profiling hook (no reference counterpart); process-wide, not thread-safe.  Results do not depend on any knob (except "lds_exclusive" = 0 and the ablation bits).
  *   "gemm"            0 = register-staged tiles, 64 / 128 = persistent LDS-DMA kernel with that tile height (default 64)
  *   "gemm3", "gemm4"  0 / 1: early-barrier LDS-DMA kernel; W-resident kernel for K = 256 layers (defaults 1)
  *   "gemm4_min_units" launches with at least this many 32-row x 128-column units use gemm4 on column halves (default 1024)
@@ -112,6 +112,8 @@ int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t
  *   "dw2", "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: LDS-DMA kernel on/off, shortest row run per workgroup,
  *                     workgroups of the Fourier layer's launch
  *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on side streams (default)
+ *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS (default); 0 reproduces the co-residence fault
+ *                     described in mlp.hip (CU_LDS_BYTES): rare wrong weight-gradient elements -- diagnosis only
  *   "raster_ablate"   profiling bits of the rasteriser (1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 K-pass
  *                     statistics in the flags): any non-zero value other than 64 makes the render WRONG
  *   "ablate", "dbg"   profiling switches of the GEMM kernels

@@ -298,3 +298,37 @@ def test_linear_relu_kernel_every_routing(n_feet, n_pts):
 	got = y.cpu().numpy()
 	assert np.isfinite(got).all()
 	assert np.abs(got - want).max() < TOL
+
+
+def test_backward_is_bit_reproducible_with_side_streams():
+	"""The backward is meant to be deterministic (slab reduces, no float atomics).  Regression test for a fault that showed only
+	with the weight-gradient kernels of several streams resident on one CU (mlp.hip, CU_LDS_BYTES): a few dW elements off by ~1 % in
+	some passes -- every pass when the dX GEMMs ran on gemm3 (tuning gemm4 = 0), so that configuration is screened too."""
+	from find_amd import _lib, synthetic
+	dev = torch.device('cuda:0')
+	n_feet = 4
+	model = synthetic.make_model(1002, train_size=n_feet, val_size=2, device=dev)
+	lat = synthetic.latents(n_feet, seed=0, device=dev)
+	named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+	def once():
+		for _, p in named:
+			p.grad = None
+		lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+		res = model.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+		((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()).backward()
+		torch.cuda.synchronize()
+		out = {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+		out.update({'latent.' + k: v.grad.detach().clone() for k, v in lv.items()})
+		return out
+
+	for gemm4 in (1, 0):
+		_lib.check(_lib.lib().find_set_tuning(b'gemm4', gemm4), 'tuning')
+		try:
+			ref = once()
+			for rep in range(25):
+				got = once()
+				bad = [n for n in ref if not torch.equal(got[n], ref[n])]
+				assert not bad, f'gemm4={gemm4}, pass {rep}: gradients of {bad} differ from the first pass'
+		finally:
+			_lib.check(_lib.lib().find_set_tuning(b'gemm4', 1), 'tuning')

@@ -1,0 +1,60 @@
+"""Runs the same forward+backward repeatedly and reports every parameter whose gradient is not bit-identical to the first run
+(the backward is meant to be deterministic: slab reduces, no float atomics). Usage: python tools/check_determinism.py [reps] [feet] [verts] [bucket]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from find_amd import distributed as fd  # noqa: E402
+from find_amd import synthetic  # noqa: E402
+synthetic.TEMPLATE_GRIDS.update({992: (30, 33), 962: (30, 32), 1026: (32, 32)})
+
+from find_amd import _lib  # noqa: E402
+torch.zeros(1, device='cuda')
+for kv in [a for a in sys.argv[1:] if '=' in a]:
+	k, v = kv.split('=')
+	_lib.check(_lib.lib().find_set_tuning(k.encode(), int(v)), 'tuning')
+sys.argv = [a for a in sys.argv if '=' not in a]
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n_feet = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+n_verts = int(sys.argv[3]) if len(sys.argv) > 3 else 1002
+use_bucket = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+dev = torch.device('cuda:0')
+model = synthetic.make_model(n_verts, train_size=n_feet, val_size=2, device=dev)
+lat = synthetic.latents(n_feet, seed=0, device=dev)
+with torch.no_grad():
+	model.shapevec.data.copy_(lat['shapevec']); model.texvec.data.copy_(lat['texvec'])
+	model.posevec.data.copy_(lat['posevec']); model.reg.data.copy_(lat['reg'])
+idx = torch.arange(n_feet, device=dev)
+named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+bucket = fd.GradBucket([p for _, p in named]) if use_bucket else None
+
+
+def once():
+	for _, p in named:
+		p.grad = None
+	if bucket is not None:
+		bucket.allreduce_()
+	batch = dict(shapevec_train=model.shapevec[idx], texvec_train=model.texvec[idx], posevec_train=model.posevec[idx], reg_train=model.reg[idx])
+	res = model.get_meshes_from_batch(batch, is_train=True)
+	((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()).backward()
+	torch.cuda.synchronize()
+	return {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+
+
+ref = once()
+bad = 0
+for i in range(reps):
+	if i % 3 == 1:
+		torch.cuda.synchronize(); x = torch.randn(4096, 4096, device=dev); (x @ x).sum().item()  # perturb timing / allocator
+	g = once()
+	for n in ref:
+		if not torch.equal(g[n], ref[n]):
+			d = (g[n] - ref[n]).abs()
+			nz = d.nonzero()
+			print(f'rep {i}: {n} {tuple(g[n].shape)} differs: max {d.max().item():.3e} (ref max {ref[n].abs().max().item():.3e}), {len(nz)} elements, first {nz[0].tolist()} last {nz[-1].tolist()}')
+			bad += 1
+			if bad <= 4:
+				print('   ', [(int(a), int(b), round(float(d[a, b]), 5)) for a, b in nz.tolist()][:64])
+print('mismatches:', bad)
