@@ -1,0 +1,150 @@
+// gemm5_kernel: the K = 256 Linear layer on the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulation) -- the opt-in
+// reduced-precision mode of BASELINE.json configs[4] ("fp16 MLP with MFMA tiles").  Activations and weights stay fp32 in HBM; both
+// MFMA operands are rounded to fp16 (round to nearest even) on their way into the matrix pipe, the products are exact and the sums
+// fp32, outputs are written as fp32.  At 16x the fp32 MFMA rate the layer is bound by HBM (2 KB per row in + out) instead of by the
+// matrix pipe, so the kernel is built around the streams, with gemm4's skeleton:
+//   * a workgroup (8 waves, two per SIMD) keeps the WHOLE weight matrix in LDS as fp16 -- 256 n x 256 k, rows padded to 528 B so
+//     that 16 consecutive lanes of a ds_read_b128 (one W row each) cover all 64 banks -- converted once in the prologue; a wave
+//     unit is 32 rows x all 256 columns, so A is read from HBM exactly once (gemm4 reads it once per column half);
+//   * A never touches LDS: lane (row l&31, half l>>5) reads 16 consecutive floats of its row per 32-k chunk (the two halves
+//     share a 128-B line), three chunks ahead across unit boundaries, and packs them into the two 8 x fp16 operands of the
+//     chunk's two MFMA k-steps.  The k order inside a chunk is therefore permuted (k = 32c + 16h + 8m + j for step m, element j);
+//     the B fragments read LDS in the same order, and a sum does not care;
+//   * no barrier and no DMA after the prologue; epilogue as gemm4 (bias + ReLU, or the ReLU mask of the backward, or plain).
+// Rounding both operands to 11 significant bits gives relative errors of ~1e-3 per layer output (tests/test_gpu_mlp_f16.py states
+// the tolerance); the fp32 kernels remain the default and the parity path.
+#pragma once
+#include "mlp_gemm4.h"
+
+namespace find {
+namespace mlp {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int G5_ROW = 528;                 // bytes per W row in LDS: 256 fp16 + 16 B of padding
+constexpr int GEMM5_LDS = 256 * G5_ROW;     // 135 168 B
+constexpr int GEMM5_NW = 8;
+
+__device__ __forceinline__ f16x8 pack_f16x8(const float4& lo, const float4& hi) {
+	f16x8 v;
+	v[0] = (_Float16)lo.x; v[1] = (_Float16)lo.y; v[2] = (_Float16)lo.z; v[3] = (_Float16)lo.w;
+	v[4] = (_Float16)hi.x; v[5] = (_Float16)hi.y; v[6] = (_Float16)hi.z; v[7] = (_Float16)hi.w;
+	return v;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int li = lane & 31, fh = lane >> 5;
+	const int V = g.V, lda = g.lda, ldy = g.ldy, upf = g.tiles_per_foot;
+
+	const int u0 = (int)((int64_t)blockIdx.x * g.ntiles / gridDim.x);
+	const int u1 = (int)((int64_t)(blockIdx.x + 1) * g.ntiles / gridDim.x);
+	if (u0 >= u1) return;
+
+	auto unit_rows = [&](int uu, int& foot, int& v0) -> const float4* {
+		foot = uu / upf;
+		v0 = (uu - foot * upf) * 32;
+		const int row = min(v0 + li, V - 1);  // rows past the end of a foot re-read its last row (never stored)
+		return reinterpret_cast<const float4*>(g.a0 + (int64_t)foot * g.a_foot_stride + (int64_t)row * lda + fh * 16);
+	};
+
+	// the first A chunks are on their way while W is converted
+	int u = u0 + wave;
+	const bool active = u < u1;
+	int foot = 0, v0 = 0;
+	const float4* cur = unit_rows(active ? u : u0, foot, v0);
+	float4 areg[4][4];
+#pragma unroll
+	for (int c = 0; c < GEMM4_PD; ++c)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) areg[c][q] = cur[c * 8 + q];
+
+	// ---- prologue: W (256, ldw) fp32 -> LDS fp16; item = (row n, 8-k group): 8192 items over 512 threads
+	{
+		const float* wb = g.w0;
+#pragma unroll 4
+		for (int it = 0; it < 16; ++it) {
+			const int item = it * (GEMM5_NW * 64) + tid;
+			const int n = item >> 5, kg = item & 31;
+			const float4* src = reinterpret_cast<const float4*>(wb + (int64_t)n * g.ldw + kg * 8);
+			const float4 lo = src[0], hi = src[1];
+			*reinterpret_cast<f16x8*>(smem + n * G5_ROW + kg * 16) = pack_f16x8(lo, hi);
+		}
+		__syncthreads();
+	}
+	if (!active) return;
+
+	// B fragment of (chunk c, step m, column block ni): W row 32 ni + li, 8 fp16 at k = 32c + 16fh + 8m
+	const char* const bbase = smem + li * G5_ROW + fh * 32;
+	auto load_b = [&](int c, int m, int ni) -> f16x8 { return *reinterpret_cast<const f16x8*>(bbase + ni * (32 * G5_ROW) + c * 64 + m * 16); };
+
+	for (; u < u1; u += GEMM5_NW) {
+		int nfoot = foot, nv0 = v0;
+		const float4* nxt = (u + GEMM5_NW < u1) ? unit_rows(u + GEMM5_NW, nfoot, nv0) : cur;
+
+		f32x16 acc[8];
+#pragma unroll
+		for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+
+#pragma unroll
+		for (int c = 0; c < 8; ++c) {
+			{  // A prefetch: chunk c+PD of this unit, or chunk c+PD-8 of the wave's next unit
+				const int pc = c + GEMM4_PD;
+				const float4* src = (pc < 8) ? cur + pc * 8 : nxt + (pc - 8) * 8;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) areg[pc & 3][q] = src[q];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int m = 0; m < 2; ++m) {
+				const f16x8 a = pack_f16x8(areg[c & 3][2 * m], areg[c & 3][2 * m + 1]);
+				f16x8 bf[8];
+#pragma unroll
+				for (int ni = 0; ni < 8; ++ni) bf[ni] = load_b(c, m, ni);
+#pragma unroll
+				for (int ni = 0; ni < 8; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf[ni], acc[ni], 0, 0, 0);
+			}
+		}
+
+		// ---- epilogue (as gemm4): element (r, lane) of block ni = row (r&3) + 8(r>>2) + 4fh, column 32ni + li
+		{
+			const int valid_rows = min(32, V - v0);
+			float* ytile = g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy;
+			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ytile)), 0, valid_rows * ldy * 4, 0x00020000);
+			const int voff = ((4 * fh) * ldy + li) * 4;
+			__amdgpu_buffer_rsrc_t msrc = rsrc;
+			if constexpr (EPI == EPI_MASK) {
+				const float* mtile = g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy;
+				msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(mtile)), 0, valid_rows * ldy * 4, 0x00020000);
+			}
+#pragma unroll
+			for (int ni = 0; ni < 8; ++ni) {
+				float bv = 0.f;
+				if constexpr (EPI == EPI_BIAS_RELU) bv = g.bias[(int64_t)foot * g.bias_foot_stride + ni * 32 + li];
+				float mv[16];
+				if constexpr (EPI == EPI_MASK) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r)
+						mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0));
+				}
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					float val = acc[ni][r];
+					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv, 0.f);
+					if constexpr (EPI == EPI_MASK) val = (mv[r] > 0.f) ? val : 0.f;
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0);
+				}
+			}
+		}
+		cur = nxt; foot = nfoot; v0 = nv0;
+	}
+}
+
+}  // namespace mlp
+}  // namespace find
