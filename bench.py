@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 N_FEET = 16
 N_VERTS = 6890
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable by a streaming kernel)
 # MAC counts per vertex evaluation: reference-equivalent fwd+bwd, and what this build executes when the
 # trunk is shared by the 16 feet of a batch (trunk fwd+bwd once per template vertex instead of once per foot-vertex).
 MAC_FWD_REF = 866304
@@ -416,7 +417,8 @@ def main():
 	ap.add_argument('--no-cpu-baseline', action='store_true')
 	ap.add_argument('--train3d', action='store_true', help='instead of the headline line: the reference training configuration (train_3d.yaml losses + optimiser steps)')
 	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
-	ap.add_argument('--c5', action='store_true', help='BASELINE configs[4] geometry in fp32: the headline workload on the 50 002-vertex dense template (the fp16 variant is not built)')
+	ap.add_argument('--c5', action='store_true', help='BASELINE configs[4] geometry: the headline workload on the 50 002-vertex dense template (fp32 unless --fp16)')
+	ap.add_argument('--fp16', action='store_true', help="opt-in reduced precision (find_amd.functional.set_mlp_precision('fp16')): the 256->256 layers, forward and dX, on the fp16 matrix pipe with fp32 accumulation -- BASELINE configs[4] with --c5; NOT the parity path, never the default line")
 	ap.add_argument('--c4', action='store_true', help='per-rank share of BASELINE configs[3]: 16 feet x 4 views @512^2, silhouette + pixel + Chamfer losses; works under torch.distributed.run')
 	ap.add_argument('--dp-overhead', action='store_true', help='diagnostic: run the headline step on ONE GPU through the data-parallel code path (one-rank RCCL group, gradient bucket + all-reduce) to see what the N>1 bookkeeping costs per step')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
@@ -424,6 +426,9 @@ def main():
 	if args.c5:
 		global N_VERTS
 		N_VERTS = 50002
+	if args.fp16:
+		from find_amd import functional as FF
+		FF.set_mlp_precision('fp16')
 	if args.subpaths:
 		return subpaths(not args.no_cpu_baseline)
 	if args.train3d:
@@ -484,8 +489,8 @@ def main():
 		out = {
 			'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': value, 'unit': 'vertices*views/s',
 			'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
-			'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-			'config': {'workload': f'{"C5 geometry, fp32" if N_VERTS == 50002 else "C2"}: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
+			'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16 operands / f32 accumulation in the 256->256 layers (fwd, dX), f32 elsewhere' if args.fp16 else 'f32', 'data': 'synthetic',
+			'config': {'workload': f'{("C5 geometry, " + ("fp16 MLP" if args.fp16 else "fp32")) if N_VERTS == 50002 else ("C2, fp16 MLP (opt-in mode)" if args.fp16 else "C2")}: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
 					   'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{world}' + (' through the one-rank bucket + RCCL path (diagnostic)' if bucket is not None and world == 1 else ''),
 					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
 					   'step_tflops_executed': fl_exec / (ms_step * 1e-3) / 1e12,
@@ -496,6 +501,14 @@ def main():
 						 'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
 										 'profiles/r01_gemm4_pmc_summary.txt; algorithmic 226.0e6'},
 		}
+		if args.fp16:
+			# gemm5 is bound by its streams: algorithmic bytes = rows x 1 KB read + rows x 1 KB written + the 256-KB weight matrix
+			nbytes = 2.0 * N_FEET * N_VERTS * 1024 + 256 * 1024
+			gbs = nbytes / (kms * 1e-3) / 1e9
+			out['roofline'] = {'bound': 'hbm', 'kernel': f'find::mlp::gemm5_kernel<1> (Linear 256->256 + bias + ReLU over {N_FEET * N_VERTS} rows, fp16 MFMA operands, fp32 tensors in HBM)',
+							   'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'avg_kernel_ms': kms,
+							   'bytes_per_launch': nbytes, 'traffic': None,
+							   'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
 		if world == 1 and not args.no_cpu_baseline:
 			out['cpu_baseline'] = cpu_baseline()
 		print(json.dumps(out), flush=True)

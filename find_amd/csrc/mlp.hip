@@ -1,6 +1,7 @@
 // C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
 #include "mlp_dw2.h"
+#include "mlp_gemm5.h"
 #include "mlp_gemm4.h"
 
 namespace find {
@@ -139,6 +140,7 @@ static int g_num_cus = 0;
 // Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
 // the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
 static int g_bwd_streams = 1;
+static int g_mlp_f16 = 0;        // 1: K = 256 Linear layers (forward and dX) on the fp16 matrix pipe (gemm5_kernel); opt-in
 static int g_lds_exclusive = 1;  // 1: the LDS-DMA ring kernels reserve the whole LDS of their CU (see CU_LDS_BYTES)
 constexpr int N_SIDE = 3;
 struct SideStream {
@@ -221,14 +223,14 @@ static void launch_gemm4_t(Gemm2Args a, int64_t feet, hipStream_t s) {
 	static bool attr_set = false;
 	constexpr int lds = NI * 32 * 1024;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, NI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, NI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
 		attr_set = true;
 	}
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	constexpr int G = 8 * (8 / NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
 	const int grid = std::max(G, (num_cus() / G) * G);
-	hipLaunchKernelGGL((gemm4_kernel<EPI, NI, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
+	hipLaunchKernelGGL((gemm4_kernel<EPI, NI, NW>), dim3(grid), dim3(NW * 64), g_lds_exclusive ? CU_LDS_BYTES : lds, s, a);
 }
 
 template <int NI, int NW = 8>
@@ -236,6 +238,25 @@ static void launch_gemm4(int epi, const Gemm2Args& a, int64_t feet, hipStream_t 
 	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU, NI, NW>(a, feet, s);
 	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK, NI, NW>(a, feet, s);
 	else launch_gemm4_t<EPI_NONE, NI, NW>(a, feet, s);
+}
+
+template <int EPI>
+static void launch_gemm5_t(Gemm2Args a, int64_t feet, hipStream_t s) {
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm5_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
+		attr_set = true;
+	}
+	a.tiles_per_foot = (int)cdiv(a.V, 32);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	const int grid = (int)std::min<int64_t>(num_cus(), cdiv(a.ntiles, GEMM5_NW));
+	hipLaunchKernelGGL((gemm5_kernel<EPI>), dim3(grid), dim3(GEMM5_NW * 64), g_lds_exclusive ? CU_LDS_BYTES : GEMM5_LDS, s, a);
+}
+
+static void launch_gemm5(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) launch_gemm5_t<EPI_BIAS_RELU>(a, feet, s);
+	else if (epi == EPI_MASK) launch_gemm5_t<EPI_MASK>(a, feet, s);
+	else launch_gemm5_t<EPI_NONE>(a, feet, s);
 }
 
 template <int BM>
@@ -264,6 +285,10 @@ static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hip
 		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = g_ablate; b.dbg = g_dbg;
 		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
 		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
+		if (g_mlp_f16 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8) {  // opt-in fp16 matrix pipe (fp32 accumulation)
+			launch_gemm5(epi, b, feet, s);
+			return;
+		}
 		// K = 256, one segment, enough 32-row units to give every SIMD of the chip work: W-resident kernel
 		if (g_gemm4 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet * 2 >= g_gemm4_min_units) {
 			launch_gemm4<4>(epi, b, feet, s);
@@ -843,6 +868,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "dw2") == 0) {
 		g_dw2 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "mlp_f16") == 0) {
+		g_mlp_f16 = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "lds_exclusive") == 0) {  // 0 reproduces the co-residence fault described at CU_LDS_BYTES (diagnosis only)

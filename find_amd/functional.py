@@ -477,3 +477,24 @@ class _Smooth(torch.autograd.Function):
 def mesh_edge_and_laplacian(verts, topo):
 	"""(mesh_edge_loss(target 0), mesh_laplacian_smoothing('cot')) for a batch sharing one topology."""
 	return _Smooth.apply(verts, topo)
+
+
+_MLP_PRECISION = 'fp32'
+
+
+def set_mlp_precision(precision):
+	"""Arithmetic of the MLP's 256 -> 256 layers (forward and the dX chain of the backward), process-wide.
+	'fp32' (default): exact fp32 MFMA -- the reference's arithmetic (no AMP anywhere in FIND) and the parity path.
+	'fp16': both MFMA operands rounded to fp16, fp32 accumulation and fp32 tensors in memory (BASELINE.json configs[4], "fp16 MLP
+	with MFMA tiles"); layer outputs then differ from fp32 by ~1e-3 relative.  The Fourier layer, the 3-wide output layers, the
+	weight gradients and everything outside the MLP stay fp32.  Returns the previous setting."""
+	global _MLP_PRECISION
+	if precision not in ('fp32', 'fp16'):
+		raise ValueError(f"set_mlp_precision: 'fp32' or 'fp16', got {precision!r}")
+	_lib.check(_lib.lib().find_set_tuning(b'mlp_f16', int(precision == 'fp16')), 'find_set_tuning(mlp_f16)')
+	prev, _MLP_PRECISION = _MLP_PRECISION, precision
+	return prev
+
+
+def get_mlp_precision():
+	return _MLP_PRECISION

@@ -1,0 +1,96 @@
+"""Opt-in fp16 matrix-pipe mode of the MLP's 256 -> 256 layers (BASELINE.json configs[4]: "fp16 MLP with MFMA tiles";
+find_amd.functional.set_mlp_precision, gemm5_kernel).  The reference computes in fp32 only, so this mode has no reference
+counterpart: the kernel is checked exactly against a float64 product of the fp16-ROUNDED operands (what the matrix pipe is
+meant to compute: exact products, fp32 sums), and the whole model against the fp32 path with the tolerance fp16 rounding implies."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def fp16_mode():
+	from find_amd import functional as F
+	prev = F.set_mlp_precision('fp16')
+	try:
+		yield
+	finally:
+		F.set_mlp_precision(prev)
+
+
+@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (1, 70), (3, 1002), (2, 6890), (16, 6890)])
+def test_linear_relu_fp16_operands_exact(fp16_mode, n_feet, n_pts):
+	"""y = relu(x w^T + b) with x, w rounded to fp16 (RNE), exact products, fp32 accumulation: against float64 on the rounded operands
+	the only error left is the fp32 summation (<= 1e-4 at these magnitudes); rows past a foot's last 32-row unit are never written."""
+	from find_amd import _lib
+	L = _lib.lib()
+	gen = torch.Generator().manual_seed(n_feet * 7919 + n_pts)
+	x = torch.randn(n_feet * n_pts, 256, generator=gen)
+	w = torch.randn(256, 256, generator=gen) / 16
+	b = torch.randn(256, generator=gen)
+	xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+	pad = torch.full((n_feet * n_pts + 64, 256), float('nan'), device='cuda')
+	y = pad[:n_feet * n_pts]
+	_lib.check(L.find_linear_relu_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), n_feet, n_pts, _lib.ptr(y),
+									  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'find_linear_relu_fwd')
+	xr = x.half().double().numpy()
+	wr = w.half().double().numpy()
+	want = np.maximum(xr @ wr.T + b.double().numpy(), 0.0)
+	got = y.cpu().numpy()
+	assert np.isfinite(got).all()
+	assert np.abs(got - want).max() < 1e-4
+	assert torch.isnan(pad[n_feet * n_pts:]).all()   # nothing stored past the last row
+	# and it is the fp16 path that ran: the fp32 product differs from it by what rounding the operands costs
+	full = np.maximum(x.double().numpy() @ w.double().numpy().T + b.double().numpy(), 0.0)
+	assert 1e-4 < np.abs(got - full).max() < 5e-2
+
+
+def _run_model(n_feet, n_verts, shared):
+	from find_amd import synthetic
+	dev = torch.device('cuda:0')
+	model = synthetic.make_model(n_verts, train_size=n_feet, val_size=1, device=dev)
+	lat = synthetic.latents(n_feet, seed=3, device=dev)
+	lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+	for p in model.parameters():
+		p.grad = None
+	if shared:
+		res = model.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+		out = torch.cat([res['verts'], res['col']], -1)
+	else:
+		g = torch.Generator().manual_seed(5)
+		pos = (torch.rand(n_feet, n_verts, 3, generator=g) * 0.2 - 0.1).to(dev)
+		res = model(pos, shapevec=lv['shapevec'], texvec=lv['texvec'], posevec=lv['posevec'])
+		out = torch.cat([res['disp'], res['col']], -1)
+	wgt = torch.linspace(0.5, 1.5, out.numel(), device=dev).reshape(out.shape)
+	(out * wgt).sum().backward()
+	torch.cuda.synchronize()
+	grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+	grads.update({'latent.' + k: v.grad.detach().clone() for k, v in lv.items() if v.grad is not None})
+	return out.detach().clone(), grads
+
+
+@pytest.mark.parametrize('n_feet,n_verts,shared', [(3, 1002, True), (2, 1002, False), (16, 6890, True)])
+def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
+	"""Whole model, forward and every gradient, fp16 mode against the fp32 path: 11 layers of operands rounded to 2^-11 relative
+	give outputs within 2e-3 absolute (disp is bounded by 0.1, colours by 1) and gradients within 2e-2 of each tensor's largest entry."""
+	from find_amd import functional as F
+	assert F.get_mlp_precision() == 'fp32'
+	out32, g32 = _run_model(n_feet, n_verts, shared)
+	prev = F.set_mlp_precision('fp16')
+	try:
+		out16, g16 = _run_model(n_feet, n_verts, shared)
+	finally:
+		F.set_mlp_precision(prev)
+	assert torch.isfinite(out16).all()
+	d = (out16 - out32).abs().max().item()
+	assert 0.0 < d < 2e-3, d     # > 0: the fp16 kernels did run
+	assert g16.keys() == g32.keys()
+	for n in g32:
+		scale = max(1e-6, g32[n].abs().max().item())
+		assert (g16[n] - g32[n]).abs().max().item() < 2e-2 * scale, n
+	# back in fp32 mode the result is the fp32 result again, bit for bit
+	out32b, _ = _run_model(n_feet, n_verts, shared)
+	assert torch.equal(out32b, out32)
