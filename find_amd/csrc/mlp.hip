@@ -140,6 +140,7 @@ static int g_num_cus = 0;
 // Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
 // the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
 static int g_bwd_streams = 1;
+// (side streams at the lowest stream priority: no difference, 2.32 ms/step either way -- the backward is work-bound, not ordering-bound)
 static int g_mlp_f16 = 0;        // 1: K = 256 Linear layers (forward and dX) on the fp16 matrix pipe (gemm5_kernel); opt-in
 static int g_lds_exclusive = 1;  // 1: the LDS-DMA ring kernels reserve the whole LDS of their CU (see CU_LDS_BYTES)
 constexpr int N_SIDE = 3;
@@ -750,19 +751,20 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		hipStream_t q0 = q;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
-			// (the per-foot column sums stay on the caller's stream: moved behind the weight gradients they measured 0.08 ms slower)
 			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps);
-			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, s, ps, b.nblk_fs, (int)n_feet, S);
-			// (the bias gradient -- S summed over feet -- rides along with the latent-gradient launch when there is one)
-			if (L > 0) db_late = gb[0];
-			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, s, S, (int)n_feet, gb[0]);
-			FIND_LAUNCH_CHECK("footsum");
 			// the foot-summed first layer is a small launch: its own side stream and slab set, so that it does not queue behind the
-			// large weight-gradient launches on q
+			// large weight-gradient launches on q.  The per-foot column sums go there too: only the latent / bias gradients read them,
+			// and on the caller's stream the small reduce (LDS-using, so it cannot share a CU with the ring kernels any more) waited
+			// for a CU behind a whole round of dw2 workgroups with the dX chain queued behind it (step time unchanged: 2.32 ms).
 			q0 = ss ? ss->qt[side] : s;
 			BwdWs bk = b;
 			bk.pw = b.pw_t[side]; bk.pb = b.pb_t[side];
 			fork_to(q0);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, q0, ps, b.nblk_fs, (int)n_feet, S);
+			// (the bias gradient -- S summed over feet -- rides along with the latent-gradient launch when there is one)
+			if (L > 0) db_late = gb[0];
+			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, q0, S, (int)n_feet, gb[0]);
+			FIND_LAUNCH_CHECK("footsum");
 			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0);
 		} else {
 			fork();
