@@ -2,6 +2,7 @@
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
 #include "mlp_dw2.h"
 #include "mlp_gemm5.h"
+#include "mlp_dw3.h"
 #include "mlp_gemm4.h"
 
 namespace find {
@@ -544,6 +545,34 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
 					   int k_valid, int pe_map, float* db, float* S, hipStream_t s) {
+	if (!pos && g_dw2 && g_mlp_f16) {
+		// opt-in fp16 mode: 64-row chunks, rows past the end of a foot zero-filled by the kernel
+		const int cpf64 = (int)cdiv(V, 64);
+		const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf64, cdiv(num_cus(), feet)));
+		const int cps3 = (int)cdiv(cpf64, want);
+		const int spf3 = (int)cdiv(cpf64, cps3);
+		const int nmain = (int)(feet * spf3);
+		float* pbuf = (db || S) ? b.pb : nullptr;
+		static bool attr3_set = false;
+		if (!attr3_set) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
+			attr3_set = true;
+		}
+		Dw3Args d3;
+		memset(&d3, 0, sizeof(d3));
+		d3.dz = dz; d3.dz_foot_stride = V * W; d3.x = x; d3.x_foot_stride = x_foot_stride;
+		d3.V = (int)V; d3.chunks_per_foot = cpf64; d3.spf = spf3; d3.cps = cps3; d3.pw = b.pw; d3.pb = pbuf;
+		hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : DW3_LDS, s, d3);
+		FIND_LAUNCH_CHECK("dw3_kernel");
+		ReduceWArgs r;
+		memset(&r, 0, sizeof(r));
+		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
+		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf3; r.db = db; r.S = S;
+		r.nwblk = 256 * 256 / 4 / 64;
+		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, s, r);
+		FIND_LAUNCH_CHECK("reduce_w_kernel");
+		return FIND_OK;
+	}
 	if (!pos && g_dw2) {
 		// LDS-DMA kernel: every foot's rows cut into spf2 contiguous runs of 16-row chunks, the <= 15 leftover rows
 		// folded into the foot's last run

@@ -486,8 +486,9 @@ def set_mlp_precision(precision):
 	"""Arithmetic of the MLP's 256 -> 256 layers (forward and the dX chain of the backward), process-wide.
 	'fp32' (default): exact fp32 MFMA -- the reference's arithmetic (no AMP anywhere in FIND) and the parity path.
 	'fp16': both MFMA operands rounded to fp16, fp32 accumulation and fp32 tensors in memory (BASELINE.json configs[4], "fp16 MLP
-	with MFMA tiles"); layer outputs then differ from fp32 by ~1e-3 relative.  The Fourier layer, the 3-wide output layers, the
-	weight gradients and everything outside the MLP stay fp32.  Returns the previous setting."""
+	with MFMA tiles"); layer outputs then differ from fp32 by ~1e-3 relative.  Covers the forward Linear layers, the dX chain and the
+	weight gradients of the 256 -> 256 layers (gemm5_kernel, dw3_kernel); the Fourier layer, the 3-wide output layers, the two-segment
+	trunk-output gradient, bias / latent gradients and everything outside the MLP stay fp32.  Returns the previous setting."""
 	global _MLP_PRECISION
 	if precision not in ('fp32', 'fp16'):
 		raise ValueError(f"set_mlp_precision: 'fp32' or 'fp16', got {precision!r}")

@@ -112,8 +112,8 @@ int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t
  *   "dw2", "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: LDS-DMA kernel on/off, shortest row run per workgroup,
  *                     workgroups of the Fourier layer's launch
  *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on side streams (default)
- *   "mlp_f16"         1 = the K = 256 Linear layers (forward and dX) run on the fp16 matrix pipe: operands rounded to fp16, fp32
- *                     accumulation, fp32 tensors (gemm5_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES change results
+ *   "mlp_f16"         1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to fp16, fp32
+ *                     accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES change results
  *                     (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
  *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS (default); 0 reproduces the co-residence fault
  *                     described in mlp.hip (CU_LDS_BYTES): rare wrong weight-gradient elements -- diagnosis only

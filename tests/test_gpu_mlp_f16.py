@@ -74,8 +74,9 @@ def _run_model(n_feet, n_verts, shared):
 
 @pytest.mark.parametrize('n_feet,n_verts,shared', [(3, 1002, True), (2, 1002, False), (16, 6890, True)])
 def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
-	"""Whole model, forward and every gradient, fp16 mode against the fp32 path: 11 layers of operands rounded to 2^-11 relative
-	give outputs within 2e-3 absolute (disp is bounded by 0.1, colours by 1) and gradients within 2e-2 of each tensor's largest entry."""
+	"""Whole model, forward and every gradient (gemm5 forward / dX, dw3 weight gradients), fp16 mode against the fp32 path: operands
+	rounded to 2^-11 relative through 11 layers give outputs within 1e-4 absolute (observed 5e-6 .. 7e-6 at the seeded initialisation:
+	disp is bounded by 0.1, colours by 1) and gradients within 1e-2 of each tensor's largest entry (observed <= 5e-3, tools/f16_deviation.py)."""
 	from find_amd import functional as F
 	assert F.get_mlp_precision() == 'fp32'
 	out32, g32 = _run_model(n_feet, n_verts, shared)
@@ -86,11 +87,11 @@ def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 		F.set_mlp_precision(prev)
 	assert torch.isfinite(out16).all()
 	d = (out16 - out32).abs().max().item()
-	assert 0.0 < d < 2e-3, d     # > 0: the fp16 kernels did run
+	assert 0.0 < d < 1e-4, d     # > 0: the fp16 kernels did run
 	assert g16.keys() == g32.keys()
 	for n in g32:
 		scale = max(1e-6, g32[n].abs().max().item())
-		assert (g16[n] - g32[n]).abs().max().item() < 2e-2 * scale, n
+		assert (g16[n] - g32[n]).abs().max().item() < 1e-2 * scale, n
 	# back in fp32 mode the result is the fp32 result again, bit for bit
 	out32b, _ = _run_model(n_feet, n_verts, shared)
 	assert torch.equal(out32b, out32)
