@@ -24,6 +24,17 @@ import time
 
 import torch
 
+
+def emit(obj):
+	"""Print the result as the LAST line of stdout: RCCL writes its version banner through C stdio, which is block-buffered on a pipe
+	and would otherwise come out after this line when the process group is destroyed."""
+	import ctypes
+	try:
+		ctypes.CDLL(None).fflush(None)
+	except Exception:
+		pass
+	print(json.dumps(obj), flush=True)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -206,7 +217,7 @@ def train3d(with_cpu, steps, warmup, n_feet=16):
 								  f'texture(1000 samples), backward, Adam/SGD/Adam steps; nothing rendered, views:=1', 'feet_per_gpu': n_feet}}
 	if with_cpu:
 		out['cpu_baseline'] = train3d_cpu(mwl, batch, gv, gf, gc)
-	print(json.dumps(out), flush=True)
+	emit(out)
 
 
 def train3d_cpu(mwl, batch, gv, gf, gc, sample_feet=1):
@@ -347,7 +358,7 @@ def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256, c4=False):
 								  f'optimiser steps', 'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{world}'}}
 	if with_cpu and world == 1 and not c4:
 		out['cpu_baseline'] = c3_cpu(mwl, gv, gf, R, T, size)
-	print(json.dumps(out), flush=True)
+	emit(out)
 	if world > 1:
 		dist.barrier()
 		dist.destroy_process_group()
@@ -406,7 +417,7 @@ def subpaths(with_cpu):
 	if not torch.cuda.is_available():
 		raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
 	for r in bench_paths.run_all(cpu if with_cpu else None):
-		print(json.dumps(r), flush=True)
+		emit(r)
 
 
 def main():
@@ -478,6 +489,12 @@ def main():
 		dist.all_reduce(t, op=dist.ReduceOp.MAX)
 		elapsed = float(t.item())
 
+	if world > 1:
+		# every rank pushes out what C stdio has buffered (RCCL's banner) before rank 0 prints the result line
+		import ctypes
+		ctypes.CDLL(None).fflush(None)
+		sys.stdout.flush()
+		dist.barrier()
 	if rank == 0:
 		ms_step = elapsed / args.steps * 1e3
 		verts_per_step = world * N_FEET * N_VERTS
@@ -511,7 +528,7 @@ def main():
 							   'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
 		if world == 1 and not args.no_cpu_baseline:
 			out['cpu_baseline'] = cpu_baseline()
-		print(json.dumps(out), flush=True)
+		emit(out)
 	if world > 1:
 		dist.barrier()
 	if dist.is_initialized():

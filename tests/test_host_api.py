@@ -226,3 +226,17 @@ def test_sample_latent_vectors_by_label_and_index():
 	assert set(out) == {'shapevec_train', 'posevec_train', 'texvec_train', 'reg_train'}
 	assert torch.equal(out['shapevec_train'][:, 0], torch.tensor([300., 0.]))  # by label
 	assert out['reg_train'].shape == (2, 9)  # by index
+
+
+def test_mlp_precision_switch_round_trip():
+	"""set_mlp_precision only flips a host-side switch of the library (no GPU needed); fp32 is the default."""
+	from find_amd import functional as F
+	assert F.get_mlp_precision() == 'fp32'
+	assert F.set_mlp_precision('fp16') == 'fp32'
+	try:
+		assert F.get_mlp_precision() == 'fp16'
+	finally:
+		assert F.set_mlp_precision('fp32') == 'fp16'
+	with pytest.raises(ValueError):
+		F.set_mlp_precision('bf16')
+	assert F.get_mlp_precision() == 'fp32'
