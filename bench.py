@@ -25,6 +25,14 @@ import time
 import torch
 
 
+def dtype_label():
+	"""Arithmetic type of the path as configured: fp32 unless the opt-in fp16 matrix-pipe mode was switched on."""
+	from find_amd import functional as FF
+	if FF.get_mlp_precision() == 'fp16':
+		return 'f16 operands / f32 accumulation in the 256->256 layers (fwd, dX, dW), f32 tensors and f32 elsewhere'
+	return 'f32'
+
+
 def emit(obj):
 	"""Print the result as the LAST line of stdout: RCCL writes its version banner through C stdio, which is block-buffered on a pipe
 	and would otherwise come out after this line when the process group is destroyed."""
@@ -211,7 +219,7 @@ def train3d(with_cpu, steps, warmup, n_feet=16):
 	torch.cuda.synchronize()
 	ms = (time.perf_counter() - t0) / steps * 1e3
 	out = {'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': n_feet * N_VERTS / (ms * 1e-3), 'unit': 'vertices*views/s', 'n_gpus': 1,
-		   'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+		   'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_label(),
 		   'data': 'synthetic',
 		   'config': {'workload': f'train_3d.yaml: {n_feet} feet x {N_VERTS}-vertex template, GT 10002-vertex scans, losses chamf(5000 samples) + smooth + '
 								  f'texture(1000 samples), backward, Adam/SGD/Adam steps; nothing rendered, views:=1', 'feet_per_gpu': n_feet}}
@@ -352,7 +360,7 @@ def c3(with_cpu, steps, warmup, n_feet=16, n_views=4, size=256, c4=False):
 	n_feet_total = n_feet * world
 	out = {'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': n_feet_total * N_VERTS * n_views / (ms * 1e-3), 'unit': 'vertices*views/s',
 		   'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-		   'dtype': 'f32', 'data': 'synthetic',
+		   'dtype': dtype_label(), 'data': 'synthetic',
 		   'config': {'workload': f'{"C4 rank share" if c4 else "C3"}: {n_feet} feet x {n_views} views @{size}^2 per GPU, {N_VERTS}-vertex template (13776 faces), 10002-vertex GT '
 								  f'scans re-rendered every step, {"silhouette + pixel + Chamfer losses" if c4 else "silhouette loss"}, backward through rasteriser + MLP, '
 								  f'optimiser steps', 'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{world}'}}
@@ -506,7 +514,7 @@ def main():
 		out = {
 			'metric': 'deformed vertices x rendered views / sec (fwd+bwd)', 'value': value, 'unit': 'vertices*views/s',
 			'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
-			'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16 operands / f32 accumulation in the 256->256 layers (fwd, dX), f32 elsewhere' if args.fp16 else 'f32', 'data': 'synthetic',
+			'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_label(), 'data': 'synthetic',
 			'config': {'workload': f'{("C5 geometry, " + ("fp16 MLP" if args.fp16 else "fp32")) if N_VERTS == 50002 else ("C2, fp16 MLP (opt-in mode)" if args.fp16 else "C2")}: {N_FEET} feet x {N_VERTS}-vertex template per GPU, PE+trunk+heads+registration fwd+bwd, views:=1',
 					   'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{world}' + (' through the one-rank bucket + RCCL path (diagnostic)' if bucket is not None and world == 1 else ''),
 					   'flops_executed_per_step': fl_exec, 'flops_reference_equiv_per_step': fl_ref,
