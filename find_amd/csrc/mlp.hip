@@ -186,7 +186,9 @@ static int num_cus() {
 // ~1 % in a handful of dW elements -- 3 % of the backward passes at 4 x 1002 rows, 13 % at 16 x 6890, every pass with the dX GEMMs
 // on gemm3 -- with every vmcnt / barrier of the ring in place, and equally with vmcnt(0) everywhere, a one-stage ring, sleeps
 // between the wait and the read, poisoned inputs (no stale global data) or device-wide syncs around the call.  Alone on the CU's
-// LDS it never happens (tools/check_determinism.py: 0 of 500 passes, 144 KB is not enough, 160 KB is).  The reservation takes
+// LDS it never happens (tools/check_determinism.py: 0 of 500 passes, 144 KB is not enough, 160 KB is), and the register-staged
+// fp16 kernels (gemm5 / dw3: no LDS-DMA, 135 KB, same streams, same co-resident reduce) run 260 passes clean WITHOUT the reservation:
+// what goes wrong is LDS-DMA data next to a foreign LDS allocation, not the stream structure.  The reservation takes
 // nothing these kernels use -- they run one workgroup per CU anyway -- and costs 0.03 ms/step of overlap with the small kernels.
 constexpr int CU_LDS_BYTES = 160 * 1024;
 
