@@ -87,6 +87,10 @@ def lib():
 	if not os.path.exists(LIB_PATH):
 		raise RuntimeError(f'find_amd: HIP library not built: {LIB_PATH} is missing. Run `python -m find_amd.build` '
 						   '(or __graft_entry__.build()). There is no CPU fallback.')
+	# PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  It must be in the process BEFORE this
+	# library is loaded so that both share that one runtime: loaded the other way round, the library binds /opt/rocm's copy, the
+	# process ends up with device pointers of one runtime handed to the other and every launch fails ("no ROCm-capable device").
+	import torch  # noqa: F401
 	L = ctypes.CDLL(LIB_PATH)
 	for name, (res, args) in PROTOTYPES.items():
 		try:
