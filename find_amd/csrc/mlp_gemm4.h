@@ -23,6 +23,9 @@
 // draining the previous unit under the MFMAs (the slices are not absorbed: every non-MFMA instruction of the wave costs
 // matrix-pipe issue time); column quarters (NI = 2) on the large launches at two and at three waves per SIMD (123 / 127 us
 // against 121); delaying the second wave of every SIMD by 8-64 K cycles so that the two waves' epilogues cannot coincide (+1 us).
+// Also dropped: cutting the units of an under-filled last round (C2: 26.9 units per row range = 3.36 rounds of 8 waves) into two
+// 64-column halves so that all 8 waves work for half a unit time -- 121 us against 120: a wave whose SIMD partner has run out of
+// units already gets the whole matrix pipe, so the round is not the loss it looks like on paper.
 // What is left is instruction issue: ~0.6 non-MFMA instructions per MFMA.
 #pragma once
 #include "mlp_gemm3.h"
