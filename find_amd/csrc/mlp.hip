@@ -791,7 +791,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 			BwdWs bk = b;
 			bk.pw = b.pw_t[side]; bk.pb = b.pb_t[side];
 			fork_to(q0);
-			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet), dim3(1024), 0, q0, ps, b.nblk_fs, (int)n_feet, S);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, q0, ps, b.nblk_fs, (int)n_feet, S);
 			// (the bias gradient -- S summed over feet -- rides along with the latent-gradient launch when there is one)
 			if (L > 0) db_late = gb[0];
 			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, q0, S, (int)n_feet, gb[0]);

@@ -485,30 +485,40 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 	if (live) *reinterpret_cast<float4*>(zsum + (int64_t)v * 256 + c0) = zs;
 }
 
-// S[b][n] = sum_blk pS[blk][b][n]: block per foot, 1024 threads = 4 slices of the block range per column.
+// S[b][n] = sum_blk pS[blk][b][n]: grid (feet, 4 column quarters); 1024 threads = 64 columns x 16 slices of the block range
+// (one block per foot left 16 workgroups to read 51 MB at the 50 002-vertex template: 318 us).
 __global__ __launch_bounds__(1024) void footsum_reduce_kernel(const float* __restrict__ pS, int nblk, int n_feet, float* __restrict__ S) {
-	__shared__ float red[4][256];
-	const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
-	const int f = blockIdx.x;
+	__shared__ float red[16][64];
+	const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+	const int f = blockIdx.x, n = blockIdx.y * 64 + c;
 	const float* p = pS + (int64_t)f * 256 + n;
-	// latency-bound (a few hundred strided loads per thread): 16 independent loads in flight per iteration
-	float acc[16];
+	const int64_t stride = (int64_t)n_feet * 256;
+	// latency-bound (strided loads): 8 independent loads in flight per iteration
+	float acc[8];
 #pragma unroll
-	for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+	for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 	int k = q;
-	for (; k + 60 < nblk; k += 64) {
+	for (; k + 112 < nblk; k += 128) {
 #pragma unroll
-		for (int i = 0; i < 16; ++i) acc[i] += p[(int64_t)(k + 4 * i) * n_feet * 256];
+		for (int i = 0; i < 8; ++i) acc[i] += p[(int64_t)(k + 16 * i) * stride];
 	}
-	for (; k < nblk; k += 4) acc[0] += p[(int64_t)k * n_feet * 256];
+	for (; k < nblk; k += 16) acc[0] += p[(int64_t)k * stride];
 #pragma unroll
-	for (int i = 8; i >= 1; i >>= 1)
+	for (int i = 4; i >= 1; i >>= 1)
 #pragma unroll
 		for (int j = 0; j < i; ++j) acc[j] += acc[j + i];
-	const float s0 = acc[0], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-	red[q][n] = (s0 + s1) + (s2 + s3);
+	red[q][c] = acc[0];
 	__syncthreads();
-	if (q == 0) S[(int64_t)f * 256 + n] = (red[0][n] + red[1][n]) + (red[2][n] + red[3][n]);
+	if (q == 0) {
+		float t[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) t[i] = red[i][c];
+#pragma unroll
+		for (int i = 8; i >= 1; i >>= 1)
+#pragma unroll
+			for (int j = 0; j < i; ++j) t[j] += t[j + i];
+		S[(int64_t)f * 256 + n] = t[0];
+	}
 }
 
 // db[n] = sum_b S[b][n]
