@@ -143,11 +143,13 @@ static int g_num_cus = 0;
 static int g_bwd_streams = 1;
 // (side streams at the lowest stream priority: no difference, 2.32 ms/step either way -- the backward is work-bound, not ordering-bound)
 static int g_mlp_f16 = 0;        // 1: K = 256 Linear layers (forward and dX) on the fp16 matrix pipe (gemm5_kernel); opt-in
+static int g_reduce_stream = 1;  // 1: slab reduces of the large head layers on their own stream (two alternating slab sets)
 static int g_lds_exclusive = 1;  // 1: the LDS-DMA ring kernels reserve the whole LDS of their CU (see CU_LDS_BYTES)
 constexpr int N_SIDE = 3;
 struct SideStream {
 	hipStream_t q = nullptr;          // weight gradients of the (large) head layers
 	hipStream_t qt[N_SIDE] = {nullptr, nullptr, nullptr};  // trunk layers, round-robin: small independent kernels that overlap each other
+	hipStream_t qr = nullptr;         // slab reduces of the large head layers (off the dw2 chain of q)
 	hipEvent_t ev[64];
 	int n = 0;      // events created
 	int next = 0;   // round-robin cursor
@@ -163,6 +165,7 @@ static SideStream* side_stream() {
 		ss->qt[0] = ss->q;
 		for (int i = 1; i < N_SIDE; ++i)
 			if (hipStreamCreateWithFlags(&ss->qt[i], hipStreamNonBlocking) != hipSuccess) { ss->qt[i] = ss->q; }
+		if (hipStreamCreateWithFlags(&ss->qr, hipStreamNonBlocking) != hipSuccess) ss->qr = ss->q;
 		for (ss->n = 0; ss->n < 64; ++ss->n)
 			if (hipEventCreateWithFlags(&ss->ev[ss->n], hipEventDisableTiming) != hipSuccess) break;
 		if (ss->n < 64) return nullptr;
@@ -485,8 +488,8 @@ struct BwdWs {
 	float* dzT[FIND_MAX_LAYERS];  // one per trunk layer: the dX chain never waits for the side stream's readers
 	float* pw;    // dW partial slabs
 	float* pb;    // bias partial slabs
-	float* pw_t[3];  // slab sets of the trunk's side streams ([0] aliases pw / pb)
-	float* pb_t[3];
+	float* pw_t[4];  // slab sets: [0] aliases pw / pb (stream q), [1], [2] the trunk's side streams, [3] alternates with [0] on q
+	float* pb_t[4];
 	float* Sd;    // (n_feet,256) per-foot column sums of the disp head's first-layer dZ
 	float* Sc;
 	float* zsD;   // shared template: (V,256) sum over feet of the disp head's first-layer dZ
@@ -520,7 +523,7 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	o->pw = c.take<float>(std::max<int64_t>(ms * W * KP0, ms2 * W * W));
 	o->pb = c.take<float>(std::max<int64_t>(ms, ms2) * W);
 	o->pw_t[0] = o->pw; o->pb_t[0] = o->pb;
-	for (int i = 1; i < 3; ++i) {  // trunk layers have matrix inputs (dw2 slabs) except layer 0, which always uses set 0
+	for (int i = 1; i < 4; ++i) {  // trunk layers have matrix inputs (dw2 slabs) except layer 0, which always uses set 0
 		o->pw_t[i] = c.take<float>(ms2 * W * W);
 		o->pb_t[i] = c.take<float>(ms2 * W);
 	}
@@ -546,7 +549,14 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 // dW / db of one Linear layer from dz (rows (foot,v)) and its input x.
 static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
-					   int k_valid, int pe_map, float* db, float* S, hipStream_t s) {
+					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, hipStream_t sr = nullptr, hipEvent_t ev = nullptr) {
+	// sr / ev: the slab reduce goes to stream sr behind event ev (recorded on s after the partial-tile kernel) instead of s
+	auto reduce_stream = [&]() -> hipStream_t {
+		if (!sr || sr == s || !ev) return s;
+		(void)hipEventRecord(ev, s);
+		(void)hipStreamWaitEvent(sr, ev, 0);
+		return sr;
+	};
 	if (!pos && g_dw2 && g_mlp_f16) {
 		// opt-in fp16 mode: 64-row chunks, rows past the end of a foot zero-filled by the kernel
 		const int cpf64 = (int)cdiv(V, 64);
@@ -571,7 +581,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf3; r.db = db; r.S = S;
 		r.nwblk = 256 * 256 / 4 / 64;
-		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, s, r);
+		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
@@ -603,7 +613,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf2; r.db = db; r.S = S;
 		r.nwblk = 256 * 256 / 4 / 64;
-		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, s, r);
+		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
@@ -628,7 +638,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
 	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
 	r.nwblk = 256 * a.Kp / 4 / 64;
-	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), 0, s, r);
+	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
 	FIND_LAUNCH_CHECK("reduce_w_kernel");
 	return FIND_OK;
 }
@@ -768,11 +778,27 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 
 	// 3. heads, last hidden layer down to the first
+	int big_toggle = 0;
+	hipEvent_t set_free[2] = {nullptr, nullptr};
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
 		for (int l = nl - 1; l >= 1; --l) {  // (one dZ buffer per layer: the dX chain never waits for the weight gradients)
 			fork();
-			int r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
+			// the large layers alternate between two slab sets and hand their slab reduce to stream qr: the reduce (LDS-using, so
+			// it only gets a CU when a ring kernel's workgroup retires) no longer sits between two dw2 launches on q
+			int r;
+			if (ss && g_reduce_stream) {
+				const int si = big_toggle & 1;
+				big_toggle += 1;
+				BwdWs bk = b;
+				bk.pw = b.pw_t[si ? 3 : 0]; bk.pb = b.pb_t[si ? 3 : 0];
+				if (set_free[si]) (void)hipStreamWaitEvent(q, set_free[si], 0);   // the set's previous reduce has read it
+				r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, q, ss->qr, next_event());
+				set_free[si] = next_event();
+				(void)hipEventRecord(set_free[si], ss->qr);
+			} else {
+				r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
+			}
 			if (r != FIND_OK) return r;
 			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s);
 			cur += 1;
@@ -799,6 +825,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0);
 		} else {
 			fork();
+			if (set_free[0]) (void)hipStreamWaitEvent(q, set_free[0], 0);   // set 0 may still be read by a reduce on qr
 			r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, q);
 		}
 		if (r != FIND_OK) return r;
@@ -854,6 +881,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 			ct += 1;
 		}
 		fork();
+		if (set_free[0]) (void)hipStreamWaitEvent(q, set_free[0], 0);
 		rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, q);
 		if (rc != FIND_OK) return rc;
 		// join: the caller's stream continues only after every gradient is written
@@ -862,6 +890,11 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 				if (i > 0 && ss->qt[i] == ss->q) continue;
 				hipEvent_t e = next_event();
 				(void)hipEventRecord(e, ss->qt[i]);
+				(void)hipStreamWaitEvent(s, e, 0);
+			}
+			if (ss->qr != ss->q) {
+				hipEvent_t e = next_event();
+				(void)hipEventRecord(e, ss->qr);
 				(void)hipStreamWaitEvent(s, e, 0);
 			}
 		}
@@ -901,6 +934,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "dw2") == 0) {
 		g_dw2 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "reduce_stream") == 0) {
+		g_reduce_stream = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "mlp_f16") == 0) {
