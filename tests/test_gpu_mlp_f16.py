@@ -51,7 +51,7 @@ def test_linear_relu_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 def _run_model(n_feet, n_verts, shared):
 	from find_amd import synthetic
 	dev = torch.device('cuda:0')
-	model = synthetic.make_model(n_verts, train_size=n_feet, val_size=1, device=dev)
+	model = synthetic.make_model(n_verts if shared else 1002, train_size=n_feet, val_size=1, device=dev)   # (free points need no template of their size)
 	lat = synthetic.latents(n_feet, seed=3, device=dev)
 	lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
 	for p in model.parameters():
@@ -72,7 +72,7 @@ def _run_model(n_feet, n_verts, shared):
 	return out.detach().clone(), grads
 
 
-@pytest.mark.parametrize('n_feet,n_verts,shared', [(3, 1002, True), (2, 1002, False), (16, 6890, True)])
+@pytest.mark.parametrize('n_feet,n_verts,shared', [(3, 1002, True), (2, 1002, False), (2, 70, False), (1, 1, False), (16, 6890, True)])
 def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 	"""Whole model, forward and every gradient (gemm5 forward / dX, dw3 weight gradients), fp16 mode against the fp32 path: operands
 	rounded to 2^-11 relative through 11 layers give outputs within 1e-4 absolute (observed 5e-6 .. 7e-6 at the seeded initialisation:
@@ -87,7 +87,9 @@ def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 		F.set_mlp_precision(prev)
 	assert torch.isfinite(out16).all()
 	d = (out16 - out32).abs().max().item()
-	assert 0.0 < d < 1e-4, d     # > 0: the fp16 kernels did run
+	assert d < 1e-4, d
+	if n_feet * n_verts >= 1000:
+		assert d > 0.0   # the fp16 kernels did run
 	assert g16.keys() == g32.keys()
 	for n in g32:
 		scale = max(1e-6, g32[n].abs().max().item())
