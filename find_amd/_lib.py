@@ -54,6 +54,8 @@ PROTOTYPES = {
 	'find_mlp_bwd_scratch_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I]),
 	'find_mlp_bwd': (c_int, [POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, POINTER(MlpGrads), _P]),
 	'find_linear_relu_fwd': (c_int, [_P, _P, _P, _I, _I, _P, _P]),
+	'find_linear_wgrad_scratch_bytes': (c_int64, [_I]),
+	'find_linear_wgrad': (c_int, [_P, _P, _I, _I, _P, _P, _P, _I, _P]),
 	'find_set_tuning': (c_int, [c_char_p, _I]),
 	'find_latent_gather_fwd': (c_int, [_P, _I, _I, _P, _I, _P, _P]),
 	'find_latent_gather_bwd': (c_int, [_P, _P, _I, _I, _I, _P, _P]),

@@ -656,6 +656,34 @@ static void linear_bwd_dx(const float* dz, const float* wt, const float* mask, f
 }  // namespace mlp
 }  // namespace find
 
+// Slabs of one weight-gradient launch: up to max(512, feet) + feet + 16 partial 256x256 tiles and as many 256-float bias rows.
+static int64_t wgrad_slabs(int64_t n_feet) { return std::max<int64_t>(512, n_feet) + n_feet + 16; }
+
+extern "C" int64_t find_linear_wgrad_scratch_bytes(int64_t n_feet) {
+	if (n_feet < 1) return -1;
+	return wgrad_slabs(n_feet) * ((int64_t)W * W + W) * (int64_t)sizeof(float);
+}
+
+extern "C" int find_linear_wgrad(const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
+								 void* scratch, int64_t scratch_bytes, void* stream) {
+	FIND_REQUIRE(dz && x && dw && scratch, "find_linear_wgrad: NULL argument");
+	FIND_REQUIRE(n_feet >= 1 && n_pts >= 1 && n_feet < (1 << 16), "find_linear_wgrad: bad sizes");
+	FIND_REQUIRE(aligned16(dz) && aligned16(x) && aligned16(scratch), "find_linear_wgrad: dz, x and scratch must be 16-byte aligned");
+	FIND_REQUIRE(g_dw2, "find_linear_wgrad: needs the dw2 / dw3 kernels (tuning dw2 = 1)");
+	if (scratch_bytes < find_linear_wgrad_scratch_bytes(n_feet)) {
+		set_error("find_linear_wgrad: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)find_linear_wgrad_scratch_bytes(n_feet));
+		return FIND_EWORKSPACE;
+	}
+	BwdWs b;
+	memset(&b, 0, sizeof(b));
+	b.pw = static_cast<float*>(scratch);
+	b.pb = b.pw + wgrad_slabs(n_feet) * W * W;
+	const int rc = weight_grad(dz, x, n_pts * W, nullptr, 0, nullptr, 1, n_feet, n_pts, b, dw, W, W, 0, db, nullptr, reinterpret_cast<hipStream_t>(stream));
+	if (rc != FIND_OK) return rc;
+	FIND_LAUNCH_CHECK("find_linear_wgrad");
+	return FIND_OK;
+}
+
 extern "C" int64_t find_mlp_bwd_scratch_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts) {
 	Dims d;
 	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;

@@ -104,6 +104,15 @@ int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, 
  * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
 int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
 
+/* Weight gradient of one 256 -> 256 layer:  dw[n][k] = sum_rows dz[row][n] * x[row][k]  (256 x 256, row-major) and, when db is not
+ * NULL, db[n] = sum_rows dz[row][n], over rows = (foot, point) as above -- what autograd computes for the `weight` / `bias` of an
+ * nn.Linear (src/model/model.py:255-257, 353-356, 362-365) from the layer's input x and the gradient dz of its output.  Exposed, like
+ * find_linear_relu_fwd, so that the kernel (dw2_kernel; dw3_kernel in the fp16 mode) can be timed and checked in isolation;
+ * find_mlp_bwd launches the same kernels.  `scratch` holds the partial tiles (find_linear_wgrad_scratch_bytes). */
+int64_t find_linear_wgrad_scratch_bytes(int64_t n_feet);
+int find_linear_wgrad(const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
+					  void* scratch, int64_t scratch_bytes, void* stream);
+
 /* Tuning / profiling hook (no reference counterpart); process-wide, not thread-safe.  Results do not depend on any knob (except "lds_exclusive" = 0 and the ablation bits).
  *   "gemm"            0 = register-staged tiles, 64 / 128 = persistent LDS-DMA kernel with that tile height (default 64)
  *   "gemm3", "gemm4"  0 / 1: early-barrier LDS-DMA kernel; W-resident kernel for K = 256 layers (defaults 1)

@@ -332,3 +332,37 @@ def test_backward_is_bit_reproducible_with_side_streams():
 				assert not bad, f'gemm4={gemm4}, pass {rep}: gradients of {bad} differ from the first pass'
 		finally:
 			_lib.check(_lib.lib().find_set_tuning(b'gemm4', 1), 'tuning')
+
+
+def _wgrad(n_feet, n_pts, seed, sparse=False):
+	"""Runs find_linear_wgrad on seeded dz, x; returns (dz, x, dw, db) on the host."""
+	import ctypes
+	from find_amd import _lib
+	L = _lib.lib()
+	gen = torch.Generator().manual_seed(seed)
+	rows = n_feet * n_pts
+	dz = torch.randn(rows, 256, generator=gen) * 0.1
+	x = torch.relu(torch.randn(rows, 256, generator=gen))
+	if sparse:
+		dz = dz * (torch.rand(rows, 256, generator=gen) < 0.3)
+	dzd, xd = dz.cuda(), x.cuda()
+	dw = torch.full((256, 256), float('nan'), device='cuda')
+	db = torch.full((256,), float('nan'), device='cuda')
+	nbytes = L.find_linear_wgrad_scratch_bytes(n_feet)
+	scratch = torch.empty(nbytes // 4, dtype=torch.float32, device='cuda')
+	_lib.check(L.find_linear_wgrad(_lib.ptr(dzd), _lib.ptr(xd), n_feet, n_pts, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nbytes,
+								   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'find_linear_wgrad')
+	torch.cuda.synchronize()
+	return dz, x, dw.cpu(), db.cpu()
+
+
+@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (5, 15), (1, 70), (3, 1002), (2, 6890), (16, 6890)])
+def test_linear_wgrad_kernel(n_feet, n_pts):
+	"""find_linear_wgrad (dw2_kernel + the slab reduce: `weight.grad` / `bias.grad` of an nn.Linear, model.py:255-257) against float64
+	at row counts with no full 16-row chunk, with leftover rows, and at the C2 shape."""
+	dz, x, dw, db = _wgrad(n_feet, n_pts, seed=n_feet * 131 + n_pts, sparse=(n_pts == 1002))
+	want = dz.double().t() @ x.double()
+	wantb = dz.double().sum(0)
+	assert torch.isfinite(dw).all() and torch.isfinite(db).all()
+	assert (dw.double() - want).abs().max().item() < TOL * max(1.0, want.abs().max().item())
+	assert (db.double() - wantb).abs().max().item() < TOL * max(1.0, wantb.abs().max().item())

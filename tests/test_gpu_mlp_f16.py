@@ -72,7 +72,7 @@ def _run_model(n_feet, n_verts, shared):
 	return out.detach().clone(), grads
 
 
-@pytest.mark.parametrize('n_feet,n_verts,shared', [(3, 1002, True), (2, 1002, False), (2, 70, False), (1, 1, False), (16, 6890, True)])
+@pytest.mark.parametrize('n_feet,n_verts,shared', [(3, 1002, True), (2, 1002, False), (2, 70, False), (16, 6890, True)])
 def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 	"""Whole model, forward and every gradient (gemm5 forward / dX, dw3 weight gradients), fp16 mode against the fp32 path: operands
 	rounded to 2^-11 relative through 11 layers give outputs within 1e-4 absolute (observed 5e-6 .. 7e-6 at the seeded initialisation:
@@ -91,9 +91,31 @@ def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 	if n_feet * n_verts >= 1000:
 		assert d > 0.0   # the fp16 kernels did run
 	assert g16.keys() == g32.keys()
+	# (a handful of points: one pre-activation whose sign flips under fp16 rounding moves a gradient by a visible fraction -- there the
+	# comparison is a sanity bound; the tile-edge arithmetic of tiny shapes is pinned exactly by test_linear_relu_fp16_operands_exact
+	# and test_linear_wgrad_fp16_operands_exact)
+	rel = 1e-2 if n_feet * n_verts >= 1000 else 2e-1
 	for n in g32:
 		scale = max(1e-6, g32[n].abs().max().item())
-		assert (g16[n] - g32[n]).abs().max().item() < 1e-2 * scale, n
+		assert torch.isfinite(g16[n]).all(), n
+		assert (g16[n] - g32[n]).abs().max().item() < rel * scale, n
 	# back in fp32 mode the result is the fp32 result again, bit for bit
 	out32b, _ = _run_model(n_feet, n_verts, shared)
 	assert torch.equal(out32b, out32)
+
+
+@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (5, 15), (1, 70), (3, 1002), (2, 6890), (16, 6890)])
+def test_linear_wgrad_fp16_operands_exact(fp16_mode, n_feet, n_pts):
+	"""dw3_kernel: dW = dz^T x with both operands rounded to fp16, exact products, fp32 sums -- against float64 on the rounded
+	operands; the bias gradient is summed from the un-rounded dz.  Covers feet shorter than one 64-row chunk and zero-filled tails."""
+	from test_gpu_mlp import _wgrad
+	dz, x, dw, db = _wgrad(n_feet, n_pts, seed=n_feet * 131 + n_pts)
+	want = dz.half().double().t() @ x.half().double()
+	wantb = dz.double().sum(0)
+	assert torch.isfinite(dw).all() and torch.isfinite(db).all()
+	scale = max(1.0, want.abs().max().item())
+	assert (dw.double() - want).abs().max().item() < 1e-5 * scale
+	assert (db.double() - wantb).abs().max().item() < 1e-4 * max(1.0, wantb.abs().max().item())
+	full = dz.double().t() @ x.double()
+	if n_feet * n_pts >= 64:
+		assert (dw.double() - full).abs().max().item() > 1e-6 * scale   # it is the fp16 path that ran
