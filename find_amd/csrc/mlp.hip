@@ -73,6 +73,7 @@ struct FwdWs {
 	float* zd;    // (rows_h,3)
 	float* zc;
 	float* hp;    // shared template: (V,256) product of the trunk output with a head's first-layer weight (no bias), reused per head
+	float* hp2;
 	int64_t bytes;
 };
 
@@ -86,6 +87,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 	o->zd = c.take<float>(d.rows_h * 3);
 	o->zc = c.take<float>(d.rows_h * 3);
 	o->hp = (d.shared && d.n_feet > 1) ? c.take<float>(d.V * W) : nullptr;
+	o->hp2 = (d.shared && d.n_feet > 1) ? c.take<float>(d.V * W) : nullptr;   // the colour head's copy: the heads run on two streams
 	float* pt[2] = {nullptr, nullptr};
 	float* pd[2] = {nullptr, nullptr};
 	float* pc[2] = {nullptr, nullptr};
@@ -143,6 +145,7 @@ static int g_num_cus = 0;
 static int g_bwd_streams = 1;
 // (side streams at the lowest stream priority: no difference, 2.32 ms/step either way -- the backward is work-bound, not ordering-bound)
 static int g_mlp_f16 = 0;        // 1: K = 256 Linear layers (forward and dX) on the fp16 matrix pipe (gemm5_kernel); opt-in
+static int g_fwd_streams = 1;     // 1: forward runs the colour head on a side stream beside the displacement head
 static int g_reduce_stream = 1;  // 1: slab reduces of the large head layers on their own stream (two alternating slab sets)
 static int g_lds_exclusive = 1;  // 1: the LDS-DMA ring kernels reserve the whole LDS of their CU (see CU_LDS_BYTES)
 constexpr int N_SIDE = 3;
@@ -425,31 +428,21 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	// first layer of a head.  Shared template: every foot multiplies the SAME trunk rows, so  H W^T  is formed once on V rows
 	// and each foot only adds its (latent-folded) bias and applies the ReLU -- a bandwidth-bound broadcast instead of a GEMM
 	// over n_feet * V rows.  (The backward has always used the same fact: footsum_kernel.)
-	auto head_first = [&](const float* w0, const float* bias, int64_t bstride, float* out) {
-		if (w.hp) {
+	auto head_first = [&](const float* w0, const float* bias, int64_t bstride, float* out, float* hp, hipStream_t st) {
+		if (hp) {
 			GemmArgs a = gemm_args_zero();
 			a.a0 = hl; a.a_foot_stride = 0; a.lda = W;
 			a.w0 = w0; a.ldw = W; a.nchunk = W / KC;
-			a.y = w.hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-			launch_gemm(AMODE_MAT, EPI_NONE, a, 1, s);
-			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, s, w.hp, bias,
+			a.y = hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+			launch_gemm(AMODE_MAT, EPI_NONE, a, 1, st);
+			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, st, hp, bias,
 							   bstride, (int)n_feet, V, out);
 		} else {
-			linear_fwd(hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, s);
+			linear_fwd(hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, st);
 		}
 	};
-	if (disp) {
-		head_first(w.wd0, bias_d0, bstride_d, w.D[0]);
-		for (int i = 1; i < p->n_disp; ++i) linear_fwd(w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s);
-	}
-	if (col) {
-		head_first(w.wc0, bias_c0, bstride_c, w.C[0]);
-		for (int i = 1; i < p->n_col; ++i) linear_fwd(w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, s);
-	}
-	FIND_LAUNCH_CHECK("head gemm");
-
-	// 5. final 256->3 layers + tanh scalings (model.py:444-449)
-	{
+	// 5. final 256->3 layers + tanh scalings (model.py:444-449), one launch per head
+	auto head_out = [&](int head, hipStream_t st) {
 		HeadOutArgs h;
 		memset(&h, 0, sizeof(h));
 		h.x[0] = w.D[p->n_disp - 1]; h.x[1] = w.C[p->n_col - 1];
@@ -459,10 +452,36 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 		h.out[0] = disp; h.out[1] = col;
 		h.avg_col = p->avg_col;
 		h.rows = d.rows_h;
+		h.head0 = head;
 		const unsigned gx = (unsigned)std::min<int64_t>(cdiv(d.rows_h, 32), 2048);
-		hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 2), dim3(256), 0, s, h);
-		FIND_LAUNCH_CHECK("head_out_fwd_kernel");
+		hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 1), dim3(256), 0, st, h);
+	};
+	// The heads are independent after the trunk.  With both active, the colour head runs on a side stream: its bandwidth-bound
+	// pieces (the bias + ReLU broadcast, the 3-wide output layer: no LDS, so they can share CUs with the W-resident GEMMs) then
+	// overlap the other head's matrix-pipe-bound layers.  Forked from and joined back into the caller's stream.
+	SideStream* ss = (g_fwd_streams && disp && col) ? side_stream() : nullptr;
+	hipStream_t sc = ss ? ss->qt[1] : s;
+	if (ss) {
+		hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63;
+		(void)hipEventRecord(e, s);
+		(void)hipStreamWaitEvent(sc, e, 0);
 	}
+	if (disp) {
+		head_first(w.wd0, bias_d0, bstride_d, w.D[0], w.hp, s);
+		for (int i = 1; i < p->n_disp; ++i) linear_fwd(w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s);
+		head_out(0, s);
+	}
+	if (col) {
+		head_first(w.wc0, bias_c0, bstride_c, w.C[0], ss ? w.hp2 : w.hp, sc);
+		for (int i = 1; i < p->n_col; ++i) linear_fwd(w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc);
+		head_out(1, sc);
+	}
+	if (ss) {
+		hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63;
+		(void)hipEventRecord(e, sc);
+		(void)hipStreamWaitEvent(s, e, 0);
+	}
+	FIND_LAUNCH_CHECK("head layers");
 	return FIND_OK;
 }
 
@@ -962,6 +981,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "dw2") == 0) {
 		g_dw2 = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "fwd_streams") == 0) {
+		g_fwd_streams = value != 0;
 		return FIND_OK;
 	}
 	if (strcmp(key, "reduce_stream") == 0) {

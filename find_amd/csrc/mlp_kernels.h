@@ -666,11 +666,12 @@ struct HeadOutArgs {
 	float* out[2];        // (rows, 3)
 	const float* avg_col; // or null
 	int64_t rows;
+	int head0;            // head of blockIdx.y == 0 (the two heads can be launched separately, grid.y = 1)
 };
 
 // 16 lanes per row (4 rows per wave, 2 row groups in flight): lane part p holds columns 4p + 64i, i = 0..3.
 __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) {
-	const int head = blockIdx.y;
+	const int head = blockIdx.y + g.head0;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const float* x = head ? g.x[1] : g.x[0];
 	const float* w = head ? g.w[1] : g.w[0];

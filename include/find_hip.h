@@ -121,6 +121,8 @@ int find_linear_wgrad(const float* dz, const float* x, int64_t n_feet, int64_t n
  *   "dw2", "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: LDS-DMA kernel on/off, shortest row run per workgroup,
  *                     workgroups of the Fourier layer's launch
  *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on side streams (default)
+ *   "fwd_streams"     1 = the forward runs the colour head on a side stream beside the displacement head (default), 0 = one stream
+ *   "reduce_stream"   1 = slab reduces of the large head layers on their own stream, two alternating slab sets (default)
  *   "mlp_f16"         1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to fp16, fp32
  *                     accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES change results
  *                     (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
