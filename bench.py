@@ -59,8 +59,10 @@ MAC_HEADS_FWD = (456 + 356) * 256 + 4 * 256 * 256 + 2 * 3 * 256
 
 
 # HBM-side traffic of one launch of the dominant kernel, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes (tools/profile_round.sh; profiles/r01_gemm4_pmc_summary.txt): 2 x 71.04 MB fetched + 112.9 MB written.
-GEMM_TRAFFIC_BYTES = 255.0e6
+# passes (tools/pmc_traffic.sh; profiles/r01_traffic_pmc_summary.txt): 2 x 62.02 MB fetched + 112.9 MB written (fp32 gemm4),
+# 2 x 57.10 MB + 112.9 MB (fp16-mode gemm5).
+GEMM_TRAFFIC_BYTES = 236.9e6
+GEMM5_TRAFFIC_BYTES = 227.1e6
 
 
 def executed_flops_per_step(n_feet, n_verts):
@@ -524,7 +526,7 @@ def main():
 						 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
 						 'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES if N_VERTS == 6890 else None,
 						 'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
-										 'profiles/r01_gemm4_pmc_summary.txt; algorithmic 226.0e6'},
+										 'profiles/r01_traffic_pmc_summary.txt; algorithmic 226.0e6'},
 		}
 		if args.fp16:
 			# gemm5 is bound by its streams: algorithmic bytes = rows x 1 KB read + rows x 1 KB written + the 256-KB weight matrix
@@ -532,7 +534,7 @@ def main():
 			gbs = nbytes / (kms * 1e-3) / 1e9
 			out['roofline'] = {'bound': 'hbm', 'kernel': f'find::mlp::gemm5_kernel<1> (Linear 256->256 + bias + ReLU over {N_FEET * N_VERTS} rows, fp16 MFMA operands, fp32 tensors in HBM)',
 							   'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'avg_kernel_ms': kms,
-							   'bytes_per_launch': nbytes, 'traffic': None,
+							   'bytes_per_launch': nbytes, 'traffic': GEMM5_TRAFFIC_BYTES if N_VERTS == 6890 else None,
 							   'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
 		if world == 1 and not args.no_cpu_baseline:
 			out['cpu_baseline'] = cpu_baseline()

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 
 	for (; u < u1; u += NW) {
 		int nfoot = foot, nv0 = v0;
-		const float4* nxt = (u + NW < u1) ? unit_rows(u + NW, nfoot, nv0) : cur;
+		const float4* nxt = (u + NW < u1) ? unit_rows(u + NW, nfoot, nv0) : cur + (8 - GEMM4_PD) * 8;  // (no next unit: re-read lines just fetched, not chunks 0..2 from HBM)
 
 		float bv[NI];
 		if constexpr (EPI == EPI_BIAS_RELU) {

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g)
 
 	for (; u < u1; u += GEMM5_NW) {
 		int nfoot = foot, nv0 = v0;
-		const float4* nxt = (u + GEMM5_NW < u1) ? unit_rows(u + GEMM5_NW, nfoot, nv0) : cur;
+		// (no next unit: the run-ahead loads re-read chunks 5..7 of this unit -- lines the wave has just fetched, served by L2 -- instead
+		// of pulling chunks 0..2 in from HBM a second time: 24 MB per launch at the C2 shape, profiles/r01_traffic_pmc_summary.txt)
+		const float4* nxt = (u + GEMM5_NW < u1) ? unit_rows(u + GEMM5_NW, nfoot, nv0) : cur + (8 - GEMM4_PD) * 8;
 
 		f32x16 acc[8];
 #pragma unroll
