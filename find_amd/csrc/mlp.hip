@@ -137,7 +137,7 @@ static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier
 static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
 static int g_gemm4_small = 64;   // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
 static int g_dw_pe_target = 256;  // workgroups of the Fourier layer's weight-gradient launch (one round over the chip)
-static int g_dw2_min_cps = 4;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic)
+static int g_dw2_min_cps = 8;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic; 4: 2.257, 8: 2.243, 12: 2.266 ms/step)
 static int g_num_cus = 0;
 
 // Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
