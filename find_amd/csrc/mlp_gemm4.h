@@ -123,6 +123,9 @@ __global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
+		// (the wave in its MFMA loop outranks the SIMD's other wave while that one runs its epilogue: 122.7 -> 121.0 us per launch at the C2
+		// shape in isolation, no difference inside the step; ablate bit 16 switches it off)
+		if (!(g.ablate & 16)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
 			// A prefetch: chunk c+PD of this unit, or chunk c+PD-8 of the wave's next unit
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 			}
 		}
 
+		if (!(g.ablate & 16)) __builtin_amdgcn_s_setprio(0);
 		// ---- epilogue: buffer stores; the SRD's size is the number of valid bytes of the unit, so rows past the end of a
 		// foot are dropped by the bounds check.  Element (r, lane) of block ni = row (r&3) + 8(r>>2) + 4fh, column 32ni + li.
 		{
