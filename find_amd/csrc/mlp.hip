@@ -580,7 +580,7 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 		// opt-in fp16 mode: 64-row chunks, rows past the end of a foot zero-filled by the kernel
 		const int cpf64 = (int)cdiv(V, 64);
 		const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf64, cdiv(num_cus(), feet)));
-		const int cps3 = (int)cdiv(cpf64, want);
+		const int cps3 = (int)std::max<int64_t>(cdiv(cpf64, want), std::min<int>(4, cpf64));  // at least 256 rows per slab (the small launches are slab-bound: 1 chunk 1.62, 2: 1.60, 4: 1.58 ms/step)
 		const int spf3 = (int)cdiv(cpf64, cps3);
 		const int nmain = (int)(feet * spf3);
 		float* pbuf = (db || S) ? b.pb : nullptr;
