@@ -144,6 +144,7 @@ static int g_num_cus = 0;
 // the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
 static int g_bwd_streams = 1;
 // (side streams at the lowest stream priority: no difference, 2.32 ms/step either way -- the backward is work-bound, not ordering-bound)
+static int g_gemm5_min_units = 1024;
 static int g_mlp_f16 = 0;        // 1: K = 256 Linear layers (forward and dX) on the fp16 matrix pipe (gemm5_kernel); opt-in
 static int g_fwd_streams = 1;     // 1: forward runs the colour head on a side stream beside the displacement head
 static int g_reduce_stream = 1;  // 1: slab reduces of the large head layers on their own stream (two alternating slab sets)
@@ -295,7 +296,9 @@ static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hip
 		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = g_ablate; b.dbg = g_dbg;
 		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
 		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
-		if (g_mlp_f16 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8) {  // opt-in fp16 matrix pipe (fp32 accumulation)
+		// opt-in fp16 matrix pipe (fp32 accumulation).  Launches of a few hundred 32-row units (the shared trunk's V rows) stay on the fp32
+		// kernels below: gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs (22 us against 13 us for gemm4 on column quarters)
+		if (g_mlp_f16 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet >= g_gemm5_min_units) {
 			launch_gemm5(epi, b, feet, s);
 			return;
 		}
@@ -989,6 +992,10 @@ extern "C" int find_set_tuning(const char* key, int64_t value) {
 	}
 	if (strcmp(key, "reduce_stream") == 0) {
 		g_reduce_stream = value != 0;
+		return FIND_OK;
+	}
+	if (strcmp(key, "gemm5_min_units") == 0) {
+		g_gemm5_min_units = (int)value;
 		return FIND_OK;
 	}
 	if (strcmp(key, "mlp_f16") == 0) {

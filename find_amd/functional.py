@@ -487,7 +487,8 @@ def set_mlp_precision(precision):
 	'fp32' (default): exact fp32 MFMA -- the reference's arithmetic (no AMP anywhere in FIND) and the parity path.
 	'fp16': both MFMA operands rounded to fp16, fp32 accumulation and fp32 tensors in memory (BASELINE.json configs[4], "fp16 MLP
 	with MFMA tiles"); layer outputs then differ from fp32 by ~1e-3 relative.  Covers the forward Linear layers, the dX chain and the
-	weight gradients of the 256 -> 256 layers (gemm5_kernel, dw3_kernel); the Fourier layer, the 3-wide output layers, the two-segment
+	weight gradients of the 256 -> 256 layers (gemm5_kernel, dw3_kernel) where a launch has at least 1024 32-row units -- smaller
+	launches, e.g. the shared trunk's template rows, are faster on the fp32 kernels and stay there; the Fourier layer, the 3-wide output layers, the two-segment
 	trunk-output gradient, bias / latent gradients and everything outside the MLP stay fp32.  Operands are rounded, not scaled:
 	activations or gradients beyond fp16's range (|x| > 65504) become inf and magnitudes under 6e-8 vanish -- FIND's activations are
 	O(1) and its dZ O(1e-6 .. 1e-1), but a loss scaled far outside that is the caller's responsibility.  Returns the previous setting."""

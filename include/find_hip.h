@@ -126,6 +126,7 @@ int find_linear_wgrad(const float* dz, const float* x, int64_t n_feet, int64_t n
  *   "mlp_f16"         1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to fp16, fp32
  *                     accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES change results
  *                     (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
+ *   "gemm5_min_units" in fp16 mode, launches of fewer 32-row units than this stay on the fp32 kernels (default 1024)
  *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS (default); 0 reproduces the co-residence fault
  *                     described in mlp.hip (CU_LDS_BYTES): rare wrong weight-gradient elements -- diagnosis only
  *   "raster_ablate"   profiling bits of the rasteriser (1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 K-pass

@@ -13,11 +13,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def fp16_mode():
-	from find_amd import functional as F
+	"""fp16 mode with gemm5 forced for every row count (by default launches of fewer than 1024 32-row units stay on the fp32 kernels,
+	which are faster there): the isolated-kernel tests below pin gemm5's tile-edge arithmetic at tiny shapes too."""
+	from find_amd import _lib, functional as F
 	prev = F.set_mlp_precision('fp16')
+	_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1), 'tuning')
 	try:
 		yield
 	finally:
+		_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1024), 'tuning')
 		F.set_mlp_precision(prev)
 
 
@@ -80,10 +84,13 @@ def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 	from find_amd import functional as F
 	assert F.get_mlp_precision() == 'fp32'
 	out32, g32 = _run_model(n_feet, n_verts, shared)
+	from find_amd import _lib
 	prev = F.set_mlp_precision('fp16')
+	_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1), 'tuning')   # every launch on the fp16 kernels, whatever its size
 	try:
 		out16, g16 = _run_model(n_feet, n_verts, shared)
 	finally:
+		_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1024), 'tuning')
 		F.set_mlp_precision(prev)
 	assert torch.isfinite(out16).all()
 	d = (out16 - out32).abs().max().item()
