@@ -452,6 +452,9 @@ __global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) {
 constexpr int FS_ROWS = 16;  // rows of v per block
 constexpr int FS_FEET = 16;  // feet per round: that many independent 16-byte loads in flight per thread
 // grid (ceil(V/16), 4): block = 16 rows x 64 columns; thread (row r = tid>>4, column group cg = tid&15) walks the feet.
+// (An LDS-free variant -- one wave per 16 columns, the 16 rows summed by shuffles, so that it could share CUs with the ring kernels
+// that claim the whole LDS -- made the step slower, 2.30 against 2.26 ms: 64-byte row segments and the interference cost more than
+// the wait for a CU.)
 __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ dz, int n_feet, int V, float* __restrict__ zsum,
 													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */) {
 	__shared__ __attribute__((aligned(16))) float red[4][FS_FEET][64];
