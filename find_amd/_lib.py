@@ -62,6 +62,7 @@ PROTOTYPES = {
 	'find_uv_sample': (c_int, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _P, _P]),
 	'find_render_frags': (c_int, [POINTER(RenderParams), _I, _I, _I, _I, _P, _P, _P, _P]),
 	'find_adam_step': (c_int, [_I, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, _I, _P]),
+	'find_adam_step_dev': (c_int, [_I, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
 	'find_sgd_step': (c_int, [_I, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, c_int, _P]),
 	'find_register_fwd': (c_int, [_P, _I, _P, _P, _I, _I, _P, _P]),
 	'find_register_bwd_ws_bytes': (c_int64, [_I, _I]),

@@ -33,8 +33,16 @@ __device__ __forceinline__ int find_tensor(const Pack& k, int blk, int* first_bl
 	return t;
 }
 
+// step_dev == NULL: step_size = lr / bias_correction1 and bias_c2_sqrt come from the host (torch's default path, Python-float
+// arithmetic).  step_dev != NULL ("capturable", for HIP-graph replay): the fp32 step count lives on the device, `lr` carries the
+// learning rate and both corrections are formed here in fp32, as torch.optim.Adam(capturable=True) does with its device step tensor.
 __global__ __launch_bounds__(256) void adam_kernel(const Pack k, float step_size, float beta1, float beta2, float eps, float weight_decay,
-												   float unused, float bias_c2_sqrt) {
+												   float lr, float bias_c2_sqrt, const float* __restrict__ step_dev) {
+	if (step_dev) {
+		const float st = *step_dev;
+		step_size = lr / (1.0f - powf(beta1, st));
+		bias_c2_sqrt = sqrtf(1.0f - powf(beta2, st));
+	}
 	int first;
 	const int t = find_tensor(k, blockIdx.x, &first);
 	const int64_t base = (int64_t)(blockIdx.x - first) * CHUNK;
@@ -43,7 +51,6 @@ __global__ __launch_bounds__(256) void adam_kernel(const Pack k, float step_size
 	float* m = k.a[t];
 	float* v = k.b[t];
 	const int64_t n = k.numel[t];
-	(void)unused;
 #pragma unroll
 	for (int u = 0; u < CHUNK / 256; ++u) {
 		const int64_t i = base + u * 256 + threadIdx.x;
@@ -86,7 +93,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(const Pack k, float lr, float 
 }
 
 static int pack_and_launch(bool adam, int64_t n, float* const* param, const float* const* grad, float* const* a, float* const* b,
-						   const int64_t* numel, hipStream_t s, float f0, float f1, float f2, float f3, float f4, float f5, float f6, int i0, int i1) {
+						   const int64_t* numel, hipStream_t s, float f0, float f1, float f2, float f3, float f4, float f5, float f6, int i0, int i1,
+						   const float* step_dev = nullptr) {
 	for (int64_t t0 = 0; t0 < n; t0 += MAXT) {
 		Pack k;
 		memset(&k, 0, sizeof(k));
@@ -102,7 +110,7 @@ static int pack_and_launch(bool adam, int64_t n, float* const* param, const floa
 			k.blk_end[t] = blocks;
 		}
 		if (blocks == 0) continue;
-		if (adam) hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k, f0, f1, f2, f3, f4, f5, f6);
+		if (adam) hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k, f0, f1, f2, f3, f4, f5, f6, step_dev);
 		else hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k, f0, f1, f2, f3, i0, i1);
 		FIND_LAUNCH_CHECK(adam ? "adam_kernel" : "sgd_kernel");
 	}
@@ -124,6 +132,15 @@ extern "C" int find_adam_step(int64_t n_tensors, float* const* param, const floa
 	const double bc2 = 1.0 - pow((double)beta2, (double)step);
 	return optim::pack_and_launch(true, n_tensors, param, grad, exp_avg, exp_avg_sq, numel, reinterpret_cast<hipStream_t>(stream), (float)((double)lr / bc1), beta1,
 								  beta2, eps, weight_decay, 0.f, (float)sqrt(bc2), 0, 0);
+}
+
+extern "C" int find_adam_step_dev(int64_t n_tensors, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+								  const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, const float* step_dev, void* stream) {
+	FIND_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || (param && grad && exp_avg && exp_avg_sq && numel)), "find_adam_step_dev: NULL argument");
+	FIND_REQUIRE(step_dev != nullptr, "find_adam_step_dev: step_dev is NULL");
+	FIND_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "find_adam_step_dev: bad hyper-parameters");
+	return optim::pack_and_launch(true, n_tensors, param, grad, exp_avg, exp_avg_sq, numel, reinterpret_cast<hipStream_t>(stream), 0.f, beta1,
+								  beta2, eps, weight_decay, lr, 0.f, 0, 0, step_dev);
 }
 
 extern "C" int find_sgd_step(int64_t n_tensors, float* const* param, const float* const* grad, float* const* momentum_buf, const int64_t* numel,

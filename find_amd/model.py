@@ -79,6 +79,7 @@ class LatentVector(nn.Module):
 			init[:] = torch.from_numpy(init_values).unsqueeze(0).float()
 		self.data = nn.Parameter(init.to(device))
 		self.name = name
+		self._label_cache = {}
 
 	def __len__(self):
 		return self.dataset_size
@@ -87,11 +88,28 @@ class LatentVector(nn.Module):
 		assert self.labels is not None, f'Tried to access item {label} from LatentVector {self.name}, LV does not have labels'
 		return self.labels.index(label)
 
-	def __getitem__(self, idx):
-		if isinstance(idx, torch.Tensor) and idx.dim() == 1 and idx.dtype in (torch.int64, torch.int32) and self.data.is_cuda \
-				and self.data.dtype == torch.float32:
-			# same rows as self.data[idx]; the backward is a deterministic scatter kernel instead of a sort-based index_put
+	def _rows(self, idx):
+		"""self.data[idx] for an integer index tensor; on the GPU through the gather kernel (deterministic scatter backward)."""
+		if self.data.is_cuda and self.data.dtype == torch.float32 and idx.dim() == 1:
 			return FN.latent_gather(self.data, idx.to(device=self.data.device, dtype=torch.int64))
+		return self.data[idx]
+
+	def _label_rows(self, labels):
+		"""Rows for a list of label strings.  The label -> row search is the reference's host-side list.index; the resulting index
+		tensor is kept per label tuple, so a batch seen before costs no host-to-device copy (a DataLoader revisits the same scans
+		every epoch)."""
+		key = tuple(labels)
+		idx = self._label_cache.get(key)
+		if idx is None or idx.device != self.data.device:
+			if len(self._label_cache) > 4096:
+				self._label_cache.clear()
+			idx = torch.tensor([self._index_of(o) for o in labels], dtype=torch.int64, device=self.data.device)
+			self._label_cache[key] = idx
+		return self._rows(idx)
+
+	def __getitem__(self, idx):
+		if isinstance(idx, torch.Tensor) and idx.dim() == 1 and idx.dtype in (torch.int64, torch.int32):
+			return self._rows(idx)
 		if isinstance(idx, (int, torch.Tensor)):
 			return self.data[idx]
 		if isinstance(idx, str):
@@ -100,7 +118,7 @@ class LatentVector(nn.Module):
 			if isinstance(idx[0], int):
 				return self.data[idx]
 			if isinstance(idx[0], str):
-				return self.data[[self._index_of(o) for o in idx]]
+				return self._label_rows(idx)
 			return None  # the reference falls through here as well (model.py:142-149)
 		raise NotImplementedError(f"Didn't understand indexing of LatentVector {self.name}, type {type(idx)}")
 

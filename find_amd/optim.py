@@ -39,12 +39,14 @@ def _check_tensors(name, tensors):
 class Adam(torch.optim.Optimizer):
 	"""torch.optim.Adam(params, lr, betas, eps, weight_decay) with the update of all tensors fused into one kernel."""
 
-	def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False):
+	def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False, capturable=False):
+		"""capturable=True (torch's keyword): state['step'] lives on the device and the bias corrections are formed there in fp32, so a
+		step can be captured in a HIP graph and replayed (find_amd.graph.GraphedStep); the default keeps torch's host arithmetic."""
 		if amsgrad or maximize:
 			raise NotImplementedError('find_amd.optim.Adam: amsgrad / maximize are not provided (the reference uses neither)')
 		if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or not 0.0 <= weight_decay:
 			raise ValueError('find_amd.optim.Adam: invalid hyper-parameter')
-		super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False))
+		super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False, capturable=bool(capturable)))
 		self._cache = {}
 
 	def load_state_dict(self, state_dict):
@@ -54,14 +56,15 @@ class Adam(torch.optim.Optimizer):
 	def _prepare(self, gi, ps):
 		"""Per-group launch tables, rebuilt only when the set of parameters with a gradient (or the state) changes: the pointer
 		arrays of parameters and moments are stable across steps, only the gradients' addresses move."""
-		key = tuple(id(p) for p in ps)
+		capturable = bool(self.param_groups[gi].get('capturable', False))
+		key = (capturable,) + tuple(id(p) for p in ps)
 		c = self._cache.get(gi)
 		if c is not None and c['key'] == key:
 			return c
 		for p in ps:
 			st = self.state[p]
 			if len(st) == 0:
-				st['step'] = torch.tensor(0.0, dtype=torch.float32)
+				st['step'] = torch.zeros((), dtype=torch.float32, device=p.device) if capturable else torch.tensor(0.0, dtype=torch.float32)
 				st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
 				st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
 		# tensors that have taken the same number of steps go out together (normally: all of them)
@@ -73,8 +76,17 @@ class Adam(torch.optim.Optimizer):
 			m = [self.state[p]['exp_avg'] for p in plist]
 			v = [self.state[p]['exp_avg_sq'] for p in plist]
 			_check_tensors('Adam', plist + m + v)
-			c['buckets'].append(dict(step=step, plist=plist, steps=[self.state[p]['step'] for p in plist], parr=_ptr_array(plist), marr=_ptr_array(m),
-									 varr=_ptr_array(v), numel=_i64_array([p.numel() for p in plist])))
+			bk = dict(step=step, plist=plist, steps=[self.state[p]['step'] for p in plist], parr=_ptr_array(plist), marr=_ptr_array(m),
+					  varr=_ptr_array(v), numel=_i64_array([p.numel() for p in plist]))
+			if capturable:
+				# one device counter per bucket; every tensor's state['step'] becomes that same tensor (torch keeps one per parameter
+				# and bumps them with a foreach add: one launch here, and the state_dict layout is unchanged)
+				cnt = torch.full((), float(step), dtype=torch.float32, device=plist[0].device)
+				for p in plist:
+					self.state[p]['step'] = cnt
+				bk['steps'] = [cnt]
+				bk['step_dev'] = cnt
+			c['buckets'].append(bk)
 		self._cache[gi] = c
 		return c
 
@@ -100,6 +112,11 @@ class Adam(torch.optim.Optimizer):
 						grads[i] = gr.contiguous()
 				bk['step'] += 1
 				torch._foreach_add_(bk['steps'], 1)
+				if 'step_dev' in bk:
+					check(L.find_adam_step_dev(len(plist), bk['parr'], _ptr_array(grads), bk['marr'], bk['varr'], bk['numel'], float(group['lr']), float(b1),
+											   float(b2), float(group['eps']), float(group['weight_decay']), ctypes.c_void_p(bk['step_dev'].data_ptr()),
+											   current_stream(plist[0].device)), 'find_adam_step_dev')
+					continue
 				check(L.find_adam_step(len(plist), bk['parr'], _ptr_array(grads), bk['marr'], bk['varr'], bk['numel'], float(group['lr']), float(b1),
 									   float(b2), float(group['eps']), float(group['weight_decay']), bk['step'], current_stream(plist[0].device)), 'find_adam_step')
 		return loss

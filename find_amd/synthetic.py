@@ -100,3 +100,15 @@ def surface_draws(n_meshes, n_samples, n_faces, seed=0, device='cuda', areas=Non
 		face = torch.randint(0, n_faces, (n_meshes, n_samples), generator=g)
 	uv = torch.rand(n_meshes, n_samples, 2, generator=g)
 	return face.to(torch.int32).to(device), uv.to(device)
+
+
+def scan_labels(n_items, scans_per_foot=2):
+	"""Label strings as Foot3DDataset.get_keys / get_all_keys produce them (reference src/data/dataset.py:176-198): every scan is
+	'<foot>-<scan>'; shape / tex codes are shared by the scans of one foot, pose / reg codes are unique per scan.
+	Returns (foot id per item, scan name per item, latent_labels dict for the model incl. two validation scans of one foot)."""
+	feet = [f'{i // scans_per_foot:04d}' for i in range(n_items)]
+	names = [f'{feet[i]}-{chr(65 + i % scans_per_foot)}' for i in range(n_items)]
+	uniq = list(dict.fromkeys(feet))
+	labels = dict(shape=list(uniq), tex=list(uniq), pose=list(names), reg=list(names),
+				  shape_val=['9000'], tex_val=['9000'], pose_val=['9000-A', '9000-B'], reg_val=['9000-A', '9000-B'])
+	return feet, names, labels

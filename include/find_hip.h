@@ -288,6 +288,12 @@ int find_render_frags(const find_render_params* rp, int64_t n_meshes, int64_t n_
  * ---------------------------------------------------------------------------------------------- */
 int find_adam_step(int64_t n_tensors, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
 				   const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+ /* find_adam_step_dev: the same update with the step count on the DEVICE -- `step_dev` points to one fp32 holding the 1-based count
+ * including this update (the caller increments it on `stream` first), and the bias corrections are formed on the device in fp32, as
+ * torch.optim.Adam(capturable=True) does: nothing step-dependent is baked into the launch, so the call can be captured in a HIP graph
+ * and replayed (find_amd/graph.py). */
+int find_adam_step_dev(int64_t n_tensors, float* const* param, const float* const* grad, float* const* exp_avg, float* const* exp_avg_sq,
+					   const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay, const float* step_dev, void* stream);
 int find_sgd_step(int64_t n_tensors, float* const* param, const float* const* grad, float* const* momentum_buf, const int64_t* numel,
 				  float lr, float momentum, float dampening, float weight_decay, int nesterov, int first_step, void* stream);
 

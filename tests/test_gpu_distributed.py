@@ -108,3 +108,99 @@ def test_rccl_one_rank_allreduce_in_place():
 			bucket.close()
 	finally:
 		dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ two ranks, the real model
+def _dp_worker(rank, world, port, n_verts, q):
+	"""One data-parallel rank running the REAL HIP model (both ranks share cuda:0; `gloo` carries the CUDA bucket): 8 of the 16 feet,
+	find_mlp_bwd with its five internal side streams writing straight into the GradBucket arena, one flat all-reduce."""
+	import os
+	os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+	import torch.distributed as dist
+	from find_amd import distributed as fd
+	from find_amd import synthetic
+	torch.cuda.set_device(0)
+	r, w, _ = fd.init_from_env(backend='gloo')
+	dev = torch.device('cuda:0')
+	n_total = 16
+	model = synthetic.make_model(n_verts, train_size=n_total, val_size=2, device=dev)
+	lat = synthetic.latents(n_total, seed=5, device=dev)
+	with torch.no_grad():
+		if rank != 0:   # ranks start apart and must agree after the broadcast
+			for p in model.parameters():
+				if p.requires_grad:
+					p.add_(0.01)
+		else:
+			for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+				getattr(model, k).data.copy_(lat[k])
+	fd.broadcast_parameters([p for p in model.parameters() if p.is_floating_point()])
+	params = [p for p in model.parameters() if p.requires_grad]
+	bucket = fd.GradBucket(params)
+	assert bucket.arena
+	lo, hi = fd.shard_range(n_total, rank, world)
+	idx = torch.arange(lo, hi, device=dev)
+	batch = dict(shapevec_train=model.shapevec[idx], texvec_train=model.texvec[idx], posevec_train=model.posevec[idx], reg_train=model.reg[idx])
+	res = model.get_meshes_from_batch(batch, is_train=True)
+	loss = ((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()) / (hi - lo)   # a batch mean, as every FIND loss
+	loss.backward()
+	in_arena = sum(int(p.grad is not None and p.grad.data_ptr() == v.data_ptr()) for p, v in zip(params, bucket.views))
+	bucket.allreduce_()
+	torch.cuda.synchronize()
+	grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).cpu()
+	q.put((rank, grads.numpy().copy(), in_arena, (lo, hi)))
+	dist.barrier()
+	bucket.close()
+	dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_of_the_find_model_equal_one_process_on_16_feet():
+	"""SURVEY 8e on the FIND model itself: two ranks x 8 feet, gradients averaged through GradBucket (arena mode) == one process x 16
+	feet.  All FIND losses are batch means, so the mean of the two shard means is the global mean."""
+	import torch.multiprocessing as mp
+	from find_amd import synthetic
+	n_verts, world = 6890, 2
+	ctx = mp.get_context('spawn')
+	q = ctx.Queue()
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	procs = [ctx.Process(target=_dp_worker, args=(r, world, port, n_verts, q)) for r in range(world)]
+	for p in procs:
+		p.start()
+	res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+	for p in procs:
+		p.join(timeout=120)
+		assert p.exitcode == 0
+	(_, ga, na, sa), (_, gb, nb, sb) = res
+	assert sa == (0, 8) and sb == (8, 16)
+	ga, gb = torch.from_numpy(ga), torch.from_numpy(gb)
+	assert torch.equal(ga, gb), 'both ranks hold the same averaged gradient'
+	# single process, all 16 feet
+	dev = torch.device('cuda:0')
+	model = synthetic.make_model(n_verts, train_size=16, val_size=2, device=dev)
+	lat = synthetic.latents(16, seed=5, device=dev)
+	with torch.no_grad():
+		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+			getattr(model, k).data.copy_(lat[k])
+	params = [p for p in model.parameters() if p.requires_grad]
+	idx = torch.arange(16, device=dev)
+	batch = dict(shapevec_train=model.shapevec[idx], texvec_train=model.texvec[idx], posevec_train=model.posevec[idx], reg_train=model.reg[idx])
+	out = model.get_meshes_from_batch(batch, is_train=True)
+	(((out['verts'] ** 2).sum() + (out['col'] ** 2).sum()) / 16).backward()
+	# every gradient the HIP backward produces went through the arena on both ranks (MLP weights + the four train tables)
+	n_hip = sum(p.grad is not None for p in params)
+	assert na == n_hip and nb == n_hip, (na, nb, n_hip)
+	o = 0
+	worst = 0.0
+	for p in params:
+		g = ga[o:o + p.numel()].view_as(p)
+		o += p.numel()
+		want = p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu()
+		scale = max(1e-6, want.abs().max().item())
+		err = (g - want).abs().max().item() / scale
+		worst = max(worst, err)
+		# fp32 sums in a different order (two partial batches, then their mean) against one pass over 16 feet
+		assert err < 1e-5, (tuple(p.shape), err)
+	print(f'2-rank DP vs 1 process: worst relative gradient difference {worst:.2e}')

@@ -25,7 +25,7 @@ def fp16_mode():
 		F.set_mlp_precision(prev)
 
 
-@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (1, 70), (3, 1002), (2, 6890), (16, 6890)])
+@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (1, 70), (3, 1002), (2, 6890), (16, 6890), (16, 50002)])
 def test_linear_relu_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 	"""y = relu(x w^T + b) with x, w rounded to fp16 (RNE), exact products, fp32 accumulation: against float64 on the rounded operands
 	the only error left is the fp32 summation (<= 1e-4 at these magnitudes); rows past a foot's last 32-row unit are never written."""
@@ -111,7 +111,7 @@ def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 	assert torch.equal(out32b, out32)
 
 
-@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (5, 15), (1, 70), (3, 1002), (2, 6890), (16, 6890)])
+@pytest.mark.parametrize('n_feet,n_pts', [(1, 1), (5, 15), (1, 70), (3, 1002), (2, 6890), (16, 6890), (16, 50002)])
 def test_linear_wgrad_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 	"""dw3_kernel: dW = dz^T x with both operands rounded to fp16, exact products, fp32 sums -- against float64 on the rounded
 	operands; the bias gradient is summed from the un-rounded dz.  Covers feet shorter than one 64-row chunk and zero-filled tails."""
@@ -121,8 +121,36 @@ def test_linear_wgrad_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 	wantb = dz.double().sum(0)
 	assert torch.isfinite(dw).all() and torch.isfinite(db).all()
 	scale = max(1.0, want.abs().max().item())
-	assert (dw.double() - want).abs().max().item() < 1e-5 * scale
+	# (fp32 sums of up to 800 032 exact products per element: the summation error grows with the row count)
+	assert (dw.double() - want).abs().max().item() < (1e-5 if n_feet * n_pts <= 16 * 6890 else 4e-5) * scale
 	assert (db.double() - wantb).abs().max().item() < 1e-4 * max(1.0, wantb.abs().max().item())
 	full = dz.double().t() @ x.double()
 	if n_feet * n_pts >= 64:
 		assert (dw.double() - full).abs().max().item() > 1e-6 * scale   # it is the fp16 path that ran
+
+
+def test_c5_dense_template_fp16_as_configured():
+	"""BASELINE.json configs[4] as it is specified: the 50 002-vertex dense template evaluated for several feet WITH the fp16 matrix
+	pipe at its default launch thresholds (every launch here has >= 1024 32-row units, so trunk, heads, dX chain and weight gradients
+	all run on gemm5 / dw3), against the fp32 path on the same inputs: outputs within 1e-4 absolute, every gradient within the
+	documented bound (5e-3 of the tensor's largest entry; asserted at 1e-2 like the smaller shapes)."""
+	from find_amd import functional as F
+	assert F.get_mlp_precision() == 'fp32'
+	n_feet, n_verts = 3, 50002
+	out32, g32 = _run_model(n_feet, n_verts, True)
+	prev = F.set_mlp_precision('fp16')
+	try:
+		out16, g16 = _run_model(n_feet, n_verts, True)
+	finally:
+		F.set_mlp_precision(prev)
+	assert out16.shape == (n_feet, n_verts, 6) and torch.isfinite(out16).all()
+	d = (out16 - out32).abs().max().item()
+	assert 0.0 < d < 1e-4, d
+	worst = 0.0
+	for n in g32:
+		scale = max(1e-6, g32[n].abs().max().item())
+		assert torch.isfinite(g16[n]).all(), n
+		e = (g16[n] - g32[n]).abs().max().item() / scale
+		worst = max(worst, e)
+		assert e < 1e-2, (n, e)
+	print(f'C5 fp16 vs fp32: outputs {d:.2e}, worst gradient deviation {worst:.2e} of the tensor maximum')

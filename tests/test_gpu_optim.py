@@ -71,3 +71,33 @@ def test_optimiser_rejects_cpu_parameters():
 	p.grad = torch.ones(4)
 	with pytest.raises(RuntimeError, match='no CPU fallback'):
 		optim.Adam([p]).step()
+
+
+def test_adam_capturable_matches_default_path():
+	"""Adam(capturable=True): step count on the device, bias corrections formed there in fp32 (find_adam_step_dev) -- the same
+	trajectory as the default host-arithmetic path to fp32 rounding, and the same state_dict layout."""
+	from find_amd import optim
+	g = torch.Generator().manual_seed(3)
+	shapes = [(256, 515), (256,), (7, 100), (3, 256)]
+	init = [torch.randn(*s, generator=g) for s in shapes]
+	grads = [[torch.randn(*s, generator=g) * 0.1 for s in shapes] for _ in range(8)]
+	res = []
+	for cap in (False, True):
+		ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+		opt = optim.Adam(ps, lr=5e-4, weight_decay=1e-3, capturable=cap)
+		for gs in grads:
+			for p, gr in zip(ps, gs):
+				p.grad = gr.cuda()
+			opt.step()
+		torch.cuda.synchronize()
+		res.append((ps, opt))
+	(pa, oa), (pb, ob) = res
+	for a, b in zip(pa, pb):
+		assert (a - b).abs().max().item() < 1e-6 * max(1.0, a.abs().max().item())
+	sa, sb = oa.state_dict(), ob.state_dict()
+	assert sa['state'].keys() == sb['state'].keys()
+	for k in sa['state']:
+		assert set(sa['state'][k]) == set(sb['state'][k]) == {'step', 'exp_avg', 'exp_avg_sq'}
+		assert float(sa['state'][k]['step']) == float(sb['state'][k]['step']) == 8.0
+		assert sb['state'][k]['step'].is_cuda and not sa['state'][k]['step'].is_cuda
+		assert torch.allclose(sa['state'][k]['exp_avg_sq'], sb['state'][k]['exp_avg_sq'])

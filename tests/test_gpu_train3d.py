@@ -1,0 +1,234 @@
+"""The reference's own training configuration at its literal batch size: cfgs/train_3d.yaml:17-27 (chamf + smooth + texture losses,
+use_pose_code, use_latent_labels) with batch_size_train = 1 (src/train/opts.py:40) -- one scan per step, latent rows addressed by the
+scan's label strings (LatentVector.__getitem__, src/model/model.py:137-149; trainer.sample_latent_vectors, src/train/trainer.py:29-46),
+full-size template (6890 vertices), GT scan (10 002 vertices) and sample counts (losses.py:27,61).  Checked against the oracle's
+composition of the same step with the sampler's draws replayed; the registration stage (train.py:197-209: chamf only, SGD on the
+registration rows) and the HIP-graph replay of the step (find_amd/graph.py) ride on the same setup."""
+import pytest
+import torch
+
+from oracle import geom_ref, mlp_ref
+
+pytestmark = pytest.mark.gpu
+
+N_ITEMS = 4   # scans 0000-A, 0000-B, 0001-A, 0001-B: two feet, two scans each
+ITEM = 3      # the step under test reads scan 0001-B -> shape/tex row 1, pose/reg row 3
+
+
+def _setup(n_verts=6890, gt_verts=10002, capturable=False, stage='net', seed=0):
+	from find_amd import optim, synthetic
+	from find_amd.model_with_loss import ModelWithLoss
+	from find_amd.opts import Opts
+	from find_amd.structures import Meshes, TexturesVertex
+	net = stage == 'net'
+	opts = Opts(chamf_loss=True, smooth_loss=net, texture_loss=net, use_pose_code=True, use_latent_labels=True)
+	feet, names, labels = synthetic.scan_labels(N_ITEMS)
+	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=N_ITEMS, val_size=2,
+						shapevec_size=100, texvec_size=100, posevec_size=100, template_mesh_loc=None, latent_labels=labels)
+	g = torch.Generator().manual_seed(1234)
+	with torch.no_grad():
+		mwl.model.mlp_disp[-1].weight.copy_(torch.randn(mwl.model.mlp_disp[-1].weight.shape, generator=g) * 0.01)
+		mwl.model.mlp_disp[-1].bias.copy_(torch.randn(3, generator=g) * 0.01)
+	mwl = mwl.to('cuda')
+	m = mwl.model
+	v, f = synthetic.template(n_verts)
+	m.set_template(v.cuda(), f.cuda())
+	# tables: shape / tex have one row per FOOT, pose / reg one per SCAN
+	assert m.shapevec.data.shape == (2, 100) and m.texvec.data.shape == (2, 100) and m.posevec.data.shape == (4, 100) and m.reg.data.shape == (4, 9)
+	lat = synthetic.latents(N_ITEMS, seed=seed, device='cuda')
+	with torch.no_grad():
+		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+			t = getattr(m, k).data
+			t.copy_(lat[k][:t.shape[0]])
+	gv, gf, gc = synthetic.gt_feet(N_ITEMS, gt_verts, seed=seed, device='cuda')
+	gc = gc.clamp(0.05, 0.95)
+	gc[:, :gt_verts // 5] = 1.25   # saturated cap: masked out of the texture loss (losses.py:43); see test_gpu_pipeline._setup
+
+	def batch_of(i):
+		# what BatchCollator.collate_batches (dataset.py:59-67) hands the trainer for a one-scan batch
+		return dict(mesh=Meshes(gv[i:i + 1].contiguous(), gf, TexturesVertex(gc[i:i + 1].contiguous())), idx=torch.tensor([i], device='cuda'),
+					name=[names[i]], shape=[feet[i]], tex=[feet[i]], pose=[names[i]], reg=[names[i]])
+
+	opt = optim.Adam(m.main_params, lr=5e-4, capturable=capturable) if net else optim.SGD(m.reg_params, lr=1e-3, momentum=0.9)
+	return mwl, opts, batch_of, (gv, gf, gc), opt
+
+
+def _oracle_inputs(mwl, rows):
+	m = mwl.model
+	sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
+		  for k, v in m.state_dict().items()}
+	lat = {k: getattr(m, k).data.detach().cpu()[r:r + 1].clone().requires_grad_(True) for k, r in rows.items()}
+	return sd, lat, m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
+
+
+ROWS = dict(shapevec=1, texvec=1, posevec=3, reg=3)
+
+
+def _check_table_grads(m, lat, tol):
+	"""Only the addressed row of each table carries gradient, and it equals the oracle's gradient of that latent."""
+	worst = 0.0
+	for k, r in ROWS.items():
+		g = getattr(m, k).data.grad
+		assert g is not None, k
+		g = g.cpu()
+		want = lat[k].grad[0]
+		s = max(1e-3, want.abs().max().item())
+		err = (g[r] - want).abs().max().item() / s
+		worst = max(worst, err)
+		assert err < tol, (k, err)
+		others = torch.cat([g[:r], g[r + 1:]])
+		assert others.abs().max().item() == 0.0, f'{k}: rows other than {r} must have exactly zero gradient'
+	return worst
+
+
+def test_batch1_label_addressed_step_matches_oracle():
+	from find_amd.train_utils import sample_latent_vectors
+	from test_gpu_pipeline import DrawRecorder
+	mwl, opts, batch_of, (gv, gf, gc), opt = _setup()
+	m = mwl.model
+	batch = batch_of(ITEM)
+	sampled = sample_latent_vectors(batch, m.latent_vectors_train)
+	assert set(sampled) == {'shapevec_train', 'posevec_train', 'texvec_train', 'reg_train'}
+	for k, r in ROWS.items():   # the label lookup picked the rows the reference's list.index picks
+		assert torch.equal(sampled[f'{k}_train'], getattr(m, k).data[r:r + 1]), k
+	batch.update(sampled)
+	opt.zero_grad(set_to_none=True)
+	with DrawRecorder() as rec:
+		loss, losses = mwl(batch, 0, opts, **opts.net_train_kwargs())
+	assert set(losses) == {'loss_chamf', 'loss_smooth', 'loss_tex'}
+	loss.backward()
+	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = rec.draws
+	assert fi_gt.shape == (1, 5000) and fi_tx.shape == (1, 1000)   # losses.py:61 / :27
+	sd, lat, B, tv, tf = _oracle_inputs(mwl, ROWS)
+	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	gvc, gfc, gcc = gv[ITEM:ITEM + 1].cpu(), gf.cpu(), gc[ITEM:ITEM + 1].cpu()
+	gt_s = geom_ref.sample_points(gvc, gfc, fi_gt, uv_gt)
+	pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
+	tx_p, tx_c = geom_ref.sample_points(gvc, gfc, fi_tx, uv_tx, attr=gcc)
+	col = mlp_ref.mlp_forward(sd, B, tx_p, lat['shapevec'], lat['texvec'], lat['posevec'])['col']
+	mask = (tx_c < 1).any(dim=-1, keepdim=True).expand(-1, -1, 3)
+	ref = {'loss_chamf': geom_ref.chamfer_distance(pr_s, gt_s) * 10000., 'loss_smooth': geom_ref.mesh_smoothness(res['verts'], tf) * 1000.,
+		   'loss_tex': (torch.nn.functional.mse_loss(col, tx_c, reduction='none') * mask).mean()}
+	for k in ref:
+		assert abs(losses[k].item() - ref[k].item()) < 1e-4 * max(1.0, abs(ref[k].item())), (k, losses[k].item(), ref[k].item())
+	rl = sum(ref.values())
+	assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
+	rl.backward()
+	worst = _check_table_grads(m, lat, 1e-3)
+	for k in ['base.0.weight', 'base.4.bias', 'mlp_disp.0.weight', 'mlp_disp.2.weight', 'mlp_disp.6.weight', 'mlp_col.0.weight', 'mlp_col.6.bias']:
+		got = dict(m.named_parameters())[k].grad.cpu()
+		want = sd[k].grad
+		s = max(1e-3, want.abs().max().item())
+		err = (got - want).abs().max().item() / s
+		worst = max(worst, err)
+		assert err < 1e-3, (k, err)
+	print(f'batch-1 label step: worst gradient error {worst:.2e} of the tensor maximum')
+	# the optimiser step of the stage: every main parameter moves, the registration rows do not (optim_network only, train.py:161)
+	before = {n: p.detach().clone() for n, p in m.named_parameters()}
+	opt.step()
+	after = dict(m.named_parameters())
+	assert not torch.equal(after['base.2.weight'], before['base.2.weight'])
+	assert not torch.equal(after['shapevec.data'][1], before['shapevec.data'][1])
+	assert torch.equal(after['reg.data'], before['reg.data'])
+
+
+def test_registration_stage_step_matches_oracle():
+	"""Stage 1 (train.py:197-209): model_kwargs = dict(chamf=True, smooth=False, gt_z_cutoff=args.gt_z_cutoff), optimiser = SGD(reg_params,
+	lr_reg, momentum 0.9).  After one step the addressed reg row is reg - lr * grad (the first momentum step is the gradient itself),
+	every other parameter is unchanged."""
+	from find_amd.train_utils import sample_latent_vectors
+	from test_gpu_pipeline import DrawRecorder
+	mwl, opts, batch_of, (gv, gf, gc), opt = _setup(stage='reg', seed=1)
+	m = mwl.model
+	batch = batch_of(ITEM)
+	batch.update(sample_latent_vectors(batch, m.latent_vectors_train))
+	before = {n: p.detach().clone() for n, p in m.named_parameters()}
+	opt.zero_grad(set_to_none=True)
+	with DrawRecorder() as rec:
+		loss, losses = mwl(batch, 0, opts, chamf=True, smooth=False, gt_z_cutoff=opts.gt_z_cutoff)
+	assert set(losses) == {'loss_chamf'}
+	loss.backward()
+	opt.step()
+	(fi_gt, uv_gt), (fi_pr, uv_pr) = rec.draws
+	sd, lat, B, tv, tf = _oracle_inputs(mwl, ROWS)
+	lat['reg'] = before['reg.data'][3:4].cpu().clone().requires_grad_(True)
+	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	gt_s = geom_ref.sample_points(gv[ITEM:ITEM + 1].cpu(), gf.cpu(), fi_gt, uv_gt)
+	pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
+	rl = geom_ref.chamfer_distance(pr_s, gt_s) * 10000.
+	assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
+	rl.backward()
+	want = lat['reg'].detach()[0] - 1e-3 * lat['reg'].grad[0]
+	got = m.reg.data[3].detach().cpu()
+	step = (1e-3 * lat['reg'].grad[0]).abs().max().item()
+	assert step > 0
+	assert (got - want).abs().max().item() < 1e-3 * step + 1e-7, ((got - want).abs().max().item(), step)
+	after = dict(m.named_parameters())
+	for n, p in after.items():
+		if n == 'reg.data':
+			assert torch.equal(p[:3], before[n][:3])
+		elif p.requires_grad:
+			assert torch.equal(p, before[n]), n   # optim_reg only holds reg_params
+
+
+class FixedDraws:
+	"""Replace the sampler's random draws by fixed ones (per call of a step) so that an eager and a graph-replayed step see the
+	same samples; the gather / lerp still runs in the HIP kernel."""
+
+	def __init__(self, draws):
+		import find_amd.losses as L
+		self.L, self.orig, self.draws, self.i = L, L.sample_points_from_meshes, draws, 0
+
+	def __enter__(self):
+		def wrapped(meshes, num_samples=10000, return_textures=False, generator=None, draws=None):
+			d = self.draws[self.i % len(self.draws)]
+			self.i += 1
+			return self.orig(meshes, num_samples, return_textures, draws=d)
+		self.L.sample_points_from_meshes = wrapped
+		return self
+
+	def __exit__(self, *a):
+		self.L.sample_points_from_meshes = self.orig
+
+
+def test_graphed_step_equals_eager_steps():
+	"""find_amd.graph.GraphedStep: the batch-1 step captured as one HIP graph (forward, backward, side-stream fork / joins, fused Adam
+	with its step count on the device) and replayed on changing scans gives the parameters the eager loop gives."""
+	from find_amd.graph import GraphedStep
+	from find_amd.train_utils import sample_latent_vectors
+	n_verts, gt_verts = 1002, 1002
+	g = torch.Generator().manual_seed(9)
+	F_gt, F_t = 2 * (gt_verts - 2), 2 * (n_verts - 2)
+	draws = [(torch.randint(0, F_gt, (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, F_t, (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, F_gt, (1, 1000), generator=g).cuda(), torch.rand(1, 1000, 2, generator=g).cuda())]
+	order = [0, 3, 1, 3, 2, 0]
+	# eager.  (GraphedStep runs `warmup` real steps on the first batch it sees before capturing: the eager loop does the same.)
+	mwl, opts, batch_of, _, opt = _setup(n_verts, gt_verts, capturable=False)
+	with FixedDraws(draws):
+		for i in [order[0]] + order:
+			b = batch_of(i)
+			b.update(sample_latent_vectors(b, mwl.model.latent_vectors_train))
+			opt.zero_grad(set_to_none=True)
+			loss, _ = mwl(b, 0, opts, **opts.net_train_kwargs())
+			loss.backward()
+			opt.step()
+		eager_loss = loss.item()
+	eager = {n: p.detach().clone() for n, p in mwl.model.named_parameters()}
+	mwl2, opts2, batch_of2, _, opt2 = _setup(n_verts, gt_verts, capturable=True)
+	gs = GraphedStep(mwl2, opts2, [opt2], warmup=1, **opts2.net_train_kwargs())
+	with FixedDraws(draws):
+		for i in order:
+			gloss, glosses = gs(batch_of2(i))
+	torch.cuda.synchronize()
+	assert len(gs._graphs) == 1   # one shape signature -> one captured graph, replayed six times
+	assert set(glosses) == {'loss_chamf', 'loss_smooth', 'loss_tex'}
+	assert abs(gloss.item() - eager_loss) < 1e-4 * max(1.0, abs(eager_loss))
+	graph = dict(mwl2.model.named_parameters())
+	assert float(opt2.state[mwl2.model.main_params[0]]['step']) == len(order) + 1
+	for n, p in eager.items():
+		d = (graph[n].detach() - p).abs().max().item()
+		# Adam's update is lr * m / (sqrt(v) + eps): the device-side fp32 bias corrections of the capturable path differ from the
+		# host's double arithmetic by ~1e-7 relative, so after 7 steps of lr 5e-4 the parameters agree to ~1e-7 absolute
+		assert d < 2e-6, (n, d)
+	assert not torch.equal(eager['base.2.weight'], _setup(n_verts, gt_verts)[0].model.base[2].weight.detach())   # the steps did move the weights
