@@ -310,7 +310,7 @@ def time_dominant_kernel(device, iters=100, warm=150):
 	stream = torch.cuda.current_stream(device)
 
 	def launch():
-		_lib.check(L.find_linear_relu_fwd(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), N_FEET, N_VERTS, _lib.ptr(y),
+		_lib.check(L.find_linear_relu_fwd(_lib.ctx(), _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), N_FEET, N_VERTS, _lib.ptr(y),
 										  ctypes.c_void_p(stream.cuda_stream)), 'find_linear_relu_fwd')
 
 	# the GPU idled while the inputs were generated on the host: launch long enough for the clock to come back up before timing

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'lib', 'libfind_hip.so')
 MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -21,6 +21,7 @@ class MlpParams(Structure):
 		('disp_w', c_void_p * MAX_LAYERS), ('disp_b', c_void_p * MAX_LAYERS),
 		('col_w', c_void_p * MAX_LAYERS), ('col_b', c_void_p * MAX_LAYERS),
 		('avg_col', c_void_p),
+		('precision', c_int32),   # 0 = context default, 1 = fp32, 2 = fp16 operands (find_hip.h)
 	]
 
 
@@ -49,14 +50,18 @@ PROTOTYPES = {
 	'find_abi_version': (c_int, []),
 	'find_last_error': (c_char_p, []),
 	'find_build_arch': (c_char_p, []),
+	'find_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+	'find_ctx_destroy': (c_int, [_P]),
+	'find_ctx_set': (c_int, [_P, c_char_p, _I]),
+	'find_ctx_get': (c_int, [_P, c_char_p, POINTER(c_int64)]),
+	'find_debug_raster_ablate': (c_int, [_I]),
 	'find_mlp_ws_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I, c_int]),
-	'find_mlp_fwd': (c_int, [POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, c_int, _P]),
+	'find_mlp_fwd': (c_int, [_P, POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, c_int, _P]),
 	'find_mlp_bwd_scratch_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I]),
-	'find_mlp_bwd': (c_int, [POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, POINTER(MlpGrads), _P]),
-	'find_linear_relu_fwd': (c_int, [_P, _P, _P, _I, _I, _P, _P]),
+	'find_mlp_bwd': (c_int, [_P, POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, POINTER(MlpGrads), _P]),
+	'find_linear_relu_fwd': (c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
 	'find_linear_wgrad_scratch_bytes': (c_int64, [_I]),
-	'find_linear_wgrad': (c_int, [_P, _P, _I, _I, _P, _P, _P, _I, _P]),
-	'find_set_tuning': (c_int, [c_char_p, _I]),
+	'find_linear_wgrad': (c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
 	'find_latent_gather_fwd': (c_int, [_P, _I, _I, _P, _I, _P, _P]),
 	'find_latent_gather_bwd': (c_int, [_P, _P, _I, _I, _I, _P, _P]),
 	'find_uv_sample': (c_int, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _P, _P]),
@@ -106,12 +111,66 @@ def lib():
 	if v != ABI_VERSION:
 		raise RuntimeError(f'find_amd: ABI mismatch: library {v}, binding {ABI_VERSION}; rebuild with python -m find_amd.build')
 	_lib = L
-	# profiling aid: FIND_TUNING="key=value,key=value" applies find_set_tuning knobs at load time (tools/, bench.py experiments)
+	# profiling aid: FIND_TUNING="key=value,key=value" becomes the default of every context created below (tools/, bench.py experiments)
 	for kv in filter(None, os.environ.get('FIND_TUNING', '').split(',')):
 		k, v = kv.split('=')
-		if L.find_set_tuning(k.strip().encode(), int(v)) != 0:
-			raise RuntimeError(f'find_amd: FIND_TUNING: bad knob {kv!r}')
+		_TUNING_DEFAULTS[k.strip()] = int(v)
 	return L
+
+
+# ---------------------------------------------------------------------------------------------- per-device contexts
+_ctx = {}               # device index -> find_ctx* (c_void_p); lives as long as the process
+_TUNING_DEFAULTS = {}   # knob -> value applied to every context when it is created
+
+
+def ctx(device=None):
+	"""The find_ctx of a device (created on first use): internal streams / events of the MLP entry points, launch attributes,
+	knobs.  `device`: torch.device, index or None (= the current device)."""
+	import torch
+	if device is None:
+		idx = torch.cuda.current_device()
+	elif isinstance(device, int):
+		idx = device
+	else:
+		device = torch.device(device)
+		idx = device.index if device.index is not None else torch.cuda.current_device()
+	h = _ctx.get(idx)
+	if h is None:
+		L = lib()
+		h = c_void_p()
+		check(L.find_ctx_create(idx, ctypes.byref(h)), 'find_ctx_create')
+		for k, v in _TUNING_DEFAULTS.items():
+			if k == 'raster_ablate':
+				check(L.find_debug_raster_ablate(v), 'find_debug_raster_ablate')
+			else:
+				check(L.find_ctx_set(h, k.encode(), v), f'find_ctx_set({k})')
+		_ctx[idx] = h
+	return h
+
+
+def set_tuning(key, value, device=None):
+	"""Set a knob (find_hip.h: find_ctx_set) on the context of `device`, or -- device None -- on every existing context and as the
+	default of contexts created later.  Returns nothing; raises on an unknown key."""
+	L = lib()
+	value = int(value)
+	if key == 'raster_ablate':
+		check(L.find_debug_raster_ablate(value), 'find_debug_raster_ablate')
+		return
+	if device is not None:
+		check(L.find_ctx_set(ctx(device), key.encode(), value), f'find_ctx_set({key})')
+		return
+	import torch
+	if not _ctx and torch.cuda.is_available():
+		ctx()
+	for h in _ctx.values():
+		check(L.find_ctx_set(h, key.encode(), value), f'find_ctx_set({key})')
+	_TUNING_DEFAULTS[key] = value
+
+
+def get_tuning(key, device=None):
+	v = c_int64()
+	check(lib().find_ctx_get(ctx(device), key.encode(), ctypes.byref(v)), f'find_ctx_get({key})')
+	return v.value
 
 
 def check(rc, what):

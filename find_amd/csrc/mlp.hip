@@ -106,223 +106,236 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 	o->bytes = c.off;
 }
 
-static int pick_bm(int64_t V, int64_t feet) {
-	if (cdiv(V, 128) * feet >= 512) return 128;
-	if (cdiv(V, 64) * feet >= 512) return 64;
-	return 32;
-}
+}  // namespace mlp
+}  // namespace find
 
-template <int AMODE, int EPI>
-static void launch_gemm_bm(int bm, const GemmArgs& a, int64_t feet, hipStream_t s) {
-	dim3 block(256);
-	if (bm == 128) {
-		dim3 grid((unsigned)cdiv(a.V, 128), (unsigned)feet);
-		hipLaunchKernelGGL((gemm_kernel<128, AMODE, EPI>), grid, block, 0, s, a);
-	} else if (bm == 64) {
-		dim3 grid((unsigned)cdiv(a.V, 64), (unsigned)feet);
-		hipLaunchKernelGGL((gemm_kernel<64, AMODE, EPI>), grid, block, 0, s, a);
-	} else {
-		dim3 grid((unsigned)cdiv(a.V, 32), (unsigned)feet);
-		hipLaunchKernelGGL((gemm_kernel<32, AMODE, EPI>), grid, block, 0, s, a);
-	}
-}
+// Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
+enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_COUNT };
+constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
+constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
-// tuning: 0 = register-staged tiles (gemm_kernel), 64 / 128 = persistent LDS-DMA kernel (gemm2_kernel) with that BM
-static int g_gemm_mode = 64;
-static int g_ablate = 0;
-static unsigned long long* g_dbg = nullptr;
-static int g_gemm4 = 1;  // 1: K=256 single-segment MAT launches use gemm4_kernel (W resident in LDS, 2 waves per SIMD)
-static int64_t g_gemm4_min_units = 1024;
-static int g_gemm3 = 1;  // 1: MAT-mode launches use gemm3_kernel (early-barrier schedule)
-static int g_dw2 = 1;            // 1: weight gradients of matrix-input layers use dw2_kernel (LDS-DMA pipeline)
-static int g_gemm4_small = 64;   // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
-static int g_dw_pe_target = 256;  // workgroups of the Fourier layer's weight-gradient launch (one round over the chip)
-static int g_dw2_min_cps = 8;    // at least this many 16-row chunks per dw2 workgroup (fewer, longer runs: less slab traffic; 4: 2.257, 8: 2.243, 12: 2.266 ms/step)
-static int g_num_cus = 0;
-
-// Side stream for the weight-gradient half of the backward pass (dW / db / latent gradients only feed the outputs, never
-// the dX chain): forked from and joined back into the caller's stream with events, one pool per device.
-static int g_bwd_streams = 1;
-// (side streams at the lowest stream priority: no difference, 2.32 ms/step either way -- the backward is work-bound, not ordering-bound)
-static int g_gemm5_min_units = 1024;
-static int g_mlp_f16 = 0;        // 1: K = 256 Linear layers (forward and dX) on the fp16 matrix pipe (gemm5_kernel); opt-in
-static int g_fwd_streams = 1;     // 1: forward runs the colour head on a side stream beside the displacement head
-static int g_reduce_stream = 1;  // 1: slab reduces of the large head layers on their own stream (two alternating slab sets)
-static int g_lds_exclusive = 1;  // 1: the LDS-DMA ring kernels reserve the whole LDS of their CU (see CU_LDS_BYTES)
-constexpr int N_SIDE = 3;
-struct SideStream {
-	hipStream_t q = nullptr;          // weight gradients of the (large) head layers
-	hipStream_t qt[N_SIDE] = {nullptr, nullptr, nullptr};  // trunk layers, round-robin: small independent kernels that overlap each other
-	hipStream_t qr = nullptr;         // slab reduces of the large head layers (off the dw2 chain of q)
-	hipEvent_t ev[64];
-	int n = 0;      // events created
-	int next = 0;   // round-robin cursor
+struct find_ctx {
+	int device = 0;
+	int num_cus = 256;
+	int lds_bytes = 160 * 1024;   // largest dynamic LDS one workgroup may ask for on this device
+	// knobs (find_hip.h: find_ctx_set)
+	int ablate = 0;
+	unsigned long long* dbg = nullptr;
+	int64_t gemm4_min_units = 1024;
+	int gemm4_small = 64;         // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
+	int dw_pe_target = 256;       // workgroups of the Fourier layer's weight-gradient launch (one round over the chip)
+	int dw2_min_cps = 8;          // at least this many 16-row chunks per dw2 workgroup (4: 2.257, 8: 2.243, 12: 2.266 ms/step at C2)
+	int bwd_streams = 1;          // weight gradients on the side streams
+	int fwd_streams = 1;          // colour head on a side stream beside the displacement head
+	int reduce_stream = 1;        // slab reduces of the large head layers on their own stream (two alternating slab sets)
+	int gemm5_min_units = 1024;
+	int mlp_f16 = 0;              // default precision of calls that do not name one
+	int lds_exclusive = 1;        // the LDS-DMA ring kernels reserve the whole LDS of their CU (see "Co-residence" below)
+	// internal streams / events
+	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[N_EVENTS];
+	int n_events = 0;
+	int next = 0;
+	int events_per_call_max = 0;
+	bool attr_done[K_COUNT] = {};
+	// set per call
+	bool f16 = false;
 };
-static SideStream g_side[16];
 
-static SideStream* side_stream() {
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-	SideStream* ss = &g_side[dev];
-	if (!ss->q) {
-		if (hipStreamCreateWithFlags(&ss->q, hipStreamNonBlocking) != hipSuccess) { ss->q = nullptr; return nullptr; }
-		ss->qt[0] = ss->q;
-		for (int i = 1; i < N_SIDE; ++i)
-			if (hipStreamCreateWithFlags(&ss->qt[i], hipStreamNonBlocking) != hipSuccess) { ss->qt[i] = ss->q; }
-		if (hipStreamCreateWithFlags(&ss->qr, hipStreamNonBlocking) != hipSuccess) ss->qr = ss->q;
-		for (ss->n = 0; ss->n < 64; ++ss->n)
-			if (hipEventCreateWithFlags(&ss->ev[ss->n], hipEventDisableTiming) != hipSuccess) break;
-		if (ss->n < 64) return nullptr;
+namespace find {
+namespace mlp {
+
+#define FIND_HIP_OK(expr, what)                                                                  \
+	do {                                                                                         \
+		hipError_t _e = (expr);                                                                  \
+		if (_e != hipSuccess) {                                                                  \
+			set_error("%s: %s", what, hipGetErrorString(_e));                                    \
+			return FIND_ELAUNCH;                                                                 \
+		}                                                                                        \
+	} while (0)
+
+// Co-residence fault and the LDS reservation.  The LDS-DMA ring kernels (dw2, gemm3, gemm2, gemm4's prologue) are launched with the
+// WHOLE LDS of a CU although their rings need 100-128 KB.  With a second LDS-using workgroup of another stream resident on the same CU
+// (the 16-KB slab reduce of a side stream is enough) dw2 produced rare wrong partial tiles: one wave reads one 128-byte piece of one
+// staged row with other contents, a rank-1 error of ~1 % in a handful of dW elements -- 3 % of the backward passes at 4 x 1002 rows,
+// 13 % at 16 x 6890, every pass with the dX GEMMs on gemm3 -- with every vmcnt / barrier of the ring in place, and equally with
+// vmcnt(0) everywhere, a one-stage ring, sleeps between the wait and the read, poisoned inputs or device-wide syncs around the call.
+// Alone on the CU's LDS it never happens (tools/check_determinism.py: 0 of 500 passes; 144 KB is not enough), and the register-staged
+// fp16 kernels (gemm5 / dw3: no LDS-DMA, 135 KB, same streams, same co-resident reduce) run clean WITHOUT the reservation.  The
+// reservation takes nothing these kernels use (one workgroup per CU anyway).  The attribute is set per (context, kernel) and its
+// return code is checked: a device that cannot grant the reservation refuses the launch instead of running unprotected.
+template <typename K>
+static int prepare_kernel(find_ctx* c, int id, K kernel, int need_bytes, int* launch_bytes) {
+	const int want = c->lds_exclusive ? c->lds_bytes : need_bytes;
+	if (need_bytes > c->lds_bytes) {
+		set_error("find_mlp: kernel needs %d bytes of LDS, device %d grants %d per workgroup", need_bytes, c->device, c->lds_bytes);
+		return FIND_EINVAL;
 	}
-	return ss;
+	if (!c->attr_done[id]) {
+		FIND_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes),
+					"hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+		c->attr_done[id] = true;
+	}
+	*launch_bytes = want;
+	return FIND_OK;
 }
 
-static int num_cus() {
-	if (g_num_cus == 0) {
-		int dev = 0, n = 0;
-		(void)hipGetDevice(&dev);
-		(void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-		g_num_cus = n > 0 ? n : 256;
-	}
-	return g_num_cus;
-}
+// Fork / join of one entry-point call onto the context's side streams.  fork_to(k) makes side stream k wait for everything issued on
+// the caller's stream so far; chain(a, b) orders side stream b behind a; join() -- called on EVERY exit path after the first fork,
+// error returns included -- makes the caller's stream wait for every side stream this call touched, so that when the call returns
+// the caller may free or reuse any buffer it passed in (stream-ordered).  Every HIP return code is kept: the first failure is
+// reported by join().  Works under stream capture: a captured call forks and joins the same streams, so the capture stays closed.
+struct Fork {
+	find_ctx* c;
+	hipStream_t s;
+	bool on;              // side streams in use for this call
+	bool used[N_SIDE] = {};
+	int n_ev = 0;
+	int rc = FIND_OK;
 
-// The LDS-DMA ring kernels (dw2, gemm3, gemm2) are launched with the WHOLE 160 KB of a CU's LDS although their rings need 100-120 KB.
-// With a second LDS-using workgroup of another stream resident on the same CU (the 16-KB slab reduce of a side stream is enough)
-// dw2 produced rare wrong partial tiles: one wave reads one 128-byte piece of one staged row with other contents, a rank-1 error of
-// ~1 % in a handful of dW elements -- 3 % of the backward passes at 4 x 1002 rows, 13 % at 16 x 6890, every pass with the dX GEMMs
-// on gemm3 -- with every vmcnt / barrier of the ring in place, and equally with vmcnt(0) everywhere, a one-stage ring, sleeps
-// between the wait and the read, poisoned inputs (no stale global data) or device-wide syncs around the call.  Alone on the CU's
-// LDS it never happens (tools/check_determinism.py: 0 of 500 passes, 144 KB is not enough, 160 KB is), and the register-staged
-// fp16 kernels (gemm5 / dw3: no LDS-DMA, 135 KB, same streams, same co-resident reduce) run 260 passes clean WITHOUT the reservation:
-// what goes wrong is LDS-DMA data next to a foreign LDS allocation, not the stream structure.  The reservation takes
-// nothing these kernels use -- they run one workgroup per CU anyway -- and costs 0.03 ms/step of overlap with the small kernels.
-constexpr int CU_LDS_BYTES = 160 * 1024;
-
-template <int BM, int AMODE, int EPI>
-static void launch_gemm2_t(Gemm2Args a, int64_t feet, hipStream_t s) {
-	static bool attr_set = false;
-	constexpr int lds = gemm2_lds_bytes<BM>();
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<BM, AMODE, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-		attr_set = true;
+	Fork(find_ctx* ctx, hipStream_t caller, bool enable) : c(ctx), s(caller), on(enable && ctx->side[0] != nullptr) {}
+	hipStream_t stream(int k) const { return on ? c->side[k] : s; }
+	void fail(hipError_t e, const char* what) {
+		if (e != hipSuccess && rc == FIND_OK) {
+			set_error("%s: %s", what, hipGetErrorString(e));
+			rc = FIND_ELAUNCH;
+		}
 	}
+	hipEvent_t event() {
+		hipEvent_t e = c->ev[c->next];
+		c->next = (c->next + 1) % N_EVENTS;
+		if (++n_ev > N_EVENTS && rc == FIND_OK) {
+			set_error("find_mlp: more than %d events in one call", N_EVENTS);
+			rc = FIND_ELAUNCH;
+		}
+		return e;
+	}
+	void order(hipStream_t from, hipStream_t to) {
+		hipEvent_t e = event();
+		fail(hipEventRecord(e, from), "hipEventRecord");
+		fail(hipStreamWaitEvent(to, e, 0), "hipStreamWaitEvent");
+	}
+	void fork_to(int k) {
+		if (!on) return;
+		order(s, c->side[k]);
+		used[k] = true;
+	}
+	// an event that fires when side stream k has run what was issued so far
+	hipEvent_t mark(int k) {
+		if (!on) return nullptr;
+		hipEvent_t e = event();
+		fail(hipEventRecord(e, c->side[k]), "hipEventRecord");
+		return e;
+	}
+	void wait(int k, hipEvent_t e) {
+		if (on && e) fail(hipStreamWaitEvent(c->side[k], e, 0), "hipStreamWaitEvent");
+	}
+	void chain(int from, int to) {
+		if (!on || from == to) return;
+		order(c->side[from], c->side[to]);
+		used[to] = true;
+	}
+	int join() {
+		if (on)
+			for (int k = 0; k < N_SIDE; ++k)
+				if (used[k]) { order(c->side[k], s); used[k] = false; }
+		c->events_per_call_max = std::max(c->events_per_call_max, n_ev);
+		return rc;
+	}
+};
+
+static int launch_gemm2_pe(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
+	constexpr int BM = 64;
+	int lds = 0;
+	const int rc = prepare_kernel(c, K_GEMM2_PE, &gemm2_kernel<BM, AMODE_PE, EPI_BIAS_RELU>, gemm2_lds_bytes<BM>(), &lds);
+	if (rc != FIND_OK) return rc;
 	a.tiles_per_foot = (int)cdiv(a.V, BM);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
-	const int grid = std::min(a.ntiles, num_cus());
-	static_assert(lds <= CU_LDS_BYTES, "ring larger than a CU's LDS");
-	hipLaunchKernelGGL((gemm2_kernel<BM, AMODE, EPI>), dim3(grid), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : lds, s, a);
+	const int grid = std::min(a.ntiles, c->num_cus);
+	hipLaunchKernelGGL((gemm2_kernel<BM, AMODE_PE, EPI_BIAS_RELU>), dim3(grid), dim3(256), lds, s, a);
+	return FIND_OK;
 }
 
 template <int BM, int EPI>
-static void launch_gemm3_t(Gemm2Args a, int64_t feet, hipStream_t s) {
-	static bool attr_set = false;
-	constexpr int lds = gemm2_lds_bytes<BM>();
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-		attr_set = true;
-	}
+static int launch_gemm3_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
+	int lds = 0;
+	const int rc = prepare_kernel(c, K_GEMM3_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2), &gemm3_kernel<BM, EPI>, gemm2_lds_bytes<BM>(), &lds);
+	if (rc != FIND_OK) return rc;
 	a.tiles_per_foot = (int)cdiv(a.V, BM);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
-	const int grid = std::min(a.ntiles, num_cus());
-	static_assert(lds <= CU_LDS_BYTES, "ring larger than a CU's LDS");
-	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : lds, s, a);
+	const int grid = std::min(a.ntiles, c->num_cus);
+	hipLaunchKernelGGL((gemm3_kernel<BM, EPI>), dim3(grid), dim3(256), lds, s, a);
+	return FIND_OK;
 }
 
 template <int EPI, int NI, int NW = 8>
-static void launch_gemm4_t(Gemm2Args a, int64_t feet, hipStream_t s) {
-	static bool attr_set = false;
-	constexpr int lds = NI * 32 * 1024;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, NI, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-		attr_set = true;
-	}
+static int launch_gemm4_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
+	int lds = 0;
+	const int id = (NI == 4 ? K_GEMM4_4_RELU : K_GEMM4_2_RELU) + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2);
+	const int rc = prepare_kernel(c, id, &gemm4_kernel<EPI, NI, NW>, NI * 32 * 1024, &lds);
+	if (rc != FIND_OK) return rc;
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	constexpr int G = 8 * (8 / NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
-	const int grid = std::max(G, (num_cus() / G) * G);
-	hipLaunchKernelGGL((gemm4_kernel<EPI, NI, NW>), dim3(grid), dim3(NW * 64), g_lds_exclusive ? CU_LDS_BYTES : lds, s, a);
+	const int grid = std::max(G, (c->num_cus / G) * G);
+	hipLaunchKernelGGL((gemm4_kernel<EPI, NI, NW>), dim3(grid), dim3(NW * 64), lds, s, a);
+	return FIND_OK;
 }
 
-template <int NI, int NW = 8>
-static void launch_gemm4(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (epi == EPI_BIAS_RELU) launch_gemm4_t<EPI_BIAS_RELU, NI, NW>(a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm4_t<EPI_MASK, NI, NW>(a, feet, s);
-	else launch_gemm4_t<EPI_NONE, NI, NW>(a, feet, s);
+template <int NI>
+static int launch_gemm4(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) return launch_gemm4_t<EPI_BIAS_RELU, NI>(c, a, feet, s);
+	if (epi == EPI_MASK) return launch_gemm4_t<EPI_MASK, NI>(c, a, feet, s);
+	return launch_gemm4_t<EPI_NONE, NI>(c, a, feet, s);
 }
 
 template <int EPI>
-static void launch_gemm5_t(Gemm2Args a, int64_t feet, hipStream_t s) {
-	static bool attr_set = false;
-	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm5_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-		attr_set = true;
-	}
+static int launch_gemm5_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
+	int lds = 0;
+	const int rc = prepare_kernel(c, K_GEMM5_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2), &gemm5_kernel<EPI>, GEMM5_LDS, &lds);
+	if (rc != FIND_OK) return rc;
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
-	const int grid = (int)std::min<int64_t>(num_cus(), cdiv(a.ntiles, GEMM5_NW));
-	hipLaunchKernelGGL((gemm5_kernel<EPI>), dim3(grid), dim3(GEMM5_NW * 64), g_lds_exclusive ? CU_LDS_BYTES : GEMM5_LDS, s, a);
+	const int grid = (int)std::min<int64_t>(c->num_cus, cdiv(a.ntiles, GEMM5_NW));
+	hipLaunchKernelGGL((gemm5_kernel<EPI>), dim3(grid), dim3(GEMM5_NW * 64), lds, s, a);
+	return FIND_OK;
 }
 
-static void launch_gemm5(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (epi == EPI_BIAS_RELU) launch_gemm5_t<EPI_BIAS_RELU>(a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm5_t<EPI_MASK>(a, feet, s);
-	else launch_gemm5_t<EPI_NONE>(a, feet, s);
+static int launch_gemm5(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) return launch_gemm5_t<EPI_BIAS_RELU>(c, a, feet, s);
+	if (epi == EPI_MASK) return launch_gemm5_t<EPI_MASK>(c, a, feet, s);
+	return launch_gemm5_t<EPI_NONE>(c, a, feet, s);
 }
 
-template <int BM>
-static void launch_gemm3(int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (epi == EPI_BIAS_RELU) launch_gemm3_t<BM, EPI_BIAS_RELU>(a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm3_t<BM, EPI_MASK>(a, feet, s);
-	else launch_gemm3_t<BM, EPI_NONE>(a, feet, s);
+static int launch_gemm3(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) return launch_gemm3_t<64, EPI_BIAS_RELU>(c, a, feet, s);
+	if (epi == EPI_MASK) return launch_gemm3_t<64, EPI_MASK>(c, a, feet, s);
+	return launch_gemm3_t<64, EPI_NONE>(c, a, feet, s);
 }
 
-template <int BM>
-static void launch_gemm2(int amode, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (amode == AMODE_PE) launch_gemm2_t<BM, AMODE_PE, EPI_BIAS_RELU>(a, feet, s);
-	else if (epi == EPI_BIAS_RELU) launch_gemm2_t<BM, AMODE_MAT, EPI_BIAS_RELU>(a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm2_t<BM, AMODE_MAT, EPI_MASK>(a, feet, s);
-	else launch_gemm2_t<BM, AMODE_MAT, EPI_NONE>(a, feet, s);
-}
-
-static void launch_gemm(int amode, int epi, const GemmArgs& a, int64_t feet, hipStream_t s) {
-	if (g_gemm_mode != 0 && a.nseg_per_base == 1) {
-		Gemm2Args b;
-		memset(&b, 0, sizeof(b));
-		b.a0 = a.a0; b.a1 = a.a1; b.nseg = a.nbase; b.a_foot_stride = a.a_foot_stride; b.lda = a.lda;
-		b.pos = a.pos; b.pos_foot_stride = a.pos_foot_stride; b.Bm = a.Bm; b.pe = a.pe;
-		b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk;
-		b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
-		b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = g_ablate; b.dbg = g_dbg;
-		// 128-row tiles halve the W re-reads but balance worse over 256 CUs; use them only when tiles are plentiful
-		const bool big = g_gemm_mode == 128 && cdiv(a.V, 128) * feet >= 4 * num_cus();
-		// opt-in fp16 matrix pipe (fp32 accumulation).  Launches of a few hundred 32-row units (the shared trunk's V rows) stay on the fp32
-		// kernels below: gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs (22 us against 13 us for gemm4 on column quarters)
-		if (g_mlp_f16 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet >= g_gemm5_min_units) {
-			launch_gemm5(epi, b, feet, s);
-			return;
-		}
-		// K = 256, one segment, enough 32-row units to give every SIMD of the chip work: W-resident kernel
-		if (g_gemm4 && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet * 2 >= g_gemm4_min_units) {
-			launch_gemm4<4>(epi, b, feet, s);
-			return;
-		}
-		// the same kernel on column quarters for launches of a few hundred 32-row units (the shared trunk: V rows)
-		if (g_gemm4 && g_gemm4_small && amode == AMODE_MAT && b.nseg == 1 && b.nchunk == 8 && cdiv(a.V, 32) * feet >= g_gemm4_small) {
-			launch_gemm4<2>(epi, b, feet, s);
-			return;
-		}
-		if (g_gemm3 && amode == AMODE_MAT && !big) {
-			launch_gemm3<64>(epi, b, feet, s);  // (the 128-row instantiation of gemm3 spills; 128-row tiles stay on gemm2)
-		} else if (big) launch_gemm2<128>(amode, epi, b, feet, s);
-		else launch_gemm2<64>(amode, epi, b, feet, s);
-		return;
-	}
-	const int bm = pick_bm(a.V, feet);
-	if (amode == AMODE_PE) launch_gemm_bm<AMODE_PE, EPI_BIAS_RELU>(bm, a, feet, s);
-	else if (epi == EPI_BIAS_RELU) launch_gemm_bm<AMODE_MAT, EPI_BIAS_RELU>(bm, a, feet, s);
-	else if (epi == EPI_MASK) launch_gemm_bm<AMODE_MAT, EPI_MASK>(bm, a, feet, s);
-	else launch_gemm_bm<AMODE_MAT, EPI_NONE>(bm, a, feet, s);
+// Kernel choice for one Linear-shaped launch (all of them exact fp32 unless the call runs in the opt-in fp16 mode):
+//   Fourier layer                                   gemm2<64, PE>   (sin / cos generated into the A tile)
+//   fp16 mode, K = 256, >= gemm5_min_units units    gemm5           (W resident as fp16, HBM-bound)
+//   K = 256, >= gemm4_min_units / 2 32-row units    gemm4<4>        (W half resident in LDS, matrix-pipe-bound)
+//   K = 256, >= gemm4_small units                   gemm4<2>        (column quarters: the shared trunk's V rows)
+//   anything else (two-segment K, tiny launches)    gemm3<64>       (LDS-DMA ring)
+static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64_t feet, hipStream_t s) {
+	Gemm2Args b;
+	memset(&b, 0, sizeof(b));
+	b.a0 = a.a0; b.a1 = a.a1; b.nseg = a.nbase; b.a_foot_stride = a.a_foot_stride; b.lda = a.lda;
+	b.pos = a.pos; b.pos_foot_stride = a.pos_foot_stride; b.Bm = a.Bm; b.pe = a.pe;
+	b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk;
+	b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
+	b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = c->ablate; b.dbg = c->dbg;
+	if (amode == AMODE_PE) return launch_gemm2_pe(c, b, feet, s);
+	const int64_t units = cdiv(a.V, 32) * feet;
+	const bool k256 = b.nseg == 1 && b.nchunk == 8;
+	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
+	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s);
+	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
+	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
+	return launch_gemm3(c, epi, b, feet, s);
 }
 
 static GemmArgs gemm_args_zero() {
@@ -334,14 +347,14 @@ static GemmArgs gemm_args_zero() {
 }
 
 // Linear + ReLU forward:  y = relu(x @ w^T + bias[foot])
-static void linear_fwd(const float* x, int64_t x_foot_stride, const float* w, int ldw, const float* bias,
-					   int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s) {
+static int linear_fwd(find_ctx* c, const float* x, int64_t x_foot_stride, const float* w, int ldw, const float* bias,
+					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s) {
 	GemmArgs a = gemm_args_zero();
 	a.a0 = x; a.a_foot_stride = x_foot_stride; a.lda = W;
 	a.w0 = w; a.ldw = ldw; a.nchunk = W / KC;
 	a.bias = bias; a.bias_foot_stride = bias_foot_stride;
 	a.y = y; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-	launch_gemm(AMODE_MAT, EPI_BIAS_RELU, a, feet, s);
+	return launch_gemm(c, AMODE_MAT, EPI_BIAS_RELU, a, feet, s);
 }
 
 static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t target = 128) {
@@ -351,40 +364,18 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 	*spf = (int)cdiv(cpf, *cps);
 }
 
-}  // namespace mlp
-}  // namespace find
+static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 != 0); }
 
-using namespace find;
-using namespace find::mlp;
+#define FIND_TRY(expr)                    \
+	do {                                  \
+		const int _r = (expr);            \
+		if (_r != FIND_OK) return _r;     \
+	} while (0)
 
-extern "C" int64_t find_mlp_ws_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts, int save_for_bwd) {
-	Dims d;
-	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;
-	FwdWs w;
-	carve_fwd(p, d, save_for_bwd != 0, nullptr, &w);
-	return w.bytes;
-}
-
-extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
-							const float* lat_disp, const float* lat_col, float* disp, float* col, void* ws,
-							int64_t ws_bytes, int save_for_bwd, void* stream) {
-	Dims d;
-	int rc = make_dims(p, pos_batch, n_feet, n_pts, &d);
-	if (rc != FIND_OK) return rc;
-	rc = check_weights(p);
-	if (rc != FIND_OK) return rc;
-	FIND_REQUIRE(pos && ws, "find_mlp_fwd: pos/ws is NULL");
-	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_fwd: lat_disp pointer does not match params.lat_disp=%d", p->lat_disp);
-	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_fwd: lat_col pointer does not match params.lat_col=%d", p->lat_col);
-	FIND_REQUIRE(disp || col, "find_mlp_fwd: both outputs NULL");
-	FwdWs w;
-	carve_fwd(p, d, save_for_bwd != 0, ws, &w);
-	if (ws_bytes < w.bytes) {
-		set_error("find_mlp_fwd: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
-		return FIND_EWORKSPACE;
-	}
-	hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-	const int64_t V = d.V;
+static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const Dims& d, const FwdWs& w, const float* pos, const float* lat_disp,
+						const float* lat_col, float* disp, float* col) {
+	hipStream_t s = fk.s;
+	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 
 	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers
@@ -419,10 +410,10 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 		a.w0 = w.w0p; a.ldw = KP0; a.nchunk = d.nchunk0;
 		a.bias = p->trunk_b[0]; a.bias_foot_stride = 0;
 		a.y = w.H[0]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-		launch_gemm(AMODE_PE, EPI_BIAS_RELU, a, d.feet_t, s);
+		FIND_TRY(launch_gemm(c, AMODE_PE, EPI_BIAS_RELU, a, d.feet_t, s));
 	}
 	for (int i = 1; i < p->n_trunk; ++i)
-		linear_fwd(w.H[i - 1], V * W, p->trunk_w[i], W, p->trunk_b[i], 0, w.H[i], V, d.feet_t, s);
+		FIND_TRY(linear_fwd(c, w.H[i - 1], V * W, p->trunk_w[i], W, p->trunk_b[i], 0, w.H[i], V, d.feet_t, s));
 	FIND_LAUNCH_CHECK("trunk gemm");
 
 	// 4. heads (model.py:439-440); the trunk rows are shared by every foot when d.shared
@@ -430,19 +421,19 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 	// first layer of a head.  Shared template: every foot multiplies the SAME trunk rows, so  H W^T  is formed once on V rows
 	// and each foot only adds its (latent-folded) bias and applies the ReLU -- a bandwidth-bound broadcast instead of a GEMM
-	// over n_feet * V rows.  (The backward has always used the same fact: footsum_kernel.)
-	auto head_first = [&](const float* w0, const float* bias, int64_t bstride, float* out, float* hp, hipStream_t st) {
+	// over n_feet * V rows.  (The backward uses the same fact: footsum_kernel.)
+	auto head_first = [&](const float* w0, const float* bias, int64_t bstride, float* out, float* hp, hipStream_t st) -> int {
 		if (hp) {
 			GemmArgs a = gemm_args_zero();
 			a.a0 = hl; a.a_foot_stride = 0; a.lda = W;
 			a.w0 = w0; a.ldw = W; a.nchunk = W / KC;
 			a.y = hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-			launch_gemm(AMODE_MAT, EPI_NONE, a, 1, st);
+			FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_NONE, a, 1, st));
 			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, st, hp, bias,
 							   bstride, (int)n_feet, V, out);
-		} else {
-			linear_fwd(hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, st);
+			return FIND_OK;
 		}
+		return linear_fwd(c, hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, st);
 	};
 	// 5. final 256->3 layers + tanh scalings (model.py:444-449), one launch per head
 	auto head_out = [&](int head, hipStream_t st) {
@@ -461,38 +452,82 @@ extern "C" int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t 
 	};
 	// The heads are independent after the trunk.  With both active, the colour head runs on a side stream: its bandwidth-bound
 	// pieces (the bias + ReLU broadcast, the 3-wide output layer: no LDS, so they can share CUs with the W-resident GEMMs) then
-	// overlap the other head's matrix-pipe-bound layers.  Forked from and joined back into the caller's stream.
-	SideStream* ss = (g_fwd_streams && disp && col) ? side_stream() : nullptr;
-	hipStream_t sc = ss ? ss->qt[1] : s;
-	if (ss) {
-		hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63;
-		(void)hipEventRecord(e, s);
-		(void)hipStreamWaitEvent(sc, e, 0);
+	// overlap the other head's matrix-pipe-bound layers.  Forked from and joined back into the caller's stream (Fork::join).
+	hipStream_t sc = s;
+	if (disp && col && fk.on) {
+		fk.fork_to(1);
+		sc = fk.stream(1);
 	}
 	if (disp) {
-		head_first(w.wd0, bias_d0, bstride_d, w.D[0], w.hp, s);
-		for (int i = 1; i < p->n_disp; ++i) linear_fwd(w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s);
+		FIND_TRY(head_first(w.wd0, bias_d0, bstride_d, w.D[0], w.hp, s));
+		for (int i = 1; i < p->n_disp; ++i) FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s));
 		head_out(0, s);
 	}
 	if (col) {
-		head_first(w.wc0, bias_c0, bstride_c, w.C[0], ss ? w.hp2 : w.hp, sc);
-		for (int i = 1; i < p->n_col; ++i) linear_fwd(w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc);
+		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], sc != s ? w.hp2 : w.hp, sc));
+		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc));
 		head_out(1, sc);
-	}
-	if (ss) {
-		hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63;
-		(void)hipEventRecord(e, sc);
-		(void)hipStreamWaitEvent(s, e, 0);
 	}
 	FIND_LAUNCH_CHECK("head layers");
 	return FIND_OK;
 }
 
-extern "C" int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream) {
+}  // namespace mlp
+}  // namespace find
+
+using namespace find;
+using namespace find::mlp;
+
+static int check_ctx(const find_ctx* c, const char* who) {
+	FIND_REQUIRE(c != nullptr, "%s: ctx is NULL (find_ctx_create)", who);
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess || dev != c->device) {
+		set_error("%s: the context belongs to device %d, the calling thread's current device is %d", who, c->device, dev);
+		return FIND_EINVAL;
+	}
+	return FIND_OK;
+}
+
+extern "C" int64_t find_mlp_ws_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts, int save_for_bwd) {
+	Dims d;
+	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;
+	FwdWs w;
+	carve_fwd(p, d, save_for_bwd != 0, nullptr, &w);
+	return w.bytes;
+}
+
+extern "C" int find_mlp_fwd(find_ctx* c, const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+							const float* lat_disp, const float* lat_col, float* disp, float* col, void* ws,
+							int64_t ws_bytes, int save_for_bwd, void* stream) {
+	FIND_TRY(check_ctx(c, "find_mlp_fwd"));
+	Dims d;
+	FIND_TRY(make_dims(p, pos_batch, n_feet, n_pts, &d));
+	FIND_TRY(check_weights(p));
+	FIND_REQUIRE(pos && ws, "find_mlp_fwd: pos/ws is NULL");
+	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_fwd: lat_disp pointer does not match params.lat_disp=%d", p->lat_disp);
+	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_fwd: lat_col pointer does not match params.lat_col=%d", p->lat_col);
+	FIND_REQUIRE(disp || col, "find_mlp_fwd: both outputs NULL");
+	FIND_REQUIRE(p->precision >= 0 && p->precision <= 2, "find_mlp_fwd: params.precision must be 0 (context default), 1 (fp32) or 2 (fp16), got %d", p->precision);
+	FwdWs w;
+	carve_fwd(p, d, save_for_bwd != 0, ws, &w);
+	if (ws_bytes < w.bytes) {
+		set_error("find_mlp_fwd: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
+		return FIND_EWORKSPACE;
+	}
+	c->f16 = call_f16(c, p);
+	Fork fk(c, reinterpret_cast<hipStream_t>(stream), c->fwd_streams != 0);
+	const int rc = mlp_fwd_body(c, fk, p, d, w, pos, lat_disp, lat_col, disp, col);
+	const int rj = fk.join();   // on every path: the caller may free `ws` right after an error return
+	return rc != FIND_OK ? rc : rj;
+}
+
+extern "C" int find_linear_relu_fwd(find_ctx* c, const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream) {
+	FIND_TRY(check_ctx(c, "find_linear_relu_fwd"));
 	FIND_REQUIRE(x && w && b && y, "find_linear_relu_fwd: NULL argument");
 	FIND_REQUIRE(n_feet >= 1 && n_pts >= 1 && n_feet < (1 << 16), "find_linear_relu_fwd: bad sizes");
 	FIND_REQUIRE(aligned16(w) && aligned16(x), "find_linear_relu_fwd: x and w must be 16-byte aligned");
-	linear_fwd(x, n_pts * W, w, W, b, 0, y, n_pts, n_feet, reinterpret_cast<hipStream_t>(stream));
+	c->f16 = c->mlp_f16 != 0;
+	FIND_TRY(linear_fwd(c, x, n_pts * W, w, W, b, 0, y, n_pts, n_feet, reinterpret_cast<hipStream_t>(stream)));
 	FIND_LAUNCH_CHECK("find_linear_relu_fwd");
 	return FIND_OK;
 }
@@ -568,91 +603,77 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	o->bytes = c.off;
 }
 
-// dW / db of one Linear layer from dz (rows (foot,v)) and its input x.
-static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
+// dW / db of one Linear layer from dz (rows (foot, v)) and its input x (or, for the Fourier layer, the positions).  The partial
+// tiles go out on stream s; the slab reduce follows on s, or -- reduce_side >= 0 -- on that side stream of the fork, ordered behind s.
+static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
-					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, hipStream_t sr = nullptr, hipEvent_t ev = nullptr) {
-	// sr / ev: the slab reduce goes to stream sr behind event ev (recorded on s after the partial-tile kernel) instead of s
+					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1) {
 	auto reduce_stream = [&]() -> hipStream_t {
-		if (!sr || sr == s || !ev) return s;
-		(void)hipEventRecord(ev, s);
-		(void)hipStreamWaitEvent(sr, ev, 0);
-		return sr;
+		if (!fk || !fk->on || reduce_side < 0 || s_side < 0 || reduce_side == s_side) return s;
+		fk->chain(s_side, reduce_side);
+		return fk->stream(reduce_side);
 	};
-	if (!pos && g_dw2 && g_mlp_f16) {
-		// opt-in fp16 mode: 64-row chunks, rows past the end of a foot zero-filled by the kernel
-		const int cpf64 = (int)cdiv(V, 64);
-		const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf64, cdiv(num_cus(), feet)));
-		const int cps3 = (int)std::max<int64_t>(cdiv(cpf64, want), std::min<int>(4, cpf64));  // at least 256 rows per slab (the small launches are slab-bound: 1 chunk 1.62, 2: 1.60, 4: 1.58 ms/step)
-		const int spf3 = (int)cdiv(cpf64, cps3);
-		const int nmain = (int)(feet * spf3);
-		float* pbuf = (db || S) ? b.pb : nullptr;
-		static bool attr3_set = false;
-		if (!attr3_set) {
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-			attr3_set = true;
+	float* pbuf = (db || S) ? b.pb : nullptr;
+	if (!pos) {
+		int nmain, spf;
+		if (c->f16) {
+			// opt-in fp16 mode: 64-row chunks, rows past the end of a foot zero-filled by the kernel
+			const int cpf64 = (int)cdiv(V, 64);
+			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf64, cdiv(c->num_cus, feet)));
+			const int cps3 = (int)std::max<int64_t>(cdiv(cpf64, want), std::min<int>(4, cpf64));  // at least 256 rows per slab (the small launches are slab-bound)
+			spf = (int)cdiv(cpf64, cps3);
+			nmain = (int)(feet * spf);
+			int lds = 0;
+			FIND_TRY(prepare_kernel(c, K_DW3, &dw3_kernel, DW3_LDS, &lds));
+			Dw3Args d3;
+			memset(&d3, 0, sizeof(d3));
+			d3.dz = dz; d3.dz_foot_stride = V * W; d3.x = x; d3.x_foot_stride = x_foot_stride;
+			d3.V = (int)V; d3.chunks_per_foot = cpf64; d3.spf = spf; d3.cps = cps3; d3.pw = b.pw; d3.pb = pbuf;
+			hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);
+			FIND_LAUNCH_CHECK("dw3_kernel");
+		} else {
+			// LDS-DMA kernel: every foot's rows cut into spf contiguous runs of 16-row chunks, the <= 15 leftover rows
+			// folded into the foot's last run
+			const int cpf16 = (int)(V / 16);
+			int cps2 = 1;
+			spf = 1;
+			if (cpf16 > 0) {
+				const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
+				cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(c->dw2_min_cps, cpf16));  // few, long runs: slab traffic
+				spf = (int)cdiv(cpf16, cps2);
+			}
+			nmain = (int)(feet * spf);
+			int lds = 0;
+			FIND_TRY(prepare_kernel(c, K_DW2, &dw2_kernel, DW2_LDS, &lds));
+			Dw2Args d2;
+			memset(&d2, 0, sizeof(d2));
+			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
+			d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
+			hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
+			FIND_LAUNCH_CHECK("dw2_kernel");
 		}
-		Dw3Args d3;
-		memset(&d3, 0, sizeof(d3));
-		d3.dz = dz; d3.dz_foot_stride = V * W; d3.x = x; d3.x_foot_stride = x_foot_stride;
-		d3.V = (int)V; d3.chunks_per_foot = cpf64; d3.spf = spf3; d3.cps = cps3; d3.pw = b.pw; d3.pb = pbuf;
-		hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : DW3_LDS, s, d3);
-		FIND_LAUNCH_CHECK("dw3_kernel");
 		ReduceWArgs r;
 		memset(&r, 0, sizeof(r));
 		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
-		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf3; r.db = db; r.S = S;
+		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
 		r.nwblk = 256 * 256 / 4 / 64;
 		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
-	if (!pos && g_dw2) {
-		// LDS-DMA kernel: every foot's rows cut into spf2 contiguous runs of 16-row chunks, the <= 15 leftover rows
-		// folded into the foot's last run
-		const int cpf16 = (int)(V / 16);
-		int spf2 = 1, cps2 = 1;
-		if (cpf16 > 0) {
-			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(num_cus(), feet)));
-			cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(g_dw2_min_cps, cpf16));  // few, long runs: slab traffic
-			spf2 = (int)cdiv(cpf16, cps2);
-		}
-		const int nmain = (int)(feet * spf2);
-		float* pbuf = (db || S) ? b.pb : nullptr;
-		static bool attr_set = false;
-		if (!attr_set) {
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_LDS_BYTES);
-			attr_set = true;
-		}
-		Dw2Args d2;
-		memset(&d2, 0, sizeof(d2));
-		d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
-		d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf2; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
-		hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), g_lds_exclusive ? CU_LDS_BYTES : DW2_LDS, s, d2);
-		FIND_LAUNCH_CHECK("dw2_kernel");
-		ReduceWArgs r;
-		memset(&r, 0, sizeof(r));
-		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
-		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf2; r.db = db; r.S = S;
-		r.nwblk = 256 * 256 / 4 / 64;
-		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
-		FIND_LAUNCH_CHECK("reduce_w_kernel");
-		return FIND_OK;
-	}
+	// Fourier layer: the inputs are regenerated from the positions (register-staged kernel, nkt k-tiles per split -- keep the
+	// launch within one round of workgroups over the chip)
 	int spf, cps;
-	// (Fourier layer: nkt k-tiles per split -- keep the launch within one round of workgroups over the chip)
-	split_policy(feet, V, &spf, &cps, pos ? std::min<int64_t>(128, std::max<int64_t>(16, g_dw_pe_target / nkt)) : 128);
+	split_policy(feet, V, &spf, &cps, std::min<int64_t>(128, std::max<int64_t>(16, c->dw_pe_target / nkt)));
 	DwArgs a;
 	memset(&a, 0, sizeof(a));
 	a.dz = dz; a.dz_foot_stride = V * W;
 	a.x = x; a.x_foot_stride = x_foot_stride; a.ldx = W;
 	a.pos = pos; a.pos_foot_stride = pos_foot_stride; a.Bm = p->B; a.pe = p->pe_size;
 	a.V = (int)V; a.spf = spf; a.cps = cps; a.Kp = nkt * 256;
-	a.pw = b.pw; a.pb = (db || S) ? b.pb : nullptr;
+	a.pw = b.pw; a.pb = pbuf;
 	const int nsplit = (int)(feet * spf);
-	dim3 grid((unsigned)nkt, (unsigned)nsplit);
-	if (pos) hipLaunchKernelGGL((dw_kernel<AMODE_PE>), grid, dim3(512), 0, s, a);
-	else hipLaunchKernelGGL((dw_kernel<AMODE_MAT>), grid, dim3(512), 0, s, a);
+	hipLaunchKernelGGL((dw_kernel<AMODE_PE>), dim3((unsigned)nkt, (unsigned)nsplit), dim3(512), 0, s, a);
 	FIND_LAUNCH_CHECK("dw_kernel");
 	ReduceWArgs r;
 	memset(&r, 0, sizeof(r));
@@ -666,107 +687,34 @@ static int weight_grad(const float* dz, const float* x, int64_t x_foot_stride, c
 }
 
 // masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
-static void linear_bwd_dx(const float* dz, const float* wt, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s) {
+static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s) {
 	GemmArgs a = gemm_args_zero();
 	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
 	a.w0 = wt; a.ldw = W; a.nchunk = W / KC;
 	a.mask = mask; a.mask_foot_stride = V * W;
 	a.y = y; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-	launch_gemm(AMODE_MAT, EPI_MASK, a, feet, s);
+	return launch_gemm(c, AMODE_MAT, EPI_MASK, a, feet, s);
 }
 
-}  // namespace mlp
-}  // namespace find
-
-// Slabs of one weight-gradient launch: up to max(512, feet) + feet + 16 partial 256x256 tiles and as many 256-float bias rows.
-static int64_t wgrad_slabs(int64_t n_feet) { return std::max<int64_t>(512, n_feet) + n_feet + 16; }
-
-extern "C" int64_t find_linear_wgrad_scratch_bytes(int64_t n_feet) {
-	if (n_feet < 1) return -1;
-	return wgrad_slabs(n_feet) * ((int64_t)W * W + W) * (int64_t)sizeof(float);
-}
-
-extern "C" int find_linear_wgrad(const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
-								 void* scratch, int64_t scratch_bytes, void* stream) {
-	FIND_REQUIRE(dz && x && dw && scratch, "find_linear_wgrad: NULL argument");
-	FIND_REQUIRE(n_feet >= 1 && n_pts >= 1 && n_feet < (1 << 16), "find_linear_wgrad: bad sizes");
-	FIND_REQUIRE(aligned16(dz) && aligned16(x) && aligned16(scratch), "find_linear_wgrad: dz, x and scratch must be 16-byte aligned");
-	FIND_REQUIRE(g_dw2, "find_linear_wgrad: needs the dw2 / dw3 kernels (tuning dw2 = 1)");
-	if (scratch_bytes < find_linear_wgrad_scratch_bytes(n_feet)) {
-		set_error("find_linear_wgrad: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)find_linear_wgrad_scratch_bytes(n_feet));
-		return FIND_EWORKSPACE;
-	}
-	BwdWs b;
-	memset(&b, 0, sizeof(b));
-	b.pw = static_cast<float*>(scratch);
-	b.pb = b.pw + wgrad_slabs(n_feet) * W * W;
-	const int rc = weight_grad(dz, x, n_pts * W, nullptr, 0, nullptr, 1, n_feet, n_pts, b, dw, W, W, 0, db, nullptr, reinterpret_cast<hipStream_t>(stream));
-	if (rc != FIND_OK) return rc;
-	FIND_LAUNCH_CHECK("find_linear_wgrad");
-	return FIND_OK;
-}
-
-extern "C" int64_t find_mlp_bwd_scratch_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts) {
-	Dims d;
-	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;
-	BwdWs b;
-	carve_bwd(p, d, nullptr, &b);
-	return b.bytes;
-}
-
-extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
-							const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col,
-							const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
-							const find_mlp_grads* g, void* stream) {
-	Dims d;
-	int rc = make_dims(p, pos_batch, n_feet, n_pts, &d);
-	if (rc != FIND_OK) return rc;
-	rc = check_weights(p);
-	if (rc != FIND_OK) return rc;
-	FIND_REQUIRE(pos && ws && scratch && g, "find_mlp_bwd: NULL argument");
-	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
-	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
-	FwdWs w;
-	carve_fwd(p, d, true, const_cast<void*>(ws), &w);
-	if (ws_bytes < w.bytes) {
-		set_error("find_mlp_bwd: forward workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
-		return FIND_EWORKSPACE;
-	}
-	BwdWs b;
-	carve_bwd(p, d, scratch, &b);
-	if (scratch_bytes < b.bytes) {
-		set_error("find_mlp_bwd: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)b.bytes);
-		return FIND_EWORKSPACE;
-	}
-	hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-	const int64_t V = d.V;
+static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const Dims& d, const FwdWs& w, const BwdWs& b, const float* pos,
+						const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col, const find_mlp_grads* g) {
+	hipStream_t s = fk.s;
+	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 	const int K0 = p->in_dim + 2 * p->pe_size;
 	const bool act_d = d_disp != nullptr, act_c = d_col != nullptr;
-
-	// weight-gradient work goes to the side stream q: fork() makes q wait for everything issued on s so far; side_done()
-	// returns an event that fires when q has finished what was issued so far (waited for by s before it overwrites a
-	// buffer q reads, and once at the end so the caller's stream sees every gradient)
-	SideStream* ss = g_bwd_streams ? side_stream() : nullptr;
-	hipStream_t q = ss ? ss->q : s;
-	auto next_event = [&]() -> hipEvent_t { hipEvent_t e = ss->ev[ss->next]; ss->next = (ss->next + 1) & 63; return e; };
-	auto fork_to = [&](hipStream_t target) {
-		if (!ss) return;
-		hipEvent_t e = next_event();
-		(void)hipEventRecord(e, s);
-		(void)hipStreamWaitEvent(target, e, 0);
-	};
-	auto fork = [&]() { fork_to(q); };
-	auto side_done = [&]() -> hipEvent_t {
-		if (!ss) return nullptr;
-		hipEvent_t e = next_event();
-		(void)hipEventRecord(e, q);
-		return e;
-	};
-	auto wait_side = [&](hipEvent_t e) { if (ss && e) (void)hipStreamWaitEvent(s, e, 0); };
+	// side streams of the fork: Q carries the large head layers' weight gradients, T1 / T2 the first head layers (foot-summed, with
+	// their column-sum reduce and latent gradients) and the trunk layers, R the slab reduces of the large head layers
+	enum { Q = 0, T1 = 1, T2 = 2, R = 3 };
 
 	// gradients of skipped parts are exact zeros
-	auto zero = [&](float* ptr, int64_t n) { if (ptr) (void)hipMemsetAsync(ptr, 0, n * sizeof(float), s); };
+	int mrc = FIND_OK;
+	auto zero = [&](float* ptr, int64_t n) {
+		if (ptr && hipMemsetAsync(ptr, 0, n * sizeof(float), s) != hipSuccess && mrc == FIND_OK) {
+			set_error("find_mlp_bwd: hipMemsetAsync failed");
+			mrc = FIND_ELAUNCH;
+		}
+	};
 	if (!act_d) {
 		zero(g->disp_w[0], (int64_t)W * ld_d0); zero(g->disp_b[0], W);
 		for (int i = 1; i < p->n_disp; ++i) { zero(g->disp_w[i], (int64_t)W * W); zero(g->disp_b[i], W); }
@@ -782,8 +730,9 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	if (!act_d && !act_c) {
 		zero(g->trunk_w[0], (int64_t)W * K0); zero(g->trunk_b[0], W);
 		for (int i = 1; i < p->n_trunk; ++i) { zero(g->trunk_w[i], (int64_t)W * W); zero(g->trunk_b[i], W); }
-		return FIND_OK;
+		return mrc;
 	}
+	if (mrc != FIND_OK) return mrc;
 
 	// 1. transposed weights for the dX GEMMs
 	{
@@ -801,7 +750,7 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	}
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
-	int cd = 0, cc = 0;  // current ping-pong index per head
+	int cd = 0, cc = 0;  // current dZ buffer per head
 	{
 		HeadOutBwdArgs h;
 		memset(&h, 0, sizeof(h));
@@ -827,58 +776,53 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 	const float* hl = w.H[p->n_trunk - 1];
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 
-	// 3. heads, last hidden layer down to the first
+	// 3. heads, last hidden layer down to the first.  Weight-gradient work (dW / db / latent gradients only feed the outputs, never
+	// the dX chain) goes to the side streams; every layer's dZ has its own buffer, so the dX chain on the caller's stream never waits.
 	int big_toggle = 0;
-	hipEvent_t set_free[2] = {nullptr, nullptr};
+	hipEvent_t set_free[2] = {nullptr, nullptr};   // fires when the slab set's previous reduce (on R) has read it
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
-		for (int l = nl - 1; l >= 1; --l) {  // (one dZ buffer per layer: the dX chain never waits for the weight gradients)
-			fork();
-			// the large layers alternate between two slab sets and hand their slab reduce to stream qr: the reduce (LDS-using, so
-			// it only gets a CU when a ring kernel's workgroup retires) no longer sits between two dw2 launches on q
-			int r;
-			if (ss && g_reduce_stream) {
+		for (int l = nl - 1; l >= 1; --l) {
+			fk.fork_to(Q);
+			// the large layers alternate between two slab sets and hand their slab reduce to stream R: the reduce (LDS-using, so
+			// it only gets a CU when a ring kernel's workgroup retires) no longer sits between two dw2 launches on Q
+			if (fk.on && c->reduce_stream) {
 				const int si = big_toggle & 1;
 				big_toggle += 1;
 				BwdWs bk = b;
 				bk.pw = b.pw_t[si ? 3 : 0]; bk.pb = b.pb_t[si ? 3 : 0];
-				if (set_free[si]) (void)hipStreamWaitEvent(q, set_free[si], 0);   // the set's previous reduce has read it
-				r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, q, ss->qr, next_event());
-				set_free[si] = next_event();
-				(void)hipEventRecord(set_free[si], ss->qr);
+				fk.wait(Q, set_free[si]);
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R));
+				set_free[si] = fk.mark(R);
 			} else {
-				r = weight_grad(dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, q);
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q)));
 			}
-			if (r != FIND_OK) return r;
-			linear_bwd_dx(dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s);
+			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s));
 			cur += 1;
 		}
-		int r;
 		float* db_late = nullptr;
-		hipStream_t q0 = q;
+		hipStream_t q0;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
 			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps);
 			// the foot-summed first layer is a small launch: its own side stream and slab set, so that it does not queue behind the
-			// large weight-gradient launches on q.  The per-foot column sums go there too: only the latent / bias gradients read them,
-			// and on the caller's stream the small reduce (LDS-using, so it cannot share a CU with the ring kernels any more) waited
-			// for a CU behind a whole round of dw2 workgroups with the dX chain queued behind it (step time unchanged: 2.32 ms).
-			q0 = ss ? ss->qt[side] : s;
+			// large weight-gradient launches on Q.  The per-foot column sums go there too: only the latent / bias gradients read them.
+			fk.fork_to(side);
+			q0 = fk.stream(side);
 			BwdWs bk = b;
 			bk.pw = b.pw_t[side]; bk.pb = b.pb_t[side];
-			fork_to(q0);
 			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, q0, ps, b.nblk_fs, (int)n_feet, S);
 			// (the bias gradient -- S summed over feet -- rides along with the latent-gradient launch when there is one)
 			if (L > 0) db_late = gb[0];
 			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, q0, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
-			r = weight_grad(zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0);
+			FIND_TRY(weight_grad(c, &fk, zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0));
 		} else {
-			fork();
-			if (set_free[0]) (void)hipStreamWaitEvent(q, set_free[0], 0);   // set 0 may still be read by a reduce on qr
-			r = weight_grad(dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, q);
+			fk.fork_to(Q);
+			q0 = fk.stream(Q);
+			fk.wait(Q, set_free[0]);   // set 0 may still be read by a reduce on R
+			FIND_TRY(weight_grad(c, &fk, dzbuf[cur], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, b, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, q0));
 		}
-		if (r != FIND_OK) return r;
 		if (L > 0) {
 			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W + (db_late ? 1 : 0))), dim3(256), 0, q0, w0full, ld0, lat, L, S, (int)n_feet, glat,
 							   gw[0], db_late);
@@ -886,14 +830,8 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		}
 		return FIND_OK;
 	};
-	if (act_d) {
-		rc = head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS, 1);
-		if (rc != FIND_OK) return rc;
-	}
-	if (act_c) {
-		rc = head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2, 2);
-		if (rc != FIND_OK) return rc;
-	}
+	if (act_d) FIND_TRY(head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS, T1));
+	if (act_c) FIND_TRY(head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2, T2));
 
 	// 4. gradient wrt the trunk output: both heads (and, for a shared trunk, every foot) summed in the K loop
 	int ct = 0;
@@ -905,128 +843,194 @@ extern "C" int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t 
 		a.nbase = nb; a.a0 = A[0]; a.w0 = Wt[0];
 		if (nb > 1) { a.a1 = A[1]; a.w1 = Wt[1]; }
 		a.lda = W; a.ldw = W; a.nchunk = W / KC;
-		a.nseg_per_base = 1; a.a_seg_stride = 0;
 		a.a_foot_stride = d.shared ? 0 : V * W;  // shared: the foot-summed (V,256) matrices
 		a.mask = hl; a.mask_foot_stride = V * W;
 		a.y = b.dzT[ct]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-		launch_gemm(AMODE_MAT, EPI_MASK, a, d.feet_t, s);
+		FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_MASK, a, d.feet_t, s));
 		FIND_LAUNCH_CHECK("trunk-out dX gemm");
 	}
 
-	// 5. trunk
-	{
-		// every layer's dZ has its own buffer (the trunk is small): the dX chain runs back to back on the caller's stream while the
-		// weight gradients follow on the side stream -- a cross-stream wait costs ~10 us here even when it is already satisfied
-		// the layers' weight gradients are independent of each other and each fills a fraction of the chip: round-robin over the side
-		// streams (own slab set each) so that they overlap; set 0 / stream q stays in order behind the heads' work
-		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			const int k = ss ? 1 + (l & 1) : 0;  // (q / set 0 keeps the heads' large launches and the Fourier layer)
-			hipStream_t qk = ss ? ss->qt[k] : s;
-			BwdWs bk = b;
-			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
-			fork_to(qk);
-			rc = weight_grad(b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, qk);
-			if (rc != FIND_OK) return rc;
-			linear_bwd_dx(b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s);
-			ct += 1;
-		}
-		fork();
-		if (set_free[0]) (void)hipStreamWaitEvent(q, set_free[0], 0);
-		rc = weight_grad(b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, q);
-		if (rc != FIND_OK) return rc;
-		// join: the caller's stream continues only after every gradient is written
-		if (ss) {
-			for (int i = 0; i < N_SIDE; ++i) {
-				if (i > 0 && ss->qt[i] == ss->q) continue;
-				hipEvent_t e = next_event();
-				(void)hipEventRecord(e, ss->qt[i]);
-				(void)hipStreamWaitEvent(s, e, 0);
-			}
-			if (ss->qr != ss->q) {
-				hipEvent_t e = next_event();
-				(void)hipEventRecord(e, ss->qr);
-				(void)hipStreamWaitEvent(s, e, 0);
-			}
-		}
+	// 5. trunk: the dX chain runs back to back on the caller's stream, the layers' weight gradients -- independent of each other,
+	// each filling a fraction of the chip -- alternate between T1 and T2 (own slab set each); Q / set 0 keeps the Fourier layer
+	for (int l = p->n_trunk - 1; l >= 1; --l) {
+		const int k = fk.on ? 1 + (l & 1) : 0;
+		BwdWs bk = b;
+		bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
+		fk.fork_to(k);
+		FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+		FIND_TRY(linear_bwd_dx(c, b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s));
+		ct += 1;
 	}
+	fk.fork_to(Q);
+	fk.wait(Q, set_free[0]);
+	FIND_TRY(weight_grad(c, &fk, b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(Q)));
 	FIND_LAUNCH_CHECK("find_mlp_bwd");
 	return FIND_OK;
 }
 
-// Tuning hook (not part of the reference surface): "gemm" -> 0 register-staged tiles, 64 / 128 persistent LDS-DMA tiles.
-extern "C" int find_set_tuning(const char* key, int64_t value) {
-	FIND_REQUIRE(key != nullptr, "find_set_tuning: NULL key");
-	if (strcmp(key, "dbg") == 0) {  // device pointer to >= 4*grid uint64 (profiling only)
-		g_dbg = reinterpret_cast<unsigned long long*>(value);
-		return FIND_OK;
+}  // namespace mlp
+}  // namespace find
+
+// Slabs of one weight-gradient launch: up to max(512, feet) + feet + 16 partial 256x256 tiles and as many 256-float bias rows.
+static int64_t wgrad_slabs(int64_t n_feet) { return std::max<int64_t>(512, n_feet) + n_feet + 16; }
+
+extern "C" int64_t find_linear_wgrad_scratch_bytes(int64_t n_feet) {
+	if (n_feet < 1) return -1;
+	return wgrad_slabs(n_feet) * ((int64_t)W * W + W) * (int64_t)sizeof(float);
+}
+
+extern "C" int find_linear_wgrad(find_ctx* c, const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
+								 void* scratch, int64_t scratch_bytes, void* stream) {
+	FIND_TRY(check_ctx(c, "find_linear_wgrad"));
+	FIND_REQUIRE(dz && x && dw && scratch, "find_linear_wgrad: NULL argument");
+	FIND_REQUIRE(n_feet >= 1 && n_pts >= 1 && n_feet < (1 << 16), "find_linear_wgrad: bad sizes");
+	FIND_REQUIRE(aligned16(dz) && aligned16(x) && aligned16(scratch), "find_linear_wgrad: dz, x and scratch must be 16-byte aligned");
+	if (scratch_bytes < find_linear_wgrad_scratch_bytes(n_feet)) {
+		set_error("find_linear_wgrad: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)find_linear_wgrad_scratch_bytes(n_feet));
+		return FIND_EWORKSPACE;
 	}
-	if (strcmp(key, "ablate") == 0) {
-		g_ablate = (int)value;
-		return FIND_OK;
+	BwdWs b;
+	memset(&b, 0, sizeof(b));
+	b.pw = static_cast<float*>(scratch);
+	b.pb = b.pw + wgrad_slabs(n_feet) * W * W;
+	c->f16 = c->mlp_f16 != 0;
+	FIND_TRY(weight_grad(c, nullptr, dz, x, n_pts * W, nullptr, 0, nullptr, 1, n_feet, n_pts, b, dw, W, W, 0, db, nullptr, reinterpret_cast<hipStream_t>(stream)));
+	FIND_LAUNCH_CHECK("find_linear_wgrad");
+	return FIND_OK;
+}
+
+extern "C" int64_t find_mlp_bwd_scratch_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts) {
+	Dims d;
+	if (make_dims(p, pos_batch, n_feet, n_pts, &d) != FIND_OK) return -1;
+	BwdWs b;
+	carve_bwd(p, d, nullptr, &b);
+	return b.bytes;
+}
+
+extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+							const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col,
+							const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
+							const find_mlp_grads* g, void* stream) {
+	FIND_TRY(check_ctx(c, "find_mlp_bwd"));
+	Dims d;
+	FIND_TRY(make_dims(p, pos_batch, n_feet, n_pts, &d));
+	FIND_TRY(check_weights(p));
+	FIND_REQUIRE(pos && ws && scratch && g, "find_mlp_bwd: NULL argument");
+	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
+	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
+	FIND_REQUIRE(p->precision >= 0 && p->precision <= 2, "find_mlp_bwd: params.precision must be 0, 1 or 2 (got %d)", p->precision);
+	FwdWs w;
+	carve_fwd(p, d, true, const_cast<void*>(ws), &w);
+	if (ws_bytes < w.bytes) {
+		set_error("find_mlp_bwd: forward workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)w.bytes);
+		return FIND_EWORKSPACE;
 	}
-	if (strcmp(key, "raster_ablate") == 0) {
-		find::g_raster_ablate = (int)value;
-		return FIND_OK;
+	BwdWs b;
+	carve_bwd(p, d, scratch, &b);
+	if (scratch_bytes < b.bytes) {
+		set_error("find_mlp_bwd: scratch too small (%lld < %lld)", (long long)scratch_bytes, (long long)b.bytes);
+		return FIND_EWORKSPACE;
 	}
-	if (strcmp(key, "gemm4_small") == 0) {
-		g_gemm4_small = (int)value;
-		return FIND_OK;
-	}
-	if (strcmp(key, "dw_pe_target") == 0) {
-		FIND_REQUIRE(value >= 16, "find_set_tuning: dw_pe_target must be >= 16");
-		g_dw_pe_target = (int)value;
-		return FIND_OK;
-	}
-	if (strcmp(key, "dw2_min_cps") == 0) {
-		FIND_REQUIRE(value >= 1, "find_set_tuning: dw2_min_cps must be >= 1");
-		g_dw2_min_cps = (int)value;
-		return FIND_OK;
-	}
-	if (strcmp(key, "dw2") == 0) {
-		g_dw2 = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "fwd_streams") == 0) {
-		g_fwd_streams = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "reduce_stream") == 0) {
-		g_reduce_stream = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "gemm5_min_units") == 0) {
-		g_gemm5_min_units = (int)value;
-		return FIND_OK;
-	}
-	if (strcmp(key, "mlp_f16") == 0) {
-		g_mlp_f16 = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "lds_exclusive") == 0) {  // 0 reproduces the co-residence fault described at CU_LDS_BYTES (diagnosis only)
-		g_lds_exclusive = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "bwd_streams") == 0) {
-		g_bwd_streams = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "gemm4") == 0) {
-		g_gemm4 = value != 0;
+	c->f16 = call_f16(c, p);
+	Fork fk(c, reinterpret_cast<hipStream_t>(stream), c->bwd_streams != 0);
+	const int rc = mlp_bwd_body(c, fk, p, d, w, b, pos, lat_disp, lat_col, d_disp, d_col, g);
+	// join on EVERY path: the caller's stream continues only after every side stream this call touched has finished, so scratch,
+	// workspace and gradient buffers may be freed (stream-ordered) as soon as the call returns -- also after an error
+	const int rj = fk.join();
+	return rc != FIND_OK ? rc : rj;
+}
+
+// ------------------------------------------------------------------------------------------- context
+extern "C" int find_ctx_create(int device, find_ctx** out) {
+	FIND_REQUIRE(out != nullptr, "find_ctx_create: out is NULL");
+	*out = nullptr;
+	int prev = 0, ndev = 0;
+	FIND_HIP_OK(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+	FIND_REQUIRE(device >= 0 && device < ndev, "find_ctx_create: device %d out of range (%d visible)", device, ndev);
+	FIND_HIP_OK(hipGetDevice(&prev), "hipGetDevice");
+	FIND_HIP_OK(hipSetDevice(device), "hipSetDevice");
+	find_ctx* c = new find_ctx();
+	c->device = device;
+	auto fail = [&](const char* what, hipError_t e) {
+		set_error("find_ctx_create: %s: %s", what, hipGetErrorString(e));
+		for (int i = 0; i < c->n_events; ++i) (void)hipEventDestroy(c->ev[i]);
+		for (int i = 0; i < N_SIDE; ++i) if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+		delete c;
+		(void)hipSetDevice(prev);
+		return FIND_ELAUNCH;
+	};
+	hipError_t e;
+	int v = 0;
+	if ((e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail("CU count", e);
+	c->num_cus = v > 0 ? v : 256;
+	if ((e = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("LDS size", e);
+	c->lds_bytes = v;
+	for (int i = 0; i < N_SIDE; ++i)
+		if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreateWithFlags", e);
+	for (c->n_events = 0; c->n_events < N_EVENTS; ++c->n_events)
+		if ((e = hipEventCreateWithFlags(&c->ev[c->n_events], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", e);
+	FIND_HIP_OK(hipSetDevice(prev), "hipSetDevice");
+	*out = c;
+	return FIND_OK;
+}
+
+extern "C" int find_ctx_destroy(find_ctx* c) {
+	if (!c) return FIND_OK;
+	int prev = 0;
+	(void)hipGetDevice(&prev);
+	(void)hipSetDevice(c->device);
+	for (int i = 0; i < N_SIDE; ++i) if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+	for (int i = 0; i < c->n_events; ++i) (void)hipEventDestroy(c->ev[i]);
+	(void)hipSetDevice(prev);
+	delete c;
+	return FIND_OK;
+}
+
+namespace {
+struct Knob { const char* key; int find_ctx::*field; int64_t lo, hi; };
+const Knob KNOBS[] = {
+	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
+	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
+	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+};
+}  // namespace
+
+extern "C" int find_ctx_set(find_ctx* c, const char* key, int64_t value) {
+	FIND_REQUIRE(c != nullptr && key != nullptr, "find_ctx_set: NULL argument");
+	if (strcmp(key, "dbg") == 0) {  // device pointer to >= 4 * grid uint64 (profiling only)
+		c->dbg = reinterpret_cast<unsigned long long*>(value);
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm4_min_units") == 0) {
-		g_gemm4_min_units = value;
+		FIND_REQUIRE(value >= 0, "find_ctx_set: gemm4_min_units must be >= 0");
+		c->gemm4_min_units = value;
 		return FIND_OK;
 	}
-	if (strcmp(key, "gemm3") == 0) {
-		g_gemm3 = value != 0;
-		return FIND_OK;
-	}
-	if (strcmp(key, "gemm") == 0) {
-		FIND_REQUIRE(value == 0 || value == 64 || value == 128, "find_set_tuning: gemm must be 0, 64 or 128");
-		g_gemm_mode = (int)value;
-		return FIND_OK;
-	}
-	set_error("find_set_tuning: unknown key %s", key);
+	for (const Knob& k : KNOBS)
+		if (strcmp(key, k.key) == 0) {
+			FIND_REQUIRE(value >= k.lo && value <= k.hi, "find_ctx_set: %s = %lld out of range [%lld, %lld]", key, (long long)value, (long long)k.lo, (long long)k.hi);
+			c->*(k.field) = (int)value;
+			return FIND_OK;
+		}
+	set_error("find_ctx_set: unknown key %s", key);
 	return FIND_EINVAL;
+}
+
+extern "C" int find_ctx_get(const find_ctx* c, const char* key, int64_t* value) {
+	FIND_REQUIRE(c != nullptr && key != nullptr && value != nullptr, "find_ctx_get: NULL argument");
+	if (strcmp(key, "num_cus") == 0) { *value = c->num_cus; return FIND_OK; }
+	if (strcmp(key, "lds_bytes") == 0) { *value = c->lds_bytes; return FIND_OK; }
+	if (strcmp(key, "device") == 0) { *value = c->device; return FIND_OK; }
+	if (strcmp(key, "events_per_call_max") == 0) { *value = c->events_per_call_max; return FIND_OK; }
+	if (strcmp(key, "gemm4_min_units") == 0) { *value = c->gemm4_min_units; return FIND_OK; }
+	for (const Knob& k : KNOBS)
+		if (strcmp(key, k.key) == 0) { *value = c->*(k.field); return FIND_OK; }
+	set_error("find_ctx_get: unknown key %s", key);
+	return FIND_EINVAL;
+}
+
+extern "C" int find_debug_raster_ablate(int64_t bits) {
+	find::g_raster_ablate = (int)bits;
+	return FIND_OK;
 }

@@ -88,137 +88,6 @@ struct GemmArgs {
 enum { AMODE_MAT = 0, AMODE_PE = 1 };
 enum { EPI_NONE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2 };
 
-template <int BM, int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-	constexpr int WM = (BM >= 64) ? 2 : 1;
-	constexpr int WN = 4 / WM;
-	constexpr int MI = BM / (32 * WM);
-	constexpr int NI = W / (32 * WN);
-	constexpr int AV = BM / 32;  // float4 A loads per thread per chunk
-
-	__shared__ __attribute__((aligned(16))) float As[BM * LDSLD];
-	__shared__ __attribute__((aligned(16))) float Bs[W * LDSLD];
-	__shared__ float Bl[(AMODE == AMODE_PE) ? 3 * 256 : 4];
-
-	const int tid = threadIdx.x;
-	const int lane = tid & 63;
-	const int wave = tid >> 6;
-	const int wm = wave / WN, wn = wave % WN;
-	const int foot = blockIdx.y;
-	const int v0 = blockIdx.x * BM;
-	const int lr = tid >> 3;          // loader row within a 32-row group
-	const int lc = (tid & 7) * 4;     // loader column (float4)
-
-	float px[AV], py[AV], pz[AV];
-	if constexpr (AMODE == AMODE_PE) {
-		for (int i = tid; i < 3 * g.pe; i += 256) Bl[i] = g.Bm[i];
-		const float* pp = g.pos + (int64_t)foot * g.pos_foot_stride;
-#pragma unroll
-		for (int i = 0; i < AV; ++i) {
-			const int v = v0 + lr + 32 * i;
-			const bool ok = v < g.V;
-			px[i] = ok ? pp[(int64_t)v * 3 + 0] : 0.f;
-			py[i] = ok ? pp[(int64_t)v * 3 + 1] : 0.f;
-			pz[i] = ok ? pp[(int64_t)v * 3 + 2] : 0.f;
-		}
-		__syncthreads();
-	}
-
-	f32x16 acc[MI][NI];
-#pragma unroll
-	for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-		for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-			for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-	float4 ra[AV], rb[8];
-	const int total = g.nbase * g.nseg_per_base * g.nchunk;
-
-	auto load_chunk = [&](int tc) {
-		const int seg = tc / g.nchunk;
-		const int c = tc - seg * g.nchunk;
-		const int base = seg / g.nseg_per_base;
-		const int s = seg - base * g.nseg_per_base;
-		const float* wp = (base ? g.w1 : g.w0) + c * KC + lc;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const float4*>(wp + (int64_t)(lr + 32 * i) * g.ldw);
-		if constexpr (AMODE == AMODE_MAT) {
-			const float* ap = (base ? g.a1 : g.a0) + (int64_t)s * g.a_seg_stride + (int64_t)foot * g.a_foot_stride + c * KC + lc;
-#pragma unroll
-			for (int i = 0; i < AV; ++i) {
-				const int v = v0 + lr + 32 * i;
-				ra[i] = (v < g.V) ? *reinterpret_cast<const float4*>(ap + (int64_t)v * g.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
-			}
-		} else {
-#pragma unroll
-			for (int i = 0; i < AV; ++i) {
-				const int kp = c * KC + lc;
-				ra[i].x = pe_value(kp + 0, g.pe, px[i], py[i], pz[i], Bl);
-				ra[i].y = pe_value(kp + 1, g.pe, px[i], py[i], pz[i], Bl);
-				ra[i].z = pe_value(kp + 2, g.pe, px[i], py[i], pz[i], Bl);
-				ra[i].w = pe_value(kp + 3, g.pe, px[i], py[i], pz[i], Bl);
-			}
-		}
-	};
-
-	load_chunk(0);
-	for (int tc = 0; tc < total; ++tc) {
-		__syncthreads();  // previous chunk's LDS reads are done
-#pragma unroll
-		for (int i = 0; i < AV; ++i) *reinterpret_cast<float4*>(&As[(lr + 32 * i) * LDSLD + lc]) = ra[i];
-#pragma unroll
-		for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(&Bs[(lr + 32 * i) * LDSLD + lc]) = rb[i];
-		__syncthreads();
-		if (tc + 1 < total) load_chunk(tc + 1);  // global loads fly under the MFMAs below
-
-		const int arow = (wm * MI * 32 + (lane & 31)) * LDSLD + (lane >> 5) * 4;
-		const int brow = (wn * NI * 32 + (lane & 31)) * LDSLD + (lane >> 5) * 4;
-#pragma unroll
-		for (int j = 0; j < KC / 8; ++j) {
-			float4 af[MI], bf[NI];
-#pragma unroll
-			for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const float4*>(&As[arow + mi * 32 * LDSLD + j * 8]);
-#pragma unroll
-			for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const float4*>(&Bs[brow + ni * 32 * LDSLD + j * 8]);
-#pragma unroll
-			for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) {
-					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
-				}
-		}
-	}
-
-	// epilogue: lane holds column (lane&31) of 16 rows per 32x32 block
-	float* yp = g.y + (int64_t)foot * g.y_foot_stride;
-	const float* mp = (EPI == EPI_MASK) ? g.mask + (int64_t)foot * g.mask_foot_stride : nullptr;
-#pragma unroll
-	for (int ni = 0; ni < NI; ++ni) {
-		const int col = wn * NI * 32 + ni * 32 + (lane & 31);
-		float bv = 0.f;
-		if constexpr (EPI == EPI_BIAS_RELU) bv = g.bias[(int64_t)foot * g.bias_foot_stride + col];
-#pragma unroll
-		for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				const int row = wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-				const int v = v0 + row;
-				if (v < g.V) {
-					float val = acc[mi][ni][r];
-					const int64_t o = (int64_t)v * g.ldy + col;
-					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv, 0.f);
-					if constexpr (EPI == EPI_MASK) val = (mp[o] > 0.f) ? val : 0.f;
-					yp[o] = val;
-				}
-			}
-		}
-	}
-}
-
 // ---------------------------------------------------------------------------------------------
 // Weight gradient  dW[n, k] = sum_rows dZ[row, n] * X[row, k]   (split over rows; partial slabs)
 // One 512-thread workgroup owns a full 256(n) x 256(k) tile so dZ and X are each read once.

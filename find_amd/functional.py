@@ -83,18 +83,23 @@ def _grads_like(tensors):
 class MLPSpec:
 	"""Static description of the network (layer counts / sizes) shared by forward and backward."""
 
-	def __init__(self, n_trunk, n_disp, n_col, pe_size, lat_disp, lat_col, in_dim=3, width=256):
+	def __init__(self, n_trunk, n_disp, n_col, pe_size, lat_disp, lat_col, in_dim=3, width=256, precision=None):
 		self.n_trunk, self.n_disp, self.n_col = n_trunk, n_disp, n_col
 		self.pe_size, self.lat_disp, self.lat_col = pe_size, lat_disp, lat_col
 		self.in_dim, self.width = in_dim, width
+		self.precision = precision   # None: the process default (set_mlp_precision); 'fp32' / 'fp16': this model only
 
 	@property
 	def n_weights(self):
 		return 2 * (self.n_trunk + self.n_disp + 1 + self.n_col + 1)
 
 
+_PRECISION_CODE = {None: 0, 'fp32': 1, 'fp16': 2}
+
+
 def _fill_params(spec, B, avg_col, weights):
 	p = MlpParams()
+	p.precision = _PRECISION_CODE[spec.precision if spec.precision is not None else _MLP_PRECISION]
 	p.width, p.in_dim, p.pe_size = spec.width, spec.in_dim, spec.pe_size
 	p.n_trunk, p.n_disp, p.n_col = spec.n_trunk, spec.n_disp, spec.n_col
 	p.lat_disp, p.lat_col = spec.lat_disp, spec.lat_col
@@ -142,10 +147,11 @@ class _MLP(torch.autograd.Function):
 		ws = _ws(nbytes, pos.device)
 		disp = torch.empty(n_feet, V, 3, device=pos.device, dtype=torch.float32)
 		col = torch.empty(n_feet, V, 3, device=pos.device, dtype=torch.float32)
-		check(L.find_mlp_fwd(ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(disp), ptr(col),
+		check(L.find_mlp_fwd(_lib.ctx(pos.device), ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(disp), ptr(col),
 							 ptr(ws), ws.numel(), int(save), current_stream(pos.device)), 'find_mlp_fwd')
 		if save:
 			ctx.spec = spec
+			ctx.precision = p.precision
 			ctx.dims = (pos_batch, n_feet, V)
 			ctx.ws = ws
 			ctx.save_for_backward(pos, lat_disp, lat_col, B, avg_col, *weights)
@@ -159,6 +165,7 @@ class _MLP(torch.autograd.Function):
 		pos_batch, n_feet, V = ctx.dims
 		g_disp, g_col = _c(g_disp), _c(g_col)
 		p = _fill_params(spec, B, avg_col, weights)
+		p.precision = ctx.precision   # the arithmetic the forward ran in, whatever the default is by now
 		grads = _grads_like(weights)
 		g_lat_disp = torch.empty_like(lat_disp) if lat_disp is not None else None
 		g_lat_col = torch.empty_like(lat_col) if lat_col is not None else None
@@ -177,7 +184,7 @@ class _MLP(torch.autograd.Function):
 		G.lat_col = None if g_lat_col is None else g_lat_col.data_ptr()
 		sb = L.find_mlp_bwd_scratch_bytes(ctypes.byref(p), pos_batch, n_feet, V)
 		scratch = _ws(sb, pos.device)
-		check(L.find_mlp_bwd(ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
+		check(L.find_mlp_bwd(_lib.ctx(pos.device), ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
 							 ptr(ctx.ws), ctx.ws.numel(), ptr(scratch), scratch.numel(), ctypes.byref(G),
 							 current_stream(pos.device)), 'find_mlp_bwd')
 		return (None, None, g_lat_disp, g_lat_col, None, None, *grads)
@@ -483,7 +490,8 @@ _MLP_PRECISION = 'fp32'
 
 
 def set_mlp_precision(precision):
-	"""Arithmetic of the MLP's 256 -> 256 layers (forward and the dX chain of the backward), process-wide.
+	"""Default arithmetic of the MLP's 256 -> 256 layers (forward, the dX chain and the weight gradients) for every model whose MLPSpec
+	names no precision of its own (model.set_mlp_precision / MLPSpec.precision); also the mode of the isolated-kernel entry points.
 	'fp32' (default): exact fp32 MFMA -- the reference's arithmetic (no AMP anywhere in FIND) and the parity path.
 	'fp16': both MFMA operands rounded to fp16, fp32 accumulation and fp32 tensors in memory (BASELINE.json configs[4], "fp16 MLP
 	with MFMA tiles"); layer outputs then differ from fp32 by ~1e-3 relative.  Covers the forward Linear layers, the dX chain and the
@@ -491,11 +499,12 @@ def set_mlp_precision(precision):
 	launches, e.g. the shared trunk's template rows, are faster on the fp32 kernels and stay there; the Fourier layer, the 3-wide output layers, the two-segment
 	trunk-output gradient, bias / latent gradients and everything outside the MLP stay fp32.  Operands are rounded, not scaled:
 	activations or gradients beyond fp16's range (|x| > 65504) become inf and magnitudes under 6e-8 vanish -- FIND's activations are
-	O(1) and its dZ O(1e-6 .. 1e-1), but a loss scaled far outside that is the caller's responsibility.  Returns the previous setting."""
+	O(1) and its dZ O(1e-6 .. 1e-1), but a loss scaled far outside that is the caller's responsibility.  The precision travels with
+	each call (find_mlp_params.precision): a backward always runs in the arithmetic of its forward.  Returns the previous setting."""
 	global _MLP_PRECISION
 	if precision not in ('fp32', 'fp16'):
 		raise ValueError(f"set_mlp_precision: 'fp32' or 'fp16', got {precision!r}")
-	_lib.check(_lib.lib().find_set_tuning(b'mlp_f16', int(precision == 'fp16')), 'find_set_tuning(mlp_f16)')
+	_lib.set_tuning('mlp_f16', int(precision == 'fp16'))   # the isolated-kernel entry points (find_linear_*) read the context's knob
 	prev, _MLP_PRECISION = _MLP_PRECISION, precision
 	return prev
 

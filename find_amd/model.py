@@ -301,6 +301,13 @@ class NeuralDisplacementField(Model):
 		self.onnx_mode = False
 
 	# ------------------------------------------------------------------ helpers
+	def set_mlp_precision(self, precision):
+		"""Arithmetic of THIS model's 256 -> 256 layers: 'fp32', 'fp16' (opt-in, find_amd.functional.set_mlp_precision for what it
+		means) or None = follow the process default.  Two models in one process may differ."""
+		if precision not in (None, 'fp32', 'fp16'):
+			raise ValueError(f"set_mlp_precision: None, 'fp32' or 'fp16', got {precision!r}")
+		self._spec.precision = precision
+
 	def _rebuild_template_mesh(self):
 		self.template_mesh = Meshes(verts=self.template_verts.data, faces=self.template_faces.data[0])
 

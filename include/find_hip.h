@@ -5,14 +5,17 @@
  * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer adds.
  *
  * Conventions
- *   - All pointers are DEVICE pointers owned by the caller (PyTorch-allocated); the library allocates
- *     nothing and keeps no state.  Scratch is passed in as `ws` + `ws_bytes`; query sizes with *_ws_bytes().
+ *   - All pointers are DEVICE pointers owned by the caller (PyTorch-allocated); the library allocates no device
+ *     memory.  Scratch is passed in as `ws` + `ws_bytes`; query sizes with *_ws_bytes().  The only persistent
+ *     state is the opaque per-device context of find_ctx_create (internal HIP streams / events of the MLP entry
+ *     points, per-kernel launch attributes, tuning knobs): nothing is process-global.
  *   - All tensors are contiguous row-major fp32 unless stated; indices are int32 or int64 as stated.
  *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
  *     and performs no device synchronisation.
  *   - Return value: 0 on success, negative FIND_E* code otherwise; find_last_error() returns a
  *     thread-local message.  Nothing throws across the ABI.
- *   - Threading: call from the thread that owns the stream; one process per GPU under data parallelism.
+ *   - Threading: a context is used by one thread at a time (the thread that owns the autograd graph); one
+ *     context per device and process under data parallelism.  Entry points without a context are re-entrant.
  */
 #ifndef FIND_HIP_H
 #define FIND_HIP_H
@@ -23,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FIND_ABI_VERSION 1
+#define FIND_ABI_VERSION 2
 
 #define FIND_OK 0
 #define FIND_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -36,6 +39,22 @@ int find_abi_version(void);
 const char* find_last_error(void);
 /* Name of the code-object architecture the library was built for ("gfx950"). */
 const char* find_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Context: per-device state of the MLP entry points -- the internal side streams and the event pool
+ * that find_mlp_fwd / find_mlp_bwd fork work onto (always joined back into the caller's stream before the call
+ * returns, also on an error return), the device's CU count and LDS size, per-kernel launch attributes and the
+ * tuning knobs.  The reference has no counterpart (its operators keep their state inside PyTorch / PyTorch3D).
+ * find_ctx_create makes `device` current for the calling thread while it builds the context and restores the
+ * previous device.  A context must be destroyed only after the work launched through it has completed.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct find_ctx find_ctx;
+int find_ctx_create(int device, find_ctx** out);
+int find_ctx_destroy(find_ctx* ctx);
+/* Knobs (see the list at find_ctx_set below); find_ctx_get reads the current value, plus the read-only
+ * "num_cus", "lds_bytes", "device", "events_per_call_max" (largest event count one MLP call has used so far). */
+int find_ctx_set(find_ctx* ctx, const char* key, int64_t value);
+int find_ctx_get(const find_ctx* ctx, const char* key, int64_t* value);
 
 /* ------------------------------------------------------------------------------------------------
  * MLP: Fourier positional encoding + trunk + displacement head + colour head.
@@ -66,6 +85,9 @@ typedef struct find_mlp_params {
 	const float* col_w[FIND_MAX_LAYERS];
 	const float* col_b[FIND_MAX_LAYERS];
 	const float* avg_col; /* (3) added to the colour output when non-NULL (use_avg_colour, model.py:446-447) */
+	int32_t precision;    /* arithmetic of the 256 -> 256 layers: 0 = the context's "mlp_f16" knob (default fp32), 1 = fp32 (the
+	                       * reference's arithmetic, the parity path), 2 = fp16 MFMA operands with fp32 accumulation (opt-in,
+	                       * BASELINE.json configs[4]; no reference counterpart) -- per call, so two models in one process may differ */
 } find_mlp_params;
 
 /* Gradient outputs, same shapes as the corresponding weights; every buffer is OVERWRITTEN. */
@@ -87,14 +109,14 @@ int64_t find_mlp_ws_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n
 
 /* pos (pos_batch, n_pts, 3); lat_disp (n_feet, lat_disp) or NULL; lat_col (n_feet, lat_col) or NULL;
  * out: disp (n_feet, n_pts, 3) = 0.1*tanh(.), col (n_feet, n_pts, 3) = 0.5*(1+tanh(.)) [+avg_col]. */
-int find_mlp_fwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+int find_mlp_fwd(find_ctx* ctx, const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
 				 const float* lat_disp, const float* lat_col, float* disp, float* col,
 				 void* ws, int64_t ws_bytes, int save_for_bwd, void* stream);
 
 /* Backward of find_mlp_fwd.  d_disp, d_col: (n_feet, n_pts, 3) upstream gradients (either may be NULL = zero).
  * `ws` is the forward workspace (save_for_bwd=1); `scratch` is extra space of find_mlp_bwd_scratch_bytes(). */
 int64_t find_mlp_bwd_scratch_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts);
-int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
+int find_mlp_bwd(find_ctx* ctx, const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
 				 const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col,
 				 const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
 				 const find_mlp_grads* grads, void* stream);
@@ -102,7 +124,7 @@ int find_mlp_bwd(const find_mlp_params* p, const float* pos, int64_t pos_batch, 
 /* One hidden layer  y = relu(x @ w^T + b)  with x (n_feet*n_pts, 256), w (256,256), b (256): the dominant kernel
  * of the path (nn.Linear + nn.ReLU pairs built at src/model/model.py:255-257, 353-356, 362-365).  Exposed so the
  * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
-int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
+int find_linear_relu_fwd(find_ctx* ctx, const float* x, const float* w, const float* b, int64_t n_feet, int64_t n_pts, float* y, void* stream);
 
 /* Weight gradient of one 256 -> 256 layer:  dw[n][k] = sum_rows dz[row][n] * x[row][k]  (256 x 256, row-major) and, when db is not
  * NULL, db[n] = sum_rows dz[row][n], over rows = (foot, point) as above -- what autograd computes for the `weight` / `bias` of an
@@ -110,30 +132,31 @@ int find_linear_relu_fwd(const float* x, const float* w, const float* b, int64_t
  * find_linear_relu_fwd, so that the kernel (dw2_kernel; dw3_kernel in the fp16 mode) can be timed and checked in isolation;
  * find_mlp_bwd launches the same kernels.  `scratch` holds the partial tiles (find_linear_wgrad_scratch_bytes). */
 int64_t find_linear_wgrad_scratch_bytes(int64_t n_feet);
-int find_linear_wgrad(const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
+int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
 					  void* scratch, int64_t scratch_bytes, void* stream);
 
-/* Tuning / profiling hook (no reference counterpart); process-wide, not thread-safe.  Results do not depend on any knob (except "lds_exclusive" = 0 and the ablation bits).
- *   "gemm"            0 = register-staged tiles, 64 / 128 = persistent LDS-DMA kernel with that tile height (default 64)
- *   "gemm3", "gemm4"  0 / 1: early-barrier LDS-DMA kernel; W-resident kernel for K = 256 layers (defaults 1)
- *   "gemm4_min_units" launches with at least this many 32-row x 128-column units use gemm4 on column halves (default 1024)
- *   "gemm4_small"     ... and launches of at least this many 32-row units use it on column quarters (default 64; 0 = never)
- *   "dw2", "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: LDS-DMA kernel on/off, shortest row run per workgroup,
- *                     workgroups of the Fourier layer's launch
- *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on side streams (default)
+/* Tuning / profiling knobs of a context (no reference counterpart).  Results do not depend on any knob except "mlp_f16",
+ * "lds_exclusive" = 0 and the ablation bits.
+ *   "gemm4_min_units" launches with at least this many 32-row x 128-column units use the W-resident kernel on column halves (default 1024)
+ *   "gemm4_small"     ... and launches of at least this many 32-row units use it on column quarters (default 64; 0 = never);
+ *                     anything smaller, and the two-segment trunk-output gradient, runs on the LDS-DMA ring kernel (gemm3)
+ *   "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: shortest row run per workgroup, workgroups of the Fourier layer's launch
+ *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on the context's side streams (default)
  *   "fwd_streams"     1 = the forward runs the colour head on a side stream beside the displacement head (default), 0 = one stream
  *   "reduce_stream"   1 = slab reduces of the large head layers on their own stream, two alternating slab sets (default)
- *   "mlp_f16"         1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to fp16, fp32
- *                     accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES change results
- *                     (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
+ *   "mlp_f16"         default precision for calls whose find_mlp_params.precision is 0, and the precision of find_linear_relu_fwd /
+ *                     find_linear_wgrad: 1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to
+ *                     fp16, fp32 accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES
+ *                     change results (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
  *   "gemm5_min_units" in fp16 mode, launches of fewer 32-row units than this stay on the fp32 kernels (default 1024)
  *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS (default); 0 reproduces the co-residence fault
- *                     described in mlp.hip (CU_LDS_BYTES): rare wrong weight-gradient elements -- diagnosis only
- *   "raster_ablate"   profiling bits of the rasteriser (1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 K-pass
- *                     statistics in the flags): any non-zero value other than 64 makes the render WRONG
+ *                     described in mlp.hip: rare wrong weight-gradient elements -- diagnosis only
  *   "ablate", "dbg"   profiling switches of the GEMM kernels
- * The Python binding applies FIND_TUNING="key=value,..." from the environment when it loads the library. */
-int find_set_tuning(const char* key, int64_t value);
+ * The Python binding applies FIND_TUNING="key=value,..." from the environment to every context it creates. */
+
+/* Process-wide profiling switch of the rasteriser (diagnosis only; any non-zero value other than 64 makes the render WRONG):
+ * bits 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 K-pass statistics in the flags. */
+int find_debug_raster_ablate(int64_t bits);
 
 /* ------------------------------------------------------------------------------------------------
  * Latent-table lookup.  Replaces LatentVector.__getitem__ with a tensor of indices (src/model/model.py:131-152;

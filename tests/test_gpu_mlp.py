@@ -292,7 +292,7 @@ def test_linear_relu_kernel_every_routing(n_feet, n_pts):
 	b = torch.randn(256, generator=gen)
 	xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
 	y = torch.full_like(xd, float('nan'))
-	_lib.check(L.find_linear_relu_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), n_feet, n_pts, _lib.ptr(y),
+	_lib.check(L.find_linear_relu_fwd(_lib.ctx(), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), n_feet, n_pts, _lib.ptr(y),
 									  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'find_linear_relu_fwd')
 	want = np.maximum(x.numpy().astype(np.float64) @ w.numpy().astype(np.float64).T + b.numpy().astype(np.float64), 0.0)
 	got = y.cpu().numpy()
@@ -302,8 +302,8 @@ def test_linear_relu_kernel_every_routing(n_feet, n_pts):
 
 def test_backward_is_bit_reproducible_with_side_streams():
 	"""The backward is meant to be deterministic (slab reduces, no float atomics).  Regression test for a fault that showed only
-	with the weight-gradient kernels of several streams resident on one CU (mlp.hip, CU_LDS_BYTES): a few dW elements off by ~1 % in
-	some passes -- every pass when the dX GEMMs ran on gemm3 (tuning gemm4 = 0), so that configuration is screened too."""
+	with the weight-gradient kernels of several streams resident on one CU (mlp.hip, 'Co-residence fault'): a few dW elements off by ~1 % in
+	some passes -- every pass when the dX GEMMs ran on gemm3 (gemm4 switched off through its thresholds), so that configuration is screened too."""
 	from find_amd import _lib, synthetic
 	dev = torch.device('cuda:0')
 	n_feet = 4
@@ -323,7 +323,9 @@ def test_backward_is_bit_reproducible_with_side_streams():
 		return out
 
 	for gemm4 in (1, 0):
-		_lib.check(_lib.lib().find_set_tuning(b'gemm4', gemm4), 'tuning')
+		# gemm4 = 0: every 256 -> 256 launch on the LDS-DMA ring kernel (gemm3) instead of the W-resident gemm4
+		_lib.set_tuning('gemm4_min_units', 1024 if gemm4 else 10 ** 12)
+		_lib.set_tuning('gemm4_small', 64 if gemm4 else 0)
 		try:
 			ref = once()
 			for rep in range(25):
@@ -331,7 +333,8 @@ def test_backward_is_bit_reproducible_with_side_streams():
 				bad = [n for n in ref if not torch.equal(got[n], ref[n])]
 				assert not bad, f'gemm4={gemm4}, pass {rep}: gradients of {bad} differ from the first pass'
 		finally:
-			_lib.check(_lib.lib().find_set_tuning(b'gemm4', 1), 'tuning')
+			_lib.set_tuning('gemm4_min_units', 1024)
+			_lib.set_tuning('gemm4_small', 64)
 
 
 def _wgrad(n_feet, n_pts, seed, sparse=False):
@@ -350,7 +353,7 @@ def _wgrad(n_feet, n_pts, seed, sparse=False):
 	db = torch.full((256,), float('nan'), device='cuda')
 	nbytes = L.find_linear_wgrad_scratch_bytes(n_feet)
 	scratch = torch.empty(nbytes // 4, dtype=torch.float32, device='cuda')
-	_lib.check(L.find_linear_wgrad(_lib.ptr(dzd), _lib.ptr(xd), n_feet, n_pts, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nbytes,
+	_lib.check(L.find_linear_wgrad(_lib.ctx(), _lib.ptr(dzd), _lib.ptr(xd), n_feet, n_pts, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nbytes,
 								   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'find_linear_wgrad')
 	torch.cuda.synchronize()
 	return dz, x, dw.cpu(), db.cpu()

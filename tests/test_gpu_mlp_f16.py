@@ -17,11 +17,11 @@ def fp16_mode():
 	which are faster there): the isolated-kernel tests below pin gemm5's tile-edge arithmetic at tiny shapes too."""
 	from find_amd import _lib, functional as F
 	prev = F.set_mlp_precision('fp16')
-	_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1), 'tuning')
+	_lib.set_tuning('gemm5_min_units', 1)
 	try:
 		yield
 	finally:
-		_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1024), 'tuning')
+		_lib.set_tuning('gemm5_min_units', 1024)
 		F.set_mlp_precision(prev)
 
 
@@ -38,7 +38,7 @@ def test_linear_relu_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 	xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
 	pad = torch.full((n_feet * n_pts + 64, 256), float('nan'), device='cuda')
 	y = pad[:n_feet * n_pts]
-	_lib.check(L.find_linear_relu_fwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), n_feet, n_pts, _lib.ptr(y),
+	_lib.check(L.find_linear_relu_fwd(_lib.ctx(), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), n_feet, n_pts, _lib.ptr(y),
 									  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'find_linear_relu_fwd')
 	xr = x.half().double().numpy()
 	wr = w.half().double().numpy()
@@ -86,11 +86,11 @@ def test_model_fp16_close_to_fp32(n_feet, n_verts, shared):
 	out32, g32 = _run_model(n_feet, n_verts, shared)
 	from find_amd import _lib
 	prev = F.set_mlp_precision('fp16')
-	_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1), 'tuning')   # every launch on the fp16 kernels, whatever its size
+	_lib.set_tuning('gemm5_min_units', 1)   # every launch on the fp16 kernels, whatever its size
 	try:
 		out16, g16 = _run_model(n_feet, n_verts, shared)
 	finally:
-		_lib.check(_lib.lib().find_set_tuning(b'gemm5_min_units', 1024), 'tuning')
+		_lib.set_tuning('gemm5_min_units', 1024)
 		F.set_mlp_precision(prev)
 	assert torch.isfinite(out16).all()
 	d = (out16 - out32).abs().max().item()
@@ -154,3 +154,46 @@ def test_c5_dense_template_fp16_as_configured():
 		worst = max(worst, e)
 		assert e < 1e-2, (n, e)
 	print(f'C5 fp16 vs fp32: outputs {d:.2e}, worst gradient deviation {worst:.2e} of the tensor maximum')
+
+
+def test_two_models_in_one_process_may_differ_in_precision():
+	"""find_mlp_params.precision travels with each call: a model pinned to fp16 and a model pinned to fp32 interleave their passes,
+	and the fp32 one stays bit-identical to a run without any fp16 model around (the precision is no longer process-wide state)."""
+	from find_amd import functional as F
+	from find_amd import synthetic
+	assert F.get_mlp_precision() == 'fp32'
+	dev = torch.device('cuda:0')
+	n_feet, n_verts = 16, 6890   # >= 1024 32-row units per head layer: the fp16 kernels engage at their default thresholds
+	lat = synthetic.latents(n_feet, seed=3, device=dev)
+	a = synthetic.make_model(n_verts, train_size=n_feet, val_size=1, device=dev)
+	b = synthetic.make_model(n_verts, train_size=n_feet, val_size=1, device=dev)
+
+	def run(m):
+		lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+		m.zero_grad()
+		res = m.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+		(res['verts'].sum() + res['col'].sum()).backward()
+		return res['verts'].detach().clone(), m.mlp_disp[2].weight.grad.detach().clone()
+
+	base_v, base_g = run(b)
+	a.set_mlp_precision('fp16')
+	b.set_mlp_precision('fp32')
+	va, ga = run(a)
+	vb, gb = run(b)
+	va2, _ = run(a)
+	assert torch.equal(vb, base_v) and torch.equal(gb, base_g)
+	assert torch.equal(va, va2)
+	d = (va - vb).abs().max().item()
+	assert 0.0 < d < 1e-4, d
+	assert not torch.equal(ga, gb)
+	# a forward in fp16 followed by a change of the process default still runs its backward in fp16
+	lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+	a.set_mlp_precision(None)
+	prev = F.set_mlp_precision('fp16')
+	try:
+		a.zero_grad()
+		res = a.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+	finally:
+		F.set_mlp_precision(prev)
+	(res['verts'].sum() + res['col'].sum()).backward()
+	assert torch.equal(a.mlp_disp[2].weight.grad, ga)

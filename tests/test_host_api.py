@@ -114,7 +114,7 @@ def test_c_abi_exports_every_declared_symbol():
 		assert hasattr(L, name), name
 	assert L.find_abi_version() == _lib.ABI_VERSION
 	assert L.find_build_arch() == b'gfx950'
-	assert ctypes.sizeof(_lib.MlpParams) == 8 * 4 + 8 + 6 * 8 * 8 + 8
+	assert ctypes.sizeof(_lib.MlpParams) == 8 * 4 + 8 + 6 * 8 * 8 + 8 + 8   # ... + avg_col + precision (padded to 8)
 	assert ctypes.sizeof(_lib.RenderParams) == 21 * 4
 
 
@@ -128,7 +128,8 @@ def test_error_reporting_without_gpu():
 	p.width = 128
 	assert L.find_mlp_ws_bytes(ctypes.byref(p), 1, 1, 10, 1) == -1
 	assert b'width=256' in L.find_last_error()
-	assert L.find_set_tuning(b'nope', 1) == -1
+	assert L.find_ctx_set(None, b'nope', 1) == -1 and b'NULL' in L.find_last_error()
+	assert L.find_ctx_create(0, None) == -1   # argument checks come before any HIP call
 
 
 def test_meshes_container_subset():

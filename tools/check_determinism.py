@@ -14,7 +14,7 @@ from find_amd import _lib  # noqa: E402
 torch.zeros(1, device='cuda')
 for kv in [a for a in sys.argv[1:] if '=' in a]:
 	k, v = kv.split('=')
-	_lib.check(_lib.lib().find_set_tuning(k.encode(), int(v)), 'tuning')
+	_lib.set_tuning(k, int(v))
 sys.argv = [a for a in sys.argv if '=' not in a]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 n_feet = int(sys.argv[2]) if len(sys.argv) > 2 else 4

@@ -6,7 +6,7 @@ from find_amd import functional_render as FR, synthetic, _lib
 from find_amd.functional import _ws, _c, _faces_i32
 from find_amd._lib import ptr, check, current_stream
 from find_amd.cameras import look_at_view_transform
-_lib.check(_lib.lib().find_set_tuning(b'raster_ablate', 64), 'tune')
+_lib.set_tuning('raster_ablate', 64)
 for size in (256, 512):
 	v, f = synthetic.template(6890)
 	g = torch.Generator().manual_seed(0)

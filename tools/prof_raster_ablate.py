@@ -16,7 +16,7 @@ R, T, fc = R.cuda(), T.cuda(), f.cuda()
 params = FR.make_params(size)
 L = _lib.lib()
 for ab in [int(x) for x in sys.argv[3:]] or [0, 1, 2, 3, 4, 0]:
-	_lib.check(L.find_set_tuning(b'raster_ablate', ab), 'tune')
+	_lib.set_tuning('raster_ablate', ab)
 	for _ in range(3):
 		FR.render(verts, None, fc, R, T, params, want_image=False)
 	torch.cuda.synchronize()

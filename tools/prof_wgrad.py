@@ -25,7 +25,7 @@ s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def launch():
-	_lib.check(L.find_linear_wgrad(_lib.ptr(dz), _lib.ptr(x), n_feet, n_pts, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nb, s), 'wgrad')
+	_lib.check(L.find_linear_wgrad(_lib.ctx(), _lib.ptr(dz), _lib.ptr(x), n_feet, n_pts, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nb, s), 'wgrad')
 
 
 for _ in range(100):

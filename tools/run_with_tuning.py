@@ -9,5 +9,5 @@ from find_amd import _lib
 sep = sys.argv.index('--')
 for kv in sys.argv[1:sep]:
 	k, v = kv.split('=')
-	_lib.check(_lib.lib().find_set_tuning(k.encode(), int(v)), 'tuning')
+	_lib.set_tuning(k, int(v))
 sys.exit(pytest.main(sys.argv[sep + 1:]))

@@ -11,7 +11,7 @@ dev = torch.device('cuda:0')
 model, params, step = bench.build_step(dev, 0)
 L = _lib.lib()
 for v in vals:
-	_lib.check(L.find_set_tuning(key, v), 'tune')
+	_lib.set_tuning(key.decode() if isinstance(key, bytes) else key, v)
 	for _ in range(5):
 		step()
 	torch.cuda.synchronize()
