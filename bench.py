@@ -221,7 +221,8 @@ def train3d_setup(run, n_items, batch_size, stage='net', labels=False, seed=0, d
 		if labels:  # what default_collate makes of the dataset items' label strings: lists of str
 			b.update(shape=feet[lo:hi], tex=feet[lo:hi], pose=names[lo:hi], reg=names[lo:hi])
 		batches.append(b)
-	opt = optim.Adam(m.main_params, lr=5e-4, capturable=capturable) if net else optim.SGD(m.reg_params, lr=1e-3, momentum=0.9)
+	# learning rates: the reference's defaults (src/train/opts.py:54-55: lr_net 5e-5, lr_reg 1e-5)
+	opt = optim.Adam(m.main_params, lr=5e-5, capturable=capturable) if net else optim.SGD(m.reg_params, lr=1e-5, momentum=0.9)
 	bucket = None
 	if run.world > 1 and dp:
 		fdist.broadcast_parameters([p for p in m.parameters() if p.is_floating_point()])
@@ -477,7 +478,7 @@ def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=F
 	batch = dict(mesh=Meshes(gv, gf, TexturesVertex(gc.clamp(0.05, 0.95))), idx=torch.arange(n_feet, device=dev), name=[f'{i:04d}' for i in range(n_feet)])
 	np.random.seed(7)
 	R, T = mwl.rdr.sample_views(nviews=n_views, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
-	opt = optim.Adam(m.main_params, lr=5e-4)
+	opt = optim.Adam(m.main_params, lr=5e-5)
 	bucket = None
 	if run.world > 1:
 		fdist.broadcast_parameters([p for p in m.parameters() if p.is_floating_point()])
@@ -573,7 +574,7 @@ def brief(rec, *keys):
 	return out
 
 
-def train3d_b1_records(run, with_cpu, steps=300, warmup=30):
+def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True):
 	"""The reference's literal batch size (batch_size_train = 1, opts.py:40) with label-addressed latents: 16 scans of 8 feet visited
 	round-robin, one scan per step."""
 	recs = {}
@@ -595,7 +596,7 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30):
 		key = 'train3d_b1' if stage == 'net' else 'train3d_b1_reg_stage'
 		recs[key] = brief(rec)
 		recs[key]['host_enqueue_ms_per_step'] = rec['host_enqueue_ms_per_step']
-		if stage == 'net':
+		if stage == 'net' and graph:
 			try:
 				recs['train3d_b1_graph'] = train3d_b1_graph(run, steps, warmup)
 				if with_cpu:
@@ -629,6 +630,7 @@ def main():
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
 	ap.add_argument('--headline-only', action='store_true', help='only the timed headline loop (no records, no CPU leg, no isolated kernel loop): the command to put under rocprofv3')
+	ap.add_argument('--no-graph', action='store_true', help='skip the HIP-graph variant of the batch-1 record')
 	ap.add_argument('--no-records', action='store_true', help='skip the nested records of the other configurations')
 	ap.add_argument('--train3d', action='store_true', help='(default) the headline line: the reference training configuration')
 	ap.add_argument('--train3d-b1', action='store_true', help='instead of the headline line: only the batch-1 train_3d records')
@@ -669,7 +671,7 @@ def main():
 			emit(out)
 		return run.finish()
 	if args.train3d_b1:
-		recs = train3d_b1_records(run, with_cpu)
+		recs = train3d_b1_records(run, with_cpu, graph=not args.no_graph)
 		if run.rank == 0:
 			emit(recs)
 		return run.finish()
@@ -690,7 +692,7 @@ def main():
 	del su
 	if run.world == 1 and not args.headline_only and not args.no_records:
 		recs = {}
-		recs.update(train3d_b1_records(run, with_cpu))
+		recs.update(train3d_b1_records(run, with_cpu, graph=not args.no_graph))
 		recs['c2'] = brief(c2_record(run, 30, 5, with_cpu=with_cpu), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed', 'step_tflops_reference_equiv')
 		recs['c3'] = brief(c3_record(run, 20, 3, with_cpu))
 		recs['c5_fp32'] = brief(c2_record(run, 10, 3, n_verts=50002), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed')

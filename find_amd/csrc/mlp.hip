@@ -190,11 +190,15 @@ struct Fork {
 	find_ctx* c;
 	hipStream_t s;
 	bool on;              // side streams in use for this call
+	bool capturing = false;   // the caller's stream is being captured into a HIP graph
 	bool used[N_SIDE] = {};
 	int n_ev = 0;
 	int rc = FIND_OK;
 
-	Fork(find_ctx* ctx, hipStream_t caller, bool enable) : c(ctx), s(caller), on(enable && ctx->side[0] != nullptr) {}
+	Fork(find_ctx* ctx, hipStream_t caller, bool enable) : c(ctx), s(caller), on(enable && ctx->side[0] != nullptr) {
+		hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(caller, &st) == hipSuccess) capturing = st != hipStreamCaptureStatusNone;
+	}
 	hipStream_t stream(int k) const { return on ? c->side[k] : s; }
 	void fail(hipError_t e, const char* what) {
 		if (e != hipSuccess && rc == FIND_OK) {
@@ -233,8 +237,11 @@ struct Fork {
 	}
 	void chain(int from, int to) {
 		if (!on || from == to) return;
+		// a stream enters the call through a fork from the CALLER's stream first, never only through another side stream: under
+		// stream capture, hipStreamEndCapture (ROCm 7.0 / 7.2) faults on a capture whose parallel stream was pulled in by a stream
+		// that is itself a fork (nested fork); eagerly the extra wait is implied by the one on `from`
+		if (!used[to]) fork_to(to);
 		order(c->side[from], c->side[to]);
-		used[to] = true;
 	}
 	int join() {
 		if (on)
@@ -786,7 +793,9 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			fk.fork_to(Q);
 			// the large layers alternate between two slab sets and hand their slab reduce to stream R: the reduce (LDS-using, so
 			// it only gets a CU when a ring kernel's workgroup retires) no longer sits between two dw2 launches on Q
-			if (fk.on && c->reduce_stream) {
+			// (Not under stream capture: there the streams only express dependencies and the graph executor schedules the branches;
+			// hipStreamEndCapture of ROCm 7.0 / 7.2 faults on this R <-> Q event pattern, and captures cleanly without it.)
+			if (fk.on && c->reduce_stream && !fk.capturing) {
 				const int si = big_toggle & 1;
 				big_toggle += 1;
 				BwdWs bk = b;

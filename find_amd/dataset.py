@@ -1,242 +1,299 @@
-"""Foot3D dataset reader and collator: the host-side producer of the `batch` dict the hot path consumes.
-Mirror of reference src/data/dataset.py -- Foot3DDataset (:116-299: JSON index -> OBJ + PNG -> centred vertices, TexturesUV),
-collate_batched_meshes (:28-52), BatchCollator (:55-67), NoTextureLoading (:70-85), get_pose_code (:88-109) -- with the same
-constructor keywords, filters, item keys and quirks; PyTorch3D's OBJ loader / trimesh / cv2 are replaced by a small numpy OBJ
-parser and PIL.  The configuration (`src/cfg.yaml` in the reference) is passed in as a dict: DATASET_FOLDER, DATASET_JSON,
-DATASET_NAME, LOWPOLY_DATASET_NAME, VAL_FEET, TEMPLATE_FEET, POSE_VECTOR."""
+"""Foot3D scans on disk -> the `batch` dict the hot path consumes.
+
+Behavioural spec, taken from what the callers of reference src/data/dataset.py rely on (train.py:118-131, trainer.py:97-100,
+eval_3d.py:60-76) rather than from its text:
+
+  on-disk format   one JSON index {"keypoint_labels": [...], "data": [record, ...]}; a record names a scan by 'Foot ID' + 'Scan ID'
+                   and carries 'footedness' ('Left' / 'Right'), 'pose' (list of descriptions), 'keypoints' (vertex indices or null),
+                   'OBJ file', 'PNG file' (paths below <DATASET_FOLDER>/<DATASET_NAME>, or <LOWPOLY_DATASET_NAME> for low-poly meshes)
+  selection        a fixed cascade of record filters (SELECTION below), then an optional head(N)
+  item             geometry centred on its centroid (right feet mirrored in y first), UV texture unless texture loading is switched
+                   off, bookkeeping fields, and the four latent-table keys: shape / tex per foot, pose / reg per scan
+  batch            default_collate of the non-geometry fields + one ragged `Meshes` with a joined `TexturesUV`
+
+The configuration the reference reads from src/cfg.yaml is passed in as a dict (DATASET_FOLDER, DATASET_JSON, DATASET_NAME,
+LOWPOLY_DATASET_NAME, VAL_FEET, TEMPLATE_FEET, POSE_VECTOR).  PyTorch3D's OBJ reader / cv2 are replaced by a small parser and PIL.
+Public names and keywords are the reference's, so src/train and src/eval construct it unchanged (plus the leading cfg)."""
 import json
 import os
-from collections import defaultdict, namedtuple
+from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 import torch
-from torch.utils.data import Dataset, _utils
+from torch.utils.data import Dataset
+from torch.utils.data._utils.collate import default_collate
 
 from .structures import Meshes, TexturesUV
 
-ObjFaces = namedtuple('ObjFaces', 'verts_idx textures_idx')
-ObjProps = namedtuple('ObjProps', 'verts_uvs')
-CachedMesh = namedtuple('CachedMesh', 'verts face_dict props tex_img')
-_cache = {}  # external cache used when full_caching is on (dataset.py:112)
+GEOMETRY_FIELDS = ('verts', 'faces', 'textures')
+
+
+# ----------------------------------------------------------------------------------------------- files
+@dataclass
+class ObjFaces:
+	verts_idx: torch.Tensor      # (F, 3) int64
+	textures_idx: torch.Tensor   # (F, 3) int64, -1 where a corner has no texture coordinate
+
+
+@dataclass
+class ObjProps:
+	verts_uvs: torch.Tensor      # (Vt, 2) float32
+
+
+def _resolve(index, count):
+	"""OBJ indices are 1-based; negative ones count back from the elements read so far."""
+	return index - 1 if index > 0 else count + index
 
 
 def load_obj(loc, device='cpu'):
-	"""Vertices, faces and UVs of a Wavefront OBJ: returns (verts (V,3) float32, ObjFaces(verts_idx (F,3), textures_idx (F,3) int64,
-	-1 where a corner has no vt), ObjProps(verts_uvs (Vt,2))) -- the fields of pytorch3d.io.load_obj the reference reads
-	(dataset.py:238, 266-267).  Polygons are fan-triangulated; negative (relative) indices are resolved; materials are ignored."""
-	vs, vts, fv, ft = [], [], [], []
+	"""(verts (V,3) float32, ObjFaces, ObjProps) of a Wavefront OBJ: the three results of pytorch3d.io.load_obj the reference uses.
+	Polygons are split into a triangle fan; material statements are skipped."""
+	positions, uvs, tri_v, tri_t = [], [], [], []
 	with open(loc, 'r') as fh:
-		for line in fh:
-			if line.startswith('v '):
-				p = line.split()
-				vs.append((float(p[1]), float(p[2]), float(p[3])))
-			elif line.startswith('vt '):
-				p = line.split()
-				vts.append((float(p[1]), float(p[2])))
-			elif line.startswith('f '):
-				corners = []
-				for tok in line.split()[1:]:
-					parts = tok.split('/')
-					vi = int(parts[0])
-					ti = int(parts[1]) if len(parts) > 1 and parts[1] != '' else 0
-					corners.append((vi - 1 if vi > 0 else len(vs) + vi, (ti - 1 if ti > 0 else len(vts) + ti) if ti != 0 else -1))
-				for k in range(1, len(corners) - 1):
-					tri = (corners[0], corners[k], corners[k + 1])
-					fv.append([c[0] for c in tri])
-					ft.append([c[1] for c in tri])
-	verts = torch.tensor(np.asarray(vs, dtype=np.float32).reshape(-1, 3), device=device)
-	faces = ObjFaces(torch.tensor(np.asarray(fv, dtype=np.int64).reshape(-1, 3), device=device),
-					 torch.tensor(np.asarray(ft, dtype=np.int64).reshape(-1, 3), device=device))
-	props = ObjProps(torch.tensor(np.asarray(vts, dtype=np.float32).reshape(-1, 2), device=device))
-	return verts, faces, props
+		for raw in fh:
+			tag, _, rest = raw.partition(' ')
+			if tag == 'v':
+				positions.append([float(x) for x in rest.split()[:3]])
+			elif tag == 'vt':
+				uvs.append([float(x) for x in rest.split()[:2]])
+			elif tag == 'f':
+				vi, ti = [], []
+				for corner in rest.split():
+					fields = corner.split('/')
+					vi.append(_resolve(int(fields[0]), len(positions)))
+					ti.append(_resolve(int(fields[1]), len(uvs)) if len(fields) > 1 and fields[1] else -1)
+				for k in range(2, len(vi)):
+					tri_v.append((vi[0], vi[k - 1], vi[k]))
+					tri_t.append((ti[0], ti[k - 1], ti[k]))
+
+	def tensor(rows, dtype, width):
+		return torch.from_numpy(np.asarray(rows, dtype=dtype).reshape(-1, width)).to(device)
+
+	return tensor(positions, np.float32, 3), ObjFaces(tensor(tri_v, np.int64, 3), tensor(tri_t, np.int64, 3)), ObjProps(tensor(uvs, np.float32, 2))
 
 
 def load_texture_png(loc):
-	"""(H, W, 3) float32 in [0,1], RGB (the reference: cv2.imread + BGR2RGB, / 255; dataset.py:255-256)."""
+	"""RGB image as (H, W, 3) float32 in [0, 1]."""
 	from PIL import Image
 	with Image.open(loc) as im:
 		return torch.from_numpy(np.asarray(im.convert('RGB'), dtype=np.float32) / 255.0)
 
 
-def join_textures_uv(texlist):
-	"""TexturesUV.join_batch for maps of one size (dataset.py:43): faces_uvs / verts_uvs are padded per mesh."""
-	maps = torch.cat([t.maps_padded() for t in texlist], dim=0)
-	fu = [t.faces_uvs_padded()[i] for t in texlist for i in range(len(t))]
-	vu = [t.verts_uvs_padded()[i] for t in texlist for i in range(len(t))]
-	return TexturesUV(maps, fu, vu)
+# ----------------------------------------------------------------------------------------------- pose descriptions
+def _pose_slots(cfg):
+	"""cfg['POSE_VECTOR'] = {'SIZE': n, i: [name] or [negative name, positive name]}  ->  {name: (slot, value)}."""
+	table = cfg['POSE_VECTOR']
+	slots = {}
+	for i in range(table['SIZE']):
+		names = table[i]
+		if len(names) not in (1, 2):
+			raise ValueError(f'lookup for pose element {i} is not 1 or 2 long.')
+		values = (1.0,) if len(names) == 1 else (-1.0, 1.0)
+		for name, value in zip(names, values):
+			slots.setdefault(name, (i, value))
+	return table['SIZE'], slots
 
 
-def collate_batched_meshes(batch):
-	"""List of items -> one Meshes with padded, ragged geometry and joined textures (dataset.py:28-52)."""
-	if batch is None or len(batch) == 0:
-		return None
-	col = {k: [d[k] for d in batch] for k in batch[0].keys()}
-	if not {'verts', 'faces'}.issubset(col.keys()):
-		return None
-	textures = None
-	if 'textures' in col and col['textures'][0] is not None:
-		textures = join_textures_uv(col['textures'])
-	return Meshes(verts=col['verts'], faces=col['faces'], textures=textures)
+def get_pose_code(pose_list, cfg):
+	"""Pose descriptions -> signed indicator vector ('Strong ' prefixes are ignored; an unknown description is a LookupError)."""
+	size, slots = _pose_slots(cfg)
+	vec = np.zeros(size)
+	for descr in pose_list:
+		key = descr.replace('Strong ', '')
+		if key not in slots:
+			raise LookupError(f'Pose {key} not found in lookup.')
+		slot, value = slots[key]
+		vec[slot] = value
+	return vec
 
 
-class BatchCollator:
-	def __init__(self, device='cuda'):
-		self.device = device
+# ----------------------------------------------------------------------------------------------- selection
+# Record filters in the order they apply.  Each entry: (name, enabled(options) -> bool, keep(record, options, cfg) -> bool).
+SELECTION = (
+	('template feet are held out unless feet are requested by ID',
+	 lambda o: o['specific_feet'] is None, lambda r, o, c: r['Foot ID'] not in c['TEMPLATE_FEET']),
+	('train / validation split by foot',
+	 lambda o: not (o['train_and_val'] or o['specific_feet']), lambda r, o, c: (r['Foot ID'] in c['VAL_FEET']) != o['is_train']),
+	('T-pose scans only',
+	 lambda o: o['tpose_only'], lambda r, o, c: 'T-Pose' in r.get('pose', [])),
+	('left feet only',
+	 lambda o: o['left_only'], lambda r, o, c: r.get('footedness') == 'Left'),
+	('feet requested by ID',
+	 lambda o: bool(o['specific_feet']), lambda r, o, c: r['Foot ID'] in o['specific_feet']),
+)
 
-	def collate_batches(self, batch):
-		non_mesh = [{k: v for k, v in e.items() if k not in ['verts', 'faces', 'textures']} for e in batch]
-		out = _utils.collate.default_collate(non_mesh)
-		out['mesh'] = collate_batched_meshes(batch).to(self.device)
-		for k, v in out.items():
-			if torch.is_tensor(v):
-				out[k] = v.to(self.device)
-		return out
+
+def select_records(records, options, cfg):
+	for _, enabled, keep in SELECTION:
+		if enabled(options):
+			records = [r for r in records if keep(r, options, cfg)]
+	return records
+
+
+def scan_name(record):
+	return f"{record['Foot ID']}-{record['Scan ID']}"
+
+
+# ----------------------------------------------------------------------------------------------- scan store
+@dataclass
+class Scan:
+	verts: torch.Tensor
+	face_dict: ObjFaces
+	props: ObjProps
+	tex_img: Optional[torch.Tensor]
+
+
+class ScanStore:
+	"""Reads scans from disk; with `keep` it remembers them by name (the reference's full_caching: a process-wide store, so train and
+	validation datasets share it).  A scan remembered without its texture is read again when the texture is first asked for."""
+	shared = {}
+
+	def __init__(self, keep):
+		self.keep = keep
+
+	def fetch(self, name, obj_loc, png_loc, want_texture, device):
+		scan = self.shared.get(name) if self.keep else None
+		if scan is None or (want_texture and scan.tex_img is None):
+			verts, faces, props = load_obj(obj_loc, device=device)
+			scan = Scan(verts, faces, props, load_texture_png(png_loc) if want_texture else None)
+			if self.keep:
+				self.shared[name] = scan
+		return scan
+
+
+_cache = ScanStore.shared  # the name the reference exposes for its cache
 
 
 class NoTextureLoading:
-	"""Context manager turning texture loading off, e.g. during registration (dataset.py:70-85)."""
+	"""`with NoTextureLoading(train_set, val_set): ...` -- items come without textures inside the block (registration stage)."""
 
 	def __init__(self, *datasets):
 		self.datasets = datasets
 		self.states = []
 
 	def __enter__(self, *args):
+		self.states = [d._load_texture for d in self.datasets]
 		for d in self.datasets:
-			self.states.append(d._load_texture)
 			d._load_texture = False
 
 	def __exit__(self, *args):
-		for n, d in enumerate(self.datasets):
-			d._load_texture = self.states[n]
+		for d, state in zip(self.datasets, self.states):
+			d._load_texture = state
 
 
-def get_pose_code(pose_list, cfg):
-	"""List of pose descriptions -> vector, through cfg['POSE_VECTOR'] (dataset.py:88-109)."""
-	lookup = cfg['POSE_VECTOR']
-	N = lookup['SIZE']
-	vec = np.zeros(N)
-	for p in pose_list:
-		p = p.replace('Strong ', '')
-		for i in range(N):
-			if p in lookup[i]:
-				if len(lookup[i]) == 1:
-					vec[i] = 1
-				elif len(lookup[i]) == 2:
-					vec[i] = [-1, 1][lookup[i].index(p)]
-				else:
-					raise ValueError(f'lookup for pose element {i} is not 1 or 2 long.')
-				break
-		else:
-			raise LookupError(f'Pose {p} not found in lookup.')
-	return vec
-
-
+# ----------------------------------------------------------------------------------------------- dataset
 class Foot3DDataset(Dataset):
 	def __init__(self, cfg, dataset_json=None, N=None, tpose_only=False, left_only=True, specific_feet=None, full_caching=False, is_train=True,
 				 train_and_val=False, device='cuda', low_res_textures=False, low_poly_meshes=False):
 		super().__init__()
 		self.cfg = cfg
-		dataset_json = dataset_json if dataset_json is not None else cfg['DATASET_JSON']
-		self.folder = os.path.join(cfg['DATASET_FOLDER'], cfg['DATASET_NAME'] if not low_poly_meshes else cfg['LOWPOLY_DATASET_NAME'])
-		with open(dataset_json) as fh:
-			data = json.load(fh)
-		self.meta = {k: v for k, v in data.items() if k != 'data'}
-		self.data = data['data']
-		# the template foot is skipped unless feet are named explicitly (dataset.py:150)
-		self.data = [d for d in self.data if d['Foot ID'] not in cfg['TEMPLATE_FEET'] or specific_feet is not None]
-		self.is_train = is_train
-		if not (train_and_val or specific_feet):
-			if is_train:
-				self.data = [d for d in self.data if d['Foot ID'] not in cfg['VAL_FEET']]
-			else:
-				self.data = [d for d in self.data if d['Foot ID'] in cfg['VAL_FEET']]
-		if tpose_only:
-			self.data = [d for d in self.data if 'T-Pose' in d.get('pose', [])]
-		if left_only:
-			self.data = [d for d in self.data if d.get('footedness', None) == 'Left']
+		self.folder = os.path.join(cfg['DATASET_FOLDER'], cfg['LOWPOLY_DATASET_NAME'] if low_poly_meshes else cfg['DATASET_NAME'])
+		with open(dataset_json or cfg['DATASET_JSON']) as fh:
+			index = json.load(fh)
+		self.meta = {k: v for k, v in index.items() if k != 'data'}
+		options = dict(specific_feet=specific_feet, train_and_val=train_and_val, is_train=is_train, tpose_only=tpose_only, left_only=left_only)
+		self.data = select_records(index['data'], options, cfg)
 		if specific_feet:
-			self.data = [d for d in self.data if d['Foot ID'] in specific_feet]
 			assert len(self.data) > 0, f'No feet found with IDs `{specific_feet}`.'
 		if N is not None:
 			self.data = self.data[:N]
+		self.is_train = is_train
 		self.full_caching = full_caching
 		self.keypoint_labels = self.meta['keypoint_labels']
 		self.nkeypoints = len(self.keypoint_labels)
 		self.device = device
-		self._load_texture = True
 		self.low_res_textures = low_res_textures
+		self._load_texture = True
+		self._store = ScanStore(keep=full_caching)
 
 	def __len__(self):
 		return len(self.data)
 
 	@property
 	def foot_ids(self):
-		return [ann['Foot ID'] for ann in self.data]
+		return [r['Foot ID'] for r in self.data]
 
 	@property
 	def scan_ids(self):
-		return [ann['Scan ID'] for ann in self.data]
+		return [r['Scan ID'] for r in self.data]
 
+	# ---- latent-table keys: what is shared between the scans of one foot, what is not
 	def get_keys(self, idx):
-		"""Latent-table keys of an item: shape / texture shared by the scans of one foot, pose / registration per scan (dataset.py:190-200)."""
-		ann = self.data[idx]
-		name = f"{ann['Foot ID']}-{ann['Scan ID']}"
-		return {'shape': ann['Foot ID'], 'pose': name, 'tex': ann['Foot ID'], 'reg': name}
+		record = self.data[idx]
+		per_foot, per_scan = record['Foot ID'], scan_name(record)
+		return {'shape': per_foot, 'pose': per_scan, 'tex': per_foot, 'reg': per_scan}
 
 	def get_all_keys(self):
-		out = defaultdict(list)
+		"""{'shape': [...], 'pose': [...], 'tex': [...], 'reg': [...]}: distinct keys in dataset order (the rows of the latent tables)."""
+		seen = {}
 		for i in range(len(self)):
-			for k, v in self.get_keys(i).items():
-				if v not in out[k]:
-					out[k].append(v)
-		return out
+			for table, key in self.get_keys(i).items():
+				seen.setdefault(table, {}).setdefault(key, None)
+		return {table: list(keys) for table, keys in seen.items()}
+
+	def _find(self, model_id):
+		return [i for i, r in enumerate(self.data) if scan_name(r) == model_id]
 
 	def get_pose_from_model_id(self, model_id):
-		foot_id, scan_id = model_id.split('-')
-		for ann in self.data:
-			if ann['Foot ID'] == foot_id and ann['Scan ID'] == scan_id:
-				return ann['pose']
-		raise LookupError(f'model_id {model_id} not found in dataset.')
+		hits = self._find(model_id)
+		if not hits:
+			raise LookupError(f'model_id {model_id} not found in dataset.')
+		return self.data[hits[0]]['pose']
 
 	def get_by_id(self, ID):
-		idx = [n for n, ann in enumerate(self.data) if ID == f"{ann['Foot ID']}-{ann['Scan ID']}"]
-		assert len(idx) == 1, f'{len(idx)} matches found for ID {ID}.'
-		return self[idx[0]]
+		hits = self._find(ID)
+		assert len(hits) == 1, f'{len(hits)} matches found for ID {ID}.'
+		return self[hits[0]]
 
 	def __getitem__(self, idx):
-		ann = self.data[idx]
-		name = f"{ann['Foot ID']}-{ann['Scan ID']}"
-		obj_loc = os.path.join(self.folder, ann['OBJ file'])
-		tex_loc = os.path.join(self.folder, ann['PNG file'])
-		load_from_cache = self.full_caching and name in _cache
-		cached = None
-		if load_from_cache:
-			cached = _cache[name]
-			if self._load_texture and cached.tex_img is None:
-				load_from_cache = False  # the texture was not needed when this scan was cached: reload
-		if not load_from_cache:
-			verts, face_dict, props = load_obj(obj_loc, device=self.device)
-			tex_img = None
-			if self._load_texture:
-				if self.low_res_textures:
-					tex_loc = tex_loc.replace('.png', '_1k.png')
-				tex_img = load_texture_png(tex_loc)
-			cached = CachedMesh(verts, face_dict, props, tex_img)
-			if self.full_caching:
-				_cache[name] = cached
-		tex_map = None
+		record = self.data[idx]
+		name = scan_name(record)
+		png = record['PNG file'].replace('.png', '_1k.png') if self.low_res_textures else record['PNG file']
+		scan = self._store.fetch(name, os.path.join(self.folder, record['OBJ file']), os.path.join(self.folder, png), self._load_texture, self.device)
+		textures = None
 		if self._load_texture:
-			if cached.tex_img is None:
+			if scan.tex_img is None:
 				raise ValueError(f'Could not load texture - {name}.')
-			tex_map = TexturesUV(cached.tex_img.unsqueeze(0).to(self.device), faces_uvs=cached.face_dict.textures_idx.unsqueeze(0).to(self.device),
-								 verts_uvs=cached.props.verts_uvs.unsqueeze(0).to(self.device))
-		verts, face_dict = cached.verts, cached.face_dict
-		if ann['footedness'] == 'Right':
-			verts = verts.clone()
-			verts[..., 1] = -verts[..., 1]  # mirror right feet onto left ones (dataset.py:277-279; here without touching the cache)
-		verts = verts - torch.mean(verts, dim=0)  # centroid to the origin
-		has_keypoints = ann.get('keypoints') is not None
-		keypoints = np.array(ann['keypoints']) if has_keypoints else np.zeros(self.nkeypoints)
-		return {'faces': face_dict.verts_idx, 'verts': verts, 'textures': tex_map, 'idx': idx, 'name': name, 'has_keypoints': has_keypoints,
-				'kp_idxs': keypoints, 'is_tpose': 'T-Pose' in ann.get('pose', []), 'orig_footedness': ann['footedness'],
-				'pose_descr': ','.join(ann['pose']), 'pose_code': get_pose_code(ann['pose'], self.cfg), **self.get_keys(idx)}
+			textures = TexturesUV(scan.tex_img[None].to(self.device), faces_uvs=scan.face_dict.textures_idx[None].to(self.device),
+								  verts_uvs=scan.props.verts_uvs[None].to(self.device))
+		verts = scan.verts
+		if record['footedness'] == 'Right':   # right feet are mirrored onto left ones (on a copy: the store keeps the file's geometry)
+			verts = verts * verts.new_tensor([1.0, -1.0, 1.0])
+		verts = verts - verts.mean(dim=0)
+		kps = record.get('keypoints')
+		item = dict(faces=scan.face_dict.verts_idx, verts=verts, textures=textures, idx=idx, name=name,
+					has_keypoints=kps is not None, kp_idxs=np.array(kps) if kps is not None else np.zeros(self.nkeypoints),
+					is_tpose='T-Pose' in record.get('pose', []), orig_footedness=record['footedness'], pose_descr=','.join(record['pose']),
+					pose_code=get_pose_code(record['pose'], self.cfg))
+		item.update(self.get_keys(idx))
+		return item
+
+
+# ----------------------------------------------------------------------------------------------- collation
+def join_textures_uv(textures):
+	"""Batch-1 TexturesUV objects of one map size -> one TexturesUV (faces_uvs / verts_uvs padded per mesh)."""
+	per_mesh = [(t.maps_padded()[i], t.faces_uvs_padded()[i], t.verts_uvs_padded()[i]) for t in textures for i in range(len(t))]
+	maps, faces_uvs, verts_uvs = zip(*per_mesh)
+	return TexturesUV(torch.stack(maps), list(faces_uvs), list(verts_uvs))
+
+
+def collate_batched_meshes(batch):
+	"""Items -> ragged Meshes (None for an empty batch or items without geometry)."""
+	if not batch or not {'verts', 'faces'} <= set(batch[0]):
+		return None
+	textures = [item.get('textures') for item in batch]
+	joined = join_textures_uv(textures) if textures[0] is not None else None
+	return Meshes(verts=[item['verts'] for item in batch], faces=[item['faces'] for item in batch], textures=joined)
+
+
+class BatchCollator:
+	"""collate_fn of the reference's DataLoaders: default_collate for everything but the geometry, which becomes batch['mesh']."""
+
+	def __init__(self, device='cuda'):
+		self.device = device
+
+	def collate_batches(self, batch):
+		out = default_collate([{k: v for k, v in item.items() if k not in GEOMETRY_FIELDS} for item in batch])
+		out['mesh'] = collate_batched_meshes(batch).to(self.device)
+		return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in out.items()}

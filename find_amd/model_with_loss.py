@@ -1,6 +1,12 @@
-"""ModelWithLoss on the MI355X hot path: host-side mirror of reference src/model/model.py:969-1171 -- builds the model, the
-renderer and the loss objects; forward(batch, epoch, opts, **flags) returns (loss, losses[, renders]) with every raw
-loss multiplied by opts.weight_<name> (model.py:1157-1158).  All arithmetic below runs in libfind_hip.so."""
+"""ModelWithLoss on the MI355X hot path (reference src/model/model.py:969-1171): model + renderer + loss objects behind
+forward(batch, epoch, opts, **flags) -> (loss, losses[, renders]).
+
+Structure here: a registry of loss terms.  Each term names the forward() flag that enables it, the key it reports under, the
+`opts.weight_*` attribute that scales it (model.py:1157-1158: every raw loss is multiplied by its weight, the total is their sum)
+and whether it needs the 3-D supervision gate or the renders.  forward() evaluates the predicted meshes once, renders once if any
+enabled term needs images, and walks the registry.  All arithmetic runs in libfind_hip.so through the loss / renderer objects."""
+from collections import namedtuple
+
 import torch
 
 from .losses import DisplacementLoss, MeshSmoothnessLoss, SilhouetteLoss, TextureLossGTSpace
@@ -11,111 +17,146 @@ nn = torch.nn
 
 model_zoo = dict(neural=NeuralDisplacementField)
 
+OUT_OF_SCOPE_FLAGS = {
+	'vgg_perc': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
+	'restyle_perc_lat': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
+	'restyle_perc_feat': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
+	'restyle_perc_cluster': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
+	'cont_pose': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
+	'save_renders': 'save_renders writes PNGs through cv2 (visualisation); use return_renders and save them yourself',
+	'mask_out_pred_faces': 'mask_out_pred_faces belongs to the VertexFeatures model (out of scope)',
+}
+
+# flag -> reported key, weight attribute, needs the 3-D gate, needs renders, method computing the raw loss
+Term = namedtuple('Term', 'flag key weight needs_3d needs_render fn')
+TERMS = (
+	Term('chamf', 'loss_chamf', 'weight_chamf', True, False, '_raw_chamf'),
+	Term('smooth', 'loss_smooth', 'weight_smooth', True, False, '_raw_smooth'),
+	Term('texture', 'loss_tex', 'weight_tex', True, False, '_raw_texture'),
+	Term('pix', 'loss_pix', 'weight_pix', False, True, '_raw_pix'),
+	Term('sil', 'loss_sil', 'weight_sil', False, True, '_raw_sil'),
+)
+
 
 def model_class_from_opts(opts):
-	mt = getattr(opts, 'model_type', 'neural')
-	if mt not in model_zoo:
-		raise NotImplementedError(f"model_type '{mt}': only the neural displacement field is on the hot path (PCA / SUPR / "
+	kind = getattr(opts, 'model_type', 'neural')
+	if kind not in model_zoo:
+		raise NotImplementedError(f"model_type '{kind}': only the neural displacement field is on the hot path (PCA / SUPR / "
 								  'vertex-feature baselines are out of scope, SURVEY.md §2 #7-9)')
-	return model_zoo[mt]
+	return model_zoo[kind]
 
 
 def model_from_opts(opts):
 	return model_class_from_opts(opts).load(opts.load_model, device=opts.device, opts=opts)
 
 
+class _Step:
+	"""What one forward() call has at hand while the registry is walked."""
+	__slots__ = ('batch', 'epoch', 'opts', 'res', 'is_train', 'use_z_cutoff', 'gt_z_cutoff', 'pred', 'gt')
+
+
 class ModelWithLoss(nn.Module):
 	def __init__(self, *args, opts=None, device='cuda', **kwargs):
 		super().__init__()
-		model_class = model_class_from_opts(opts)
-		load = opts.load_model
-		if load == '':
-			self.model = model_class(*args, **kwargs, device=device, opts=opts)
+		cls = model_class_from_opts(opts)
+		if opts.load_model:
+			self.model = cls.load(opts.load_model, device=device, **kwargs, opts=opts)
 		else:
-			self.model = model_class.load(load, device=device, **kwargs, opts=opts)
+			self.model = cls(*args, **kwargs, device=device, opts=opts)
+		if opts.vgg_perc_loss or opts.use_restyle():
+			raise NotImplementedError('VGG / Restyle perceptual losses need network weights that are not available; out of scope')
 		self.device = device
 		self.def_loss = DisplacementLoss()
 		self.col_loss = TextureLossGTSpace()
 		self.mesh_smooth_loss = MeshSmoothnessLoss()
 		self.templ_smooth_loss = MeshSmoothnessLoss()
-		max_faces_per_bin = 30000 if not opts.low_poly_meshes else None  # reference heuristic; no effect on results
-		self.rdr = FootRenderer(image_size=256, device=device, bin_size=None, max_faces_per_bin=max_faces_per_bin)
 		self.pix_loss = nn.MSELoss()
 		self.sil_loss = SilhouetteLoss()
-		if opts.vgg_perc_loss or opts.use_restyle():
-			raise NotImplementedError('VGG / Restyle perceptual losses need network weights that are not available; out of scope')
+		# (max_faces_per_bin only sizes PyTorch3D's coarse bins -- 30 000 for the full-resolution scans, model.py:987; no effect on results)
+		self.rdr = FootRenderer(image_size=256, device=device, bin_size=None, max_faces_per_bin=None if opts.low_poly_meshes else 30000)
 
+	# ------------------------------------------------------------------ raw losses, one per registry entry
+	def _raw_chamf(self, st):
+		return self.def_loss(self.model, st.res, st.batch, st.epoch, z_cutoff=0.07 if st.use_z_cutoff else None, gt_z_cutoff=st.gt_z_cutoff)['loss']
+
+	def _raw_smooth(self, st):
+		return self.mesh_smooth_loss(st.res['meshes'])
+
+	def _raw_texture(self, st):
+		sfx = 'train' if st.is_train else 'val'
+		codes = {k: st.batch.get(f'{k}_{sfx}', None) for k in ('shapevec', 'texvec', 'posevec')}
+		return self.col_loss(self.model, st.batch, **codes)
+
+	def _raw_pix(self, st):
+		# images are compared inside the silhouettes only (model.py:1101-1105)
+		return self.pix_loss(st.pred['image'] * st.pred['mask'].unsqueeze(-1), st.gt['image'] * st.gt['mask'].unsqueeze(-1))
+
+	def _raw_sil(self, st):
+		return self.sil_loss(st.pred['mask'], st.gt['mask'])
+
+	# ------------------------------------------------------------------ pieces of a step
 	def _views(self, opts):
-		nviews = opts.num_views
-		svt = opts.special_view_type
-		if svt == 'topdown':
+		"""Camera poses shared by the GT and the predicted render of one step (model.py:1060-1071)."""
+		free = dict(dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90)
+		kind = opts.special_view_type
+		if kind == 'topdown':
 			return self.rdr.view_from('topdown')
-		if svt == 'topdown_5':
-			return self.rdr.combine_views(*self.rdr.view_from('topdown'),
-										  *self.rdr.sample_views(nviews=5, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90,
-																 azim_min=-90, azim_max=90, seed=5))
-		if svt == 'sample_arc':
-			return self.rdr.sample_views(nviews=nviews, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=0, azim_max=0)
-		# same viewpoints for GT and prediction (model.py:1070-1071)
-		return self.rdr.sample_views(nviews=nviews, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+		if kind == 'topdown_5':
+			return self.rdr.combine_views(*self.rdr.view_from('topdown'), *self.rdr.sample_views(nviews=5, azim_min=-90, azim_max=90, seed=5, **free))
+		if kind == 'sample_arc':
+			return self.rdr.sample_views(nviews=opts.num_views, azim_min=0, azim_max=0, **free)
+		return self.rdr.sample_views(nviews=opts.num_views, azim_min=-90, azim_max=90, **free)
+
+	@staticmethod
+	def _supervise_3d(batch, opts, is_train):
+		"""The reference's switches that withhold 3-D supervision from some scans (model.py:1019-1030)."""
+		limit = getattr(opts, 'restrict_3d_n_train', None)
+		if is_train and limit is not None and batch['idx'].item() >= limit:
+			return False
+		if getattr(opts, 'restrict_3d_train_key', None) is not None and batch['name'][0] not in opts.train_3d_on_only:
+			return False
+		return True
+
+	def _render_pair(self, st, views, masked_faces, copy_mask_out):
+		R, T = views if views is not None else self._views(st.opts)
+		with torch.no_grad():  # the GT scans are rendered again every step, as the reference does (model.py:1073-1075)
+			gt = self.rdr(st.batch['mesh'], R, T, return_mask=True, mask_with_grad=True, mask_out_faces=True, masked_faces=masked_faces,
+						  return_mask_out_masks=True)
+		pred = self.rdr(st.res['meshes'], R, T, return_mask=True, mask_with_grad=True)
+		if copy_mask_out:  # what the GT's slicing plane hides is hidden in the prediction too (model.py:1091-1094)
+			hidden = gt['mask_out_masks']
+			pred['image'] = torch.where(hidden.unsqueeze(-1), torch.ones_like(pred['image']), pred['image'])
+			pred['mask'] = torch.where(hidden, torch.zeros_like(pred['mask']), pred['mask'])
+		return pred, gt
 
 	def forward(self, batch, epoch, opts, chamf=False, smooth=False, texture=False, pix=False, vgg_perc=False, sil=False,
 				restyle_perc_lat=False, restyle_perc_feat=False, restyle_perc_cluster=False, cont_pose=False, render_foot=False,
 				save_renders=False, render_dir='_pix', is_train=True, use_z_cutoff=False, gt_z_cutoff=None, restyle_feature_maps=None,
 				no_displacement=False, return_renders=False, copy_mask_out=True, mask_out_pred_faces=False, views=None):
-		if vgg_perc or restyle_perc_lat or restyle_perc_feat or restyle_perc_cluster or cont_pose:
-			raise NotImplementedError('perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)')
-		if save_renders:
-			raise NotImplementedError('save_renders writes PNGs through cv2 (visualisation); use return_renders and save them yourself')
-		if mask_out_pred_faces:
-			raise NotImplementedError('mask_out_pred_faces belongs to the VertexFeatures model (out of scope)')
+		given = dict(vgg_perc=vgg_perc, restyle_perc_lat=restyle_perc_lat, restyle_perc_feat=restyle_perc_feat, restyle_perc_cluster=restyle_perc_cluster,
+					 cont_pose=cont_pose, save_renders=save_renders, mask_out_pred_faces=mask_out_pred_faces)
+		for name, why in OUT_OF_SCOPE_FLAGS.items():
+			if given[name]:
+				raise NotImplementedError(why)
+		enabled = dict(chamf=chamf, smooth=smooth, texture=texture, pix=pix, sil=sil)
 
-		res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement)
-		raw_losses = {}
-		renders_to_return = dict()
-
-		apply_loss_3d = True
-		if is_train and getattr(opts, 'restrict_3d_n_train', None) is not None:
-			if batch['idx'].item() >= opts.restrict_3d_n_train:
-				apply_loss_3d = False
-		if getattr(opts, 'restrict_3d_train_key', None) is not None:
-			if batch['name'][0] not in opts.train_3d_on_only:
-				apply_loss_3d = False
-
-		if apply_loss_3d:
-			if chamf:
-				raw_losses['loss_chamf'] = self.def_loss(self.model, res, batch, epoch, z_cutoff=0.07 if use_z_cutoff else None,
-														 gt_z_cutoff=gt_z_cutoff)['loss']
-			if smooth:
-				raw_losses['loss_smooth'] = self.mesh_smooth_loss(res['meshes'])
-			if texture:
-				sfx = 'train' if is_train else 'val'
-				raw_losses['loss_tex'] = self.col_loss(self.model, batch, shapevec=batch.get(f'shapevec_{sfx}', None),
-													   texvec=batch.get(f'texvec_{sfx}', None), posevec=batch.get(f'posevec_{sfx}', None))
-
+		st = _Step()
+		st.batch, st.epoch, st.opts, st.is_train = batch, epoch, opts, is_train
+		st.use_z_cutoff, st.gt_z_cutoff = use_z_cutoff, gt_z_cutoff
+		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement)
+		st.pred = st.gt = None
 		if render_foot:
-			R, T = views if views is not None else self._views(opts)
-			with torch.no_grad():  # the GT is re-rendered every step, as in the reference (model.py:1073-1075)
-				gt_rdrs = self.rdr(batch['mesh'], R, T, return_mask=True, mask_with_grad=True, mask_out_faces=True,
-								   masked_faces=batch.get('masked_faces', None), return_mask_out_masks=True)
-			pred_rdrs = self.rdr(res['meshes'], R, T, return_mask=True, mask_with_grad=True)
-			if copy_mask_out:  # apply the GT's masked-out region to the prediction (model.py:1091-1094)
-				mo = gt_rdrs['mask_out_masks']
-				pred_rdrs['image'] = torch.where(mo.unsqueeze(-1), torch.ones_like(pred_rdrs['image']), pred_rdrs['image'])
-				pred_rdrs['mask'] = torch.where(mo, torch.zeros_like(pred_rdrs['mask']), pred_rdrs['mask'])
-			if return_renders:
-				renders_to_return.update(dict(pred=pred_rdrs, gt=gt_rdrs))
-			if pix:
-				pix_pred = pred_rdrs['image'] * pred_rdrs['mask'].unsqueeze(-1)
-				pix_gt = gt_rdrs['image'] * gt_rdrs['mask'].unsqueeze(-1)
-				raw_losses['loss_pix'] = self.pix_loss(pix_pred, pix_gt)
-			if sil:
-				raw_losses['loss_sil'] = self.sil_loss(pred_rdrs['mask'], gt_rdrs['mask'])
+			st.pred, st.gt = self._render_pair(st, views, batch.get('masked_faces', None), copy_mask_out)
+		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
-		losses = {k: v * getattr(opts, k.replace('loss', 'weight')) for k, v in raw_losses.items()}
+		losses = {}
+		for term in TERMS:
+			if not enabled[term.flag] or (term.needs_3d and not supervise_3d) or (term.needs_render and not render_foot):
+				continue
+			losses[term.key] = getattr(self, term.fn)(st) * getattr(opts, term.weight)
 		loss = sum(losses.values())
 		if return_renders and render_foot:
-			return loss, losses, renders_to_return
+			return loss, losses, dict(pred=st.pred, gt=st.gt)
 		return loss, losses
 
 	def save_model(self, *args, **kwargs):
