@@ -32,7 +32,8 @@ constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
 constexpr int KU = 16;            // list entries in flight per lane in the K-nearest passes (they are L2-latency-bound)
 constexpr int KN_CAP = 1024;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1])
-constexpr int RASTER_WGS = 1280;  // persistent rasteriser workgroups (5 per CU: 95 VGPRs, 22 KB LDS; 6 per CU spills and is slower); each owns KN_CAP x 256 x 8 B of scratch
+constexpr int RING = 8;           // candidates a lane collects in LDS before it writes them out: 2 x 32 contiguous bytes per flush
+constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 per CU: 95 VGPRs, 38 KB LDS); each owns 256 x KN_CAP x 8 B of scratch
 
 struct Ws {
 	float* vproj;     // (n_img, V, 3)
@@ -46,8 +47,10 @@ struct Ws {
 	float* raw_normals; // (n_meshes, V, 3) un-normalised vertex-normal sums (backward)
 	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tile counter
 	float* zthr;      // (n_img, H, W) depth of the K-th nearest silhouette candidate (+inf: every candidate counts)  [backward]
-	float2* scratch;  // (raster workgroups, KN_CAP, 256) per-pixel candidate lists (depth, 1 - p) of the tile in flight
+	float2* scratch;  // (raster workgroups, 2, 256, KN_CAP) per-pixel candidate lists of the tile in flight: depths, then 1 - p; one contiguous run per pixel
 	int32_t* tile_any; // (n_img, tiles) 1 = some face's blurred bbox touches the tile
+	int32_t* tile_cnt; // (n_img, tiles) estimate of how many do (sampled)
+	int32_t* tile_order; // (n_img * tiles) tile ids, the tiles with the most faces first
 	int64_t raster_wgs;
 	int64_t bytes;
 };
@@ -70,7 +73,9 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	const int64_t tiles = n_img * cdiv(rp->image_w, TS) * cdiv(rp->image_h, TS);
 	o->raster_wgs = std::min<int64_t>(tiles, RASTER_WGS);
 	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
-	o->tile_any = c.take<int32_t>(tiles);
+	o->tile_any = c.take<int32_t>(2 * tiles);
+	o->tile_cnt = o->tile_any + tiles;
+	o->tile_order = c.take<int32_t>(tiles);
 	o->bytes = c.off;
 }
 
@@ -136,7 +141,7 @@ __device__ __forceinline__ void pix_range(float cmin, float cmax, int S, int* lo
 __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
 								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
 								  float4* __restrict__ frec, uint32_t* __restrict__ tb, int32_t* __restrict__ flags,
-								  int32_t* __restrict__ tile_any, int tiles_x, int tiles_per_img) {
+								  int32_t* __restrict__ tile_any, int32_t* __restrict__ tile_cnt, int tiles_x, int tiles_per_img) {
 	const int img = blockIdx.y;
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= F) return;
@@ -165,11 +170,15 @@ __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t
 			pix_range(fminf(y0, fminf(y1, y2)) - br, fmaxf(y0, fmaxf(y1, y2)) + br, H, &ylo, &yhi);
 			if (xlo <= xhi && ylo <= yhi) {
 				packed = (uint32_t)(xlo / TS) | ((uint32_t)(xhi / TS) << 8) | ((uint32_t)(ylo / TS) << 16) | ((uint32_t)(yhi / TS) << 24);
-				// mark the tiles this face can touch: the rasteriser skips the scan of a tile nobody marked (most of an image)
+				// count the faces of every tile this face can touch: the rasteriser skips the scan of a tile with none (most of an image)
+				// and takes the crowded tiles first (tile_order_kernel)
 				for (int ty = ylo / TS; ty <= yhi / TS; ++ty)
 					for (int tx = xlo / TS; tx <= xhi / TS; ++tx) {
-						int32_t* t = tile_any + (int64_t)img * tiles_per_img + ty * tiles_x + tx;
-						if (*t == 0) *t = 1;  // benign race: every writer stores 1
+						const int64_t ti = (int64_t)img * tiles_per_img + ty * tiles_x + tx;
+						if (tile_any[ti] == 0) tile_any[ti] = 1;  // benign race: every writer stores 1
+						// how MANY faces touch the tile is estimated from every 16th face (a cost estimate for the tile order: an atomic
+						// per face and tile serialises on the crowded tiles and made this kernel 20x slower)
+						if ((f & 15) == 0) atomicAdd(tile_cnt + ti, 16);
 					}
 			}
 		}
@@ -287,6 +296,35 @@ __global__ void normals_normalize_kernel(float* __restrict__ normals, int64_t n)
 	normals[i * 3] = x; normals[i * 3 + 1] = y; normals[i * 3 + 2] = z;
 }
 
+// ------------------------------------------------------------------------------------------------ tile order
+// The persistent rasteriser takes tiles from a queue, and a tile's cost grows with the faces that touch it (a pole of the mesh:
+// > 1000 candidates per pixel; most of an image: none).  Taken in image order, the expensive tiles of the last images arrive when
+// nothing is left to overlap them with -- the average wave was alive for 63 % of the kernel (SQ_WAVE_CYCLES / waves / duration).
+// Longest-processing-time-first: bucket the tiles by log2(face count), crowded buckets first.  One workgroup, counting sort.
+constexpr int ORDER_BUCKETS = 24;
+__global__ __launch_bounds__(1024) void tile_order_kernel(const int32_t* __restrict__ tile_any, const int32_t* __restrict__ tile_cnt, int total,
+														   int32_t* __restrict__ order) {
+	__shared__ int hist[ORDER_BUCKETS];
+	__shared__ int start[ORDER_BUCKETS];
+	const int tid = threadIdx.x;
+	if (tid < ORDER_BUCKETS) hist[tid] = 0;
+	__syncthreads();
+	// crowded -> small index; touched tiles whose faces all escaped the sample sit just in front of the empty ones
+	auto bucket = [&](int t) {
+		if (tile_any[t] == 0) return ORDER_BUCKETS - 1;
+		const int c = tile_cnt[t];
+		return c <= 0 ? ORDER_BUCKETS - 2 : max(0, ORDER_BUCKETS - 3 - (31 - __builtin_clz(c)));
+	};
+	for (int t = tid; t < total; t += 1024) atomicAdd(&hist[bucket(t)], 1);
+	__syncthreads();
+	if (tid == 0) {
+		int acc = 0;
+		for (int b = 0; b < ORDER_BUCKETS; ++b) { start[b] = acc; acc += hist[b]; }
+	}
+	__syncthreads();
+	for (int t = tid; t < total; t += 1024) order[atomicAdd(&start[bucket(t)], 1)] = t;  // order inside a bucket does not matter
+}
+
 // ------------------------------------------------------------------------------------------------ 3. tile rasteriser
 struct TileArgs {
 	find_render_params rp;
@@ -309,6 +347,7 @@ struct TileArgs {
 	float* zthr;
 	float2* scratch;
 	const int32_t* tile_any;
+	const int32_t* tile_order;
 	int tiles_per_img, total_tiles;
 	int ablate;              // profiling only (find_set_tuning "raster_ablate"): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math
 };
@@ -320,9 +359,11 @@ struct TileArgs {
 __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	__shared__ int list[2 * BATCH];
 	__shared__ FaceRec rec[BATCH];
-	__shared__ int wcount[4];
-	__shared__ int n_list;
+	__shared__ int wcount2[2][4];
 	__shared__ int s_tile;
+	// write-combining rings of the candidate lists: [slot][thread], so that a wave's appends (different slots per lane) never conflict
+	__shared__ float ring_z[RING][256];
+	__shared__ float ring_q[RING][256];
 
 	const int H = a.rp.image_h, W = a.rp.image_w;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,15 +372,33 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	const int K = a.rp.sil_faces_per_pixel;
 	const bool want_sil = a.mask != nullptr;
 	const bool want_rgb = a.image != nullptr || a.p2f_out != nullptr || a.zbuf_out != nullptr;
-	float* const scr_z = reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256);  // [KN_CAP][256] depths
-	float* const scr_q = scr_z + KN_CAP * 256;                                                        // [KN_CAP][256] 1 - p
+	// Candidate lists: every pixel (thread) owns ONE contiguous run of KN_CAP depths and one of KN_CAP (1 - p) values.  A lane collects
+	// RING candidates in LDS and writes them out as whole 32-byte pieces (two 16-byte stores per array): the lists reach memory as
+	// full sectors, once.  (First version: entry i of all 256 pixels interleaved, one 4-byte store per candidate -- lanes of a wave sit
+	// at different i, so every store dirtied its own line: 5.3 GB written and 2.9 GB read per C3 launch for 0.5 GB of list data.)
+	float* const scr_z = reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256) + tid * KN_CAP;
+	float* const scr_q = scr_z + KN_CAP * 256;
+	auto flush_ring = [&](int base, int valid) {   // ring -> list entries [base, base + RING); slots >= valid become (+inf, 1): never selected
+		float zv[RING], qv[RING];
+#pragma unroll
+		for (int u = 0; u < RING; ++u) {
+			zv[u] = u < valid ? ring_z[u][tid] : INFINITY;
+			qv[u] = u < valid ? ring_q[u][tid] : 1.0f;
+		}
+#pragma unroll
+		for (int u = 0; u < RING; u += 4) {
+			*reinterpret_cast<float4*>(scr_z + base + u) = make_float4(zv[u], zv[u + 1], zv[u + 2], zv[u + 3]);
+			*reinterpret_cast<float4*>(scr_q + base + u) = make_float4(qv[u], qv[u + 1], qv[u + 2], qv[u + 3]);
+		}
+	};
 
 	for (;;) {
 		if (tid == 0) s_tile = atomicAdd(&a.flags[3], 1);
 		__syncthreads();
-		const int t_id = s_tile;
+		const int t_q = s_tile;
 		__syncthreads();
-		if (t_id >= a.total_tiles) break;
+		if (t_q >= a.total_tiles) break;
+		const int t_id = a.tile_order[t_q];
 		const int img = t_id / a.tiles_per_img, tile = t_id - img * a.tiles_per_img;
 		const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
 		// wave w owns the 8x8-pixel quadrant (w&1, w>>1) of the tile: faces are culled per wave against that quadrant
@@ -356,9 +415,6 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 		int cnt = 0;
 		float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
 		int bf = -1;
-
-		if (tid == 0) n_list = 0;
-		__syncthreads();
 
 		const uint32_t* tbp = a.tb + (int64_t)img * a.F;
 		const float4* frp = a.frec + (int64_t)img * a.F * 3;
@@ -385,7 +441,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						const float sd = fr.inside ? -fr.dist : fr.dist;
 						const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
 						alpha *= (1.0f - prob);
-						if (cnt < KN_CAP && !(a.ablate & 1)) { scr_z[cnt * 256 + tid] = fr.pz_clip; scr_q[cnt * 256 + tid] = 1.0f - prob; }
+						if (cnt < KN_CAP && !(a.ablate & 1)) {
+							const int slot = cnt & (RING - 1);
+							ring_z[slot][tid] = fr.pz_clip; ring_q[slot][tid] = 1.0f - prob;
+							if (slot == RING - 1) flush_ring(cnt - (RING - 1), RING);
+						}
 						++cnt;
 						z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bisection bounds)
 					}
@@ -398,39 +458,49 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 		};
 
 		const int nF = a.tile_any[t_id] ? a.F : 0;  // nothing can touch this tile: straight to the background write
-		for (int base = 0; base < nF; base += 256) {
-			const int f = base + tid;
-			bool hit = false;
-			if (f < nF) {
-				const uint32_t t = tbp[f];
-				const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
-				hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;
+		// Scan of the packed bboxes, 1024 faces per round: the four loads of a thread are in flight together (the scan is bound by the
+		// latency of this load, not by its bytes), then four ordered compactions -- ballot per wave, exclusive offsets across the waves
+		// through LDS (one barrier each: the wave counts alternate between two sets), the running length kept in a register.
+		int nl = 0;   // == n_list, replicated in every thread
+		int par = 0;
+		for (int base = 0; base < nF; base += 1024) {
+			uint32_t tbv[4];
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int f = base + r * 256 + tid;
+				tbv[r] = f < nF ? tbp[f] : TB_EMPTY;
 			}
-			// ordered compaction: ballot per wave, exclusive offsets across waves through LDS
-			const unsigned long long m = __ballot(hit);
-			if (lane == 0) wcount[wave] = __popcll(m);
-			__syncthreads();
-			int off = n_list;
-			for (int w = 0; w < wave; ++w) off += wcount[w];
-			if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = f;
-			__syncthreads();
-			if (tid == 0) n_list += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-			__syncthreads();
-			if (n_list >= BATCH) {  // uniform
-				shade_batch(BATCH);
-				const int rest = n_list - BATCH;
-				int moved = 0;
-				if (tid < rest) moved = list[BATCH + tid];
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				if (base + r * 256 >= nF) break;  // uniform
+				const uint32_t t = tbv[r];
+				const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
+				const bool hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;  // (TB_EMPTY: tx0 = 255 > tx1 = 0)
+				const unsigned long long m = __ballot(hit);
+				if (lane == 0) wcount2[par][wave] = __popcll(m);
 				__syncthreads();
-				if (tid < rest) list[tid] = moved;
-				if (tid == 0) n_list = rest;
-				__syncthreads();
+				int off = nl;
+				for (int w = 0; w < wave; ++w) off += wcount2[par][w];
+				if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = base + r * 256 + tid;
+				nl += wcount2[par][0] + wcount2[par][1] + wcount2[par][2] + wcount2[par][3];
+				par ^= 1;
+				if (nl >= BATCH) {  // uniform
+					__syncthreads();
+					shade_batch(BATCH);
+					const int rest = nl - BATCH;
+					int moved = 0;
+					if (tid < rest) moved = list[BATCH + tid];
+					__syncthreads();
+					if (tid < rest) list[tid] = moved;
+					nl = rest;
+					__syncthreads();
+				}
 			}
 		}
-		if (n_list > 0) shade_batch(n_list);
+		if (nl > 0) { __syncthreads(); shade_batch(nl); }
 
 		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
-		// lane finds the K-th smallest depth of its OWN list (reads scr_z[i*256 + tid]: coalesced across the wave) by bisection
+		// lane finds the K-th smallest depth of its OWN list (16-byte reads of its contiguous run) by a radix search
 		// on the integer image of the depth (non-negative floats order like their bit patterns) with one counting pass per
 		// step, then blends, in face order, the candidates in front of it and as many of those AT it as still fit.
 		float thr = INFINITY;
@@ -456,8 +526,29 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					atomicAdd(&a.flags[21], (int)__popcll(ov_all));
 				}
 				if (over && cnt <= KN_CAP) {
-					const float* zp = scr_z + tid;
-					const float* qp = scr_q + tid;
+					// the candidates still in the ring join the list, padded to a whole piece with (+inf, 1) entries that no pass selects
+					if (cnt & (RING - 1)) flush_ring(cnt & ~(RING - 1), cnt & (RING - 1));
+					const float4* z4 = reinterpret_cast<const float4*>(scr_z);
+					const float4* q4 = reinterpret_cast<const float4*>(scr_q);
+					const int n4 = (cnt + 3) >> 2;   // 16-byte pieces to read (the padding of the last one is inert)
+					// one pass over the lane's depths, KU entries in flight, fn(bits of the depth)
+					auto scan_z = [&](auto&& fn) {
+						int i = 0;
+						for (; i + KU / 4 <= n4; i += KU / 4) {
+							float4 v[KU / 4];
+#pragma unroll
+							for (int u = 0; u < KU / 4; ++u) v[u] = z4[i + u];
+#pragma unroll
+							for (int u = 0; u < KU / 4; ++u) {
+								fn(__float_as_uint(v[u].x + 0.0f)); fn(__float_as_uint(v[u].y + 0.0f));
+								fn(__float_as_uint(v[u].z + 0.0f)); fn(__float_as_uint(v[u].w + 0.0f));
+							}
+						}
+						for (; i < n4; ++i) {
+							const float4 v = z4[i];
+							fn(__float_as_uint(v.x + 0.0f)); fn(__float_as_uint(v.y + 0.0f)); fn(__float_as_uint(v.z + 0.0f)); fn(__float_as_uint(v.w + 0.0f));
+						}
+					};
 					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
 					// Radix search for the K-th smallest depth.  Invariant: every candidate lies in [lo, hi] or was counted in c_lo
 					// (candidates in front of lo) or lies behind hi; the K-th smallest is inside [lo, hi].  A level histograms
@@ -472,20 +563,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						const int shift = span < 32u ? 0 : (27 - __builtin_clz(span));  // (span >> shift) <= 31
 #pragma unroll
 						for (int w = 0; w < 16; ++w) hist[w * 256] = 0u;
-						auto tally = [&](unsigned zb) {
+						scan_z([&](unsigned zb) {
 							if (zb < lo || zb > hi) return;
 							const unsigned bin = (zb - lo) >> shift;
 							__hip_atomic_fetch_add(hist + (bin >> 1) * 256, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						};
-						int i = 0;
-						for (; i + KU <= cnt; i += KU) {
-							unsigned bz[KU];
-#pragma unroll
-							for (int u = 0; u < KU; ++u) bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f);
-#pragma unroll
-							for (int u = 0; u < KU; ++u) tally(bz[u]);
-						}
-						for (; i < cnt; ++i) tally(__float_as_uint(zp[i * 256] + 0.0f));
+						});
 						// the bin that holds the (K - c_lo)-th candidate of the range
 						const int need = K - c_lo;
 						int acc = 0, sel = 31, in_sel = 0;
@@ -510,13 +592,12 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 							// fetch the (at most 4) candidates of the bin and take the (K - c_lo)-th smallest of them
 							unsigned c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
 							int m = 0;
-							for (int j = 0; j < cnt; ++j) {
-								const unsigned zb = __float_as_uint(zp[j * 256] + 0.0f);
+							scan_z([&](unsigned zb) {
 								if (zb >= lo && zb <= hi) {
 									if (m == 0) c0 = zb; else if (m == 1) c1 = zb; else if (m == 2) c2 = zb; else c3 = zb;
 									++m;
 								}
-							}
+							});
 							// sort the four (absent ones are +max) and index
 							unsigned t;
 							if (c0 > c1) { t = c0; c0 = c1; c1 = t; }
@@ -535,23 +616,24 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					int ties = K - c_lo;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
 					float asel = 1.0f;
 					{
+						auto take = [&](float z, float q) {
+							const unsigned zb = __float_as_uint(z + 0.0f);
+							if (zb < lo) asel *= q;
+							else if (zb == lo && ties > 0) { asel *= q; --ties; }
+						};
 						int i = 0;
-						for (; i + KU <= cnt; i += KU) {
-							unsigned bz[KU];
-							float qv[KU];
+						for (; i + KU / 4 <= n4; i += KU / 4) {
+							float4 zv[KU / 4], qv[KU / 4];
 #pragma unroll
-							for (int u = 0; u < KU; ++u) { bz[u] = __float_as_uint(zp[(i + u) * 256] + 0.0f); qv[u] = qp[(i + u) * 256]; }
+							for (int u = 0; u < KU / 4; ++u) { zv[u] = z4[i + u]; qv[u] = q4[i + u]; }
 #pragma unroll
-							for (int u = 0; u < KU; ++u) {
-								if (bz[u] < lo) asel *= qv[u];
-								else if (bz[u] == lo && ties > 0) { asel *= qv[u]; --ties; }
+							for (int u = 0; u < KU / 4; ++u) {
+								take(zv[u].x, qv[u].x); take(zv[u].y, qv[u].y); take(zv[u].z, qv[u].z); take(zv[u].w, qv[u].w);
 							}
 						}
-						for (; i < cnt; ++i) {
-							const unsigned zb = __float_as_uint(zp[i * 256] + 0.0f);
-							const float qi = qp[i * 256];
-							if (zb < lo) asel *= qi;
-							else if (zb == lo && ties > 0) { asel *= qi; --ties; }
+						for (; i < n4; ++i) {
+							const float4 zv = z4[i], qv = q4[i];
+							take(zv.x, qv.x); take(zv.y, qv.y); take(zv.z, qv.z); take(zv.w, qv.w);
 						}
 					}
 					alpha = asel;
@@ -995,9 +1077,9 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one scan serves both
 	const float blur = mask ? rp->sil_blur_radius : 0.0f;
 	const int tiles_x = (int)cdiv(W, TS), tiles_per_img = tiles_x * (int)cdiv(H, TS);
-	(void)hipMemsetAsync(w.tile_any, 0, n_img * (int64_t)tiles_per_img * sizeof(int32_t), s);
+	(void)hipMemsetAsync(w.tile_any, 0, 2 * n_img * (int64_t)tiles_per_img * sizeof(int32_t), s);   // flags and counts
 	hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, w.vproj, faces, fstride, (int)n_views, V, F, H, W,
-					   blur, rp->z_clip, w.frec, w.tb, w.flags, w.tile_any, tiles_x, tiles_per_img);
+					   blur, rp->z_clip, w.frec, w.tb, w.flags, w.tile_any, w.tile_cnt, tiles_x, tiles_per_img);
 	if (image) {
 		(void)hipMemsetAsync(w.normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.normals);
@@ -1013,8 +1095,9 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = (int)cdiv(W, TS);
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
-	a.zthr = w.zthr; a.scratch = w.scratch; a.tile_any = w.tile_any;
+	a.zthr = w.zthr; a.scratch = w.scratch; a.tile_any = w.tile_any; a.tile_order = w.tile_order;
 	a.tiles_per_img = (int)(a.tiles_x * cdiv(H, TS)); a.total_tiles = (int)(a.tiles_per_img * n_img);
+	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, w.tile_any, w.tile_cnt, a.total_tiles, w.tile_order);
 	a.ablate = find::g_raster_ablate;
 	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)w.raster_wgs), dim3(256), 0, s, a);
 	FIND_LAUNCH_CHECK("find_render_fwd");
