@@ -413,6 +413,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 
 		float alpha = 1.0f, z_lo = INFINITY, z_hi = 0.0f;
 		int cnt = 0;
+		int n_eval = 0;   // diagnostics (ablate bit 64): (pixel, face) tests this lane ran
 		float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
 		int bf = -1;
 
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					const int k = kb + __builtin_ctzll(qm);
 					qm &= qm - 1;
 					Frag fr;
+					if (a.ablate & 64) ++n_eval;
 					if ((a.ablate & 4) || !in_img || !eval_frag(rec[k], px, py, &fr)) continue;
 					if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
 						const float sd = fr.inside ? -fr.dist : fr.dist;
@@ -643,6 +645,12 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			}
 		}
 
+		if (a.ablate & 64) {  // diagnostics: [24] (pixel, face) tests issued (64-lane slots, in units of 64), [25] silhouette candidates (units of 64)
+			int te = n_eval, tc = in_img ? cnt : 0;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { te += __shfl_xor(te, d, 64); tc += __shfl_xor(tc, d, 64); }
+			if (lane == 0 && te) { atomicAdd(&a.flags[24], (te + 32) >> 6); atomicAdd(&a.flags[25], (tc + 32) >> 6); }
+		}
 		if (in_img) {
 			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
 			if (want_sil) {

@@ -29,6 +29,58 @@ def make_params(image_size=256, faces_per_pixel=100, background=(1., 1., 1.), li
 	return p
 
 
+# ---------------------------------------------------------------------------------------------- render watchdog
+# PyTorch3D clips faces that straddle the z-clip plane (znear / 2, renderer.py:231-234) into 1-2 triangles; this rasteriser does not:
+# it counts them (find_render_flags) and, like the pixels that collect more than 1024 silhouette candidates, they make the result differ
+# from the reference.  Neither occurs with FIND's cameras (0.3 m from a <= 0.15 m object; view_from('toes') leaves 0.06 m), so instead
+# of an implementation nobody exercises, a render that hits either case FAILS: the two counters travel to a pinned host buffer behind
+# the launch and are looked at when they have arrived -- at the next render call, or in check_render_flags() -- so the check costs no
+# synchronisation.  FLAG_POLICY: 'async' (default), 'sync' (wait and raise in the same call: tests), 'ignore'.
+FLAG_POLICY = 'async'
+_pending = []   # (event, pinned int32[2], description)
+
+
+def _raise_if_flagged(vals, what):
+	if vals[0] > 0 or vals[1] > 0:
+		raise RuntimeError(f'find_amd.render: {what}: {vals[0]} face(s) straddle the z-clip plane (PyTorch3D would clip them; this rasteriser '
+						   f'does not) and {vals[1]} pixel(s) collected more than 1024 silhouette candidates (K-nearest rule not applied): the '
+						   'result would differ from the reference.  Move the camera, or set functional_render.FLAG_POLICY = "ignore".')
+
+
+def check_render_flags(wait=False):
+	"""Look at the counters of earlier renders that have arrived (all of them with wait=True); raises RuntimeError on the first bad one."""
+	global _pending
+	keep = []
+	try:
+		for i, (ev, host, what) in enumerate(_pending):
+			if wait:
+				ev.synchronize()
+			if ev.query():
+				_raise_if_flagged(host.tolist(), what)
+			else:
+				keep.append((ev, host, what))
+	except RuntimeError:
+		keep += _pending[i + 1:]
+		raise
+	finally:
+		_pending = keep
+
+
+def _watch(ws, what):
+	if FLAG_POLICY == 'ignore' or torch.cuda.is_current_stream_capturing():
+		return
+	check_render_flags()
+	host = torch.empty(2, dtype=torch.int32).pin_memory()
+	host.copy_(ws[:8].view(torch.int32), non_blocking=True)
+	ev = torch.cuda.Event()
+	ev.record()
+	_pending.append((ev, host, what))
+	if len(_pending) > 64:   # nobody ever looked: do it now rather than grow without bound
+		check_render_flags(wait=True)
+	if FLAG_POLICY == 'sync':
+		check_render_flags(wait=True)
+
+
 class _Render(torch.autograd.Function):
 	@staticmethod
 	def forward(ctx, verts, colors, faces, R, T, params, want_mask, want_image, want_frags):
@@ -52,6 +104,7 @@ class _Render(torch.autograd.Function):
 		zbuf = torch.empty(N, M, H, W, device=dev) if want_frags else None
 		check(L.find_render_fwd(ctypes.byref(params), ptr(verts), ptr(faces), fb, ptr(colors), ptr(R), ptr(T), N, M, V, F, ptr(mask), ptr(image),
 								ptr(p2f), ptr(zbuf), ptr(ws), ws.numel(), current_stream(dev)), 'find_render_fwd')
+		_watch(ws, f'render of {N} meshes x {M} views @{H}x{W}')
 		ctx.params, ctx.ws, ctx.dims = params, ws, (N, M, V, F, fb)
 		ctx.save_for_backward(verts, colors, faces, R, T, mask)
 		ctx.mark_non_differentiable(*[t for t in (p2f, zbuf) if t is not None])

@@ -107,12 +107,12 @@ def test_train_3d_loss_set_matches_oracle():
 		got = getattr(mwl.model, name).data.grad.cpu()
 		want = lat[k].grad
 		s = max(1e-3, want.abs().max().item())
-		assert (got - want).abs().max().item() < 2e-3 * s, (k, (got - want).abs().max().item(), s)
+		assert (got - want).abs().max().item() < 2e-4 * s, (k, (got - want).abs().max().item(), s)   # measured 1e-5 (nearest-neighbour picks are identical)
 	for k in ['base.0.weight', 'base.4.bias', 'mlp_disp.2.weight', 'mlp_disp.6.weight', 'mlp_col.0.weight', 'mlp_col.6.bias']:
 		got = dict(mwl.model.named_parameters())[k].grad.cpu()
 		want = sd[k].grad
 		s = max(1e-3, want.abs().max().item())
-		assert (got - want).abs().max().item() < 2e-3 * s, (k, (got - want).abs().max().item(), s)
+		assert (got - want).abs().max().item() < 2e-4 * s, (k, (got - want).abs().max().item(), s)   # measured 1e-5 (nearest-neighbour picks are identical)
 
 
 def test_z_cutoff_variants_match_oracle():

@@ -1,7 +1,9 @@
 """GPU parity of the HIP renderer (C-ABI find_render_fwd / find_render_bwd) against the render oracle
 (oracle/raster_ref.c naive rasteriser + shaders; oracle/render_ref.py differentiable restatement for gradients).
-Floats within the north_star's 1e-4; the nearest-face index map is compared exactly except on pixel centres that
-fall (to rounding) on a shared edge."""
+Floats -- outputs AND gradients -- within the north_star's 1e-4 (gradients relative to the tensor's largest entry; the kernel's
+v_rcp_f32 normalisations and its atomics' summation order stay far below that: measured 1e-6 .. 1.3e-5).  The nearest-face index
+map is compared exactly: a differing pixel must sit on a face boundary to rounding (_assert_index_mismatches_are_edge_ties; none
+differ at the test sizes).  The one looser bound is the K-overflow gradient test, which says why."""
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from oracle import camera_ref, render_ref
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+GRAD_TOL = 1e-4   # gradients relative to the tensor's largest entry; measured on MI355X: silhouette 1e-5, Phong image 1e-6 .. 1.3e-5
 
 
 def _scene(n_meshes=2, rings=14, segs=18, seed=0, n_views=2):
@@ -29,6 +32,40 @@ def _render_gpu(verts, faces, cols, R, T, size, **kw):
 	return FR.render(verts.cuda(), cols.cuda() if cols is not None else None, faces.cuda(), R.cuda(), T.cuda(), params, **kw), params
 
 
+def _assert_index_mismatches_are_edge_ties(p2f_gpu, p2f_ref, verts, faces, R, T, size, faces_per_mesh=None):
+	"""Index work is compared exactly: wherever the two nearest-face maps differ, the pixel centre must lie ON the boundary of a face
+	one of them picked -- to rounding: the smallest barycentric coordinate of that face, evaluated in float64 from the oracle's
+	projected vertices, is below 1e-5 in magnitude (`inside` is w > 0 for all three; the two implementations round the edge functions
+	differently, so only such pixels may legitimately flip).  Everything else is an error, however rare."""
+	rp = render_ref.default_params(size)
+	vproj = render_ref.project(rp, np.ascontiguousarray(verts), np.ascontiguousarray(R), np.ascontiguousarray(T)).astype(np.float64)   # (n_img, V, 3)
+	faces = np.asarray(faces)
+	a, b = np.asarray(p2f_gpu).reshape(-1, size, size), np.asarray(p2f_ref).reshape(-1, size, size)
+	F = faces.shape[-2]
+	n_views = R.shape[0]
+	bad = np.argwhere(a != b)
+	worst = 0.0
+	for img, yi, xi in bad:
+		px, py = 1.0 - (2.0 * xi + 1.0) / size, 1.0 - (2.0 * yi + 1.0) / size
+		tie = False
+		for packed in (a[img, yi, xi], b[img, yi, xi]):
+			if packed < 0:
+				continue
+			f = packed - img * F
+			assert 0 <= f < F, (packed, img, F)
+			fv = faces[f] if faces.ndim == 2 else faces[img // n_views][f]
+			(x0, y0, _), (x1, y1, _), (x2, y2, _) = vproj[img][fv]
+			area = (x2 - x0) * (y1 - y0) - (y2 - y0) * (x1 - x0)
+			w = [((px - x1) * (y2 - y1) - (py - y1) * (x2 - x1)) / area, ((px - x2) * (y0 - y2) - (py - y2) * (x0 - x2)) / area,
+				 ((px - x0) * (y1 - y0) - (py - y0) * (x1 - x0)) / area]
+			m = min(abs(x) for x in w)
+			if m < 1e-5:
+				tie = True
+				worst = max(worst, m)
+		assert tie, f'pix_to_face differs at image {img} pixel ({yi},{xi}) [{a[img, yi, xi]} vs {b[img, yi, xi]}] away from any face boundary'
+	return len(bad), worst
+
+
 @pytest.mark.parametrize('size', [64, 128])
 def test_forward_mask_image_vs_oracle(size):
 	verts, faces, cols, R, T = _scene()
@@ -38,6 +75,8 @@ def test_forward_mask_image_vs_oracle(size):
 	assert em < TOL, em
 	assert ref['mask'].max() > 0.99 and ref['mask'].min() == 0.0
 	same = (p2f.cpu().numpy() == ref['pix_to_face'])
+	n_bad, worst = _assert_index_mismatches_are_edge_ties(p2f.cpu().numpy(), ref['pix_to_face'], verts.numpy(), faces.numpy(), R.numpy(), T.numpy(), size)
+	print(f'pix_to_face @{size}: {n_bad} of {same.size} pixels differ, all on a face boundary (|w_min| <= {worst:.1e})')
 	assert same.mean() > 0.999, same.mean()
 	ei = np.abs(image.cpu().numpy() - ref['image'])[same].max()
 	assert ei < TOL, ei
@@ -78,7 +117,8 @@ def test_silhouette_backward_vs_oracle_autograd():
 	scale = vr.grad.abs().max().item()
 	assert scale > 0
 	err = (vg.grad.cpu() - vr.grad).abs().max().item()
-	assert err < 2e-3 * scale, (err, scale)
+	print(f'silhouette backward: max err {err:.3e} of scale {scale:.3e} = {err / scale:.2e}')
+	assert err < GRAD_TOL * scale, (err, scale)
 
 
 @pytest.mark.parametrize('rings,segs,size', [(8, 10, 48), (40, 50, 24)])
@@ -100,7 +140,8 @@ def test_image_backward_vs_oracle_autograd(rings, segs, size):
 	assert (cg.grad.cpu() - cr.grad).abs().max().item() < 1e-4 * sc
 	sv = vr.grad.abs().max().item()
 	err = (vg.grad.cpu() - vr.grad).abs().max().item()
-	assert err < 2e-3 * sv, (err, sv)
+	print(f'image backward ({rings}x{segs} @{size}): max err {err:.3e} of scale {sv:.3e} = {err / sv:.2e}')
+	assert err < GRAD_TOL * sv, (err, sv)
 
 
 def test_c3_size_properties():
@@ -218,8 +259,20 @@ def test_forward_edge_cases_vs_oracle():
 	"""What PyTorch3D's rasteriser handles at the edges (rasterize_meshes.cu / FootRenderer, renderer.py:208-245): per-mesh ragged
 	face lists (-1 padding), a zero-area face, a mesh wholly behind the camera, a view that sees nothing, an image size that is
 	not a multiple of the 16-pixel tile.  Same checks as the regular forward test."""
+	from find_amd import functional_render as FR
 	size = 40
 	verts, faces, cols, R, T = _scene(n_meshes=3, rings=7, segs=9, seed=11, n_views=3)
+	# (the mesh pushed behind one camera crosses the z-clip plane of another: faces that straddle it are rasterised unclipped by both
+	# the oracle and the kernel -- the documented deviation from PyTorch3D -- so the render watchdog is told to let this scene through)
+	monkey = FR.FLAG_POLICY
+	FR.FLAG_POLICY = 'ignore'
+	try:
+		_edge_cases_body(size, verts, faces, cols, R, T)
+	finally:
+		FR.FLAG_POLICY = monkey
+
+
+def _edge_cases_body(size, verts, faces, cols, R, T):
 	F = faces.shape[0]
 	fr = faces[None].expand(3, -1, -1).clone()
 	fr[1, F - 9:] = -1                      # mesh 1 has 9 faces fewer (ragged batch)
@@ -237,6 +290,7 @@ def test_forward_edge_cases_vs_oracle():
 	m = mask.cpu().numpy()
 	assert np.abs(m - ref['mask']).max() < TOL
 	same = (p2f.cpu().numpy() == ref['pix_to_face'])
+	_assert_index_mismatches_are_edge_ties(p2f.cpu().numpy(), ref['pix_to_face'], verts.numpy(), fr.numpy(), R.numpy(), T.numpy(), size)
 	assert same.mean() > 0.999, same.mean()
 	assert np.abs(image.cpu().numpy() - ref['image'])[same].max() < TOL
 	assert np.abs(zbuf.cpu().numpy() - ref['zbuf'])[same].max() < 1e-5
@@ -256,3 +310,38 @@ def test_forward_edge_cases_vs_oracle():
 	(mk, _, _, _), _ = _render_gpu(vg, fr, None, R, T, size, want_image=False)
 	mk.sum().backward()
 	assert torch.isfinite(vg.grad).all() and vg.grad[0].abs().max() > 0 and vg.grad[2].abs().max() >= 0
+
+
+def test_toes_view_matches_oracle_and_straddling_faces_fail_loudly():
+	"""view_from('toes') (renderer.py:192), the closest camera the reference defines, against the oracle; then a camera pushed INTO the
+	mesh: faces straddle the z-clip plane, PyTorch3D would clip them, this rasteriser does not -- the render must fail (checked
+	synchronously here; by default the counters are looked at one call later, functional_render.FLAG_POLICY)."""
+	from find_amd import functional_render as FR
+	from find_amd import synthetic
+	from find_amd.renderer import FootRenderer
+	v, f = synthetic.template(1002)
+	verts = v[None].clone()
+	rdr = FootRenderer(image_size=64, device='cuda')
+	R, T = rdr.view_from('toes')
+	Rn, Tn = camera_ref.look_at_view_transform(dist=0.1, elev=0.0, azim=0.0, at=((0.1, 0, 0),), up=((1, 0, 0),))
+	assert np.abs(R.numpy() - Rn).max() < 1e-6 and np.abs(T.numpy() - Tn).max() < 1e-6
+	prev, FR.FLAG_POLICY = FR.FLAG_POLICY, 'sync'
+	try:
+		(mask, _, p2f, zbuf), _ = _render_gpu(verts, f, None, R, T, 64, want_image=False, want_frags=True)
+		ref = render_ref.render(verts.numpy(), f.numpy(), None, Rn, Tn, image_size=64, want_image=False)
+		assert np.abs(mask.cpu().numpy() - ref['mask']).max() < TOL
+		assert zbuf[p2f >= 0].min().item() > 0.059
+		# camera 0.02 m from the origin, inside the ellipsoid: its far wall crosses z = 0.01
+		Rb, Tb = camera_ref.look_at_view_transform(dist=0.02, elev=0.0, azim=0.0, up=((1, 0, 0),))
+		with pytest.raises(RuntimeError, match='straddle the z-clip plane'):
+			_render_gpu(verts, f, None, torch.from_numpy(Rb), torch.from_numpy(Tb), 64, want_image=False)
+		FR.FLAG_POLICY = 'async'   # the default: the bad render returns, the NEXT call (or an explicit check) reports it
+		_render_gpu(verts, f, None, torch.from_numpy(Rb), torch.from_numpy(Tb), 64, want_image=False)
+		with pytest.raises(RuntimeError, match='straddle the z-clip plane'):
+			FR.check_render_flags(wait=True)
+	finally:
+		FR.FLAG_POLICY = prev
+		try:
+			FR.check_render_flags(wait=True)
+		except RuntimeError:
+			pass

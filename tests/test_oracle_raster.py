@@ -190,3 +190,74 @@ def test_phong_known_colour_and_background():
 	p2f1 = torch.from_numpy(np.where(out['pix_to_face'][0] >= 0, out['pix_to_face'][0], -1)).long().reshape(1, W, W, 1)
 	timg = render_ref.torch_phong_image(rp, torch.from_numpy(tri), torch.from_numpy(col), torch.from_numpy(faces), torch.from_numpy(I3), torch.from_numpy(T0), p2f1, 1)
 	np.testing.assert_allclose(timg[0, 0].numpy(), img, atol=2e-5)
+
+
+def test_two_triangle_fragment_table_computed_by_hand():
+	"""K = 2 fragment table of one pixel under two stacked triangles, every number derived by hand from SURVEY A.3 (not from the
+	oracle's code): a 1x1 image has its pixel centre at NDC (0, 0).
+	A (face 0), constant depth 1:  a0 (-.5,-.5)  a1 (.5,-.5)  a2 (0,.5)
+	   unnormalised edge functions at the origin: (0.25, 0.25, 0.5) of area 1 -> bary (1/4, 1/4, 1/2); z = 1;
+	   distances to the edges: bottom edge y = -.5 -> 0.5^2 = 0.25; side edges 2x + y - .5 = 0 -> (.5/sqrt 5)^2 = 0.05 -> dist = -0.05 (inside).
+	B (face 1), depths (1.5, 2.5, 2.0):  b0 (-.6,-.4)  b1 (.6,-.4)  b2 (0,.8): the origin is its centroid -> screen bary (1/3, 1/3, 1/3);
+	   perspective correction t = (w0 z1 z2, z0 w1 z2, z0 z1 w2) = (5/3, 1, 5/4), sum 47/12 -> bary (20/47, 12/47, 15/47);
+	   z = sum bary_i z_i = (30 + 30 + 30)/47 = 90/47 (the harmonic mean 3 / (1/1.5 + 1/2.5 + 1/2));
+	   edges: y = -.4 -> 0.16; side edges 1.2x + .6y - .48 = 0 -> .48^2 / 1.8 = 0.128 -> dist = -0.128.
+	Output order: ascending depth -> [A, B]."""
+	vp = np.array([[[-.5, -.5, 1.0], [.5, -.5, 1.0], [0.0, .5, 1.0], [-.6, -.4, 1.5], [.6, -.4, 2.5], [0.0, .8, 2.0]]], np.float32)
+	faces = np.array([[0, 1, 2], [3, 4, 5]])
+	p2f, zb, ba, di = render_ref.rasterize(vp, faces, 1, 1, 1, 2, 0.0)
+	assert p2f[0, 0, 0].tolist() == [0, 1]
+	np.testing.assert_allclose(zb[0, 0, 0], [1.0, 90.0 / 47.0], rtol=2e-7)
+	np.testing.assert_allclose(ba[0, 0, 0, 0], [0.25, 0.25, 0.5], atol=1e-7)
+	np.testing.assert_allclose(ba[0, 0, 0, 1], [20.0 / 47.0, 12.0 / 47.0, 15.0 / 47.0], atol=1e-7)
+	np.testing.assert_allclose(di[0, 0, 0], [-0.05, -0.128], rtol=1e-6)
+	# the same two faces listed the other way round: the table is ordered by depth, not by face index
+	p2f_r, zb_r, _, _ = render_ref.rasterize(vp, faces[::-1].copy(), 1, 1, 1, 2, 0.0)
+	assert p2f_r[0, 0, 0].tolist() == [1, 0]
+	np.testing.assert_allclose(zb_r[0, 0, 0], [1.0, 90.0 / 47.0], rtol=2e-7)
+	# with the silhouette pass's clipped barycentrics (blur > 0) an inside pixel keeps the same numbers, and the soft mask of the two
+	# fragments is 1 - (1 - sigmoid(.05 / 1e-4)) (1 - sigmoid(.128 / 1e-4)) = 1 to fp32
+	p2f_c, zb_c, ba_c, di_c = render_ref.rasterize(vp, faces, 1, 1, 1, 2, 9.21e-4)
+	np.testing.assert_allclose(ba_c[0, 0, 0, 1], [20.0 / 47.0, 12.0 / 47.0, 15.0 / 47.0], atol=1e-7)
+	assert render_ref.silhouette(p2f_c, di_c)[0, 0, 0] == 1.0
+
+
+def test_sphere_silhouette_area_is_analytic():
+	"""A sphere of radius r seen from distance d through FoVPerspectiveCameras(fov 60) projects to a disc of NDC radius
+	rho = s r / sqrt(d^2 - r^2), s = 1 / tan(30 deg) (the tangent cone of the sphere): the pixels covered by the K = 1 / blur 0 pass,
+	times the NDC area of a pixel, must be pi rho^2.  Pins the projection scale, the pixel <-> NDC mapping and the coverage test in one
+	number.  The SOFT silhouette is wider by the blur margin (every face within sqrt(blur_radius) = 0.03 NDC of a pixel adds to it)."""
+	from find_amd import synthetic
+	r, d, W = 0.1, 0.3, 128
+	v, f = synthetic.ellipsoid_mesh(40, 80, axes=(r, r, r))
+	R, T = camera_ref.look_at_view_transform(dist=d, elev=20.0, azim=-35.0, up=((1, 0, 0),))
+	rp = render_ref.default_params(W)
+	vp = render_ref.project(rp, v[None].numpy(), R, T)
+	p2f, _, _, _ = render_ref.rasterize(vp, f.numpy(), 1, W, W, 1, 0.0)
+	rho = S * r / math.sqrt(d * d - r * r)
+	hard = (p2f[0, :, :, 0] >= 0).astype(np.float64)
+	area = float(hard.sum()) * (2.0 / W) ** 2
+	assert abs(area / (math.pi * rho * rho) - 1.0) < 0.005, (area, math.pi * rho * rho)
+	# the disc is centred: its centroid is the image centre to a fraction of a pixel
+	ys, xs = np.mgrid[0:W, 0:W]
+	assert abs((hard * xs).sum() / hard.sum() - (W - 1) / 2) < 0.3 and abs((hard * ys).sum() / hard.sum() - (W - 1) / 2) < 0.3
+	# soft silhouette: contains the disc, and exceeds it by a ring no wider than the blur margin
+	soft = render_ref.render(v[None].numpy(), f.numpy(), None, R, T, image_size=W, want_image=False)['mask'][0, 0]
+	assert (soft[hard > 0] > 0.5).all()
+	soft_area = float(soft.sum()) * (2.0 / W) ** 2
+	ring = 2 * math.pi * rho * math.sqrt(rp.sil_blur_radius)
+	assert math.pi * rho * rho < soft_area < math.pi * rho * rho + ring
+
+
+def test_toes_view_stays_in_front_of_the_clip_plane():
+	"""FootRenderer.view_from('toes') (renderer.py:192: dist 0.1, looking at (0.1, 0, 0)) is the closest camera the reference defines:
+	a foot-sized template stays 0.06 m in front of it, six times the z-clip distance znear / 2 = 0.01, so no face straddles the plane
+	and the cull-only treatment of the clip plane is exact for every FIND camera."""
+	from find_amd import synthetic
+	v, f = synthetic.template(1002)
+	R, T = camera_ref.look_at_view_transform(dist=0.1, elev=0.0, azim=0.0, at=((0.1, 0, 0),), up=((1, 0, 0),))
+	rp = render_ref.default_params(32)
+	vp = render_ref.project(rp, v[None].numpy(), R, T)
+	assert vp[..., 2].min() > 0.059
+	p2f, zb, _, _ = render_ref.rasterize(vp, f.numpy(), 1, 32, 32, 1, 0.0)
+	assert (p2f >= 0).mean() > 0.3 and zb[p2f >= 0].min() > 0.059

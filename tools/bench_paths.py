@@ -48,6 +48,34 @@ def views(m, seed=7):
 	return look_at_view_transform(dist=np.full(m, 0.3), elev=rng.uniform(-90, 90, m), azim=rng.uniform(-90, 90, m), up=((1, 0, 0),))
 
 
+# HBM-side bytes per forward launch of raster_tile_kernel / per launch of sil_bwd_kernel at the C3 shape, rocprofv3 --pmc FETCH_SIZE (x2, the
+# gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r02_raster_pmc.txt)
+RASTER_TRAFFIC_C3 = {'raster_tile_kernel': None, 'sil_bwd_kernel': None}
+
+
+def raster_counts(verts, fc, Rc, Tc, params):
+	"""(pixel x face tests issued, silhouette candidates) of one forward render: the rasteriser's diagnostic counters (ablation bit 64)."""
+	import ctypes
+	from find_amd import _lib
+	from find_amd._lib import check, current_stream, ptr
+	from find_amd.functional import _faces_i32, _ws
+	L = _lib.lib()
+	N, V = verts.shape[0], verts.shape[1]
+	M, F = Rc.shape[0], fc.shape[0]
+	faces = _faces_i32(fc)
+	_lib.set_tuning('raster_ablate', 64)
+	try:
+		ws = _ws(L.find_render_ws_bytes(ctypes.byref(params), N, M, V, F), verts.device)
+		mask = torch.empty(N, M, params.image_h, params.image_w, device=verts.device)
+		check(L.find_render_fwd(ctypes.byref(params), ptr(verts), ptr(faces), 1, None, ptr(Rc), ptr(Tc), N, M, V, F, ptr(mask), None, None, None, ptr(ws),
+								ws.numel(), current_stream(verts.device)), 'find_render_fwd')
+		torch.cuda.synchronize()
+		fl = ws[:256].view(torch.int32).cpu().tolist()
+	finally:
+		_lib.set_tuning('raster_ablate', 0)
+	return fl[24] * 64, fl[25] * 64, fl[4]
+
+
 def bench_render(n_feet, n_views, size, want_image, cpu=None):
 	v, f = synthetic.template(6890)
 	g = torch.Generator().manual_seed(0)
@@ -72,6 +100,7 @@ def bench_render(n_feet, n_views, size, want_image, cpu=None):
 		loss.backward()
 
 	ms_f, ms_fb = gpu_ms(fwd), gpu_ms(fwdbwd)
+	tests, cands, over_px = raster_counts(verts, fc, Rc, Tc, params)
 	px = n_feet * n_views * size * size
 	images = n_feet * n_views
 	F = f.shape[0]
@@ -79,7 +108,10 @@ def bench_render(n_feet, n_views, size, want_image, cpu=None):
 	out = dict(path=f'render+{"phong+" if want_image else ""}silhouette fwd+bwd', workload=f'{n_feet} feet x {n_views} views @{size}^2, V=6890 F={F}',
 			   ms_fwd=ms_f, ms_fwd_bwd=ms_fb, vertices_views_per_s=n_feet * 6890 * n_views / (ms_fb * 1e-3), mpix_per_s_fwd=px / ms_f / 1e3,
 			   bytes_algorithmic=alg, achieved_GBs_fwd=alg / (ms_f * 1e-3) / 1e9, hbm_frac_fwd=alg / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
-			   bound='VALU/LDS (pixel x candidate-face tests); HBM floor %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
+			   pixel_face_tests=tests, tests_per_s_fwd=tests / (ms_f * 1e-3), silhouette_candidates=cands, pixels_over_K=over_px,
+			   candidate_list_bytes=8 * cands, lane_efficiency=cands / max(tests, 1),
+			   bound='latency of the per-tile work (VALU pipe ~22 %% busy, waves wait 60 %% of their time: profiles/r02_raster_pmc.txt), then HBM traffic of the '
+					 'per-pixel candidate lists (8 B per candidate, written once, read ~3x by the K-nearest pass); HBM floor of the fused output %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
 	if cpu:
 		dt = cpu('render', verts=verts[:1].cpu().numpy(), faces=f.numpy(), colors=cols[:1].cpu().numpy(), R=R[:1].numpy(), T=T[:1].numpy(), size=size,
 				 want_image=want_image)
