@@ -4,6 +4,7 @@
 #include "mlp_gemm5.h"
 #include "mlp_dw3.h"
 #include "mlp_gemm4.h"
+#include "mlp_fused.h"
 
 namespace find {
 namespace mlp {
@@ -111,7 +112,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -132,6 +133,7 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 1;        // the LDS-DMA ring kernels reserve the whole LDS of their CU (see "Co-residence" below)
+	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
 	// internal streams / events
 	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
 	hipEvent_t ev[N_EVENTS];
@@ -155,6 +157,12 @@ namespace mlp {
 		}                                                                                        \
 	} while (0)
 
+#define FIND_TRY(expr)                    \
+	do {                                  \
+		const int _r = (expr);            \
+		if (_r != FIND_OK) return _r;     \
+	} while (0)
+
 // Co-residence fault and the LDS reservation.  The LDS-DMA ring kernels (dw2, gemm3, gemm2, gemm4's prologue) are launched with the
 // WHOLE LDS of a CU although their rings need 100-128 KB.  With a second LDS-using workgroup of another stream resident on the same CU
 // (the 16-KB slab reduce of a side stream is enough) dw2 produced rare wrong partial tiles: one wave reads one 128-byte piece of one
@@ -166,8 +174,8 @@ namespace mlp {
 // reservation takes nothing these kernels use (one workgroup per CU anyway).  The attribute is set per (context, kernel) and its
 // return code is checked: a device that cannot grant the reservation refuses the launch instead of running unprotected.
 template <typename K>
-static int prepare_kernel(find_ctx* c, int id, K kernel, int need_bytes, int* launch_bytes) {
-	const int want = c->lds_exclusive ? c->lds_bytes : need_bytes;
+static int prepare_kernel(find_ctx* c, int id, K kernel, int need_bytes, int* launch_bytes, bool reserve = true) {
+	const int want = (reserve && c->lds_exclusive) ? c->lds_bytes : need_bytes;
 	if (need_bytes > c->lds_bytes) {
 		set_error("find_mlp: kernel needs %d bytes of LDS, device %d grants %d per workgroup", need_bytes, c->device, c->lds_bytes);
 		return FIND_EINVAL;
@@ -345,6 +353,39 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	return launch_gemm3(c, epi, b, feet, s);
 }
 
+// ---- fused chains (mlp_fused.h): one launch takes every 32-row tile through a list of layers
+struct Chain {
+	FusedArgs a;
+	Chain() { memset(&a, 0, sizeof(a)); }
+	FusedStep& add() { return a.step[a.n_steps++]; }
+	bool full(int more) const { return a.n_steps + more > FUSED_MAX_STEPS; }
+	// y = epi(x @ w^T): x from LDS (the previous step's result) unless src is given
+	FusedStep& gemm(const float* w, int ldw, int nchunk, const float* src = nullptr) {
+		FusedStep& s = add();
+		s.kind = FS_GEMM; s.w = w; s.ldw = ldw; s.nchunk = nchunk;
+		s.src = src; s.src_kind = src ? FS_SRC_GLOBAL : FS_SRC_LDS;
+		return s;
+	}
+};
+
+static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s) {
+	int lds = 0;
+	FIND_TRY(prepare_kernel(c, K_FUSED, &fused_chain_kernel, FUSED_LDS, &lds, false));   // no LDS-DMA in this kernel: no reservation
+	ch.a.V = (int)V;
+	ch.a.tiles_per_foot = (int)cdiv(V, 32);
+	ch.a.ntiles = (int)(ch.a.tiles_per_foot * feet);
+	const int grid = std::min(ch.a.ntiles, c->num_cus);
+	hipLaunchKernelGGL(fused_chain_kernel, dim3(grid), dim3(256), lds, s, ch.a);
+	FIND_LAUNCH_CHECK("fused_chain_kernel");
+	return FIND_OK;
+}
+
+static bool use_fused(const find_ctx* c, int64_t V, int64_t feet) {
+	const int64_t units = cdiv(V, 32) * feet;
+	if (c->f16 && units >= c->gemm5_min_units) return false;   // the opt-in fp16 kernels take launches of this size (the chain is fp32)
+	return c->fused_max_units > 0 && units <= c->fused_max_units;
+}
+
 static GemmArgs gemm_args_zero() {
 	GemmArgs a;
 	memset(&a, 0, sizeof(a));
@@ -372,12 +413,6 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 }
 
 static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 != 0); }
-
-#define FIND_TRY(expr)                    \
-	do {                                  \
-		const int _r = (expr);            \
-		if (_r != FIND_OK) return _r;     \
-	} while (0)
 
 static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const Dims& d, const FwdWs& w, const float* pos, const float* lat_disp,
 						const float* lat_col, float* disp, float* col) {
@@ -410,18 +445,54 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 	FIND_LAUNCH_CHECK("latent_bias_kernel");
 
-	// 3. trunk (model.py:421-426).  Layer 0 generates the Fourier features on the fly.
-	{
+	// 3 (+ 4, 5 for small calls). trunk (model.py:421-426); layer 0 generates the Fourier features on the fly
+	const bool fused = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	const bool fused_heads = fused && !(d.shared && n_feet > 1);   // per-foot rows: the heads are as small as the trunk
+	if (fused) {
+		Chain ch;
+		ch.a.pos = pos; ch.a.pos_foot_stride = V * 3; ch.a.Bm = p->B; ch.a.pe = p->pe_size;
+		{
+			FusedStep& s0 = ch.gemm(w.w0p, KP0, d.nchunk0);
+			s0.src_kind = FS_SRC_PE; s0.relu = 1; s0.bias = p->trunk_b[0]; s0.dst = w.H[0]; s0.to_lds = 1;
+		}
+		for (int i = 1; i < p->n_trunk; ++i) {
+			FusedStep& st = ch.gemm(p->trunk_w[i], W, W / KC);
+			st.relu = 1; st.bias = p->trunk_b[i]; st.dst = w.H[i]; st.to_lds = 1;
+		}
+		const float* hlast = w.H[p->n_trunk - 1];
+		if (!fused_heads) {
+			// shared template: the first layer of each head is H W0^T on the V template rows (bias + ReLU are broadcast per foot below)
+			if (disp) { FusedStep& st = ch.gemm(w.wd0, W, W / KC); st.dst = w.hp; }
+			if (col) { FusedStep& st = ch.gemm(w.wc0, W, W / KC); st.dst = disp ? w.hp2 : w.hp; }
+		} else {
+			auto head = [&](int which, float* const* act, int nl, const float* w0, const float* b0, int64_t bstride, const float* const* hw, const float* const* hb,
+							float* z, float* out, bool reload) {
+				FusedStep& f0 = ch.gemm(w0, W, W / KC, reload ? hlast : nullptr);
+				f0.relu = 1; f0.bias = b0; f0.bias_foot_stride = (int)bstride; f0.dst = act[0]; f0.to_lds = 1;
+				for (int i = 1; i < nl; ++i) {
+					FusedStep& st = ch.gemm(hw[i], W, W / KC);
+					st.relu = 1; st.bias = hb[i]; st.dst = act[i]; st.to_lds = 1;
+				}
+				FusedStep& o = ch.add();
+				o.kind = FS_OUT; o.w = hw[nl]; o.bias = hb[nl]; o.dst = out; o.dst2 = z; o.head = (unsigned char)which;
+				o.aux = which ? p->avg_col : nullptr;
+			};
+			if (disp) head(0, w.D, p->n_disp, w.wd0, bias_d0, bstride_d, p->disp_w, p->disp_b, w.zd, disp, false);
+			if (col) head(1, w.C, p->n_col, w.wc0, bias_c0, bstride_c, p->col_w, p->col_b, w.zc, col, disp != nullptr);
+		}
+		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		if (fused_heads) return FIND_OK;
+	} else {
 		GemmArgs a = gemm_args_zero();
 		a.pos = pos; a.pos_foot_stride = V * 3; a.Bm = p->B; a.pe = p->pe_size;
 		a.w0 = w.w0p; a.ldw = KP0; a.nchunk = d.nchunk0;
 		a.bias = p->trunk_b[0]; a.bias_foot_stride = 0;
 		a.y = w.H[0]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
 		FIND_TRY(launch_gemm(c, AMODE_PE, EPI_BIAS_RELU, a, d.feet_t, s));
+		for (int i = 1; i < p->n_trunk; ++i)
+			FIND_TRY(linear_fwd(c, w.H[i - 1], V * W, p->trunk_w[i], W, p->trunk_b[i], 0, w.H[i], V, d.feet_t, s));
+		FIND_LAUNCH_CHECK("trunk gemm");
 	}
-	for (int i = 1; i < p->n_trunk; ++i)
-		FIND_TRY(linear_fwd(c, w.H[i - 1], V * W, p->trunk_w[i], W, p->trunk_b[i], 0, w.H[i], V, d.feet_t, s));
-	FIND_LAUNCH_CHECK("trunk gemm");
 
 	// 4. heads (model.py:439-440); the trunk rows are shared by every foot when d.shared
 	const float* hl = w.H[p->n_trunk - 1];
@@ -431,11 +502,13 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	// over n_feet * V rows.  (The backward uses the same fact: footsum_kernel.)
 	auto head_first = [&](const float* w0, const float* bias, int64_t bstride, float* out, float* hp, hipStream_t st) -> int {
 		if (hp) {
-			GemmArgs a = gemm_args_zero();
-			a.a0 = hl; a.a_foot_stride = 0; a.lda = W;
-			a.w0 = w0; a.ldw = W; a.nchunk = W / KC;
-			a.y = hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-			FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_NONE, a, 1, st));
+			if (!fused) {   // (the fused trunk launch has already formed the product)
+				GemmArgs a = gemm_args_zero();
+				a.a0 = hl; a.a_foot_stride = 0; a.lda = W;
+				a.w0 = w0; a.ldw = W; a.nchunk = W / KC;
+				a.y = hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+				FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_NONE, a, 1, st));
+			}
 			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, st, hp, bias,
 							   bstride, (int)n_feet, V, out);
 			return FIND_OK;
@@ -471,7 +544,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		head_out(0, s);
 	}
 	if (col) {
-		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], sc != s ? w.hp2 : w.hp, sc));
+		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], (sc != s || (fused && disp)) ? w.hp2 : w.hp, sc));
 		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc));
 		head_out(1, sc);
 	}
@@ -783,6 +856,80 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const float* hl = w.H[p->n_trunk - 1];
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 
+	const bool fused = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	if (fused && !d.shared) {
+		// ---- small call (every layer has few rows: the reference's batch 1, the texture samples): the whole dX chain of both heads and
+		// the trunk is ONE fused launch (mlp_fused.h); every layer's dZ lands in its own buffer, and the weight gradients follow on the
+		// side streams (round-robin, one slab set per stream)
+		Chain ch;
+		int cd2 = 0, cc2 = 0;
+		auto head_chain = [&](int nl, float* const* act, float* const* dzbuf, float* const* wt, int& cur) {
+			for (int l = nl - 1; l >= 1; --l) {
+				FusedStep& st = ch.gemm(wt[l], W, W / KC, cur == 0 ? dzbuf[0] : nullptr);
+				st.mask = 1; st.aux = act[l - 1]; st.dst = dzbuf[cur + 1]; st.to_lds = 1;
+				cur += 1;
+			}
+		};
+		if (act_c) head_chain(p->n_col, w.C, b.dzC, b.Ct, cc2);
+		if (act_d) head_chain(p->n_disp, w.D, b.dzD, b.Dt, cd2);
+		{
+			// gradient wrt the trunk output: both heads summed in one accumulator, then masked by the trunk's last activation
+			const float* A[2]; const float* Wt[2]; int nb = 0;
+			if (act_d) { A[nb] = b.dzD[cd2]; Wt[nb] = b.Dt[0]; ++nb; }
+			if (act_c) { A[nb] = b.dzC[cc2]; Wt[nb] = b.Ct[0]; ++nb; }
+			for (int i = 0; i < nb; ++i) {
+				FusedStep& st = ch.gemm(Wt[i], W, W / KC, A[i]);
+				st.accum = i > 0;
+				if (i + 1 < nb) { st.keep = 1; continue; }
+				st.mask = 1; st.aux = hl; st.dst = b.dzT[0]; st.to_lds = 1;
+			}
+		}
+		int ct2 = 0;
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			FusedStep& st = ch.gemm(b.Tt[l], W, W / KC);
+			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[ct2 + 1]; st.to_lds = 1;
+			ct2 += 1;
+		}
+		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		// weight gradients: all inputs exist now.  Stream k uses slab set k (in order on its stream, so a set is never shared)
+		int rr = 0;
+		auto next_side = [&](BwdWs* bk) -> int {
+			const int k = fk.on ? rr % 3 : 0;
+			rr += 1;
+			*bk = b;
+			bk->pw = b.pw_t[k]; bk->pb = b.pb_t[k];
+			fk.fork_to(k);
+			return k;
+		};
+		auto head_wgrads = [&](int nl, float* const* act, float* const* dzbuf, int cur_last, float* const* gw, float* const* gb, const float* w0full, int ld0,
+							   const float* lat, int L, float* S, float* glat) -> int {
+			for (int l = nl - 1; l >= 1; --l) {
+				BwdWs bk; const int k = next_side(&bk);
+				FIND_TRY(weight_grad(c, &fk, dzbuf[nl - 1 - l], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(k)));
+			}
+			BwdWs bk; const int k = next_side(&bk);
+			FIND_TRY(weight_grad(c, &fk, dzbuf[cur_last], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, bk, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, fk.stream(k)));
+			if (L > 0) {
+				hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, fk.stream(k), w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0],
+								   (float*)nullptr);
+				FIND_LAUNCH_CHECK("latent_grad_kernel");
+			}
+			return FIND_OK;
+		};
+		if (act_d) FIND_TRY(head_wgrads(p->n_disp, w.D, b.dzD, cd2, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp));
+		if (act_c) FIND_TRY(head_wgrads(p->n_col, w.C, b.dzC, cc2, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col));
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			BwdWs bk; const int k = next_side(&bk);
+			FIND_TRY(weight_grad(c, &fk, b.dzT[p->n_trunk - 1 - l], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+		}
+		{
+			BwdWs bk; const int k = next_side(&bk);
+			FIND_TRY(weight_grad(c, &fk, b.dzT[ct2], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, bk, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(k)));
+		}
+		FIND_LAUNCH_CHECK("find_mlp_bwd");
+		return FIND_OK;
+	}
+
 	// 3. heads, last hidden layer down to the first.  Weight-gradient work (dW / db / latent gradients only feed the outputs, never
 	// the dX chain) goes to the side streams; every layer's dZ has its own buffer, so the dX chain on the caller's stream never waits.
 	int big_toggle = 0;
@@ -842,33 +989,61 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	if (act_d) FIND_TRY(head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS, T1));
 	if (act_c) FIND_TRY(head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2, T2));
 
-	// 4. gradient wrt the trunk output: both heads (and, for a shared trunk, every foot) summed in the K loop
+	// 4 + 5.  gradient wrt the trunk output -- both heads (and, for a shared trunk, every foot) summed in the K loop -- and the trunk's
+	// dX chain.  With few trunk rows (the shared template) all of it is one fused launch; the weight gradients follow on T1 / T2.
 	int ct = 0;
-	{
-		GemmArgs a = gemm_args_zero();
+	if (fused) {
+		Chain ch;
 		const float* A[2]; const float* Wt[2]; int nb = 0;
 		if (act_d) { A[nb] = d.shared ? b.zsD : b.dzD[cd]; Wt[nb] = b.Dt[0]; ++nb; }
 		if (act_c) { A[nb] = d.shared ? b.zsC : b.dzC[cc]; Wt[nb] = b.Ct[0]; ++nb; }
-		a.nbase = nb; a.a0 = A[0]; a.w0 = Wt[0];
-		if (nb > 1) { a.a1 = A[1]; a.w1 = Wt[1]; }
-		a.lda = W; a.ldw = W; a.nchunk = W / KC;
-		a.a_foot_stride = d.shared ? 0 : V * W;  // shared: the foot-summed (V,256) matrices
-		a.mask = hl; a.mask_foot_stride = V * W;
-		a.y = b.dzT[ct]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
-		FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_MASK, a, d.feet_t, s));
-		FIND_LAUNCH_CHECK("trunk-out dX gemm");
-	}
+		for (int i = 0; i < nb; ++i) {
+			FusedStep& st = ch.gemm(Wt[i], W, W / KC, A[i]);
+			st.accum = i > 0;
+			if (i + 1 < nb) { st.keep = 1; continue; }
+			st.mask = 1; st.aux = hl; st.dst = b.dzT[0]; st.to_lds = 1;
+		}
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			FusedStep& st = ch.gemm(b.Tt[l], W, W / KC);
+			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[p->n_trunk - l]; st.to_lds = 1;
+		}
+		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			const int k = fk.on ? 1 + (l & 1) : 0;
+			BwdWs bk = b;
+			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
+			fk.fork_to(k);
+			FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+			ct += 1;
+		}
+	} else {
+	// 4. gradient wrt the trunk output: both heads (and, for a shared trunk, every foot) summed in the K loop
+		{
+			GemmArgs a = gemm_args_zero();
+			const float* A[2]; const float* Wt[2]; int nb = 0;
+			if (act_d) { A[nb] = d.shared ? b.zsD : b.dzD[cd]; Wt[nb] = b.Dt[0]; ++nb; }
+			if (act_c) { A[nb] = d.shared ? b.zsC : b.dzC[cc]; Wt[nb] = b.Ct[0]; ++nb; }
+			a.nbase = nb; a.a0 = A[0]; a.w0 = Wt[0];
+			if (nb > 1) { a.a1 = A[1]; a.w1 = Wt[1]; }
+			a.lda = W; a.ldw = W; a.nchunk = W / KC;
+			a.a_foot_stride = d.shared ? 0 : V * W;  // shared: the foot-summed (V,256) matrices
+			a.mask = hl; a.mask_foot_stride = V * W;
+			a.y = b.dzT[ct]; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
+			FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_MASK, a, d.feet_t, s));
+			FIND_LAUNCH_CHECK("trunk-out dX gemm");
+		}
 
 	// 5. trunk: the dX chain runs back to back on the caller's stream, the layers' weight gradients -- independent of each other,
-	// each filling a fraction of the chip -- alternate between T1 and T2 (own slab set each); Q / set 0 keeps the Fourier layer
-	for (int l = p->n_trunk - 1; l >= 1; --l) {
-		const int k = fk.on ? 1 + (l & 1) : 0;
-		BwdWs bk = b;
-		bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
-		fk.fork_to(k);
-		FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
-		FIND_TRY(linear_bwd_dx(c, b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s));
-		ct += 1;
+		// each filling a fraction of the chip -- alternate between T1 and T2 (own slab set each); Q / set 0 keeps the Fourier layer
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			const int k = fk.on ? 1 + (l & 1) : 0;
+			BwdWs bk = b;
+			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
+			fk.fork_to(k);
+			FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+			FIND_TRY(linear_bwd_dx(c, b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s));
+			ct += 1;
+		}
 	}
 	fk.fork_to(Q);
 	fk.wait(Q, set_free[0]);
@@ -1001,7 +1176,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, INT32_MAX}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 

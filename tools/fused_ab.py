@@ -1,0 +1,49 @@
+"""A/B of the fused layer chains (find_ctx knob fused_max_units): MLP forward + backward at batch 1 (6890 template rows), on 1000 free
+points (the texture pass), and the C2 step (16 feet, shared trunk).  python tools/fused_ab.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from find_amd import _lib, synthetic
+
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, n=200, warm=30):
+	for _ in range(warm):
+		fn()
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	for _ in range(n):
+		fn()
+	torch.cuda.synchronize()
+	return (time.perf_counter() - t0) / n * 1e3
+
+
+def mlp_case(n_feet, n_verts, free_pts):
+	model = synthetic.make_model(n_verts if not free_pts else 1002, train_size=max(n_feet, 1), val_size=1, device=dev)
+	lat = synthetic.latents(n_feet, seed=0, device=dev)
+	pos = (torch.rand(n_feet, n_verts, 3, device=dev) * 0.2 - 0.1) if free_pts else None
+	params = [p for p in model.parameters() if p.requires_grad]
+
+	def step():
+		for p in params:
+			p.grad = None
+		lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+		if free_pts:
+			r = model(pos, shapevec=lv['shapevec'], texvec=lv['texvec'], posevec=lv['posevec'])
+			(r['disp'].sum() + r['col'].sum()).backward()
+		else:
+			r = model.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+			(r['verts'].sum() + r['col'].sum()).backward()
+	return step
+
+
+cases = [('batch 1 x 6890 template rows', mlp_case(1, 6890, False)), ('1 x 1000 free points', mlp_case(1, 1000, True)),
+		 ('C2: 16 feet x 6890 (shared trunk)', bench.build_step(dev, 0)[2])]
+for name, step in cases:
+	res = {}
+	for v in (0, 512, 0, 512):
+		_lib.set_tuning('fused_max_units', v)
+		res.setdefault(v, []).append(timeit(step, n=100 if 'C2' in name else 300))
+	print(f'{name}: unfused {min(res[0]):.3f} ms   fused {min(res[512]):.3f} ms', flush=True)
