@@ -112,7 +112,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_DW2G, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -374,8 +374,9 @@ static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStre
 	ch.a.V = (int)V;
 	ch.a.tiles_per_foot = (int)cdiv(V, 32);
 	ch.a.ntiles = (int)(ch.a.tiles_per_foot * feet);
+	ch.a.ablate = c->ablate;
 	const int grid = std::min(ch.a.ntiles, c->num_cus);
-	hipLaunchKernelGGL(fused_chain_kernel, dim3(grid), dim3(256), lds, s, ch.a);
+	hipLaunchKernelGGL(fused_chain_kernel, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
 	FIND_LAUNCH_CHECK("fused_chain_kernel");
 	return FIND_OK;
 }
@@ -452,7 +453,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		Chain ch;
 		ch.a.pos = pos; ch.a.pos_foot_stride = V * 3; ch.a.Bm = p->B; ch.a.pe = p->pe_size;
 		{
-			FusedStep& s0 = ch.gemm(w.w0p, KP0, d.nchunk0);
+			FusedStep& s0 = ch.gemm(w.w0p, KP0, (d.nchunk0 + 1) & ~1);   // even chunk counts (the padding columns of w0p are zeros)
 			s0.src_kind = FS_SRC_PE; s0.relu = 1; s0.bias = p->trunk_b[0]; s0.dst = w.H[0]; s0.to_lds = 1;
 		}
 		for (int i = 1; i < p->n_trunk; ++i) {
@@ -638,8 +639,14 @@ struct BwdWs {
 	float* pbo[2];
 	int nblk_out;
 	int64_t max_split;
+	float* grp_pw;   // small calls: slabs of the grouped weight-gradient launch, [job][slab][256][256], then the bias rows [job][slab][256]
+	int64_t grp_slabs;  // slabs per job
+	int grp_jobs;
 	int64_t bytes;
 };
+
+constexpr int64_t GROUP_MAX_UNITS = 1024;   // largest call (32-row tiles) that may take the fused / grouped small-call path
+constexpr int GROUP_MIN_CPS = 8;            // 16-row chunks per workgroup of a grouped weight gradient, at least
 
 static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, BwdWs* o) {
 	Carver c(scratch);
@@ -674,6 +681,12 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 		o->pS2 = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
 	} else {
 		o->zsD = o->zsC = o->pS = o->pS2 = nullptr;
+	}
+	o->grp_pw = nullptr; o->grp_slabs = 0; o->grp_jobs = 0;
+	if (!d.shared && cdiv(d.V, 32) * d.feet_t <= GROUP_MAX_UNITS) {
+		o->grp_jobs = (p->n_trunk - 1) + p->n_disp + p->n_col;
+		o->grp_slabs = d.n_feet * (cdiv(d.V / 16, GROUP_MIN_CPS) + 1);
+		o->grp_pw = c.take<float>((int64_t)o->grp_jobs * o->grp_slabs * ((int64_t)W * W + W));
 	}
 	o->nblk_out = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(d.rows_h, 64), 512));
 	for (int i = 0; i < 2; ++i) {
@@ -763,6 +776,52 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	r.nwblk = 256 * a.Kp / 4 / 64;
 	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
 	FIND_LAUNCH_CHECK("reduce_w_kernel");
+	return FIND_OK;
+}
+
+// Grouped weight gradients of a small call: every 256 x 256 layer's dW / db (and per-foot column sums) in ONE dw2 launch + ONE slab reduce.
+struct WgradGroup {
+	Dw2Group d;
+	ReduceWGroup r;
+	int n = 0, nmain = 0;
+	int64_t feet = 0;
+	WgradGroup() { memset(&d, 0, sizeof(d)); memset(&r, 0, sizeof(r)); }
+};
+
+static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const float* dz, const float* x, int64_t x_foot_stride, int64_t feet, int64_t V,
+						   float* dw, int ld_out, float* db, float* S) {
+	FIND_REQUIRE(G.n < b.grp_jobs && G.n < DW2_MAX_JOBS, "find_mlp_bwd: too many grouped weight gradients");
+	const int cpf16 = (int)(V / 16);
+	int spf = 1, cps2 = 1;
+	if (cpf16 > 0) {
+		const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
+		cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(GROUP_MIN_CPS, cpf16));
+		spf = (int)cdiv(cpf16, cps2);
+	}
+	const int nmain = (int)(feet * spf);
+	FIND_REQUIRE(nmain <= b.grp_slabs, "find_mlp_bwd: grouped weight gradient needs %d slabs, %lld reserved", nmain, (long long)b.grp_slabs);
+	float* pw = b.grp_pw + (int64_t)G.n * b.grp_slabs * W * W;
+	float* pb = b.grp_pw + (int64_t)b.grp_jobs * b.grp_slabs * W * W + (int64_t)G.n * b.grp_slabs * W;
+	Dw2Args& d2 = G.d.job[G.n];
+	d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
+	d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = pw; d2.pb = (db || S) ? pb : nullptr;
+	ReduceWArgs& r = G.r.job[G.n];
+	r.pw = pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = W;
+	r.pb = d2.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
+	r.nwblk = 256 * 256 / 4 / 64;
+	G.nmain = nmain; G.feet = feet;   // (every job of a group has the same geometry)
+	G.n += 1;
+	return FIND_OK;
+}
+
+static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
+	if (G.n == 0) return FIND_OK;
+	int lds = 0;
+	FIND_TRY(prepare_kernel(c, K_DW2G, &dw2_group_kernel, DW2_LDS, &lds));
+	hipLaunchKernelGGL(dw2_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(256), lds, s, G.d);
+	FIND_LAUNCH_CHECK("dw2_group_kernel");
+	hipLaunchKernelGGL(reduce_w_group_kernel, dim3((unsigned)(256 * 256 / 4 / 64 + (int)G.feet + 1), (unsigned)G.n), dim3(1024), 0, s, G.r);
+	FIND_LAUNCH_CHECK("reduce_w_group_kernel");
 	return FIND_OK;
 }
 
@@ -891,40 +950,57 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			ct2 += 1;
 		}
 		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
-		// weight gradients: all inputs exist now.  Stream k uses slab set k (in order on its stream, so a set is never shared)
+		// weight gradients: all inputs exist now.  fp32: every 256 x 256 layer in ONE grouped launch (+ one grouped slab reduce) on a side
+		// stream, the Fourier layer on another; the opt-in fp16 mode keeps its per-layer dw3 launches.
+		const bool grouped = !c->f16 && b.grp_pw != nullptr;
+		WgradGroup G;
 		int rr = 0;
 		auto next_side = [&](BwdWs* bk) -> int {
-			const int k = fk.on ? rr % 3 : 0;
+			const int k = fk.on ? 1 + rr % 2 : 0;
 			rr += 1;
 			*bk = b;
 			bk->pw = b.pw_t[k]; bk->pb = b.pb_t[k];
 			fk.fork_to(k);
 			return k;
 		};
+		auto one = [&](const float* dz, const float* x, int64_t xs, int64_t feet, float* dw, int ld_out, float* db, float* S) -> int {
+			if (grouped) return wgrad_group_add(c, G, b, dz, x, xs, feet, V, dw, ld_out, db, S);
+			BwdWs bk; const int k = next_side(&bk);
+			return weight_grad(c, &fk, dz, x, xs, nullptr, 0, p, 1, feet, V, bk, dw, ld_out, W, 0, db, S, fk.stream(k));
+		};
+		struct Lat { const float* w0full; int ld0; const float* lat; int L; float* S; float* glat; float* gw0; };
+		Lat lats[2]; int nlat = 0;
 		auto head_wgrads = [&](int nl, float* const* act, float* const* dzbuf, int cur_last, float* const* gw, float* const* gb, const float* w0full, int ld0,
 							   const float* lat, int L, float* S, float* glat) -> int {
-			for (int l = nl - 1; l >= 1; --l) {
-				BwdWs bk; const int k = next_side(&bk);
-				FIND_TRY(weight_grad(c, &fk, dzbuf[nl - 1 - l], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(k)));
-			}
-			BwdWs bk; const int k = next_side(&bk);
-			FIND_TRY(weight_grad(c, &fk, dzbuf[cur_last], hl, hl_stride, nullptr, 0, p, 1, n_feet, V, bk, gw[0], ld0, W, 0, gb[0], (L > 0) ? S : nullptr, fk.stream(k)));
-			if (L > 0) {
-				hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, fk.stream(k), w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0],
-								   (float*)nullptr);
-				FIND_LAUNCH_CHECK("latent_grad_kernel");
-			}
+			for (int l = nl - 1; l >= 1; --l) FIND_TRY(one(dzbuf[nl - 1 - l], act[l - 1], V * W, n_feet, gw[l], W, gb[l], nullptr));
+			FIND_TRY(one(dzbuf[cur_last], hl, hl_stride, n_feet, gw[0], ld0, gb[0], (L > 0) ? S : nullptr));
+			if (L > 0) lats[nlat++] = Lat{w0full, ld0, lat, L, S, glat, gw[0]};
 			return FIND_OK;
 		};
 		if (act_d) FIND_TRY(head_wgrads(p->n_disp, w.D, b.dzD, cd2, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp));
 		if (act_c) FIND_TRY(head_wgrads(p->n_col, w.C, b.dzC, cc2, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col));
-		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			BwdWs bk; const int k = next_side(&bk);
-			FIND_TRY(weight_grad(c, &fk, b.dzT[p->n_trunk - 1 - l], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+		for (int l = p->n_trunk - 1; l >= 1; --l)
+			FIND_TRY(one(b.dzT[p->n_trunk - 1 - l], w.H[l - 1], V * W, d.feet_t, g->trunk_w[l], W, g->trunk_b[l], nullptr));
+		// the latent gradients read the per-foot column sums S (written by the slab reduce): same stream, behind it
+		hipStream_t sl = s;
+		if (grouped) {
+			fk.fork_to(1);
+			sl = fk.stream(1);
+			FIND_TRY(wgrad_group_launch(c, G, sl));
+		} else if (fk.on) {
+			// (per-layer launches went to streams 1 / 2 round-robin: wait for both before the latent gradients on stream 1)
+			fk.chain(2, 1);
+			sl = fk.stream(1);
+		}
+		for (int i = 0; i < nlat; ++i) {
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, sl, lats[i].w0full, lats[i].ld0, lats[i].lat, lats[i].L, lats[i].S,
+							   (int)n_feet, lats[i].glat, lats[i].gw0, (float*)nullptr);
+			FIND_LAUNCH_CHECK("latent_grad_kernel");
 		}
 		{
-			BwdWs bk; const int k = next_side(&bk);
-			FIND_TRY(weight_grad(c, &fk, b.dzT[ct2], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, bk, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(k)));
+			const int k = fk.on ? 2 : 0;
+			fk.fork_to(k);
+			FIND_TRY(weight_grad(c, &fk, b.dzT[ct2], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(k)));
 		}
 		FIND_LAUNCH_CHECK("find_mlp_bwd");
 		return FIND_OK;
@@ -1176,7 +1252,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, INT32_MAX}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 

@@ -35,7 +35,7 @@ struct Dw2Args {
 constexpr int DW2_STAGE = 2 * 16 * 1024;                // dZ rows then X rows
 constexpr int DW2_LDS = 3 * DW2_STAGE + 4 * 256 * 4;    // + bias reduction scratch
 
-__global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
+__device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const unsigned lds_base = (unsigned)(uintptr_t)smem;
 	float* red = reinterpret_cast<float*>(smem + 3 * DW2_STAGE);
@@ -45,7 +45,6 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wn = wave >> 1, wk = wave & 1;
 	const int fh = lane >> 5;
-	const int split = blockIdx.x;
 	const int foot = split / g.spf;
 	const int sidx = split - foot * g.spf;
 	const int q0 = sidx * g.cps;
@@ -211,6 +210,21 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 		__syncthreads();
 		pb[tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
 	}
+}
+
+__global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) { dw2_body(g, blockIdx.x); }
+
+// Several weight gradients of the same geometry in ONE launch (blockIdx.y = job): the small calls -- batch 1, the texture samples --
+// have eleven 256 x 256 weight gradients of 54 workgroups each; launched one by one they neither fill the chip nor overlap well.
+constexpr int DW2_MAX_JOBS = 24;
+struct Dw2Group { Dw2Args job[DW2_MAX_JOBS]; };
+__global__ __launch_bounds__(256, 1) void dw2_group_kernel(const Dw2Group grp) {
+	const int j = blockIdx.y;
+	Dw2Args g;   // (fields copied one by one: a reference into the kernel-argument array makes the compiler copy the array to scratch)
+	g.dz = grp.job[j].dz; g.dz_foot_stride = grp.job[j].dz_foot_stride; g.x = grp.job[j].x; g.x_foot_stride = grp.job[j].x_foot_stride;
+	g.chunks_per_foot = grp.job[j].chunks_per_foot; g.tail_rows = grp.job[j].tail_rows; g.spf = grp.job[j].spf; g.cps = grp.job[j].cps;
+	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb;
+	dw2_body(g, blockIdx.x);
 }
 
 }  // namespace mlp

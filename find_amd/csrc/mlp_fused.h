@@ -9,10 +9,14 @@
 // in the kernel arguments, so the same kernel runs the forward (Fourier features -> trunk -> heads -> 3-wide outputs) and the dX
 // chain of the backward (masked transposed products, two-operand sums).
 //
-// MFMA: v_mfma_f32_32x32x2_f32, exact fp32.  A wave owns 64 output columns (two 32 x 32 accumulators) of the tile's 32 rows.
+// MFMA: v_mfma_f32_32x32x2_f32, exact fp32.  Eight waves (two per SIMD); a wave owns 32 output columns (one 32 x 32 accumulator) of
+// the tile's 32 rows and stages ITS OWN 32 weight rows through a private two-stage LDS ring: no workgroup barrier inside a layer, the
+// waves drift apart and one wave's staging / epilogue runs under the other's MFMAs (with four lock-stepped waves every phase of a chunk
+// -- L2 loads, LDS stores, barrier, fragment reads -- added to the MFMA time: 235 us per 12-layer chain against 84 us of matrix pipe;
+// tools/fused_micro.py).  Only the activation tile X is shared: two barriers per layer.
 // Operand reads: one ds_read_b128 per operand per EIGHT k -- lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 k = 8g+4 .. 8g+7, and MFMA s
 // pairs component s of both halves (the contraction order inside a chunk is permuted; the sum is the same set of products).
-// LDS: X 32 x 260 floats (rows padded by 16 B: conflict-free ds_read_b128 across 32 rows), two W chunks of 256 x 36 floats.
+// LDS: X 32 x 260 floats (rows padded by 16 B: conflict-free ds_read_b128 across 32 rows), per wave two W chunks of 32 x 36 floats.
 #pragma once
 #include "mlp_kernels.h"
 
@@ -30,7 +34,7 @@ struct FusedStep {
 	float* dst;           // GEMM: output rows (ld 256) or null.  OUT: activated output (rows, 3)
 	float* dst2;          // OUT: pre-activation z (rows, 3) or null
 	int ldw;
-	int nchunk;           // K = 32 * nchunk (PE: 8 chunks per regenerated 256-wide k-tile)
+	int nchunk;           // K = 32 * nchunk, EVEN (PE: 8 chunks per regenerated 256-wide k-tile; the padded weight's extra chunk is zeros)
 	int bias_foot_stride;
 	unsigned char kind;   // FS_GEMM / FS_OUT
 	unsigned char src_kind;
@@ -53,51 +57,50 @@ struct FusedArgs {
 	int V;                    // rows per foot
 	int tiles_per_foot;
 	int ntiles;
+	int ablate;               // profiling only: 1 no W staging (loads + LDS stores), 2 no MFMAs, 4 no epilogue, 8 no Fourier features
 };
 
 constexpr int FX_LD = 260;                       // X row stride (floats)
 constexpr int FW_LD = 36;                        // W chunk row stride (floats)
+constexpr int FUSED_NW = 8;                      // waves per workgroup
 constexpr int FUSED_X_BYTES = 32 * FX_LD * 4;    // 33 280
-constexpr int FUSED_W_BYTES = 256 * FW_LD * 4;   // 36 864 per stage
-constexpr int FUSED_LDS = FUSED_X_BYTES + 2 * FUSED_W_BYTES + 3 * 256 * 4;   // + Fourier matrix
+constexpr int FUSED_WS_BYTES = 32 * FW_LD * 4;   // one wave's chunk: 32 rows x 32 k, padded (4 608)
+constexpr int FUSED_LDS = FUSED_X_BYTES + FUSED_NW * 2 * FUSED_WS_BYTES + 3 * 256 * 4;   // + Fourier matrix
 
-__global__ __launch_bounds__(256, 1) void fused_chain_kernel(const FusedArgs g) {
+// A wave's W staging: lane -> row = lane / 8 (+ 8 q), 16-byte part = lane % 8: 8 lanes read one 128-B row piece.  The chunk stream of a
+// tile -- every 32-k chunk of every GEMM step, in order -- runs two chunks ahead of the MFMAs: chunk k+2 is requested into one of two
+// register sets while chunk k is multiplied, and chunk k+1 moves from its registers into the wave's idle LDS stage.
+#define FUSED_W_LOAD(set, wp, ldw_, c_)                                                                            \
+	do {                                                                                                           \
+		const float* _b = (wp) + (int64_t)(wave * 32 + w_row) * (ldw_) + (c_) * 32 + w_part * 4;                   \
+		const int64_t _s = (int64_t)8 * (ldw_);                                                                    \
+		set##0 = *reinterpret_cast<const float4*>(_b); set##1 = *reinterpret_cast<const float4*>(_b + _s);         \
+		set##2 = *reinterpret_cast<const float4*>(_b + 2 * _s); set##3 = *reinterpret_cast<const float4*>(_b + 3 * _s); \
+	} while (0)
+#define FUSED_W_STORE(set, Wc_)                                                                                    \
+	do {                                                                                                           \
+		float* _d = (Wc_) + w_row * FW_LD + w_part * 4;                                                            \
+		*reinterpret_cast<float4*>(_d) = set##0; *reinterpret_cast<float4*>(_d + 8 * FW_LD) = set##1;              \
+		*reinterpret_cast<float4*>(_d + 16 * FW_LD) = set##2; *reinterpret_cast<float4*>(_d + 24 * FW_LD) = set##3; \
+	} while (0)
+
+__global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* const X = reinterpret_cast<float*>(smem);
-	float* const Wc0 = reinterpret_cast<float*>(smem + FUSED_X_BYTES);
-	float* const Wc1 = reinterpret_cast<float*>(smem + FUSED_X_BYTES + FUSED_W_BYTES);
-	float* const Bl = reinterpret_cast<float*>(smem + FUSED_X_BYTES + 2 * FUSED_W_BYTES);
-
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	float* const Wc0 = reinterpret_cast<float*>(smem + FUSED_X_BYTES + wave * 2 * FUSED_WS_BYTES);   // this wave's ring
+	float* const Wc1 = Wc0 + 32 * FW_LD;
+	float* const Bl = reinterpret_cast<float*>(smem + FUSED_X_BYTES + FUSED_NW * 2 * FUSED_WS_BYTES);
 	const int li = lane & 31, lh = lane >> 5;
 	const int V = g.V;
+	const int w_row = lane >> 3, w_part = lane & 7;
 
 	if (g.pe > 0) {
-		for (int i = tid; i < 3 * g.pe; i += 256) Bl[i] = g.Bm[i];
+		for (int i = tid; i < 3 * g.pe; i += 512) Bl[i] = g.Bm[i];
 	}
-
-	// W chunk staging: thread -> 8 x 16 B of the 256 x 32 chunk (row = idx / 8, part = idx % 8: 8 threads read one 128-B row piece)
-	// (kept in eight named registers and moved by unconditional code: behind conditionals the compiler parks them in scratch memory)
-	float4 wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7;
-	const int w_row = tid >> 3, w_part = tid & 7;   // + 32 rows per q
-#define FUSED_W_LOAD(wp, ldw_, c_)                                                                              \
-	do {                                                                                                        \
-		const float* _b = (wp) + (int64_t)w_row * (ldw_) + (c_) * 32 + w_part * 4;                              \
-		const int64_t _s = (int64_t)32 * (ldw_);                                                                \
-		wr0 = *reinterpret_cast<const float4*>(_b); wr1 = *reinterpret_cast<const float4*>(_b + _s);            \
-		wr2 = *reinterpret_cast<const float4*>(_b + 2 * _s); wr3 = *reinterpret_cast<const float4*>(_b + 3 * _s); \
-		wr4 = *reinterpret_cast<const float4*>(_b + 4 * _s); wr5 = *reinterpret_cast<const float4*>(_b + 5 * _s); \
-		wr6 = *reinterpret_cast<const float4*>(_b + 6 * _s); wr7 = *reinterpret_cast<const float4*>(_b + 7 * _s); \
-	} while (0)
-#define FUSED_W_STORE(Wc_)                                                                                      \
-	do {                                                                                                        \
-		float* _d = (Wc_) + w_row * FW_LD + w_part * 4;                                                         \
-		*reinterpret_cast<float4*>(_d) = wr0; *reinterpret_cast<float4*>(_d + 32 * FW_LD) = wr1;                \
-		*reinterpret_cast<float4*>(_d + 64 * FW_LD) = wr2; *reinterpret_cast<float4*>(_d + 96 * FW_LD) = wr3;   \
-		*reinterpret_cast<float4*>(_d + 128 * FW_LD) = wr4; *reinterpret_cast<float4*>(_d + 160 * FW_LD) = wr5; \
-		*reinterpret_cast<float4*>(_d + 192 * FW_LD) = wr6; *reinterpret_cast<float4*>(_d + 224 * FW_LD) = wr7; \
-	} while (0)
+	int first_gemm = 0;
+	while (first_gemm < g.n_steps && g.step[first_gemm].kind != FS_GEMM) ++first_gemm;
 
 	for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
 		const int foot = tile / g.tiles_per_foot;
@@ -105,37 +108,47 @@ __global__ __launch_bounds__(256, 1) void fused_chain_kernel(const FusedArgs g) 
 		const int valid = min(32, V - v0);
 		const int64_t row0 = (int64_t)foot * V + v0;   // first global row of the tile
 
-		f32x16 acc[2];
-		int stage = 0;        // W ring stage holding the chunk about to be multiplied
-		bool primed = false;  // chunk 0 of the current step already sits in the ring (prefetched under the previous step)
+		// ---- prefetch cursor over the tile's chunk stream (wave-uniform scalars)
+		int pf_si = first_gemm, pf_c = 0;
+		const float* pf_w = g.step[pf_si < g.n_steps ? pf_si : 0].w;
+		int pf_ldw = g.step[pf_si < g.n_steps ? pf_si : 0].ldw, pf_n = g.step[pf_si < g.n_steps ? pf_si : 0].nchunk;
+		auto pf_advance = [&]() {   // past the end the cursor stays on the last chunk (re-fetched, never used)
+			if (pf_c + 1 < pf_n) { ++pf_c; return; }
+			int nx = pf_si + 1;
+			while (nx < g.n_steps && g.step[nx].kind != FS_GEMM) ++nx;
+			if (nx < g.n_steps) { pf_si = nx; pf_c = 0; pf_w = g.step[nx].w; pf_ldw = g.step[nx].ldw; pf_n = g.step[nx].nchunk; }
+		};
+		float4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;   // (named registers: a struct or an array ends up in scratch)
+		FUSED_W_LOAD(wa, pf_w, pf_ldw, pf_c); pf_advance();   // chunk 0
+		FUSED_W_LOAD(wb, pf_w, pf_ldw, pf_c); pf_advance();   // chunk 1
+		FUSED_W_STORE(wa, Wc0);                                // (the ring is this wave's own: its previous tile is done with it)
+		// chunk k of the stream sits in ring stage k & 1 when its turn comes, chunk k + 1 in register set (k + 1) & 1
 
+		f32x16 acc;
 		for (int si = 0; si < g.n_steps; ++si) {
 			// the step's fields as scalars (indexing the kernel-argument array through a reference makes the compiler copy it to scratch)
-			struct { const float *w, *bias, *src, *aux; float *dst, *dst2; int ldw, nchunk, bias_foot_stride, kind, src_kind, relu, mask, keep, accum, to_lds, head; } s;
+			struct { const float *w, *bias, *src, *aux; float *dst, *dst2; int nchunk, bias_foot_stride, kind, src_kind, relu, mask, keep, accum, to_lds, head; } s;
 			s.w = g.step[si].w; s.bias = g.step[si].bias; s.src = g.step[si].src; s.aux = g.step[si].aux; s.dst = g.step[si].dst; s.dst2 = g.step[si].dst2;
-			s.ldw = g.step[si].ldw; s.nchunk = g.step[si].nchunk; s.bias_foot_stride = g.step[si].bias_foot_stride; s.kind = g.step[si].kind;
+			s.nchunk = g.step[si].nchunk; s.bias_foot_stride = g.step[si].bias_foot_stride; s.kind = g.step[si].kind;
 			s.src_kind = g.step[si].src_kind; s.relu = g.step[si].relu; s.mask = g.step[si].mask; s.keep = g.step[si].keep; s.accum = g.step[si].accum;
 			s.to_lds = g.step[si].to_lds; s.head = g.step[si].head;
-			const bool next_gemm = si + 1 < g.n_steps && g.step[si + 1].kind == FS_GEMM;
-			const float* const next_w = next_gemm ? g.step[si + 1].w : nullptr;
-			const int next_ldw = next_gemm ? g.step[si + 1].ldw : 0;
 			if (s.kind == FS_OUT) {
-				// final 256 -> 3 layer + tanh scaling on the X tile: 8 lanes per row, 32 columns each
+				// final 256 -> 3 layer + tanh scaling on the X tile: 16 lanes per row, 16 columns each
 				__syncthreads();
-				const int row = tid >> 3, seg = tid & 7;
+				const int row = tid >> 4, seg = tid & 15;
 				float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
-				for (int c4 = 0; c4 < 8; ++c4) {
-					const float4 x = *reinterpret_cast<const float4*>(X + row * FX_LD + seg * 32 + c4 * 4);
-					const float4 a = *reinterpret_cast<const float4*>(s.w + 0 * W + seg * 32 + c4 * 4);
-					const float4 b = *reinterpret_cast<const float4*>(s.w + 1 * W + seg * 32 + c4 * 4);
-					const float4 c = *reinterpret_cast<const float4*>(s.w + 2 * W + seg * 32 + c4 * 4);
+				for (int c4 = 0; c4 < 4; ++c4) {
+					const float4 x = *reinterpret_cast<const float4*>(X + row * FX_LD + seg * 16 + c4 * 4);
+					const float4 a = *reinterpret_cast<const float4*>(s.w + 0 * W + seg * 16 + c4 * 4);
+					const float4 b = *reinterpret_cast<const float4*>(s.w + 1 * W + seg * 16 + c4 * 4);
+					const float4 c = *reinterpret_cast<const float4*>(s.w + 2 * W + seg * 16 + c4 * 4);
 					p0 += x.x * a.x + x.y * a.y + x.z * a.z + x.w * a.w;
 					p1 += x.x * b.x + x.y * b.y + x.z * b.z + x.w * b.w;
 					p2 += x.x * c.x + x.y * c.y + x.z * c.z + x.w * c.w;
 				}
 #pragma unroll
-				for (int d = 1; d < 8; d <<= 1) { p0 += __shfl_xor(p0, d, 64); p1 += __shfl_xor(p1, d, 64); p2 += __shfl_xor(p2, d, 64); }
+				for (int d = 1; d < 16; d <<= 1) { p0 += __shfl_xor(p0, d, 64); p1 += __shfl_xor(p1, d, 64); p2 += __shfl_xor(p2, d, 64); }
 				if (seg < 3 && row < valid) {
 					const float zz = (seg == 0 ? p0 : (seg == 1 ? p1 : p2)) + s.bias[seg];
 					const float t = tanhf(zz);
@@ -143,123 +156,128 @@ __global__ __launch_bounds__(256, 1) void fused_chain_kernel(const FusedArgs g) 
 					if (s.dst2) s.dst2[o] = zz;
 					s.dst[o] = s.head ? ((s.aux ? s.aux[seg] : 0.f) + 0.5f * (1.0f + t)) : 0.1f * t;
 				}
-				primed = false;
 				continue;
 			}
 			// ---- GEMM step
-			if (!primed) { FUSED_W_LOAD(s.w, s.ldw, 0); }
 			if (s.src_kind == FS_SRC_GLOBAL) {
 				__syncthreads();   // everyone is done with the previous X
 #pragma unroll
-				for (int q = 0; q < 8; ++q) {
-					const int idx = tid + 256 * q;
+				for (int q = 0; q < 4; ++q) {
+					const int idx = tid + 512 * q;
 					const int row = idx >> 6, part = idx & 63;
 					const float4 v = *reinterpret_cast<const float4*>(s.src + (row0 + min(row, valid - 1)) * W + part * 4);
 					*reinterpret_cast<float4*>(X + row * FX_LD + part * 4) = v;
 				}
 			}
-			if (!primed) { FUSED_W_STORE(stage ? Wc1 : Wc0); }
 			if (!s.accum) {
 #pragma unroll
-				for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+				for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 			}
-			__syncthreads();
+			__syncthreads();   // X is in place
 
+			// The chunk loop is unrolled by two with the parity of the chunk index a COMPILE-TIME constant (every step has an even chunk
+			// count, so parity in the stream = parity in the step): which register set receives chunk k + 2 and which one is stored must not
+			// be a run-time choice -- the compiler turns `if (k & 1) load(set B) else load(set A)` into loads to temporaries, s_waitcnt
+			// vmcnt(0) and v_cndmask moves, i.e. it waits for the prefetch it has just issued.
 			const int nchunk = s.nchunk;
-			for (int c = 0; c < nchunk; ++c) {
-				if (s.src_kind == FS_SRC_PE && (c & 7) == 0) {
-					// regenerate the X tile with the Fourier features of k-tile c / 8 (padded order of pe_value); 32 values per thread
-					if (c > 0) __syncthreads();   // the previous k-tile has been consumed
-					const int row = tid >> 3, seg = tid & 7;
+			const float* const xa0 = X + li * FX_LD + lh * 4;
+			const float* const wfrag0 = Wc0 + li * FW_LD + lh * 4;
+			const float* const wfrag1 = Wc1 + li * FW_LD + lh * 4;
+#define FUSED_CHUNK(PAR, c_)                                                                                                   \
+			do {                                                                                                               \
+				if (!(g.ablate & 1)) { if (PAR) FUSED_W_LOAD(wb, pf_w, pf_ldw, pf_c); else FUSED_W_LOAD(wa, pf_w, pf_ldw, pf_c); }   \
+				pf_advance();                                                                                                  \
+				__builtin_amdgcn_sched_barrier(0); /* the prefetch is issued BEFORE the MFMAs (else it sinks next to its store) */ \
+				const float* xa = xa0 + (s.src_kind == FS_SRC_PE ? ((c_) & 7) : (c_)) * 32;                                    \
+				const float* wbp = PAR ? wfrag1 : wfrag0;                                                                      \
+				float4 fa[2], fb[2];                                                                                           \
+				fa[0] = *reinterpret_cast<const float4*>(xa);                                                                  \
+				fb[0] = *reinterpret_cast<const float4*>(wbp);                                                                 \
+				_Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                             \
+					const int cur = gq & 1, nxt = cur ^ 1;                                                                     \
+					if (gq < 3) { /* fragments of k-group q+1 are requested before the MFMAs of group q */                      \
+						fa[nxt] = *reinterpret_cast<const float4*>(xa + (gq + 1) * 8);                                         \
+						fb[nxt] = *reinterpret_cast<const float4*>(wbp + (gq + 1) * 8);                                        \
+					}                                                                                                          \
+					__builtin_amdgcn_sched_barrier(0);                                                                         \
+					const float4 a = fa[cur], b = fb[cur];                                                                     \
+					if (!(g.ablate & 2)) {                                                                                     \
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);                                    \
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);                                    \
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);                                    \
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);                                    \
+					} else { acc[0] += a.x + b.x; }                                                                            \
+					__builtin_amdgcn_sched_barrier(0);                                                                         \
+				}                                                                                                              \
+				/* chunk k + 1 (requested one iteration ago) moves into the stage chunk k - 1 has left; the ring is private to */ \
+				/* the wave, whose LDS operations complete in order: no barrier */                                              \
+				if (!(g.ablate & 1)) { if (PAR) FUSED_W_STORE(wa, Wc0); else FUSED_W_STORE(wb, Wc1); }                          \
+			} while (0)
+			for (int c = 0; c < nchunk; c += 2) {
+				if (s.src_kind == FS_SRC_PE && (c & 7) == 0 && !(g.ablate & 8)) {
+					// regenerate the X tile with the Fourier features of k-tile c / 8; a thread fills 16 columns of one row
+					if (c > 0) __syncthreads();   // the previous k-tile has been consumed by every wave
+					const int row = tid >> 4, seg = tid & 15;
 					const float* pp = g.pos + (int64_t)foot * g.pos_foot_stride + (int64_t)(v0 + min(row, valid - 1)) * 3;
 					const float px = pp[0], py = pp[1], pz = pp[2];
-					// this thread's 32 columns are chunk cc of the padded order (mlp_kernels.h: pe_value): sin of 32 features, cos of the same
-					// 32, ..., then [x y z 0 ...], then zeros
-					const int cc = (c >> 3) * 8 + seg, nsc = g.pe >> 4;
-					float* xr = X + row * FX_LD + seg * 32;
+					// chunk cc of the padded order (mlp_kernels.h: pe_value): sin of 32 features, cos of the same 32, ..., [x y z 0 ...], zeros
+					const int cc = (c >> 3) * 8 + (seg >> 1), nsc = g.pe >> 4, j0 = (seg & 1) * 16;
+					float* xr = X + row * FX_LD + (seg >> 1) * 32 + j0;
 					if (cc < nsc) {
-						const float* b0 = Bl + (cc >> 1) * 32;
+						const float* b0 = Bl + (cc >> 1) * 32 + j0;
 						const bool is_cos = cc & 1;
 #pragma unroll 4
-						for (int j = 0; j < 32; ++j) {
+						for (int j = 0; j < 16; ++j) {
 							const float t = 2.0f * fmaf(pz, b0[2 * g.pe + j], fmaf(py, b0[g.pe + j], px * b0[j]));
 							xr[j] = is_cos ? cospif(t) : sinpif(t);
 						}
 					} else {
 #pragma unroll
-						for (int j = 0; j < 32; j += 4) *reinterpret_cast<float4*>(xr + j) = make_float4(0.f, 0.f, 0.f, 0.f);
-						if (cc == nsc) { xr[0] = px; xr[1] = py; xr[2] = pz; }
+						for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(xr + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+						if (cc == nsc && j0 == 0) { xr[0] = px; xr[1] = py; xr[2] = pz; }
 					}
 					__syncthreads();
 				}
-				// prefetch the next chunk of the stream: of this step, or chunk 0 of the next GEMM step
-				// (when nothing follows, the same chunk is fetched again into the idle stage: unconditional code keeps the registers registers)
-				const bool more = c + 1 < nchunk;
-				const bool ns = more || next_gemm;
-				{
-					const float* pw = more ? s.w : (next_gemm ? next_w : s.w);
-					const int pl = more ? s.ldw : (next_gemm ? next_ldw : s.ldw);
-					const int pc = more ? c + 1 : (next_gemm ? 0 : c);
-					FUSED_W_LOAD(pw, pl, pc);
-				}
-
-				__builtin_amdgcn_sched_barrier(0);   // the prefetch is issued BEFORE the MFMAs (left alone, the compiler sinks it next to its store)
-				const float* Wc = stage ? Wc1 : Wc0;
-				const int xk = (s.src_kind == FS_SRC_PE ? (c & 7) : c) * 32;
-				const float* xa = X + li * FX_LD + xk + lh * 4;
-				const float* wb = Wc + (wave * 64 + li) * FW_LD + lh * 4;
-				// fragments of k-group q+1 are requested before the MFMAs of group q (two register sets)
-				float4 fa[2], fb0[2], fb1[2];
-				fa[0] = *reinterpret_cast<const float4*>(xa);
-				fb0[0] = *reinterpret_cast<const float4*>(wb);
-				fb1[0] = *reinterpret_cast<const float4*>(wb + 32 * FW_LD);
-#pragma unroll
-				for (int gq = 0; gq < 4; ++gq) {
-					const int cur = gq & 1, nxt = cur ^ 1;
-					if (gq < 3) {
-						fa[nxt] = *reinterpret_cast<const float4*>(xa + (gq + 1) * 8);
-						fb0[nxt] = *reinterpret_cast<const float4*>(wb + (gq + 1) * 8);
-						fb1[nxt] = *reinterpret_cast<const float4*>(wb + 32 * FW_LD + (gq + 1) * 8);
-					}
-					__builtin_amdgcn_sched_barrier(0);
-					const float4 a = fa[cur], b0 = fb0[cur], b1 = fb1[cur];
-					acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-					acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-					acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-					acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-					acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-					acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-					acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-					acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
-					__builtin_amdgcn_sched_barrier(0);
-				}
-				FUSED_W_STORE(stage ? Wc0 : Wc1);
-				(void)ns;
-				stage ^= 1;
-				__syncthreads();
+				FUSED_CHUNK(0, c);
+				FUSED_CHUNK(1, c + 1);
 			}
-			primed = next_gemm;
-			if (s.keep) continue;
+#undef FUSED_CHUNK
+			if (s.keep || (g.ablate & 4)) continue;
 
 			// ---- epilogue: bias + ReLU / mask, store to HBM, hand the tile to the next step through LDS
-			// (every wave has passed the barrier that ended the last chunk: nobody reads X any more)
+			__syncthreads();   // every wave has multiplied its last chunk: nobody reads X any more
+			{
+				// (separate straight-line passes under wave-uniform branches: the four conditions inside one unrolled loop cost > 100 registers)
+				const int col = wave * 32 + li;
+				if (s.relu) {
+					const float bv = s.bias[(int64_t)foot * s.bias_foot_stride + col];
 #pragma unroll
-			for (int nt = 0; nt < 2; ++nt) {
-				const int col = wave * 64 + nt * 32 + li;
-				const float bv = s.relu ? s.bias[(int64_t)foot * s.bias_foot_stride + col] : 0.f;
+					for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + bv, 0.f);
+				}
+				if (s.mask) {
+					const float* mp = s.aux + row0 * W + col;
 #pragma unroll
-				for (int r = 0; r < 16; ++r) {
-					const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-					float val = acc[nt][r];
-					if (s.relu) val = fmaxf(val + bv, 0.f);
-					if (s.mask) val = (s.aux[(row0 + min(row, valid - 1)) * W + col] > 0.f) ? val : 0.f;
-					if (s.dst && row < valid) s.dst[(row0 + row) * W + col] = val;
-					if (s.to_lds) X[row * FX_LD + col] = val;
+					for (int r = 0; r < 16; ++r) {
+						const int row = min((r & 3) + 8 * (r >> 2) + 4 * lh, valid - 1);
+						acc[r] = (mp[row * W] > 0.f) ? acc[r] : 0.f;
+					}
+				}
+				if (s.dst) {
+					float* dp = s.dst + row0 * W + col;
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+						if (row < valid) dp[row * W] = acc[r];
+					}
+				}
+				if (s.to_lds) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) X[((r & 3) + 8 * (r >> 2) + 4 * lh) * FX_LD + col] = acc[r];
 				}
 			}
 			// (the next step starts with a barrier before anyone reads X)
 		}
-		__syncthreads();   // the next tile overwrites X and the ring
+		__syncthreads();   // the next tile overwrites X
 	}
 }
 

@@ -253,7 +253,7 @@ struct ReduceWArgs {
 	int nwblk;        // 256*Kp/4/64
 };
 
-__global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) {
+__device__ __forceinline__ void reduce_w_body(const ReduceWArgs& g) {
 	__shared__ __attribute__((aligned(16))) float red[16 * 256];
 	const int tid = threadIdx.x;
 	if ((int)blockIdx.x >= g.nwblk) {
@@ -313,6 +313,20 @@ __global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) {
 		if (ko >= 0) g.out[(int64_t)nn * g.ld_out + ko] = t;
 	}
 	(void)n; (void)k;
+}
+
+__global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) { reduce_w_body(g); }
+
+// the slab reduces of a grouped weight-gradient launch (mlp_dw2.h: dw2_group_kernel), blockIdx.y = job
+constexpr int REDUCE_MAX_JOBS = 24;
+struct ReduceWGroup { ReduceWArgs job[REDUCE_MAX_JOBS]; };
+__global__ __launch_bounds__(1024) void reduce_w_group_kernel(const ReduceWGroup grp) {
+	const int j = blockIdx.y;
+	ReduceWArgs g;
+	g.pw = grp.job[j].pw; g.nsplit = grp.job[j].nsplit; g.Kp = grp.job[j].Kp; g.out = grp.job[j].out; g.ld_out = grp.job[j].ld_out;
+	g.K_valid = grp.job[j].K_valid; g.pe_map = grp.job[j].pe_map; g.pe = grp.job[j].pe; g.in_dim = grp.job[j].in_dim; g.pb = grp.job[j].pb;
+	g.n_feet = grp.job[j].n_feet; g.spf = grp.job[j].spf; g.db = grp.job[j].db; g.S = grp.job[j].S; g.nwblk = grp.job[j].nwblk;
+	reduce_w_body(g);
 }
 
 // Shared-template backward of a head's first layer: because every foot multiplies the SAME trunk rows,
