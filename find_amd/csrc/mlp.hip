@@ -112,7 +112,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_DW2G, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_DW2G, K_REDUCE, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -123,6 +123,7 @@ struct find_ctx {
 	// knobs (find_hip.h: find_ctx_set)
 	int ablate = 0;
 	unsigned long long* dbg = nullptr;
+	unsigned long long* dw2_verify = nullptr;   // diagnosis (tools/probe_lds_fault.py): log buffer of dw2_kernel's stage verification
 	int64_t gemm4_min_units = 1024;
 	int gemm4_small = 64;         // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
 	int dw_pe_target = 256;       // workgroups of the Fourier layer's weight-gradient launch (one round over the chip)
@@ -133,6 +134,7 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 1;        // the LDS-DMA ring kernels reserve the whole LDS of their CU (see "Co-residence" below)
+	int reduce_exclusive = 0;     // diagnosis only: the slab reduce (16 KB of LDS) reserves its CU's whole LDS instead of the ring kernels
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
 	// internal streams / events
 	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
@@ -696,6 +698,17 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	o->bytes = c.off;
 }
 
+// (diagnosis) dynamic LDS of the slab reduce: 0, or everything the CU has left beside its 16 KB of static LDS
+static int reduce_lds(find_ctx* c) {
+	if (!c->reduce_exclusive) return 0;
+	const int dyn = c->lds_bytes - 16 * 1024 - 256;
+	if (!c->attr_done[K_REDUCE]) {
+		if (hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return 0;
+		c->attr_done[K_REDUCE] = true;
+	}
+	return dyn;
+}
+
 // dW / db of one Linear layer from dz (rows (foot, v)) and its input x (or, for the Fourier layer, the positions).  The partial
 // tiles go out on stream s; the slab reduce follows on s, or -- reduce_side >= 0 -- on that side stream of the fork, ordered behind s.
 static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
@@ -742,6 +755,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			memset(&d2, 0, sizeof(d2));
 			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
 			d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
+			d2.dbg = c->dw2_verify;   // diagnosis: verify every published ring stage (tools/probe_lds_fault.py)
 			hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
 			FIND_LAUNCH_CHECK("dw2_kernel");
 		}
@@ -750,7 +764,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
 		r.nwblk = 256 * 256 / 4 / 64;
-		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
+		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), reduce_lds(c), reduce_stream(), r);
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
@@ -774,7 +788,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
 	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
 	r.nwblk = 256 * a.Kp / 4 / 64;
-	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
+	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), reduce_lds(c), reduce_stream(), r);
 	FIND_LAUNCH_CHECK("reduce_w_kernel");
 	return FIND_OK;
 }
@@ -1252,7 +1266,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 1}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 
@@ -1260,6 +1274,10 @@ extern "C" int find_ctx_set(find_ctx* c, const char* key, int64_t value) {
 	FIND_REQUIRE(c != nullptr && key != nullptr, "find_ctx_set: NULL argument");
 	if (strcmp(key, "dbg") == 0) {  // device pointer to >= 4 * grid uint64 (profiling only)
 		c->dbg = reinterpret_cast<unsigned long long*>(value);
+		return FIND_OK;
+	}
+	if (strcmp(key, "dw2_verify") == 0) {  // device pointer to 8 + 64 * 8 uint64 (diagnosis only)
+		c->dw2_verify = reinterpret_cast<unsigned long long*>(value);
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm4_min_units") == 0) {

@@ -30,10 +30,53 @@ struct Dw2Args {
 	int cps;                 // chunks per split
 	float* pw;               // [n_feet*spf][256][256]
 	float* pb;               // [n_feet*spf][256] or nullptr
+	unsigned long long* dbg; // diagnosis only (tools/probe_lds_fault.py): every published ring stage is compared with its source in HBM
 };
 
 constexpr int DW2_STAGE = 2 * 16 * 1024;                // dZ rows then X rows
 constexpr int DW2_LDS = 3 * DW2_STAGE + 4 * 256 * 4;    // + bias reduction scratch
+
+// Diagnosis of the LDS co-residence fault (mlp.hip): thread t compares bytes [128 t, 128 t + 128) of a published stage (16 dZ rows then 16 X
+// rows of 1 KB) with the same bytes read straight from HBM.  Log layout (uint64): [0] mismatching 16-byte pieces, [1] stages checked by
+// thread 0, [2] stages checked by workgroups whose LDS base is not 0, then up to 64 records of 8 words:
+// {split | chunk << 32, stage | tid << 8 | piece << 24, HW_REG_LDS_ALLOC, HW_REG_HW_ID, got.x bits | expected.x bits << 32,
+//  1 if the piece equals what the stage held three chunks ago (stale) else 0, XCC id, 0}.
+__device__ __noinline__ void dw2_verify_stage(unsigned long long* log, const char* stage, const float* zsrc, const float* xsrc, const float* zold,
+											   const float* xold, int split, int chunk, int stage_idx) {
+	const int tid = threadIdx.x;
+	const int row = tid >> 3, part = tid & 7;   // 32 rows x 8 pieces of 128 B
+	const float* src = row < 16 ? zsrc + row * 256 + part * 32 : xsrc + (row - 16) * 256 + part * 32;
+	const float* old = row < 16 ? (zold ? zold + row * 256 + part * 32 : nullptr) : (xold ? xold + (row - 16) * 256 + part * 32 : nullptr);
+	const unsigned alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+	if (tid == 0) {
+		atomicAdd(log + 1, 1ull);
+		if (alloc & 0xFF) atomicAdd(log + 2, 1ull);
+	}
+#pragma unroll 1
+	for (int i = 0; i < 8; ++i) {
+		const float4 got = *reinterpret_cast<const float4*>(stage + row * 1024 + part * 128 + i * 16);
+		const float4 want = *reinterpret_cast<const float4*>(src + i * 4);
+		if (got.x != want.x || got.y != want.y || got.z != want.z || got.w != want.w) {
+			const unsigned long long n = atomicAdd(log, 1ull);
+			if (n < 64) {
+				unsigned long long* r = log + 8 + n * 8;
+				int stale = 0;
+				if (old) {
+					const float4 o = *reinterpret_cast<const float4*>(old + i * 4);
+					stale = (got.x == o.x && got.y == o.y && got.z == o.z && got.w == o.w) ? 1 : 0;
+				}
+				r[0] = (unsigned)split | ((unsigned long long)chunk << 32);
+				r[1] = (unsigned)stage_idx | ((unsigned)tid << 8) | ((unsigned)i << 24);
+				r[2] = alloc;
+				r[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+				r[4] = __float_as_uint(got.x) | ((unsigned long long)__float_as_uint(want.x) << 32);
+				r[5] = stale;
+				r[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+				r[7] = 0;
+			}
+		}
+	}
+}
 
 __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,6 +184,8 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 				if (ahead <= 0) FIND_WAIT_VMCNT(0);
 				else FIND_WAIT_VMCNT(8);
 				__builtin_amdgcn_s_barrier();
+				if (g.dbg) dw2_verify_stage(g.dbg, nsb, zb + (int64_t)(c + 1) * 4096, xb + (int64_t)(c + 1) * 4096, c >= 2 ? zb + (int64_t)(c - 2) * 4096 : nullptr,
+											c >= 2 ? xb + (int64_t)(c - 2) * 4096 : nullptr, split, c + 1, ns);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			mfma_ja(a1, b1, 0);
@@ -223,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void dw2_group_kernel(const Dw2Group grp) {
 	Dw2Args g;   // (fields copied one by one: a reference into the kernel-argument array makes the compiler copy the array to scratch)
 	g.dz = grp.job[j].dz; g.dz_foot_stride = grp.job[j].dz_foot_stride; g.x = grp.job[j].x; g.x_foot_stride = grp.job[j].x_foot_stride;
 	g.chunks_per_foot = grp.job[j].chunks_per_foot; g.tail_rows = grp.job[j].tail_rows; g.spf = grp.job[j].spf; g.cps = grp.job[j].cps;
-	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb;
+	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb; g.dbg = nullptr;
 	dw2_body(g, blockIdx.x);
 }
 

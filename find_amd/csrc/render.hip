@@ -31,7 +31,7 @@ constexpr int BATCH = 256;      // candidates shaded per LDS batch
 constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
 constexpr int KU = 16;            // list entries in flight per lane in the K-nearest passes (they are L2-latency-bound)
-constexpr int KN_CAP = 1024;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1])
+constexpr int KN_CAP = 4096;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1]); the pole of a 10 002-vertex lat-long scan @256^2 collects ~2000
 constexpr int RING = 8;           // candidates a lane collects in LDS before it writes them out: 2 x 32 contiguous bytes per flush
 constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 per CU: 95 VGPRs, 38 KB LDS); each owns 256 x KN_CAP x 8 B of scratch
 

@@ -132,11 +132,23 @@ class _MLP(torch.autograd.Function):
 		L = _lib.lib()
 		pos, lat_disp, lat_col, B, avg_col = _c(pos), _c(lat_disp), _c(lat_col), _c(B), _c(avg_col)
 		weights = tuple(w.contiguous() for w in weights)
+		if pos.dim() != 3 or pos.shape[-1] != spec.in_dim:
+			raise RuntimeError(f'find_amd.mlp: pos must be (B|1, V, {spec.in_dim}), got {tuple(pos.shape)}')
 		pos_batch, V, _ = pos.shape
 		n_feet = pos_batch
-		for lat in (lat_disp, lat_col):
-			if lat is not None:
-				n_feet = lat.shape[0]
+		batches = set()
+		for name, lat, width in (('lat_disp', lat_disp, spec.lat_disp), ('lat_col', lat_col, spec.lat_col)):
+			if lat is None:
+				if width != 0:
+					raise RuntimeError(f'find_amd.mlp: {name} is missing but the head expects {width} latent columns')
+				continue
+			if lat.dim() != 2 or lat.shape[1] != width:
+				raise RuntimeError(f'find_amd.mlp: {name} must be (n_feet, {width}), got {tuple(lat.shape)}')
+			batches.add(int(lat.shape[0]))
+		if len(batches) > 1:   # (the reference fails in torch.cat / expand; here it would be an out-of-bounds device read)
+			raise RuntimeError(f'find_amd.mlp: lat_disp and lat_col have different batch sizes {sorted(batches)}')
+		if batches:
+			n_feet = batches.pop()
 		if pos_batch != 1 and pos_batch != n_feet:
 			raise RuntimeError(f'find_amd.mlp: pos batch {pos_batch} does not match latent batch {n_feet}')
 		p = _fill_params(spec, B, avg_col, weights)
@@ -435,14 +447,20 @@ class MeshTopology:
 
 	@classmethod
 	def get(cls, faces, n_verts):
-		key = (faces.data_ptr(), tuple(faces.shape), str(faces.device), int(n_verts), int(faces._version))
-		t = cls._cache.get(key)
-		if t is None:
-			if len(cls._cache) > 16:
-				cls._cache.clear()
-			t = cls(faces, n_verts)
-			cls._cache[key] = t
-		return t
+		"""Tables of a faces tensor, built once per tensor OBJECT: the entry keeps a weak reference to the tensor it was built from, so a
+		freed tensor whose address (or id) is reused by different connectivity never matches, and an in-place edit (_version) rebuilds."""
+		import weakref
+		key = (id(faces), int(n_verts))
+		ent = cls._cache.get(key)
+		if ent is not None:
+			ref, version, topo = ent
+			if ref() is faces and version == int(faces._version):
+				return topo
+		if len(cls._cache) > 16:
+			cls._cache.clear()
+		topo = cls(faces, n_verts)
+		cls._cache[key] = (weakref.ref(faces), int(faces._version), topo)
+		return topo
 
 
 class _Smooth(torch.autograd.Function):

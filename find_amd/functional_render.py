@@ -31,7 +31,7 @@ def make_params(image_size=256, faces_per_pixel=100, background=(1., 1., 1.), li
 
 # ---------------------------------------------------------------------------------------------- render watchdog
 # PyTorch3D clips faces that straddle the z-clip plane (znear / 2, renderer.py:231-234) into 1-2 triangles; this rasteriser does not:
-# it counts them (find_render_flags) and, like the pixels that collect more than 1024 silhouette candidates, they make the result differ
+# it counts them (find_render_flags) and, like the pixels that collect more than 4096 silhouette candidates, they make the result differ
 # from the reference.  Neither occurs with FIND's cameras (0.3 m from a <= 0.15 m object; view_from('toes') leaves 0.06 m), so instead
 # of an implementation nobody exercises, a render that hits either case FAILS: the two counters travel to a pinned host buffer behind
 # the launch and are looked at when they have arrived -- at the next render call, or in check_render_flags() -- so the check costs no
@@ -43,7 +43,7 @@ _pending = []   # (event, pinned int32[2], description)
 def _raise_if_flagged(vals, what):
 	if vals[0] > 0 or vals[1] > 0:
 		raise RuntimeError(f'find_amd.render: {what}: {vals[0]} face(s) straddle the z-clip plane (PyTorch3D would clip them; this rasteriser '
-						   f'does not) and {vals[1]} pixel(s) collected more than 1024 silhouette candidates (K-nearest rule not applied): the '
+						   f'does not) and {vals[1]} pixel(s) collected more than 4096 silhouette candidates (K-nearest rule not applied): the '
 						   'result would differ from the reference.  Move the camera, or set functional_render.FLAG_POLICY = "ignore".')
 
 
@@ -135,7 +135,7 @@ def render(verts, colors, faces, R, T, params, want_mask=True, want_image=True, 
 
 
 def render_flags(ws):
-	"""(faces straddling the clip plane, pixels with more than 1024 silhouette candidates -- the only ones the K-nearest rule
+	"""(faces straddling the clip plane, pixels with more than 4096 silhouette candidates -- the only ones the K-nearest rule
 	leaves unresolved) of the forward that used ws."""
 	L = _lib.lib()
 	out = (ctypes.c_int32 * 2)()

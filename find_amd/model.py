@@ -91,6 +91,11 @@ class LatentVector(nn.Module):
 	def _rows(self, idx):
 		"""self.data[idx] for an integer index tensor; on the GPU through the gather kernel (deterministic scatter backward)."""
 		if self.data.is_cuda and self.data.dtype == torch.float32 and idx.dim() == 1:
+			if not idx.is_cuda and idx.numel() > 0:   # a host index can be checked for free; torch raises IndexError here as well
+				lo, hi = int(idx.min()), int(idx.max())
+				if lo < -self.data.shape[0] or hi >= self.data.shape[0]:
+					raise IndexError(f'LatentVector {self.name}: index {lo if lo < -self.data.shape[0] else hi} is out of range for {self.data.shape[0]} rows')
+			# (a device index is not read back: the gather kernel answers an out-of-range row with NaNs instead of a host synchronisation)
 			return FN.latent_gather(self.data, idx.to(device=self.data.device, dtype=torch.int64))
 		return self.data[idx]
 
@@ -154,25 +159,45 @@ class Model(nn.Module):
 		return model
 
 
-def _read_obj(path):
-	"""Vertices / triangle faces / optional per-vertex RGB of a Wavefront OBJ (polygons are fan-triangulated)."""
-	verts, cols, faces = [], [], []
-	with open(path, 'r') as f:
-		for line in f:
-			if line.startswith('v '):
-				p = line.split()
-				verts.append([float(p[1]), float(p[2]), float(p[3])])
-				if len(p) >= 7:
-					cols.append([float(p[4]), float(p[5]), float(p[6])])
-			elif line.startswith('f '):
-				idx = [int(tok.split('/')[0]) for tok in line.split()[1:]]
-				idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
-				for k in range(1, len(idx) - 1):
-					faces.append([idx[0], idx[k], idx[k + 1]])
-	v = torch.tensor(verts, dtype=torch.float32)
-	fc = torch.tensor(faces, dtype=torch.int64)
-	c = torch.tensor(cols, dtype=torch.float32) if len(cols) == len(verts) and cols else None
-	return v, fc, c
+def _template_texture_image(obj_path):
+	"""The image behind the template OBJ's first material (`mtllib` -> `newmtl` -> `map_Kd`), as (H, W, 3) float32 in [0, 1] -- what
+	pytorch3d.io.load_obj returns as props.texture_images['material_0'] in the reference (model.py:268) -- or None when there is none."""
+	folder = os.path.dirname(obj_path)
+	mtl = None
+	with open(obj_path, 'r') as fh:
+		for line in fh:
+			if line.startswith('mtllib '):
+				mtl = os.path.join(folder, line.split(None, 1)[1].strip())
+				break
+	if mtl is None or not os.path.isfile(mtl):
+		return None
+	with open(mtl, 'r') as fh:
+		for line in fh:
+			if line.strip().startswith('map_Kd'):
+				img = os.path.join(folder, line.split(None, 1)[1].strip())
+				if os.path.isfile(img):
+					from .dataset import load_texture_png
+					return load_texture_png(img)
+				return None
+	return None
+
+
+def _average_template_colour(verts, faces, faces_uvs, verts_uvs, image, num_samples=1000):
+	"""Mean colour of `num_samples` surface samples of the UV-textured template (reference model.py:266-277: sample_points_from_meshes(mesh,
+	1000, return_textures=True).mean).  One-off set-up arithmetic at construction, in plain torch on the tensors' device, drawing from that
+	device's default generator in PyTorch3D's order (faces ~ multinomial(area), then rand(2, 1, S) for the barycentrics)."""
+	v0, v1, v2 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+	areas = 0.5 * torch.linalg.cross(v1 - v0, v2 - v0).norm(dim=1)
+	fi = areas.multinomial(num_samples, replacement=True)
+	uv = torch.rand(2, 1, num_samples, dtype=verts.dtype, device=verts.device)
+	su = uv[0, 0].sqrt()
+	w = torch.stack([1.0 - su, su * (1.0 - uv[1, 0]), su * uv[1, 0]], dim=1)               # (S, 3) barycentrics
+	tri_uv = verts_uvs[faces_uvs[fi]]                                                        # (S, 3, 2)
+	p = (w[:, :, None] * tri_uv).sum(dim=1)                                                  # (S, 2) texture coordinates
+	grid = (p * 2.0 - 1.0).view(1, 1, num_samples, 2)
+	tex = torch.flip(image, [0]).permute(2, 0, 1)[None]                                      # TexturesUV: v = 0 is the bottom row
+	cols = torch.nn.functional.grid_sample(tex, grid, mode='bilinear', align_corners=True, padding_mode='border')
+	return cols[0, :, 0, :].mean(dim=1)
 
 
 class NeuralDisplacementField(Model):
@@ -220,9 +245,19 @@ class NeuralDisplacementField(Model):
 
 		# --- template (centred at its centroid, model.py:274-275)
 		if template_mesh_loc is not None:
-			verts, faces, cols = _read_obj(template_mesh_loc)
+			from .dataset import load_obj
+			verts, face_dict, props = load_obj(template_mesh_loc)
+			faces = face_dict.verts_idx
+			image = _template_texture_image(template_mesh_loc)
+			if image is not None and props.verts_uvs.numel() > 0 and bool((face_dict.textures_idx >= 0).all()):
+				dev = torch.device(device)
+				avg_col = _average_template_colour(verts.to(dev), faces.to(dev), face_dict.textures_idx.to(dev), props.verts_uvs.to(dev), image.to(dev)).cpu()
+			elif use_avg_colour:
+				raise NotImplementedError('use_avg_colour=True needs the template\'s UV texture (OBJ with vt coordinates + mtllib / map_Kd image): the reference '
+										  'averages 1000 surface samples of it (model.py:266-277); a checkpoint that carries avg_col restores it without one')
+			else:
+				avg_col = torch.zeros(3)
 			verts = verts - verts.mean(dim=0)
-			avg_col = cols.mean(dim=0) if cols is not None else torch.zeros(3)
 		else:
 			verts = torch.zeros((1, 3), dtype=torch.float32)
 			faces = torch.ones((1, 3), dtype=torch.int)
@@ -364,7 +399,9 @@ class NeuralDisplacementField(Model):
 		if self.use_texvec:
 			meshes.textures = TexturesVertex(col[..., :3])
 		else:
-			raise NotImplementedError('use_texvec=False needs the template UV texture (template_tex), which is out of scope')
+			# (the reference falls back to self.template_tex here, model.py:500 -- an attribute its constructor never assigns (the lines that
+			# built it are commented out, model.py:288-295): upstream raises AttributeError on this path as well)
+			raise NotImplementedError('use_texvec=False: the template-texture fallback of get_meshes does not exist upstream either (model.py:288-295, 500)')
 		return dict(meshes=meshes, offsets=offsets, verts=X, **res)
 
 	def get_meshes_from_batch(self, batch, is_train=True, no_displacement=False):

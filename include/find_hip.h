@@ -282,7 +282,7 @@ int find_render_bwd(const find_render_params* rp, const float* verts, const int3
  * plane (PyTorch3D would clip them; they are rasterised whole here -- none exists on FIND's camera set-up),
  * out2[1] = pixels left UNRESOLVED by the K-nearest rule: a pixel with more silhouette candidates than
  * sil_faces_per_pixel keeps the K nearest in depth (ties to the earlier face, as PyTorch3D's per-pixel K-buffer);
- * only a pixel with more than 1024 candidates is not resolved -- all of its candidates stay blended. */
+ * only a pixel with more than 4096 candidates is not resolved -- all of its candidates stay blended. */
 int find_render_flags(const void* ws, int32_t* out2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -202,5 +202,9 @@ def test_two_ranks_of_the_find_model_equal_one_process_on_16_feet():
 		err = (g - want).abs().max().item() / scale
 		worst = max(worst, err)
 		# fp32 sums in a different order (two partial batches, then their mean) against one pass over 16 feet
-		assert err < 1e-5, (tuple(p.shape), err)
+		if err >= 1e-5:   # say where: a handful of elements of one weight gradient is the signature of the LDS co-residence fault (mlp.hip)
+			d = (g - want).abs()
+			bad = (d > 1e-5 * scale).nonzero()
+			raise AssertionError(f'{tuple(p.shape)}: relative error {err:.3e}; {bad.shape[0]} element(s) off, first at {bad[:8].tolist()}, '
+								 f'values {[(float(g[tuple(i)]), float(want[tuple(i)])) for i in bad[:4]]}')
 	print(f'2-rank DP vs 1 process: worst relative gradient difference {worst:.2e}')

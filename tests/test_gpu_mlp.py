@@ -369,3 +369,52 @@ def test_linear_wgrad_kernel(n_feet, n_pts):
 	assert torch.isfinite(dw).all() and torch.isfinite(db).all()
 	assert (dw.double() - want).abs().max().item() < TOL * max(1.0, want.abs().max().item())
 	assert (db.double() - wantb).abs().max().item() < TOL * max(1.0, wantb.abs().max().item())
+
+
+def test_argument_checks_fail_before_the_launch(golden_main):
+	"""Shape errors the reference meets in torch.cat / expand (model.py:403-437) must not become out-of-bounds device reads here."""
+	m = _model_from_golden(golden_main)
+	pos = torch.zeros(2, 8, 3, device='cuda')
+	z = lambda n, w=100: torch.zeros(n, w, device='cuda')
+	with pytest.raises(RuntimeError, match='different batch sizes'):
+		m(pos, shapevec=z(2), texvec=z(3), posevec=z(2))
+	with pytest.raises((RuntimeError, ValueError)):
+		m(torch.zeros(2, 8, 2, device='cuda'), shapevec=z(2), texvec=z(2), posevec=z(2))
+	with pytest.raises(RuntimeError, match='does not match latent batch'):
+		m(torch.zeros(3, 8, 3, device='cuda'), shapevec=z(2), texvec=z(2), posevec=z(2))
+	with pytest.raises(IndexError):
+		m.shapevec[torch.tensor([0, 7])]          # 4 rows: a host index is range-checked like torch's indexing
+	assert m.shapevec[torch.tensor([0, 3])].shape == (2, 100)
+
+
+def test_context_reports_the_device_and_keeps_its_knobs():
+	"""find_ctx (include/find_hip.h): per-device state instead of process globals -- device facts, knob round trip, error on unknown keys,
+	and the event budget of a backward call stays far below the ring."""
+	import ctypes
+	from find_amd import _lib, synthetic
+	L = _lib.lib()
+	assert _lib.get_tuning('num_cus') == 256 and _lib.get_tuning('lds_bytes') >= 160 * 1024 and _lib.get_tuning('device') == torch.cuda.current_device()
+	prev = _lib.get_tuning('dw2_min_cps')
+	_lib.set_tuning('dw2_min_cps', 4)
+	assert _lib.get_tuning('dw2_min_cps') == 4
+	_lib.set_tuning('dw2_min_cps', prev)
+	with pytest.raises(RuntimeError, match='unknown key'):
+		_lib.set_tuning('no_such_knob', 1)
+	with pytest.raises(RuntimeError, match='out of range'):
+		_lib.set_tuning('bwd_streams', 7)
+	# a second context on the same device is independent of the first
+	h = ctypes.c_void_p()
+	_lib.check(L.find_ctx_create(torch.cuda.current_device(), ctypes.byref(h)), 'find_ctx_create')
+	try:
+		_lib.check(L.find_ctx_set(h, b'fused_max_units', 0), 'find_ctx_set')
+		v = ctypes.c_int64()
+		_lib.check(L.find_ctx_get(h, b'fused_max_units', ctypes.byref(v)), 'find_ctx_get')
+		assert v.value == 0 and _lib.get_tuning('fused_max_units') == 512
+	finally:
+		_lib.check(L.find_ctx_destroy(h), 'find_ctx_destroy')
+	model = synthetic.make_model(1002, train_size=3, val_size=1, device='cuda')
+	lat = synthetic.latents(3, seed=0, device='cuda')
+	res = model.get_meshes(shapevec=lat['shapevec'].requires_grad_(True), reg=lat['reg'], texvec=lat['texvec'], posevec=lat['posevec'])
+	(res['verts'].sum() + res['col'].sum()).backward()
+	torch.cuda.synchronize()
+	assert 0 < _lib.get_tuning('events_per_call_max') < 128

@@ -108,3 +108,32 @@ def test_collator_builds_ragged_meshes_with_joined_uv_textures(foot3d):
 	assert t.maps_padded().shape == (2, 8, 6, 3) and t.faces_uvs_padded().shape == (2, 50, 3) and t.verts_uvs_padded().shape == (2, 36, 2)
 	assert batch['name'] == ['0005-A', '0005-B'] and batch['idx'].tolist() == [0, 1] and batch['pose_code'].shape == (2, 8)
 	assert batch['shape'] == ['0005', '0005'] and batch['reg'] == ['0005-A', '0005-B']
+
+
+def test_template_average_colour_comes_from_the_uv_texture(tmp_path):
+	"""NeuralDisplacementField(template_mesh_loc=...): avg_col is the mean of 1000 surface samples of the template's UV texture
+	(reference model.py:266-277), not of per-vertex colours; without a texture use_avg_colour=True fails loudly."""
+	from PIL import Image
+	from find_amd.model import NeuralDisplacementField
+	root = str(tmp_path)
+	_write_scan(root, 'templ.obj', 'templ.png', 6, (0.0, 0.0, 0.0))
+	kw = dict(device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=2, val_size=1, shapevec_size=8, texvec_size=8, posevec_size=8)
+	# no .mtl yet: the OBJ names one that does not exist
+	m0 = NeuralDisplacementField(template_mesh_loc=os.path.join(root, 'templ.obj'), **kw)
+	assert m0.template_verts.shape == (1, 36, 3) and m0.template_verts.data.mean(dim=1).abs().max() < 1e-6   # centred
+	assert float(m0.avg_col.abs().max()) == 0.0
+	with pytest.raises(NotImplementedError):
+		NeuralDisplacementField(template_mesh_loc=os.path.join(root, 'templ.obj'), use_avg_colour=True, **kw)
+	# a uniform texture: every sample has that colour
+	Image.fromarray(np.full((8, 6, 3), (51, 102, 204), np.uint8)).save(os.path.join(root, 'templ.png'))
+	with open(os.path.join(root, 'none.mtl'), 'w') as fh:
+		fh.write('newmtl material_0\nKd 1 1 1\nmap_Kd templ.png\n')
+	m1 = NeuralDisplacementField(template_mesh_loc=os.path.join(root, 'templ.obj'), use_avg_colour=True, **kw)
+	assert torch.allclose(m1.avg_col.data, torch.tensor([0.2, 0.4, 0.8]), atol=1e-6)
+	# a left-to-right ramp in the red channel: the mean over a uniformly covered UV square is its midpoint
+	ramp = np.zeros((8, 64, 3), np.uint8)
+	ramp[..., 0] = np.linspace(0, 255, 64).astype(np.uint8)[None, :]
+	Image.fromarray(ramp).save(os.path.join(root, 'templ.png'))
+	torch.manual_seed(0)
+	m2 = NeuralDisplacementField(template_mesh_loc=os.path.join(root, 'templ.obj'), **kw)
+	assert abs(float(m2.avg_col[0]) - 0.5) < 0.05 and float(m2.avg_col[1:].abs().max()) == 0.0
