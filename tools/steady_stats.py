@@ -1,0 +1,31 @@
+"""Steady-state per-kernel statistics of a rocprofv3 --kernel-trace CSV of `bench.py --headline-only --steps K --warmup W`: the
+launches of the W warm-up steps (GPU clocks still ramping, allocator still growing) are dropped, only the last K / (K + W) of every
+kernel's launches are averaged.  Prints a CSV (kernel, calls per step, avg us, min us, max us, us per step, % of kernel time).
+python tools/steady_stats.py <kernel_trace.csv> <steps> <warmup> [> profiles/rNN_headline_steady_kernel_stats.csv]"""
+import collections
+import csv
+import sys
+
+path, steps, warmup = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+by = collections.defaultdict(list)
+for r in rows:
+	by[r['Kernel_Name']].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+out = []
+total = 0.0
+for name, iv in by.items():
+	per_step = len(iv) / (steps + warmup)
+	keep = iv[-max(1, int(round(per_step * steps))):] if per_step >= 1 else iv
+	d = [(e - s) / 1e3 for s, e in keep]
+	us_step = sum(d) / steps if per_step >= 1 else sum(d) / (steps + warmup)
+	out.append((name, per_step, sum(d) / len(d), min(d), max(d), us_step))
+	total += us_step
+# span of the steady steps: first kept launch to last end
+kept_starts = [iv[-max(1, int(round(len(iv) / (steps + warmup) * steps)))][0] for iv in by.values() if len(iv) >= steps + warmup]
+span = (max(e for iv in by.values() for _, e in iv) - min(kept_starts)) / 1e3 if kept_starts else 0.0
+w = csv.writer(sys.stdout)
+w.writerow(['kernel', 'calls_per_step', 'avg_us', 'min_us', 'max_us', 'us_per_step', 'pct_of_kernel_time'])
+for name, ps, avg, mn, mx, us in sorted(out, key=lambda t: -t[5]):
+	w.writerow([name[:120], f'{ps:.2f}', f'{avg:.1f}', f'{mn:.1f}', f'{mx:.1f}', f'{us:.1f}', f'{100 * us / total:.1f}'])
+w.writerow(['# steady steps', steps, 'warm-up steps dropped', warmup, 'sum of kernel time per step (us)', f'{total:.1f}', f'wall span per step (us): {span / steps:.1f}'])
