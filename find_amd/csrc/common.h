@@ -12,7 +12,7 @@
 namespace find {
 
 void set_error(const char* fmt, ...);
-extern int g_raster_ablate;  // profiling only (render.hip; find_set_tuning "raster_ablate")
+extern int g_raster_ablate;  // profiling only (render.hip; find_debug_raster_ablate)
 
 inline int check_launch(const char* what) {
 	hipError_t e = hipGetLastError();

@@ -349,7 +349,7 @@ struct TileArgs {
 	const int32_t* tile_any;
 	const int32_t* tile_order;
 	int tiles_per_img, total_tiles;
-	int ablate;              // profiling only (find_set_tuning "raster_ablate"): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math
+	int ablate;              // profiling only (find_debug_raster_ablate): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math
 };
 
 // Persistent: workgroups take (image, tile) pairs from an atomic counter.  Silhouette candidates of every pixel are also

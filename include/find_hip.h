@@ -149,9 +149,16 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *                     fp16, fp32 accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES
  *                     change results (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
  *   "gemm5_min_units" in fp16 mode, launches of fewer 32-row units than this stay on the fp32 kernels (default 1024)
+ *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
+ *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped
+ *                     launch + one grouped reduce; 0 = one launch per layer at every size
  *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS (default); 0 reproduces the co-residence fault
  *                     described in mlp.hip: rare wrong weight-gradient elements -- diagnosis only
- *   "ablate", "dbg"   profiling switches of the GEMM kernels
+ *   "reduce_exclusive" 1 = the slab-reduce kernels reserve their CU's whole LDS as well (default 0; diagnosis of the same fault)
+ *   "dw2_verify"      device pointer to 8 + 64 * 8 uint64: dw2_kernel re-reads every staged LDS chunk against global memory and logs
+ *                     mismatches there (diagnosis only, slows the kernel; 0 = off)
+ *   "ablate", "dbg"   profiling switches of the GEMM kernels ("ablate" bits in fused_chain_kernel: 1 no W staging, 2 no MFMAs, 4 no
+ *                     epilogue, 8 no Fourier features -- results are WRONG with any bit set); "dbg" = device pointer to per-workgroup timers
  * The Python binding applies FIND_TUNING="key=value,..." from the environment to every context it creates. */
 
 /* Process-wide profiling switch of the rasteriser (diagnosis only; any non-zero value other than 64 makes the render WRONG):

@@ -1,4 +1,4 @@
-"""Forward silhouette render of the C3 end-to-end shapes under the rasteriser's ablation bits (find_set_tuning "raster_ablate"):
+"""Forward silhouette render of the C3 end-to-end shapes under the rasteriser's ablation bits (find_debug_raster_ablate; _lib.set_tuning("raster_ablate", bits)):
 where the time of raster_tile_kernel goes.  Usage: python tools/prof_raster_ablate.py [n_verts] [size]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""python tools/run_with_tuning.py key=value [key=value ...] -- <pytest args>: set find_set_tuning knobs, then run pytest in-process."""
+"""python tools/run_with_tuning.py key=value [key=value ...] -- <pytest args>: set find_ctx knobs (_lib.set_tuning), then run pytest in-process."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pytest

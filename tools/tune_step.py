@@ -1,4 +1,4 @@
-"""Time the bench step under different find_set_tuning values: python tools/tune_step.py key v1 v2 ..."""
+"""Time the bench step under different find_ctx knob values (_lib.set_tuning): python tools/tune_step.py key v1 v2 ..."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
