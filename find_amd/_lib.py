@@ -77,6 +77,15 @@ PROTOTYPES = {
 	'find_face_areas': (c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
 	'find_nn_fwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 	'find_nn_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+	'find_sample_surface_ws_bytes': (c_int64, [_I, _I]),
+	'find_sample_surface_fwd': (c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+	'find_chamfer_ws_bytes': (c_int64, [_I, _I, _I]),
+	'find_chamfer_fwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+	'find_chamfer_bwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+	'find_masked_mse_fwd': (c_int, [_P, _P, _I, _P, _P]),
+	'find_masked_mse_bwd': (c_int, [_P, _P, _I, _P, _P, _P]),
+	'find_smooth_loss_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, c_float, c_float, _P, _P, _I, _P]),
+	'find_smooth_loss_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, c_float, c_float, _P, _P, _I, _P, _P]),
 	'find_smooth_ws_bytes': (c_int64, [_I, _I, _I]),
 	'find_smooth_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
 	'find_smooth_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),

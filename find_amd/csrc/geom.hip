@@ -88,76 +88,341 @@ __global__ void sample_bwd_kernel(const int32_t* __restrict__ faces, int64_t fac
 	}
 }
 
-// ------------------------------------------------------------------------------------------- nearest neighbour
-// A lane owns NQ query points; the four waves of a block own the SAME 64*NQ queries and each scans one quarter of every
-// target tile (targets stream through LDS in tiles of NN_TILE, x,y,z,pad float4, a wave-uniform ds_read_b128 broadcasts one
-// target to all lanes), so that FIND's small clouds (5-10 k points x 16 feet) still put more than two waves on every SIMD.
-// Strict '<' on ascending j keeps the lowest index on ties inside a wave; the four partial results are merged through LDS by
-// (distance, index), which is the same rule.
-constexpr int NN_TILE = 1024;
-constexpr int NQ = 2;
+// Sampler with the face choice on the device: pytorch3d.ops.sample_points_from_meshes draws faces ~ multinomial(area) with
+// replacement; torch.multinomial normalises the weights, builds their running sum and searches it with a uniform draw -- five
+// launches and a 13 776-element scan per mesh.  Here: one block per mesh computes the areas and their running sum (rounds of 4096
+// faces, four per thread, block scan of the 1024 four-face totals), then one thread per sample searches the running sum
+// with its own uniform draw r in [0,1): the first face whose running sum exceeds r * total.  Faces of zero area (the -1 padding of
+// ragged batches included) can never be that first face.
+__global__ __launch_bounds__(1024) void area_cdf_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+														 int n_verts, int n_faces, float* __restrict__ cdf) {
+	__shared__ float wsum[16];
+	const int m = blockIdx.x;
+	const int32_t* fp = faces + (int64_t)m * faces_mesh_stride;
+	const float* vp = verts + (int64_t)m * n_verts * 3;
+	float* out = cdf + (int64_t)m * n_faces;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	float carry = 0.f;   // running sum of the faces before this round (the same value in every thread)
+	// rounds of 4096 faces: a thread takes 4 consecutive faces (coalesced index loads, one 16-byte store), the block scans the 1024
+	// four-face totals -- shuffles inside the wave, LDS across the 16 waves: a fixed order, so the result is deterministic
+	for (int f0 = 0; f0 < n_faces; f0 += 4096) {
+		const int f = f0 + 4 * (int)threadIdx.x;
+		float a[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			a[k] = 0.f;
+			if (f + k < n_faces && fp[3 * (f + k)] >= 0) {
+				const float3 p = ld3(vp + 3 * fp[3 * (f + k)]), q = ld3(vp + 3 * fp[3 * (f + k) + 1]), r = ld3(vp + 3 * fp[3 * (f + k) + 2]);
+				a[k] = 0.5f * norm3(cross3(sub3(q, p), sub3(r, p)));
+			}
+		}
+		a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
+		float inc = a[3];
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const float t = __shfl_up(inc, o, 64);
+			if (lane >= o) inc += t;
+		}
+		__syncthreads();   // (the previous round's wsum has been read)
+		if (lane == 63) wsum[wave] = inc;
+		__syncthreads();
+		float base = carry, total = carry;
+		for (int w = 0; w < 16; ++w) {
+			if (w < wave) base += wsum[w];
+			total += wsum[w];
+		}
+		const float off = base + (inc - a[3]);
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			if (f + k < n_faces) out[f + k] = off + a[k];
+		carry = total;
+	}
+}
 
-__global__ __launch_bounds__(256) void nn_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_len,
-													  const float* __restrict__ y, const int32_t* __restrict__ y_len, int p1_max,
-													  int p2_max, float* __restrict__ dist, int32_t* __restrict__ idx) {
+__global__ void sample_surface_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+									  const float* __restrict__ cdf, const float* __restrict__ rnd /* (n, s, 3): face draw, u, v */, int n_verts,
+									  int n_faces, int n_samples, int32_t* __restrict__ face_idx, float* __restrict__ uv, float* __restrict__ out,
+									  const float* __restrict__ attr, float* __restrict__ attr_out) {
+	const int m = blockIdx.y;
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n_samples) return;
+	const int64_t o = (int64_t)m * n_samples + s;
+	const float* c = cdf + (int64_t)m * n_faces;
+	const float total = c[n_faces - 1];
+	// r < total always: a draw that rounds up to the total would find no face
+	const float r = fminf(rnd[o * 3] * total, __uint_as_float(__float_as_uint(total) - 1u));
+	int lo = 0, hi = n_faces - 1;   // first f with c[f] > r; c[n_faces - 1] = total > r
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (c[mid] > r) hi = mid; else lo = mid + 1;
+	}
+	const int f = total > 0.f ? lo : 0;
+	face_idx[o] = f;
+	const float u2[2] = {rnd[o * 3 + 1], rnd[o * 3 + 2]};
+	uv[o * 2] = u2[0]; uv[o * 2 + 1] = u2[1];
+	const int32_t* fp = faces + (int64_t)m * faces_mesh_stride + (int64_t)f * 3;
+	float w[3];
+	bary_weights(u2, w);
+	const float* vp = verts + (int64_t)m * n_verts * 3;
+	float3 p = make_float3(0.f, 0.f, 0.f), q = p;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const int vi = max(fp[k], 0);
+		const float3 v = ld3(vp + 3 * vi);
+		p.x += w[k] * v.x; p.y += w[k] * v.y; p.z += w[k] * v.z;
+		if (attr) {
+			const float3 t = ld3(attr + ((int64_t)m * n_verts + vi) * 3);
+			q.x += w[k] * t.x; q.y += w[k] * t.y; q.z += w[k] * t.z;
+		}
+	}
+	out[o * 3 + 0] = p.x; out[o * 3 + 1] = p.y; out[o * 3 + 2] = p.z;
+	if (attr) { attr_out[o * 3 + 0] = q.x; attr_out[o * 3 + 1] = q.y; attr_out[o * 3 + 2] = q.z; }
+}
+
+// Masked mean squared error of the texture loss (reference losses.py:43-57): points whose target colour is saturated in every channel
+// (no channel < 1) are left out of the sum, the mean is over ALL n * 3 elements.  One workgroup, deterministic.
+__global__ __launch_bounds__(1024) void masked_mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n_pts,
+															   float* __restrict__ loss) {
+	__shared__ float red[16];
+	float s = 0.f;
+	for (int64_t i = threadIdx.x; i < n_pts; i += 1024) {
+		const float t0 = target[i * 3], t1 = target[i * 3 + 1], t2 = target[i * 3 + 2];
+		if (t0 < 1.f || t1 < 1.f || t2 < 1.f) {
+			const float a = pred[i * 3] - t0, b = pred[i * 3 + 1] - t1, c = pred[i * 3 + 2] - t2;
+			s += a * a + b * b + c * c;
+		}
+	}
+	s = wave_sum(s);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float t = 0.f;
+		for (int w = 0; w < 16; ++w) t += red[w];
+		*loss = t / (float)(n_pts * 3);
+	}
+}
+
+__global__ void masked_mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, int64_t n_pts, const float* __restrict__ g_loss,
+									  float* __restrict__ d_pred) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_pts) return;
+	const float t0 = target[i * 3], t1 = target[i * 3 + 1], t2 = target[i * 3 + 2];
+	const float g = (t0 < 1.f || t1 < 1.f || t2 < 1.f) ? 2.0f * (*g_loss) / (float)(n_pts * 3) : 0.f;
+	d_pred[i * 3] = g * (pred[i * 3] - t0); d_pred[i * 3 + 1] = g * (pred[i * 3 + 1] - t1); d_pred[i * 3 + 2] = g * (pred[i * 3 + 2] - t2);
+}
+
+// ------------------------------------------------------------------------------------------- nearest neighbour
+// A lane owns 2*NP query points, held as NP packed pairs (v_pk_add/mul/fma_f32: two queries per VALU instruction); the four waves
+// of a block own the SAME 128*NP queries and each scans one quarter of every target tile (targets stream through LDS in tiles of
+// NN_TILE, x,y,z,pad float4; a wave-uniform ds_read broadcasts one target to all lanes), so that FIND's small clouds (5-10 k points
+// x 1-16 feet) still put several waves on every SIMD.  Targets are taken four at a time: the minimum of the four distances is
+// compared with the running best (strict '<': the EARLIEST group of four wins a tie) and only the group's first index is kept --
+// 4.9 VALU instructions per query-target pair instead of 9 for a compare-and-select per pair.  After the scan each query recomputes
+// the four distances of its winning group with the same three roundings (mul, fma, fma) and takes the first that equals the best:
+// lowest index on ties, as knn_points.  The four partial results -- and, when the target range of a cloud is split over `splits`
+// blocks to fill the chip at batch 1, the partial results of the blocks -- are merged as 64-bit keys (distance bits << 32 | index),
+// whose unsigned order IS (distance, index) for the non-negative distances here.
+constexpr int NN_TILE = 1024;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct NnDir {
+	const float* x;          // queries (n, p1_max, 3)
+	const int32_t* x_len;    // (n) or NULL
+	const float* y;          // targets (n, p2_max, 3)
+	const int32_t* y_len;
+	int p1_max, p2_max;
+	float* dist;             // (n, p1_max) or NULL   \ direct outputs (splits == 1 only)
+	int32_t* idx;            // (n, p1_max) or NULL   /
+	unsigned long long* key; // (n, p1_max) or NULL: merged keys; plain store when splits == 1, atomicMin (buffer preset to ~0) otherwise
+};
+struct NnArgs {
+	NnDir d[2];
+	int n_dirs, splits;
+	unsigned* counter;   // or NULL: zeroed by the first block (the block counter of the reduction that follows this launch)
+};
+
+__device__ __forceinline__ float nn_dist(float qx, float qy, float qz, float tx, float ty, float tz) {
+	const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+	return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ unsigned long long nn_key(float d, int i) {
+	return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)i;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void nn_kernel(const NnArgs a) {
+	constexpr int NQ = 2 * NP;
 	__shared__ float4 ty[NN_TILE];
-	__shared__ float pbest[4][64 * NQ];
-	__shared__ int pidx[4][64 * NQ];
+	__shared__ unsigned long long pkey[3][64 * NQ];
+	const int dir = blockIdx.z / a.splits, split = blockIdx.z - dir * a.splits;
+	if (a.counter && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) *a.counter = 0u;
+	// (copy the fields: a reference into the kernel-argument array would move it to scratch)
+	const float* __restrict__ x = dir ? a.d[1].x : a.d[0].x;
+	const float* __restrict__ y = dir ? a.d[1].y : a.d[0].y;
+	const int32_t* x_len = dir ? a.d[1].x_len : a.d[0].x_len;
+	const int32_t* y_len = dir ? a.d[1].y_len : a.d[0].y_len;
+	const int p1_max = dir ? a.d[1].p1_max : a.d[0].p1_max, p2_max = dir ? a.d[1].p2_max : a.d[0].p2_max;
+	if ((int)blockIdx.x * 64 * NQ >= p1_max) return;
 	const int n = blockIdx.y;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int p1 = x_len ? x_len[n] : p1_max;
 	const int p2 = y_len ? y_len[n] : p2_max;
 	const float* xp = x + (int64_t)n * p1_max * 3;
 	const float* yp = y + (int64_t)n * p2_max * 3;
-	float qx[NQ], qy[NQ], qz[NQ], best[NQ];
-	int bi[NQ], qi[NQ];
+	// this block's share of the targets: whole groups of four
+	const int share = (int)((((int64_t)p2 + a.splits - 1) / a.splits + 3) & ~3ll);
+	const int lo = min(p2, split * share), hi = min(p2, lo + share);
+	v2f qx[NP], qy[NP], qz[NP];
+	float best[NQ];
+	int gj[NQ], qi[NQ];
 #pragma unroll
 	for (int k = 0; k < NQ; ++k) {
 		qi[k] = (blockIdx.x * NQ + k) * 64 + lane;
 		const int i = min(qi[k], p1_max - 1);
-		qx[k] = xp[i * 3 + 0]; qy[k] = xp[i * 3 + 1]; qz[k] = xp[i * 3 + 2];
-		best[k] = INFINITY; bi[k] = -1;
+		qx[k >> 1][k & 1] = xp[i * 3 + 0]; qy[k >> 1][k & 1] = xp[i * 3 + 1]; qz[k >> 1][k & 1] = xp[i * 3 + 2];
+		best[k] = INFINITY; gj[k] = -1;
 	}
-	for (int j0 = 0; j0 < p2; j0 += NN_TILE) {
-		const int cnt = min(NN_TILE, p2 - j0);
+	for (int j0 = lo; j0 < hi; j0 += NN_TILE) {
+		const int cnt = min(NN_TILE, hi - j0);
+		const int cnt4 = (cnt + 3) & ~3;
 		__syncthreads();
-		for (int j = threadIdx.x; j < cnt; j += 256) {
-			const float* s = yp + (int64_t)(j0 + j) * 3;
-			ty[j] = make_float4(s[0], s[1], s[2], 0.f);
+		for (int j = threadIdx.x; j < cnt4; j += 256) {
+			const float* s = yp + (int64_t)(j0 + min(j, cnt - 1)) * 3;
+			// the last group is padded with targets at an infinite distance: never '<' the running best
+			ty[j] = j < cnt ? make_float4(s[0], s[1], s[2], 0.f) : make_float4(1e30f, 1e30f, 1e30f, 0.f);
 		}
 		__syncthreads();
-		const int ja = wave * (NN_TILE / 4), jb = min(cnt, ja + NN_TILE / 4);
-#pragma unroll 4
-		for (int j = ja; j < jb; ++j) {
-			const float4 t = ty[j];
+		const int ja = __builtin_amdgcn_readfirstlane(wave * (NN_TILE / 4));
+		const int jb = __builtin_amdgcn_readfirstlane(min(cnt4, ja + NN_TILE / 4));
+#pragma unroll 2
+		for (int j = ja; j < jb; j += 4) {
+			const float4 t0 = ty[j], t1 = ty[j + 1], t2 = ty[j + 2], t3 = ty[j + 3];
 #pragma unroll
-			for (int k = 0; k < NQ; ++k) {
-				const float dx = qx[k] - t.x, dy = qy[k] - t.y, dz = qz[k] - t.z;
-				const float d = dx * dx + dy * dy + dz * dz;
-				if (d < best[k]) { best[k] = d; bi[k] = j0 + j; }
+			for (int k = 0; k < NP; ++k) {
+#define FIND_NN_D2(t) ({ const v2f dx = qx[k] - t.x, dy = qy[k] - t.y, dz = qz[k] - t.z;                                 \
+						 __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx)); })
+				const v2f d0 = FIND_NN_D2(t0), d1 = FIND_NN_D2(t1), d2 = FIND_NN_D2(t2), d3 = FIND_NN_D2(t3);
+#undef FIND_NN_D2
+				const float m0 = fminf(fminf(d0.x, d1.x), fminf(d2.x, d3.x));
+				const float m1 = fminf(fminf(d0.y, d1.y), fminf(d2.y, d3.y));
+				if (m0 < best[2 * k]) { best[2 * k] = m0; gj[2 * k] = j0 + j; }
+				if (m1 < best[2 * k + 1]) { best[2 * k + 1] = m1; gj[2 * k + 1] = j0 + j; }
 			}
 		}
 	}
+	// the winning group -> the first of its targets at the best distance
+	unsigned long long key[NQ];
 #pragma unroll
-	for (int k = 0; k < NQ; ++k) { pbest[wave][k * 64 + lane] = best[k]; pidx[wave][k * 64 + lane] = bi[k]; }
+	for (int k = 0; k < NQ; ++k) {
+		key[k] = ~0ull;
+		if (gj[k] >= 0) {
+			const float fx = qx[k >> 1][k & 1], fy = qy[k >> 1][k & 1], fz = qz[k >> 1][k & 1];
+			int jj = gj[k];
+#pragma unroll
+			for (int c = 3; c >= 0; --c) {
+				const int j = gj[k] + c;
+				if (j < hi) {
+					const float* s = yp + (int64_t)j * 3;
+					if (nn_dist(fx, fy, fz, s[0], s[1], s[2]) == best[k]) jj = j;
+				}
+			}
+			key[k] = nn_key(best[k], jj);
+		}
+	}
+	if (wave) {
+#pragma unroll
+		for (int k = 0; k < NQ; ++k) pkey[wave - 1][k * 64 + lane] = key[k];
+	}
 	__syncthreads();
 	if (wave == 0) {
+		float* dist = dir ? a.d[1].dist : a.d[0].dist;
+		int32_t* idx = dir ? a.d[1].idx : a.d[0].idx;
+		unsigned long long* kout = dir ? a.d[1].key : a.d[0].key;
 #pragma unroll
 		for (int k = 0; k < NQ; ++k) {
-			float b = best[k];
-			int ib = bi[k];
+			unsigned long long b = key[k];
 #pragma unroll
-			for (int w = 1; w < 4; ++w) {
-				const float ob = pbest[w][k * 64 + lane];
-				const int oi = pidx[w][k * 64 + lane];
-				if (oi >= 0 && (ib < 0 || ob < b || (ob == b && oi < ib))) { b = ob; ib = oi; }
+			for (int w = 0; w < 3; ++w) b = min(b, pkey[w][k * 64 + lane]);
+			if (qi[k] >= p1_max) continue;
+			const int64_t o = (int64_t)n * p1_max + qi[k];
+			const bool valid = qi[k] < p1 && b != ~0ull;
+			if (kout) {
+				if (a.splits == 1) kout[o] = qi[k] < p1 ? b : ~0ull;
+				else if (valid) atomicMin(kout + o, b);
 			}
-			if (qi[k] < p1_max) {
-				const bool valid = qi[k] < p1 && p2 > 0;
-				dist[(int64_t)n * p1_max + qi[k]] = valid ? b : 0.f;
-				idx[(int64_t)n * p1_max + qi[k]] = valid ? ib : -1;
-			}
+			if (dist) dist[o] = valid ? __uint_as_float((unsigned)(b >> 32)) : 0.f;
+			if (idx) idx[o] = valid ? (int)(unsigned)b : -1;
 		}
+	}
+}
+
+// Chamfer loss from the merged keys of both directions (pytorch3d.loss.chamfer_distance defaults: point mean, batch mean):
+//   loss = ( sum_n sum_i d_xy[n,i] / max(len_x[n],1)  +  sum_n sum_j d_yx[n,j] / max(len_y[n],1) ) / N
+// Block (n, dir) sums one cloud in a fixed thread -> element mapping and reduction tree; the block that finishes last (a counter in
+// the workspace, zeroed by the nearest-neighbour launch before) adds the 2 N partial means in index order: deterministic.
+__global__ __launch_bounds__(1024) void chamfer_reduce_kernel(const unsigned long long* __restrict__ kx, const int32_t* __restrict__ x_len, int p1_max,
+															  const unsigned long long* __restrict__ ky, const int32_t* __restrict__ y_len, int p2_max,
+															  int n_clouds, float* __restrict__ partial, unsigned* __restrict__ counter,
+															  float* __restrict__ loss) {
+	__shared__ float red[16];
+	__shared__ bool last;
+	const int n = blockIdx.x, dir = blockIdx.y;
+	const unsigned long long* k = dir ? ky : kx;
+	const int32_t* len = dir ? y_len : x_len;
+	const int pmax = dir ? p2_max : p1_max;
+	const int p = len ? len[n] : pmax;
+	float s = 0.f;
+	for (int i = threadIdx.x; i < p; i += 1024) {
+		const unsigned long long v = k[(int64_t)n * pmax + i];
+		s += v == ~0ull ? 0.f : __uint_as_float((unsigned)(v >> 32));
+	}
+	s = wave_sum(s);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float t = 0.f;
+		for (int w = 0; w < 16; ++w) t += red[w];
+		partial[dir * n_clouds + n] = t / (float)max(p, 1);
+		__threadfence();
+		last = atomicAdd(counter, 1u) == 2u * n_clouds - 1u;
+	}
+	__syncthreads();
+	if (last && threadIdx.x == 0) {
+		__threadfence();
+		float total = 0.f;
+		for (int i = 0; i < 2 * n_clouds; ++i) total += __builtin_nontemporal_load(partial + i);
+		*loss = total / (float)max(n_clouds, 1);
+	}
+}
+
+// Gradient of that loss: for every valid point i of either direction with nearest neighbour j,
+//   g = 2 * (*g_loss) / (N * max(len,1)) * (a_i - b_j);   d_a[i] += g;  d_b[j] -= g      (d_x / d_y zero-initialised by the caller)
+__global__ void chamfer_bwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ x_len, int p1_max, const float* __restrict__ y,
+								   const int32_t* __restrict__ y_len, int p2_max, const unsigned long long* __restrict__ kx,
+								   const unsigned long long* __restrict__ ky, const float* __restrict__ g_loss, int n_clouds,
+								   float* __restrict__ d_x, float* __restrict__ d_y) {
+	const int n = blockIdx.y, dir = blockIdx.z;
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int pa_max = dir ? p2_max : p1_max, pb_max = dir ? p1_max : p2_max;
+	const int32_t* la = dir ? y_len : x_len;
+	const int pa = la ? la[n] : pa_max;
+	if (i >= pa) return;
+	const unsigned long long v = (dir ? ky : kx)[(int64_t)n * pa_max + i];
+	if (v == ~0ull) return;
+	const int j = (int)(unsigned)v;
+	const float* ap = (dir ? y : x) + ((int64_t)n * pa_max + i) * 3;
+	const float* bp = (dir ? x : y) + ((int64_t)n * pb_max + j) * 3;
+	const float g = 2.0f * (*g_loss) / ((float)n_clouds * (float)max(pa, 1));
+	const float gx = g * (ap[0] - bp[0]), gy = g * (ap[1] - bp[1]), gz = g * (ap[2] - bp[2]);
+	float* da = dir ? d_y : d_x;
+	float* db = dir ? d_x : d_y;
+	if (da) {
+		float* o = da + ((int64_t)n * pa_max + i) * 3;
+		unsafeAtomicAdd(o + 0, gx); unsafeAtomicAdd(o + 1, gy); unsafeAtomicAdd(o + 2, gz);
+	}
+	if (db) {
+		float* o = db + ((int64_t)n * pb_max + j) * 3;
+		unsafeAtomicAdd(o + 0, -gx); unsafeAtomicAdd(o + 1, -gy); unsafeAtomicAdd(o + 2, -gz);
 	}
 }
 
@@ -271,24 +536,27 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float* __restrict
 }
 
 __global__ void smooth_finalize_kernel(const float* __restrict__ partial, int n_meshes, int nblk, int n_verts, int n_edges,
-									   float* __restrict__ loss_edge, float* __restrict__ loss_lap) {
+									   float* __restrict__ loss_edge, float* __restrict__ loss_lap, float w_edge, float w_lap,
+									   float* __restrict__ loss_sum) {
 	// single wave; deterministic order
 	float lap = 0.f, edge = 0.f;
 	for (int k = threadIdx.x; k < n_meshes * nblk; k += 64) { lap += partial[k * 2 + 0]; edge += partial[k * 2 + 1]; }
 	lap = wave_sum(lap);
 	edge = wave_sum(edge);
 	if (threadIdx.x == 0) {
-		*loss_lap = lap / (float)n_verts / (float)n_meshes;
-		*loss_edge = 0.5f * edge / (float)n_edges / (float)n_meshes;
+		const float l = lap / (float)n_verts / (float)n_meshes, e = 0.5f * edge / (float)n_edges / (float)n_meshes;
+		if (loss_lap) *loss_lap = l;
+		if (loss_edge) *loss_edge = e;
+		if (loss_sum) *loss_sum = w_lap * l + w_edge * e;   // MeshSmoothnessLoss: 0.1 * laplacian + 10 * edge (losses.py:95-99)
 	}
 }
 
 // backward: with u_i = g_lap/(V N) * lapdir_i and q_i = nw_i * u_i:   dV_i = (L q)_i - u_i  +  g_edge/(E N) * 2 * sum_j (v_i - v_j)
-__global__ void smooth_bwd_q_kernel(const float* __restrict__ nw, const float* __restrict__ lapdir, const float* __restrict__ g_lap,
+__global__ void smooth_bwd_q_kernel(const float* __restrict__ nw, const float* __restrict__ lapdir, const float* __restrict__ g_lap, float s_lap,
 									int n_meshes, int n_verts, float* __restrict__ q) {
 	const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (o >= (int64_t)n_meshes * n_verts) return;
-	const float s = (*g_lap) / (float)n_verts / (float)n_meshes * nw[o];
+	const float s = (*g_lap) * s_lap / (float)n_verts / (float)n_meshes * nw[o];
 	q[o * 3 + 0] = s * lapdir[o * 3 + 0]; q[o * 3 + 1] = s * lapdir[o * 3 + 1]; q[o * 3 + 2] = s * lapdir[o * 3 + 2];
 }
 
@@ -297,8 +565,8 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float* __restrict
 														  const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
 														  const int32_t* __restrict__ nbr_idx, const float* __restrict__ q,
 														  const float* __restrict__ lapdir, const float* __restrict__ g_edge,
-														  const float* __restrict__ g_lap, int n_meshes, int n_verts, int n_faces,
-														  int n_edges, float* __restrict__ d_verts) {
+														  const float* __restrict__ g_lap, float s_edge, float s_lap, int n_meshes, int n_verts,
+														  int n_faces, int n_edges, float* __restrict__ d_verts) {
 	const int m = blockIdx.y;
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_verts) return;
@@ -308,9 +576,9 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float* __restrict
 	float rs;
 	apply_L(qp, faces, fw + (int64_t)m * n_faces * 3, vf_off, vf_items, i, &r, &rs);
 	const int64_t o = (int64_t)m * n_verts + i;
-	const float su = (*g_lap) / (float)n_verts / (float)n_meshes;
+	const float su = (*g_lap) * s_lap / (float)n_verts / (float)n_meshes;
 	float3 g = make_float3(r.x - su * lapdir[o * 3 + 0], r.y - su * lapdir[o * 3 + 1], r.z - su * lapdir[o * 3 + 2]);
-	const float se = 2.0f * (*g_edge) / (float)n_edges / (float)n_meshes;
+	const float se = 2.0f * (*g_edge) * s_edge / (float)n_edges / (float)n_meshes;
 	const float3 v = ld3(vp + 3 * i);
 	float3 es = make_float3(0.f, 0.f, 0.f);
 	for (int e = nbr_off[i]; e < nbr_off[i + 1]; ++e) {
@@ -387,14 +655,31 @@ extern "C" int find_sample_points_bwd(const int32_t* faces, int64_t faces_batch,
 	return FIND_OK;
 }
 
+// queries per lane and target splits of a launch: enough blocks to give every SIMD work at batch 1, whole waves of blocks at batch 16
+static void nn_shape(int64_t blocks_np1, int64_t p2_max, int* np, int* splits) {
+	*np = blocks_np1 >= 4096 ? 2 : 1;
+	*splits = 1;
+	while (blocks_np1 * *splits < 512 && *splits < 8 && p2_max / (*splits * 2) >= 256) *splits *= 2;
+}
+
+static int launch_nn(const NnArgs& a, int np, int64_t p_max, int64_t n, hipStream_t s) {
+	const dim3 grid((unsigned)cdiv(p_max, 128 * np), (unsigned)n, (unsigned)(a.n_dirs * a.splits));
+	if (np == 2) hipLaunchKernelGGL(nn_kernel<2>, grid, dim3(256), 0, s, a);
+	else hipLaunchKernelGGL(nn_kernel<1>, grid, dim3(256), 0, s, a);
+	return check_launch("nn_kernel");
+}
+
 extern "C" int find_nn_fwd(const float* x, const int32_t* x_len, const float* y, const int32_t* y_len, int64_t n, int64_t p1_max,
 						   int64_t p2_max, float* dist, int32_t* idx, void* stream) {
 	FIND_REQUIRE(x && y && dist && idx, "find_nn_fwd: NULL argument");
 	FIND_REQUIRE(!bad_dims(n, p1_max) && p2_max >= 1 && p2_max < (1ll << 30), "find_nn_fwd: bad sizes");
-	hipLaunchKernelGGL(nn_fwd_kernel, dim3((unsigned)cdiv(p1_max, 64 * NQ), (unsigned)n), dim3(256), 0, (hipStream_t)stream, x, x_len, y, y_len,
-					   (int)p1_max, (int)p2_max, dist, idx);
-	FIND_LAUNCH_CHECK("nn_fwd_kernel");
-	return FIND_OK;
+	NnArgs a = {};
+	a.d[0] = NnDir{x, x_len, y, y_len, (int)p1_max, (int)p2_max, dist, idx, nullptr};
+	a.n_dirs = 1;
+	int np, splits;
+	nn_shape(cdiv(p1_max, 128) * n, p2_max, &np, &splits);
+	a.splits = 1;   // the direct outputs cannot be merged across blocks
+	return launch_nn(a, np, p1_max, n, (hipStream_t)stream);
 }
 
 extern "C" int find_nn_bwd(const float* x, const int32_t* x_len, const float* y, const int32_t* idx, const float* w, int64_t n,
@@ -408,6 +693,111 @@ extern "C" int find_nn_bwd(const float* x, const int32_t* x_len, const float* y,
 	return FIND_OK;
 }
 
+struct ChamferWs {
+	unsigned long long* kx;  // (n, p1_max)
+	unsigned long long* ky;  // (n, p2_max)
+	int64_t key_bytes;       // of kx + ky: what a split launch presets to ~0
+	float* partial;          // (2, n) per-cloud means of the reduction
+	unsigned* counter;
+	int64_t bytes;
+};
+static void carve_chamfer(int64_t n, int64_t p1_max, int64_t p2_max, void* ws, ChamferWs* o) {
+	Carver c(ws);
+	o->kx = c.take<unsigned long long>(n * p1_max);
+	o->ky = c.take<unsigned long long>(n * p2_max);
+	o->key_bytes = c.off;
+	o->partial = c.take<float>(2 * n);
+	o->counter = c.take<unsigned>(1);
+	o->bytes = c.off;
+}
+
+extern "C" int64_t find_chamfer_ws_bytes(int64_t n, int64_t p1_max, int64_t p2_max) {
+	if (bad_dims(n, p1_max) || bad_dims(n, p2_max)) return -1;
+	ChamferWs w;
+	carve_chamfer(n, p1_max, p2_max, nullptr, &w);
+	return w.bytes;
+}
+
+extern "C" int find_chamfer_fwd(const float* x, const int32_t* x_len, const float* y, const int32_t* y_len, int64_t n, int64_t p1_max, int64_t p2_max,
+								float* loss, void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(x && y && loss && ws, "find_chamfer_fwd: NULL argument");
+	FIND_REQUIRE(!bad_dims(n, p1_max) && !bad_dims(n, p2_max), "find_chamfer_fwd: bad sizes");
+	ChamferWs w;
+	carve_chamfer(n, p1_max, p2_max, ws, &w);
+	if (ws_bytes < w.bytes) { set_error("find_chamfer_fwd: workspace too small"); return FIND_EWORKSPACE; }
+	hipStream_t s = (hipStream_t)stream;
+	NnArgs a = {};
+	a.d[0] = NnDir{x, x_len, y, y_len, (int)p1_max, (int)p2_max, nullptr, nullptr, w.kx};
+	a.d[1] = NnDir{y, y_len, x, x_len, (int)p2_max, (int)p1_max, nullptr, nullptr, w.ky};
+	a.n_dirs = 2;
+	a.counter = w.counter;
+	const int64_t p_max = std::max(p1_max, p2_max);
+	int np;
+	nn_shape(cdiv(p_max, 128) * n * 2, std::min(p1_max, p2_max), &np, &a.splits);
+	if (a.splits > 1) {
+		hipError_t e = hipMemsetAsync(ws, 0xff, (size_t)w.key_bytes, s);
+		if (e != hipSuccess) { set_error("find_chamfer_fwd: hipMemsetAsync: %s", hipGetErrorString(e)); return FIND_ELAUNCH; }
+	}
+	int rc = launch_nn(a, np, p_max, n, s);
+	if (rc != FIND_OK) return rc;
+	hipLaunchKernelGGL(chamfer_reduce_kernel, dim3((unsigned)n, 2), dim3(1024), 0, s, w.kx, x_len, (int)p1_max, w.ky, y_len, (int)p2_max, (int)n, w.partial, w.counter,
+					   loss);
+	FIND_LAUNCH_CHECK("chamfer_reduce_kernel");
+	return FIND_OK;
+}
+
+extern "C" int find_chamfer_bwd(const float* x, const int32_t* x_len, const float* y, const int32_t* y_len, int64_t n, int64_t p1_max, int64_t p2_max,
+								const float* g_loss, const void* ws, int64_t ws_bytes, float* d_x, float* d_y, void* stream) {
+	FIND_REQUIRE(x && y && g_loss && ws, "find_chamfer_bwd: NULL argument");
+	FIND_REQUIRE(d_x || d_y, "find_chamfer_bwd: both gradient outputs NULL");
+	FIND_REQUIRE(!bad_dims(n, p1_max) && !bad_dims(n, p2_max), "find_chamfer_bwd: bad sizes");
+	ChamferWs w;
+	carve_chamfer(n, p1_max, p2_max, const_cast<void*>(ws), &w);
+	if (ws_bytes < w.bytes) { set_error("find_chamfer_bwd: workspace too small"); return FIND_EWORKSPACE; }
+	hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((unsigned)cdiv(std::max(p1_max, p2_max), 256), (unsigned)n, 2), dim3(256), 0, (hipStream_t)stream, x, x_len,
+					   (int)p1_max, y, y_len, (int)p2_max, w.kx, w.ky, g_loss, (int)n, d_x, d_y);
+	FIND_LAUNCH_CHECK("chamfer_bwd_kernel");
+	return FIND_OK;
+}
+
+extern "C" int64_t find_sample_surface_ws_bytes(int64_t n_meshes, int64_t n_faces) {
+	if (bad_dims(n_meshes, n_faces)) return -1;
+	return align_up(n_meshes * n_faces * (int64_t)sizeof(float), 256);
+}
+
+extern "C" int find_sample_surface_fwd(const float* verts, const int32_t* faces, int64_t faces_batch, const float* rnd, int64_t n_meshes, int64_t n_verts,
+									   int64_t n_faces, int64_t n_samples, int32_t* face_idx, float* uv, float* out, const float* attr, float* attr_out,
+									   void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(verts && faces && rnd && face_idx && uv && out && ws, "find_sample_surface_fwd: NULL argument");
+	FIND_REQUIRE((attr == nullptr) == (attr_out == nullptr), "find_sample_surface_fwd: attr and attr_out must both be given or both NULL");
+	FIND_REQUIRE(!bad_dims(n_meshes, n_samples) && !bad_dims(n_meshes, n_faces) && n_verts >= 1, "find_sample_surface_fwd: bad sizes");
+	FIND_REQUIRE(faces_batch == 1 || faces_batch == n_meshes, "find_sample_surface_fwd: faces_batch must be 1 or n_meshes");
+	if (ws_bytes < find_sample_surface_ws_bytes(n_meshes, n_faces)) { set_error("find_sample_surface_fwd: workspace too small"); return FIND_EWORKSPACE; }
+	hipStream_t s = (hipStream_t)stream;
+	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
+	hipLaunchKernelGGL(area_cdf_kernel, dim3((unsigned)n_meshes), dim3(1024), 0, s, verts, faces, fstride, (int)n_verts, (int)n_faces, (float*)ws);
+	hipLaunchKernelGGL(sample_surface_kernel, dim3((unsigned)cdiv(n_samples, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, (const float*)ws, rnd,
+					   (int)n_verts, (int)n_faces, (int)n_samples, face_idx, uv, out, attr, attr_out);
+	FIND_LAUNCH_CHECK("sample_surface");
+	return FIND_OK;
+}
+
+extern "C" int find_masked_mse_fwd(const float* pred, const float* target, int64_t n_pts, float* loss, void* stream) {
+	FIND_REQUIRE(pred && target && loss, "find_masked_mse_fwd: NULL argument");
+	FIND_REQUIRE(n_pts >= 1 && n_pts < (1ll << 40), "find_masked_mse_fwd: bad sizes");
+	hipLaunchKernelGGL(masked_mse_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, n_pts, loss);
+	FIND_LAUNCH_CHECK("masked_mse_fwd_kernel");
+	return FIND_OK;
+}
+
+extern "C" int find_masked_mse_bwd(const float* pred, const float* target, int64_t n_pts, const float* g_loss, float* d_pred, void* stream) {
+	FIND_REQUIRE(pred && target && g_loss && d_pred, "find_masked_mse_bwd: NULL argument");
+	FIND_REQUIRE(n_pts >= 1 && n_pts < (1ll << 40), "find_masked_mse_bwd: bad sizes");
+	hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3((unsigned)cdiv(n_pts, 256)), dim3(256), 0, (hipStream_t)stream, pred, target, n_pts, g_loss, d_pred);
+	FIND_LAUNCH_CHECK("masked_mse_bwd_kernel");
+	return FIND_OK;
+}
+
 extern "C" int64_t find_smooth_ws_bytes(int64_t n_meshes, int64_t n_verts, int64_t n_faces) {
 	if (bad_dims(n_meshes, n_verts) || n_faces < 1) return -1;
 	SmoothWs w;
@@ -415,36 +805,67 @@ extern "C" int64_t find_smooth_ws_bytes(int64_t n_meshes, int64_t n_verts, int64
 	return w.bytes;
 }
 
-extern "C" int find_smooth_fwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
-							   const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
-							   int64_t n_edges, float* loss_edge, float* loss_lap, void* ws, int64_t ws_bytes, void* stream) {
-	FIND_REQUIRE(verts && faces && vf_off && vf_items && nbr_off && nbr_idx && loss_edge && loss_lap && ws, "find_smooth_fwd: NULL argument");
-	FIND_REQUIRE(!bad_dims(n_meshes, n_verts) && n_faces >= 1 && n_edges >= 1, "find_smooth_fwd: bad sizes");
+static int smooth_fwd_body(const char* who, const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items, const int32_t* nbr_off,
+						   const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_edges, float* loss_edge, float* loss_lap,
+						   float w_edge, float w_lap, float* loss_sum, void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(verts && faces && vf_off && vf_items && nbr_off && nbr_idx && ws, "%s: NULL argument", who);
+	FIND_REQUIRE(!bad_dims(n_meshes, n_verts) && n_faces >= 1 && n_edges >= 1, "%s: bad sizes", who);
 	SmoothWs w;
 	carve_smooth(n_meshes, n_verts, n_faces, ws, &w);
-	if (ws_bytes < w.bytes) { set_error("find_smooth_fwd: workspace too small"); return FIND_EWORKSPACE; }
+	if (ws_bytes < w.bytes) { set_error("%s: workspace too small", who); return FIND_EWORKSPACE; }
 	hipStream_t s = (hipStream_t)stream;
 	hipLaunchKernelGGL(cot_weights_kernel, dim3((unsigned)cdiv(n_faces, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, (int)n_verts, (int)n_faces, w.fw);
 	hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off,
 					   nbr_idx, (int)n_verts, (int)n_faces, w.nw, w.lapdir, w.partial);
-	hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(64), 0, s, w.partial, (int)n_meshes, w.nblk, (int)n_verts, (int)n_edges, loss_edge, loss_lap);
-	FIND_LAUNCH_CHECK("smooth_fwd");
+	hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(64), 0, s, w.partial, (int)n_meshes, w.nblk, (int)n_verts, (int)n_edges, loss_edge, loss_lap,
+					   w_edge, w_lap, loss_sum);
+	FIND_LAUNCH_CHECK(who);
 	return FIND_OK;
+}
+
+static int smooth_bwd_body(const char* who, const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items, const int32_t* nbr_off,
+						   const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_edges, const float* g_edge, const float* g_lap,
+						   float s_edge, float s_lap, void* ws, int64_t ws_bytes, float* d_verts, void* stream) {
+	FIND_REQUIRE(verts && faces && vf_off && vf_items && nbr_off && nbr_idx && g_edge && g_lap && ws && d_verts, "%s: NULL argument", who);
+	FIND_REQUIRE(!bad_dims(n_meshes, n_verts) && n_faces >= 1 && n_edges >= 1, "%s: bad sizes", who);
+	SmoothWs w;
+	carve_smooth(n_meshes, n_verts, n_faces, ws, &w);
+	if (ws_bytes < w.bytes) { set_error("%s: workspace too small", who); return FIND_EWORKSPACE; }
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(smooth_bwd_q_kernel, dim3((unsigned)cdiv(n_meshes * n_verts, 256)), dim3(256), 0, s, w.nw, w.lapdir, g_lap, s_lap, (int)n_meshes, (int)n_verts, w.q);
+	hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off, nbr_idx,
+					   w.q, w.lapdir, g_edge, g_lap, s_edge, s_lap, (int)n_meshes, (int)n_verts, (int)n_faces, (int)n_edges, d_verts);
+	FIND_LAUNCH_CHECK(who);
+	return FIND_OK;
+}
+
+extern "C" int find_smooth_fwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
+							   const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
+							   int64_t n_edges, float* loss_edge, float* loss_lap, void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(loss_edge && loss_lap, "find_smooth_fwd: NULL argument");
+	return smooth_fwd_body("find_smooth_fwd", verts, faces, vf_off, vf_items, nbr_off, nbr_idx, n_meshes, n_verts, n_faces, n_edges, loss_edge, loss_lap, 0.f, 0.f,
+						   nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int find_smooth_bwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
 							   const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
 							   int64_t n_edges, const float* g_edge, const float* g_lap, void* ws, int64_t ws_bytes, float* d_verts,
 							   void* stream) {
-	FIND_REQUIRE(verts && faces && vf_off && vf_items && nbr_off && nbr_idx && g_edge && g_lap && ws && d_verts, "find_smooth_bwd: NULL argument");
-	FIND_REQUIRE(!bad_dims(n_meshes, n_verts) && n_faces >= 1 && n_edges >= 1, "find_smooth_bwd: bad sizes");
-	SmoothWs w;
-	carve_smooth(n_meshes, n_verts, n_faces, ws, &w);
-	if (ws_bytes < w.bytes) { set_error("find_smooth_bwd: workspace too small"); return FIND_EWORKSPACE; }
-	hipStream_t s = (hipStream_t)stream;
-	hipLaunchKernelGGL(smooth_bwd_q_kernel, dim3((unsigned)cdiv(n_meshes * n_verts, 256)), dim3(256), 0, s, w.nw, w.lapdir, g_lap, (int)n_meshes, (int)n_verts, w.q);
-	hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off, nbr_idx,
-					   w.q, w.lapdir, g_edge, g_lap, (int)n_meshes, (int)n_verts, (int)n_faces, (int)n_edges, d_verts);
-	FIND_LAUNCH_CHECK("smooth_bwd");
-	return FIND_OK;
+	return smooth_bwd_body("find_smooth_bwd", verts, faces, vf_off, vf_items, nbr_off, nbr_idx, n_meshes, n_verts, n_faces, n_edges, g_edge, g_lap, 1.f, 1.f, ws,
+						   ws_bytes, d_verts, stream);
+}
+
+extern "C" int find_smooth_loss_fwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items, const int32_t* nbr_off,
+									const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_edges, float w_edge, float w_lap,
+									float* loss, void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(loss, "find_smooth_loss_fwd: NULL argument");
+	return smooth_fwd_body("find_smooth_loss_fwd", verts, faces, vf_off, vf_items, nbr_off, nbr_idx, n_meshes, n_verts, n_faces, n_edges, nullptr, nullptr, w_edge,
+						   w_lap, loss, ws, ws_bytes, stream);
+}
+
+extern "C" int find_smooth_loss_bwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items, const int32_t* nbr_off,
+									const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces, int64_t n_edges, float w_edge, float w_lap,
+									const float* g_loss, void* ws, int64_t ws_bytes, float* d_verts, void* stream) {
+	return smooth_bwd_body("find_smooth_loss_bwd", verts, faces, vf_off, vf_items, nbr_off, nbr_idx, n_meshes, n_verts, n_faces, n_edges, g_loss, g_loss, w_edge,
+						   w_lap, ws, ws_bytes, d_verts, stream);
 }

@@ -135,6 +135,7 @@ struct find_ctx {
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 1;        // the LDS-DMA ring kernels reserve the whole LDS of their CU (see "Co-residence" below)
 	int reduce_exclusive = 0;     // diagnosis only: the slab reduce (16 KB of LDS) reserves its CU's whole LDS instead of the ring kernels
+	int group_spf = 0;            // grouped weight gradients: splits per foot (0 = cost model of group_geometry)
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
 	// internal streams / events
 	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
@@ -685,10 +686,11 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 		o->zsD = o->zsC = o->pS = o->pS2 = nullptr;
 	}
 	o->grp_pw = nullptr; o->grp_slabs = 0; o->grp_jobs = 0;
-	if (!d.shared && cdiv(d.V, 32) * d.feet_t <= GROUP_MAX_UNITS) {
-		o->grp_jobs = (p->n_trunk - 1) + p->n_disp + p->n_col;
-		o->grp_slabs = d.n_feet * (cdiv(d.V / 16, GROUP_MIN_CPS) + 1);
-		o->grp_pw = c.take<float>((int64_t)o->grp_jobs * o->grp_slabs * ((int64_t)W * W + W));
+	if (cdiv(d.V, 32) * d.feet_t <= GROUP_MAX_UNITS) {
+		// (a shared trunk groups its own layers only: the heads' layers there have n_feet times the rows and keep their own launches)
+		o->grp_jobs = d.shared ? (p->n_trunk - 1) : (p->n_trunk - 1) + p->n_disp + p->n_col;
+		o->grp_slabs = std::max<int64_t>(d.feet_t * (cdiv(d.V / 16, GROUP_MIN_CPS) + 1), std::min<int64_t>(d.feet_t * cdiv(d.V / 16, 2), 32));
+		if (o->grp_jobs > 0) o->grp_pw = c.take<float>((int64_t)o->grp_jobs * o->grp_slabs * ((int64_t)W * W + W));
 	}
 	o->nblk_out = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(d.rows_h, 64), 512));
 	for (int i = 0; i < 2; ++i) {
@@ -802,16 +804,32 @@ struct WgradGroup {
 	WgradGroup() { memset(&d, 0, sizeof(d)); memset(&r, 0, sizeof(r)); }
 };
 
+// Splits per foot of a grouped weight gradient.  A workgroup owns a whole 256 x 256 tile over `cps` 16-row chunks (3.4 us of MFMA issue
+// each at the fp32 peak) and writes a 256-KB slab that the grouped reduce reads back; one workgroup per CU (whole-LDS reservation), so the
+// launch runs in ceil(workgroups / CUs) rounds.  Few long splits leave CUs idle or pay a whole round for a few leftover workgroups; many
+// short ones pay the per-workgroup prologue + slab and make the reduce (~0.06 us per slab) the longer kernel: take the cheapest of
+// the candidates under this model ("group_spf" knob: 0 = model, n = force n splits per foot; measured with tools/fused_ab.py).
+static void group_geometry(const find_ctx* c, int cpf16, int64_t feet, int jobs, int64_t max_slabs, int* spf_out, int* cps_out) {
+	auto take = [&](int s) { *cps_out = (int)cdiv(cpf16, s); *spf_out = (int)cdiv(cpf16, *cps_out); };
+	const int s_max = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, max_slabs / std::max<int64_t>(feet, 1)));
+	if (c->group_spf > 0) { take(std::min(c->group_spf, s_max)); return; }
+	double best = 1e30;
+	take(1);
+	for (int s = 1; s <= s_max; ++s) {
+		const int cps = (int)cdiv(cpf16, s);
+		if ((int)cdiv(cpf16, cps) != s || (cps < 2 && s > 1)) continue;   // (same geometry as a smaller s; single-chunk splits)
+		const int64_t wgs = feet * s * std::max(jobs, 1);
+		const double cost = (double)cdiv(wgs, c->num_cus) * (cps * 3.6 + 6.0) + wgs * 0.06;
+		if (cost < best) { best = cost; take(s); }
+	}
+}
+
 static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const float* dz, const float* x, int64_t x_foot_stride, int64_t feet, int64_t V,
 						   float* dw, int ld_out, float* db, float* S) {
 	FIND_REQUIRE(G.n < b.grp_jobs && G.n < DW2_MAX_JOBS, "find_mlp_bwd: too many grouped weight gradients");
 	const int cpf16 = (int)(V / 16);
 	int spf = 1, cps2 = 1;
-	if (cpf16 > 0) {
-		const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
-		cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(GROUP_MIN_CPS, cpf16));
-		spf = (int)cdiv(cpf16, cps2);
-	}
+	if (cpf16 > 0) group_geometry(c, cpf16, feet, b.grp_jobs, b.grp_slabs, &spf, &cps2);
 	const int nmain = (int)(feet * spf);
 	FIND_REQUIRE(nmain <= b.grp_slabs, "find_mlp_bwd: grouped weight gradient needs %d slabs, %lld reserved", nmain, (long long)b.grp_slabs);
 	float* pw = b.grp_pw + (int64_t)G.n * b.grp_slabs * W * W;
@@ -1098,13 +1116,24 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[p->n_trunk - l]; st.to_lds = 1;
 		}
 		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		// the trunk's weight gradients: all their inputs exist now -- one grouped launch + one grouped reduce (fp32), as in the small-call path
+		const bool grouped = !c->f16 && b.grp_pw != nullptr;
+		WgradGroup G;
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			const int k = fk.on ? 1 + (l & 1) : 0;
-			BwdWs bk = b;
-			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
-			fk.fork_to(k);
-			FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+			if (grouped) {
+				FIND_TRY(wgrad_group_add(c, G, b, b.dzT[ct], w.H[l - 1], V * W, d.feet_t, V, g->trunk_w[l], W, g->trunk_b[l], nullptr));
+			} else {
+				const int k = fk.on ? 1 + (l & 1) : 0;
+				BwdWs bk = b;
+				bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
+				fk.fork_to(k);
+				FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
+			}
 			ct += 1;
+		}
+		if (grouped) {
+			fk.fork_to(T1);
+			FIND_TRY(wgrad_group_launch(c, G, fk.stream(T1)));
 		}
 	} else {
 	// 4. gradient wrt the trunk output: both heads (and, for a shared trunk, every foot) summed in the K loop
@@ -1266,7 +1295,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 1}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 1}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 

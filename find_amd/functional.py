@@ -179,6 +179,14 @@ class _MLP(torch.autograd.Function):
 		p = _fill_params(spec, B, avg_col, weights)
 		p.precision = ctx.precision   # the arithmetic the forward ran in, whatever the default is by now
 		grads = _grads_like(weights)
+		# A second backward through the same weights inside one backward() call (FIND's texture pass and its main pass) would have
+		# autograd add 26 pairs of gradient tensors one launch each (InputBuffer accumulation).  The first call's gradients are still
+		# parked at the parameters' AccumulateGrad nodes at that point -- those nodes run only after every MLP node that feeds them --, so
+		# this call adds its own to them with one multi-tensor launch and reports "no contribution" for the weights instead.
+		task = _graph_task_id()
+		key = tuple(w.data_ptr() for w in weights)
+		pending = _PENDING_WGRADS.get(key)
+		fold = pending is not None and task >= 0 and pending[0] == task and all(ctx.needs_input_grad[6:])
 		g_lat_disp = torch.empty_like(lat_disp) if lat_disp is not None else None
 		g_lat_col = torch.empty_like(lat_col) if lat_col is not None else None
 		G = MlpGrads()
@@ -199,7 +207,22 @@ class _MLP(torch.autograd.Function):
 		check(L.find_mlp_bwd(_lib.ctx(pos.device), ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
 							 ptr(ctx.ws), ctx.ws.numel(), ptr(scratch), scratch.numel(), ctypes.byref(G),
 							 current_stream(pos.device)), 'find_mlp_bwd')
+		if fold:
+			torch._foreach_add_([base[o:o + g.numel()].view(g.shape) for (base, o), g in zip(pending[1], grads)], grads)
+			return (None, None, g_lat_disp, g_lat_col, None, None, *([None] * len(grads)))
+		_PENDING_WGRADS.clear()
+		if task >= 0 and all(ctx.needs_input_grad[6:]) and all(g._base is not None and g._base.dim() == 1 for g in grads):
+			# (where the gradients live, not the tensors themselves: autograd adopts a gradient as .grad only while nothing else holds it)
+			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) for g in grads])
 		return (None, None, g_lat_disp, g_lat_col, None, None, *grads)
+
+
+_PENDING_WGRADS = {}   # weight data_ptrs -> (autograd graph-task id, [(flat buffer, offset)] of the gradients the first backward of that task handed to the engine)
+
+
+def _graph_task_id():
+	f = getattr(torch._C, '_current_graph_task_id', None)
+	return int(f()) if f is not None else -1
 
 
 def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights):
@@ -349,6 +372,67 @@ def sample_points(verts, faces, face_idx, uv, attr=None):
 	return _SamplePoints.apply(verts, faces, face_idx, uv, attr)
 
 
+class _SampleSurface(torch.autograd.Function):
+	"""sample_points_from_meshes with the face choice on the device: rnd (N,S,3) uniform draws [face, u, v] -> points (N,S,3)
+	[, attr samples], plus the chosen faces and (u,v) as non-differentiable outputs (find_sample_surface_fwd)."""
+
+	@staticmethod
+	def forward(ctx, verts, faces, rnd, attr):
+		_require_gpu(verts, rnd, attr)
+		L = _lib.lib()
+		verts, rnd, attr = _c(verts), _c(rnd), _c(attr)
+		faces = _faces_i32(faces)
+		N, V, _ = verts.shape
+		S = rnd.shape[1]
+		if rnd.shape != (N, S, 3):
+			raise RuntimeError(f'find_amd.sample_surface: rnd must be ({N}, S, 3), got {tuple(rnd.shape)}')
+		fb = 1 if faces.dim() == 2 else faces.shape[0]
+		F = faces.shape[-2]
+		dev = verts.device
+		out = torch.empty(N, S, 3, device=dev, dtype=torch.float32)
+		aout = torch.empty_like(out) if attr is not None else None
+		face_idx = torch.empty(N, S, device=dev, dtype=torch.int32)
+		uv = torch.empty(N, S, 2, device=dev, dtype=torch.float32)
+		ws = _ws(L.find_sample_surface_ws_bytes(N, F), dev)
+		check(L.find_sample_surface_fwd(ptr(verts.detach()), ptr(faces), fb, ptr(rnd), N, V, F, S, ptr(face_idx), ptr(uv), ptr(out), ptr(attr), ptr(aout),
+										ptr(ws), ws.numel(), current_stream(dev)), 'find_sample_surface_fwd')
+		ctx.save_for_backward(faces, face_idx, uv)
+		ctx.dims = (N, V, F, S, fb)
+		ctx.has_attr = attr is not None
+		ctx.mark_non_differentiable(face_idx, uv)
+		if attr is None:
+			return out, face_idx, uv
+		return out, aout, face_idx, uv
+
+	@staticmethod
+	def backward(ctx, g_out, *rest):
+		L = _lib.lib()
+		faces, face_idx, uv = ctx.saved_tensors
+		N, V, F, S, fb = ctx.dims
+		g_attr = rest[0] if ctx.has_attr else None
+
+		def scatter(g):
+			if g is None:
+				return None
+			d = torch.zeros(N, V, 3, device=g.device, dtype=torch.float32)
+			check(L.find_sample_points_bwd(ptr(faces), fb, ptr(face_idx), ptr(uv), ptr(_c(g)), N, V, F, S, ptr(d), current_stream(g.device)),
+				  'find_sample_points_bwd')
+			return d
+
+		d_verts = scatter(g_out) if ctx.needs_input_grad[0] else None
+		d_attr = scatter(g_attr) if (ctx.has_attr and ctx.needs_input_grad[3]) else None
+		return d_verts, None, None, d_attr
+
+
+def sample_surface(verts, faces, rnd, attr=None):
+	"""All of sample_points_from_meshes on the device given the uniform draws rnd (N,S,3) = [face draw, u, v]: faces ~ multinomial(area).
+	Returns (points (N,S,3), attr samples or None, face_idx (N,S) int32, uv (N,S,2))."""
+	r = _SampleSurface.apply(verts, faces, rnd, attr)
+	if attr is None:
+		return r[0], None, r[1], r[2]
+	return r
+
+
 # ----------------------------------------------------------------------------------------------- Chamfer / KNN
 class _NN(torch.autograd.Function):
 	"""dist[n,i] = min_j |x_i - y_j|^2 (K=1 knn_points); gradient flows to both x and the selected y."""
@@ -391,21 +475,78 @@ def knn1(x, y, x_len=None, y_len=None):
 	return _NN.apply(x, y, x_len, y_len)
 
 
+class _Chamfer(torch.autograd.Function):
+	"""pytorch3d.loss.chamfer_distance (defaults) as one scalar: both nearest-neighbour directions in one launch + a deterministic
+	reduction (find_chamfer_fwd); the backward is one kernel over both directions (find_chamfer_bwd)."""
+
+	@staticmethod
+	def forward(ctx, x, y, x_len, y_len):
+		_require_gpu(x, y)
+		L = _lib.lib()
+		x, y = _c(x), _c(y)
+		N, P1, _ = x.shape
+		P2 = y.shape[1]
+		if y.shape[0] != N:
+			raise RuntimeError('find_amd.chamfer_distance: batch mismatch')
+		dev = x.device
+		xl = None if x_len is None else x_len.to(device=dev, dtype=torch.int32).contiguous()
+		yl = None if y_len is None else y_len.to(device=dev, dtype=torch.int32).contiguous()
+		ws = _ws(L.find_chamfer_ws_bytes(N, P1, P2), dev)
+		loss = torch.empty((), device=dev, dtype=torch.float32)
+		check(L.find_chamfer_fwd(ptr(x), ptr(xl), ptr(y), ptr(yl), N, P1, P2, ptr(loss), ptr(ws), ws.numel(), current_stream(dev)), 'find_chamfer_fwd')
+		ctx.save_for_backward(x, y, ws)
+		ctx.lens = (xl, yl)
+		return loss
+
+	@staticmethod
+	def backward(ctx, g):
+		L = _lib.lib()
+		x, y, ws = ctx.saved_tensors
+		xl, yl = ctx.lens
+		N, P1, _ = x.shape
+		P2 = y.shape[1]
+		need_x, need_y = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+		if not (need_x or need_y):
+			return None, None, None, None
+		buf = torch.zeros((N * P1 * 3 if need_x else 0) + (N * P2 * 3 if need_y else 0), device=x.device, dtype=torch.float32)
+		d_x = buf[:N * P1 * 3].view(N, P1, 3) if need_x else None
+		d_y = buf[buf.numel() - N * P2 * 3:].view(N, P2, 3) if need_y else None
+		check(L.find_chamfer_bwd(ptr(x), ptr(xl), ptr(y), ptr(yl), N, P1, P2, ptr(_c(g)), ptr(ws), ws.numel(), ptr(d_x), ptr(d_y), current_stream(x.device)),
+			  'find_chamfer_bwd')
+		return d_x, d_y, None, None
+
+
 def chamfer_distance(x, y, x_lengths=None, y_lengths=None):
 	"""pytorch3d.loss.chamfer_distance with its defaults (bidirectional, squared L2, point mean, batch mean).
 	Returns (loss, None) like PyTorch3D (the second value is the normals term, never used by FIND: losses.py:77,85,88)."""
-	N = x.shape[0]
-	dx, _ = knn1(x, y, x_lengths, y_lengths)
-	dy, _ = knn1(y, x, y_lengths, x_lengths)
-	if x_lengths is None:
-		cx = dx.sum(1) / float(x.shape[1])
-	else:
-		cx = dx.sum(1) / x_lengths.to(dx.device).clamp(min=1).to(dx.dtype)
-	if y_lengths is None:
-		cy = dy.sum(1) / float(y.shape[1])
-	else:
-		cy = dy.sum(1) / y_lengths.to(dy.device).clamp(min=1).to(dy.dtype)
-	return (cx.sum() + cy.sum()) / max(N, 1), None
+	return _Chamfer.apply(x, y, x_lengths, y_lengths), None
+
+
+class _MaskedMSE(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, pred, target):
+		_require_gpu(pred, target)
+		L = _lib.lib()
+		pred, target = _c(pred), _c(target.detach())
+		if pred.shape != target.shape or pred.shape[-1] != 3:
+			raise RuntimeError(f'find_amd.masked_mse: pred {tuple(pred.shape)} and target {tuple(target.shape)} must both be (..., 3)')
+		loss = torch.empty((), device=pred.device, dtype=torch.float32)
+		check(L.find_masked_mse_fwd(ptr(pred), ptr(target), pred.numel() // 3, ptr(loss), current_stream(pred.device)), 'find_masked_mse_fwd')
+		ctx.save_for_backward(pred, target)
+		return loss
+
+	@staticmethod
+	def backward(ctx, g):
+		L = _lib.lib()
+		pred, target = ctx.saved_tensors
+		d = torch.empty_like(pred)
+		check(L.find_masked_mse_bwd(ptr(pred), ptr(target), pred.numel() // 3, ptr(_c(g)), ptr(d), current_stream(pred.device)), 'find_masked_mse_bwd')
+		return d, None
+
+
+def masked_mse(pred, target):
+	"""mean over all elements of any(target < 1, -1) * (pred - target)^2: the texture loss's masked L2 (reference losses.py:43-57)."""
+	return _MaskedMSE.apply(pred, target)
 
 
 # ----------------------------------------------------------------------------------------------- smoothness
@@ -502,6 +643,42 @@ class _Smooth(torch.autograd.Function):
 def mesh_edge_and_laplacian(verts, topo):
 	"""(mesh_edge_loss(target 0), mesh_laplacian_smoothing('cot')) for a batch sharing one topology."""
 	return _Smooth.apply(verts, topo)
+
+
+class _SmoothLoss(torch.autograd.Function):
+	@staticmethod
+	def forward(ctx, verts, topo, w_edge, w_lap):
+		_require_gpu(verts)
+		L = _lib.lib()
+		verts = _c(verts)
+		N, V, _ = verts.shape
+		if V != topo.n_verts:
+			raise RuntimeError(f'find_amd.smooth: verts have {V} vertices, topology {topo.n_verts}')
+		ws = _ws(L.find_smooth_ws_bytes(N, V, topo.n_faces), verts.device)
+		out = torch.empty((), device=verts.device, dtype=torch.float32)
+		check(L.find_smooth_loss_fwd(ptr(verts), ptr(topo.faces), ptr(topo.vf_off), ptr(topo.vf_items), ptr(topo.nbr_off), ptr(topo.nbr_idx),
+									 N, V, topo.n_faces, topo.n_edges, w_edge, w_lap, ptr(out), ptr(ws), ws.numel(), current_stream(verts.device)),
+			  'find_smooth_loss_fwd')
+		ctx.topo, ctx.ws, ctx.w = topo, ws, (w_edge, w_lap)
+		ctx.save_for_backward(verts)
+		return out
+
+	@staticmethod
+	def backward(ctx, g):
+		L = _lib.lib()
+		(verts,) = ctx.saved_tensors
+		topo = ctx.topo
+		N, V, _ = verts.shape
+		d = torch.empty_like(verts)
+		check(L.find_smooth_loss_bwd(ptr(verts), ptr(topo.faces), ptr(topo.vf_off), ptr(topo.vf_items), ptr(topo.nbr_off), ptr(topo.nbr_idx),
+									 N, V, topo.n_faces, topo.n_edges, ctx.w[0], ctx.w[1], ptr(_c(g)), ptr(ctx.ws), ctx.ws.numel(), ptr(d),
+									 current_stream(verts.device)), 'find_smooth_loss_bwd')
+		return d, None, None, None
+
+
+def mesh_smoothness_loss(verts, topo, w_edge=10.0, w_lap=0.1):
+	"""w_edge * mesh_edge_loss + w_lap * mesh_laplacian_smoothing('cot') as one scalar (MeshSmoothnessLoss, reference losses.py:93-99)."""
+	return _SmoothLoss.apply(verts, topo, float(w_edge), float(w_lap))
 
 
 _MLP_PRECISION = 'fp32'

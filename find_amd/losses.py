@@ -5,7 +5,6 @@ In scope: TextureLossGTSpace, DisplacementLoss (Chamfer, incl
 MeshSmoothnessLoss, SilhouetteLoss.  Perceptual / Restyle / Contrastive losses need absent network weights or
 submodules and are out of scope."""
 import torch
-from torch.nn import functional as F
 
 from . import functional as FN
 from . import functional_render as FR
@@ -16,32 +15,34 @@ nn = torch.nn
 
 def sample_points_from_meshes(meshes: Meshes, num_samples: int = 10000, return_textures: bool = False, generator=None, draws=None):
 	"""pytorch3d.ops.sample_points_from_meshes: faces ~ multinomial(area) with replacement, (w0,w1,w2) = (1-sqrt(u),
-	sqrt(u)(1-v), sqrt(u)v).  The random draws use torch's generator on the mesh device (or are passed in
-	as draws=(face_idx (N,S) int, uv (N,S,2)) for reproducible CPU/GPU comparisons); the gather/lerp is the HIP kernel."""
+	sqrt(u)(1-v), sqrt(u)v).  The uniform draws come from torch's generator on the mesh device; the areas, the face
+	choice and the gather / lerp run in find_sample_surface_fwd.  draws=(face_idx (N,S) int, uv (N,S,2)) replays given draws for
+	reproducible CPU/GPU comparisons (find_sample_points_fwd)."""
 	verts = meshes.verts_padded()
 	faces = meshes.faces_shared()
 	if faces is None:
 		faces = meshes.faces_padded()
 	N = verts.shape[0]
+	tex = meshes.textures if return_textures else None
+	if return_textures and not isinstance(tex, (TexturesUV, TexturesVertex)):
+		raise NotImplementedError('return_textures needs TexturesVertex or TexturesUV')
+	attr = tex.verts_features_padded()[..., :3].contiguous() if isinstance(tex, TexturesVertex) else None
 	if draws is None:
-		with torch.no_grad():
-			areas = FN.face_areas(verts, faces)
-			face_idx = torch.multinomial(areas, num_samples, replacement=True, generator=generator)
-			uv = torch.rand(N, num_samples, 2, device=verts.device, generator=generator)
+		# one launch for the draws (torch's device generator, where PyTorch3D draws), two for areas -> running sum -> search -> gather
+		rnd = torch.rand(N, num_samples, 3, device=verts.device, generator=generator)
+		pts, cols, face_idx, uv = FN.sample_surface(verts, faces, rnd, attr)
 	else:
 		face_idx, uv = draws
-	if return_textures:
-		tex = meshes.textures
-		if isinstance(tex, TexturesUV):
-			# PyTorch3D: barycentrics of the sample (w0 = 1 - sqrt(u), w1 = sqrt(u)(1 - v), w2 = sqrt(u) v), then TexturesUV.sample_textures
-			pts = FN.sample_points(verts, faces, face_idx, uv)
-			su = uv[..., 0].sqrt()
-			bary = torch.stack([1.0 - su, su * (1.0 - uv[..., 1]), su * uv[..., 1]], dim=-1)
-			return pts, FR.uv_sample(tex.maps_padded(), tex.verts_uvs_padded(), tex.faces_uvs_padded(), face_idx, bary)
-		if not isinstance(tex, TexturesVertex):
-			raise NotImplementedError('return_textures needs TexturesVertex or TexturesUV')
-		return FN.sample_points(verts, faces, face_idx, uv, tex.verts_features_padded()[..., :3].contiguous())
-	return FN.sample_points(verts, faces, face_idx, uv)
+		r = FN.sample_points(verts, faces, face_idx, uv, attr)
+		pts, cols = r if attr is not None else (r, None)
+	if not return_textures:
+		return pts
+	if isinstance(tex, TexturesUV):
+		# PyTorch3D: barycentrics of the sample (w0 = 1 - sqrt(u), w1 = sqrt(u)(1 - v), w2 = sqrt(u) v), then TexturesUV.sample_textures
+		su = uv[..., 0].sqrt()
+		bary = torch.stack([1.0 - su, su * (1.0 - uv[..., 1]), su * uv[..., 1]], dim=-1)
+		return pts, FR.uv_sample(tex.maps_padded(), tex.verts_uvs_padded(), tex.faces_uvs_padded(), face_idx, bary)
+	return pts, cols
 
 
 def _compact_by_mask(points, keep):
@@ -60,13 +61,12 @@ class TextureLossGTSpace(nn.Module):
 		"""Sample points + colours on the GT meshes, query the colour field there, masked L2 (reference losses.py:22-57)."""
 		mesh_gt = batch['mesh']
 		sampled_verts, sampled_gt_colours = sample_points_from_meshes(mesh_gt, num_samples=num_samples, return_textures=True)
-		mask = (sampled_gt_colours < 1).any(dim=-1).unsqueeze(-1).expand(-1, -1, 3)
 		texvec = texvec if texvec is not None else batch.get('texvec', None)
 		shapevec = shapevec if shapevec is not None else batch.get('shapevec', None)
 		posevec = posevec if posevec is not None else batch.get('posevec', None)
 		res = model(sampled_verts.detach(), texvec=texvec, shapevec=shapevec, posevec=posevec)
-		loss = F.mse_loss(res['col'], sampled_gt_colours, reduction='none')
-		return (loss * mask).mean()
+		# F.mse_loss(reduction='none') * mask, .mean() with mask = any(gt < 1) per point (losses.py:43,55-57), as one kernel
+		return FN.masked_mse(res['col'], sampled_gt_colours)
 
 
 class DisplacementLoss(nn.Module):
@@ -94,8 +94,7 @@ class MeshSmoothnessLoss(nn.Module):
 			raise NotImplementedError('MeshSmoothnessLoss expects meshes sharing one topology (the template), as on the FIND path')
 		verts = meshes.verts_padded()
 		topo = FN.MeshTopology.get(faces, verts.shape[1])
-		loss_edge, loss_laplacian = FN.mesh_edge_and_laplacian(verts, topo)
-		return 0.1 * loss_laplacian + 10 * loss_edge
+		return FN.mesh_smoothness_loss(verts, topo, w_edge=10.0, w_lap=0.1)
 
 
 class SilhouetteLoss(nn.Module):

@@ -208,6 +208,16 @@ int find_sample_points_bwd(const int32_t* faces, int64_t faces_batch, const int3
 /* Face areas 0.5*|(v1-v0)x(v2-v0)| (n_meshes, n_faces): the multinomial weights of the sampler. */
 int find_face_areas(const float* verts, const int32_t* faces, int64_t faces_batch, int64_t n_meshes, int64_t n_verts,
 					int64_t n_faces, float* areas, void* stream);
+/* The whole of sample_points_from_meshes with the face choice on the device (same call sites): faces ~ multinomial(area) with
+ * replacement -- a block per mesh builds the running sum of the face areas (ws: find_sample_surface_ws_bytes), a thread per sample
+ * searches it with its uniform draw -- then the gather above.  rnd (n_meshes, n_samples, 3) uniform in [0,1): [face draw, u, v];
+ * only the DRAWS are inputs (torch's device generator, exactly where PyTorch3D would draw).  Outputs: face_idx (n_meshes, n_samples)
+ * int32 and uv (n_meshes, n_samples, 2) -- what find_sample_points_bwd / find_uv_sample need --, out and optionally attr_out as
+ * above.  Faces of zero area (and the -1 padding of ragged batches) are never chosen; a mesh of total area 0 yields face 0. */
+int64_t find_sample_surface_ws_bytes(int64_t n_meshes, int64_t n_faces);
+int find_sample_surface_fwd(const float* verts, const int32_t* faces, int64_t faces_batch, const float* rnd, int64_t n_meshes,
+							int64_t n_verts, int64_t n_faces, int64_t n_samples, int32_t* face_idx, float* uv, float* out,
+							const float* attr, float* attr_out, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Chamfer nearest neighbour (K=1, squared L2, brute force).
@@ -224,6 +234,25 @@ int find_nn_fwd(const float* x, const int32_t* x_len, const float* y, const int3
  * direction's contribution); either may be NULL. */
 int find_nn_bwd(const float* x, const int32_t* x_len, const float* y, const int32_t* idx, const float* w, int64_t n,
 				int64_t p1_max, int64_t p2_max, float* d_x, float* d_y, void* stream);
+/* pytorch3d.loss.chamfer_distance with its defaults as ONE loss (the reference never uses anything else: losses.py:77,85,88;
+ * eval_3d.py:151,159): both nearest-neighbour directions in one launch, then
+ *   loss = ( sum_n sum_i min_j|x_i-y_j|^2 / max(x_len[n],1)  +  sum_n sum_j min_i|x_i-y_j|^2 / max(y_len[n],1) ) / n
+ * as a 1-element device scalar (deterministic reduction).  ws (find_chamfer_ws_bytes) keeps the neighbours for the backward and must
+ * be passed to it untouched.  find_chamfer_bwd: g_loss = device scalar, the upstream gradient; d_x (n,p1_max,3) / d_y (n,p2_max,3)
+ * must be zero-initialised, either may be NULL; contributions are added with float atomics (as PyTorch3D's knn backward). */
+int64_t find_chamfer_ws_bytes(int64_t n, int64_t p1_max, int64_t p2_max);
+int find_chamfer_fwd(const float* x, const int32_t* x_len, const float* y, const int32_t* y_len, int64_t n, int64_t p1_max,
+					 int64_t p2_max, float* loss, void* ws, int64_t ws_bytes, void* stream);
+int find_chamfer_bwd(const float* x, const int32_t* x_len, const float* y, const int32_t* y_len, int64_t n, int64_t p1_max,
+					 int64_t p2_max, const float* g_loss, const void* ws, int64_t ws_bytes, float* d_x, float* d_y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Masked colour error of TextureLossGTSpace (src/model/losses.py:43-57): mask = any(target < 1) per point, loss = mean over all
+ * n_pts * 3 elements of mask * (pred - target)^2 -- F.mse_loss(reduction='none') * mask, .mean() -- as a 1-element device scalar.
+ * pred, target (n_pts, 3).  The backward overwrites d_pred (n_pts, 3) with g_loss * dloss/dpred (g_loss: device scalar).
+ * ---------------------------------------------------------------------------------------------- */
+int find_masked_mse_fwd(const float* pred, const float* target, int64_t n_pts, float* loss, void* stream);
+int find_masked_mse_bwd(const float* pred, const float* target, int64_t n_pts, const float* g_loss, float* d_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mesh smoothness: mesh_edge_loss(target 0) and mesh_laplacian_smoothing('cot').
@@ -244,6 +273,15 @@ int find_smooth_bwd(const float* verts, const int32_t* faces, const int32_t* vf_
 					const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
 					int64_t n_edges, const float* g_edge, const float* g_lap, void* ws, int64_t ws_bytes, float* d_verts,
 					void* stream);
+/* MeshSmoothnessLoss as one scalar (src/model/losses.py:93-99: 0.1 * laplacian + 10 * edge): loss = w_edge * loss_edge + w_lap * loss_lap
+ * written by the same three kernels; the backward takes the upstream gradient of that scalar (device pointer) and the two weights. */
+int find_smooth_loss_fwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
+						 const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
+						 int64_t n_edges, float w_edge, float w_lap, float* loss, void* ws, int64_t ws_bytes, void* stream);
+int find_smooth_loss_bwd(const float* verts, const int32_t* faces, const int32_t* vf_off, const int32_t* vf_items,
+						 const int32_t* nbr_off, const int32_t* nbr_idx, int64_t n_meshes, int64_t n_verts, int64_t n_faces,
+						 int64_t n_edges, float w_edge, float w_lap, const float* g_loss, void* ws, int64_t ws_bytes,
+						 float* d_verts, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Differentiable mesh render: world->view->NDC transform, rasterisation, fused shading.

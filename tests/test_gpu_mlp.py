@@ -418,3 +418,48 @@ def test_context_reports_the_device_and_keeps_its_knobs():
 	(res['verts'].sum() + res['col'].sum()).backward()
 	torch.cuda.synchronize()
 	assert 0 < _lib.get_tuning('events_per_call_max') < 128
+
+
+def test_two_passes_in_one_backward_fold_their_weight_gradients(golden_main):
+	"""FIND's step runs the MLP twice on the same weights (main pass + texture pass).  The second backward of one backward() call adds
+	its weight gradients to the first's with one multi-tensor launch and reports none of its own: the parameters' .grad must equal the
+	sum of the two passes differentiated separately, and a later, separate backward() must accumulate on top as usual."""
+	from find_amd import functional as FN
+	m = _model_from_golden(golden_main)
+	g = torch.Generator().manual_seed(3)
+	lat = {k: torch.randn(2, 100, generator=g).cuda() * 0.1 for k in ['shapevec', 'texvec', 'posevec']}
+	pos1 = (torch.rand(1, 700, 3, generator=g) * 0.2).cuda()
+	pos2 = (torch.rand(2, 300, 3, generator=g) * 0.2).cuda()
+	params = [p for p in m.parameters() if p.requires_grad and p.dim() <= 2 and p.shape[0] in (3, 256)]
+
+	def l1():
+		r = m(pos1, **lat)
+		return (r['disp'] ** 2).sum() + (r['col'] ** 2).sum()
+
+	def l2():
+		return (m(pos2, **lat)['col'] ** 2).sum() * 0.5
+
+	m.zero_grad(set_to_none=True)
+	l1().backward()
+	a = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+	m.zero_grad(set_to_none=True)
+	l2().backward()
+	b = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+	m.zero_grad(set_to_none=True)
+	FN._PENDING_WGRADS.clear()
+	(l1() + l2()).backward()
+	folded = 0
+	for n, p in m.named_parameters():
+		if n not in a:
+			continue
+		want = a[n] + b.get(n, 0)
+		assert (p.grad - want).abs().max().item() <= 2e-6 * max(1e-3, want.abs().max().item()), n
+		folded += 1
+	assert folded >= 26
+	# a later backward() is a different graph task: nothing folds into stale tensors, autograd accumulates into .grad
+	l2().backward()
+	for n, p in m.named_parameters():
+		if n in a and n in b:
+			want = a[n] + 2 * b[n]
+			assert (p.grad - want).abs().max().item() <= 4e-6 * max(1e-3, want.abs().max().item()), n
+	assert params

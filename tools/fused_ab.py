@@ -1,5 +1,6 @@
-"""A/B of the fused layer chains (find_ctx knob fused_max_units): MLP forward + backward at batch 1 (6890 template rows), on 1000 free
-points (the texture pass), and the C2 step (16 feet, shared trunk).  python tools/fused_ab.py"""
+"""A/B of the small-call machinery through find_ctx knobs -- fused layer chains (fused_max_units), their L2 warm-up (ablate bit 16), splits
+per foot of the grouped weight gradients (group_spf; 0 = cost model) -- on the MLP forward + backward at batch 1 (6890 template rows), on
+1000 free points x 1 and x 16 feet (the texture pass) and on the C2 step (16 feet, shared trunk).  python tools/fused_ab.py [knob ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -40,10 +41,16 @@ def mlp_case(n_feet, n_verts, free_pts):
 
 
 cases = [('batch 1 x 6890 template rows', mlp_case(1, 6890, False)), ('1 x 1000 free points', mlp_case(1, 1000, True)),
-		 ('C2: 16 feet x 6890 (shared trunk)', bench.build_step(dev, 0)[2])]
+		 ('16 x 1000 free points', mlp_case(16, 1000, True)), ('C2: 16 feet x 6890 (shared trunk)', bench.build_step(dev, 0)[2])]
+# (knob, A, B): A/B pairs measured twice, interleaved
+KNOBS = [('fused_max_units', 0, 512), ('ablate', 16, 0)] + [('group_spf', v, 0) for v in (1, 2, 4, 8)]
+if len(sys.argv) > 1:
+	KNOBS = [k for k in KNOBS if k[0] in sys.argv[1:]]
 for name, step in cases:
-	res = {}
-	for v in (0, 512, 0, 512):
-		_lib.set_tuning('fused_max_units', v)
-		res.setdefault(v, []).append(timeit(step, n=100 if 'C2' in name else 300))
-	print(f'{name}: unfused {min(res[0]):.3f} ms   fused {min(res[512]):.3f} ms', flush=True)
+	for knob, a, b in KNOBS:
+		res = {}
+		for v in (a, b, a, b):
+			_lib.set_tuning(knob, v)
+			res.setdefault(v, []).append(timeit(step, n=100 if 'C2' in name else 300))
+		_lib.set_tuning(knob, b)
+		print(f'{name}: {knob}={a}: {min(res[a]):.3f} ms   {knob}={b}: {min(res[b]):.3f} ms', flush=True)
