@@ -90,32 +90,22 @@ __global__ void sample_bwd_kernel(const int32_t* __restrict__ faces, int64_t fac
 
 // Sampler with the face choice on the device: pytorch3d.ops.sample_points_from_meshes draws faces ~ multinomial(area) with
 // replacement; torch.multinomial normalises the weights, builds their running sum and searches it with a uniform draw -- five
-// launches and a 13 776-element scan per mesh.  Here: one block per mesh computes the areas and their running sum (rounds of 4096
-// faces, four per thread, block scan of the 1024 four-face totals), then one thread per sample searches the running sum
+// launches and a 13 776-element scan per mesh.  Here: face_areas_kernel, one block per mesh turns the areas into their running sum
+// in place (rounds of 4096 faces, four per thread, block scan of the 1024 four-face totals), then one thread per sample searches it
 // with its own uniform draw r in [0,1): the first face whose running sum exceeds r * total.  Faces of zero area (the -1 padding of
 // ragged batches included) can never be that first face.
-__global__ __launch_bounds__(1024) void area_cdf_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
-														 int n_verts, int n_faces, float* __restrict__ cdf) {
+__global__ __launch_bounds__(1024) void area_scan_kernel(int n_faces, float* __restrict__ cdf /* in: areas, out: their running sum */) {
 	__shared__ float wsum[16];
-	const int m = blockIdx.x;
-	const int32_t* fp = faces + (int64_t)m * faces_mesh_stride;
-	const float* vp = verts + (int64_t)m * n_verts * 3;
-	float* out = cdf + (int64_t)m * n_faces;
+	float* out = cdf + (int64_t)blockIdx.x * n_faces;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	float carry = 0.f;   // running sum of the faces before this round (the same value in every thread)
-	// rounds of 4096 faces: a thread takes 4 consecutive faces (coalesced index loads, one 16-byte store), the block scans the 1024
-	// four-face totals -- shuffles inside the wave, LDS across the 16 waves: a fixed order, so the result is deterministic
+	// rounds of 4096 faces: a thread takes 4 consecutive areas, the block scans the 1024 four-face totals -- shuffles inside the wave,
+	// LDS across the 16 waves: a fixed order, so the result is deterministic
 	for (int f0 = 0; f0 < n_faces; f0 += 4096) {
 		const int f = f0 + 4 * (int)threadIdx.x;
 		float a[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			a[k] = 0.f;
-			if (f + k < n_faces && fp[3 * (f + k)] >= 0) {
-				const float3 p = ld3(vp + 3 * fp[3 * (f + k)]), q = ld3(vp + 3 * fp[3 * (f + k) + 1]), r = ld3(vp + 3 * fp[3 * (f + k) + 2]);
-				a[k] = 0.5f * norm3(cross3(sub3(q, p), sub3(r, p)));
-			}
-		}
+		for (int k = 0; k < 4; ++k) a[k] = f + k < n_faces ? out[f + k] : 0.f;
 		a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
 		float inc = a[3];
 #pragma unroll
@@ -775,7 +765,9 @@ extern "C" int find_sample_surface_fwd(const float* verts, const int32_t* faces,
 	if (ws_bytes < find_sample_surface_ws_bytes(n_meshes, n_faces)) { set_error("find_sample_surface_fwd: workspace too small"); return FIND_EWORKSPACE; }
 	hipStream_t s = (hipStream_t)stream;
 	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
-	hipLaunchKernelGGL(area_cdf_kernel, dim3((unsigned)n_meshes), dim3(1024), 0, s, verts, faces, fstride, (int)n_verts, (int)n_faces, (float*)ws);
+	hipLaunchKernelGGL(face_areas_kernel, dim3((unsigned)cdiv(n_faces, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, (int)n_verts, (int)n_faces,
+					   (float*)ws);
+	hipLaunchKernelGGL(area_scan_kernel, dim3((unsigned)n_meshes), dim3(1024), 0, s, (int)n_faces, (float*)ws);
 	hipLaunchKernelGGL(sample_surface_kernel, dim3((unsigned)cdiv(n_samples, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, (const float*)ws, rnd,
 					   (int)n_verts, (int)n_faces, (int)n_samples, face_idx, uv, out, attr, attr_out);
 	FIND_LAUNCH_CHECK("sample_surface");

@@ -8,6 +8,10 @@
 // output is written to HBM once (the backward needs it) and handed to the next layer through LDS.  The chain is a list of steps
 // in the kernel arguments, so the same kernel runs the forward (Fourier features -> trunk -> heads -> 3-wide outputs) and the dX
 // chain of the backward (masked transposed products, two-operand sums).
+// (Measured and dropped: an up-front L2 warm-up of the chain's weights -- every workgroup of an XCD requesting its share of the 128-byte
+// lines once through LDS-DMA into a sink -- on the theory that the per-tile time, 12 us per layer whatever the tile count, was a chain of
+// cold L2 misses; it changed nothing (0.642 against 0.634 ms for a batch-1 forward + backward): the tile time is the matrix pipe's 6.8 us
+// per layer for a 32 x 256 x 256 tile on one CU plus the staging around it, not the weights' latency.)
 //
 // MFMA: v_mfma_f32_32x32x2_f32, exact fp32.  Eight waves (two per SIMD); a wave owns 32 output columns (one 32 x 32 accumulator) of
 // the tile's 32 rows and stages ITS OWN 32 weight rows through a private two-stage LDS ring: no workgroup barrier inside a layer, the
@@ -57,7 +61,7 @@ struct FusedArgs {
 	int V;                    // rows per foot
 	int tiles_per_foot;
 	int ntiles;
-	int ablate;               // profiling only: 1 no W staging (loads + LDS stores), 2 no MFMAs, 4 no epilogue, 8 no Fourier features, 16 no L2 warm-up
+	int ablate;               // profiling only: 1 no W staging (loads + LDS stores), 2 no MFMAs, 4 no epilogue, 8 no Fourier features
 };
 
 constexpr int FX_LD = 260;                       // X row stride (floats)
@@ -65,9 +69,7 @@ constexpr int FW_LD = 36;                        // W chunk row stride (floats)
 constexpr int FUSED_NW = 8;                      // waves per workgroup
 constexpr int FUSED_X_BYTES = 32 * FX_LD * 4;    // 33 280
 constexpr int FUSED_WS_BYTES = 32 * FW_LD * 4;   // one wave's chunk: 32 rows x 32 k, padded (4 608)
-constexpr int FUSED_B_BYTES = 3 * 256 * 4;       // Fourier matrix
-constexpr int FUSED_SINK = FUSED_X_BYTES + FUSED_NW * 2 * FUSED_WS_BYTES + FUSED_B_BYTES;   // 256 B per wave: where the L2 warm-up's LDS-DMA lands
-constexpr int FUSED_LDS = FUSED_SINK + FUSED_NW * 256;
+constexpr int FUSED_LDS = FUSED_X_BYTES + FUSED_NW * 2 * FUSED_WS_BYTES + 3 * 256 * 4;   // + Fourier matrix
 
 // A wave's W staging: lane -> row = lane / 8 (+ 8 q), 16-byte part = lane % 8: 8 lanes read one 128-B row piece.  The chunk stream of a
 // tile -- every 32-k chunk of every GEMM step, in order -- runs two chunks ahead of the MFMAs: chunk k+2 is requested into one of two
@@ -86,20 +88,6 @@ constexpr int FUSED_LDS = FUSED_SINK + FUSED_NW * 256;
 		*reinterpret_cast<float4*>(_d + 16 * FW_LD) = set##2; *reinterpret_cast<float4*>(_d + 24 * FW_LD) = set##3; \
 	} while (0)
 
-// One dword per lane from base + off (bytes) into the wave's LDS sink: an L2 fill with no register and no wait attached.
-__device__ __forceinline__ void l2_touch(const float* base, unsigned off, unsigned sink) {
-	unsigned keep;
-	asm volatile(
-		"s_mov_b32 %0, m0\n\t"
-		"s_mov_b32 m0, %3\n\t"
-		"s_nop 0\n\t"
-		"global_load_lds_dword %1, %2\n\t"
-		"s_mov_b32 m0, %0"
-		: "=&s"(keep)
-		: "v"(off), "s"(base), "s"(sink)
-		: "memory", "scc");
-}
-
 __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* const X = reinterpret_cast<float*>(smem);
@@ -117,25 +105,6 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 	}
 	int first_gemm = 0;
 	while (first_gemm < g.n_steps && g.step[first_gemm].kind != FS_GEMM) ++first_gemm;
-
-	// L2 warm-up.  Every workgroup streams the same weights, 256 KB per layer, and an XCD's L2 holds none of them when the kernel starts
-	// (the optimiser rewrote them; the backward reads transposed copies made a moment ago on other XCDs): each layer's first pass over its
-	// chunks was a chain of HBM-latency misses that the two-chunk prefetch cannot cover, and because all workgroups of an XCD walk the
-	// chain together they all waited on the same misses -- 12 us per layer against 3.4 us of matrix pipe.  So the workgroups of an XCD
-	// (block ids congruent mod 8) split the chain's weights between them and request every 128-byte line once, up front, through
-	// LDS-DMA into a sink: no registers, nothing waits for it, and the chunk loads that follow find their lines in L2 or on their way.
-	if (!(g.ablate & 16)) {
-		const int share = max(1, min(8, (int)gridDim.x >> 3));
-		const int part = ((int)blockIdx.x >> 3) % share;
-		const unsigned sink = (unsigned)FUSED_SINK + (unsigned)wave * 256u;
-		const int row = tid & 255, half = tid >> 8;
-		for (int si = first_gemm; si < g.n_steps; ++si) {
-			if (g.step[si].kind != FS_GEMM) continue;
-			const float* wbase = g.step[si].w;
-			const int ldw = g.step[si].ldw, nch = g.step[si].nchunk;
-			for (int c = part + share * half; c < nch; c += 2 * share) l2_touch(wbase, (unsigned)(row * ldw + c * 32) * 4u, sink);
-		}
-	}
 
 	for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
 		const int foot = tile / g.tiles_per_foot;

@@ -123,6 +123,7 @@ class _MLP(torch.autograd.Function):
 
 	@staticmethod
 	def forward(ctx, spec, pos, lat_disp, lat_col, B, avg_col, *weights):
+		spec, heads = spec if isinstance(spec, tuple) else (spec, 3)   # heads: bit 0 = displacement, bit 1 = colour
 		if len(weights) != spec.n_weights:
 			raise RuntimeError(f'find_amd.mlp: expected {spec.n_weights} weight tensors, got {len(weights)}')
 		_require_gpu(pos, lat_disp, lat_col, B, avg_col, *weights)
@@ -157,8 +158,8 @@ class _MLP(torch.autograd.Function):
 		if nbytes < 0:
 			check(-1, 'find_mlp_ws_bytes')
 		ws = _ws(nbytes, pos.device)
-		disp = torch.empty(n_feet, V, 3, device=pos.device, dtype=torch.float32)
-		col = torch.empty(n_feet, V, 3, device=pos.device, dtype=torch.float32)
+		disp = torch.empty(n_feet, V, 3, device=pos.device, dtype=torch.float32) if heads & 1 else None
+		col = torch.empty(n_feet, V, 3, device=pos.device, dtype=torch.float32) if heads & 2 else None
 		check(L.find_mlp_fwd(_lib.ctx(pos.device), ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(disp), ptr(col),
 							 ptr(ws), ws.numel(), int(save), current_stream(pos.device)), 'find_mlp_fwd')
 		if save:
@@ -186,7 +187,9 @@ class _MLP(torch.autograd.Function):
 		task = _graph_task_id()
 		key = tuple(w.data_ptr() for w in weights)
 		pending = _PENDING_WGRADS.get(key)
-		fold = pending is not None and task >= 0 and pending[0] == task and all(ctx.needs_input_grad[6:])
+		# (same stream only: the sum must be ordered with whatever reads the parked gradients next)
+		fold = (pending is not None and task >= 0 and pending[0] == task and all(ctx.needs_input_grad[6:])
+				and pending[2] == torch.cuda.current_stream(pos.device))
 		g_lat_disp = torch.empty_like(lat_disp) if lat_disp is not None else None
 		g_lat_col = torch.empty_like(lat_col) if lat_col is not None else None
 		G = MlpGrads()
@@ -213,11 +216,12 @@ class _MLP(torch.autograd.Function):
 		_PENDING_WGRADS.clear()
 		if task >= 0 and all(ctx.needs_input_grad[6:]) and all(g._base is not None and g._base.dim() == 1 for g in grads):
 			# (where the gradients live, not the tensors themselves: autograd adopts a gradient as .grad only while nothing else holds it)
-			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) for g in grads])
+			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) for g in grads], torch.cuda.current_stream(pos.device))
 		return (None, None, g_lat_disp, g_lat_col, None, None, *grads)
 
 
-_PENDING_WGRADS = {}   # weight data_ptrs -> (autograd graph-task id, [(flat buffer, offset)] of the gradients the first backward of that task handed to the engine)
+_PENDING_WGRADS = {}   # weight data_ptrs -> (autograd graph-task id, [(flat buffer, offset)] of the gradients the first backward of that task handed to
+                        # the engine, the stream they were produced on)
 
 
 def _graph_task_id():
@@ -225,11 +229,15 @@ def _graph_task_id():
 	return int(f()) if f is not None else -1
 
 
-def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights):
+def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights, want=('disp', 'col')):
 	"""Fused Fourier-PE + trunk + heads.  pos (1|N, V, 3); lat_disp (N, Ld)|None; lat_col (N, Lc)|None;
 	weights: flat list [trunk w,b ..., disp w,b ..., col w,b ...] in reference state_dict order.
-	Returns disp (N,V,3), col (N,V,3)   (reference: NeuralDisplacementField.forward, model.py:393-453)."""
-	return _MLP.apply(spec, pos, lat_disp, lat_col, B, avg_col, *weights)
+	Returns disp (N,V,3), col (N,V,3)   (reference: NeuralDisplacementField.forward, model.py:393-453); a head that `want` does not
+	name is not evaluated and comes back as None (its parameters then get exact zero gradients from this call)."""
+	heads = (1 if 'disp' in want else 0) | (2 if 'col' in want else 0)
+	if heads == 0:
+		raise ValueError("find_amd.mlp: want must name 'disp', 'col' or both")
+	return _MLP.apply((spec, heads), pos, lat_disp, lat_col, B, avg_col, *weights)
 
 
 # ----------------------------------------------------------------------------------------------- registration

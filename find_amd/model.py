@@ -362,9 +362,10 @@ class NeuralDisplacementField(Model):
 		return vecs[0] if len(vecs) == 1 else torch.cat(vecs, dim=-1)
 
 	# ------------------------------------------------------------------ reference API
-	def forward(self, pos, shapevec=None, texvec=None, posevec=None):
+	def forward(self, pos, shapevec=None, texvec=None, posevec=None, want=('disp', 'col')):
 		"""pos [B|1, V, 3]; shapevec/texvec/posevec [B, L] -> dict(disp [B,V,3], col [B,V,3])   (model.py:393-453).
-		A batch-1 `pos` with batched latents is evaluated once through the trunk and shared by every foot."""
+		A batch-1 `pos` with batched latents is evaluated once through the trunk and shared by every foot.
+		`want` (not in the reference, which always evaluates both heads): the heads to evaluate -- the texture loss reads 'col' only."""
 		if self.onnx_mode:
 			raise NotImplementedError('onnx_mode (web export) is out of scope')
 		if pos.dim() != 3 or pos.shape[-1] != self.input_dim:
@@ -379,8 +380,8 @@ class NeuralDisplacementField(Model):
 		enc = self.encoder[0] if len(self.encoder) else None
 		B = enc.B(pos.device) if enc is not None else None
 		avg = self.avg_col if self.use_avg_colour else None
-		disp, col = FN.mlp(self._spec, pos, lat_disp, lat_col, B, avg, self._weights())
-		return {'disp': disp, 'col': col}
+		disp, col = FN.mlp(self._spec, pos, lat_disp, lat_col, B, avg, self._weights(), want=want)
+		return {k: v for k, v in (('disp', disp), ('col', col)) if v is not None}
 
 	def get_meshes(self, shapevec=None, reg=None, texvec=None, posevec=None, no_displacement=False, include_texture=True):
 		"""Evaluate the field at every template vertex, apply the learned similarity registration and return

@@ -463,3 +463,36 @@ def test_two_passes_in_one_backward_fold_their_weight_gradients(golden_main):
 			want = a[n] + 2 * b[n]
 			assert (p.grad - want).abs().max().item() <= 4e-6 * max(1e-3, want.abs().max().item()), n
 	assert params
+
+
+@pytest.mark.parametrize('shape', [(2, 300), (16, 1000), (1, 6890)])
+def test_colour_head_alone_equals_the_full_forward(golden_main, shape):
+	"""model(..., want=('col',)) -- what the texture loss asks for -- skips the displacement head in the forward: same colours, same
+	gradients as the full forward differentiated through its colour output only, exact zeros for the displacement head's parameters."""
+	m = _model_from_golden(golden_main)
+	n, v = shape
+	g = torch.Generator().manual_seed(n * 1000 + v)
+	lat = {k: (torch.randn(n, 100, generator=g) * 0.1).cuda() for k in ['shapevec', 'texvec', 'posevec']}
+	pos = (torch.rand(n, v, 3, generator=g) * 0.2).cuda()
+	wgt = torch.randn(n, v, 3, generator=g).cuda()
+	out = {}
+	for want in (('disp', 'col'), ('col',)):
+		m.zero_grad(set_to_none=True)
+		lv = {k: t.clone().requires_grad_(True) for k, t in lat.items()}
+		res = m(pos, **lv, want=want)
+		assert set(res) == set(want)
+		(res['col'] * wgt).sum().backward()
+		out[want] = (res['col'].detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, {k: t.grad for k, t in lv.items()})
+	(c0, g0, l0), (c1, g1, l1) = out[('disp', 'col')], out[('col',)]
+	assert torch.equal(c0, c1)
+	assert set(g0) == set(g1)
+	for k in g0:
+		assert (g0[k] - g1[k]).abs().max().item() <= 1e-6 * max(1e-3, g0[k].abs().max().item()), k
+		if k.startswith('mlp_disp'):
+			assert float(g1[k].abs().max()) == 0.0
+	for k in l0:
+		assert (l0[k] is None) == (l1[k] is None)
+		if l0[k] is not None:
+			assert (l0[k] - l1[k]).abs().max().item() <= 1e-6 * max(1e-3, l0[k].abs().max().item()), k
+	with pytest.raises(ValueError):
+		m(pos, **lat, want=())

@@ -41,32 +41,34 @@ def _setup(n_feet=3, n_verts=1002, gt_verts=1002, seed=0):
 
 
 class DrawRecorder:
-	"""Wraps find_amd.losses.sample_points_from_meshes: draws on the GPU exactly as the product does, but keeps them."""
+	"""Wraps find_amd.functional.sample_surface -- the sampler the product runs (uniform draws from torch's device generator, faces chosen
+	on the device) -- and keeps what it drew: (face_idx, uv) per call, in call order."""
 
 	def __init__(self):
-		import find_amd.losses as L
-		self.L = L
-		self.orig = L.sample_points_from_meshes
+		from find_amd import functional as FN
+		self.FN = FN
+		self.orig = FN.sample_surface
 		self.draws = []
 
 	def __enter__(self):
-		from find_amd import functional as FN
+		def wrapped(verts, faces, rnd, attr=None):
+			out = self.orig(verts, faces, rnd, attr)
+			self.draws.append((out[2].long().cpu(), out[3].cpu()))
+			return out
 
-		def wrapped(meshes, num_samples=10000, return_textures=False, generator=None, draws=None):
-			verts = meshes.verts_padded()
-			faces = meshes.faces_shared() if meshes.faces_shared() is not None else meshes.faces_padded()
-			with torch.no_grad():
-				areas = FN.face_areas(verts, faces)
-				fi = torch.multinomial(areas, num_samples, replacement=True)
-				uv = torch.rand(verts.shape[0], num_samples, 2, device=verts.device)
-			self.draws.append((fi.cpu(), uv.cpu()))
-			return self.orig(meshes, num_samples, return_textures, draws=(fi, uv))
-
-		self.L.sample_points_from_meshes = wrapped
+		self.FN.sample_surface = wrapped
 		return self
 
 	def __exit__(self, *a):
-		self.L.sample_points_from_meshes = self.orig
+		self.FN.sample_surface = self.orig
+
+	def chamfer_and_texture(self):
+		"""(GT draws of the Chamfer term, prediction draws of the Chamfer term, GT draws of the texture term), whatever order the terms
+		were issued in: the texture term draws 1000 samples where the Chamfer term draws 5000 (losses.py:27,61)."""
+		tex = [d for d in self.draws if d[0].shape[1] == 1000]
+		cham = [d for d in self.draws if d[0].shape[1] != 1000]
+		assert len(tex) == 1 and len(cham) == 2, [tuple(d[0].shape) for d in self.draws]
+		return cham[0], cham[1], tex[0]
 
 
 def _oracle_model(mwl, batch):
@@ -83,8 +85,8 @@ def test_train_3d_loss_set_matches_oracle():
 		loss, losses = mwl(batch, 0, opts, chamf=True, smooth=True, texture=True)
 	assert set(losses) == {'loss_chamf', 'loss_smooth', 'loss_tex'}
 	loss.backward()
-	# ---- oracle with the recorded draws: order of sampler calls = GT (chamf), pred (chamf), GT+tex (texture)
-	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = rec.draws
+	# ---- oracle with the recorded draws
+	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = rec.chamfer_and_texture()
 	sd, lat, B, tv, tf = _oracle_model(mwl, batch)
 	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
 	gvc, gfc, gcc = gv.cpu(), gf.cpu(), gc.cpu()

@@ -97,7 +97,7 @@ def test_batch1_label_addressed_step_matches_oracle():
 		loss, losses = mwl(batch, 0, opts, **opts.net_train_kwargs())
 	assert set(losses) == {'loss_chamf', 'loss_smooth', 'loss_tex'}
 	loss.backward()
-	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = rec.draws
+	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = rec.chamfer_and_texture()
 	assert fi_gt.shape == (1, 5000) and fi_tx.shape == (1, 1000)   # losses.py:61 / :27
 	sd, lat, B, tv, tf = _oracle_inputs(mwl, ROWS)
 	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
@@ -172,8 +172,9 @@ def test_registration_stage_step_matches_oracle():
 
 
 class FixedDraws:
-	"""Replace the sampler's random draws by fixed ones (per call of a step) so that an eager and a graph-replayed step see the
-	same samples; the gather / lerp still runs in the HIP kernel."""
+	"""Replace the sampler's random draws by fixed ones so that an eager and a graph-replayed step see the same samples; the gather /
+	lerp still runs in the HIP kernel (draws= path of sample_points_from_meshes).  draws = (GT / Chamfer, prediction / Chamfer,
+	GT / texture); the texture term is the call with 1000 samples (losses.py:27), the Chamfer term calls GT then prediction (losses.py:63,67)."""
 
 	def __init__(self, draws):
 		import find_amd.losses as L
@@ -181,8 +182,11 @@ class FixedDraws:
 
 	def __enter__(self):
 		def wrapped(meshes, num_samples=10000, return_textures=False, generator=None, draws=None):
-			d = self.draws[self.i % len(self.draws)]
-			self.i += 1
+			if num_samples == 1000:
+				d = self.draws[2]
+			else:
+				d = self.draws[self.i % 2]
+				self.i += 1
 			return self.orig(meshes, num_samples, return_textures, draws=d)
 		self.L.sample_points_from_meshes = wrapped
 		return self

@@ -1,4 +1,4 @@
-"""A/B of the small-call machinery through find_ctx knobs -- fused layer chains (fused_max_units), their L2 warm-up (ablate bit 16), splits
+"""A/B of the small-call machinery through find_ctx knobs -- fused layer chains (fused_max_units), splits
 per foot of the grouped weight gradients (group_spf; 0 = cost model) -- on the MLP forward + backward at batch 1 (6890 template rows), on
 1000 free points x 1 and x 16 feet (the texture pass) and on the C2 step (16 feet, shared trunk).  python tools/fused_ab.py [knob ...]"""
 import os, sys, time
@@ -43,7 +43,7 @@ def mlp_case(n_feet, n_verts, free_pts):
 cases = [('batch 1 x 6890 template rows', mlp_case(1, 6890, False)), ('1 x 1000 free points', mlp_case(1, 1000, True)),
 		 ('16 x 1000 free points', mlp_case(16, 1000, True)), ('C2: 16 feet x 6890 (shared trunk)', bench.build_step(dev, 0)[2])]
 # (knob, A, B): A/B pairs measured twice, interleaved
-KNOBS = [('fused_max_units', 0, 512), ('ablate', 16, 0)] + [('group_spf', v, 0) for v in (1, 2, 4, 8)]
+KNOBS = [('fused_max_units', 0, 512)] + [('group_spf', v, 0) for v in (1, 2, 4, 8)]
 if len(sys.argv) > 1:
 	KNOBS = [k for k in KNOBS if k[0] in sys.argv[1:]]
 for name, step in cases:
