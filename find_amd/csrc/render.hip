@@ -39,6 +39,7 @@ struct Ws {
 	float* vproj;     // (n_img, V, 3)
 	float4* frec;     // (n_img, F, 3) float4: [x0 y0 x1 y1][x2 y2 z0 z1][z2 - - -]
 	uint32_t* tb;     // (n_img, F) packed tile bbox
+	uint32_t* tbb;    // (n_img, ceil(F / 64)) packed tile bbox of every run of 64 consecutive faces
 	float* normals;   // (n_meshes, V, 3) area-weighted vertex normals (world)
 	int32_t* p2f;     // (n_img, H, W) nearest inside face (local id) or -1   [saved for backward]
 	float* bary;      // (n_img, H, W, 3) its perspective-correct barycentrics
@@ -63,6 +64,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->vproj = c.take<float>(n_img * V * 3);
 	o->frec = c.take<float4>(n_img * F * 3);
 	o->tb = c.take<uint32_t>(n_img * F);
+	o->tbb = c.take<uint32_t>(n_img * cdiv(F, 64));
 	o->normals = c.take<float>(n_meshes * V * 3);
 	o->p2f = c.take<int32_t>(px);
 	o->bary = c.take<float>(px * 3);
@@ -140,16 +142,15 @@ __device__ __forceinline__ void pix_range(float cmin, float cmax, int S, int* lo
 
 __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
 								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
-								  float4* __restrict__ frec, uint32_t* __restrict__ tb, int32_t* __restrict__ flags,
+								  float4* __restrict__ frec, uint32_t* __restrict__ tb, uint32_t* __restrict__ tbb, int32_t* __restrict__ flags,
 								  int32_t* __restrict__ tile_any, int32_t* __restrict__ tile_cnt, int tiles_x, int tiles_per_img) {
 	const int img = blockIdx.y;
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= F) return;
 	const int mesh = img / n_views;
-	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)f * 3;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)min(f, F - 1) * 3;
 	uint32_t packed = TB_EMPTY;
 	const int64_t o = (int64_t)img * F + f;
-	if (fp[0] >= 0) {
+	if (f < F && fp[0] >= 0) {
 		const float* vp = vproj + (int64_t)img * V * 3;
 		const float x0 = vp[3 * fp[0]], y0 = vp[3 * fp[0] + 1], z0 = vp[3 * fp[0] + 2];
 		const float x1 = vp[3 * fp[1]], y1 = vp[3 * fp[1] + 1], z1 = vp[3 * fp[1] + 2];
@@ -183,8 +184,20 @@ __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t
 			}
 		}
 	}
-	tb[o] = packed;
+	if (f < F) tb[o] = packed;
+	// the tile bbox of the wave's 64 consecutive faces: the rasteriser tests these first and only opens the runs that reach its tile
+	// (faces that are neighbours in the index are neighbours on the surface in any mesh that was not shuffled on purpose)
+	int bx0 = packed & 255, bx1 = (packed >> 8) & 255, by0 = (packed >> 16) & 255, by1 = packed >> 24;
+	if (packed == TB_EMPTY) { bx0 = 255; bx1 = 0; by0 = 255; by1 = 0; }
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		bx0 = min(bx0, __shfl_xor(bx0, d, 64)); bx1 = max(bx1, __shfl_xor(bx1, d, 64));
+		by0 = min(by0, __shfl_xor(by0, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+	}
+	if ((threadIdx.x & 63) == 0 && f < F)
+		tbb[(int64_t)img * ((F + 63) / 64) + f / 64] = bx0 > bx1 ? TB_EMPTY : ((uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24));
 }
+
 
 // ------------------------------------------------------------------------------------------------ shared fragment math
 struct FaceRec {  // staged in LDS, one per candidate (80 bytes)
@@ -330,6 +343,7 @@ struct TileArgs {
 	find_render_params rp;
 	const float4* frec;
 	const uint32_t* tb;
+	const uint32_t* tbb;     // per run of 64 faces
 	const int32_t* faces;
 	int64_t faces_mesh_stride;
 	const float* verts;      // world (n_meshes,V,3)
@@ -360,6 +374,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	__shared__ int list[2 * BATCH];
 	__shared__ FaceRec rec[BATCH];
 	__shared__ int wcount2[2][4];
+	__shared__ int runs[256];
+	__shared__ int wit[4];
 	__shared__ int s_tile;
 	// write-combining rings of the candidate lists: [slot][thread], so that a wave's appends (different slots per lane) never conflict
 	__shared__ float ring_z[RING][256];
@@ -425,7 +441,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			if (tid < nb) make_rec(frp + (int64_t)list[tid] * 3, list[tid], br, &rec[tid]);
 			__syncthreads();
 			// candidates of this wave's quadrant: bbox-vs-quadrant test by 64 lanes at a time, then a scalar loop over the set
-			// bits (increasing k: the order of the alpha product and of the candidate lists is that of the face list)
+			// bits (increasing k: the order of the alpha product and of the candidate lists is that of the face list).
+			// (Measured and dropped in round 2: 16-lane groups owning 4x4-pixel blocks, each walking its own mask of faces in the same
+			// instruction stream -- 45 % of the lane-level tests produce a candidate instead of 26 %, 141 M tests instead of 245 M at C3, and
+			// the render is no faster, 1.87 against 1.80 ms: the loop runs for the longest of the four masks, and in the tiles that decide the
+			// kernel's duration -- the rim, the poles -- that is the quadrant's whole list.)
 			for (int kb = 0; kb < nb; kb += 64) {
 				bool ov = false;
 				if (kb + lane < nb) {
@@ -460,44 +480,70 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 		};
 
 		const int nF = a.tile_any[t_id] ? a.F : 0;  // nothing can touch this tile: straight to the background write
-		// Scan of the packed bboxes, 1024 faces per round: the four loads of a thread are in flight together (the scan is bound by the
-		// latency of this load, not by its bytes), then four ordered compactions -- ballot per wave, exclusive offsets across the waves
-		// through LDS (one barrier each: the wave counts alternate between two sets), the running length kept in a register.
+		// Two-level scan of the packed tile bboxes.  Level 1: the bboxes of the runs of 64 consecutive faces (face_setup_kernel), 256 runs
+		// per round, compacted in order into `runs`.  Level 2: the faces of the runs that reach this tile, 16 runs = 1024 faces per
+		// round: the four loads of a thread are in flight together (the scan is bound by the latency of this load, not by its bytes),
+		// then four ordered compactions -- ballot per wave, exclusive offsets across the waves through LDS (one barrier each: the wave
+		// counts alternate between two sets), the running length kept in a register.  Runs and faces stay in index order, so the
+		// candidate order is the face order whichever runs were skipped.  (One level -- every tile reading every face's bbox -- was
+		// 14 rounds per tile at 13 776 faces; a 16 x 16 tile is reached by a tenth of the runs of a mesh with coherent face order.)
 		int nl = 0;   // == n_list, replicated in every thread
 		int par = 0;
-		for (int base = 0; base < nF; base += 1024) {
-			uint32_t tbv[4];
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				const int f = base + r * 256 + tid;
-				tbv[r] = f < nF ? tbp[f] : TB_EMPTY;
-			}
-#pragma unroll
-			for (int r = 0; r < 4; ++r) {
-				if (base + r * 256 >= nF) break;  // uniform
-				const uint32_t t = tbv[r];
-				const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
-				const bool hit = tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;  // (TB_EMPTY: tx0 = 255 > tx1 = 0)
-				const unsigned long long m = __ballot(hit);
+		const int n_runs = (nF + 63) >> 6;
+		const uint32_t* tbbp = a.tbb + (int64_t)img * ((a.F + 63) >> 6);
+		auto tile_hit = [&](uint32_t t) {
+			const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
+			return tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;  // (TB_EMPTY: tx0 = 255 > tx1 = 0)
+		};
+		for (int rbase = 0; rbase < n_runs; rbase += 256) {
+			int n_hit;
+			{
+				const bool rh = rbase + tid < n_runs && tile_hit(tbbp[rbase + tid]);
+				const unsigned long long m = __ballot(rh);
 				if (lane == 0) wcount2[par][wave] = __popcll(m);
 				__syncthreads();
-				int off = nl;
+				int off = 0;
 				for (int w = 0; w < wave; ++w) off += wcount2[par][w];
-				if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = base + r * 256 + tid;
-				nl += wcount2[par][0] + wcount2[par][1] + wcount2[par][2] + wcount2[par][3];
+				if (rh) runs[off + __popcll(m & ((1ull << lane) - 1ull))] = rbase + tid;
+				n_hit = wcount2[par][0] + wcount2[par][1] + wcount2[par][2] + wcount2[par][3];
 				par ^= 1;
-				if (nl >= BATCH) {  // uniform
+				__syncthreads();
+			}
+			for (int j0 = 0; j0 < n_hit; j0 += 16) {
+				uint32_t tbv[4];
+				int fidx[4];
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int j = j0 + r * 4 + wave;
+					fidx[r] = j < n_hit ? runs[j] * 64 + lane : nF;
+					tbv[r] = fidx[r] < nF ? tbp[fidx[r]] : TB_EMPTY;
+				}
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					if (j0 + r * 4 >= n_hit) break;  // uniform
+					const bool hit = tile_hit(tbv[r]);
+					const unsigned long long m = __ballot(hit);
+					if (lane == 0) wcount2[par][wave] = __popcll(m);
 					__syncthreads();
-					shade_batch(BATCH);
-					const int rest = nl - BATCH;
-					int moved = 0;
-					if (tid < rest) moved = list[BATCH + tid];
-					__syncthreads();
-					if (tid < rest) list[tid] = moved;
-					nl = rest;
-					__syncthreads();
+					int off = nl;
+					for (int w = 0; w < wave; ++w) off += wcount2[par][w];
+					if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = fidx[r];
+					nl += wcount2[par][0] + wcount2[par][1] + wcount2[par][2] + wcount2[par][3];
+					par ^= 1;
+					if (nl >= BATCH) {  // uniform
+						__syncthreads();
+						shade_batch(BATCH);
+						const int rest = nl - BATCH;
+						int moved = 0;
+						if (tid < rest) moved = list[BATCH + tid];
+						__syncthreads();
+						if (tid < rest) list[tid] = moved;
+						nl = rest;
+						__syncthreads();
+					}
 				}
 			}
+			__syncthreads();   // `runs` is rewritten by the next round
 		}
 		if (nl > 0) { __syncthreads(); shade_batch(nl); }
 
@@ -650,6 +696,15 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) { te += __shfl_xor(te, d, 64); tc += __shfl_xor(tc, d, 64); }
 			if (lane == 0 && te) { atomicAdd(&a.flags[24], (te + 32) >> 6); atomicAdd(&a.flags[25], (tc + 32) >> 6); }
+			// [26] sum over tiles of the LONGEST of the four quadrants' face loops, [27] sum over tiles of all four: 4 x [26] / [27] is how
+			// much longer the tile's waves stay in the fragment phase than their own work needs (the others wait at the barrier)
+			if (lane == 0) wit[wave] = n_eval;
+			__syncthreads();
+			if (tid == 0) {
+				atomicAdd(&a.flags[26], max(max(wit[0], wit[1]), max(wit[2], wit[3])));
+				atomicAdd(&a.flags[27], wit[0] + wit[1] + wit[2] + wit[3]);
+			}
+			__syncthreads();
 		}
 		if (in_img) {
 			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
@@ -1087,7 +1142,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	const int tiles_x = (int)cdiv(W, TS), tiles_per_img = tiles_x * (int)cdiv(H, TS);
 	(void)hipMemsetAsync(w.tile_any, 0, 2 * n_img * (int64_t)tiles_per_img * sizeof(int32_t), s);   // flags and counts
 	hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, w.vproj, faces, fstride, (int)n_views, V, F, H, W,
-					   blur, rp->z_clip, w.frec, w.tb, w.flags, w.tile_any, w.tile_cnt, tiles_x, tiles_per_img);
+					   blur, rp->z_clip, w.frec, w.tb, w.tbb, w.flags, w.tile_any, w.tile_cnt, tiles_x, tiles_per_img);
 	if (image) {
 		(void)hipMemsetAsync(w.normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.normals);
@@ -1098,7 +1153,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	TileArgs a;
 	memset(&a, 0, sizeof(a));
 	a.rp = *rp;
-	a.frec = w.frec; a.tb = w.tb; a.faces = faces; a.faces_mesh_stride = fstride;
+	a.frec = w.frec; a.tb = w.tb; a.tbb = w.tbb; a.faces = faces; a.faces_mesh_stride = fstride;
 	a.verts = verts; a.normals = w.normals; a.colors = vert_colors; a.cam = cam;
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = (int)cdiv(W, TS);
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;

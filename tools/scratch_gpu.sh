@@ -1,6 +1,5 @@
 #!/bin/bash
 set -x
-O=gpurun_out/r3g; mkdir -p $O
+O=gpurun_out/r3k; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > $O/tests_all.txt
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 600 python tools/bench_paths.py > $O/subpaths.jsonl 2> $O/subpaths.err
