@@ -781,6 +781,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	a.pos = pos; a.pos_foot_stride = pos_foot_stride; a.Bm = p->B; a.pe = p->pe_size;
 	a.V = (int)V; a.spf = spf; a.cps = cps; a.Kp = nkt * 256;
 	a.pw = b.pw; a.pb = pbuf;
+	a.all_blocks = (c->ablate & 32) ? 1 : 0;
 	const int nsplit = (int)(feet * spf);
 	hipLaunchKernelGGL((dw_kernel<AMODE_PE>), dim3((unsigned)nkt, (unsigned)nsplit), dim3(512), 0, s, a);
 	FIND_LAUNCH_CHECK("dw_kernel");

@@ -110,6 +110,7 @@ struct DwArgs {
 	int Kp;                 // padded K = 256 * gridDim.x
 	float* pw;              // [n_feet*spf][256][Kp]
 	float* pb;              // [n_feet*spf][256] or nullptr
+	int all_blocks;         // profiling only ("ablate" bit 32): multiply the padding blocks of the Fourier layer's last k-tile as well
 };
 
 template <int AMODE>
@@ -132,6 +133,14 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 	const int q1 = min(q0 + g.cps, cpf);
 	const int lr = tid >> 6;         // loader row within an 8-row group
 	const int lc = (tid & 63) * 4;   // loader column
+	// 32-column blocks of this wave that hold any real column.  The Fourier layer's padded K is (pe / 16 + 1) chunks of 32 -- 544 of the
+	// 768 columns its three k-tiles span: the last tile has ONE live block (x, y, z and 29 zeros), and multiplying its other seven
+	// was a third of this kernel's matrix work.
+	int nact = 2;
+	if constexpr (AMODE == AMODE_PE) {
+		const int live = ((g.pe >> 4) + 1) * 32 - (kt * 256 + wk * 64);
+		nact = __builtin_amdgcn_readfirstlane((live >= 64 || g.all_blocks) ? 2 : (live > 0 ? 1 : 0));
+	}
 
 	if constexpr (AMODE == AMODE_PE) {
 		for (int i = tid; i < 3 * g.pe; i += 512) Bl[i] = g.Bm[i];
@@ -192,18 +201,27 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 
 		const int zo = (lane >> 5) * 256 + wn * 128 + (lane & 31);
 		const int xo = (lane >> 5) * 256 + wk * 64 + (lane & 31);
+		if (nact == 2) {
 #pragma unroll
-		for (int t = 0; t < 16; ++t) {
-			float a[4], b[2];
+			for (int t = 0; t < 16; ++t) {
+				float a[4], b[2];
 #pragma unroll
-			for (int mi = 0; mi < 4; ++mi) a[mi] = Zs[zo + t * 512 + mi * 32];
+				for (int mi = 0; mi < 4; ++mi) a[mi] = Zs[zo + t * 512 + mi * 32];
 #pragma unroll
-			for (int ni = 0; ni < 2; ++ni) b[ni] = Xs[xo + t * 512 + ni * 32];
+				for (int ni = 0; ni < 2; ++ni) b[ni] = Xs[xo + t * 512 + ni * 32];
 #pragma unroll
-			for (int mi = 0; mi < 4; ++mi)
+				for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-				for (int ni = 0; ni < 2; ++ni)
-					acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+					for (int ni = 0; ni < 2; ++ni)
+						acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+			}
+		} else if (nact == 1) {
+#pragma unroll
+			for (int t = 0; t < 16; ++t) {
+				const float b0 = Xs[xo + t * 512];
+#pragma unroll
+				for (int mi = 0; mi < 4; ++mi) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Zs[zo + t * 512 + mi * 32], b0, acc[mi][0], 0, 0, 0);
+			}
 		}
 	}
 
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 		for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) {
+				if (ni >= nact) continue;   // (padding columns: the slab reduce never maps them to an output)
 				const int n = wn * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 				const int k = wk * 64 + ni * 32 + (lane & 31);
 				pw[(int64_t)n * g.Kp + k] = acc[mi][ni][r];

@@ -43,7 +43,7 @@ def mlp_case(n_feet, n_verts, free_pts):
 cases = [('batch 1 x 6890 template rows', mlp_case(1, 6890, False)), ('1 x 1000 free points', mlp_case(1, 1000, True)),
 		 ('16 x 1000 free points', mlp_case(16, 1000, True)), ('C2: 16 feet x 6890 (shared trunk)', bench.build_step(dev, 0)[2])]
 # (knob, A, B): A/B pairs measured twice, interleaved
-KNOBS = [('fused_max_units', 0, 512)] + [('group_spf', v, 0) for v in (1, 2, 4, 8)]
+KNOBS = [('fused_max_units', 0, 512), ('ablate', 32, 0)] + [('group_spf', v, 0) for v in (1, 2, 4, 8)]
 if len(sys.argv) > 1:
 	KNOBS = [k for k in KNOBS if k[0] in sys.argv[1:]]
 for name, step in cases:
