@@ -64,6 +64,10 @@ PROTOTYPES = {
 	'find_linear_wgrad': (c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P]),
 	'find_latent_gather_fwd': (c_int, [_P, _I, _I, _P, _I, _P, _P]),
 	'find_latent_gather_bwd': (c_int, [_P, _P, _I, _I, _I, _P, _P]),
+	'find_latent_gather_many_fwd': (c_int, [_I, _P, _P, _P, _P, _I, _P, _P]),
+	'find_latent_gather_many_bwd': (c_int, [_I, _P, _P, _P, _P, _I, _P, _P]),
+	'find_weighted_terms_fwd': (c_int, [_I, _P, _P, _P, _P, _P]),
+	'find_weighted_terms_bwd': (c_int, [_I, _P, _P, _P, _P, _P]),
 	'find_uv_sample': (c_int, [_P, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P, _I, _I, _P, _P]),
 	'find_render_frags': (c_int, [POINTER(RenderParams), _I, _I, _I, _I, _P, _P, _P, _P]),
 	'find_adam_step': (c_int, [_I, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, _I, _P]),

@@ -274,6 +274,93 @@ def latent_gather(table, idx):
 	return _LatentGather.apply(table, idx)
 
 
+def _ptr_array(tensors):
+	"""Host array of device pointers (NULL for None)."""
+	return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class _LatentGatherMany(torch.autograd.Function):
+	"""rows_t = table_t[idx_t] for up to 8 tables in one launch each way (find_latent_gather_many_fwd / _bwd)."""
+
+	@staticmethod
+	def forward(ctx, n, *args):
+		tables, idxs = args[:n], args[n:]
+		_require_gpu(*tables)
+		L = _lib.lib()
+		tables = [_c(t) for t in tables]
+		idxs = [_c(i) for i in idxs]
+		n_idx = idxs[0].shape[0]
+		for t, i in zip(tables, idxs):
+			if t.dim() != 2 or i.dim() != 1 or i.dtype != torch.int64 or i.shape[0] != n_idx or not i.is_cuda:
+				raise RuntimeError(f'find_amd.latent_gather_many: tables (rows, dim) and device int64 idx ({n_idx}) expected, got {tuple(t.shape)} / {tuple(i.shape)} {i.dtype}')
+		dev = tables[0].device
+		outs = [torch.empty(n_idx, t.shape[1], device=dev, dtype=torch.float32) for t in tables]
+		rows = (ctypes.c_int64 * n)(*[t.shape[0] for t in tables])
+		dims = (ctypes.c_int64 * n)(*[t.shape[1] for t in tables])
+		check(L.find_latent_gather_many_fwd(n, _ptr_array(tables), rows, dims, _ptr_array(idxs), n_idx, _ptr_array(outs), current_stream(dev)),
+			  'find_latent_gather_many_fwd')
+		ctx.save_for_backward(*idxs)
+		ctx.shapes = [tuple(t.shape) for t in tables]
+		ctx.keys = [(t.data_ptr(), t.numel()) for t in tables]
+		return tuple(outs)
+
+	@staticmethod
+	def backward(ctx, *gs):
+		L = _lib.lib()
+		idxs = ctx.saved_tensors
+		n = len(idxs)
+		dev = idxs[0].device
+		gs = [_c(g) for g in gs]
+		d_tables = [_grad_for(k, sh, dev) for k, sh in zip(ctx.keys, ctx.shapes)]
+		rows = (ctypes.c_int64 * n)(*[sh[0] for sh in ctx.shapes])
+		dims = (ctypes.c_int64 * n)(*[sh[1] for sh in ctx.shapes])
+		check(L.find_latent_gather_many_bwd(n, _ptr_array(gs), rows, dims, _ptr_array(idxs), idxs[0].shape[0], _ptr_array(d_tables), current_stream(dev)),
+			  'find_latent_gather_many_bwd')
+		return (None, *d_tables, *([None] * n))
+
+
+def latent_gather_many(tables, idxs):
+	"""[table[idx] for table, idx in zip(tables, idxs)] in one launch (and one launch for all the scatter gradients)."""
+	if not 1 <= len(tables) <= 8 or len(tables) != len(idxs):
+		raise ValueError('find_amd.latent_gather_many: 1 .. 8 tables, one index tensor each')
+	return list(_LatentGatherMany.apply(len(tables), *tables, *idxs))
+
+
+class _WeightedTerms(torch.autograd.Function):
+	"""(sum_i w_i * term_i, [w_i * term_i]) for 0-dim device terms: ModelWithLoss's loss weighting (reference model.py:1157-1163)."""
+
+	@staticmethod
+	def forward(ctx, weights, *terms):
+		_require_gpu(*terms)
+		L = _lib.lib()
+		n = len(terms)
+		terms = [_c(t) for t in terms]
+		dev = terms[0].device
+		out = torch.empty(n + 1, device=dev, dtype=torch.float32)
+		w = (ctypes.c_float * n)(*weights)
+		check(L.find_weighted_terms_fwd(n, _ptr_array(terms), w, ptr(out), ctypes.c_void_p(out.data_ptr() + 4 * n), current_stream(dev)), 'find_weighted_terms_fwd')
+		ctx.weights = tuple(float(x) for x in weights)
+		return out[n], out[:n]
+
+	@staticmethod
+	def backward(ctx, g_total, g_scaled):
+		L = _lib.lib()
+		n = len(ctx.weights)
+		ref = g_total if g_total is not None else g_scaled
+		d = torch.empty(n, device=ref.device, dtype=torch.float32)
+		w = (ctypes.c_float * n)(*ctx.weights)
+		check(L.find_weighted_terms_bwd(n, w, ptr(_c(g_total)), ptr(_c(g_scaled)), ptr(d), current_stream(ref.device)), 'find_weighted_terms_bwd')
+		return (None, *[d[i] for i in range(n)])
+
+
+def weighted_terms(terms, weights):
+	"""total = sum_i weights[i] * terms[i] (in order) and the list of the weighted terms, for 0-dim device tensors: one launch."""
+	if not 1 <= len(terms) <= 8 or len(terms) != len(weights):
+		raise ValueError('find_amd.weighted_terms: 1 .. 8 terms, one weight each')
+	total, scaled = _WeightedTerms.apply(tuple(float(w) for w in weights), *terms)
+	return total, [scaled[i] for i in range(len(terms))]
+
+
 class _Register(torch.autograd.Function):
 	"""X = ((verts + disp) * S) @ R(euler XYZ) + t     (model.py:481-491)."""
 

@@ -15,6 +15,8 @@ Constraints (checked or documented): every batch of one shape signature shares a
 (opts.restrict_3d_n_train) cannot be captured.  The warm-up iterations that precede a capture are real training steps."""
 import torch
 
+from . import functional as FN
+
 from .structures import Meshes, TexturesUV, TexturesVertex
 
 
@@ -114,12 +116,20 @@ class GraphedStep:
 		def body():
 			b = dict(st.batch)
 			j = 0
+			sel = []
 			for vec in self.latent_vectors:
 				if vec.labels is not None:
-					b[vec.name] = vec[st.idx_dev[j]]
+					sel.append(st.idx_dev[j])
 					j += 1
 				else:
-					b[vec.name] = vec[b['idx']]
+					sel.append(b['idx'])
+			idx = [vec.device_index(s) for vec, s in zip(self.latent_vectors, sel)]
+			if len(idx) > 1 and all(i is not None for i in idx):   # every table in one launch, as train_utils.sample_latent_vectors
+				rows = FN.latent_gather_many([vec.data for vec in self.latent_vectors], idx)
+			else:
+				rows = [vec[s] for vec, s in zip(self.latent_vectors, sel)]
+			for vec, r in zip(self.latent_vectors, rows):
+				b[vec.name] = r
 			out = self.mwl(b, epoch, self.opts, **self.flags)
 			loss, losses = out[0], out[1]
 			loss.backward()

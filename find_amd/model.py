@@ -101,16 +101,34 @@ class LatentVector(nn.Module):
 
 	def _label_rows(self, labels):
 		"""Rows for a list of label strings.  The label -> row search is the reference's host-side list.index; the resulting index
-		tensor is kept per label tuple, so a batch seen before costs no host-to-device copy (a DataLoader revisits the same scans
-		every epoch)."""
-		key = tuple(labels)
-		idx = self._label_cache.get(key)
-		if idx is None or idx.device != self.data.device:
-			if len(self._label_cache) > 4096:
-				self._label_cache.clear()
+		tensor is kept per label tuple (device_index), so a batch seen before costs no host-to-device copy (a DataLoader revisits the
+		same scans every epoch)."""
+		idx = self.device_index(labels)
+		if idx is None:   # CPU table
 			idx = torch.tensor([self._index_of(o) for o in labels], dtype=torch.int64, device=self.data.device)
-			self._label_cache[key] = idx
 		return self._rows(idx)
+
+	def device_index(self, sel):
+		"""The int64 device index vector that self[sel] would gather with on the GPU path -- sel a 1-D integer tensor or a list of label
+		strings -- or None when self[sel] takes another route (CPU table, scalar index, list of ints ...).  Same checks as __getitem__."""
+		if not (self.data.is_cuda and self.data.dtype == torch.float32):
+			return None
+		if isinstance(sel, torch.Tensor) and sel.dim() == 1 and sel.dtype in (torch.int64, torch.int32):
+			if not sel.is_cuda and sel.numel() > 0:
+				lo, hi = int(sel.min()), int(sel.max())
+				if lo < -self.data.shape[0] or hi >= self.data.shape[0]:
+					raise IndexError(f'LatentVector {self.name}: index {lo if lo < -self.data.shape[0] else hi} is out of range for {self.data.shape[0]} rows')
+			return sel.to(device=self.data.device, dtype=torch.int64)
+		if isinstance(sel, list) and sel and isinstance(sel[0], str):
+			key = tuple(sel)
+			idx = self._label_cache.get(key)
+			if idx is None or idx.device != self.data.device:
+				if len(self._label_cache) > 4096:
+					self._label_cache.clear()
+				idx = torch.tensor([self._index_of(o) for o in sel], dtype=torch.int64, device=self.data.device)
+				self._label_cache[key] = idx
+			return idx
+		return None
 
 	def __getitem__(self, idx):
 		if isinstance(idx, torch.Tensor) and idx.dim() == 1 and idx.dtype in (torch.int64, torch.int32):

@@ -9,6 +9,7 @@ from collections import namedtuple
 
 import torch
 
+from . import functional as FN
 from .losses import DisplacementLoss, MeshSmoothnessLoss, SilhouetteLoss, TextureLossGTSpace
 from .model import NeuralDisplacementField
 from .renderer import FootRenderer
@@ -149,12 +150,19 @@ class ModelWithLoss(nn.Module):
 			st.pred, st.gt = self._render_pair(st, views, batch.get('masked_faces', None), copy_mask_out)
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
-		losses = {}
+		raw, weights = {}, []
 		for term in TERMS:
 			if not enabled[term.flag] or (term.needs_3d and not supervise_3d) or (term.needs_render and not render_foot):
 				continue
-			losses[term.key] = getattr(self, term.fn)(st) * getattr(opts, term.weight)
-		loss = sum(losses.values())
+			raw[term.key] = getattr(self, term.fn)(st)
+			weights.append(float(getattr(opts, term.weight)))
+		# losses[k] = raw * opts.weight_k, loss = sum(losses.values())   (model.py:1157-1163): one launch for all terms on the GPU
+		if raw and all(torch.is_tensor(v) and v.is_cuda and v.dim() == 0 and v.dtype == torch.float32 for v in raw.values()) and len(raw) <= 8:
+			loss, scaled = FN.weighted_terms(list(raw.values()), weights)
+			losses = dict(zip(raw, scaled))
+		else:
+			losses = {k: v * w for (k, v), w in zip(raw.items(), weights)}
+			loss = sum(losses.values())
 		if return_renders and render_foot:
 			return loss, losses, dict(pred=st.pred, gt=st.gt)
 		return loss, losses

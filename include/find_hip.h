@@ -174,6 +174,21 @@ int find_debug_raster_ablate(int64_t bits);
  * ---------------------------------------------------------------------------------------------- */
 int find_latent_gather_fwd(const float* table, int64_t n_rows, int64_t dim, const int64_t* idx, int64_t n_idx, float* out, void* stream);
 int find_latent_gather_bwd(const float* d_out, const int64_t* idx, int64_t n_idx, int64_t n_rows, int64_t dim, float* d_table, void* stream);
+/* The same for up to 8 tables in one launch each way -- trainer.sample_latent_vectors (src/train/trainer.py:29-46) looks up the shape,
+ * pose, texture and registration rows of a batch, one LatentVector.__getitem__ each.  tables / idx / outs (and n_rows, dims) are HOST
+ * arrays of n_tables entries; every lookup has n_idx indices.  Backward: d_outs[t] may be NULL (no gradient arrived: d_tables[t] = 0). */
+int find_latent_gather_many_fwd(int64_t n_tables, const float* const* tables, const int64_t* n_rows, const int64_t* dims,
+								const int64_t* const* idx, int64_t n_idx, float* const* outs, void* stream);
+int find_latent_gather_many_bwd(int64_t n_tables, const float* const* d_outs, const int64_t* n_rows, const int64_t* dims,
+								const int64_t* const* idx, int64_t n_idx, float* const* d_tables, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Loss weighting: scaled[i] = *terms[i] * weights[i], *total = sum_i scaled[i] in term order (ModelWithLoss.forward,
+ * src/model/model.py:1157-1163: losses[k] = raw * opts.weight_k, loss = sum).  terms: HOST array of n <= 8 device scalars; weights:
+ * host floats; scaled (n) and total: device.  Backward: d_terms[i] = weights[i] * (*g_total + g_scaled[i]); either upstream may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int find_weighted_terms_fwd(int64_t n, const float* const* terms, const float* weights, float* scaled, float* total, void* stream);
+int find_weighted_terms_bwd(int64_t n, const float* weights, const float* g_total, const float* g_scaled, float* d_terms, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Similarity registration  X = ((v + disp) * S) @ R(euler 'XYZ') + t.

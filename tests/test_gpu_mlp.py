@@ -496,3 +496,32 @@ def test_colour_head_alone_equals_the_full_forward(golden_main, shape):
 			assert (l0[k] - l1[k]).abs().max().item() <= 1e-6 * max(1e-3, l0[k].abs().max().item()), k
 	with pytest.raises(ValueError):
 		m(pos, **lat, want=())
+
+
+def test_latent_gather_many_and_weighted_terms():
+	"""One launch for the four latent-table lookups of a step and one for the loss weighting: same values and gradients as the
+	per-table gather and as raw * weight / Python's sum()."""
+	from find_amd import functional as FN
+	g = torch.Generator().manual_seed(8)
+	tables = [torch.randn(n, d, generator=g).cuda().requires_grad_(True) for n, d in [(5, 100), (9, 100), (5, 100), (9, 9)]]
+	idxs = [torch.tensor(i, device='cuda') for i in ([0, 4, 4], [8, 2, 2], [1, 1, 1], [-1, 3, 0])]
+	outs = FN.latent_gather_many(tables, idxs)
+	w = [torch.randn(o.shape, generator=g).cuda() for o in outs]
+	sum((o * x).sum() for o, x in zip(outs, w[:3])).backward()   # the fourth lookup gets no gradient: its table's gradient is zero
+	got = [t.grad.clone() for t in tables]
+	for t in tables:
+		t.grad = None
+	ref = [t[i] for t, i in zip(tables, idxs)]
+	for o, r in zip(outs, ref):
+		assert torch.equal(o, r)
+	sum((o * x).sum() for o, x in zip(ref, w[:3])).backward()
+	for k, (a, t) in enumerate(zip(got, tables)):
+		want = t.grad if t.grad is not None else torch.zeros_like(t)
+		assert (a - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item()), k
+	assert torch.isnan(FN.latent_gather_many(tables[:2], [torch.tensor([7], device='cuda'), torch.tensor([0], device='cuda')])[0]).all()   # out of range: NaN row
+	# weighted terms
+	raws = [torch.tensor(v, device='cuda', requires_grad=True) for v in (0.25, 3.0, 1e-3)]
+	total, scaled = FN.weighted_terms(raws, [10000.0, 1000.0, 1.0])
+	assert abs(total.item() - (2500.0 + 3000.0 + 1e-3)) < 1e-3 and abs(scaled[1].item() - 3000.0) < 1e-3
+	(total * 2.0 + scaled[2]).backward()
+	assert [round(r.grad.item(), 4) for r in raws] == [20000.0, 2000.0, 3.0]
