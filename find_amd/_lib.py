@@ -127,7 +127,10 @@ def lib():
 	# profiling aid: FIND_TUNING="key=value,key=value" becomes the default of every context created below (tools/, bench.py experiments)
 	for kv in filter(None, os.environ.get('FIND_TUNING', '').split(',')):
 		k, v = kv.split('=')
-		_TUNING_DEFAULTS[k.strip()] = int(v)
+		if k.strip() == 'raster_ablate':   # process-wide, not a context knob: takes effect now
+			check(L.find_debug_raster_ablate(int(v)), 'find_debug_raster_ablate')
+		else:
+			_TUNING_DEFAULTS[k.strip()] = int(v)
 	return L
 
 

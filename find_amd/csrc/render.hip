@@ -26,8 +26,8 @@ namespace find {
 int g_raster_ablate = 0;
 namespace render {
 
-constexpr int TS = 16;          // tile edge in pixels
-constexpr int BATCH = 256;      // candidates shaded per LDS batch
+constexpr int TS_WG = 16;       // tile edge in pixels: one workgroup per tile, a quadrant per wave (raster_tile_kernel<4>) ...
+constexpr int TS_WAVE = 8;      // ... or one wave per tile (raster_tile_kernel<1>: find_debug_raster_ablate bit 128, measured slower)
 constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
 constexpr int KU = 16;            // list entries in flight per lane in the K-nearest passes (they are L2-latency-bound)
@@ -72,7 +72,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->d_normals = c.take<float>(n_meshes * V * 3);
 	o->raw_normals = c.take<float>(n_meshes * V * 3);
 	o->zthr = c.take<float>(px);
-	const int64_t tiles = n_img * cdiv(rp->image_w, TS) * cdiv(rp->image_h, TS);
+	const int64_t tiles = n_img * cdiv(rp->image_w, TS_WAVE) * cdiv(rp->image_h, TS_WAVE);   // (the finer of the two tilings)
 	o->raster_wgs = std::min<int64_t>(tiles, RASTER_WGS);
 	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
 	o->tile_any = c.take<int32_t>(2 * tiles);
@@ -143,7 +143,7 @@ __device__ __forceinline__ void pix_range(float cmin, float cmax, int S, int* lo
 __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
 								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
 								  float4* __restrict__ frec, uint32_t* __restrict__ tb, uint32_t* __restrict__ tbb, int32_t* __restrict__ flags,
-								  int32_t* __restrict__ tile_any, int32_t* __restrict__ tile_cnt, int tiles_x, int tiles_per_img) {
+								  int32_t* __restrict__ tile_any, int32_t* __restrict__ tile_cnt, int tiles_x, int tiles_per_img, int TS) {
 	const int img = blockIdx.y;
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	const int mesh = img / n_views;
@@ -370,19 +370,49 @@ struct TileArgs {
 // appended, in face order, to the workgroup's scratch (depth, 1 - p): a pixel that ends with more than faces_per_pixel
 // candidates is resolved at the end of its tile by its own wave -- rank by depth, ties to the earlier face (PyTorch3D's
 // insertion into the per-pixel K-buffer), blend the K nearest, record the K-th depth for the backward pass.
+//
+// NW = waves that share a tile.  NW = 4 (what find_render_fwd launches): a 16x16 tile per workgroup, one 8x8 quadrant per wave, the tile's
+// face list and records built together (workgroup barriers between the phases).  NW = 1 (find_debug_raster_ablate bit 128): every wave is
+// its own worker on 8x8 tiles -- own list, own records, own queue slot, no workgroup barrier anywhere.  The reason to try it: with NW = 4
+// the waves of a tile meet at a barrier after every batch of 256 faces, and the longest quadrant loop of a batch is 1.79 x the mean of the
+// four at C3 (1.43 x per whole tile; diagnostic counters [26] - [28]).  Measured (same faces per pixel, values equal to rounding): 2.03 against 1.78 ms at 256^2,
+// 6.27 against 4.25 ms at 512^2 -- four times the tiles means four times the scans and record stagings, each a chain of dependent loads
+// that a lone wave cannot overlap with anything, and that costs more than the barriers did.  Kept as a switch, not as the default.
+template <int NW>
 __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
-	__shared__ int list[2 * BATCH];
-	__shared__ FaceRec rec[BATCH];
-	__shared__ int wcount2[2][4];
-	__shared__ int runs[256];
+	constexpr int TSZ = NW == 4 ? 16 : 8;   // tile edge
+	constexpr int GB = NW * 64;             // threads of a group = faces per batch
+	constexpr int NG = 4 / NW;              // groups per workgroup
+	constexpr int LPR = 4;                  // face-bbox loads a lane keeps in flight per scan round (12 for NW = 1: slower still)
+	__shared__ int list[NG][2 * GB];
+	__shared__ FaceRec rec[NG][GB];
+	__shared__ int wcount2[NG][2][4];
+	__shared__ int runs[NG][GB];
 	__shared__ int wit[4];
-	__shared__ int s_tile;
+	__shared__ int s_tile[NG];
 	// write-combining rings of the candidate lists: [slot][thread], so that a wave's appends (different slots per lane) never conflict
 	__shared__ float ring_z[RING][256];
 	__shared__ float ring_q[RING][256];
 
 	const int H = a.rp.image_h, W = a.rp.image_w;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int g = NW == 4 ? 0 : wave, wg = NW == 4 ? wave : 0, gtid = NW == 4 ? tid : lane;   // group, wave inside it, thread inside it
+	// barrier of the group: the workgroup's, or -- one wave: its LDS operations execute in order -- only a fence for the compiler
+	auto gsync = [&]() {
+		if constexpr (NW == 4) {
+			__syncthreads();
+		} else {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+	};
+	auto wtotal = [&](int par) {
+		int t = 0;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) t += wcount2[g][par][w];
+		return t;
+	};
 	const float blur = a.rp.sil_blur_radius, br = sqrtf(blur);
 	const float inv_sigma = 1.0f / a.rp.sil_sigma;
 	const int K = a.rp.sil_faces_per_pixel;
@@ -409,16 +439,16 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	};
 
 	for (;;) {
-		if (tid == 0) s_tile = atomicAdd(&a.flags[3], 1);
-		__syncthreads();
-		const int t_q = s_tile;
-		__syncthreads();
+		if (gtid == 0) s_tile[g] = atomicAdd(&a.flags[3], 1);
+		gsync();
+		const int t_q = s_tile[g];
+		gsync();
 		if (t_q >= a.total_tiles) break;
 		const int t_id = a.tile_order[t_q];
 		const int img = t_id / a.tiles_per_img, tile = t_id - img * a.tiles_per_img;
 		const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
 		// wave w owns the 8x8-pixel quadrant (w&1, w>>1) of the tile: faces are culled per wave against that quadrant
-		const int qx0 = tile_x * TS + (wave & 1) * 8, qy0 = tile_y * TS + (wave >> 1) * 8;
+		const int qx0 = tile_x * TSZ + (wg & 1) * 8, qy0 = tile_y * TSZ + (wg >> 1) * 8;
 		const int xi = qx0 + (lane & 7), yi = qy0 + (lane >> 3);
 		const bool in_img = xi < W && yi < H;
 		const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
@@ -429,7 +459,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 
 		float alpha = 1.0f, z_lo = INFINITY, z_hi = 0.0f;
 		int cnt = 0;
-		int n_eval = 0;   // diagnostics (ablate bit 64): (pixel, face) tests this lane ran
+		int n_eval = 0, n_eval_prev = 0;   // diagnostics (ablate bit 64): (pixel, face) tests this lane ran
 		float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
 		int bf = -1;
 
@@ -438,8 +468,8 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 
 		auto shade_batch = [&](int nb) {
 			// stage the records of list[0 .. nb) in LDS
-			if (tid < nb) make_rec(frp + (int64_t)list[tid] * 3, list[tid], br, &rec[tid]);
-			__syncthreads();
+			if (gtid < nb) make_rec(frp + (int64_t)list[g][gtid] * 3, list[g][gtid], br, &rec[g][gtid]);
+			gsync();
 			// candidates of this wave's quadrant: bbox-vs-quadrant test by 64 lanes at a time, then a scalar loop over the set
 			// bits (increasing k: the order of the alpha product and of the candidate lists is that of the face list).
 			// (Measured and dropped in round 2: 16-lane groups owning 4x4-pixel blocks, each walking its own mask of faces in the same
@@ -449,7 +479,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			for (int kb = 0; kb < nb; kb += 64) {
 				bool ov = false;
 				if (kb + lane < nb) {
-					const FaceRec& rr = rec[kb + lane];
+					const FaceRec& rr = rec[g][kb + lane];
 					ov = !(q_xlo > rr.xmax || q_xhi < rr.xmin || q_ylo > rr.ymax || q_yhi < rr.ymin);
 				}
 				unsigned long long qm = __ballot(ov);
@@ -458,7 +488,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					qm &= qm - 1;
 					Frag fr;
 					if (a.ablate & 64) ++n_eval;
-					if ((a.ablate & 4) || !in_img || !eval_frag(rec[k], px, py, &fr)) continue;
+					if ((a.ablate & 4) || !in_img || !eval_frag(rec[g][k], px, py, &fr)) continue;
 					if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
 						const float sd = fr.inside ? -fr.dist : fr.dist;
 						const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
@@ -472,11 +502,18 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bisection bounds)
 					}
 					if (want_rgb && fr.inside && fr.pz >= 0.f && fr.pz < bz) {
-						bz = fr.pz; bf = rec[k].f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
+						bz = fr.pz; bf = rec[g][k].f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
 					}
 				}
 			}
-			__syncthreads();
+			gsync();
+			if (NW == 4 && (a.ablate & 64)) {   // diagnostics [28]: sum over BATCHES of the longest quadrant loop (the barrier above waits for it)
+				if (lane == 0) wit[wave] = n_eval - n_eval_prev;
+				n_eval_prev = n_eval;
+				__syncthreads();
+				if (tid == 0) atomicAdd(&a.flags[28], max(max(wit[0], wit[1]), max(wit[2], wit[3])));
+				__syncthreads();
+			}
 		};
 
 		const int nF = a.tile_any[t_id] ? a.F : 0;  // nothing can touch this tile: straight to the background write
@@ -495,57 +532,57 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
 			return tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;  // (TB_EMPTY: tx0 = 255 > tx1 = 0)
 		};
-		for (int rbase = 0; rbase < n_runs; rbase += 256) {
+		for (int rbase = 0; rbase < n_runs; rbase += GB) {
 			int n_hit;
 			{
-				const bool rh = rbase + tid < n_runs && tile_hit(tbbp[rbase + tid]);
+				const bool rh = rbase + gtid < n_runs && tile_hit(tbbp[rbase + gtid]);
 				const unsigned long long m = __ballot(rh);
-				if (lane == 0) wcount2[par][wave] = __popcll(m);
-				__syncthreads();
+				if (lane == 0) wcount2[g][par][wg] = __popcll(m);
+				gsync();
 				int off = 0;
-				for (int w = 0; w < wave; ++w) off += wcount2[par][w];
-				if (rh) runs[off + __popcll(m & ((1ull << lane) - 1ull))] = rbase + tid;
-				n_hit = wcount2[par][0] + wcount2[par][1] + wcount2[par][2] + wcount2[par][3];
+				for (int w = 0; w < wg; ++w) off += wcount2[g][par][w];
+				if (rh) runs[g][off + __popcll(m & ((1ull << lane) - 1ull))] = rbase + gtid;
+				n_hit = wtotal(par);
 				par ^= 1;
-				__syncthreads();
+				gsync();
 			}
-			for (int j0 = 0; j0 < n_hit; j0 += 16) {
-				uint32_t tbv[4];
-				int fidx[4];
+			for (int j0 = 0; j0 < n_hit; j0 += LPR * NW) {
+				uint32_t tbv[LPR];
+				int fidx[LPR];
 #pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					const int j = j0 + r * 4 + wave;
-					fidx[r] = j < n_hit ? runs[j] * 64 + lane : nF;
+				for (int r = 0; r < LPR; ++r) {
+					const int j = j0 + r * NW + wg;
+					fidx[r] = j < n_hit ? runs[g][j] * 64 + lane : nF;
 					tbv[r] = fidx[r] < nF ? tbp[fidx[r]] : TB_EMPTY;
 				}
 #pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					if (j0 + r * 4 >= n_hit) break;  // uniform
+				for (int r = 0; r < LPR; ++r) {
+					if (j0 + r * NW >= n_hit) break;  // uniform
 					const bool hit = tile_hit(tbv[r]);
 					const unsigned long long m = __ballot(hit);
-					if (lane == 0) wcount2[par][wave] = __popcll(m);
-					__syncthreads();
+					if (lane == 0) wcount2[g][par][wg] = __popcll(m);
+					gsync();
 					int off = nl;
-					for (int w = 0; w < wave; ++w) off += wcount2[par][w];
-					if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = fidx[r];
-					nl += wcount2[par][0] + wcount2[par][1] + wcount2[par][2] + wcount2[par][3];
+					for (int w = 0; w < wg; ++w) off += wcount2[g][par][w];
+					if (hit) list[g][off + __popcll(m & ((1ull << lane) - 1ull))] = fidx[r];
+					nl += wtotal(par);
 					par ^= 1;
-					if (nl >= BATCH) {  // uniform
-						__syncthreads();
-						shade_batch(BATCH);
-						const int rest = nl - BATCH;
+					if (nl >= GB) {  // uniform
+						gsync();
+						shade_batch(GB);
+						const int rest = nl - GB;
 						int moved = 0;
-						if (tid < rest) moved = list[BATCH + tid];
-						__syncthreads();
-						if (tid < rest) list[tid] = moved;
+						if (gtid < rest) moved = list[g][GB + gtid];
+						gsync();
+						if (gtid < rest) list[g][gtid] = moved;
 						nl = rest;
-						__syncthreads();
+						gsync();
 					}
 				}
 			}
-			__syncthreads();   // `runs` is rewritten by the next round
+			gsync();   // `runs` is rewritten by the next round
 		}
-		if (nl > 0) { __syncthreads(); shade_batch(nl); }
+		if (nl > 0) { gsync(); shade_batch(nl); }
 
 		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
 		// lane finds the K-th smallest depth of its OWN list (16-byte reads of its contiguous run) by a radix search
@@ -604,17 +641,17 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					// that holds the K-th; once that bin has at most 4 candidates they are fetched and ranked directly.
 					int c_lo = 0;
 					// the lane's 32 counters (16 bits each) live in LDS, on top of the face records nobody needs any more in this tile:
-					// hist[w * 256 + tid], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
-					unsigned* const hist = reinterpret_cast<unsigned*>(rec) + tid;
+					// hist[w * GB + gtid], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
+					unsigned* const hist = reinterpret_cast<unsigned*>(rec[g]) + gtid;
 					while (lo < hi) {
 						const unsigned span = hi - lo;
 						const int shift = span < 32u ? 0 : (27 - __builtin_clz(span));  // (span >> shift) <= 31
 #pragma unroll
-						for (int w = 0; w < 16; ++w) hist[w * 256] = 0u;
+						for (int w = 0; w < 16; ++w) hist[w * GB] = 0u;
 						scan_z([&](unsigned zb) {
 							if (zb < lo || zb > hi) return;
 							const unsigned bin = (zb - lo) >> shift;
-							__hip_atomic_fetch_add(hist + (bin >> 1) * 256, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							__hip_atomic_fetch_add(hist + (bin >> 1) * GB, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						});
 						// the bin that holds the (K - c_lo)-th candidate of the range
 						const int need = K - c_lo;
@@ -622,7 +659,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						bool found = false;
 #pragma unroll
 						for (int w = 0; w < 16; ++w) {
-							const unsigned hw = hist[w * 256];
+							const unsigned hw = hist[w * GB];
 #pragma unroll
 							for (int h = 0; h < 2; ++h) {
 								const int cb = (int)((hw >> (h * 16)) & 0xFFFFu);
@@ -698,13 +735,15 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			if (lane == 0 && te) { atomicAdd(&a.flags[24], (te + 32) >> 6); atomicAdd(&a.flags[25], (tc + 32) >> 6); }
 			// [26] sum over tiles of the LONGEST of the four quadrants' face loops, [27] sum over tiles of all four: 4 x [26] / [27] is how
 			// much longer the tile's waves stay in the fragment phase than their own work needs (the others wait at the barrier)
-			if (lane == 0) wit[wave] = n_eval;
-			__syncthreads();
-			if (tid == 0) {
-				atomicAdd(&a.flags[26], max(max(wit[0], wit[1]), max(wit[2], wit[3])));
-				atomicAdd(&a.flags[27], wit[0] + wit[1] + wit[2] + wit[3]);
+			if constexpr (NW == 4) {
+				if (lane == 0) wit[wave] = n_eval;
+				__syncthreads();
+				if (tid == 0) {
+					atomicAdd(&a.flags[26], max(max(wit[0], wit[1]), max(wit[2], wit[3])));
+					atomicAdd(&a.flags[27], wit[0] + wit[1] + wit[2] + wit[3]);
+				}
+				__syncthreads();
 			}
-			__syncthreads();
 		}
 		if (in_img) {
 			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
@@ -762,7 +801,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 				}
 			}
 		}
-		__syncthreads();  // the next tile reuses list / rec / scratch
+		gsync();  // the next tile reuses list / rec / scratch
 	}
 }
 
@@ -1102,7 +1141,7 @@ using namespace find::render;
 
 static int check_params(const find_render_params* rp, int64_t n_meshes, int64_t n_views, int64_t V, int64_t F) {
 	FIND_REQUIRE(rp != nullptr, "find_render: params is NULL");
-	FIND_REQUIRE(rp->image_h >= 1 && rp->image_w >= 1 && rp->image_h <= 4096 && rp->image_w <= 4096, "find_render: image size out of range");
+	FIND_REQUIRE(rp->image_h >= 1 && rp->image_w >= 1 && rp->image_h <= 2048 && rp->image_w <= 2048, "find_render: image size out of range (1 .. 2048: tile coordinates are packed in 8 bits)");
 	FIND_REQUIRE(n_meshes >= 1 && n_views >= 1 && n_views <= 256 && n_meshes * n_views < 65536, "find_render: bad batch (%lld meshes x %lld views)", (long long)n_meshes, (long long)n_views);
 	FIND_REQUIRE(V >= 1 && F >= 1 && V < (1ll << 28) && F < (1ll << 28), "find_render: bad mesh size");
 	FIND_REQUIRE(rp->sil_sigma > 0.f && rp->rgb_sigma > 0.f && rp->rgb_gamma > 0.f && rp->zfar > rp->znear, "find_render: bad blend parameters");
@@ -1139,10 +1178,12 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv(V, 256), (unsigned)n_img), dim3(256), 0, s, verts, R, T, sc, (int)n_views, V, w.vproj);
 	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one scan serves both
 	const float blur = mask ? rp->sil_blur_radius : 0.0f;
+	const bool per_wg = (find::g_raster_ablate & 128) == 0;   // bit 128: one wave per 8x8 tile (measured slower, see raster_tile_kernel)
+	const int TS = per_wg ? TS_WG : TS_WAVE;
 	const int tiles_x = (int)cdiv(W, TS), tiles_per_img = tiles_x * (int)cdiv(H, TS);
-	(void)hipMemsetAsync(w.tile_any, 0, 2 * n_img * (int64_t)tiles_per_img * sizeof(int32_t), s);   // flags and counts
+	(void)hipMemsetAsync(w.tile_any, 0, 2 * n_img * cdiv(W, TS_WAVE) * cdiv(H, TS_WAVE) * sizeof(int32_t), s);   // flags and counts (both arrays, sized for the finer tiling)
 	hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, w.vproj, faces, fstride, (int)n_views, V, F, H, W,
-					   blur, rp->z_clip, w.frec, w.tb, w.tbb, w.flags, w.tile_any, w.tile_cnt, tiles_x, tiles_per_img);
+					   blur, rp->z_clip, w.frec, w.tb, w.tbb, w.flags, w.tile_any, w.tile_cnt, tiles_x, tiles_per_img, TS);
 	if (image) {
 		(void)hipMemsetAsync(w.normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.normals);
@@ -1155,14 +1196,15 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.rp = *rp;
 	a.frec = w.frec; a.tb = w.tb; a.tbb = w.tbb; a.faces = faces; a.faces_mesh_stride = fstride;
 	a.verts = verts; a.normals = w.normals; a.colors = vert_colors; a.cam = cam;
-	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = (int)cdiv(W, TS);
+	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = tiles_x;
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
 	a.zthr = w.zthr; a.scratch = w.scratch; a.tile_any = w.tile_any; a.tile_order = w.tile_order;
-	a.tiles_per_img = (int)(a.tiles_x * cdiv(H, TS)); a.total_tiles = (int)(a.tiles_per_img * n_img);
+	a.tiles_per_img = tiles_per_img; a.total_tiles = (int)(a.tiles_per_img * n_img);
 	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, w.tile_any, w.tile_cnt, a.total_tiles, w.tile_order);
 	a.ablate = find::g_raster_ablate;
-	hipLaunchKernelGGL(raster_tile_kernel, dim3((unsigned)w.raster_wgs), dim3(256), 0, s, a);
+	if (per_wg) hipLaunchKernelGGL(raster_tile_kernel<4>, dim3((unsigned)std::min<int64_t>(a.total_tiles, w.raster_wgs)), dim3(256), 0, s, a);
+	else hipLaunchKernelGGL(raster_tile_kernel<1>, dim3((unsigned)std::min<int64_t>(cdiv(a.total_tiles, 4), w.raster_wgs)), dim3(256), 0, s, a);
 	FIND_LAUNCH_CHECK("find_render_fwd");
 	return FIND_OK;
 }

@@ -161,8 +161,9 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *                     epilogue, 8 no Fourier features -- results are WRONG with any bit set); "dbg" = device pointer to per-workgroup timers
  * The Python binding applies FIND_TUNING="key=value,..." from the environment to every context it creates. */
 
-/* Process-wide profiling switch of the rasteriser (diagnosis only; any non-zero value other than 64 makes the render WRONG):
- * bits 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 K-pass statistics in the flags. */
+/* Process-wide profiling switch of the rasteriser (diagnosis only; bits 1, 2 and 4 make the render WRONG):
+ * bits 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 64 statistics in the flags, 128 one wave per 8x8 tile instead of
+ * one workgroup per 16x16 tile (same results, measured slower: render.hip). */
 int find_debug_raster_ablate(int64_t bits);
 
 /* ------------------------------------------------------------------------------------------------

@@ -63,7 +63,8 @@ def raster_counts(verts, fc, Rc, Tc, params):
 	N, V = verts.shape[0], verts.shape[1]
 	M, F = Rc.shape[0], fc.shape[0]
 	faces = _faces_i32(fc)
-	_lib.set_tuning('raster_ablate', 64)
+	keep = int(os.environ.get('RASTER_ABLATE_KEEP', '0'))   # bits to keep while counting (128 = the wave-per-tile kernel)
+	_lib.set_tuning('raster_ablate', 64 | keep)
 	try:
 		ws = _ws(L.find_render_ws_bytes(ctypes.byref(params), N, M, V, F), verts.device)
 		mask = torch.empty(N, M, params.image_h, params.image_w, device=verts.device)
@@ -72,7 +73,7 @@ def raster_counts(verts, fc, Rc, Tc, params):
 		torch.cuda.synchronize()
 		fl = ws[:256].view(torch.int32).cpu().tolist()
 	finally:
-		_lib.set_tuning('raster_ablate', 0)
+		_lib.set_tuning('raster_ablate', keep)
 	raster_counts.last_flags = fl
 	return fl[24] * 64, fl[25] * 64, fl[4]
 
@@ -112,6 +113,7 @@ def bench_render(n_feet, n_views, size, want_image, cpu=None):
 			   pixel_face_tests=tests, tests_per_s_fwd=tests / (ms_f * 1e-3), silhouette_candidates=cands, pixels_over_K=over_px,
 			   candidate_list_bytes=8 * cands, lane_efficiency=cands / max(tests, 1),
 			   quadrant_imbalance=4.0 * raster_counts.last_flags[26] / max(raster_counts.last_flags[27], 1),
+			   quadrant_imbalance_per_batch=4.0 * raster_counts.last_flags[28] / max(raster_counts.last_flags[27], 1),
 			   hbm_traffic_bytes_fwd_launch=RASTER_TRAFFIC_C3['raster_tile_kernel'] if (size == 256 and n_feet == 16 and n_views == 4 and not want_image) else None,
 			   bound='latency of the per-tile work (VALU pipe ~22 %% busy, waves wait 60 %% of their time: profiles/r02_raster_pmc.txt), then HBM traffic of the '
 					 'per-pixel candidate lists (8 B per candidate, written once, read ~3x by the K-nearest pass); HBM floor of the fused output %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
