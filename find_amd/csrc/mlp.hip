@@ -1,6 +1,7 @@
 // C-ABI: find_mlp_fwd / find_mlp_bwd  -- launch sequences over the kernels in mlp_kernels.h.
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
 #include "mlp_dw2.h"
+#include "mlp_dw4.h"
 #include "mlp_gemm5.h"
 #include "mlp_dw3.h"
 #include "mlp_gemm4.h"
@@ -134,7 +135,9 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 1;        // the LDS-DMA ring kernels reserve the whole LDS of their CU (see "Co-residence" below)
-	int reduce_exclusive = 0;     // diagnosis only: the slab reduce (16 KB of LDS) reserves its CU's whole LDS instead of the ring kernels
+	int reduce_exclusive = 0;     // diagnosis only: 1 = the slab reduce (16 KB of LDS) reserves its CU's whole LDS; 2 = LDS-free, slow reduce: the stress
+	                              // configuration for the co-residence fault (long-lived foreign waves beside the weight-gradient kernels)
+	int dw_lds_free = 1;          // 256 x 256 weight gradients: 1 = dw4_kernel (operands straight from global memory, no LDS), 0 = dw2_kernel (LDS-DMA ring)
 	int group_spf = 0;            // grouped weight gradients: splits per foot (0 = cost model of group_geometry)
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
 	// internal streams / events
@@ -166,16 +169,32 @@ namespace mlp {
 		if (_r != FIND_OK) return _r;     \
 	} while (0)
 
-// Co-residence fault and the LDS reservation.  The LDS-DMA ring kernels (dw2, gemm3, gemm2, gemm4's prologue) are launched with the
-// WHOLE LDS of a CU although their rings need 100-128 KB.  With a second LDS-using workgroup of another stream resident on the same CU
-// (the 16-KB slab reduce of a side stream is enough) dw2 produced rare wrong partial tiles: one wave reads one 128-byte piece of one
-// staged row with other contents, a rank-1 error of ~1 % in a handful of dW elements -- 3 % of the backward passes at 4 x 1002 rows,
-// 13 % at 16 x 6890, every pass with the dX GEMMs on gemm3 -- with every vmcnt / barrier of the ring in place, and equally with
-// vmcnt(0) everywhere, a one-stage ring, sleeps between the wait and the read, poisoned inputs or device-wide syncs around the call.
-// Alone on the CU's LDS it never happens (tools/check_determinism.py: 0 of 500 passes; 144 KB is not enough), and the register-staged
-// fp16 kernels (gemm5 / dw3: no LDS-DMA, 135 KB, same streams, same co-resident reduce) run clean WITHOUT the reservation.  The
-// reservation takes nothing these kernels use (one workgroup per CU anyway).  The attribute is set per (context, kernel) and its
-// return code is checked: a device that cannot grant the reservation refuses the launch instead of running unprotected.
+// Co-residence fault, the LDS reservation, and what round 2 found.
+// Round 1: with a second workgroup of another stream resident on the same CU, dw2_kernel (weight gradient, both MFMA operands through
+// an LDS-DMA ring, one wave per SIMD, 256 accumulator registers) produced rare wrong partial tiles -- a rank-1 error of ~1 % in a handful
+// of dW elements, 3 % of the backward passes at 4 x 1002 rows, 13 % at 16 x 6890 -- with every vmcnt / barrier of the ring in place, and
+// equally with vmcnt(0) everywhere, a one-stage ring, sleeps between the wait and the read, poisoned inputs or device-wide syncs around the
+// call.  Launching the LDS-DMA ring kernels with the WHOLE LDS of their CU made it disappear (0 of 500 passes), and that reservation was
+// the containment: it was read as "an LDS-using neighbour disturbs the ring".
+// Round 2 (tools/check_determinism.py with the knobs below; every number is wrong tensors per 150-200 passes of a 16 x 6890 backward):
+//   * the neighbour does not need LDS.  With the slab reduce replaced by an LDS-FREE, slow one ("reduce_exclusive" = 2: a thread walks
+//     the slabs alone, so reduces of earlier layers stay resident beside the weight-gradient kernels of later ones) the fault rate goes
+//     from 1 per ~300 passes to ~6 wrong tensors in EVERY pass -- with the whole-LDS reservation ON (it cannot keep an LDS-free kernel
+//     out) as well as off.  The layers that break are exactly those whose dw2 launch overlaps a reduce: never the first large layer;
+//     with the reduce on dw2's own stream the large layers are clean and the first head layers (other streams) break.
+//   * it is not the slabs: a private slab set per weight gradient changes nothing; it is not the ring's contents: every stage of every
+//     chunk compares equal to HBM when it is published AND after the wave has consumed it (2.35 M stages per run, 0 mismatches, fault
+//     present); not the barrier timing (sleep after the barrier, no DMA in flight across it, all counters drained: same rate); not an
+//     M0 hazard (32+ idle cycles between every LDS-DMA instruction and the next M0 write: same rate).
+//   * it is dw2_kernel and only dw2_kernel: with the same weight gradients on dw4_kernel (mlp_dw4.h: the same operand layout read straight
+//     from global memory, two waves per SIMD, no LDS, no barrier) the stress configuration gives 0 wrong tensors in 1000 passes, with and
+//     WITHOUT the reservation on the remaining ring kernels (gemm2 / gemm3 / gemm4's prologue), at batch 16 and batch 1.
+// So the fault needs foreign waves on dw2's SIMDs, not LDS pressure; what inside dw2 they disturb is still not known (its ring protocol
+// holds under every check above; the wrong values enter between the LDS read and the accumulator).  dw4_kernel is the default now
+// ("dw_lds_free" = 1: 148 against 139 us per 110 240-row weight gradient, 0.3 % of the training step); dw2 stays behind the knob as the
+// reproducer.  The reservation is kept for the other ring kernels: it takes nothing they use (one workgroup per CU anyway), and it is
+// what round 1 validated.  The attribute is set per (context, kernel) and its return code is checked: a device that cannot grant the
+// reservation refuses the launch instead of running unprotected.
 template <typename K>
 static int prepare_kernel(find_ctx* c, int id, K kernel, int need_bytes, int* launch_bytes, bool reserve = true) {
 	const int want = (reserve && c->lds_exclusive) ? c->lds_bytes : need_bytes;
@@ -702,7 +721,7 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 
 // (diagnosis) dynamic LDS of the slab reduce: 0, or everything the CU has left beside its 16 KB of static LDS
 static int reduce_lds(find_ctx* c) {
-	if (!c->reduce_exclusive) return 0;
+	if (c->reduce_exclusive != 1) return 0;
 	const int dyn = c->lds_bytes - 16 * 1024 - 256;
 	if (!c->attr_done[K_REDUCE]) {
 		if (hipFuncSetAttribute(reinterpret_cast<const void*>(&reduce_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) return 0;
@@ -752,13 +771,14 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			}
 			nmain = (int)(feet * spf);
 			int lds = 0;
-			FIND_TRY(prepare_kernel(c, K_DW2, &dw2_kernel, DW2_LDS, &lds));
+			if (!c->dw_lds_free) FIND_TRY(prepare_kernel(c, K_DW2, &dw2_kernel, DW2_LDS, &lds));
 			Dw2Args d2;
 			memset(&d2, 0, sizeof(d2));
 			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
 			d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
 			d2.dbg = c->dw2_verify;   // diagnosis: verify every published ring stage (tools/probe_lds_fault.py)
-			hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
+			if (c->dw_lds_free) hipLaunchKernelGGL(dw4_kernel, dim3((unsigned)nmain), dim3(512), 0, s, d2);
+			else hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
 			FIND_LAUNCH_CHECK("dw2_kernel");
 		}
 		ReduceWArgs r;
@@ -766,7 +786,8 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 		r.pw = b.pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = k_valid;
 		r.pb = pbuf; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
 		r.nwblk = 256 * 256 / 4 / 64;
-		hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), reduce_lds(c), reduce_stream(), r);
+		if (c->reduce_exclusive == 2) hipLaunchKernelGGL(reduce_w_nolds_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
+		else hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (pbuf ? (int)feet + 1 : 0))), dim3(1024), reduce_lds(c), reduce_stream(), r);
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
@@ -791,7 +812,8 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	r.pe_map = pe_map; r.pe = p->pe_size; r.in_dim = p->in_dim;
 	r.pb = a.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
 	r.nwblk = 256 * a.Kp / 4 / 64;
-	hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), reduce_lds(c), reduce_stream(), r);
+	if (c->reduce_exclusive == 2) hipLaunchKernelGGL(reduce_w_nolds_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), 0, reduce_stream(), r);
+	else hipLaunchKernelGGL(reduce_w_kernel, dim3((unsigned)(r.nwblk + (a.pb ? (int)feet + 1 : 0))), dim3(1024), reduce_lds(c), reduce_stream(), r);
 	FIND_LAUNCH_CHECK("reduce_w_kernel");
 	return FIND_OK;
 }
@@ -849,10 +871,14 @@ static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const flo
 
 static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 	if (G.n == 0) return FIND_OK;
-	int lds = 0;
-	FIND_TRY(prepare_kernel(c, K_DW2G, &dw2_group_kernel, DW2_LDS, &lds));
-	hipLaunchKernelGGL(dw2_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(256), lds, s, G.d);
-	FIND_LAUNCH_CHECK("dw2_group_kernel");
+	if (c->dw_lds_free) {
+		hipLaunchKernelGGL(dw4_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(512), 0, s, G.d);
+	} else {
+		int lds = 0;
+		FIND_TRY(prepare_kernel(c, K_DW2G, &dw2_group_kernel, DW2_LDS, &lds));
+		hipLaunchKernelGGL(dw2_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(256), lds, s, G.d);
+	}
+	FIND_LAUNCH_CHECK("grouped weight-gradient kernel");
 	hipLaunchKernelGGL(reduce_w_group_kernel, dim3((unsigned)(256 * 256 / 4 / 64 + (int)G.feet + 1), (unsigned)G.n), dim3(1024), 0, s, G.r);
 	FIND_LAUNCH_CHECK("reduce_w_group_kernel");
 	return FIND_OK;
@@ -1296,7 +1322,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 1}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 

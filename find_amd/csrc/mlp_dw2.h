@@ -5,11 +5,10 @@
 // (Tried for the launches with few rows -- the shared trunk's V rows, the texture pass: 64x64 output blocks over 16-64 row splits
 // with both MFMA operands loaded straight from global memory in operand layout, no LDS; 20 us against 25 us in isolation, but no
 // faster inside the step, where these launches overlap the large ones: dropped.)
-// (Tried in round 2 for the large launches as well, to get rid of the LDS ring and its whole-LDS reservation: eight waves, two per SIMD,
-// 128 x 64 tiles, the same operand layout read straight from global memory -- a 16-byte dZ load and an 8-byte X load per k-pair feed 8
-// MFMAs --, a ring of 8 register slots six k-pairs ahead, no LDS, no barrier.  Correct, and no faster: 148 us against 139 us per
-// 110 240-row weight gradient including its slab reduce (this kernel alone is at ~0.77 of the fp32 MFMA peak, not the 0.6 its
-// durations inside the step suggest -- there it shares the CUs with gemm4), 3.65 against 3.61 ms per training step.  Dropped.)
+// ROUND 2: NOT the default any more.  This kernel -- and only this one -- produces rare wrong elements when waves of another kernel share
+// its CU (mlp.hip, "Co-residence fault": reproduced at will, narrowed to this kernel, mechanism unknown); mlp_dw4.h (no LDS, 148 against
+// 139 us per 110 240-row weight gradient including the slab reduce) replaces it.  Kept behind the context knob "dw_lds_free" = 0 as the
+// reproducer and for A/B timing.
 //
 //   * chunk = 16 rows of dZ (16 KB) + 16 rows of X (16 KB), each row one 1-KB global_load_lds_dwordx4; 3-stage ring;
 //   * MFMA operands come from LDS with ONE ds_read_b128 per operand per k-pair: lane l reads columns 4(l&31)..+3 of row
@@ -184,6 +183,8 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 			const char* nsb = smem + ns * DW2_STAGE;
 			const int ahead = issued - (consumed + 2);
 			mfma_step(a0, b0);
+			// (diagnosis) the stage this wave has just consumed must still hold chunk c: stage index + 8 in the log
+			if (g.dbg) dw2_verify_stage(g.dbg, sb, zb + (int64_t)c * 4096, xb + (int64_t)c * 4096, nullptr, nullptr, split, c, cs + 8);
 			if (more) {
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				if (ahead <= 0) FIND_WAIT_VMCNT(0);

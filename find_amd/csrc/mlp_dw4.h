@@ -1,0 +1,140 @@
+// dw4_kernel: weight gradient  dW[n,k] = sum_rows dZ[row,n] * X[row,k]  (256 x 256 output, exact fp32 MFMA) WITHOUT LDS: the default
+// kernel for every 256 x 256 weight gradient since round 2 -- dw2_kernel (mlp_dw2.h), 6 % faster in isolation, produces wrong elements when
+// foreign waves share its CU (mlp.hip, "Co-residence fault"); this kernel is immune (0 wrong tensors in 1000 stress passes).
+// The operand layout of dw2 read straight from global memory.  Lane l of a k-pair (two rows of dZ and X) loads 16 bytes of dZ at
+// columns 4(l&31).. of row 2t + (l>>5) and 8 bytes of X at columns 2(l&31)..; component ja of the first feeds MFMA row-block ja,
+// component jb of the second column-block jb, so accumulator (ja, jb) holds the outputs n = 4i + ja, k = 2j + jb (i, j = MFMA row /
+// column).  Eight waves = two per SIMD: wave (wn, wk) owns n in [128 wn, +128), k in [64 wk, +64): 4 x 2 accumulator blocks.  No LDS,
+// no barrier, no DMA: operands are prefetched DW4_PD k-pairs ahead through a ring of 8 register slots.  Same split geometry and slab
+// layout as dw2 (Dw2Args), so reduce_w_kernel sums the slabs unchanged.
+#pragma once
+#include "mlp_dw2.h"
+
+namespace find {
+namespace mlp {
+
+constexpr int DW4_PD = 6;   // prefetch distance in k-pairs (ring of 8)
+
+__device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wn = wave >> 2, wk = wave & 3;
+	const int li = lane & 31, fh = lane >> 5;
+	const int foot = split / g.spf;
+	const int sidx = split - foot * g.spf;
+	const int q0 = sidx * g.cps;
+	const int q1 = min(q0 + g.cps, g.chunks_per_foot);
+	const int total = max(q1 - q0, 0);            // whole 16-row chunks
+	const int tail = (sidx == g.spf - 1) ? g.tail_rows : 0;
+	float* const pw = g.pw + (int64_t)split * 65536;
+	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
+	const float* const zfoot = g.dz + (int64_t)foot * g.dz_foot_stride;
+	const float* const xfoot = g.x + (int64_t)foot * g.x_foot_stride;
+
+	f32x16 acc[4][2];
+#pragma unroll
+	for (int a = 0; a < 4; ++a)
+#pragma unroll
+		for (int b = 0; b < 2; ++b)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+	float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+	const bool do_bias = pb != nullptr && wk == 0;
+
+	const float* zp = zfoot + ((int64_t)q0 * 16 + fh) * 256 + wn * 128 + 4 * li;
+	const float* xp = xfoot + ((int64_t)q0 * 16 + fh) * 256 + wk * 64 + 2 * li;
+	const int nkp = total * 8;   // k-pairs of the whole chunks
+
+	auto mfma8 = [&](const float4& a, const float2& b) {
+#pragma unroll
+		for (int ja = 0; ja < 4; ++ja) {
+			const float av = ja == 0 ? a.x : (ja == 1 ? a.y : (ja == 2 ? a.z : a.w));
+			acc[ja][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.x, acc[ja][0], 0, 0, 0);
+			acc[ja][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.y, acc[ja][1], 0, 0, 0);
+		}
+	};
+
+	if (nkp > 0) {
+		float4 ra[8];
+		float2 rb[8];
+		// k-pair t lives at row offset 2t: 512 floats further.  Loads past the end of the run re-read its last k-pair (never used).
+		const int last = nkp - 1;
+#pragma unroll
+		for (int t = 0; t < DW4_PD; ++t) {
+			const int tt = min(t, last);
+			ra[t] = *reinterpret_cast<const float4*>(zp + (int64_t)tt * 512);
+			rb[t] = *reinterpret_cast<const float2*>(xp + (int64_t)tt * 512);
+		}
+		for (int t0 = 0; t0 < nkp; t0 += 8) {
+#pragma unroll
+			for (int s = 0; s < 8; ++s) {
+				{
+					const int tt = min(t0 + s + DW4_PD, last);
+					ra[(s + DW4_PD) & 7] = *reinterpret_cast<const float4*>(zp + (int64_t)tt * 512);
+					rb[(s + DW4_PD) & 7] = *reinterpret_cast<const float2*>(xp + (int64_t)tt * 512);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+				const float4 a = ra[s];
+				if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+				mfma8(a, rb[s]);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		}
+	}
+
+	// ---- leftover rows [16 * chunks_per_foot, V) of the foot (last split only): un-pipelined; a row past the end contributes zeros
+	if (tail > 0) {
+		const float* tz = zfoot + ((int64_t)g.chunks_per_foot * 16) * 256 + wn * 128 + 4 * li;
+		const float* tx = xfoot + ((int64_t)g.chunks_per_foot * 16) * 256 + wk * 64 + 2 * li;
+		const int steps = (tail + 1) >> 1;
+		for (int t = 0; t < steps; ++t) {
+			const int row = 2 * t + fh;
+			const bool ok = row < tail;
+			const int rr = min(row, tail - 1);
+			float4 a = *reinterpret_cast<const float4*>(tz + (int64_t)rr * 256);
+			const float2 b = *reinterpret_cast<const float2*>(tx + (int64_t)rr * 256);
+			if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+			mfma8(a, b);
+		}
+	}
+
+	// ---- epilogue: accumulator (ja, jb) element (i, j) is output n = 128 wn + 4 i + ja, k = 64 wk + 2 j + jb;
+	// i = (r & 3) + 8 (r >> 2) + 4 fh, j = lane & 31: a half-wave stores 256 contiguous bytes of one output row.
+	{
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(pw)), 0, 65536 * 4, 0x00020000);
+		const int voff = ((wn * 128 + 16 * fh) * 256 + wk * 64 + 2 * li) * 4;
+#pragma unroll
+		for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int nrow = 4 * ((r & 3) + 8 * (r >> 2)) + ja;
+				typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+				u32x2 v;
+				const float f0 = acc[ja][0][r], f1 = acc[ja][1][r];   // (value copies: __builtin_bit_cast on a vector-element lvalue reads element 0)
+				v.x = __float_as_uint(f0); v.y = __float_as_uint(f1);
+				__builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voff, nrow * 1024, 0);
+			}
+	}
+	if (do_bias) {
+		bsum.x += __shfl_xor(bsum.x, 32, 64); bsum.y += __shfl_xor(bsum.y, 32, 64);
+		bsum.z += __shfl_xor(bsum.z, 32, 64); bsum.w += __shfl_xor(bsum.w, 32, 64);
+		if (fh == 0) *reinterpret_cast<float4*>(pb + wn * 128 + 4 * li) = bsum;
+	}
+}
+
+__global__ __launch_bounds__(512) void dw4_kernel(const Dw2Args g) { dw4_body(g, blockIdx.x); }
+
+// Several weight gradients of the same geometry in ONE launch (blockIdx.y = job), as dw2_group_kernel.
+__global__ __launch_bounds__(512) void dw4_group_kernel(const Dw2Group grp) {
+	const int j = blockIdx.y;
+	Dw2Args g;   // (fields copied one by one: a reference into the kernel-argument array makes the compiler copy the array to scratch)
+	g.dz = grp.job[j].dz; g.dz_foot_stride = grp.job[j].dz_foot_stride; g.x = grp.job[j].x; g.x_foot_stride = grp.job[j].x_foot_stride;
+	g.chunks_per_foot = grp.job[j].chunks_per_foot; g.tail_rows = grp.job[j].tail_rows; g.spf = grp.job[j].spf; g.cps = grp.job[j].cps;
+	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb; g.dbg = nullptr;
+	dw4_body(g, blockIdx.x);
+}
+
+}  // namespace mlp
+}  // namespace find

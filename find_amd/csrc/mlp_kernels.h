@@ -336,6 +336,36 @@ __device__ __forceinline__ void reduce_w_body(const ReduceWArgs& g) {
 
 __global__ __launch_bounds__(1024) void reduce_w_kernel(const ReduceWArgs g) { reduce_w_body(g); }
 
+// Diagnosis only ("reduce_exclusive" = 2): the same sums with NO LDS -- a thread owns its outputs and walks the slabs alone (same grid as
+// reduce_w_kernel, the extra threads idle).  If the rare wrong weight-gradient elements that appear without the whole-LDS reservation
+// (mlp.hip) need the reduce to USE LDS beside a ring kernel, they must vanish under this kernel; if they are a race on the slab buffers,
+// they must not.  (The summation order differs from reduce_w_kernel's: compare runs of this kernel with each other.)
+__global__ __launch_bounds__(1024) void reduce_w_nolds_kernel(const ReduceWArgs g) {
+	const int tid = threadIdx.x;
+	if ((int)blockIdx.x >= g.nwblk) {
+		if (g.pb == nullptr || tid >= 256) return;
+		const int f = (int)blockIdx.x - g.nwblk;
+		const bool all = f >= g.n_feet;
+		if ((!all && g.S == nullptr) || (all && g.db == nullptr)) return;
+		const int lo = all ? 0 : f * g.spf, hi = all ? g.n_feet * g.spf : (f + 1) * g.spf;
+		float s = 0.f;
+		for (int k = lo; k < hi; ++k) s += g.pb[(int64_t)k * 256 + tid];
+		if (all) g.db[tid] = s;
+		else g.S[(int64_t)f * 256 + tid] = s;
+		return;
+	}
+	if (tid >= 256) return;
+	const int64_t e = (int64_t)blockIdx.x * 256 + tid;   // scalar output of the block's 64 float4
+	const int nn = (int)(e / g.Kp), kk = (int)(e - (int64_t)nn * g.Kp);
+	const int64_t stride = (int64_t)256 * g.Kp;
+	float t = 0.f;
+	for (int sidx = 0; sidx < g.nsplit; ++sidx) t += g.pw[e + sidx * stride];
+	int ko;
+	if (g.pe_map) ko = pe_col_to_orig(kk, g.pe, g.in_dim);
+	else ko = (kk < g.K_valid) ? kk : -1;
+	if (ko >= 0) g.out[(int64_t)nn * g.ld_out + ko] = t;
+}
+
 // the slab reduces of a grouped weight-gradient launch (mlp_dw2.h: dw2_group_kernel), blockIdx.y = job
 constexpr int REDUCE_MAX_JOBS = 24;
 struct ReduceWGroup { ReduceWArgs job[REDUCE_MAX_JOBS]; };

@@ -525,3 +525,38 @@ def test_latent_gather_many_and_weighted_terms():
 	assert abs(total.item() - (2500.0 + 3000.0 + 1e-3)) < 1e-3 and abs(scaled[1].item() - 3000.0) < 1e-3
 	(total * 2.0 + scaled[2]).backward()
 	assert [round(r.grad.item(), 4) for r in raws] == [20000.0, 2000.0, 3.0]
+
+
+@pytest.mark.parametrize('n_feet', [16, 1])
+def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet):
+	"""The stress configuration that made round 1's rare fault happen in every pass (mlp.hip, 'Co-residence fault'): the slab reduces are
+	replaced by an LDS-free, slow kernel ("reduce_exclusive" = 2), so that reduces of earlier layers stay resident on the CUs beside the
+	weight-gradient kernels of later layers.  With dw2_kernel (LDS-DMA ring) ~6 weight gradients per pass came out wrong; the LDS-free
+	dw4_kernel, the default, must give bit-identical gradients in every pass, with and without the whole-LDS reservation."""
+	from find_amd import _lib, synthetic
+	dev = torch.device('cuda:0')
+	model = synthetic.make_model(6890, train_size=n_feet, val_size=2, device=dev)
+	lat = synthetic.latents(n_feet, seed=0, device=dev)
+	named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+	def once():
+		for _, p in named:
+			p.grad = None
+		res = model.get_meshes(shapevec=lat['shapevec'], reg=lat['reg'], texvec=lat['texvec'], posevec=lat['posevec'])
+		((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()).backward()
+		torch.cuda.synchronize()
+		return {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+
+	assert _lib.get_tuning('dw_lds_free') == 1
+	_lib.set_tuning('reduce_exclusive', 2)
+	try:
+		for excl in (1, 0):
+			_lib.set_tuning('lds_exclusive', excl)
+			ref = once()
+			for rep in range(30):
+				got = once()
+				bad = [n for n in ref if not torch.equal(got[n], ref[n])]
+				assert not bad, f'lds_exclusive={excl}, pass {rep}: gradients of {bad} differ from the first pass'
+	finally:
+		_lib.set_tuning('reduce_exclusive', 0)
+		_lib.set_tuning('lds_exclusive', 1)

@@ -45,10 +45,13 @@ def once():
 
 ref = once()
 bad = 0
+prev, vs_prev = ref, 0   # how many reps differ from the rep before them (a one-off difference of the first pass shows up as bad >> vs_prev)
 for i in range(reps):
 	if i % 3 == 1:
 		torch.cuda.synchronize(); x = torch.randn(4096, 4096, device=dev); (x @ x).sum().item()  # perturb timing / allocator
 	g = once()
+	vs_prev += int(any(not torch.equal(g[n], prev[n]) for n in ref))
+	prev = g
 	for n in ref:
 		if not torch.equal(g[n], ref[n]):
 			d = (g[n] - ref[n]).abs()
@@ -57,4 +60,4 @@ for i in range(reps):
 			bad += 1
 			if bad <= 4:
 				print('   ', [(int(a), int(b), round(float(d[a, b]), 5)) for a, b in nz.tolist()][:64])
-print('mismatches:', bad)
+print('mismatches:', bad, ' reps that differ from the rep before:', vs_prev)
