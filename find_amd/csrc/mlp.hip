@@ -185,7 +185,9 @@ namespace mlp {
 //   * it is not the slabs: a private slab set per weight gradient changes nothing; it is not the ring's contents: every stage of every
 //     chunk compares equal to HBM when it is published AND after the wave has consumed it (2.35 M stages per run, 0 mismatches, fault
 //     present); not the barrier timing (sleep after the barrier, no DMA in flight across it, all counters drained: same rate); not an
-//     M0 hazard (32+ idle cycles between every LDS-DMA instruction and the next M0 write: same rate).
+//     M0 hazard (32+ idle cycles between every LDS-DMA instruction and the next M0 write: same rate); not a register reuse hazard
+//     (64 idle cycles between every group of MFMAs and the reload of their operand registers: same rate); __syncthreads() instead of
+//     the bare s_barrier: same rate.
 //   * it is dw2_kernel and only dw2_kernel: with the same weight gradients on dw4_kernel (mlp_dw4.h: the same operand layout read straight
 //     from global memory, two waves per SIMD, no LDS, no barrier) the stress configuration gives 0 wrong tensors in 1000 passes, with and
 //     WITHOUT the reservation on the remaining ring kernels (gemm2 / gemm3 / gemm4's prologue), at batch 16 and batch 1.
