@@ -39,7 +39,8 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 		for (int b = 0; b < 2; ++b)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-	float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+	typedef float v2f __attribute__((ext_vector_type(2)));
+	v2f bs01 = {0.f, 0.f}, bs23 = {0.f, 0.f};   // column sums of the dZ values this lane loads
 	const bool do_bias = pb != nullptr && wk == 0;
 
 	const float* zp = zfoot + ((int64_t)q0 * 16 + fh) * 256 + wn * 128 + 4 * li;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 				}
 				__builtin_amdgcn_sched_barrier(0);
 				const float4 a = ra[s];
-				if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+				bs01 += v2f{a.x, a.y}; bs23 += v2f{a.z, a.w};   // (every wave, packed: cheaper than a select; only the wk = 0 waves store it)
 				mfma8(a, rb[s]);
 				__builtin_amdgcn_sched_barrier(0);
 			}
@@ -95,7 +96,7 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 			float4 a = *reinterpret_cast<const float4*>(tz + (int64_t)rr * 256);
 			const float2 b = *reinterpret_cast<const float2*>(tx + (int64_t)rr * 256);
 			if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (do_bias) { bsum.x += a.x; bsum.y += a.y; bsum.z += a.z; bsum.w += a.w; }
+			bs01 += v2f{a.x, a.y}; bs23 += v2f{a.z, a.w};
 			mfma8(a, b);
 		}
 	}
@@ -118,6 +119,8 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 			}
 	}
 	if (do_bias) {
+		// the two row parities of a k-pair sit in the two halves of the wave
+		float4 bsum = make_float4(bs01.x, bs01.y, bs23.x, bs23.y);
 		bsum.x += __shfl_xor(bsum.x, 32, 64); bsum.y += __shfl_xor(bsum.y, 32, 64);
 		bsum.z += __shfl_xor(bsum.z, 32, 64); bsum.w += __shfl_xor(bsum.w, 32, 64);
 		if (fh == 0) *reinterpret_cast<float4*>(pb + wn * 128 + 4 * li) = bsum;
