@@ -113,7 +113,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_DW2G, K_REDUCE, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -134,10 +134,12 @@ struct find_ctx {
 	int reduce_stream = 1;        // slab reduces of the large head layers on their own stream (two alternating slab sets)
 	int gemm5_min_units = 1024;
 	int mlp_f16 = 0;              // default precision of calls that do not name one
-	int lds_exclusive = 1;        // the LDS-DMA ring kernels reserve the whole LDS of their CU (see "Co-residence" below)
+	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which
+	                              // round 2 showed to be about registers, not LDS (see "Co-residence" below); off by default now
 	int reduce_exclusive = 0;     // diagnosis only: 1 = the slab reduce (16 KB of LDS) reserves its CU's whole LDS; 2 = LDS-free, slow reduce: the stress
 	                              // configuration for the co-residence fault (long-lived foreign waves beside the weight-gradient kernels)
-	int dw_lds_free = 1;          // 256 x 256 weight gradients: 1 = dw4_kernel (operands straight from global memory, no LDS), 0 = dw2_kernel (LDS-DMA ring)
+	int dw_lds_free = 1;          // 256 x 256 weight gradients: 1 = dw4_kernel (no LDS, <= 256 registers), 0 = dw2_kernel (LDS-DMA ring, whole register file claimed);
+	                              // reproducers of the co-residence fault: 2 = dw4_wide_kernel (no LDS, 328 registers), 3 = dw2_repro_kernel (312 registers)
 	int group_spf = 0;            // grouped weight gradients: splits per foot (0 = cost model of group_geometry)
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
 	// internal streams / events
@@ -169,34 +171,33 @@ namespace mlp {
 		if (_r != FIND_OK) return _r;     \
 	} while (0)
 
-// Co-residence fault, the LDS reservation, and what round 2 found.
+// Co-residence fault: what it was.
 // Round 1: with a second workgroup of another stream resident on the same CU, dw2_kernel (weight gradient, both MFMA operands through
-// an LDS-DMA ring, one wave per SIMD, 256 accumulator registers) produced rare wrong partial tiles -- a rank-1 error of ~1 % in a handful
-// of dW elements, 3 % of the backward passes at 4 x 1002 rows, 13 % at 16 x 6890 -- with every vmcnt / barrier of the ring in place, and
-// equally with vmcnt(0) everywhere, a one-stage ring, sleeps between the wait and the read, poisoned inputs or device-wide syncs around the
-// call.  Launching the LDS-DMA ring kernels with the WHOLE LDS of their CU made it disappear (0 of 500 passes), and that reservation was
-// the containment: it was read as "an LDS-using neighbour disturbs the ring".
-// Round 2 (tools/check_determinism.py with the knobs below; every number is wrong tensors per 150-200 passes of a 16 x 6890 backward):
-//   * the neighbour does not need LDS.  With the slab reduce replaced by an LDS-FREE, slow one ("reduce_exclusive" = 2: a thread walks
-//     the slabs alone, so reduces of earlier layers stay resident beside the weight-gradient kernels of later ones) the fault rate goes
-//     from 1 per ~300 passes to ~6 wrong tensors in EVERY pass -- with the whole-LDS reservation ON (it cannot keep an LDS-free kernel
-//     out) as well as off.  The layers that break are exactly those whose dw2 launch overlaps a reduce: never the first large layer;
-//     with the reduce on dw2's own stream the large layers are clean and the first head layers (other streams) break.
-//   * it is not the slabs: a private slab set per weight gradient changes nothing; it is not the ring's contents: every stage of every
-//     chunk compares equal to HBM when it is published AND after the wave has consumed it (2.35 M stages per run, 0 mismatches, fault
-//     present); not the barrier timing (sleep after the barrier, no DMA in flight across it, all counters drained: same rate); not an
-//     M0 hazard (32+ idle cycles between every LDS-DMA instruction and the next M0 write: same rate); not a register reuse hazard
-//     (64 idle cycles between every group of MFMAs and the reload of their operand registers: same rate); __syncthreads() instead of
-//     the bare s_barrier: same rate.
-//   * it is dw2_kernel and only dw2_kernel: with the same weight gradients on dw4_kernel (mlp_dw4.h: the same operand layout read straight
-//     from global memory, two waves per SIMD, no LDS, no barrier) the stress configuration gives 0 wrong tensors in 1000 passes, with and
-//     WITHOUT the reservation on the remaining ring kernels (gemm2 / gemm3 / gemm4's prologue), at batch 16 and batch 1.
-// So the fault needs foreign waves on dw2's SIMDs, not LDS pressure; what inside dw2 they disturb is still not known (its ring protocol
-// holds under every check above; the wrong values enter between the LDS read and the accumulator).  dw4_kernel is the default now
-// ("dw_lds_free" = 1: 148 against 139 us per 110 240-row weight gradient, 0.3 % of the training step); dw2 stays behind the knob as the
-// reproducer.  The reservation is kept for the other ring kernels: it takes nothing they use (one workgroup per CU anyway), and it is
-// what round 1 validated.  The attribute is set per (context, kernel) and its return code is checked: a device that cannot grant the
-// reservation refuses the launch instead of running unprotected.
+// an LDS-DMA ring, one wave per SIMD) produced rare wrong partial tiles -- a rank-1 error of ~1 % in a handful of dW elements, 3 % of the
+// backward passes at 4 x 1002 rows, 13 % at 16 x 6890, every pass when the dX GEMMs ran on the masked gemm3 -- with every vmcnt / barrier of
+// the ring in place.  Launching the LDS-DMA ring kernels with the WHOLE LDS of their CU made it disappear (0 of 500 passes) and was taken
+// for the cure: "an LDS-using neighbour disturbs the ring".  It was a coincidence of which neighbours it kept out.
+// Round 2 (tools/check_determinism.py with the knobs named; numbers = wrong tensors per 150 passes of a 16 x 6890 backward):
+//   * a stress configuration reproduces it in EVERY pass: the slab reduce replaced by an LDS-free, slow one ("reduce_exclusive" = 2),
+//     so that reduces of earlier layers stay resident beside the weight-gradient kernels of later ones: ~850 -- with the LDS reservation
+//     on as well as off (it cannot keep an LDS-free kernel out).  The layers that break are exactly those whose weight-gradient launch
+//     overlaps a running reduce; on one stream ("bwd_streams" = 0): 0.
+//   * not the slabs (a private slab set per weight gradient: same rate); not the ring (every stage of every chunk equals HBM when it is
+//     published AND after the wave has consumed it, 2.35 M stages per run); not barrier timing, DMA in flight, M0 hazards, operand-register
+//     reuse, barrier flavour (each padded / changed: same rate).
+//   * not LDS at all: dw4_wide_kernel -- no LDS, no DMA, no barrier, dw2's tile shape read straight from global memory -- breaks the
+//     same way (663), while dw4_kernel, the same code with half the tile per wave, never does (0 in 1450 passes).
+//   * what the victims share is their REGISTER COUNT.  dw2 312, dw2_group 300, dw4_wide 328, the masked gemm3 328 (round 1's "every
+//     pass"): one wave per SIMD with 256 accumulator registers in the AGPR half of the unified file, more than 256 registers in all.
+//     Every kernel that never broke has <= 256.  And dw2 UNCHANGED except for its allocation padded to all 512 registers of the SIMD
+//     (FIND_CLAIM_WHOLE_REGISTER_FILE: no foreign wave fits beside it any more): 0 in 600 passes, LDS reservation off.
+// So: a wave that owns more than 256 registers gets wrong register contents when waves of another kernel are allocated on its SIMD.
+// The kernel descriptors are right (dw2: granulated VGPR count 38 = 312 registers, accum_offset 56); whether the silicon, the firmware's
+// wave save / restore or the runtime mishandles such waves cannot be told from inside a kernel.  The rule that follows, enforced by
+// tests/test_host_api.py on the compiler's output: a kernel either fits in 256 registers or claims the whole file.  dw4_kernel (<= 256,
+// two waves per SIMD, no LDS) is the default weight gradient; dw2 / dw2_group / dw3 claim the file; gemm3 is capped at 256 through its
+// launch bounds; dw2_repro_kernel and dw4_wide_kernel stay as the reproducers ("dw_lds_free" = 3 / 2).  The whole-LDS reservation is
+// off by default ("lds_exclusive"): the stress runs are clean without it, and what it really did was keep most neighbours away.
 template <typename K>
 static int prepare_kernel(find_ctx* c, int id, K kernel, int need_bytes, int* launch_bytes, bool reserve = true) {
 	const int want = (reserve && c->lds_exclusive) ? c->lds_bytes : need_bytes;
@@ -773,13 +774,16 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			}
 			nmain = (int)(feet * spf);
 			int lds = 0;
-			if (!c->dw_lds_free) FIND_TRY(prepare_kernel(c, K_DW2, &dw2_kernel, DW2_LDS, &lds));
+			if (c->dw_lds_free == 0) FIND_TRY(prepare_kernel(c, K_DW2, &dw2_kernel, DW2_LDS, &lds));
+			if (c->dw_lds_free == 3) FIND_TRY(prepare_kernel(c, K_DW2_REPRO, &dw2_repro_kernel, DW2_LDS, &lds));
 			Dw2Args d2;
 			memset(&d2, 0, sizeof(d2));
 			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
 			d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
 			d2.dbg = c->dw2_verify;   // diagnosis: verify every published ring stage (tools/probe_lds_fault.py)
-			if (c->dw_lds_free) hipLaunchKernelGGL(dw4_kernel, dim3((unsigned)nmain), dim3(512), 0, s, d2);
+			if (c->dw_lds_free == 3) hipLaunchKernelGGL(dw2_repro_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
+			else if (c->dw_lds_free == 2) hipLaunchKernelGGL(dw4_wide_kernel, dim3((unsigned)nmain), dim3(256), 0, s, d2);
+			else if (c->dw_lds_free == 1) hipLaunchKernelGGL(dw4_kernel, dim3((unsigned)nmain), dim3(512), 0, s, d2);
 			else hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
 			FIND_LAUNCH_CHECK("dw2_kernel");
 		}
@@ -873,7 +877,7 @@ static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const flo
 
 static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 	if (G.n == 0) return FIND_OK;
-	if (c->dw_lds_free) {
+	if (c->dw_lds_free == 1 || c->dw_lds_free == 2) {
 		hipLaunchKernelGGL(dw4_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(512), 0, s, G.d);
 	} else {
 		int lds = 0;
@@ -1324,7 +1328,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 

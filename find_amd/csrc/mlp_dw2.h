@@ -5,10 +5,11 @@
 // (Tried for the launches with few rows -- the shared trunk's V rows, the texture pass: 64x64 output blocks over 16-64 row splits
 // with both MFMA operands loaded straight from global memory in operand layout, no LDS; 20 us against 25 us in isolation, but no
 // faster inside the step, where these launches overlap the large ones: dropped.)
-// ROUND 2: NOT the default any more.  This kernel -- and only this one -- produces rare wrong elements when waves of another kernel share
-// its CU (mlp.hip, "Co-residence fault": reproduced at will, narrowed to this kernel, mechanism unknown); mlp_dw4.h (no LDS, 148 against
-// 139 us per 110 240-row weight gradient including the slab reduce) replaces it.  Kept behind the context knob "dw_lds_free" = 0 as the
-// reproducer and for A/B timing.
+// ROUND 2: this kernel was the victim of the co-residence fault (mlp.hip): 312 registers per lane, and a wave above 256 registers gets
+// wrong register contents when waves of another kernel share its SIMD.  dw2_kernel now claims the whole register file (nothing fits
+// beside it: 0 wrong tensors in 600 stress passes) and is selectable with "dw_lds_free" = 0; the default is dw4_kernel (mlp_dw4.h: no
+// LDS, <= 256 registers, 148 against 139-142 us per 110 240-row weight gradient including the slab reduce, the same step time);
+// dw2_repro_kernel is the kernel as round 1 had it, the reproducer.
 //
 //   * chunk = 16 rows of dZ (16 KB) + 16 rows of X (16 KB), each row one 1-KB global_load_lds_dwordx4; 3-stage ring;
 //   * MFMA operands come from LDS with ONE ds_read_b128 per operand per k-pair: lane l reads columns 4(l&31)..+3 of row
@@ -263,7 +264,12 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 	}
 }
 
-__global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) { dw2_body(g, blockIdx.x); }
+__global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
+	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 312 registers by itself: the fault's victim (see the macro); with all 512, 0 wrong tensors in 450 stress passes
+	dw2_body(g, blockIdx.x);
+}
+// The kernel as round 1 had it (312 registers, foreign waves fit beside it): the reproducer of the fault ("dw_lds_free" = 3), nothing else.
+__global__ __launch_bounds__(256, 1) void dw2_repro_kernel(const Dw2Args g) { dw2_body(g, blockIdx.x); }
 
 // Several weight gradients of the same geometry in ONE launch (blockIdx.y = job): the small calls -- batch 1, the texture samples --
 // have eleven 256 x 256 weight gradients of 54 workgroups each; launched one by one they neither fill the chip nor overlap well.
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(256, 1) void dw2_group_kernel(const Dw2Group grp) {
 	g.dz = grp.job[j].dz; g.dz_foot_stride = grp.job[j].dz_foot_stride; g.x = grp.job[j].x; g.x_foot_stride = grp.job[j].x_foot_stride;
 	g.chunks_per_foot = grp.job[j].chunks_per_foot; g.tail_rows = grp.job[j].tail_rows; g.spf = grp.job[j].spf; g.cps = grp.job[j].cps;
 	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb; g.dbg = nullptr;
+	FIND_CLAIM_WHOLE_REGISTER_FILE();
 	dw2_body(g, blockIdx.x);
 }
 

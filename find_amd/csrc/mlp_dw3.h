@@ -36,6 +36,7 @@ constexpr int DW3_BUF = 2 * DW3_OPER;          // dZ then X
 constexpr int DW3_LDS = 2 * DW3_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 135 168 B
 
 __global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) {
+	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 432 registers by itself (256 fp32 accumulators in AGPRs): see the macro
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* red = reinterpret_cast<float*>(smem + 2 * DW3_BUF);
 

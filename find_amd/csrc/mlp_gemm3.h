@@ -66,7 +66,9 @@ __device__ __forceinline__ void dma2(const float* base, unsigned dst, unsigned o
 }
 
 template <int BM, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm3_kernel(const Gemm2Args g) {
+// (launch bounds of two workgroups per CU although the ring admits one: that caps the kernel at 256 registers -- the masked variant took 328
+// when it was allowed to, and waves above 256 registers are the victims of the co-residence fault, mlp_kernels.h)
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Args g) {
 	constexpr int MI = BM / 64;
 	constexpr int NI = 4;
 	constexpr int A_BYTES = BM * 128;

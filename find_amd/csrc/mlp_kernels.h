@@ -16,6 +16,12 @@ namespace mlp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// A wave that owns MORE THAN 256 registers (accumulators spilling into the AGPR half of the unified file) gets wrong register contents
+// when waves of another kernel are allocated on the same SIMD (mlp.hip, "Co-residence fault": reproduced at will in round 2 with and
+// without LDS).  Kernels either stay within 256 registers or claim the whole file with this: marking v255 clobbered makes the kernel's
+// allocation 256 architectural + 256 accumulator registers = all 512 of the SIMD, and no other wave fits beside it.
+#define FIND_CLAIM_WHOLE_REGISTER_FILE() asm volatile("" ::: "v255")
+
 constexpr int W = 256;      // hidden width (reference default, model.py:207)
 constexpr int KC = 32;      // K chunk staged through LDS per step
 constexpr int LDSLD = 36;   // padded LDS row stride (floats): ds_read_b128 of 16 rows hits 16 distinct 16-B slots
@@ -134,8 +140,8 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 	const int lr = tid >> 6;         // loader row within an 8-row group
 	const int lc = (tid & 63) * 4;   // loader column
 	// 32-column blocks of this wave that hold any real column.  The Fourier layer's padded K is (pe / 16 + 1) chunks of 32 -- 544 of the
-	// 768 columns its three k-tiles span: the last tile has ONE live block (x, y, z and 29 zeros), and multiplying its other seven
-	// was a third of this kernel's matrix work.
+	// 768 columns its three k-tiles span: the last tile has ONE live block (x, y, z and 29 zeros); six of its eight waves own nothing
+	// but padding, and multiplying it was a third of this kernel's matrix work.
 	int nact = 2;
 	if constexpr (AMODE == AMODE_PE) {
 		const int live = ((g.pe >> 4) + 1) * 32 - (kt * 256 + wk * 64);
@@ -201,7 +207,8 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 
 		const int zo = (lane >> 5) * 256 + wn * 128 + (lane & 31);
 		const int xo = (lane >> 5) * 256 + wk * 64 + (lane & 31);
-		if (nact == 2) {
+		if (nact > 0) {   // (a wave whose two blocks are both padding skips the chunk; one live block still multiplies both: a third
+			            //  code path for it made the compiler spill)
 #pragma unroll
 			for (int t = 0; t < 16; ++t) {
 				float a[4], b[2];
@@ -214,13 +221,6 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 #pragma unroll
 					for (int ni = 0; ni < 2; ++ni)
 						acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-			}
-		} else if (nact == 1) {
-#pragma unroll
-			for (int t = 0; t < 16; ++t) {
-				const float b0 = Xs[xo + t * 512];
-#pragma unroll
-				for (int mi = 0; mi < 4; ++mi) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Zs[zo + t * 512 + mi * 32], b0, acc[mi][0], 0, 0, 0);
 			}
 		}
 	}

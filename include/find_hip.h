@@ -136,7 +136,7 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
 					  void* scratch, int64_t scratch_bytes, void* stream);
 
 /* Tuning / profiling knobs of a context (no reference counterpart).  Results do not depend on any knob except "mlp_f16",
- * "dw_lds_free" = 0 (the fault it reproduces), the summation order of "reduce_exclusive" = 2 and the ablation bits.
+ * "dw_lds_free" = 2 / 3 (the fault they reproduce), the summation order of "reduce_exclusive" = 2 and the ablation bits.
  *   "gemm4_min_units" launches with at least this many 32-row x 128-column units use the W-resident kernel on column halves (default 1024)
  *   "gemm4_small"     ... and launches of at least this many 32-row units use it on column quarters (default 64; 0 = never);
  *                     anything smaller, and the two-segment trunk-output gradient, runs on the LDS-DMA ring kernel (gemm3)
@@ -152,15 +152,15 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
  *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped
  *                     launch + one grouped reduce; 0 = one launch per layer at every size
- *   "dw_lds_free"     1 = the 256 x 256 weight gradients run on dw4_kernel (operands straight from global memory, no LDS; default);
- *                     0 = on dw2_kernel (LDS-DMA ring, 6 % faster in isolation), which produces rare wrong elements when waves of another
- *                     kernel share its CU (mlp.hip, "Co-residence fault") -- reproducer / A-B timing only
- *   "lds_exclusive"   1 = the remaining LDS-DMA ring kernels reserve their CU's whole LDS (default, round 1's containment of that fault)
+ *   "dw_lds_free"     kernel of the 256 x 256 weight gradients: 1 = dw4_kernel (operands straight from global memory, no LDS, <= 256
+ *                     registers; default), 0 = dw2_kernel (LDS-DMA ring, the whole register file of its SIMDs claimed).  2 / 3 =
+ *                     dw4_wide_kernel / dw2_repro_kernel: waves of 328 / 312 registers, the reproducers of the co-residence fault
+ *                     (mlp.hip: wrong weight-gradient elements whenever waves of another kernel share their SIMD) -- diagnosis only
+ *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS: round 1's containment of that fault, which turned out
+ *                     to be about registers; default 0
  *   "reduce_exclusive" diagnosis of the same fault: 1 = the slab-reduce kernels reserve their CU's whole LDS; 2 = they use no LDS and are
  *                     slow, so that they stay resident beside later weight-gradient kernels (the stress configuration: with
- *                     "dw_lds_free" = 0 every backward pass has wrong elements); default 0
- *   "dw2_verify"      device pointer to 8 + 64 * 8 uint64: dw2_kernel re-reads every staged LDS chunk against global memory and logs
- *                     mismatches there (diagnosis only, slows the kernel; 0 = off)
+ *                     "dw_lds_free" = 2 or 3 every backward pass has wrong elements); default 0
  *   "ablate", "dbg"   profiling switches of the GEMM kernels ("ablate" bits in fused_chain_kernel: 1 no W staging, 2 no MFMAs, 4 no
  *                     epilogue, 8 no Fourier features -- results are WRONG with any bit set); "dbg" = device pointer to per-workgroup timers
  * The Python binding applies FIND_TUNING="key=value,..." from the environment to every context it creates. */

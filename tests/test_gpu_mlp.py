@@ -527,12 +527,14 @@ def test_latent_gather_many_and_weighted_terms():
 	assert [round(r.grad.item(), 4) for r in raws] == [20000.0, 2000.0, 3.0]
 
 
-@pytest.mark.parametrize('n_feet', [16, 1])
-def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet):
+@pytest.mark.parametrize('n_feet,variant', [(16, 'dw4'), (1, 'dw4'), (16, 'dw2_whole_file'), (16, 'fp16')])
+def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet, variant):
 	"""The stress configuration that made round 1's rare fault happen in every pass (mlp.hip, 'Co-residence fault'): the slab reduces are
 	replaced by an LDS-free, slow kernel ("reduce_exclusive" = 2), so that reduces of earlier layers stay resident on the CUs beside the
-	weight-gradient kernels of later layers.  With dw2_kernel (LDS-DMA ring) ~6 weight gradients per pass came out wrong; the LDS-free
-	dw4_kernel, the default, must give bit-identical gradients in every pass, with and without the whole-LDS reservation."""
+	weight-gradient kernels of later layers.  The victims were waves that own more than 256 registers (dw2_kernel as round 1 had it: ~6
+	wrong weight gradients per pass).  Every weight-gradient kernel the product can select -- dw4 (<= 256 registers, the default), dw2
+	with the whole register file claimed, the fp16 mode's dw3 likewise -- must give bit-identical gradients in every pass, with and
+	without the LDS reservation."""
 	from find_amd import _lib, synthetic
 	dev = torch.device('cuda:0')
 	model = synthetic.make_model(6890, train_size=n_feet, val_size=2, device=dev)
@@ -547,16 +549,20 @@ def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet):
 		torch.cuda.synchronize()
 		return {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
 
-	assert _lib.get_tuning('dw_lds_free') == 1
+	assert _lib.get_tuning('dw_lds_free') == 1 and _lib.get_tuning('lds_exclusive') == 0
 	_lib.set_tuning('reduce_exclusive', 2)
+	_lib.set_tuning('dw_lds_free', 0 if variant == 'dw2_whole_file' else 1)
+	_lib.set_tuning('mlp_f16', int(variant == 'fp16'))
 	try:
-		for excl in (1, 0):
+		for excl in (0, 1):
 			_lib.set_tuning('lds_exclusive', excl)
 			ref = once()
 			for rep in range(30):
 				got = once()
 				bad = [n for n in ref if not torch.equal(got[n], ref[n])]
-				assert not bad, f'lds_exclusive={excl}, pass {rep}: gradients of {bad} differ from the first pass'
+				assert not bad, f'{variant}, lds_exclusive={excl}, pass {rep}: gradients of {bad} differ from the first pass'
 	finally:
 		_lib.set_tuning('reduce_exclusive', 0)
-		_lib.set_tuning('lds_exclusive', 1)
+		_lib.set_tuning('lds_exclusive', 0)
+		_lib.set_tuning('dw_lds_free', 1)
+		_lib.set_tuning('mlp_f16', 0)

@@ -241,3 +241,40 @@ def test_mlp_precision_switch_round_trip():
 	with pytest.raises(ValueError):
 		F.set_mlp_precision('bf16')
 	assert F.get_mlp_precision() == 'fp32'
+
+
+def test_no_kernel_sits_between_256_and_512_registers():
+	"""The rule round 2 extracted from the co-residence fault (find_amd/csrc/mlp.hip): a wave that owns more than 256 registers is
+	corrupted when waves of another kernel share its SIMD, so a kernel either fits in 256 registers or claims the whole file of 512
+	(FIND_CLAIM_WHOLE_REGISTER_FILE) and has the SIMD to itself.  Checked on the assembly hipcc produces for gfx950 (no GPU needed);
+	the two reproducers of the fault are the only exceptions."""
+	import os
+	import re
+	import shutil
+	import subprocess
+	import tempfile
+	hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+	if not os.path.exists(hipcc):
+		pytest.skip('hipcc not available')
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	csrc = os.path.join(root, 'find_amd', 'csrc')
+	allowed = ('dw2_repro_kernel', 'dw4_wide_kernel')
+	seen = 0
+	with tempfile.TemporaryDirectory() as d:
+		for src in ('mlp.hip', 'render.hip'):
+			out = os.path.join(d, src + '.s')
+			r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(root, 'include'), '-I' + csrc, '-S', '--cuda-device-only',
+								os.path.join(csrc, src), '-o', out], capture_output=True, text=True)
+			assert r.returncode == 0, r.stderr[-2000:]
+			kernel = None
+			for line in open(out):
+				m = re.match(r'\s*\.amdhsa_kernel\s+(\S+)', line)
+				if m:
+					kernel = m.group(1)
+				m = re.match(r'\s*\.amdhsa_next_free_vgpr\s+(\d+)', line)
+				if m and kernel:
+					n = int(m.group(1))
+					seen += 1
+					assert n <= 256 or n == 512 or any(k in kernel for k in allowed), f'{kernel}: {n} registers per lane'
+	assert seen > 30
+	shutil.rmtree(d, ignore_errors=True)
