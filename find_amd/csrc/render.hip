@@ -678,10 +678,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 							unsigned c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
 							int m = 0;
 							scan_z([&](unsigned zb) {
-								if (zb >= lo && zb <= hi) {
-									if (m == 0) c0 = zb; else if (m == 1) c1 = zb; else if (m == 2) c2 = zb; else c3 = zb;
-									++m;
-								}
+								// (selects, not an if-chain: the compiler turned that into a four-element array in scratch)
+								const bool in = zb >= lo && zb <= hi;
+								c0 = (in && m == 0) ? zb : c0; c1 = (in && m == 1) ? zb : c1;
+								c2 = (in && m == 2) ? zb : c2; c3 = (in && m == 3) ? zb : c3;
+								m += in ? 1 : 0;
 							});
 							// sort the four (absent ones are +max) and index
 							unsigned t;
@@ -767,8 +768,10 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						const int32_t* fp = a.faces + (int64_t)mesh * a.faces_mesh_stride + (int64_t)bf * 3;
 						const float bw[3] = {bw0, bw1, bw2};
 						float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
+#pragma unroll
 						for (int k = 0; k < 3; ++k) {
 							const int64_t vo = ((int64_t)mesh * a.V + fp[k]) * 3;
+#pragma unroll
 							for (int c = 0; c < 3; ++c) {
 								pos[c] += bw[k] * a.verts[vo + c];
 								nrm[c] += bw[k] * a.normals[vo + c];
@@ -793,6 +796,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						const float wnum = prob * __expf((z_inv - z_inv_max) / a.rp.rgb_gamma);
 						const float delta = fmaxf(__expf((eps - z_inv_max) / a.rp.rgb_gamma), eps);
 						const float den = wnum + delta;
+#pragma unroll
 						for (int c = 0; c < 3; ++c) {
 							const float col = (a.rp.ambient + diff) * tex[c] + spec;
 							o[c] = (wnum * col + delta * a.rp.background[c]) / den;
