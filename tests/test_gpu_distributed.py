@@ -202,7 +202,7 @@ def test_two_ranks_of_the_find_model_equal_one_process_on_16_feet():
 		err = (g - want).abs().max().item() / scale
 		worst = max(worst, err)
 		# fp32 sums in a different order (two partial batches, then their mean) against one pass over 16 feet
-		if err >= 1e-5:   # say where: a handful of elements of one weight gradient is the signature of the LDS co-residence fault (mlp.hip)
+		if err >= 1e-5:   # say where: a handful of elements of one weight gradient was the signature of the co-residence fault (mlp.hip: waves above 256 registers)
 			d = (g - want).abs()
 			bad = (d > 1e-5 * scale).nonzero()
 			raise AssertionError(f'{tuple(p.shape)}: relative error {err:.3e}; {bad.shape[0]} element(s) off, first at {bad[:8].tolist()}, '
