@@ -174,7 +174,7 @@ namespace mlp {
 // Co-residence fault: what it was.
 // Round 1: with a second workgroup of another stream resident on the same CU, dw2_kernel (weight gradient, both MFMA operands through
 // an LDS-DMA ring, one wave per SIMD) produced rare wrong partial tiles -- a rank-1 error of ~1 % in a handful of dW elements, 3 % of the
-// backward passes at 4 x 1002 rows, 13 % at 16 x 6890, every pass when the dX GEMMs ran on the masked gemm3 -- with every vmcnt / barrier of
+// backward passes at 4 x 1002 rows, 13 % at 16 x 6890, every pass when the dX GEMMs ran on gemm3 beside it -- with every vmcnt / barrier of
 // the ring in place.  Launching the LDS-DMA ring kernels with the WHOLE LDS of their CU made it disappear (0 of 500 passes) and was taken
 // for the cure: "an LDS-using neighbour disturbs the ring".  It was a coincidence of which neighbours it kept out.
 // Round 2 (tools/check_determinism.py with the knobs named; numbers = wrong tensors per 150 passes of a 16 x 6890 backward):
@@ -187,14 +187,18 @@ namespace mlp {
 //     reuse, barrier flavour (each padded / changed: same rate).
 //   * not LDS at all: dw4_wide_kernel -- no LDS, no DMA, no barrier, dw2's tile shape read straight from global memory -- breaks the
 //     same way (663), while dw4_kernel, the same code with half the tile per wave, never does (0 in 1450 passes).
-//   * what the victims share is their REGISTER COUNT.  dw2 312, dw2_group 300, dw4_wide 328, the masked gemm3 328 (round 1's "every
-//     pass"): one wave per SIMD with 256 accumulator registers in the AGPR half of the unified file, more than 256 registers in all.
-//     Every kernel that never broke has <= 256.  And dw2 UNCHANGED except for its allocation padded to all 512 registers of the SIMD
-//     (FIND_CLAIM_WHOLE_REGISTER_FILE: no foreign wave fits beside it any more): 0 in 600 passes, LDS reservation off.
-// So: a wave that owns more than 256 registers gets wrong register contents when waves of another kernel are allocated on its SIMD.
+//   * what the victims share is their REGISTER SHAPE: dw2 312, dw2_group 300, dw4_wide 328 registers per lane -- all 256 accumulator
+//     registers (the whole AGPR set) behind fewer than 256 architectural ones, one wave per SIMD.  Every kernel with at most 256 registers
+//     was clean; so was the masked gemm3 when it still took 328 (200 architectural + 128 accumulator registers: 0 in 160 stress passes,
+//     rebuilt with -DFIND_GEMM3_MIN_WGS=1), so the trigger is narrower than "more than 256".  And dw2 UNCHANGED except for its allocation
+//     padded to all 512 registers of the SIMD (FIND_CLAIM_WHOLE_REGISTER_FILE: no foreign wave fits beside it any more): 0 in 600
+//     passes, LDS reservation off.
+// So: a wave that owns the full accumulator set within an allocation of fewer than 512 registers gets wrong register contents when
+// waves of another kernel are allocated on its SIMD.
 // The kernel descriptors are right (dw2: granulated VGPR count 38 = 312 registers, accum_offset 56); whether the silicon, the firmware's
-// wave save / restore or the runtime mishandles such waves cannot be told from inside a kernel.  The rule that follows, enforced by
-// tests/test_host_api.py on the compiler's output: a kernel either fits in 256 registers or claims the whole file.  dw4_kernel (<= 256,
+// wave save / restore or the runtime mishandles such waves cannot be told from inside a kernel (a stand-alone two-kernel program with a
+// 292-register victim ran clean: something else of the step's setting takes part).  The rule adopted, a superset of every shape that
+// broke and enforced by tests/test_host_api.py on the compiler's output: a kernel either fits in 256 registers or claims the whole file.  dw4_kernel (<= 256,
 // two waves per SIMD, no LDS) is the default weight gradient; dw2 / dw2_group / dw3 claim the file; gemm3 is capped at 256 through its
 // launch bounds; dw2_repro_kernel and dw4_wide_kernel stay as the reproducers ("dw_lds_free" = 3 / 2).  The whole-LDS reservation is
 // off by default ("lds_exclusive"): the stress runs are clean without it, and what it really did was keep most neighbours away.

@@ -67,8 +67,12 @@ __device__ __forceinline__ void dma2(const float* base, unsigned dst, unsigned o
 
 template <int BM, int EPI>
 // (launch bounds of two workgroups per CU although the ring admits one: that caps the kernel at 256 registers -- the masked variant took 328
-// when it was allowed to, and waves above 256 registers are the victims of the co-residence fault, mlp_kernels.h)
-__global__ __launch_bounds__(256, 2) void gemm3_kernel(const Gemm2Args g) {
+// when it was allowed to -- in line with the rule that came out of the co-residence fault, mlp_kernels.h.  The 328-register build itself ran
+// clean under the stress configuration: the cap is policy, not a fix.)
+#ifndef FIND_GEMM3_MIN_WGS
+#define FIND_GEMM3_MIN_WGS 2   // (-DFIND_GEMM3_MIN_WGS=1 rebuilds the 328-register variant)
+#endif
+__global__ __launch_bounds__(256, FIND_GEMM3_MIN_WGS) void gemm3_kernel(const Gemm2Args g) {
 	constexpr int MI = BM / 64;
 	constexpr int NI = 4;
 	constexpr int A_BYTES = BM * 128;

@@ -16,10 +16,11 @@ namespace mlp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// A wave that owns MORE THAN 256 registers (accumulators spilling into the AGPR half of the unified file) gets wrong register contents
-// when waves of another kernel are allocated on the same SIMD (mlp.hip, "Co-residence fault": reproduced at will in round 2 with and
-// without LDS).  Kernels either stay within 256 registers or claim the whole file with this: marking v255 clobbered makes the kernel's
-// allocation 256 architectural + 256 accumulator registers = all 512 of the SIMD, and no other wave fits beside it.
+// Waves that own all 256 accumulator registers inside an allocation of fewer than 512 (300 - 328 registers per lane in the kernels
+// that showed it) get wrong register contents when waves of another kernel are allocated on the same SIMD (mlp.hip, "Co-residence
+// fault": reproduced at will in round 2, with and without LDS in the victim).  Policy: a kernel either stays within 256 registers or
+// claims the whole file with this -- marking v255 clobbered makes the allocation 256 architectural + 256 accumulator registers = all 512
+// of the SIMD, and no other wave fits beside it.
 #define FIND_CLAIM_WHOLE_REGISTER_FILE() asm volatile("" ::: "v255")
 
 constexpr int W = 256;      // hidden width (reference default, model.py:207)

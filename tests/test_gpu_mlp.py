@@ -531,8 +531,8 @@ def test_latent_gather_many_and_weighted_terms():
 def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet, variant):
 	"""The stress configuration that made round 1's rare fault happen in every pass (mlp.hip, 'Co-residence fault'): the slab reduces are
 	replaced by an LDS-free, slow kernel ("reduce_exclusive" = 2), so that reduces of earlier layers stay resident on the CUs beside the
-	weight-gradient kernels of later layers.  The victims were waves that own more than 256 registers (dw2_kernel as round 1 had it: ~6
-	wrong weight gradients per pass).  Every weight-gradient kernel the product can select -- dw4 (<= 256 registers, the default), dw2
+	weight-gradient kernels of later layers.  The victims were waves with the full accumulator set in a 300-328 register allocation (dw2_kernel as round 1
+	had it: ~6 wrong weight gradients per pass).  Every weight-gradient kernel the product can select -- dw4 (<= 256 registers, the default), dw2
 	with the whole register file claimed, the fp16 mode's dw3 likewise -- must give bit-identical gradients in every pass, with and
 	without the LDS reservation."""
 	from find_amd import _lib, synthetic
