@@ -90,24 +90,36 @@ __global__ void sample_bwd_kernel(const int32_t* __restrict__ faces, int64_t fac
 
 // Sampler with the face choice on the device: pytorch3d.ops.sample_points_from_meshes draws faces ~ multinomial(area) with
 // replacement; torch.multinomial normalises the weights, builds their running sum and searches it with a uniform draw -- five
-// launches and a 13 776-element scan per mesh.  Here: face_areas_kernel, one block per mesh turns the areas into their running sum
-// in place (rounds of 4096 faces, four per thread, block scan of the 1024 four-face totals), then one thread per sample searches it
-// with its own uniform draw r in [0,1): the first face whose running sum exceeds r * total.  Faces of zero area (the -1 padding of
-// ragged batches included) can never be that first face.
+// launches and a 13 776-element scan per mesh.  Here: face_areas_kernel (the vertex gathers spread over the whole chip), one block per
+// mesh turns the areas into their running sum in place (rounds of 16 384 faces, sixteen consecutive ones per thread, block scan of the
+// 1024 per-thread totals), then one thread per sample searches it with its own uniform draw r in [0,1): the first face whose running
+// sum exceeds r * total.  Faces of zero area (the -1 padding of ragged batches included) can never be that first face.
+// (Measured and dropped: areas computed inside the scan block -- one launch less, but a mesh's 13 776 x 12 scattered loads then go
+// through ONE CU's L1: 44 - 67 us against 5 + 12.)
+constexpr int CDF_PER = 16;
 __global__ __launch_bounds__(1024) void area_scan_kernel(int n_faces, float* __restrict__ cdf /* in: areas, out: their running sum */) {
 	__shared__ float wsum[16];
 	float* out = cdf + (int64_t)blockIdx.x * n_faces;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const bool vec = (n_faces & 3) == 0;   // rows of the (n_meshes, n_faces) buffer stay 16-byte aligned
 	float carry = 0.f;   // running sum of the faces before this round (the same value in every thread)
-	// rounds of 4096 faces: a thread takes 4 consecutive areas, the block scans the 1024 four-face totals -- shuffles inside the wave,
-	// LDS across the 16 waves: a fixed order, so the result is deterministic
-	for (int f0 = 0; f0 < n_faces; f0 += 4096) {
-		const int f = f0 + 4 * (int)threadIdx.x;
-		float a[4];
+	// a fixed order -- consecutive faces inside a thread, shuffles inside the wave, LDS across the 16 waves --, so the result is deterministic
+	for (int f0 = 0; f0 < n_faces; f0 += 1024 * CDF_PER) {
+		const int f = f0 + CDF_PER * (int)threadIdx.x;
+		float a[CDF_PER];
+		if (vec && f + CDF_PER <= n_faces) {
 #pragma unroll
-		for (int k = 0; k < 4; ++k) a[k] = f + k < n_faces ? out[f + k] : 0.f;
-		a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
-		float inc = a[3];
+			for (int k = 0; k < CDF_PER; k += 4) {
+				const float4 t = *reinterpret_cast<const float4*>(out + f + k);
+				a[k] = t.x; a[k + 1] = t.y; a[k + 2] = t.z; a[k + 3] = t.w;
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < CDF_PER; ++k) a[k] = f + k < n_faces ? out[f + k] : 0.f;
+		}
+#pragma unroll
+		for (int k = 1; k < CDF_PER; ++k) a[k] += a[k - 1];
+		float inc = a[CDF_PER - 1];
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
 			const float t = __shfl_up(inc, o, 64);
@@ -121,10 +133,16 @@ __global__ __launch_bounds__(1024) void area_scan_kernel(int n_faces, float* __r
 			if (w < wave) base += wsum[w];
 			total += wsum[w];
 		}
-		const float off = base + (inc - a[3]);
+		const float off = base + (inc - a[CDF_PER - 1]);
+		if (vec && f + CDF_PER <= n_faces) {
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
-			if (f + k < n_faces) out[f + k] = off + a[k];
+			for (int k = 0; k < CDF_PER; k += 4)
+				*reinterpret_cast<float4*>(out + f + k) = make_float4(off + a[k], off + a[k + 1], off + a[k + 2], off + a[k + 3]);
+		} else {
+#pragma unroll
+			for (int k = 0; k < CDF_PER; ++k)
+				if (f + k < n_faces) out[f + k] = off + a[k];
+		}
 		carry = total;
 	}
 }
@@ -466,62 +484,83 @@ __global__ void cot_weights_kernel(const float* __restrict__ verts, const int32_
 
 // r_i = sum over incident corners of [ w1 * q_j1 + w2 * q_j2 ]  (= (L q)_i),  rowsum_i = sum (w1 + w2).
 // Corner c of face (a0,a1,a2) sees neighbour a[(c+1)%3] with weight cot[(c+2)%3] and a[(c+2)%3] with weight cot[(c+1)%3].
-__device__ __forceinline__ void apply_L(const float* __restrict__ q, const int32_t* __restrict__ faces, const float* __restrict__ fw,
-										const int32_t* __restrict__ vf_off, const int32_t* __restrict__ vf_items, int i,
+// FOUR LANES PER VERTEX: lane t of a quad walks the corner entries lo + t, lo + t + 4, ... and the quad adds up with two xor-shuffles.
+// Every entry is a chain of dependent loads (item -> face corners -> vertex rows), so a vertex of valence 6 was six such chains one
+// after the other in one lane (40 us for 16 x 6890 vertices, most of the chip idle); per quad lane it is at most two.
+// Every lane of the wave has to call this (shuffles): a quad whose vertex is past the end passes live = false.
+__device__ __forceinline__ float quad_sum(float v) {
+	v += __shfl_xor(v, 1, 64);
+	v += __shfl_xor(v, 2, 64);
+	return v;
+}
+
+// Q(j) -> float3: the vector of vertex j the operator is applied to
+template <typename Q>
+__device__ __forceinline__ void apply_L(Q qv, const int32_t* __restrict__ faces, const float* __restrict__ fw,
+										const int32_t* __restrict__ vf_off, const int32_t* __restrict__ vf_items, int i, int t, bool live,
 										float3* r, float* rowsum) {
 	float3 acc = make_float3(0.f, 0.f, 0.f);
 	float rs = 0.f;
-	for (int e = vf_off[i]; e < vf_off[i + 1]; ++e) {
-		const int item = vf_items[e];
-		const int f = item / 3, c = item - f * 3;
-		const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-		const int j1 = faces[f * 3 + c1], j2 = faces[f * 3 + c2];
-		const float w1 = fw[f * 3 + c2], w2 = fw[f * 3 + c1];
-		const float3 a = ld3(q + 3 * j1), b = ld3(q + 3 * j2);
-		acc.x += w1 * a.x + w2 * b.x; acc.y += w1 * a.y + w2 * b.y; acc.z += w1 * a.z + w2 * b.z;
-		rs += w1 + w2;
+	if (live) {
+		const int hi = vf_off[i + 1];
+		for (int e = vf_off[i] + t; e < hi; e += 4) {
+			const int item = vf_items[e];
+			const int f = item / 3, c = item - f * 3;
+			const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+			const int j1 = faces[f * 3 + c1], j2 = faces[f * 3 + c2];
+			const float w1 = fw[f * 3 + c2], w2 = fw[f * 3 + c1];
+			const float3 a = qv(j1), b = qv(j2);
+			acc.x += w1 * a.x + w2 * b.x; acc.y += w1 * a.y + w2 * b.y; acc.z += w1 * a.z + w2 * b.z;
+			rs += w1 + w2;
+		}
 	}
-	*r = acc;
-	*rowsum = rs;
+	*r = make_float3(quad_sum(acc.x), quad_sum(acc.y), quad_sum(acc.z));
+	*rowsum = quad_sum(rs);
 }
+
+constexpr int SMOOTH_VPB = 256;   // vertices per block: 1024 threads = 256 quads
 
 // forward per vertex: lap = (L V)_i * nw_i - V_i; block partial sums of |lap| and of the half edge-length sums.
 // Saves nw_i (rowsum>0 ? 1/rowsum : rowsum) and u_i = lap_i/|lap_i| scaled later in backward.
-__global__ __launch_bounds__(256) void smooth_fwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
-														  const float* __restrict__ fw, const int32_t* __restrict__ vf_off,
-														  const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
-														  const int32_t* __restrict__ nbr_idx, int n_verts, int n_faces,
-														  float* __restrict__ nw_out, float* __restrict__ lapdir_out,
-														  float* __restrict__ partial /* [n_meshes][gridDim.x][2] */) {
+__global__ __launch_bounds__(1024) void smooth_fwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+														   const float* __restrict__ fw, const int32_t* __restrict__ vf_off,
+														   const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
+														   const int32_t* __restrict__ nbr_idx, int n_verts, int n_faces,
+														   float* __restrict__ nw_out, float* __restrict__ lapdir_out,
+														   float* __restrict__ partial /* [n_meshes][gridDim.x][2] */) {
 	const int m = blockIdx.y;
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int i = blockIdx.x * SMOOTH_VPB + ((int)threadIdx.x >> 2), t = threadIdx.x & 3;
+	const bool live = i < n_verts;
 	const float* vp = verts + (int64_t)m * n_verts * 3;
+	float3 r;
+	float rs;
+	apply_L([&](int j) { return ld3(vp + 3 * j); }, faces, fw + (int64_t)m * n_faces * 3, vf_off, vf_items, i, t, live, &r, &rs);
 	float lap_n = 0.f, edge_s = 0.f;
-	if (i < n_verts) {
-		float3 r;
-		float rs;
-		apply_L(vp, faces, fw + (int64_t)m * n_faces * 3, vf_off, vf_items, i, &r, &rs);
-		const float nw = rs > 0.f ? 1.0f / rs : rs;
+	if (live) {
 		const float3 v = ld3(vp + 3 * i);
-		const float3 lap = make_float3(r.x * nw - v.x, r.y * nw - v.y, r.z * nw - v.z);
-		lap_n = norm3(lap);
-		const float inv = lap_n > 0.f ? 1.0f / lap_n : 0.f;
-		const int64_t o = (int64_t)m * n_verts + i;
-		nw_out[o] = nw;
-		lapdir_out[o * 3 + 0] = lap.x * inv; lapdir_out[o * 3 + 1] = lap.y * inv; lapdir_out[o * 3 + 2] = lap.z * inv;
-		for (int e = nbr_off[i]; e < nbr_off[i + 1]; ++e) {
+		const int hi = nbr_off[i + 1];
+		for (int e = nbr_off[i] + t; e < hi; e += 4) {
 			const float3 d = sub3(v, ld3(vp + 3 * nbr_idx[e]));
 			edge_s += d.x * d.x + d.y * d.y + d.z * d.z;  // every undirected edge is visited from both ends
 		}
+		if (t == 0) {
+			const float nw = rs > 0.f ? 1.0f / rs : rs;
+			const float3 lap = make_float3(r.x * nw - v.x, r.y * nw - v.y, r.z * nw - v.z);
+			lap_n = norm3(lap);
+			const float inv = lap_n > 0.f ? 1.0f / lap_n : 0.f;
+			const int64_t o = (int64_t)m * n_verts + i;
+			nw_out[o] = nw;
+			lapdir_out[o * 3 + 0] = lap.x * inv; lapdir_out[o * 3 + 1] = lap.y * inv; lapdir_out[o * 3 + 2] = lap.z * inv;
+		}
 	}
-	__shared__ float red[2][4];
+	__shared__ float red[2][16];
 	const float a = wave_sum(lap_n), b = wave_sum(edge_s);
 	if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		float* p = partial + ((int64_t)m * gridDim.x + blockIdx.x) * 2;
-		p[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-		p[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+	if (threadIdx.x < 2) {
+		float sum = 0.f;
+		for (int w = 0; w < 16; ++w) sum += red[threadIdx.x][w];
+		partial[((int64_t)m * gridDim.x + blockIdx.x) * 2 + threadIdx.x] = sum;
 	}
 }
 
@@ -542,49 +581,49 @@ __global__ void smooth_finalize_kernel(const float* __restrict__ partial, int n_
 }
 
 // backward: with u_i = g_lap/(V N) * lapdir_i and q_i = nw_i * u_i:   dV_i = (L q)_i - u_i  +  g_edge/(E N) * 2 * sum_j (v_i - v_j)
-__global__ void smooth_bwd_q_kernel(const float* __restrict__ nw, const float* __restrict__ lapdir, const float* __restrict__ g_lap, float s_lap,
-									int n_meshes, int n_verts, float* __restrict__ q) {
-	const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (o >= (int64_t)n_meshes * n_verts) return;
-	const float s = (*g_lap) * s_lap / (float)n_verts / (float)n_meshes * nw[o];
-	q[o * 3 + 0] = s * lapdir[o * 3 + 0]; q[o * 3 + 1] = s * lapdir[o * 3 + 1]; q[o * 3 + 2] = s * lapdir[o * 3 + 2];
-}
-
-__global__ __launch_bounds__(256) void smooth_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
-														  const float* __restrict__ fw, const int32_t* __restrict__ vf_off,
-														  const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
-														  const int32_t* __restrict__ nbr_idx, const float* __restrict__ q,
-														  const float* __restrict__ lapdir, const float* __restrict__ g_edge,
-														  const float* __restrict__ g_lap, float s_edge, float s_lap, int n_meshes, int n_verts,
-														  int n_faces, int n_edges, float* __restrict__ d_verts) {
+// (q is formed where it is read -- nw_j and lapdir_j instead of a stored q_j: one launch and one (N, V, 3) buffer less)
+__global__ __launch_bounds__(1024) void smooth_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+														   const float* __restrict__ fw, const int32_t* __restrict__ vf_off,
+														   const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
+														   const int32_t* __restrict__ nbr_idx, const float* __restrict__ nw,
+														   const float* __restrict__ lapdir, const float* __restrict__ g_edge,
+														   const float* __restrict__ g_lap, float s_edge, float s_lap, int n_meshes, int n_verts,
+														   int n_faces, int n_edges, float* __restrict__ d_verts) {
 	const int m = blockIdx.y;
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_verts) return;
+	const int i = blockIdx.x * SMOOTH_VPB + ((int)threadIdx.x >> 2), t = threadIdx.x & 3;
+	const bool live = i < n_verts;
 	const float* vp = verts + (int64_t)m * n_verts * 3;
-	const float* qp = q + (int64_t)m * n_verts * 3;
+	const float* nwp = nw + (int64_t)m * n_verts;
+	const float* ldp = lapdir + (int64_t)m * n_verts * 3;
+	const float su = (*g_lap) * s_lap / (float)n_verts / (float)n_meshes;
 	float3 r;
 	float rs;
-	apply_L(qp, faces, fw + (int64_t)m * n_faces * 3, vf_off, vf_items, i, &r, &rs);
-	const int64_t o = (int64_t)m * n_verts + i;
-	const float su = (*g_lap) * s_lap / (float)n_verts / (float)n_meshes;
-	float3 g = make_float3(r.x - su * lapdir[o * 3 + 0], r.y - su * lapdir[o * 3 + 1], r.z - su * lapdir[o * 3 + 2]);
-	const float se = 2.0f * (*g_edge) * s_edge / (float)n_edges / (float)n_meshes;
-	const float3 v = ld3(vp + 3 * i);
+	apply_L([&](int j) { const float sj = su * nwp[j]; const float3 u = ld3(ldp + 3 * j); return make_float3(sj * u.x, sj * u.y, sj * u.z); },
+			faces, fw + (int64_t)m * n_faces * 3, vf_off, vf_items, i, t, live, &r, &rs);
 	float3 es = make_float3(0.f, 0.f, 0.f);
-	for (int e = nbr_off[i]; e < nbr_off[i + 1]; ++e) {
-		const float3 d = sub3(v, ld3(vp + 3 * nbr_idx[e]));
-		es.x += d.x; es.y += d.y; es.z += d.z;
+	float3 v = es;
+	if (live) {
+		v = ld3(vp + 3 * i);
+		const int hi = nbr_off[i + 1];
+		for (int e = nbr_off[i] + t; e < hi; e += 4) {
+			const float3 d = sub3(v, ld3(vp + 3 * nbr_idx[e]));
+			es.x += d.x; es.y += d.y; es.z += d.z;
+		}
 	}
-	d_verts[o * 3 + 0] = g.x + se * es.x;
-	d_verts[o * 3 + 1] = g.y + se * es.y;
-	d_verts[o * 3 + 2] = g.z + se * es.z;
+	es = make_float3(quad_sum(es.x), quad_sum(es.y), quad_sum(es.z));
+	if (live && t == 0) {
+		const int64_t o = (int64_t)m * n_verts + i;
+		const float se = 2.0f * (*g_edge) * s_edge / (float)n_edges / (float)n_meshes;
+		d_verts[o * 3 + 0] = r.x - su * ldp[3 * i + 0] + se * es.x;
+		d_verts[o * 3 + 1] = r.y - su * ldp[3 * i + 1] + se * es.y;
+		d_verts[o * 3 + 2] = r.z - su * ldp[3 * i + 2] + se * es.z;
+	}
 }
 
 struct SmoothWs {
 	float* fw;       // (n_meshes, n_faces, 3)
 	float* nw;       // (n_meshes, n_verts)
 	float* lapdir;   // (n_meshes, n_verts, 3)
-	float* q;        // (n_meshes, n_verts, 3)
 	float* partial;  // (n_meshes, nblk, 2)
 	int nblk;
 	int64_t bytes;
@@ -592,11 +631,10 @@ struct SmoothWs {
 
 static void carve_smooth(int64_t n_meshes, int64_t n_verts, int64_t n_faces, void* ws, SmoothWs* o) {
 	Carver c(ws);
-	o->nblk = (int)cdiv(n_verts, 256);
+	o->nblk = (int)cdiv(n_verts, SMOOTH_VPB);
 	o->fw = c.take<float>(n_meshes * n_faces * 3);
 	o->nw = c.take<float>(n_meshes * n_verts);
 	o->lapdir = c.take<float>(n_meshes * n_verts * 3);
-	o->q = c.take<float>(n_meshes * n_verts * 3);
 	o->partial = c.take<float>(n_meshes * o->nblk * 2);
 	o->bytes = c.off;
 }
@@ -807,7 +845,7 @@ static int smooth_fwd_body(const char* who, const float* verts, const int32_t* f
 	if (ws_bytes < w.bytes) { set_error("%s: workspace too small", who); return FIND_EWORKSPACE; }
 	hipStream_t s = (hipStream_t)stream;
 	hipLaunchKernelGGL(cot_weights_kernel, dim3((unsigned)cdiv(n_faces, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, (int)n_verts, (int)n_faces, w.fw);
-	hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off,
+	hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(1024), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off,
 					   nbr_idx, (int)n_verts, (int)n_faces, w.nw, w.lapdir, w.partial);
 	hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(64), 0, s, w.partial, (int)n_meshes, w.nblk, (int)n_verts, (int)n_edges, loss_edge, loss_lap,
 					   w_edge, w_lap, loss_sum);
@@ -824,9 +862,8 @@ static int smooth_bwd_body(const char* who, const float* verts, const int32_t* f
 	carve_smooth(n_meshes, n_verts, n_faces, ws, &w);
 	if (ws_bytes < w.bytes) { set_error("%s: workspace too small", who); return FIND_EWORKSPACE; }
 	hipStream_t s = (hipStream_t)stream;
-	hipLaunchKernelGGL(smooth_bwd_q_kernel, dim3((unsigned)cdiv(n_meshes * n_verts, 256)), dim3(256), 0, s, w.nw, w.lapdir, g_lap, s_lap, (int)n_meshes, (int)n_verts, w.q);
-	hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off, nbr_idx,
-					   w.q, w.lapdir, g_edge, g_lap, s_edge, s_lap, (int)n_meshes, (int)n_verts, (int)n_faces, (int)n_edges, d_verts);
+	hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(1024), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off, nbr_idx,
+					   w.nw, w.lapdir, g_edge, g_lap, s_edge, s_lap, (int)n_meshes, (int)n_verts, (int)n_faces, (int)n_edges, d_verts);
 	FIND_LAUNCH_CHECK(who);
 	return FIND_OK;
 }

@@ -379,6 +379,19 @@ __global__ __launch_bounds__(1024) void reduce_w_group_kernel(const ReduceWGroup
 	reduce_w_body(g);
 }
 
+// Exact zeros into up to ZERO_MAX_JOBS buffers in one launch (grid (blocks, jobs)): the gradients of the parts a call skipped.
+constexpr int ZERO_MAX_JOBS = 24;
+struct ZeroArgs {
+	float* p[ZERO_MAX_JOBS];
+	int64_t n[ZERO_MAX_JOBS];
+	int njobs;
+};
+__global__ __launch_bounds__(256) void zero_many_kernel(const ZeroArgs a) {
+	float* __restrict__ p = a.p[blockIdx.y];
+	const int64_t n = a.n[blockIdx.y];
+	for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+
 // Shared-template backward of a head's first layer: because every foot multiplies the SAME trunk rows,
 //   sum_b dZ0[b,v,:] @ W  ==  (sum_b dZ0[b,v,:]) @ W      and      dW0 = (sum_b dZ0[b])^T @ H.
 // One pass over dZ0 (n_feet, V, 256) produces  zsum[v] = sum_b dZ0[b,v]  and partial per-foot column sums.

@@ -340,6 +340,7 @@ class _WeightedTerms(torch.autograd.Function):
 		w = (ctypes.c_float * n)(*weights)
 		check(L.find_weighted_terms_fwd(n, _ptr_array(terms), w, ptr(out), ctypes.c_void_p(out.data_ptr() + 4 * n), current_stream(dev)), 'find_weighted_terms_fwd')
 		ctx.weights = tuple(float(x) for x in weights)
+		ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as a zero tensor (one fill launch each)
 		return out[n], out[:n]
 
 	@staticmethod
@@ -347,6 +348,8 @@ class _WeightedTerms(torch.autograd.Function):
 		L = _lib.lib()
 		n = len(ctx.weights)
 		ref = g_total if g_total is not None else g_scaled
+		if ref is None:
+			return (None,) * (n + 1)
 		d = torch.empty(n, device=ref.device, dtype=torch.float32)
 		w = (ctypes.c_float * n)(*ctx.weights)
 		check(L.find_weighted_terms_bwd(n, w, ptr(_c(g_total)), ptr(_c(g_scaled)), ptr(d), current_stream(ref.device)), 'find_weighted_terms_bwd')
@@ -438,6 +441,7 @@ class _SamplePoints(torch.autograd.Function):
 		ctx.save_for_backward(faces, face_idx, uv)
 		ctx.dims = (N, V, F, S, fb)
 		ctx.has_attr = attr is not None
+		ctx.set_materialize_grads(False)
 		if attr is None:
 			return out
 		return out, aout
@@ -495,6 +499,7 @@ class _SampleSurface(torch.autograd.Function):
 		ctx.dims = (N, V, F, S, fb)
 		ctx.has_attr = attr is not None
 		ctx.mark_non_differentiable(face_idx, uv)
+		ctx.set_materialize_grads(False)   # (autograd would hand zero tensors for face_idx / uv to backward: two fill launches per call)
 		if attr is None:
 			return out, face_idx, uv
 		return out, aout, face_idx, uv

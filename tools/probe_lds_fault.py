@@ -1,4 +1,4 @@
-"""Diagnosis of the co-residence fault (mlp.hip; it turned out to be about waves above 256 registers, not LDS): dw2_repro_kernel compares every published
+"""Diagnosis of the co-residence fault (mlp.hip; it turned out to be about waves that own the full accumulator set in a partial register allocation, not LDS): dw2_repro_kernel compares every published
 ring stage with the same bytes in HBM and logs the mismatching 16-byte pieces with the workgroup's HW_REG_LDS_ALLOC (LDS base / size),
 HW_ID and whether the piece still holds what the stage held three chunks ago.  python tools/probe_lds_fault.py [passes] [lds_exclusive]"""
 import os, sys
