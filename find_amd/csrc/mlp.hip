@@ -113,7 +113,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_FUSED2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -398,14 +398,18 @@ struct Chain {
 };
 
 static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s) {
+	// more 32-row blocks than CUs: 64-row tiles (one round of workgroups instead of two, half the weight staging per MFMA)
+	const int nt = (cdiv(V, 32) * feet > c->num_cus && !(c->ablate & 128)) ? 2 : 1;
 	int lds = 0;
-	FIND_TRY(prepare_kernel(c, K_FUSED, &fused_chain_kernel, FUSED_LDS, &lds, false));   // no LDS-DMA in this kernel: no reservation
+	if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED2, &fused_chain_kernel<2>, fused_lds(2), &lds, false));
+	else FIND_TRY(prepare_kernel(c, K_FUSED, &fused_chain_kernel<1>, fused_lds(1), &lds, false));   // no LDS-DMA in this kernel: no reservation
 	ch.a.V = (int)V;
-	ch.a.tiles_per_foot = (int)cdiv(V, 32);
+	ch.a.tiles_per_foot = (int)cdiv(V, 32 * nt);
 	ch.a.ntiles = (int)(ch.a.tiles_per_foot * feet);
 	ch.a.ablate = c->ablate;
 	const int grid = std::min(ch.a.ntiles, c->num_cus);
-	hipLaunchKernelGGL(fused_chain_kernel, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
+	if (nt == 2) hipLaunchKernelGGL(fused_chain_kernel<2>, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
+	else hipLaunchKernelGGL(fused_chain_kernel<1>, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
 	FIND_LAUNCH_CHECK("fused_chain_kernel");
 	return FIND_OK;
 }
@@ -1114,6 +1118,9 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		hipStream_t q0;
 		if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
+			// (Measured and dropped: the foot sum on the head's side stream, the caller's stream going straight on to the other head's dX
+			// chain and waiting for the sums in step 4 -- 3.49 against 3.38 ms per train_3d step: the HBM-bound pass beside the dX GEMMs
+			// costs them more than the wait it removes.)
 			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps);
 			// the foot-summed first layer is a small launch: its own side stream and slab set, so that it does not queue behind the
 			// large weight-gradient launches on Q.  The per-foot column sums go there too: only the latent / bias gradients read them.

@@ -1,4 +1,4 @@
-// fused_chain_kernel: a whole chain of 256-wide Linear layers on ONE 32-row tile per workgroup, in one launch.
+// fused_chain_kernel: a whole chain of 256-wide Linear layers on ONE 32-row (or 64-row: NT = 2) tile per workgroup, in one launch.
 //
 // Why: when a call has few rows -- the reference's own batch size 1 (6890 template vertices = 216 32-row tiles), the 1000 texture
 // samples, the shared trunk of a 16-foot batch -- every layer of the MLP was its own launch over fewer tiles than the chip has CUs,
@@ -21,6 +21,10 @@
 // Operand reads: one ds_read_b128 per operand per EIGHT k -- lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 k = 8g+4 .. 8g+7, and MFMA s
 // pairs component s of both halves (the contraction order inside a chunk is permuted; the sum is the same set of products).
 // LDS: X 32 x 260 floats (rows padded by 16 B: conflict-free ds_read_b128 across 32 rows), per wave two W chunks of 32 x 36 floats.
+// NT = 2 (64-row tiles, two accumulators per wave, every B fragment multiplied with two A fragments) for calls of more 32-row blocks than
+// CUs: the 16 x 1000 texture samples 243 -> ~200 us per pass.  Epilogue through buffer loads / stores (one VGPR offset for the sixteen
+// rows of a lane instead of sixteen 64-bit addresses): 256 -> 193 registers at NT = 1, and what lets NT = 2 fit in 256 without scratch;
+// train_3d step 3.39 -> 3.30 (epilogue) -> 3.25 ms (NT = 2).
 #pragma once
 #include "mlp_kernels.h"
 
@@ -67,9 +71,11 @@ struct FusedArgs {
 constexpr int FX_LD = 260;                       // X row stride (floats)
 constexpr int FW_LD = 36;                        // W chunk row stride (floats)
 constexpr int FUSED_NW = 8;                      // waves per workgroup
-constexpr int FUSED_X_BYTES = 32 * FX_LD * 4;    // 33 280
 constexpr int FUSED_WS_BYTES = 32 * FW_LD * 4;   // one wave's chunk: 32 rows x 32 k, padded (4 608)
-constexpr int FUSED_LDS = FUSED_X_BYTES + FUSED_NW * 2 * FUSED_WS_BYTES + 3 * 256 * 4;   // + Fourier matrix
+// NT = 32-row blocks per tile: 1, or 2 for calls of more 32-row blocks than the chip has CUs (the 16 x 1000 texture samples: 512 blocks
+// were two rounds of workgroups; as 256 64-row tiles they are one, and every staged weight chunk feeds twice the MFMAs)
+constexpr int fused_x_bytes(int nt) { return 32 * nt * FX_LD * 4; }   // 33 280 per 32 rows
+constexpr int fused_lds(int nt) { return fused_x_bytes(nt) + FUSED_NW * 2 * FUSED_WS_BYTES + 3 * 256 * 4; }   // + Fourier matrix
 
 // A wave's W staging: lane -> row = lane / 8 (+ 8 q), 16-byte part = lane % 8: 8 lanes read one 128-B row piece.  The chunk stream of a
 // tile -- every 32-k chunk of every GEMM step, in order -- runs two chunks ahead of the MFMAs: chunk k+2 is requested into one of two
@@ -88,7 +94,9 @@ constexpr int FUSED_LDS = FUSED_X_BYTES + FUSED_NW * 2 * FUSED_WS_BYTES + 3 * 25
 		*reinterpret_cast<float4*>(_d + 16 * FW_LD) = set##2; *reinterpret_cast<float4*>(_d + 24 * FW_LD) = set##3; \
 	} while (0)
 
+template <int NT>
 __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) {
+	constexpr int ROWS = 32 * NT, FUSED_X_BYTES = fused_x_bytes(NT);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* const X = reinterpret_cast<float*>(smem);
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 
 	for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
 		const int foot = tile / g.tiles_per_foot;
-		const int v0 = (tile - foot * g.tiles_per_foot) * 32;
-		const int valid = min(32, V - v0);
+		const int v0 = (tile - foot * g.tiles_per_foot) * ROWS;
+		const int valid = min(ROWS, V - v0);
 		const int64_t row0 = (int64_t)foot * V + v0;   // first global row of the tile
 
 		// ---- prefetch cursor over the tile's chunk stream (wave-uniform scalars)
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 		FUSED_W_STORE(wa, Wc0);                                // (the ring is this wave's own: its previous tile is done with it)
 		// chunk k of the stream sits in ring stage k & 1 when its turn comes, chunk k + 1 in register set (k + 1) & 1
 
-		f32x16 acc;
+		f32x16 acc[NT];
 		for (int si = 0; si < g.n_steps; ++si) {
 			// the step's fields as scalars (indexing the kernel-argument array through a reference makes the compiler copy it to scratch)
 			struct { const float *w, *bias, *src, *aux; float *dst, *dst2; int nchunk, bias_foot_stride, kind, src_kind, relu, mask, keep, accum, to_lds, head; } s;
@@ -139,7 +147,10 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 			if (s.kind == FS_OUT) {
 				// final 256 -> 3 layer + tanh scaling on the X tile: 16 lanes per row, 16 columns each
 				__syncthreads();
-				const int row = tid >> 4, seg = tid & 15;
+				const int seg = tid & 15;
+#pragma unroll
+				for (int rt = 0; rt < NT; ++rt) {
+				const int row = rt * 32 + (tid >> 4);
 				float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
 				for (int c4 = 0; c4 < 4; ++c4) {
@@ -160,13 +171,14 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 					if (s.dst2) s.dst2[o] = zz;
 					s.dst[o] = s.head ? ((s.aux ? s.aux[seg] : 0.f) + 0.5f * (1.0f + t)) : 0.1f * t;
 				}
+				}
 				continue;
 			}
 			// ---- GEMM step
 			if (s.src_kind == FS_SRC_GLOBAL) {
 				__syncthreads();   // everyone is done with the previous X
 #pragma unroll
-				for (int q = 0; q < 4; ++q) {
+				for (int q = 0; q < 4 * NT; ++q) {
 					const int idx = tid + 512 * q;
 					const int row = idx >> 6, part = idx & 63;
 					const float4 v = *reinterpret_cast<const float4*>(s.src + (row0 + min(row, valid - 1)) * W + part * 4);
@@ -175,7 +187,9 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 			}
 			if (!s.accum) {
 #pragma unroll
-				for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+				for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+					for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
 			}
 			__syncthreads();   // X is in place
 
@@ -194,23 +208,27 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 				__builtin_amdgcn_sched_barrier(0); /* the prefetch is issued BEFORE the MFMAs (else it sinks next to its store) */ \
 				const float* xa = xa0 + (s.src_kind == FS_SRC_PE ? ((c_) & 7) : (c_)) * 32;                                    \
 				const float* wbp = PAR ? wfrag1 : wfrag0;                                                                      \
-				float4 fa[2], fb[2];                                                                                           \
-				fa[0] = *reinterpret_cast<const float4*>(xa);                                                                  \
-				fb[0] = *reinterpret_cast<const float4*>(wbp);                                                                 \
+				float4 fa[2][NT], fb[2];                                                                                       \
+				_Pragma("unroll") for (int rt = 0; rt < NT; ++rt) fa[0][rt] = *reinterpret_cast<const float4*>(xa + rt * 32 * FX_LD); \
+				fb[0] = *reinterpret_cast<const float4*>(wbp);                                                                  \
 				_Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                             \
 					const int cur = gq & 1, nxt = cur ^ 1;                                                                     \
 					if (gq < 3) { /* fragments of k-group q+1 are requested before the MFMAs of group q */                      \
-						fa[nxt] = *reinterpret_cast<const float4*>(xa + (gq + 1) * 8);                                         \
+						_Pragma("unroll") for (int rt = 0; rt < NT; ++rt)                                                      \
+							fa[nxt][rt] = *reinterpret_cast<const float4*>(xa + rt * 32 * FX_LD + (gq + 1) * 8);               \
 						fb[nxt] = *reinterpret_cast<const float4*>(wbp + (gq + 1) * 8);                                        \
 					}                                                                                                          \
 					__builtin_amdgcn_sched_barrier(0);                                                                         \
-					const float4 a = fa[cur], b = fb[cur];                                                                     \
+					const float4 b = fb[cur];                                                                                  \
 					if (!(g.ablate & 2)) {                                                                                     \
-						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);                                    \
-						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);                                    \
-						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);                                    \
-						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);                                    \
-					} else { acc[0] += a.x + b.x; }                                                                            \
+						_Pragma("unroll") for (int rt = 0; rt < NT; ++rt) {                                                    \
+							const float4 a = fa[cur][rt];                                                                      \
+							acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[rt], 0, 0, 0);                        \
+							acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[rt], 0, 0, 0);                        \
+							acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[rt], 0, 0, 0);                        \
+							acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[rt], 0, 0, 0);                        \
+						}                                                                                                      \
+					} else { acc[0][0] += fa[cur][0].x + b.x; }                                                                \
 					__builtin_amdgcn_sched_barrier(0);                                                                         \
 				}                                                                                                              \
 				/* chunk k + 1 (requested one iteration ago) moves into the stage chunk k - 1 has left; the ring is private to */ \
@@ -221,7 +239,10 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 				if (s.src_kind == FS_SRC_PE && (c & 7) == 0 && !(g.ablate & 8)) {
 					// regenerate the X tile with the Fourier features of k-tile c / 8; a thread fills 16 columns of one row
 					if (c > 0) __syncthreads();   // the previous k-tile has been consumed by every wave
-					const int row = tid >> 4, seg = tid & 15;
+					const int seg = tid & 15;
+#pragma unroll
+					for (int rt = 0; rt < NT; ++rt) {
+					const int row = rt * 32 + (tid >> 4);
 					const float* pp = g.pos + (int64_t)foot * g.pos_foot_stride + (int64_t)(v0 + min(row, valid - 1)) * 3;
 					const float px = pp[0], py = pp[1], pz = pp[2];
 					// chunk cc of the padded order (mlp_kernels.h: pe_value): sin of 32 features, cos of the same 32, ..., [x y z 0 ...], zeros
@@ -240,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 						for (int j = 0; j < 16; j += 4) *reinterpret_cast<float4*>(xr + j) = make_float4(0.f, 0.f, 0.f, 0.f);
 						if (cc == nsc && j0 == 0) { xr[0] = px; xr[1] = py; xr[2] = pz; }
 					}
+					}
 					__syncthreads();
 				}
 				FUSED_CHUNK(0, c);
@@ -256,27 +278,39 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 				if (s.relu) {
 					const float bv = s.bias[(int64_t)foot * s.bias_foot_stride + col];
 #pragma unroll
-					for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r] + bv, 0.f);
-				}
-				if (s.mask) {
-					const float* mp = s.aux + row0 * W + col;
+					for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						const int row = min((r & 3) + 8 * (r >> 2) + 4 * lh, valid - 1);
-						acc[r] = (mp[row * W] > 0.f) ? acc[r] : 0.f;
+						for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r] + bv, 0.f);
+				}
+				// buffer loads / stores as in gemm4: one VGPR offset, the row of element r in the immediate / scalar offset, and the
+				// descriptor's size = the tile's valid bytes, so rows past the end of a foot are dropped by the bounds check
+				// (per-row 64-bit addresses and clamps cost the 64-row tile its registers: 608 bytes of scratch)
+				const int voff = ((4 * lh) * W + col) * 4;
+				if (s.mask) {
+					const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(s.aux + row0 * W)), 0, valid * W * 4, 0x00020000);
+#pragma unroll
+					for (int rt = 0; rt < NT; ++rt) {
+						float mv[16];
+#pragma unroll
+						for (int r = 0; r < 16; ++r)
+							mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * W) * 4, ((rt * 32 + 8 * (r >> 2)) * W) * 4, 0));
+#pragma unroll
+						for (int r = 0; r < 16; ++r) acc[rt][r] = (mv[r] > 0.f) ? acc[rt][r] : 0.f;   // (a row past the end reads 0: its value is never stored)
 					}
 				}
 				if (s.dst) {
-					float* dp = s.dst + row0 * W + col;
+					const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(s.dst + row0 * W)), 0, valid * W * 4, 0x00020000);
 #pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-						if (row < valid) dp[row * W] = acc[r];
-					}
+					for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+						for (int r = 0; r < 16; ++r)
+							__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[rt][r]), drs, voff + ((r & 3) * W) * 4, ((rt * 32 + 8 * (r >> 2)) * W) * 4, 0);
 				}
 				if (s.to_lds) {
 #pragma unroll
-					for (int r = 0; r < 16; ++r) X[((r & 3) + 8 * (r >> 2) + 4 * lh) * FX_LD + col] = acc[r];
+					for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+						for (int r = 0; r < 16; ++r) X[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * FX_LD + col] = acc[rt][r];
 				}
 			}
 			// (the next step starts with a barrier before anyone reads X)

@@ -162,7 +162,9 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *                     slow, so that they stay resident beside later weight-gradient kernels (the stress configuration: with
  *                     "dw_lds_free" = 2 or 3 every backward pass has wrong elements); default 0
  *   "ablate", "dbg"   profiling switches of the GEMM kernels ("ablate" bits in fused_chain_kernel: 1 no W staging, 2 no MFMAs, 4 no
- *                     epilogue, 8 no Fourier features -- results are WRONG with any bit set); "dbg" = device pointer to per-workgroup timers
+ *                     epilogue, 8 no Fourier features -- results are WRONG with any of these set; bits with unchanged results: 16 no
+ *                     s_setprio in gemm4, 32 every column block in the Fourier layer's weight gradient, 128 fused chains always on
+ *                     32-row tiles); "dbg" = device pointer to per-workgroup timers
  * The Python binding applies FIND_TUNING="key=value,..." from the environment to every context it creates. */
 
 /* Process-wide profiling switch of the rasteriser (diagnosis only; bits 1, 2 and 4 make the render WRONG):

@@ -566,3 +566,38 @@ def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet, variant)
 		_lib.set_tuning('lds_exclusive', 0)
 		_lib.set_tuning('dw_lds_free', 1)
 		_lib.set_tuning('mlp_f16', 0)
+
+
+@pytest.mark.parametrize('shape', [(16, 1000), (9, 1000), (5, 2100)])
+def test_fused_chain_64_row_tiles_equal_the_32_row_tiles(golden_main, shape):
+	"""A fused chain over more 32-row blocks than the chip has CUs runs on 64-row tiles (fused_chain_kernel<2>; 1000 rows per foot leave a
+	40-row last tile, 2100 a 52-row one): every output row and every gradient must be bit-identical to the 32-row tiles (ablate bit 128),
+	which the golden-vector tests pin -- a row's products and their order do not depend on the tile it sits in."""
+	from find_amd import _lib
+	m = _model_from_golden(golden_main)
+	n, v = shape
+	g = torch.Generator().manual_seed(n * 77 + v)
+	lat = {k: (torch.randn(n, 100, generator=g) * 0.1).cuda() for k in ['shapevec', 'texvec', 'posevec']}
+	pos = (torch.rand(n, v, 3, generator=g) * 0.2).cuda()
+	wd = torch.randn(n, v, 3, generator=g).cuda()
+	wc = torch.randn(n, v, 3, generator=g).cuda()
+	out = {}
+	try:
+		for tiles, knob in (('64', 0), ('32', 128)):
+			_lib.set_tuning('ablate', knob)
+			m.zero_grad(set_to_none=True)
+			lv = {k: t.clone().requires_grad_(True) for k, t in lat.items()}
+			res = m(pos, **lv)
+			((res['disp'] * wd).sum() + (res['col'] * wc).sum()).backward()
+			torch.cuda.synchronize()
+			out[tiles] = (res['disp'].detach().clone(), res['col'].detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+						  {k: t.grad.clone() for k, t in lv.items()})
+	finally:
+		_lib.set_tuning('ablate', 0)
+	a, b = out['64'], out['32']
+	assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+	assert a[0].abs().max().item() > 0 and a[1].abs().max().item() > 0
+	for k in b[2]:
+		assert torch.equal(a[2][k], b[2][k]), k
+	for k in b[3]:
+		assert torch.equal(a[3][k], b[3][k]), k
