@@ -5,6 +5,8 @@ Structure here: a registry of loss terms.  Each term names the forward() flag th
 `opts.weight_*` attribute that scales it (model.py:1157-1158: every raw loss is multiplied by its weight, the total is their sum)
 and whether it needs the 3-D supervision gate or the renders.  forward() evaluates the predicted meshes once, renders once if any
 enabled term needs images, and walks the registry.  All arithmetic runs in libfind_hip.so through the loss / renderer objects."""
+import contextlib
+import os
 from collections import namedtuple
 
 import torch
@@ -37,6 +39,18 @@ TERMS = (
 	Term('pix', 'loss_pix', 'weight_pix', False, True, '_raw_pix'),
 	Term('sil', 'loss_sil', 'weight_sil', False, True, '_raw_sil'),
 )
+
+
+# the GT render on a second stream beside the predicted one (ModelWithLoss._render_gt); FIND_OVERLAP_GT_RENDER=0 turns it off
+OVERLAP_GT_RENDER = os.environ.get('FIND_OVERLAP_GT_RENDER', '1') != '0'
+_SECOND_STREAMS = {}
+
+
+def _second_stream(device):
+	s = _SECOND_STREAMS.get(device)
+	if s is None:
+		s = _SECOND_STREAMS[device] = torch.cuda.Stream(device=device)
+	return s
 
 
 def model_class_from_opts(opts):
@@ -118,17 +132,37 @@ class ModelWithLoss(nn.Module):
 			return False
 		return True
 
-	def _render_pair(self, st, views, masked_faces, copy_mask_out):
+	def _render_gt(self, st, views, masked_faces):
+		"""The GT render of a step: (gt, R, T, second stream or None).  It carries no gradient and reads nothing of the prediction, so it
+		runs on a second stream beside the predicted render.  A rasteriser launch ends in a long tail -- a few crowded tiles keep their CUs
+		while the rest of the chip idles, DESIGN 4.2 --: two launches side by side fill each other's tails (C3 step 8.76 -> 7.77 ms).
+		(Issued before the MLP forward instead, it takes CUs from the forward's GEMMs for longer than it saves: 8.3 ms.)  Not under
+		stream capture."""
 		R, T = views if views is not None else self._views(st.opts)
-		with torch.no_grad():  # the GT scans are rendered again every step, as the reference does (model.py:1073-1075)
+		dev = torch.device(st.batch['mesh'].device)
+		side = None
+		if OVERLAP_GT_RENDER and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+			side = _second_stream(dev)
+			side.wait_stream(torch.cuda.current_stream(dev))
+		with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+			# the GT scans are rendered again every step, as the reference does (model.py:1073-1075)
 			gt = self.rdr(st.batch['mesh'], R, T, return_mask=True, mask_with_grad=True, mask_out_faces=True, masked_faces=masked_faces,
 						  return_mask_out_masks=True)
+		return gt, R, T, side
+
+	def _render_pred(self, st, gt, R, T, side, copy_mask_out):
 		pred = self.rdr(st.res['meshes'], R, T, return_mask=True, mask_with_grad=True)
+		if side is not None:
+			main = torch.cuda.current_stream(side.device)
+			for t in gt.values():   # allocated on the second stream, read on this one from here on
+				if torch.is_tensor(t):
+					t.record_stream(main)
+			main.wait_stream(side)
 		if copy_mask_out:  # what the GT's slicing plane hides is hidden in the prediction too (model.py:1091-1094)
 			hidden = gt['mask_out_masks']
 			pred['image'] = torch.where(hidden.unsqueeze(-1), torch.ones_like(pred['image']), pred['image'])
 			pred['mask'] = torch.where(hidden, torch.zeros_like(pred['mask']), pred['mask'])
-		return pred, gt
+		return pred
 
 	def forward(self, batch, epoch, opts, chamf=False, smooth=False, texture=False, pix=False, vgg_perc=False, sil=False,
 				restyle_perc_lat=False, restyle_perc_feat=False, restyle_perc_cluster=False, cont_pose=False, render_foot=False,
@@ -147,7 +181,8 @@ class ModelWithLoss(nn.Module):
 		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement)
 		st.pred = st.gt = None
 		if render_foot:
-			st.pred, st.gt = self._render_pair(st, views, batch.get('masked_faces', None), copy_mask_out)
+			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None))
+			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out)
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
 		raw, weights = {}, []

@@ -166,6 +166,52 @@ def test_render_losses_match_oracle():
 	assert mwl.model.base[0].weight.grad.abs().max().item() > 0
 
 
+def test_gt_render_on_the_second_stream_changes_nothing():
+	"""ModelWithLoss renders the GT scans on a second stream beside the predicted render (model_with_loss.OVERLAP_GT_RENDER): renders,
+	losses and gradients are those of the one-stream order -- over several steps, so that a missing wait between the streams (or a buffer
+	handed back to the allocator too early) would show."""
+	from find_amd import model_with_loss as MWL
+	from find_amd.train_utils import sample_latent_vectors
+	mwl, opts, batch, _ = _setup(n_feet=3, seed=5)
+	mwl.rdr = type(mwl.rdr)(image_size=128, device='cuda')
+	np.random.seed(12)
+	R, T = mwl.rdr.sample_views(nviews=3, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+	names = ['reg', 'shapevec', 'texvec', 'posevec']
+	out = {}
+	prev = MWL.OVERLAP_GT_RENDER
+	try:
+		for mode in (True, False):
+			MWL.OVERLAP_GT_RENDER = mode
+			rec = []
+			for _ in range(4):
+				mwl.zero_grad(set_to_none=True)
+				batch.update(sample_latent_vectors(batch, mwl.model.latent_vectors_train))
+				loss, losses, renders = mwl(batch, 0, opts, sil=True, pix=True, render_foot=True, return_renders=True, views=(R, T))
+				loss.backward()
+				# (garbage in between: a buffer freed on one stream and reused on the other would be overwritten here)
+				junk = [torch.full((3, 3, 128, 128, 3), 7.0, device='cuda') for _ in range(4)]
+				del junk
+				rec.append((loss.detach().clone(), renders['gt']['mask'].clone(), renders['gt']['image'].clone(), renders['pred']['mask'].detach().clone(),
+							[getattr(mwl.model, n).data.grad.clone() for n in names], mwl.model.base[0].weight.grad.clone()))
+			torch.cuda.synchronize()
+			out[mode] = rec
+	finally:
+		MWL.OVERLAP_GT_RENDER = prev
+	# every step has the same inputs (no optimiser step): all eight results agree -- the silhouettes bit for bit, what goes through the
+	# vertex normals (accumulated with atomics: order-dependent rounding) to rounding
+	ref = out[False][0]
+
+	def close(x, y, tol):
+		return (x - y).abs().max().item() <= tol * max(1e-6, y.abs().max().item())
+
+	for rec in out[True] + out[False][1:]:
+		assert torch.equal(rec[1], ref[1]) and torch.equal(rec[3], ref[3])
+		assert close(rec[0], ref[0], 1e-6) and close(rec[2], ref[2], 1e-5)
+		for x, y in zip(rec[4], ref[4]):
+			assert close(x, y, 1e-4)
+		assert close(rec[5], ref[5], 1e-4)
+
+
 def test_loss_weights_are_applied_and_flags_respected():
 	mwl, opts, batch, _ = _setup(n_feet=2, seed=4)
 	l0, d0 = mwl(batch, 0, opts)
