@@ -47,10 +47,34 @@ _SECOND_STREAMS = {}
 
 
 def _second_stream(device):
+	"""A stream whose launches really run beside the current stream's.  HIP multiplexes streams onto a few hardware queues (four by
+	default; raising GPU_MAX_HW_QUEUES makes every step here SLOWER, bench.py 3.25 -> 4.6 ms: the sharing is part of how the MLP's side
+	streams are laid out), and two streams on one queue run in order -- which queue a new stream lands on depends on what else the
+	process has created (inside bench.py's full run the first candidate shared the main stream's queue and the overlap was lost).  So:
+	try a few streams once, with a spinning kernel on the current stream, and keep the first whose work finishes while that one spins."""
 	s = _SECOND_STREAMS.get(device)
-	if s is None:
-		s = _SECOND_STREAMS[device] = torch.cuda.Stream(device=device)
-	return s
+	if s is not None:
+		return s
+	main = torch.cuda.current_stream(device)
+	probe = torch.zeros(64, device=device)
+	cands = [torch.cuda.Stream(device=device) for _ in range(6)]
+	pick = cands[0]
+	for c in cands:
+		torch.cuda.synchronize(device)
+		spun, done = torch.cuda.Event(), torch.cuda.Event()
+		torch.cuda._sleep(4_000_000)   # ~2 ms on the current stream
+		spun.record(main)
+		with torch.cuda.stream(c):
+			probe.add_(1.0)
+			done.record(c)
+		done.synchronize()
+		beside = not spun.query()
+		torch.cuda.synchronize(device)
+		if beside:
+			pick = c
+			break
+	_SECOND_STREAMS[device] = pick
+	return pick
 
 
 def model_class_from_opts(opts):

@@ -4,6 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of the headline loop alone (bench.py --headline-only) -> kernel stats of that command, and the
 #      steady-state statistics (warm-up launches dropped, tools/steady_stats.py)
 #   2b. the same for the batch-1 records (bench.py --train3d-b1): per-step statistics cut at the optimiser kernel (tools/step_stats.py)
+#   2c. tools/step_timeline.py: one step of the headline trace launch by launch (what runs beside what)
 #   3. PMC passes of the dominant kernel (find_linear_relu_fwd at the C2 shape): MFMA busy / traffic
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
 cd $R
@@ -19,6 +20,7 @@ done
 cd $R
 python3 tools/steady_stats.py $O/headline/*/*kernel_trace.csv 30 10 > $O/headline_steady_kernel_stats.csv
 python3 tools/step_stats.py $O/headline/*/*kernel_trace.csv adam_kernel 25 > $O/headline_step_stats.csv
+python3 tools/step_timeline.py $O/headline/*/*kernel_trace.csv adam_kernel 6 > $O/headline_step_timeline.txt
 python3 tools/step_stats.py $O/b1/*/*kernel_trace.csv adam_kernel 200 > $O/b1_step_stats.csv
 cp $O/headline/*/*kernel_stats.csv $O/headline_kernel_stats.csv
 for i in 0 1 2; do python3 tools/pmc_summary.py gemm4_kernel $O/gemm4_pmc_$i/*/; done > $O/gemm4_pmc_summary.txt
