@@ -52,6 +52,7 @@ PROTOTYPES = {
 	'find_build_arch': (c_char_p, []),
 	'find_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
 	'find_ctx_destroy': (c_int, [_P]),
+	'find_debug_stream_groups': (c_int, [_P, _P, _P]),
 	'find_ctx_set': (c_int, [_P, c_char_p, _I]),
 	'find_ctx_get': (c_int, [_P, c_char_p, POINTER(c_int64)]),
 	'find_debug_raster_ablate': (c_int, [_I]),

@@ -144,6 +144,9 @@ struct find_ctx {
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
 	// internal streams / events
 	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+	bool side_bound = false;      // the side streams have been chosen against the hardware queue of a caller's stream (bind_side_streams)
+	int bind_streams = 1;         // knob: 0 = keep the side streams as created
+	int r_queue = 2;              // knob: the side stream (0 = Q, 1 = T1, 2 = T2) whose hardware queue the slab-reduce stream R shares
 	hipEvent_t ev[N_EVENTS];
 	int n_events = 0;
 	int next = 0;
@@ -223,6 +226,8 @@ static int prepare_kernel(find_ctx* c, int id, K kernel, int need_bytes, int* la
 // error returns included -- makes the caller's stream wait for every side stream this call touched, so that when the call returns
 // the caller may free or reuse any buffer it passed in (stream-ordered).  Every HIP return code is kept: the first failure is
 // reported by join().  Works under stream capture: a captured call forks and joins the same streams, so the capture stays closed.
+static int bind_side_streams(find_ctx* c, hipStream_t caller);   // (below, with the probe)
+
 struct Fork {
 	find_ctx* c;
 	hipStream_t s;
@@ -235,6 +240,7 @@ struct Fork {
 	Fork(find_ctx* ctx, hipStream_t caller, bool enable) : c(ctx), s(caller), on(enable && ctx->side[0] != nullptr) {
 		hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
 		if (hipStreamIsCapturing(caller, &st) == hipSuccess) capturing = st != hipStreamCaptureStatusNone;
+		if (on && !capturing && !ctx->side_bound && ctx->bind_streams) (void)bind_side_streams(ctx, caller);   // (a failed probe keeps the streams as created)
 	}
 	hipStream_t stream(int k) const { return on ? c->side[k] : s; }
 	void fail(hipError_t e, const char* what) {
@@ -1296,6 +1302,116 @@ extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* 
 	return rc != FIND_OK ? rc : rj;
 }
 
+// ------------------------------------------------------------------------------------------- streams and hardware queues
+// HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, four by default), in creation order; two streams on one queue
+// run their launches in order.  Which of the context's side streams really run beside the caller's stream -- and beside each other --
+// therefore depends on what the process created before: a probe launch tells.
+namespace find {
+namespace mlp {
+__global__ void spin_kernel(long long ticks) {
+	const long long t0 = wall_clock64();   // 100 MHz
+	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+__global__ void nop_kernel() {}
+}  // namespace mlp
+}  // namespace find
+
+// does a launch on b run while a is busy?
+static int runs_beside(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb, bool* beside) {
+	FIND_HIP_OK(hipStreamSynchronize(a), "hipStreamSynchronize");
+	FIND_HIP_OK(hipStreamSynchronize(b), "hipStreamSynchronize");
+	hipLaunchKernelGGL(find::mlp::spin_kernel, dim3(1), dim3(64), 0, a, 30000ll);   // ~0.3 ms
+	FIND_HIP_OK(hipEventRecord(ea, a), "hipEventRecord");
+	hipLaunchKernelGGL(find::mlp::nop_kernel, dim3(1), dim3(64), 0, b);
+	FIND_HIP_OK(hipEventRecord(eb, b), "hipEventRecord");
+	FIND_HIP_OK(hipEventSynchronize(eb), "hipEventSynchronize");
+	*beside = hipEventQuery(ea) == hipErrorNotReady;
+	FIND_HIP_OK(hipStreamSynchronize(a), "hipStreamSynchronize");
+	return FIND_OK;
+}
+
+// groups[0] = 0 for the caller's stream, groups[1 + k] for side stream k: streams with the same number share a hardware queue
+static int stream_groups(hipStream_t const* st, int n, hipEvent_t ea, hipEvent_t eb, int* groups) {
+	int ngroups = 0;
+	int rep[16];
+	for (int i = 0; i < n; ++i) {
+		groups[i] = -1;
+		for (int g = 0; g < ngroups && groups[i] < 0; ++g) {
+			bool beside = false;
+			FIND_TRY(runs_beside(st[rep[g]], st[i], ea, eb, &beside));
+			if (!beside) groups[i] = g;
+		}
+		if (groups[i] < 0) {
+			if (ngroups == 16) { groups[i] = 15; continue; }
+			rep[ngroups] = i;
+			groups[i] = ngroups++;
+		}
+	}
+	return FIND_OK;
+}
+
+extern "C" int find_debug_stream_groups(find_ctx* c, void* caller_stream, int32_t* groups) {
+	FIND_TRY(check_ctx(c, "find_debug_stream_groups"));
+	FIND_REQUIRE(groups != nullptr, "find_debug_stream_groups: groups is NULL");
+	hipStream_t st[1 + N_SIDE];
+	st[0] = reinterpret_cast<hipStream_t>(caller_stream);
+	for (int k = 0; k < N_SIDE; ++k) st[1 + k] = c->side[k];
+	int g[1 + N_SIDE];
+	FIND_TRY(stream_groups(st, 1 + N_SIDE, c->ev[0], c->ev[1], g));
+	for (int k = 0; k < 1 + N_SIDE; ++k) groups[k] = g[k];
+	return FIND_OK;
+}
+
+// The layout the step was tuned with (and gets in a process that creates nothing else first): the large weight gradients (Q) and the two
+// small-launch streams (T1, T2) each on a queue of their own, none of them the caller's, and the slab reduces (R) behind T2's queue.
+// After torch.distributed has created RCCL's streams the same four hipStreamCreate calls put R on the CALLER's queue -- the reduces then
+// sit between the dX GEMMs: 3.47 instead of 3.25 ms per train_3d step on every rank of a multi-GPU run.  So the first call that forks
+// chooses its side streams among a dozen candidates by probing (once per context, ~20 ms).
+namespace find {
+namespace mlp {
+static int bind_side_streams(find_ctx* c, hipStream_t caller) {
+	c->side_bound = true;   // (one attempt: a failure below keeps the streams as created)
+	constexpr int N_CAND = 12;
+	hipStream_t st[1 + N_CAND];
+	st[0] = caller;
+	int n = 1;
+	for (int k = 0; k < N_SIDE; ++k) st[n++] = c->side[k];
+	for (; n < 1 + N_CAND; ++n)
+		if (hipStreamCreateWithFlags(&st[n], hipStreamNonBlocking) != hipSuccess) break;
+	int g[1 + N_CAND];
+	int rc = stream_groups(st, n, c->ev[0], c->ev[1], g);
+	int pick[N_SIDE] = {-1, -1, -1, -1};
+	if (rc == FIND_OK) {
+		int ng = 0;
+		for (int k = 0; k < 3; ++k)   // Q, T1, T2: first candidate on a queue that is neither the caller's nor an earlier pick's
+			for (int i = 1; i < n && pick[k] < 0; ++i) {
+				bool fresh = g[i] != 0;
+				for (int j = 0; j < k; ++j) fresh = fresh && g[i] != g[pick[j]];
+				if (fresh) { pick[k] = i; ++ng; }
+			}
+		if (ng == 3) {
+			const int rq = pick[c->r_queue];
+			for (int i = 1; i < n && pick[3] < 0; ++i)   // R: another stream on T2's queue (knob r_queue: Q's or T1's)
+				if (i != pick[0] && i != pick[1] && i != pick[2] && g[i] == g[rq]) pick[3] = i;
+			if (pick[3] < 0)   // (none: any stream that is not on the caller's queue and not a pick)
+				for (int i = 1; i < n && pick[3] < 0; ++i)
+					if (g[i] != 0 && i != pick[0] && i != pick[1] && i != pick[2]) pick[3] = i;
+		}
+	}
+	const bool ok = rc == FIND_OK && pick[0] > 0 && pick[1] > 0 && pick[2] > 0 && pick[3] > 0;
+	hipStream_t chosen[N_SIDE];
+	for (int k = 0; k < N_SIDE; ++k) chosen[k] = ok ? st[pick[k]] : c->side[k];
+	for (int i = 1; i < n; ++i) {
+		bool keep = false;
+		for (int k = 0; k < N_SIDE; ++k) keep = keep || st[i] == chosen[k];
+		if (!keep) (void)hipStreamDestroy(st[i]);
+	}
+	for (int k = 0; k < N_SIDE; ++k) c->side[k] = chosen[k];
+	return rc;
+}
+}  // namespace mlp
+}  // namespace find
+
 // ------------------------------------------------------------------------------------------- context
 extern "C" int find_ctx_create(int device, find_ctx** out) {
 	FIND_REQUIRE(out != nullptr, "find_ctx_create: out is NULL");
@@ -1348,7 +1464,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
 };
 }  // namespace
 

@@ -51,6 +51,10 @@ const char* find_build_arch(void);
 typedef struct find_ctx find_ctx;
 int find_ctx_create(int device, find_ctx** out);
 int find_ctx_destroy(find_ctx* ctx);
+/* Diagnosis: which of the context's four side streams share a hardware queue with `caller_stream` or with each other (HIP maps streams
+ * onto GPU_MAX_HW_QUEUES queues in creation order; two streams on one queue run in order).  groups[0] = 0 is the caller's stream,
+ * groups[1 + k] side stream k; equal numbers = same queue.  Synchronises the streams it probes (~0.3 ms per probe). */
+int find_debug_stream_groups(find_ctx* ctx, void* caller_stream, int32_t* groups /* [5] */);
 /* Knobs (see the list at find_ctx_set below); find_ctx_get reads the current value, plus the read-only
  * "num_cus", "lds_bytes", "device", "events_per_call_max" (largest event count one MLP call has used so far). */
 int find_ctx_set(find_ctx* ctx, const char* key, int64_t value);

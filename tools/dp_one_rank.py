@@ -1,0 +1,47 @@
+"""The headline step on ONE GPU through the data-parallel code path: a one-rank RCCL group, parameters broadcast, gradients in the
+bucket, all-reduce before the optimiser step -- what a rank of `bench.py --gpus N` runs, minus the other ranks.  RCCL creates its
+streams before the MLP context creates its side streams: if the step time moved with that (HIP maps streams onto four hardware queues in
+creation order), the multi-GPU line would not be the single-GPU line.  python tools/dp_one_rank.py [steps] [dp | pg_only (group and its streams created, no bucket) | plain]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from find_amd import distributed as fdist
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+run = bench.Run(1)
+mode = sys.argv[2] if len(sys.argv) > 2 else 'dp'
+if mode in ('dp', 'pg_only'):
+	torch.distributed.init_process_group('nccl', init_method='tcp://127.0.0.1:29534', rank=0, world_size=1)
+	t = torch.ones(4, device=run.dev)
+	torch.distributed.all_reduce(t)
+	torch.cuda.synchronize()
+su = bench.train3d_setup(run, 16, 16, stage='net', labels=False, dp=False)
+m = su['mwl'].model
+bucket = None
+if mode == 'dp':
+	fdist.broadcast_parameters([p for p in m.parameters() if p.is_floating_point()])
+	bucket = fdist.GradBucket([p for p in m.parameters() if p.requires_grad])
+opt, mwl, opts, flags, batches = su['opt'], su['mwl'], su['opts'], su['flags'], su['batches']
+from find_amd.train_utils import sample_latent_vectors
+state = dict(i=0)
+def step():
+	opt.zero_grad(set_to_none=True)
+	b = dict(batches[state['i'] % len(batches)]); state['i'] += 1
+	b.update(sample_latent_vectors(b, m.latent_vectors_train))
+	loss, _ = mwl(b, 0, opts, **flags)
+	loss.backward()
+	if bucket is not None:
+		bucket.allreduce_()
+	opt.step()
+import ctypes
+from find_amd import _lib
+g = (ctypes.c_int32 * 5)()
+step(); torch.cuda.synchronize()
+_lib.check(_lib.lib().find_debug_stream_groups(_lib.ctx(run.dev), _lib.current_stream(run.dev), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+print(f'{mode}: hardware-queue groups [caller, Q, T1, T2, R] = {list(g)}', flush=True)
+for rep in range(2):
+	print(f'{mode}: {run.timed(step, steps, 10):.3f} ms/step', flush=True)
+if bucket is not None:
+	bucket.close()
+if mode in ('dp', 'pg_only'):
+	torch.distributed.destroy_process_group()
