@@ -131,7 +131,9 @@ struct find_ctx {
 	int dw2_min_cps = 8;          // at least this many 16-row chunks per dw2 workgroup (4: 2.257, 8: 2.243, 12: 2.266 ms/step at C2)
 	int bwd_streams = 1;          // weight gradients on the side streams
 	int fwd_streams = 1;          // colour head on a side stream beside the displacement head
-	int reduce_stream = 1;        // slab reduces of the large head layers on their own stream (two alternating slab sets)
+	int reduce_stream = 0;        // 1 = slab reduces of the large head layers on their own stream R (two alternating slab sets): what the LDS-ring weight
+	                              // gradient needed (its reduce only got a CU when a ring workgroup retired); with dw4_kernel the reduce behind its
+	                              // launch on Q is 0.6 - 0.9 % faster (train_3d 3.245 -> 3.225 ms, C2 2.220 -> 2.199), so off by default
 	int gemm5_min_units = 1024;
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which

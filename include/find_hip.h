@@ -147,7 +147,11 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: shortest row run per workgroup, workgroups of the Fourier layer's launch
  *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on the context's side streams (default)
  *   "fwd_streams"     1 = the forward runs the colour head on a side stream beside the displacement head (default), 0 = one stream
- *   "reduce_stream"   1 = slab reduces of the large head layers on their own stream, two alternating slab sets (default)
+ *   "reduce_stream"   1 = slab reduces of the large head layers on their own stream, two alternating slab sets; default 0 (behind their
+ *                     weight-gradient launch: measured 0.6 - 0.9 % faster since the weight gradients use no LDS)
+ *   "bind_streams"    1 (default) = the first call that forks picks the four side streams among a dozen candidates by probing which
+ *                     hardware queue each one shares (see find_debug_stream_groups); 0 = keep them as created
+ *   "r_queue"         which side stream's hardware queue the slab-reduce stream shares: 0 = Q, 1 = T1, 2 = T2 (default, measured best)
  *   "mlp_f16"         default precision for calls whose find_mlp_params.precision is 0, and the precision of find_linear_relu_fwd /
  *                     find_linear_wgrad: 1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to
  *                     fp16, fp32 accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES

@@ -322,19 +322,26 @@ def test_backward_is_bit_reproducible_with_side_streams():
 		out.update({'latent.' + k: v.grad.detach().clone() for k, v in lv.items()})
 		return out
 
-	for gemm4 in (1, 0):
+	for gemm4, reduce_stream in ((1, 0), (0, 0), (1, 1)):
 		# gemm4 = 0: every 256 -> 256 launch on the LDS-DMA ring kernel (gemm3) instead of the W-resident gemm4
+		# reduce_stream = 1: the slab reduces of the large layers on their own stream with two alternating slab sets (off by default)
 		_lib.set_tuning('gemm4_min_units', 1024 if gemm4 else 10 ** 12)
 		_lib.set_tuning('gemm4_small', 64 if gemm4 else 0)
+		_lib.set_tuning('reduce_stream', reduce_stream)
 		try:
 			ref = once()
+			if reduce_stream:
+				assert all(torch.equal(ref[n], first[n]) for n in ref), 'the reduce stream changed a gradient'
+			elif gemm4:
+				first = ref
 			for rep in range(25):
 				got = once()
 				bad = [n for n in ref if not torch.equal(got[n], ref[n])]
-				assert not bad, f'gemm4={gemm4}, pass {rep}: gradients of {bad} differ from the first pass'
+				assert not bad, f'gemm4={gemm4}, reduce_stream={reduce_stream}, pass {rep}: gradients of {bad} differ from the first pass'
 		finally:
 			_lib.set_tuning('gemm4_min_units', 1024)
 			_lib.set_tuning('gemm4_small', 64)
+			_lib.set_tuning('reduce_stream', 0)
 
 
 def _wgrad(n_feet, n_pts, seed, sparse=False):
