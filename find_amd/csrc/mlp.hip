@@ -845,6 +845,7 @@ struct WgradGroup {
 	Dw2Group d;
 	ReduceWGroup r;
 	int n = 0, nmain = 0;
+	int live_jobs = 0;   // jobs this launch will really carry (a call that skips a head has fewer than the workspace reserves): what the geometry is sized for
 	int64_t feet = 0;
 	WgradGroup() { memset(&d, 0, sizeof(d)); memset(&r, 0, sizeof(r)); }
 };
@@ -874,7 +875,7 @@ static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const flo
 	FIND_REQUIRE(G.n < b.grp_jobs && G.n < DW2_MAX_JOBS, "find_mlp_bwd: too many grouped weight gradients");
 	const int cpf16 = (int)(V / 16);
 	int spf = 1, cps2 = 1;
-	if (cpf16 > 0) group_geometry(c, cpf16, feet, b.grp_jobs, b.grp_slabs, &spf, &cps2);
+	if (cpf16 > 0) group_geometry(c, cpf16, feet, G.live_jobs > 0 ? G.live_jobs : b.grp_jobs, b.grp_slabs, &spf, &cps2);
 	const int nmain = (int)(feet * spf);
 	FIND_REQUIRE(nmain <= b.grp_slabs, "find_mlp_bwd: grouped weight gradient needs %d slabs, %lld reserved", nmain, (long long)b.grp_slabs);
 	float* pw = b.grp_pw + (int64_t)G.n * b.grp_slabs * W * W;
@@ -1044,6 +1045,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		// stream, the Fourier layer on another; the opt-in fp16 mode keeps its per-layer dw3 launches.
 		const bool grouped = !c->f16 && b.grp_pw != nullptr;
 		WgradGroup G;
+		G.live_jobs = (act_d ? p->n_disp : 0) + (act_c ? p->n_col : 0) + (p->n_trunk - 1);
 		int rr = 0;
 		auto next_side = [&](BwdWs* bk) -> int {
 			const int k = fk.on ? 1 + rr % 2 : 0;
