@@ -158,12 +158,15 @@ class ModelWithLoss(nn.Module):
 
 	def _render_gt(self, st, views, masked_faces):
 		"""The GT render of a step: (gt, R, T, second stream or None).  It carries no gradient and reads nothing of the prediction, so it
-		runs on a second stream beside the predicted render.  A rasteriser launch ends in a long tail -- a few crowded tiles keep their CUs
-		while the rest of the chip idles, DESIGN 4.2 --: two launches side by side fill each other's tails (C3 step 8.76 -> 7.77 ms).
-		(Issued before the MLP forward instead, it takes CUs from the forward's GEMMs for longer than it saves: 8.3 ms.)  Not under
-		stream capture."""
+		runs on a second stream beside the predicted render: C3 step 8.3 -> 7.8 ms (the two rasteriser launches share the chip
+		5 % better than they use it alone, and the predicted render's small launches run under the GT render's tail).  (Issued before the
+		MLP forward instead, it takes CUs from the forward's GEMMs for longer than it saves: 8.3 ms.)  Not under stream capture."""
 		R, T = views if views is not None else self._views(st.opts)
 		dev = torch.device(st.batch['mesh'].device)
+		if dev.type == 'cuda' and not R.is_cuda:
+			# the camera poses go to the device once per step, through pinned memory: a pageable copy per render call (four of them) made
+			# the host wait for the queue to drain each time
+			R, T = (t.float().pin_memory().to(dev, non_blocking=True) for t in (R, T))
 		side = None
 		if OVERLAP_GT_RENDER and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
 			side = _second_stream(dev)
