@@ -156,7 +156,7 @@ class ModelWithLoss(nn.Module):
 			return False
 		return True
 
-	def _render_gt(self, st, views, masked_faces):
+	def _render_gt(self, st, views, masked_faces, images=True):
 		"""The GT render of a step: (gt, R, T, second stream or None).  It carries no gradient and reads nothing of the prediction, so it
 		runs on a second stream beside the predicted render: C3 step 8.3 -> 7.8 ms (the two rasteriser launches share the chip
 		5 % better than they use it alone, and the predicted render's small launches run under the GT render's tail).  (Issued before the
@@ -173,12 +173,12 @@ class ModelWithLoss(nn.Module):
 			side.wait_stream(torch.cuda.current_stream(dev))
 		with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
 			# the GT scans are rendered again every step, as the reference does (model.py:1073-1075)
-			gt = self.rdr(st.batch['mesh'], R, T, return_mask=True, mask_with_grad=True, mask_out_faces=True, masked_faces=masked_faces,
-						  return_mask_out_masks=True)
+			gt = self.rdr(st.batch['mesh'], R, T, return_images=images, return_mask=True, mask_with_grad=True, mask_out_faces=True,
+						  masked_faces=masked_faces, return_mask_out_masks=True)
 		return gt, R, T, side
 
-	def _render_pred(self, st, gt, R, T, side, copy_mask_out):
-		pred = self.rdr(st.res['meshes'], R, T, return_mask=True, mask_with_grad=True)
+	def _render_pred(self, st, gt, R, T, side, copy_mask_out, images=True):
+		pred = self.rdr(st.res['meshes'], R, T, return_images=images, return_mask=True, mask_with_grad=True)
 		if side is not None:
 			main = torch.cuda.current_stream(side.device)
 			for t in gt.values():   # allocated on the second stream, read on this one from here on
@@ -187,7 +187,8 @@ class ModelWithLoss(nn.Module):
 			main.wait_stream(side)
 		if copy_mask_out:  # what the GT's slicing plane hides is hidden in the prediction too (model.py:1091-1094)
 			hidden = gt['mask_out_masks']
-			pred['image'] = torch.where(hidden.unsqueeze(-1), torch.ones_like(pred['image']), pred['image'])
+			if images:
+				pred['image'] = torch.where(hidden.unsqueeze(-1), torch.ones_like(pred['image']), pred['image'])
 			pred['mask'] = torch.where(hidden, torch.zeros_like(pred['mask']), pred['mask'])
 		return pred
 
@@ -208,8 +209,11 @@ class ModelWithLoss(nn.Module):
 		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement)
 		st.pred = st.gt = None
 		if render_foot:
-			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None))
-			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out)
+			# the images (shading, vertex normals) are rendered only when something reads them: the pixel loss or the caller (the reference
+			# renders them regardless, renderer.py:290-291; nothing downstream can tell)
+			images = bool(pix or return_renders)
+			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None), images)
+			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images)
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
 		raw, weights = {}, []

@@ -212,6 +212,35 @@ def test_gt_render_on_the_second_stream_changes_nothing():
 		assert close(rec[5], ref[5], 1e-4)
 
 
+def test_silhouette_only_step_skips_the_images_and_keeps_its_numbers():
+	"""With the silhouette loss alone nothing reads the rendered images: ModelWithLoss does not render them (no shading, no vertex normals,
+	no RGB backward).  Loss and gradients must be those of the same step with the images rendered (return_renders=True)."""
+	from find_amd.train_utils import sample_latent_vectors
+	mwl, opts, batch, _ = _setup(n_feet=2, seed=6)
+	mwl.rdr = type(mwl.rdr)(image_size=96, device='cuda')
+	np.random.seed(13)
+	R, T = mwl.rdr.sample_views(nviews=2, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+	names = ['reg', 'shapevec', 'texvec', 'posevec']
+	got = {}
+	for with_images in (True, False):
+		mwl.zero_grad(set_to_none=True)
+		batch.update(sample_latent_vectors(batch, mwl.model.latent_vectors_train))
+		out = mwl(batch, 0, opts, sil=True, render_foot=True, return_renders=with_images, views=(R, T))
+		if with_images:
+			assert 'image' in out[2]['pred'] and 'image' in out[2]['gt']
+		out[0].backward()
+		got[with_images] = (out[0].detach().clone(), out[1]['loss_sil'].detach().clone(),
+							[None if getattr(mwl.model, n).data.grad is None else getattr(mwl.model, n).data.grad.clone() for n in names],
+							mwl.model.base[0].weight.grad.clone())
+	a, b = got[True], got[False]
+	assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+	for x, y in zip(a[2], b[2]):
+		assert (x is None) == (y is None)
+		if x is not None:   # (texvec: no gradient either way -- the silhouette does not depend on colour)
+			assert (x - y).abs().max().item() <= 1e-6 * max(1e-6, x.abs().max().item())
+	assert (a[3] - b[3]).abs().max().item() <= 1e-6 * max(1e-6, a[3].abs().max().item())
+
+
 def test_loss_weights_are_applied_and_flags_respected():
 	mwl, opts, batch, _ = _setup(n_feet=2, seed=4)
 	l0, d0 = mwl(batch, 0, opts)
