@@ -608,3 +608,40 @@ def test_fused_chain_64_row_tiles_equal_the_32_row_tiles(golden_main, shape):
 		assert torch.equal(a[2][k], b[2][k]), k
 	for k in b[3]:
 		assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_side_streams_are_bound_to_queues_beside_the_callers():
+	"""HIP maps streams onto a few hardware queues in creation order; two streams on one queue run in order.  After a call that forks, the
+	context's side streams Q, T1, T2 must each sit on a queue of their own that is not the caller's, and the reduce stream R on T2's -- also
+	when the process created a pile of streams first (what torch.distributed / RCCL does before the first MLP call of a rank)."""
+	import ctypes
+	from find_amd import _lib, synthetic
+	L = _lib.lib()
+	clutter = [torch.cuda.Stream() for _ in range(5)]   # (kept alive: they hold their queues)
+	for s in clutter:
+		with torch.cuda.stream(s):
+			torch.zeros(8, device='cuda').add_(1)
+	torch.cuda.synchronize()
+	h = ctypes.c_void_p()
+	_lib.check(L.find_ctx_create(torch.cuda.current_device(), ctypes.byref(h)), 'find_ctx_create')
+	try:
+		model = synthetic.make_model(1002, train_size=2, val_size=1, device='cuda')
+		lat = synthetic.latents(2, seed=0, device='cuda')
+		prev = _lib._ctx.get(torch.cuda.current_device())
+		_lib._ctx[torch.cuda.current_device()] = h   # the fresh context serves this model's calls
+		try:
+			lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+			res = model.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+			((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()).backward()
+			torch.cuda.synchronize()
+		finally:
+			_lib._ctx[torch.cuda.current_device()] = prev
+		g = (ctypes.c_int32 * 5)()
+		_lib.check(L.find_debug_stream_groups(h, _lib.current_stream(torch.device('cuda')), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+		caller, q, t1, t2, r = list(g)
+		assert caller == 0
+		assert len({caller, q, t1, t2}) == 4, list(g)
+		assert r == t2, list(g)
+	finally:
+		_lib.check(L.find_ctx_destroy(h), 'find_ctx_destroy')
+	del clutter
