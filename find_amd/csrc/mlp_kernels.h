@@ -204,7 +204,11 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 			}
 		}
 		__syncthreads();
-		if (q + 1 < q1) load_chunk(q + 1);
+		// The two waves of a SIMD (w and w + 4) take the two halves of the iteration in opposite orders: one regenerates the next chunk's
+		// operands (global loads, sin / cos: VALU) while the other multiplies (matrix pipe).  In the same order both waited for their
+		// loads together and then queued for the matrix pipe together (PMC: the pipe 22 % busy, the waves waiting 80 % of their time).
+		const bool load_first = wave < 4;
+		if (load_first && q + 1 < q1) load_chunk(q + 1);
 
 		const int zo = (lane >> 5) * 256 + wn * 128 + (lane & 31);
 		const int xo = (lane >> 5) * 256 + wk * 64 + (lane & 31);
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(512) void dw_kernel(const DwArgs g) {
 						acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
 			}
 		}
+		if (!load_first && q + 1 < q1) load_chunk(q + 1);
 	}
 
 	float* pw = g.pw + (int64_t)split * 256 * g.Kp + kt * 256;
