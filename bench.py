@@ -48,9 +48,9 @@ MAC_FWDBWD_REF = 2465536
 MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 
 # HBM-side traffic of one launch of the dominant kernel, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes (tools/profile_round2.sh; profiles/r02_gemm4_pmc_summary.txt): 2 x 64.5 MB fetched + 112.9 MB written (fp32 gemm4);
+# passes (tools/profile_round2.sh; profiles/r02_gemm4_pmc_summary.txt): 2 x 65.3 MB fetched + 112.9 MB written (fp32 gemm4; 241.8 - 243.4 MB over the passes);
 # fp16-mode gemm5 (profiles/r01_traffic_pmc_summary.txt): 2 x 57.10 MB + 112.9 MB.
-GEMM_TRAFFIC_BYTES = 241.9e6
+GEMM_TRAFFIC_BYTES = 243.4e6
 GEMM5_TRAFFIC_BYTES = 227.1e6
 
 
