@@ -59,20 +59,23 @@ def _second_stream(device):
 	probe = torch.zeros(64, device=device)
 	cands = [torch.cuda.Stream(device=device) for _ in range(6)]
 	pick = cands[0]
-	for c in cands:
-		torch.cuda.synchronize(device)
-		spun, done = torch.cuda.Event(), torch.cuda.Event()
-		torch.cuda._sleep(4_000_000)   # ~2 ms on the current stream
-		spun.record(main)
-		with torch.cuda.stream(c):
-			probe.add_(1.0)
-			done.record(c)
-		done.synchronize()
-		beside = not spun.query()
-		torch.cuda.synchronize(device)
-		if beside:
-			pick = c
-			break
+	try:
+		for c in cands:
+			torch.cuda.synchronize(device)
+			spun, done = torch.cuda.Event(), torch.cuda.Event()
+			torch.cuda._sleep(4_000_000)   # ~2 ms on the current stream
+			spun.record(main)
+			with torch.cuda.stream(c):
+				probe.add_(1.0)
+				done.record(c)
+			done.synchronize()
+			beside = not spun.query()
+			torch.cuda.synchronize(device)
+			if beside:
+				pick = c
+				break
+	except (RuntimeError, AttributeError):   # (no spin kernel in this build of torch: any stream will do, the overlap may be lost)
+		pass
 	_SECOND_STREAMS[device] = pick
 	return pick
 
