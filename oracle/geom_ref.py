@@ -52,6 +52,11 @@ def knn1(x, y, x_len=None, y_len=None):
 		bad = torch.arange(P2)[None, None, :] >= y_len.view(N, 1, 1)
 		d = d.masked_fill(bad, float('inf'))
 	dist, idx = d.min(dim=2)
+	if y_len is not None:
+		# a cloud without targets: knn_points pads what it cannot find with distance 0 / index -1 [P3D-recall]
+		none = (y_len.view(N, 1) <= 0).expand(N, P1)
+		dist = dist.masked_fill(none, 0.0)
+		idx = idx.masked_fill(none, -1)
 	if x_len is not None:
 		padx = torch.arange(P1)[None, :] >= x_len.view(N, 1)
 		dist = dist.masked_fill(padx, 0.0)

@@ -74,6 +74,33 @@ def test_nn_ragged_and_ties():
 	assert int(i2[0, 0]) == 3
 
 
+def test_chamfer_with_an_empty_cloud():
+	"""A cloud that the z-cutoff empties on one or both sides (losses.py:69-85 builds ragged point sets): no query, no target -- its terms are
+	0 (lengths clamp to 1 in the means), the other clouds' terms and gradients are unaffected, nothing is NaN."""
+	from find_amd import functional as FN
+	g = torch.Generator().manual_seed(21)
+	x = torch.randn(3, 64, 3, generator=g) * 0.05
+	y = torch.randn(3, 80, 3, generator=g) * 0.05
+	for xl, yl in [(torch.tensor([64, 0, 10]), torch.tensor([80, 33, 0])), (torch.tensor([0, 0, 0]), torch.tensor([80, 0, 5]))]:
+		xg = x.clone().cuda().requires_grad_(True)
+		yg = y.clone().cuda().requires_grad_(True)
+		loss, _ = FN.chamfer_distance(xg, yg, xl.cuda(), yl.cuda())
+		loss.backward()
+		xr = x.clone().requires_grad_(True)
+		yr = y.clone().requires_grad_(True)
+		ref = G.chamfer_distance(xr, yr, xl, yl)
+		assert torch.isfinite(ref) and abs(loss.item() - ref.item()) < 1e-6 * max(1e-3, abs(ref.item()))
+		if ref.requires_grad and ref.grad_fn is not None:
+			ref.backward()
+		for got, want in ((xg.grad, xr.grad), (yg.grad, yr.grad)):
+			want = torch.zeros_like(x if got.shape == x.shape else y) if want is None else want
+			assert torch.isfinite(got).all()
+			assert (got.cpu() - want).abs().max().item() < 1e-7
+		d, i = FN.knn1(x.cuda(), y.cuda(), xl.cuda(), yl.cuda())
+		rd, ri = G.knn1(x, y, xl, yl)
+		assert torch.equal(i.cpu().long(), ri) and (d.cpu() - rd).abs().max().item() < 1e-6
+
+
 def test_chamfer_forward_backward_vs_oracle():
 	from find_amd import functional as FN
 	g = torch.Generator().manual_seed(5)
