@@ -373,3 +373,25 @@ def test_wave_per_tile_variant_renders_the_same_image():
 	# float-atomic sums on top (two runs of the SAME variant differ)
 	assert (i0 - i1).abs().max().item() < 1e-4
 	assert float(m0.max()) > 0.9
+
+
+def test_largest_image_size_renders_and_the_next_one_is_refused():
+	"""Image sizes go up to 2048 (tile coordinates are packed in 8 bits, render.hip): one mesh, one view at 2048^2 must give the silhouette
+	of the 512^2 render -- same covered fraction of the image, soft mask in [0, 1], every covered pixel's face a real face -- with
+	gradients flowing; 2049 must be refused before anything is launched."""
+	from find_amd import functional_render as FR
+	verts, faces, cols, R, T = _scene(n_meshes=1, rings=10, segs=12, seed=21, n_views=1)
+	cover = {}
+	for size in (512, 2048):
+		vg = verts.clone().cuda().requires_grad_(True)
+		(mask, image, p2f, zbuf), _ = _render_gpu(vg, faces, cols, R, T, size, want_frags=True)
+		assert mask.shape == (1, 1, size, size) and image.shape == (1, 1, size, size, 3)
+		assert float(mask.detach().min()) >= 0.0 and float(mask.detach().max()) <= 1.0 and torch.isfinite(image).all()
+		ids = p2f.cpu()
+		assert int(ids.max()) < faces.shape[0] and int(ids.min()) >= -1
+		cover[size] = float((ids >= 0).float().mean())
+		mask.sum().backward()
+		assert torch.isfinite(vg.grad).all() and float(vg.grad.abs().max()) > 0
+	assert abs(cover[2048] - cover[512]) < 0.01 * cover[512], cover
+	with pytest.raises(RuntimeError, match='image size out of range'):
+		_render_gpu(verts, faces, cols, R, T, 2049)
