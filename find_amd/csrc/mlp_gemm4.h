@@ -123,11 +123,34 @@ __global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
+		// (epilogue descriptors up front: the first mask block is requested under the last chunk's MFMAs)
+		const int valid_rows = min(32, V - v0);
+		float* ytile = g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy;
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ytile)), 0, valid_rows * ldy * 4, 0x00020000);
+		const int voff = ((4 * fh) * ldy + col0 + li) * 4;
+		__amdgpu_buffer_rsrc_t msrc = rsrc;
+		if constexpr (EPI == EPI_MASK) {
+			const float* mtile = g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy;
+			msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(mtile)), 0, valid_rows * ldy * 4, 0x00020000);
+		}
+		// EPI_MASK: the mask values of block ni + 1 are requested before block ni is stored -- the compiler keeps a buffer load behind
+		// the buffer stores in front of it (two descriptors: it cannot rule out aliasing), so block by block the epilogue paid the
+		// load latency four times per unit -- and those of block 0 before the unit's last chunk is multiplied.
+		float mv[2][16];
+		auto load_mask = [&](int ni, float (&m)[16]) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				m[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0));
+		};
+
 		// (the wave in its MFMA loop outranks the SIMD's other wave while that one runs its epilogue: 122.7 -> 121.0 us per launch at the C2
 		// shape in isolation, no difference inside the step; ablate bit 16 switches it off)
 		if (!(g.ablate & 16)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
 		for (int c = 0; c < 8; ++c) {
+			if constexpr (EPI == EPI_MASK) {
+				if (c == 7) load_mask(0, mv[0]);
+			}
 			// A prefetch: chunk c+PD of this unit, or chunk c+PD-8 of the wave's next unit
 			{
 				const int pc = c + GEMM4_PD;
@@ -160,28 +183,16 @@ __global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 		// ---- epilogue: buffer stores; the SRD's size is the number of valid bytes of the unit, so rows past the end of a
 		// foot are dropped by the bounds check.  Element (r, lane) of block ni = row (r&3) + 8(r>>2) + 4fh, column 32ni + li.
 		{
-			const int valid_rows = min(32, V - v0);
-			float* ytile = g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy;
-			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ytile)), 0, valid_rows * ldy * 4, 0x00020000);
-			const int voff = ((4 * fh) * ldy + col0 + li) * 4;
-			__amdgpu_buffer_rsrc_t msrc = rsrc;
-			if constexpr (EPI == EPI_MASK) {
-				const float* mtile = g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy;
-				msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(mtile)), 0, valid_rows * ldy * 4, 0x00020000);
-			}
 #pragma unroll
 			for (int ni = 0; ni < NI; ++ni) {
-				float mv[16];
 				if constexpr (EPI == EPI_MASK) {
-#pragma unroll
-					for (int r = 0; r < 16; ++r)
-						mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0));
+					if (ni + 1 < NI) load_mask(ni + 1, mv[(ni + 1) & 1]);
 				}
 #pragma unroll
 				for (int r = 0; r < 16; ++r) {
 					float val = acc[ni][r];
 					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv[ni], 0.f);
-					if constexpr (EPI == EPI_MASK) val = (mv[r] > 0.f) ? val : 0.f;
+					if constexpr (EPI == EPI_MASK) val = (mv[ni & 1][r] > 0.f) ? val : 0.f;
 					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0);
 				}
 			}
