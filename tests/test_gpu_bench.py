@@ -1,0 +1,35 @@
+"""The driver's contract for bench.py: one JSON line on stdout with the metric of BASELINE.json, the timing fields, and the roofline /
+cpu_baseline objects of the hot-path tier.  (A short run: 3 timed steps, no extra records.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-records'],
+					   capture_output=True, text=True, timeout=900, cwd=ROOT)
+	assert r.returncode == 0, r.stderr[-2000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+	assert len(lines) == 1, lines
+	d = json.loads(lines[0])
+	base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+	# BASELINE.json: "deformed vertices x rendered views / sec (fwd+bwd); Chamfer vs ref" -- the throughput clause is the bench metric
+	assert d['metric'] == base['metric'].split(';')[0].replace('\u00d7', 'x').strip() and d['unit'] == 'vertices*views/s'
+	assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1
+	assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic' and d['dtype'] == 'f32'
+	assert d['vs_baseline'] is None   # BASELINE.md holds no published number for this metric
+	assert d['value'] > 0 and d['ms_per_step'] > 0
+	assert abs(d['value'] - 16 * 6890 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+	assert isinstance(d['config'].get('workload'), str) and 'model' not in d['config']
+	rf = d['roofline']
+	assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s')
+	assert rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and 0.3 < rf['frac'] < 1.0
+	assert rf['traffic'] is None or rf['traffic'] > 0
+	cb = d['cpu_baseline']
+	assert cb['value'] > 0 and cb['unit'] == d['unit'] and cb['cores'] >= 1 and cb['kind'] in ('reference', 'port') and isinstance(cb['sample'], str)
