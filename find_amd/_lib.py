@@ -89,6 +89,9 @@ PROTOTYPES = {
 	'find_chamfer_bwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
 	'find_masked_mse_fwd': (c_int, [_P, _P, _I, _P, _P]),
 	'find_masked_mse_bwd': (c_int, [_P, _P, _I, _P, _P, _P]),
+	'find_image_mse_ws_bytes': (c_int64, []),
+	'find_image_mse_fwd': (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P]),
+	'find_image_mse_bwd': (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
 	'find_smooth_loss_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, c_float, c_float, _P, _P, _I, _P]),
 	'find_smooth_loss_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, c_float, c_float, _P, _P, _I, _P, _P]),
 	'find_smooth_ws_bytes': (c_int64, [_I, _I, _I]),

@@ -219,6 +219,59 @@ __global__ void masked_mse_bwd_kernel(const float* __restrict__ pred, const floa
 	d_pred[i * 3] = g * (pred[i * 3] - t0); d_pred[i * 3 + 1] = g * (pred[i * 3 + 1] - t1); d_pred[i * 3 + 2] = g * (pred[i * 3 + 2] - t2);
 }
 
+// ------------------------------------------------------------------------------------------- image losses
+// mean( (a * am - b * bm)^2 ) over n_pix x C values: FIND's pixel loss compares the rendered images INSIDE their silhouettes (a, b (.., C)
+// images, am, bm (..) masks: model.py:1101-1105) and its silhouette loss the two masks (C = 1, no am / bm: model.py:1107-1108, losses.py:122-128).
+// As torch expressions these were five elementwise passes + a reduction forward and as many backward over 12.6 M-value tensors at 512^2
+// (~0.1 ms each, 1.7 ms of the C4 step between the render and its backward); here one pass each way.  Deterministic: fixed block ->
+// element mapping, per-block partial sums, one wave adds the partials in index order.
+constexpr int IMSE_BLOCKS = 1024;
+__global__ __launch_bounds__(1024) void image_mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ am, const float* __restrict__ b,
+															  const float* __restrict__ bm, int64_t n_pix, int C, float* __restrict__ partial) {
+	__shared__ float red[16];
+	float s = 0.f;
+	for (int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 1024) {
+		const float ma = am ? am[p] : 1.f, mb = bm ? bm[p] : 1.f;
+		for (int c = 0; c < C; ++c) {
+			const float d = a[p * C + c] * ma - b[p * C + c] * mb;
+			s += d * d;
+		}
+	}
+	s = wave_sum(s);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float t = 0.f;
+		for (int w = 0; w < 16; ++w) t += red[w];
+		partial[blockIdx.x] = t;
+	}
+}
+
+__global__ __launch_bounds__(64) void image_mse_finalize_kernel(const float* __restrict__ partial, int nblk, float scale, float* __restrict__ loss) {
+	float t = 0.f;
+	for (int k = threadIdx.x; k < nblk; k += 64) t += partial[k];
+	t = wave_sum(t);
+	if (threadIdx.x == 0) *loss = t * scale;
+}
+
+// d_a = g * 2 / (n_pix C) * (a am - b bm) * am;   d_am = g * 2 / (n_pix C) * sum_c (a am - b bm) * a
+__global__ __launch_bounds__(256) void image_mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ am, const float* __restrict__ b,
+															 const float* __restrict__ bm, int64_t n_pix, int C, const float* __restrict__ g_loss,
+															 float* __restrict__ d_a, float* __restrict__ d_am) {
+	const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (p >= n_pix) return;
+	const float s = 2.0f * (*g_loss) / ((float)n_pix * (float)C);
+	const float ma = am ? am[p] : 1.f, mb = bm ? bm[p] : 1.f;
+	float dm = 0.f;
+	for (int c = 0; c < C; ++c) {
+		const float av = a[p * C + c];
+		const float d = s * (av * ma - b[p * C + c] * mb);
+		if (d_a) d_a[p * C + c] = d * ma;
+		dm += d * av;
+	}
+	if (d_am) d_am[p] = dm;
+}
+
 // ------------------------------------------------------------------------------------------- nearest neighbour
 // A lane owns 2*NP query points, held as NP packed pairs (v_pk_add/mul/fma_f32: two queries per VALU instruction); the four waves
 // of a block own the SAME 128*NP queries and each scans one quarter of every target tile (targets stream through LDS in tiles of
@@ -825,6 +878,32 @@ extern "C" int find_masked_mse_bwd(const float* pred, const float* target, int64
 	FIND_REQUIRE(n_pts >= 1 && n_pts < (1ll << 40), "find_masked_mse_bwd: bad sizes");
 	hipLaunchKernelGGL(masked_mse_bwd_kernel, dim3((unsigned)cdiv(n_pts, 256)), dim3(256), 0, (hipStream_t)stream, pred, target, n_pts, g_loss, d_pred);
 	FIND_LAUNCH_CHECK("masked_mse_bwd_kernel");
+	return FIND_OK;
+}
+
+extern "C" int64_t find_image_mse_ws_bytes(void) { return IMSE_BLOCKS * (int64_t)sizeof(float); }
+
+extern "C" int find_image_mse_fwd(const float* a, const float* a_mask, const float* b, const float* b_mask, int64_t n_pix, int64_t channels, float* loss,
+								  void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(a && b && loss && ws, "find_image_mse_fwd: NULL argument");
+	FIND_REQUIRE(n_pix >= 1 && n_pix < (1ll << 40) && channels >= 1 && channels <= 16, "find_image_mse_fwd: bad sizes");
+	if (ws_bytes < find_image_mse_ws_bytes()) { set_error("find_image_mse_fwd: workspace too small"); return FIND_EWORKSPACE; }
+	const int nblk = (int)std::min<int64_t>(IMSE_BLOCKS, cdiv(n_pix, 1024));
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(image_mse_fwd_kernel, dim3((unsigned)nblk), dim3(1024), 0, s, a, a_mask, b, b_mask, n_pix, (int)channels, (float*)ws);
+	hipLaunchKernelGGL(image_mse_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, nblk, 1.0f / ((float)n_pix * (float)channels), loss);
+	FIND_LAUNCH_CHECK("image_mse_fwd_kernel");
+	return FIND_OK;
+}
+
+extern "C" int find_image_mse_bwd(const float* a, const float* a_mask, const float* b, const float* b_mask, int64_t n_pix, int64_t channels,
+								  const float* g_loss, float* d_a, float* d_a_mask, void* stream) {
+	FIND_REQUIRE(a && b && g_loss && (d_a || d_a_mask), "find_image_mse_bwd: NULL argument");
+	FIND_REQUIRE(n_pix >= 1 && n_pix < (1ll << 40) && channels >= 1 && channels <= 16, "find_image_mse_bwd: bad sizes");
+	FIND_REQUIRE(!d_a_mask || a_mask, "find_image_mse_bwd: d_a_mask without a_mask");
+	hipLaunchKernelGGL(image_mse_bwd_kernel, dim3((unsigned)cdiv(n_pix, 256)), dim3(256), 0, (hipStream_t)stream, a, a_mask, b, b_mask, n_pix, (int)channels,
+					   g_loss, d_a, d_a_mask);
+	FIND_LAUNCH_CHECK("image_mse_bwd_kernel");
 	return FIND_OK;
 }
 

@@ -650,6 +650,47 @@ def masked_mse(pred, target):
 
 
 # ----------------------------------------------------------------------------------------------- smoothness
+class _ImageMSE(torch.autograd.Function):
+	"""mean((a * am - b * bm)^2): the pixel loss on images inside their silhouettes / the silhouette loss on the masks themselves
+	(find_image_mse_fwd / _bwd); gradients to a and am only (b, bm are the GT render)."""
+
+	@staticmethod
+	def forward(ctx, a, am, b, bm):
+		_require_gpu(a, am, b, bm)
+		L = _lib.lib()
+		a, am, b, bm = _c(a), _c(am), _c(b.detach()), _c(None if bm is None else bm.detach())
+		if a.shape != b.shape:
+			raise RuntimeError(f'find_amd.image_mse: shapes differ: {tuple(a.shape)} / {tuple(b.shape)}')
+		C = 1 if am is None and bm is None else int(a.shape[-1])
+		n_pix = a.numel() // C
+		for m in (am, bm):
+			if m is not None and m.numel() != n_pix:
+				raise RuntimeError(f'find_amd.image_mse: a mask of {m.numel()} values for {n_pix} pixels')
+		loss = torch.empty((), device=a.device, dtype=torch.float32)
+		ws = _ws(L.find_image_mse_ws_bytes(), a.device)
+		check(L.find_image_mse_fwd(ptr(a), ptr(am), ptr(b), ptr(bm), n_pix, C, ptr(loss), ptr(ws), ws.numel(), current_stream(a.device)), 'find_image_mse_fwd')
+		ctx.save_for_backward(a, am, b, bm)
+		ctx.dims = (n_pix, C)
+		return loss
+
+	@staticmethod
+	def backward(ctx, g):
+		L = _lib.lib()
+		a, am, b, bm = ctx.saved_tensors
+		n_pix, C = ctx.dims
+		d_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+		d_am = torch.empty_like(am) if (am is not None and ctx.needs_input_grad[1]) else None
+		if d_a is None and d_am is None:
+			return None, None, None, None
+		check(L.find_image_mse_bwd(ptr(a), ptr(am), ptr(b), ptr(bm), n_pix, C, ptr(_c(g)), ptr(d_a), ptr(d_am), current_stream(a.device)), 'find_image_mse_bwd')
+		return d_a, d_am, None, None
+
+
+def image_mse(a, b, a_mask=None, b_mask=None):
+	"""F.mse_loss(a * a_mask[..., None], b * b_mask[..., None]) (masks optional) in one pass each way; b / b_mask carry no gradient."""
+	return _ImageMSE.apply(a, a_mask, b, b_mask)
+
+
 class MeshTopology:
 	"""Static per-template tables for the smoothness kernels: unique undirected edges, vertex->incident-corner CSR and
 	vertex->neighbour CSR (host-built once, cached per faces tensor)."""

@@ -129,11 +129,20 @@ class ModelWithLoss(nn.Module):
 		codes = {k: st.batch.get(f'{k}_{sfx}', None) for k in ('shapevec', 'texvec', 'posevec')}
 		return self.col_loss(self.model, st.batch, **codes)
 
+	@staticmethod
+	def _on_gpu(*ts):
+		return all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in ts)
+
 	def _raw_pix(self, st):
-		# images are compared inside the silhouettes only (model.py:1101-1105)
-		return self.pix_loss(st.pred['image'] * st.pred['mask'].unsqueeze(-1), st.gt['image'] * st.gt['mask'].unsqueeze(-1))
+		# images are compared inside the silhouettes only (model.py:1101-1105): MSE(image * mask, gt image * gt mask), one pass each way
+		pi, pm, gi, gm = st.pred['image'], st.pred['mask'], st.gt['image'], st.gt['mask']
+		if self._on_gpu(pi, pm, gi, gm):
+			return FN.image_mse(pi, gi, pm, gm)
+		return self.pix_loss(pi * pm.unsqueeze(-1), gi * gm.unsqueeze(-1))
 
 	def _raw_sil(self, st):
+		if self._on_gpu(st.pred['mask'], st.gt['mask']):
+			return FN.image_mse(st.pred['mask'], st.gt['mask'])
 		return self.sil_loss(st.pred['mask'], st.gt['mask'])
 
 	# ------------------------------------------------------------------ pieces of a step

@@ -283,6 +283,15 @@ int find_chamfer_bwd(const float* x, const int32_t* x_len, const float* y, const
  * ---------------------------------------------------------------------------------------------- */
 int find_masked_mse_fwd(const float* pred, const float* target, int64_t n_pts, float* loss, void* stream);
 int find_masked_mse_bwd(const float* pred, const float* target, int64_t n_pts, const float* g_loss, float* d_pred, void* stream);
+/* Image losses in one pass each way: loss = mean over n_pix x channels of (a * a_mask - b * b_mask)^2, masks per pixel or NULL (= 1).
+ * Replaces nn.MSELoss on image * mask.unsqueeze(-1) products (pixel loss, src/model/model.py:1101-1105: images compared inside their
+ * silhouettes) and on the two masks (silhouette loss, model.py:1107-1108 / losses.py:122-128: channels = 1, no masks).  ws: find_image_mse_ws_bytes().
+ * Backward: gradients w.r.t. a (d_a, same shape) and a_mask (d_a_mask, per pixel), either may be NULL; b / b_mask are the GT side. */
+int64_t find_image_mse_ws_bytes(void);
+int find_image_mse_fwd(const float* a, const float* a_mask, const float* b, const float* b_mask, int64_t n_pix, int64_t channels, float* loss,
+					   void* ws, int64_t ws_bytes, void* stream);
+int find_image_mse_bwd(const float* a, const float* a_mask, const float* b, const float* b_mask, int64_t n_pix, int64_t channels,
+					   const float* g_loss, float* d_a, float* d_a_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mesh smoothness: mesh_edge_loss(target 0) and mesh_laplacian_smoothing('cot').

@@ -325,3 +325,37 @@ def test_smoothness_loss_scalar_vs_oracle():
 	assert (vg.grad.cpu() - vr.grad).abs().max().item() < 2e-4 * vr.grad.abs().max().item()
 	e, l = FN.mesh_edge_and_laplacian(verts.cuda(), topo)
 	assert abs(loss.item() - (10.0 * e.item() + 0.1 * l.item())) < 1e-6 * abs(loss.item())
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 40, 40), (1, 1, 7, 5), (3, 2, 129, 65)])
+def test_image_mse_vs_torch(shape):
+	"""find_image_mse_*: MSE(image * mask, gt image * gt mask) (pixel loss, model.py:1101-1105) and MSE(mask, gt mask) (silhouette loss),
+	values and both gradients against the torch expression on the host."""
+	from find_amd import functional as FN
+	g = torch.Generator().manual_seed(sum(shape))
+	img, gimg = torch.rand(*shape, 3, generator=g), torch.rand(*shape, 3, generator=g)
+	m, gm = torch.rand(*shape, generator=g), (torch.rand(*shape, generator=g) > 0.4).float()
+	a, am = img.clone().cuda().requires_grad_(True), m.clone().cuda().requires_grad_(True)
+	loss = FN.image_mse(a, gimg.cuda(), am, gm.cuda())
+	(loss * 3.0).backward()
+	ar, amr = img.clone().requires_grad_(True), m.clone().requires_grad_(True)
+	ref = torch.nn.functional.mse_loss(ar * amr.unsqueeze(-1), gimg * gm.unsqueeze(-1))
+	(ref * 3.0).backward()
+	assert abs(loss.item() - ref.item()) < 1e-6 * max(1e-3, abs(ref.item()))
+	assert (a.grad.cpu() - ar.grad).abs().max().item() < 1e-6 * max(1e-6, ar.grad.abs().max().item()) + 1e-12
+	assert (am.grad.cpu() - amr.grad).abs().max().item() < 1e-5 * max(1e-6, amr.grad.abs().max().item()) + 1e-12
+	# silhouettes: no masks, one channel
+	s = m.clone().cuda().requires_grad_(True)
+	ls = FN.image_mse(s, gm.cuda())
+	ls.backward()
+	sr = m.clone().requires_grad_(True)
+	rs = torch.nn.functional.mse_loss(sr, gm)
+	rs.backward()
+	assert abs(ls.item() - rs.item()) < 1e-6 * max(1e-3, abs(rs.item()))
+	assert (s.grad.cpu() - sr.grad).abs().max().item() < 1e-6 * max(1e-6, sr.grad.abs().max().item()) + 1e-12
+	# only the mask needs a gradient; a shape mismatch raises
+	am2 = m.clone().cuda().requires_grad_(True)
+	FN.image_mse(img.cuda(), gimg.cuda(), am2, gm.cuda()).backward()
+	assert (am2.grad * 3.0 - am.grad).abs().max().item() < 1e-5 * max(1e-6, am.grad.abs().max().item()) + 1e-12
+	with pytest.raises(RuntimeError):
+		FN.image_mse(img.cuda(), gimg.cuda()[:, :, :-1])
