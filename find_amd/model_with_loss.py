@@ -189,7 +189,7 @@ class ModelWithLoss(nn.Module):
 						  masked_faces=masked_faces, return_mask_out_masks=True)
 		return gt, R, T, side
 
-	def _render_pred(self, st, gt, R, T, side, copy_mask_out, images=True):
+	def _render_pred(self, st, gt, R, T, side, copy_mask_out, images=True, mask_image=True):
 		pred = self.rdr(st.res['meshes'], R, T, return_images=images, return_mask=True, mask_with_grad=True)
 		if side is not None:
 			main = torch.cuda.current_stream(side.device)
@@ -199,7 +199,8 @@ class ModelWithLoss(nn.Module):
 			main.wait_stream(side)
 		if copy_mask_out:  # what the GT's slicing plane hides is hidden in the prediction too (model.py:1091-1094)
 			hidden = gt['mask_out_masks']
-			if images:
+			# (the image is whitened only for a caller who looks at it: the pixel loss reads it through the mask, which is zero there)
+			if images and mask_image:
 				pred['image'] = torch.where(hidden.unsqueeze(-1), torch.ones_like(pred['image']), pred['image'])
 			pred['mask'] = torch.where(hidden, torch.zeros_like(pred['mask']), pred['mask'])
 		return pred
@@ -225,7 +226,7 @@ class ModelWithLoss(nn.Module):
 			# renders them regardless, renderer.py:290-291; nothing downstream can tell)
 			images = bool(pix or return_renders)
 			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None), images)
-			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images)
+			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images, mask_image=bool(return_renders))
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
 		raw, weights = {}, []

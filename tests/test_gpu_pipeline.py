@@ -241,6 +241,35 @@ def test_silhouette_only_step_skips_the_images_and_keeps_its_numbers():
 	assert (a[3] - b[3]).abs().max().item() <= 1e-6 * max(1e-6, a[3].abs().max().item())
 
 
+def test_pixel_loss_step_without_returned_renders_keeps_its_numbers():
+	"""With copy_mask_out the predicted image is whitened where the GT's slicing plane hides the foot (model.py:1091-1094) -- for a caller who
+	looks at it.  The pixel loss reads the image through the mask, which is zero there, so a step that does not return its renders skips the
+	whitening: loss and gradients must be those of the step that returns them."""
+	from find_amd.train_utils import sample_latent_vectors
+	mwl, opts, batch, _ = _setup(n_feet=2, seed=7)
+	mwl.rdr = type(mwl.rdr)(image_size=96, device='cuda')
+	np.random.seed(14)
+	R, T = mwl.rdr.sample_views(nviews=2, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
+	# faces to mask out, so that `hidden` is not empty
+	batch = dict(batch)
+	batch['masked_faces'] = [torch.arange(0, 400), torch.arange(200, 900)]
+	names = ['reg', 'shapevec', 'texvec', 'posevec']
+	got = {}
+	for ret in (True, False):
+		mwl.zero_grad(set_to_none=True)
+		batch.update(sample_latent_vectors(batch, mwl.model.latent_vectors_train))
+		out = mwl(batch, 0, opts, sil=True, pix=True, render_foot=True, return_renders=ret, views=(R, T))
+		if ret:
+			assert bool(out[2]['gt']['mask_out_masks'].any()), 'the scene must hide some pixels'
+		out[0].backward()
+		got[ret] = (out[0].detach().clone(), [getattr(mwl.model, n).data.grad.clone() for n in names], mwl.model.base[0].weight.grad.clone())
+	a, b = got[True], got[False]
+	assert abs(a[0].item() - b[0].item()) <= 1e-6 * max(1e-6, abs(a[0].item()))
+	for x, y in zip(a[1], b[1]):
+		assert (x - y).abs().max().item() <= 1e-5 * max(1e-6, x.abs().max().item())
+	assert (a[2] - b[2]).abs().max().item() <= 1e-5 * max(1e-6, a[2].abs().max().item())
+
+
 def test_loss_weights_are_applied_and_flags_respected():
 	mwl, opts, batch, _ = _setup(n_feet=2, seed=4)
 	l0, d0 = mwl(batch, 0, opts)
