@@ -226,15 +226,39 @@ __global__ void masked_mse_bwd_kernel(const float* __restrict__ pred, const floa
 // (~0.1 ms each, 1.7 ms of the C4 step between the render and its backward); here one pass each way.  Deterministic: fixed block ->
 // element mapping, per-block partial sums, one wave adds the partials in index order.
 constexpr int IMSE_BLOCKS = 1024;
+// A thread takes FOUR consecutive pixels when it can (n_pix a multiple of 4, C = 3 or 1: 16-byte loads of a, b and of the masks); the
+// scalar version moved 134 MB in 137 us at 512^2.
+template <int C, bool VEC>
 __global__ __launch_bounds__(1024) void image_mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ am, const float* __restrict__ b,
-															  const float* __restrict__ bm, int64_t n_pix, int C, float* __restrict__ partial) {
+															  const float* __restrict__ bm, int64_t n_pix, int Cdyn, float* __restrict__ partial) {
 	__shared__ float red[16];
 	float s = 0.f;
-	for (int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 1024) {
-		const float ma = am ? am[p] : 1.f, mb = bm ? bm[p] : 1.f;
-		for (int c = 0; c < C; ++c) {
-			const float d = a[p * C + c] * ma - b[p * C + c] * mb;
-			s += d * d;
+	if constexpr (VEC) {
+		const int64_t nq = n_pix >> 2;
+		for (int64_t q = (int64_t)blockIdx.x * 1024 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 1024) {
+			float va[4 * C], vb[4 * C], ma[4], mb[4];
+#pragma unroll
+			for (int k = 0; k < C; ++k) {
+				const float4 x = reinterpret_cast<const float4*>(a)[q * C + k], y = reinterpret_cast<const float4*>(b)[q * C + k];
+				va[4 * k] = x.x; va[4 * k + 1] = x.y; va[4 * k + 2] = x.z; va[4 * k + 3] = x.w;
+				vb[4 * k] = y.x; vb[4 * k + 1] = y.y; vb[4 * k + 2] = y.z; vb[4 * k + 3] = y.w;
+			}
+			const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+			const float4 x = am ? reinterpret_cast<const float4*>(am)[q] : one, y = bm ? reinterpret_cast<const float4*>(bm)[q] : one;
+			ma[0] = x.x; ma[1] = x.y; ma[2] = x.z; ma[3] = x.w; mb[0] = y.x; mb[1] = y.y; mb[2] = y.z; mb[3] = y.w;
+#pragma unroll
+			for (int i = 0; i < 4 * C; ++i) {
+				const float d = va[i] * ma[i / C] - vb[i] * mb[i / C];
+				s += d * d;
+			}
+		}
+	} else {
+		for (int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 1024) {
+			const float ma = am ? am[p] : 1.f, mb = bm ? bm[p] : 1.f;
+			for (int c = 0; c < Cdyn; ++c) {
+				const float d = a[p * Cdyn + c] * ma - b[p * Cdyn + c] * mb;
+				s += d * d;
+			}
 		}
 	}
 	s = wave_sum(s);
@@ -255,21 +279,48 @@ __global__ __launch_bounds__(64) void image_mse_finalize_kernel(const float* __r
 }
 
 // d_a = g * 2 / (n_pix C) * (a am - b bm) * am;   d_am = g * 2 / (n_pix C) * sum_c (a am - b bm) * a
+template <int C, bool VEC>
 __global__ __launch_bounds__(256) void image_mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ am, const float* __restrict__ b,
-															 const float* __restrict__ bm, int64_t n_pix, int C, const float* __restrict__ g_loss,
+															 const float* __restrict__ bm, int64_t n_pix, int Cdyn, const float* __restrict__ g_loss,
 															 float* __restrict__ d_a, float* __restrict__ d_am) {
-	const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (p >= n_pix) return;
-	const float s = 2.0f * (*g_loss) / ((float)n_pix * (float)C);
-	const float ma = am ? am[p] : 1.f, mb = bm ? bm[p] : 1.f;
-	float dm = 0.f;
-	for (int c = 0; c < C; ++c) {
-		const float av = a[p * C + c];
-		const float d = s * (av * ma - b[p * C + c] * mb);
-		if (d_a) d_a[p * C + c] = d * ma;
-		dm += d * av;
+	const float s = 2.0f * (*g_loss) / ((float)n_pix * (float)(VEC ? C : Cdyn));
+	if constexpr (VEC) {
+		const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+		if (q >= (n_pix >> 2)) return;
+		float va[4 * C], vb[4 * C], ma[4], mb[4], da[4 * C], dm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+		for (int k = 0; k < C; ++k) {
+			const float4 x = reinterpret_cast<const float4*>(a)[q * C + k], y = reinterpret_cast<const float4*>(b)[q * C + k];
+			va[4 * k] = x.x; va[4 * k + 1] = x.y; va[4 * k + 2] = x.z; va[4 * k + 3] = x.w;
+			vb[4 * k] = y.x; vb[4 * k + 1] = y.y; vb[4 * k + 2] = y.z; vb[4 * k + 3] = y.w;
+		}
+		const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+		const float4 x = am ? reinterpret_cast<const float4*>(am)[q] : one, y = bm ? reinterpret_cast<const float4*>(bm)[q] : one;
+		ma[0] = x.x; ma[1] = x.y; ma[2] = x.z; ma[3] = x.w; mb[0] = y.x; mb[1] = y.y; mb[2] = y.z; mb[3] = y.w;
+#pragma unroll
+		for (int i = 0; i < 4 * C; ++i) {
+			const float d = s * (va[i] * ma[i / C] - vb[i] * mb[i / C]);
+			da[i] = d * ma[i / C];
+			dm[i / C] += d * va[i];
+		}
+		if (d_a) {
+#pragma unroll
+			for (int k = 0; k < C; ++k) reinterpret_cast<float4*>(d_a)[q * C + k] = make_float4(da[4 * k], da[4 * k + 1], da[4 * k + 2], da[4 * k + 3]);
+		}
+		if (d_am) reinterpret_cast<float4*>(d_am)[q] = make_float4(dm[0], dm[1], dm[2], dm[3]);
+	} else {
+		const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+		if (p >= n_pix) return;
+		const float ma = am ? am[p] : 1.f, mb = bm ? bm[p] : 1.f;
+		float dm = 0.f;
+		for (int c = 0; c < Cdyn; ++c) {
+			const float av = a[p * Cdyn + c];
+			const float d = s * (av * ma - b[p * Cdyn + c] * mb);
+			if (d_a) d_a[p * Cdyn + c] = d * ma;
+			dm += d * av;
+		}
+		if (d_am) d_am[p] = dm;
 	}
-	if (d_am) d_am[p] = dm;
 }
 
 // ------------------------------------------------------------------------------------------- nearest neighbour
@@ -881,6 +932,8 @@ extern "C" int find_masked_mse_bwd(const float* pred, const float* target, int64
 	return FIND_OK;
 }
 
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }   // (NULL counts as aligned)
+
 extern "C" int64_t find_image_mse_ws_bytes(void) { return IMSE_BLOCKS * (int64_t)sizeof(float); }
 
 extern "C" int find_image_mse_fwd(const float* a, const float* a_mask, const float* b, const float* b_mask, int64_t n_pix, int64_t channels, float* loss,
@@ -890,7 +943,10 @@ extern "C" int find_image_mse_fwd(const float* a, const float* a_mask, const flo
 	if (ws_bytes < find_image_mse_ws_bytes()) { set_error("find_image_mse_fwd: workspace too small"); return FIND_EWORKSPACE; }
 	const int nblk = (int)std::min<int64_t>(IMSE_BLOCKS, cdiv(n_pix, 1024));
 	hipStream_t s = (hipStream_t)stream;
-	hipLaunchKernelGGL(image_mse_fwd_kernel, dim3((unsigned)nblk), dim3(1024), 0, s, a, a_mask, b, b_mask, n_pix, (int)channels, (float*)ws);
+	const bool vec = (n_pix & 3) == 0 && (channels == 3 || channels == 1) && al16(a) && al16(b) && al16(a_mask) && al16(b_mask);
+	if (vec && channels == 3) hipLaunchKernelGGL((image_mse_fwd_kernel<3, true>), dim3((unsigned)nblk), dim3(1024), 0, s, a, a_mask, b, b_mask, n_pix, 3, (float*)ws);
+	else if (vec) hipLaunchKernelGGL((image_mse_fwd_kernel<1, true>), dim3((unsigned)nblk), dim3(1024), 0, s, a, a_mask, b, b_mask, n_pix, 1, (float*)ws);
+	else hipLaunchKernelGGL((image_mse_fwd_kernel<1, false>), dim3((unsigned)nblk), dim3(1024), 0, s, a, a_mask, b, b_mask, n_pix, (int)channels, (float*)ws);
 	hipLaunchKernelGGL(image_mse_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, nblk, 1.0f / ((float)n_pix * (float)channels), loss);
 	FIND_LAUNCH_CHECK("image_mse_fwd_kernel");
 	return FIND_OK;
@@ -901,8 +957,15 @@ extern "C" int find_image_mse_bwd(const float* a, const float* a_mask, const flo
 	FIND_REQUIRE(a && b && g_loss && (d_a || d_a_mask), "find_image_mse_bwd: NULL argument");
 	FIND_REQUIRE(n_pix >= 1 && n_pix < (1ll << 40) && channels >= 1 && channels <= 16, "find_image_mse_bwd: bad sizes");
 	FIND_REQUIRE(!d_a_mask || a_mask, "find_image_mse_bwd: d_a_mask without a_mask");
-	hipLaunchKernelGGL(image_mse_bwd_kernel, dim3((unsigned)cdiv(n_pix, 256)), dim3(256), 0, (hipStream_t)stream, a, a_mask, b, b_mask, n_pix, (int)channels,
-					   g_loss, d_a, d_a_mask);
+	hipStream_t s = (hipStream_t)stream;
+	const bool vec = (n_pix & 3) == 0 && (channels == 3 || channels == 1) && al16(a) && al16(b) && al16(a_mask) && al16(b_mask) && al16(d_a) && al16(d_a_mask);
+	if (vec && channels == 3)
+		hipLaunchKernelGGL((image_mse_bwd_kernel<3, true>), dim3((unsigned)cdiv(n_pix >> 2, 256)), dim3(256), 0, s, a, a_mask, b, b_mask, n_pix, 3, g_loss, d_a, d_a_mask);
+	else if (vec)
+		hipLaunchKernelGGL((image_mse_bwd_kernel<1, true>), dim3((unsigned)cdiv(n_pix >> 2, 256)), dim3(256), 0, s, a, a_mask, b, b_mask, n_pix, 1, g_loss, d_a, d_a_mask);
+	else
+		hipLaunchKernelGGL((image_mse_bwd_kernel<1, false>), dim3((unsigned)cdiv(n_pix, 256)), dim3(256), 0, s, a, a_mask, b, b_mask, n_pix, (int)channels, g_loss, d_a,
+						   d_a_mask);
 	FIND_LAUNCH_CHECK("image_mse_bwd_kernel");
 	return FIND_OK;
 }
