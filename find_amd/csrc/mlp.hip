@@ -1320,17 +1320,21 @@ __global__ void nop_kernel() {}
 }  // namespace mlp
 }  // namespace find
 
-// does a launch on b run while a is busy?
+// does a launch on b run while a is busy?  "Yes" cannot be wrong (on one queue b's launch cannot finish before a's spin); "no" can, when
+// the host thread is held up between b's completion and the query for longer than the spin: a "no" is asked again, twice.
 static int runs_beside(hipStream_t a, hipStream_t b, hipEvent_t ea, hipEvent_t eb, bool* beside) {
-	FIND_HIP_OK(hipStreamSynchronize(a), "hipStreamSynchronize");
-	FIND_HIP_OK(hipStreamSynchronize(b), "hipStreamSynchronize");
-	hipLaunchKernelGGL(find::mlp::spin_kernel, dim3(1), dim3(64), 0, a, 30000ll);   // ~0.3 ms
-	FIND_HIP_OK(hipEventRecord(ea, a), "hipEventRecord");
-	hipLaunchKernelGGL(find::mlp::nop_kernel, dim3(1), dim3(64), 0, b);
-	FIND_HIP_OK(hipEventRecord(eb, b), "hipEventRecord");
-	FIND_HIP_OK(hipEventSynchronize(eb), "hipEventSynchronize");
-	*beside = hipEventQuery(ea) == hipErrorNotReady;
-	FIND_HIP_OK(hipStreamSynchronize(a), "hipStreamSynchronize");
+	*beside = false;
+	for (int attempt = 0; attempt < 3 && !*beside; ++attempt) {
+		FIND_HIP_OK(hipStreamSynchronize(a), "hipStreamSynchronize");
+		FIND_HIP_OK(hipStreamSynchronize(b), "hipStreamSynchronize");
+		hipLaunchKernelGGL(find::mlp::spin_kernel, dim3(1), dim3(64), 0, a, 30000ll << attempt);   // ~0.3 ms, then 0.6, 1.2
+		FIND_HIP_OK(hipEventRecord(ea, a), "hipEventRecord");
+		hipLaunchKernelGGL(find::mlp::nop_kernel, dim3(1), dim3(64), 0, b);
+		FIND_HIP_OK(hipEventRecord(eb, b), "hipEventRecord");
+		FIND_HIP_OK(hipEventSynchronize(eb), "hipEventSynchronize");
+		*beside = hipEventQuery(ea) == hipErrorNotReady;
+		FIND_HIP_OK(hipStreamSynchronize(a), "hipStreamSynchronize");
+	}
 	return FIND_OK;
 }
 
