@@ -718,11 +718,12 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	if (d.shared) {
 		o->zsD = c.take<float>(d.V * W);
 		o->zsC = c.take<float>(d.V * W);
-		o->pS = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
-		o->pS2 = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
 	} else {
-		o->zsD = o->zsC = o->pS = o->pS2 = nullptr;
+		o->zsD = o->zsC = nullptr;
 	}
+	// (also without a shared template: the latents-only backward of a frozen network takes its per-foot column sums this way)
+	o->pS = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
+	o->pS2 = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
 	o->grp_pw = nullptr; o->grp_slabs = 0; o->grp_jobs = 0;
 	if (cdiv(d.V, 32) * d.feet_t <= GROUP_MAX_UNITS) {
 		// (a shared trunk groups its own layers only: the heads' layers there have n_feet times the rows and keep their own launches)
@@ -924,6 +925,9 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 	const int K0 = p->in_dim + 2 * p->pe_size;
 	const bool act_d = d_disp != nullptr, act_c = d_col != nullptr;
+	// no weight-gradient buffer at all: the network is frozen (requires_grad False on every weight -- stage 3 of train.py refines the
+	// latent codes only, train.py:217-224) and the call returns the latent gradients alone
+	const bool frozen = g->trunk_w[0] == nullptr;
 	// side streams of the fork: Q carries the large head layers' weight gradients, T1 / T2 the first head layers (foot-summed, with
 	// their column-sum reduce and latent gradients) and the trunk layers, R the slab reduces of the large head layers
 	enum { Q = 0, T1 = 1, T2 = 2, R = 3 };
@@ -964,18 +968,20 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	zero_flush();
 	if (mrc != FIND_OK) return mrc;
 
-	// 1. transposed weights for the dX GEMMs
+	// 1. transposed weights for the dX GEMMs (a frozen network's backward stops at the heads' first layers: only their later layers)
 	{
 		RepackArgs ra;
 		memset(&ra, 0, sizeof(ra));
 		int n = 0;
-		for (int i = 1; i < p->n_trunk; ++i) ra.job[n++] = RepackJob{p->trunk_w[i], b.Tt[i], W, W, W, 0, W, 1, 0, 0};
-		ra.job[n++] = RepackJob{p->disp_w[0], b.Dt[0], W, W, ld_d0, 0, W, 1, 0, 0};
+		if (!frozen) {
+			for (int i = 1; i < p->n_trunk; ++i) ra.job[n++] = RepackJob{p->trunk_w[i], b.Tt[i], W, W, W, 0, W, 1, 0, 0};
+			ra.job[n++] = RepackJob{p->disp_w[0], b.Dt[0], W, W, ld_d0, 0, W, 1, 0, 0};
+			ra.job[n++] = RepackJob{p->col_w[0], b.Ct[0], W, W, ld_c0, 0, W, 1, 0, 0};
+		}
 		for (int i = 1; i < p->n_disp; ++i) ra.job[n++] = RepackJob{p->disp_w[i], b.Dt[i], W, W, W, 0, W, 1, 0, 0};
-		ra.job[n++] = RepackJob{p->col_w[0], b.Ct[0], W, W, ld_c0, 0, W, 1, 0, 0};
 		for (int i = 1; i < p->n_col; ++i) ra.job[n++] = RepackJob{p->col_w[i], b.Ct[i], W, W, W, 0, W, 1, 0, 0};
 		ra.njobs = n;
-		hipLaunchKernelGGL(repack_kernel, dim3(64, n), dim3(256), 0, s, ra);
+		if (n > 0) hipLaunchKernelGGL(repack_kernel, dim3(64, n), dim3(256), 0, s, ra);
 		FIND_LAUNCH_CHECK("repack_kernel(T)");
 	}
 
@@ -999,7 +1005,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		hr.dw[0] = act_d ? g->disp_w[p->n_disp] : nullptr; hr.db[0] = g->disp_b[p->n_disp];
 		hr.dw[1] = act_c ? g->col_w[p->n_col] : nullptr; hr.db[1] = g->col_b[p->n_col];
 		hr.nblk = b.nblk_out;
-		hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(1024), 0, s, hr);
+		if (!frozen) hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(1024), 0, s, hr);
 		FIND_LAUNCH_CHECK("head_out_bwd");
 	}
 
@@ -1007,6 +1013,43 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 
 	const bool fused = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	if (frozen) {
+		// ---- latents only.  d loss / d latent[foot] = (sum_v dZ0[foot, v]) . W0[:, 256:]: the heads' dX chains down to their first layers,
+		// per-foot column sums, one small product per head.  Nothing reaches the trunk, no weight gradient is formed: at the reference's
+		// batch size this backward is 4 of the 9 layer-steps of the full chain and none of its thirteen weight-gradient jobs.
+		const bool want_d = act_d && p->lat_disp > 0 && g->lat_disp != nullptr, want_c = act_c && p->lat_col > 0 && g->lat_col != nullptr;
+		if (!want_d && !want_c) return FIND_OK;
+		if (fused && !d.shared) {
+			Chain ch;
+			int nsteps = 0;
+			auto head_chain = [&](int nl, float* const* act, float* const* dzbuf, float* const* wt, int& cur) {
+				for (int l = nl - 1; l >= 1; --l) {
+					FusedStep& st = ch.gemm(wt[l], W, W / KC, cur == 0 ? dzbuf[0] : nullptr);
+					st.mask = 1; st.aux = act[l - 1]; st.dst = dzbuf[cur + 1]; st.to_lds = 1;
+					cur += 1; nsteps += 1;
+				}
+			};
+			if (want_c) head_chain(p->n_col, w.C, b.dzC, b.Ct, cc);
+			if (want_d) head_chain(p->n_disp, w.D, b.dzD, b.Dt, cd);
+			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		} else {
+			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzD[cd], b.Dt[l], w.D[l - 1], b.dzD[cd + 1], V, n_feet, s)); cd += 1; }
+			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzC[cc], b.Ct[l], w.C[l - 1], b.dzC[cc + 1], V, n_feet, s)); cc += 1; }
+		}
+		struct Job { const float* dz; float* ps; float* S; const float* w0; int ld0; const float* lat; int L; float* glat; };
+		const Job jobs[2] = {{b.dzD[cd], b.pS, b.Sd, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, g->lat_disp},
+							 {b.dzC[cc], b.pS2, b.Sc, p->col_w[0], ld_c0, lat_col, p->lat_col, g->lat_col}};
+		for (int h = 0; h < 2; ++h) {
+			if (!(h == 0 ? want_d : want_c)) continue;
+			const Job& j = jobs[h];
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, j.dz, (int)n_feet, (int)V, (float*)nullptr, j.ps);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, s, j.ps, b.nblk_fs, (int)n_feet, j.S);
+			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)n_feet), dim3(256), 0, s, j.w0, j.ld0, j.lat, j.L, j.S, (int)n_feet, j.glat,
+							   (float*)nullptr, (float*)nullptr);
+			FIND_LAUNCH_CHECK("latent gradients of a frozen network");
+		}
+		return FIND_OK;
+	}
 	if (fused && !d.shared) {
 		// ---- small call (every layer has few rows: the reference's batch 1, the texture samples): the whole dX chain of both heads and
 		// the trunk is ONE fused launch (mlp_fused.h); every layer's dZ lands in its own buffer, and the weight gradients follow on the
@@ -1285,6 +1328,16 @@ extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* 
 	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
 	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
 	FIND_REQUIRE(p->precision >= 0 && p->precision <= 2, "find_mlp_bwd: params.precision must be 0, 1 or 2 (got %d)", p->precision);
+	{
+		// weight-gradient buffers: all of them (a head without an upstream gradient may leave its own out: nothing is written for it), or
+		// none at all (frozen network: latent gradients only)
+		const bool frozen = g->trunk_w[0] == nullptr;
+		bool ok = true;
+		for (int i = 0; i < p->n_trunk; ++i) ok = ok && ((g->trunk_w[i] == nullptr) == frozen) && ((g->trunk_b[i] == nullptr) == frozen);
+		for (int i = 0; i <= p->n_disp; ++i) ok = ok && (frozen ? !g->disp_w[i] && !g->disp_b[i] : (d_disp == nullptr || (g->disp_w[i] && g->disp_b[i])));
+		for (int i = 0; i <= p->n_col; ++i) ok = ok && (frozen ? !g->col_w[i] && !g->col_b[i] : (d_col == nullptr || (g->col_w[i] && g->col_b[i])));
+		FIND_REQUIRE(ok, "find_mlp_bwd: grads must name every weight-gradient buffer of the evaluated heads and the trunk, or none at all (frozen network)");
+	}
 	FwdWs w;
 	carve_fwd(p, d, true, const_cast<void*>(ws), &w);
 	if (ws_bytes < w.bytes) {

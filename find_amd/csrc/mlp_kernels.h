@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 		}
 		__syncthreads();
 	}
-	if (live) *reinterpret_cast<float4*>(zsum + (int64_t)v * 256 + c0) = zs;
+	if (live && zsum != nullptr) *reinterpret_cast<float4*>(zsum + (int64_t)v * 256 + c0) = zs;   // (no zsum: only the per-foot column sums are wanted)
 }
 
 // S[b][n] = sum_blk pS[blk][b][n]: grid (feet, 4 column quarters); 1024 threads = 64 columns x 16 slices of the block range

@@ -48,6 +48,7 @@ struct Ws {
 	float* raw_normals; // (n_meshes, V, 3) un-normalised vertex-normal sums (backward)
 	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tile counter
 	float* zthr;      // (n_img, H, W) depth of the K-th nearest silhouette candidate (+inf: every candidate counts)  [backward]
+	float* alpha;     // (n_img, H, W) prod (1 - p_k) over the blended candidates  [backward: 1 - mask has lost it wherever the mask rounds to 1]
 	float2* scratch;  // (raster workgroups, 2, 256, KN_CAP) per-pixel candidate lists of the tile in flight: depths, then 1 - p; one contiguous run per pixel
 	int32_t* tile_any; // (n_img, tiles) 1 = some face's blurred bbox touches the tile
 	int32_t* tile_cnt; // (n_img, tiles) estimate of how many do (sampled)
@@ -72,6 +73,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->d_normals = c.take<float>(n_meshes * V * 3);
 	o->raw_normals = c.take<float>(n_meshes * V * 3);
 	o->zthr = c.take<float>(px);
+	o->alpha = c.take<float>(px);
 	const int64_t tiles = n_img * cdiv(rp->image_w, TS_WAVE) * cdiv(rp->image_h, TS_WAVE);   // (the finer of the two tilings)
 	o->raster_wgs = std::min<int64_t>(tiles, RASTER_WGS);
 	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
@@ -359,6 +361,7 @@ struct TileArgs {
 	float* bary_ws;
 	int32_t* flags;
 	float* zthr;
+	float* alpha_ws;
 	float2* scratch;
 	const int32_t* tile_any;
 	const int32_t* tile_order;
@@ -701,11 +704,16 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					// lo = bits of the K-th smallest depth, c_lo = candidates strictly in front of it
 					int ties = K - c_lo;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
 					float asel = 1.0f;
+					unsigned nxt = 0x7F800000u;   // bits of the nearest depth BEHIND the K-th
+					bool excess = false;          // more candidates at the K-th depth than are kept
 					{
 						auto take = [&](float z, float q) {
 							const unsigned zb = __float_as_uint(z + 0.0f);
 							if (zb < lo) asel *= q;
-							else if (zb == lo && ties > 0) { asel *= q; --ties; }
+							else if (zb == lo) {
+								if (ties > 0) { asel *= q; --ties; }
+								else excess = true;
+							} else nxt = min(nxt, zb);
 						};
 						int i = 0;
 						for (; i + KU / 4 <= n4; i += KU / 4) {
@@ -723,7 +731,14 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						}
 					}
 					alpha = asel;
-					thr = __uint_as_float(lo);
+					// What the backward compares a candidate's depth with.  It recomputes that depth in another kernel, and the compiler is free
+					// to contract the same expression differently there: with the K-th depth itself as the bound, the K-th candidate fell on
+					// the wrong side of its own depth in about half of the overflow pixels (2.5e-3 of the gradient's scale on a dense mesh at
+					// 64^2).  The bound is the MIDPOINT between the K-th depth and the next one behind it -- any rounding difference smaller
+					// than half that gap selects the same K candidates -- and the K-th depth itself only where candidates tied AT it were
+					// left out (the backward then takes every tied one: the one case it cannot tell apart without face ids in the lists).
+					const float zk = __uint_as_float(lo);
+					thr = excess ? zk : 0.5f * (zk + __uint_as_float(nxt));
 				}
 				if ((a.ablate & 64) && lane == 0) atomicAdd(&a.flags[22], (int)((wall_clock64() - kt0) >> 4));  // K-pass time of the wave, 16-tick units (100 MHz)
 			}
@@ -751,6 +766,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 			if (want_sil) {
 				a.mask[pix] = 1.0f - alpha;
 				a.zthr[pix] = thr;
+				a.alpha_ws[pix] = alpha;
 			}
 			if (want_rgb) {
 				if (a.p2f_ws) {
@@ -810,7 +826,9 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ 4. silhouette backward
-// mask = 1 - prod_k (1 - p_k),  p_k = sigmoid(-d_k / sigma)   =>   d mask / d d_k = -alpha * p_k / sigma.
+// mask = 1 - prod_k (1 - p_k),  p_k = sigmoid(-d_k / sigma)   =>   d mask / d d_k = -alpha * p_k / sigma, alpha = the product as the forward
+// formed it (saved; 1 - mask is zero wherever the mask has rounded to 1, while the true product -- 1e-8, 1e-9 -- times p_k / sigma = 1e4 is
+// a gradient autograd through the K fragments does deliver: 2.5e-3 of the gradient's scale on a dense mesh at 64^2).
 // LPF lanes per (image, face) (8 for small blurred bboxes, 32 for large ones): they stride over the pixels of the face's blurred bbox (coalesced rows of d_mask / mask / zthr, no
 // divergence between faces with different bbox sizes), accumulate the gradients of its three NDC vertices in registers
 // (PointTriangleDistanceBackward: nearest edge only, projection parameter treated as constant), butterfly-reduce them, and
@@ -818,7 +836,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 template <int LPF>
 __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
 													   const int32_t* __restrict__ faces, int64_t faces_mesh_stride, int n_views, int V, int F,
-													   const float* __restrict__ mask, const float* __restrict__ d_mask, const float* __restrict__ zthr,
+													   const float* __restrict__ alpha_ws, const float* __restrict__ d_mask, const float* __restrict__ zthr,
 													   float* __restrict__ d_vproj) {
 	const int img = blockIdx.y;
 	const int sub = threadIdx.x & (LPF - 1);
@@ -848,14 +866,14 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 	float g = 0.f, zt = 0.f, mk = 0.f;
 	if (sub < npx) {
 		const int64_t pix = pixel_of(sub, &yi, &xi);
-		g = d_mask[pix]; zt = zthr[pix]; mk = mask[pix];
+		g = d_mask[pix]; zt = zthr[pix]; mk = alpha_ws[pix];
 	}
 	for (int pi = sub; pi < npx; pi += LPF) {
 		const int cy = yi, cx = xi;
 		const float cg = g, czt = zt, cmk = mk;
 		if (pi + LPF < npx) {
 			const int64_t pix = pixel_of(pi + LPF, &yi, &xi);
-			g = d_mask[pix]; zt = zthr[pix]; mk = mask[pix];
+			g = d_mask[pix]; zt = zthr[pix]; mk = alpha_ws[pix];
 		}
 		const float py = 1.0f - (2.0f * cy + 1.0f) / (float)H;
 		{
@@ -867,7 +885,7 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			if (fr.pz_clip > czt) continue;  // pixel with more than K candidates: this one is not among the K nearest
 			const float sd = fr.inside ? -fr.dist : fr.dist;
 			const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
-			const float alpha = 1.0f - cmk;
+			const float alpha = cmk;
 			// gradient w.r.t. the UNSIGNED distance: sign * dmask/dd
 			const float gd = (fr.inside ? -1.0f : 1.0f) * (-cg * alpha * prob * inv_sigma);
 			// nearest edge (a,b), q = a + t (b - a):  d = |q - p|^2,  dd/da = 2 (1-t) (q - p),  dd/db = 2 t (q - p)
@@ -1219,7 +1237,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = tiles_x;
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
-	a.zthr = w.zthr; a.scratch = w.scratch; a.tile_any = w.tile_any; a.tile_order = w.tile_order;
+	a.zthr = w.zthr; a.alpha_ws = w.alpha; a.scratch = w.scratch; a.tile_any = w.tile_any; a.tile_order = w.tile_order;
 	a.tiles_per_img = tiles_per_img; a.total_tiles = (int)(a.tiles_per_img * n_img);
 	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, w.tile_any, w.tile_cnt, a.total_tiles, w.tile_order);
 	a.ablate = find::g_raster_ablate;
@@ -1257,13 +1275,13 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 		// (8 lanes per face up to ~12 x 12 pixels, 16 up to ~25 x 25 -- 512^2: 17.5 x 17.5, measured 1 % of the C4 step better than 32 --, 32 above)
 		if (side * side > 640.0f)
 			hipLaunchKernelGGL(sil_bwd_kernel<32>, dim3((unsigned)cdiv(F, 8), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-							   mask, d_mask, w.zthr, w.d_vproj);
+							   w.alpha, d_mask, w.zthr, w.d_vproj);
 		else if (side * side > 160.0f)
 			hipLaunchKernelGGL(sil_bwd_kernel<16>, dim3((unsigned)cdiv(F, 16), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-							   mask, d_mask, w.zthr, w.d_vproj);
+							   w.alpha, d_mask, w.zthr, w.d_vproj);
 		else
 			hipLaunchKernelGGL(sil_bwd_kernel<8>, dim3((unsigned)cdiv(F, 32), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-						   mask, d_mask, w.zthr, w.d_vproj);
+						   w.alpha, d_mask, w.zthr, w.d_vproj);
 	}
 	if (d_image) {
 		(void)hipMemsetAsync(w.d_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);

@@ -132,6 +132,7 @@ class _MLP(torch.autograd.Function):
 							   'GT points carry no grad, model.py:285, losses.py:39-51)')
 		L = _lib.lib()
 		pos, lat_disp, lat_col, B, avg_col = _c(pos), _c(lat_disp), _c(lat_col), _c(B), _c(avg_col)
+		leaves = all(w.is_leaf for w in weights)   # (the fold in backward() parks gradients at AccumulateGrad nodes: leaves only)
 		weights = tuple(w.contiguous() for w in weights)
 		if pos.dim() != 3 or pos.shape[-1] != spec.in_dim:
 			raise RuntimeError(f'find_amd.mlp: pos must be (B|1, V, {spec.in_dim}), got {tuple(pos.shape)}')
@@ -167,6 +168,10 @@ class _MLP(torch.autograd.Function):
 			ctx.precision = p.precision
 			ctx.dims = (pos_batch, n_feet, V)
 			ctx.ws = ws
+			ctx.leaves = leaves
+			# an output nothing reads hands None to backward, not a tensor of zeros: the main pass of a train_3d.yaml step never reads its
+			# colours (no pixel loss), and a materialised zero gradient sent the whole colour head through its backward on zeros
+			ctx.set_materialize_grads(False)
 			ctx.save_for_backward(pos, lat_disp, lat_col, B, avg_col, *weights)
 		return disp, col
 
@@ -179,44 +184,69 @@ class _MLP(torch.autograd.Function):
 		g_disp, g_col = _c(g_disp), _c(g_col)
 		p = _fill_params(spec, B, avg_col, weights)
 		p.precision = ctx.precision   # the arithmetic the forward ran in, whatever the default is by now
-		grads = _grads_like(weights)
+		nt, nd = 2 * spec.n_trunk, 2 * (spec.n_disp + 1)
+		# Which gradients exist.  A head nothing read (no upstream gradient) contributes nothing: its weights and latents get None, as
+		# in the reference, where such a head never enters the graph (the texture pass reads 'col' only, losses.py:45-51; the main pass of
+		# train_3d.yaml never reads its colours) -- an exact-zero tensor instead would still advance Adam's moments and apply weight decay.
+		# No weight asks for a gradient at all: frozen network, latent gradients only (find_hip.h: find_mlp_grads).
+		frozen = not any(ctx.needs_input_grad[6:])
+		live = [False] * len(weights)
+		if not frozen and (g_disp is not None or g_col is not None):
+			live[:nt] = [True] * nt
+			if g_disp is not None:
+				live[nt:nt + nd] = [True] * nd
+			if g_col is not None:
+				live[nt + nd:] = [True] * (len(weights) - nt - nd)
+		idx = [i for i, on in enumerate(live) if on]
+		grads = [None] * len(weights)
+		for i, g in zip(idx, _grads_like([weights[i] for i in idx]) if idx else []):
+			grads[i] = g
 		# A second backward through the same weights inside one backward() call (FIND's texture pass and its main pass) would have
 		# autograd add 26 pairs of gradient tensors one launch each (InputBuffer accumulation).  The first call's gradients are still
 		# parked at the parameters' AccumulateGrad nodes at that point -- those nodes run only after every MLP node that feeds them --, so
-		# this call adds its own to them with one multi-tensor launch and reports "no contribution" for the weights instead.
+		# this call adds its own to them with one multi-tensor launch and reports "no contribution" for those weights instead.  That
+		# rests on the parameters being leaves whose gradients nothing else touches before the engine accumulates them: leaves only, no
+		# double backward (create_graph), same graph task, same stream.
 		task = _graph_task_id()
 		key = tuple(w.data_ptr() for w in weights)
 		pending = _PENDING_WGRADS.get(key)
+		can_park = ctx.leaves and not torch.is_grad_enabled() and task >= 0 and all(ctx.needs_input_grad[6:])
 		# (same stream only: the sum must be ordered with whatever reads the parked gradients next)
-		fold = (pending is not None and task >= 0 and pending[0] == task and all(ctx.needs_input_grad[6:])
-				and pending[2] == torch.cuda.current_stream(pos.device))
-		g_lat_disp = torch.empty_like(lat_disp) if lat_disp is not None else None
-		g_lat_col = torch.empty_like(lat_col) if lat_col is not None else None
+		fold = (pending is not None and can_park and pending[0] == task and pending[2] == torch.cuda.current_stream(pos.device))
+		g_lat_disp = torch.empty_like(lat_disp) if (lat_disp is not None and g_disp is not None and ctx.needs_input_grad[2]) else None
+		g_lat_col = torch.empty_like(lat_col) if (lat_col is not None and g_col is not None and ctx.needs_input_grad[3]) else None
+		if not idx and g_lat_disp is None and g_lat_col is None:
+			return (None,) * (6 + len(weights))
 		G = MlpGrads()
 		it = iter(grads)
 		for i in range(spec.n_trunk):
-			G.trunk_w[i] = next(it).data_ptr()
-			G.trunk_b[i] = next(it).data_ptr()
+			G.trunk_w[i] = ptr(next(it))
+			G.trunk_b[i] = ptr(next(it))
 		for i in range(spec.n_disp + 1):
-			G.disp_w[i] = next(it).data_ptr()
-			G.disp_b[i] = next(it).data_ptr()
+			G.disp_w[i] = ptr(next(it))
+			G.disp_b[i] = ptr(next(it))
 		for i in range(spec.n_col + 1):
-			G.col_w[i] = next(it).data_ptr()
-			G.col_b[i] = next(it).data_ptr()
-		G.lat_disp = None if g_lat_disp is None else g_lat_disp.data_ptr()
-		G.lat_col = None if g_lat_col is None else g_lat_col.data_ptr()
+			G.col_w[i] = ptr(next(it))
+			G.col_b[i] = ptr(next(it))
+		G.lat_disp = ptr(g_lat_disp)
+		G.lat_col = ptr(g_lat_col)
 		sb = L.find_mlp_bwd_scratch_bytes(ctypes.byref(p), pos_batch, n_feet, V)
 		scratch = _ws(sb, pos.device)
 		check(L.find_mlp_bwd(_lib.ctx(pos.device), ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
 							 ptr(ctx.ws), ctx.ws.numel(), ptr(scratch), scratch.numel(), ctypes.byref(G),
 							 current_stream(pos.device)), 'find_mlp_bwd')
 		if fold:
-			torch._foreach_add_([base[o:o + g.numel()].view(g.shape) for (base, o), g in zip(pending[1], grads)], grads)
-			return (None, None, g_lat_disp, g_lat_col, None, None, *([None] * len(grads)))
+			# add into the parked gradients where the first call parked one; a weight it had nothing for gets this call's gradient as its own
+			slots = pending[1]
+			both = [i for i in idx if slots[i] is not None]
+			if both:
+				torch._foreach_add_([slots[i][0][slots[i][1]:slots[i][1] + grads[i].numel()].view(grads[i].shape) for i in both], [grads[i] for i in both])
+			out = [None if slots[i] is not None else grads[i] for i in range(len(weights))]
+			return (None, None, g_lat_disp, g_lat_col, None, None, *out)
 		_PENDING_WGRADS.clear()
-		if task >= 0 and all(ctx.needs_input_grad[6:]) and all(g._base is not None and g._base.dim() == 1 for g in grads):
+		if can_park and idx and all(grads[i]._base is not None and grads[i]._base.dim() == 1 for i in idx):
 			# (where the gradients live, not the tensors themselves: autograd adopts a gradient as .grad only while nothing else holds it)
-			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) for g in grads], torch.cuda.current_stream(pos.device))
+			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) if g is not None else None for g in grads], torch.cuda.current_stream(pos.device))
 		return (None, None, g_lat_disp, g_lat_col, None, None, *grads)
 
 
@@ -233,7 +263,7 @@ def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights, want=('disp', 'col'))
 	"""Fused Fourier-PE + trunk + heads.  pos (1|N, V, 3); lat_disp (N, Ld)|None; lat_col (N, Lc)|None;
 	weights: flat list [trunk w,b ..., disp w,b ..., col w,b ...] in reference state_dict order.
 	Returns disp (N,V,3), col (N,V,3)   (reference: NeuralDisplacementField.forward, model.py:393-453); a head that `want` does not
-	name is not evaluated and comes back as None (its parameters then get exact zero gradients from this call)."""
+	name is not evaluated and comes back as None (its parameters then get no gradient from this call, as a head nothing reads)."""
 	heads = (1 if 'disp' in want else 0) | (2 if 'col' in want else 0)
 	if heads == 0:
 		raise ValueError("find_amd.mlp: want must name 'disp', 'col' or both")

@@ -12,7 +12,9 @@ the reference; only the resulting row indices travel to the device.
 
 Constraints (checked or documented): every batch of one shape signature shares a graph; optimisers must be capture-safe
 (find_amd.optim.Adam(capturable=True), find_amd.optim.SGD); flags that make ModelWithLoss.forward read device values on the host
-(opts.restrict_3d_n_train) cannot be captured.  The warm-up iterations that precede a capture are real training steps."""
+(opts.restrict_3d_n_train) cannot be captured.  The warm-up iterations that precede a capture are DRY: parameters and optimiser
+state are put back before the capture, so N calls are N training steps, the first batch of a shape included (only the random
+generators -- the sampler's device generator, numpy's for the camera poses -- have advanced)."""
 import torch
 
 from . import functional as FN
@@ -39,11 +41,16 @@ class _Captured:
 
 
 class GraphedStep:
-	def __init__(self, model_with_loss, opts, optimizers, latent_vectors=None, warmup=2, pre_step=None, **flags):
+	def __init__(self, model_with_loss, opts, optimizers, latent_vectors=None, warmup=2, pre_step=None, stream=None, **flags):
 		"""model_with_loss: find_amd.model_with_loss.ModelWithLoss; optimizers: list stepped after backward; latent_vectors: the
 		LatentVector list to sample per batch (default: model.latent_vectors_train, or _val when flags has is_train=False);
 		pre_step: optional callable run between backward and the optimiser steps (e.g. a gradient all-reduce); flags: the loss
-		switches handed to ModelWithLoss.forward."""
+		switches handed to ModelWithLoss.forward.
+		stream: the (non-default) stream warm-up and capture run on.  autograd ties every parameter's AccumulateGrad node to the stream it
+		was created on and keeps the node while ANY graph that reaches the parameter is alive; a backward captured on another stream
+		then records a dependency on that foreign stream, which hipStreamEndCapture (ROCm 7.x) answers with a segmentation fault.  A
+		caller that also runs eager steps on these parameters passes the stream it runs them on (find_amd.trainer.Trainer does);
+		without one, a capture refuses to start while such a graph is alive (a loss, or sampled latent rows, kept from an eager step)."""
 		from . import optim
 		self.mwl, self.opts, self.flags = model_with_loss, opts, dict(flags)
 		self.optimizers = list(optimizers)
@@ -54,6 +61,15 @@ class GraphedStep:
 				raise RuntimeError(f'GraphedStep: {type(o).__name__} is not known to be capture-safe; use find_amd.optim.Adam(capturable=True) / SGD')
 		if getattr(opts, 'restrict_3d_n_train', None) is not None:
 			raise RuntimeError('GraphedStep: opts.restrict_3d_n_train makes the step read batch["idx"] on the host; not capturable')
+		if self.flags.get('save_renders'):
+			raise RuntimeError('GraphedStep: save_renders reads the images and batch["idx"] on the host; run that step eagerly '
+							   '(find_amd.trainer.Trainer does: the reference asks for it only on checkpoint epochs, train.py:58-66)')
+		# Camera poses.  ModelWithLoss draws them on the host (numpy's global generator, model.py:1060-1071) -- inside a capture that would
+		# freeze the first step's poses into every replay.  They are a static INPUT of the graph instead: drawn per call in _load(), as the
+		# eager step draws them, or the caller's own device tensors (refreshed from the same objects every call).
+		self._draw_views = bool(self.flags.get('render_foot')) and self.flags.get('views') is None
+		if self.flags.get('views') is not None and not all(torch.is_tensor(t) and t.is_cuda for t in self.flags['views']):
+			raise RuntimeError('GraphedStep: views=(R, T) must be device tensors (a host tensor would be copied from pageable memory inside the capture)')
 		m = model_with_loss.model
 		if latent_vectors is None:
 			latent_vectors = m.latent_vectors_train if self.flags.get('is_train', True) else m.latent_vectors_val
@@ -66,6 +82,7 @@ class GraphedStep:
 		self.pre_step = pre_step
 		self._graphs = {}
 		self._pool = None
+		self.stream, self._own_stream = stream, stream is None
 
 	# ------------------------------------------------------------------ batch -> static buffers
 	@staticmethod
@@ -100,8 +117,10 @@ class GraphedStep:
 		st = _Captured()
 		# static copies of everything the step reads from the batch
 		st.batch = {}
-		st.pairs = []  # (static tensor, key path) to refresh per call
 		for k, v in batch.items():
+			if torch.is_tensor(v) and not v.is_cuda:
+				raise RuntimeError(f'GraphedStep: batch[{k!r}] is a CPU tensor; move the batch to the device first (trainer.batch_to_device): '
+								   'a host tensor would be read from pageable memory inside the capture and never refreshed')
 			if torch.is_tensor(v) and v.is_cuda:
 				st.batch[k] = v.clone()
 			elif isinstance(v, Meshes):
@@ -112,6 +131,16 @@ class GraphedStep:
 		bsz = len(batch['idx']) if 'idx' in batch else len(next(iter(batch.values())))
 		st.idx_host = torch.zeros(max(n_lab, 1), bsz, dtype=torch.int64).pin_memory()
 		st.idx_dev = torch.zeros(max(n_lab, 1), bsz, dtype=torch.int64, device=dev)
+		flags = dict(self.flags)
+		st.views_host = st.views_dev = None
+		if self._draw_views:
+			R, T = self.mwl._views(self.opts)
+			st.views_host = torch.cat([R.reshape(-1, 9), T.reshape(-1, 3)], dim=1).float().pin_memory()   # (M, 12)
+			st.views_dev = st.views_host.to(dev)
+			flags['views'] = (st.views_dev[:, :9].reshape(-1, 3, 3), st.views_dev[:, 9:])
+			st.views_fresh = True   # the poses just drawn serve the first step
+		# hyper-parameters the optimiser kernels receive BY VALUE are frozen into the graph: remember them, refuse a replay after a change
+		st.hyper = self._hyper()
 
 		def body():
 			b = dict(st.batch)
@@ -130,7 +159,7 @@ class GraphedStep:
 				rows = [vec[s] for vec, s in zip(self.latent_vectors, sel)]
 			for vec, r in zip(self.latent_vectors, rows):
 				b[vec.name] = r
-			out = self.mwl(b, epoch, self.opts, **self.flags)
+			out = self.mwl(b, epoch, self.opts, **flags)
 			loss, losses = out[0], out[1]
 			loss.backward()
 			if self.pre_step is not None:
@@ -140,7 +169,12 @@ class GraphedStep:
 			return loss, losses
 
 		self._load(st, batch)
-		side = torch.cuda.Stream(device=dev)
+		snap = self._snapshot()
+		if self.stream is None:
+			self.stream = torch.cuda.Stream(device=dev)
+		if self._own_stream:
+			self._refuse_live_graphs()
+		side = self.stream
 		side.wait_stream(torch.cuda.current_stream(dev))
 		with torch.cuda.stream(side):
 			for _ in range(self.warmup):
@@ -148,19 +182,96 @@ class GraphedStep:
 					o.zero_grad(set_to_none=True)
 				body()
 		torch.cuda.current_stream(dev).wait_stream(side)
+		self._restore(snap)
 		torch.cuda.synchronize(dev)
 		for o in self.optimizers:
 			o.zero_grad(set_to_none=True)
 		if self._pool is None:
 			self._pool = torch.cuda.graph_pool_handle()
 		st.graph = torch.cuda.CUDAGraph()
-		with torch.cuda.graph(st.graph, pool=self._pool):
+		with torch.cuda.graph(st.graph, pool=self._pool, stream=self.stream):
 			st.loss, st.losses = body()
 		return st
 
+	def _refuse_live_graphs(self):
+		"""Raise if an autograd graph that reaches one of the optimised parameters is still alive (see __init__: stream).  A parameter's
+		AccumulateGrad node exists only while such a graph does: fetch it twice, tagging it the first time -- a node that is still
+		tagged on the second fetch outlived our own reference, so something else holds it."""
+		import gc
+		def alive():
+			out = []
+			for o in self.optimizers:
+				for g in o.param_groups:
+					for p in g['params']:
+						if not p.requires_grad:
+							continue
+						p.view_as(p).grad_fn.next_functions[0][0].metadata['find_probe'] = True
+						if p.view_as(p).grad_fn.next_functions[0][0].metadata.pop('find_probe', False):
+							out.append(tuple(p.shape))
+			return out
+		if alive():
+			gc.collect()
+			shapes = alive()
+			if shapes:
+				raise RuntimeError(f'GraphedStep: an autograd graph from an earlier step still references {len(shapes)} of the optimised parameters (shapes '
+								   f'{shapes[:4]} ...): something keeps a loss, an output or sampled latent rows of that step.  Drop those references, '
+								   'or run the eager steps and this capture on one stream (GraphedStep(stream=...)); capturing now would crash in hipStreamEndCapture.')
+
+	def _snapshot(self):
+		"""Values of every optimised parameter and of its optimiser state, to undo the warm-up steps."""
+		snap = []
+		for o in self.optimizers:
+			for g in o.param_groups:
+				for p in g['params']:
+					st = o.state.get(p, {})
+					snap.append((o, g, p, p.detach().clone(), {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}))
+		return snap
+
+	@torch.no_grad()
+	def _restore(self, snap):
+		"""In place (the capture that follows records these tensors' addresses).  State the warm-up created is reset to its initial value:
+		Adam's moments and step count to zero; SGD's momentum buffer to zero, which makes the next step torch's "first step" (buffer :=
+		gradient) exactly when dampening is 0 -- FIND's setting (train.py:162) -- and is refused otherwise."""
+		for o, g, p, value, state in snap:
+			p.copy_(value)
+			for k, v in o.state.get(p, {}).items():
+				if not torch.is_tensor(v):
+					continue
+				if k in state:
+					v.copy_(state[k])
+				else:
+					if k == 'momentum_buffer' and g.get('dampening', 0) != 0:
+						raise RuntimeError('GraphedStep: SGD with dampening != 0 cannot take a dry warm-up step (its first step differs from the later ones)')
+					v.zero_()
+		for o in self.optimizers:   # host mirrors of the step counts (find_amd.optim.Adam keeps one per bucket beside the device counter)
+			for c in getattr(o, '_cache', {}).values():
+				for bk in c.get('buckets', []):
+					if 'step_dev' in bk:
+						bk['step'] = int(bk['step_dev'].item())
+
+	def _hyper(self):
+		keys = ('lr', 'betas', 'eps', 'weight_decay', 'momentum', 'dampening', 'nesterov')
+		return [tuple((k, g[k]) for k in keys if k in g) for o in self.optimizers for g in o.param_groups]
+
 	def _load(self, st, batch):
+		if getattr(st, 'hyper', None) is not None and st.hyper != self._hyper():
+			raise RuntimeError('GraphedStep: an optimiser hyper-parameter (lr, betas, ...) changed after the capture; they are launch arguments '
+							   'frozen into the graph -- build a new GraphedStep (FIND trains with constant rates, train.py:161-168)')
+		if st.views_host is not None:
+			if st.views_fresh:
+				st.views_fresh = False
+			else:
+				R, T = self.mwl._views(self.opts)
+				if getattr(st, 'views_event', None) is not None:
+					st.views_event.synchronize()
+				st.views_host.copy_(torch.cat([R.reshape(-1, 9), T.reshape(-1, 3)], dim=1))
+				st.views_dev.copy_(st.views_host, non_blocking=True)
+				st.views_event = torch.cuda.Event()
+				st.views_event.record()
 		for k, v in batch.items():
 			s = st.batch[k]
+			if torch.is_tensor(v) and not v.is_cuda:
+				raise RuntimeError(f'GraphedStep: batch[{k!r}] is a CPU tensor; move the batch to the device first')
 			if torch.is_tensor(v) and v.is_cuda:
 				if s.data_ptr() != v.data_ptr():
 					s.copy_(v, non_blocking=True)

@@ -100,9 +100,6 @@ class MeshSmoothnessLoss(nn.Module):
 
 
 class SilhouetteLoss(nn.Module):
-	def __init__(self):
-		super().__init__()
-		self.crit = nn.MSELoss()
-
 	def forward(self, pred, gt):
-		return self.crit(pred, gt)
+		"""MSE of the soft silhouettes (reference losses.py:122-128: nn.MSELoss), one pass each way in find_image_mse_*."""
+		return FN.image_mse(pred, gt)

@@ -26,7 +26,6 @@ OUT_OF_SCOPE_FLAGS = {
 	'restyle_perc_feat': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
 	'restyle_perc_cluster': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
 	'cont_pose': 'perceptual / restyle / contrastive losses are out of scope (SURVEY.md §2 #4)',
-	'save_renders': 'save_renders writes PNGs through cv2 (visualisation); use return_renders and save them yourself',
 	'mask_out_pred_faces': 'mask_out_pred_faces belongs to the VertexFeatures model (out of scope)',
 }
 
@@ -112,7 +111,7 @@ class ModelWithLoss(nn.Module):
 		self.col_loss = TextureLossGTSpace()
 		self.mesh_smooth_loss = MeshSmoothnessLoss()
 		self.templ_smooth_loss = MeshSmoothnessLoss()
-		self.pix_loss = nn.MSELoss()
+		self.pix_loss = nn.MSELoss()      # (attributes of the reference; the forward computes both losses through find_image_mse_*)
 		self.sil_loss = SilhouetteLoss()
 		# (max_faces_per_bin only sizes PyTorch3D's coarse bins -- 30 000 for the full-resolution scans, model.py:987; no effect on results)
 		self.rdr = FootRenderer(image_size=256, device=device, bin_size=None, max_faces_per_bin=None if opts.low_poly_meshes else 30000)
@@ -129,21 +128,13 @@ class ModelWithLoss(nn.Module):
 		codes = {k: st.batch.get(f'{k}_{sfx}', None) for k in ('shapevec', 'texvec', 'posevec')}
 		return self.col_loss(self.model, st.batch, **codes)
 
-	@staticmethod
-	def _on_gpu(*ts):
-		return all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in ts)
-
 	def _raw_pix(self, st):
 		# images are compared inside the silhouettes only (model.py:1101-1105): MSE(image * mask, gt image * gt mask), one pass each way
-		pi, pm, gi, gm = st.pred['image'], st.pred['mask'], st.gt['image'], st.gt['mask']
-		if self._on_gpu(pi, pm, gi, gm):
-			return FN.image_mse(pi, gi, pm, gm)
-		return self.pix_loss(pi * pm.unsqueeze(-1), gi * gm.unsqueeze(-1))
+		# (find_image_mse_*; CPU tensors raise there: no fallback)
+		return FN.image_mse(st.pred['image'], st.gt['image'], st.pred['mask'], st.gt['mask'])
 
 	def _raw_sil(self, st):
-		if self._on_gpu(st.pred['mask'], st.gt['mask']):
-			return FN.image_mse(st.pred['mask'], st.gt['mask'])
-		return self.sil_loss(st.pred['mask'], st.gt['mask'])
+		return FN.image_mse(st.pred['mask'], st.gt['mask'])
 
 	# ------------------------------------------------------------------ pieces of a step
 	def _views(self, opts):
@@ -210,7 +201,7 @@ class ModelWithLoss(nn.Module):
 				save_renders=False, render_dir='_pix', is_train=True, use_z_cutoff=False, gt_z_cutoff=None, restyle_feature_maps=None,
 				no_displacement=False, return_renders=False, copy_mask_out=True, mask_out_pred_faces=False, views=None):
 		given = dict(vgg_perc=vgg_perc, restyle_perc_lat=restyle_perc_lat, restyle_perc_feat=restyle_perc_feat, restyle_perc_cluster=restyle_perc_cluster,
-					 cont_pose=cont_pose, save_renders=save_renders, mask_out_pred_faces=mask_out_pred_faces)
+					 cont_pose=cont_pose, mask_out_pred_faces=mask_out_pred_faces)
 		for name, why in OUT_OF_SCOPE_FLAGS.items():
 			if given[name]:
 				raise NotImplementedError(why)
@@ -221,30 +212,50 @@ class ModelWithLoss(nn.Module):
 		st.use_z_cutoff, st.gt_z_cutoff = use_z_cutoff, gt_z_cutoff
 		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement)
 		st.pred = st.gt = None
-		if render_foot:
-			# the images (shading, vertex normals) are rendered only when something reads them: the pixel loss or the caller (the reference
-			# renders them regardless, renderer.py:290-291; nothing downstream can tell)
-			images = bool(pix or return_renders)
+		# train_network asks for renders whenever a checkpoint is saved (train.py:58-66: save_renders at epoch 0, every *_save_every epochs
+		# and on the last one), with or without a render loss: `if render_foot or save_renders` (model.py:1057)
+		rendering = bool(render_foot or save_renders)
+		if rendering:
+			# the images (shading, vertex normals) are rendered only when something reads them: the pixel loss, the caller or the PNG (the
+			# reference renders them regardless, renderer.py:290-291; nothing downstream can tell)
+			images = bool(pix or return_renders or save_renders)
 			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None), images)
-			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images, mask_image=bool(return_renders))
+			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images, mask_image=bool(return_renders or save_renders))
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
 		raw, weights = {}, []
 		for term in TERMS:
-			if not enabled[term.flag] or (term.needs_3d and not supervise_3d) or (term.needs_render and not render_foot):
+			if not enabled[term.flag] or (term.needs_3d and not supervise_3d) or (term.needs_render and not rendering):
 				continue
 			raw[term.key] = getattr(self, term.fn)(st)
 			weights.append(float(getattr(opts, term.weight)))
-		# losses[k] = raw * opts.weight_k, loss = sum(losses.values())   (model.py:1157-1163): one launch for all terms on the GPU
-		if raw and all(torch.is_tensor(v) and v.is_cuda and v.dim() == 0 and v.dtype == torch.float32 for v in raw.values()) and len(raw) <= 8:
+		if save_renders:
+			self._save_renders(st, render_dir)
+		# losses[k] = raw * opts.weight_k, loss = sum(losses.values())   (model.py:1157-1163): one launch for all terms (find_weighted_terms_*)
+		if raw:
 			loss, scaled = FN.weighted_terms(list(raw.values()), weights)
 			losses = dict(zip(raw, scaled))
 		else:
-			losses = {k: v * w for (k, v), w in zip(raw.items(), weights)}
-			loss = sum(losses.values())
-		if return_renders and render_foot:
+			loss, losses = 0, {}   # sum({}.values()) of the reference: the trainer's `if loss == 0: continue` (trainer.py:108) relies on it
+		if return_renders and rendering:
 			return loss, losses, dict(pred=st.pred, gt=st.gt)
 		return loss, losses
+
+	@staticmethod
+	def _save_renders(st, render_dir):
+		"""The GT | prediction strip of a step, `{render_dir}/{epoch:04d}_{idx:02d}.png` (model.py:1149-1156): the images of all feet and
+		views stacked top to bottom, GT column left, prediction right, 8 bits per channel by truncation of 255 * value.  (The reference
+		writes through cv2 after an RGB -> BGR swap, i.e. an RGB file; PIL writes the same pixels.  Reads batch['idx'] on the host, as the
+		reference does: not for a captured step.)"""
+		import numpy as np
+		from PIL import Image
+		idx = st.batch['idx'][0].item()
+		gt, pred = st.gt['image'], st.pred['image']
+		H, W = gt.shape[-3], gt.shape[-2]
+		both = torch.cat([gt.detach().reshape(-1, W, 3), pred.detach().reshape(-1, W, 3)], dim=1)   # rows: (foot, view, y); columns: GT | prediction
+		strip = (both.cpu().numpy() * 255).astype(np.uint8)
+		os.makedirs(render_dir, exist_ok=True)
+		Image.fromarray(strip, mode='RGB').save(os.path.join(render_dir, f'{st.epoch:04d}_{idx:02d}.png'))
 
 	def save_model(self, *args, **kwargs):
 		self.model.save_model(*args, **kwargs)

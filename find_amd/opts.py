@@ -5,6 +5,9 @@ reference `Opts` instance can be passed instead (only attribute access is used).
 
 
 class Opts:
+	restyle_losses = ['restyle_perc_lat', 'restyle_perc_feat', 'restyle_perc_cluster']
+	render_losses = ['pix', 'sil', 'vgg_perc', 'restyle_perc_lat', 'restyle_perc_feat', 'restyle_perc_cluster']   # opts.py:12-13
+
 	DEFAULTS = dict(
 		model_type='neural', load_model='', device='cuda', low_poly_meshes=False, dont_load_latents=False,
 		template_features_pth=None,
@@ -20,6 +23,12 @@ class Opts:
 		restrict_3d_n_train=None, restrict_3d_train_key=None, train_3d_on_only=None,
 		restyle_features_per_vertex=False, restyle_cluster_per_vertex=False, restyle_no_masking=False,
 		use_pose_code=False, use_latent_labels=False, gt_z_cutoff=None, use_z_cutoff=False,
+		# what train.py's stages and train_network read around the step (opts.py:38-76,140-152): optimiser rates, schedule, switches
+		batch_size_train=1, batch_size_val=1, lr_net=5e-5, lr_reg=1e-5, lr_val=5e-5, lr_latent=1e-4,
+		reg=False, reg_epochs=2000, reg_save_every=250, no_net_train=False, net_epochs=1000, net_save_every=100, net_val_every=50,
+		val_crit='chamf', no_latent_refinement=False, latent_epochs=500, latent_optim='Adam', latent_save_every=250, latent_val_every=25,
+		no_rendering=False, restyle_feature_maps=None, only_classifier_head=False, step_per_epoch=False, net_repeat_dataset=1,
+		render_dir='_pix',
 	)
 
 	def __init__(self, **kw):
@@ -36,6 +45,8 @@ class Opts:
 		return self.restyle_perc_lat_loss or self.restyle_perc_feat_loss or self.restyle_perc_cluster_loss
 
 	def net_train_kwargs(self):
-		"""Loss flags handed to ModelWithLoss.forward for the network / latent stages (opts.py:207-215)."""
+		"""Loss flags handed to ModelWithLoss.forward for the network / latent stages: the reference's ten keys (opts.py:207-215).
+		render_foot / save_renders / copy_mask_out ... are added by the caller (train.py:58-70; find_amd.trainer.stage_model_kwargs)."""
 		return dict(chamf=self.chamf_loss, smooth=self.smooth_loss, texture=self.texture_loss, pix=self.pix_loss, sil=self.sil_loss,
-					render_foot=self.pix_loss or self.sil_loss, copy_mask_out=self.copy_over_masking)
+					vgg_perc=self.vgg_perc_loss, restyle_perc_lat=self.restyle_perc_lat_loss, restyle_perc_feat=self.restyle_perc_feat_loss,
+					restyle_perc_cluster=self.restyle_perc_cluster_loss, cont_pose=self.cont_pose_loss)

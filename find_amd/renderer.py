@@ -26,45 +26,47 @@ class FootRenderer(nn.Module):
 		self.params = FR.make_params(image_size, faces_per_pixel=100, background=self.background_color, light_pos=self.light_location,
 									 znear=0.02, z_clip=z_clip_value)
 
-	# ------------------------------------------------------------------ view helpers (numpy RNG, as the reference)
+	# ------------------------------------------------------------------ camera poses
+	# Every FIND camera looks along a ray through `at` with the world x axis as "up" (the foot's long axis; renderer.py:152,171,198).
+	# What the callers rely on: (i) sample_views draws distance, elevation, azimuth -- in that order, `nviews` values each -- from numpy's
+	# GLOBAL generator and reseeds it only for a truthy seed (renderer.py:146-151: `if seed`, so seed=0 means "do not reseed");
+	# (ii) the six named poses below (renderer.py:176-196).  Both are data that must match; the code around them is this file's own.
+	UP = ((1, 0, 0),)
+	NAMED_VIEWS = {   # name: (dist, elev, azim, look-at point)
+		'topdown': (0.30, 0, 0, (0, 0, 0)),
+		'side1': (0.35, 90, 0, (0, 0, 0)),
+		'side2': (0.35, -90, 180, (0, 0, 0)),
+		'toes': (0.10, 0, 0, (0.1, 0, 0)),
+		'45': (0.35, -45, 0, (0, 0, 0)),
+		'60': (0.35, -60, 0, (0, 0, 0)),
+	}
+
+	@classmethod
+	def _poses(cls, dist, elev, azim, at=((0, 0, 0),)):
+		return look_at_view_transform(dist=dist, elev=elev, azim=azim, up=cls.UP, at=at)
+
 	def sample_views(self, nviews=1, dist_mean=.25, dist_std=0.05, elev_min=-90, elev_max=90, azim_min=0, azim_max=360, seed: int = None):
+		"""Random poses: dist ~ N(dist_mean, dist_std), elev ~ U(elev_min, elev_max), azim ~ U(azim_min, azim_max), degrees."""
 		if seed:
 			np.random.seed(seed)
-		distances = np.random.normal(dist_mean, dist_std, (nviews))
-		elev = np.random.uniform(elev_min, elev_max, (nviews))
-		azim = np.random.uniform(azim_min, azim_max, (nviews))
-		return look_at_view_transform(dist=distances, elev=elev, azim=azim, up=((1, 0, 0),))
+		draws = [np.random.normal(dist_mean, dist_std, nviews)]
+		draws += [np.random.uniform(lo, hi, nviews) for lo, hi in ((elev_min, elev_max), (azim_min, azim_max))]
+		return self._poses(*draws)
 
 	def linspace_views(self, nviews=1, dist=.3, dist_min=None, dist_max=None, elev_min=None, elev_max=None, azim_min=None, azim_max=None,
 					   at=((0, 0, 0),)):
-		if dist_min is not None:
-			dist = np.linspace(dist_min, dist_max, nviews)
-		elev = 0 if elev_min is None else np.linspace(elev_min, elev_max, nviews)
-		azim = 0 if azim_min is None else np.linspace(azim_min, azim_max, nviews)
-		return look_at_view_transform(dist=dist, elev=elev, azim=azim, up=((1, 0, 0),), at=at)
+		"""Evenly spaced poses: each of dist / elev / azim sweeps its [min, max] when a min is given, else stays at dist / 0 / 0."""
+		def sweep(lo, hi, fixed):
+			return fixed if lo is None else np.linspace(lo, hi, nviews)
+		return self._poses(sweep(dist_min, dist_max, dist), sweep(elev_min, elev_max, 0), sweep(azim_min, azim_max, 0), at=at)
 
 	def view_from(self, view_kw='topdown'):
-		kws = ['topdown', 'side1', 'side2', 'toes', '45', '60']
-		if isinstance(view_kw, str):
-			view_kw = [view_kw]
-		N = len(view_kw)
-		R, T = torch.empty((N, 3, 3)), torch.empty((N, 3))
-		for n, v in enumerate(view_kw):
-			assert v in kws, f'View description `{view_kw}` not understood'
-			dist, elev, azim, point = 0.3, 0, 0, ((0, 0, 0),)
-			if v == 'side1':
-				elev, dist = 90, 0.35
-			if v == 'side2':
-				elev, azim, dist = -90, 180, 0.35
-			if v == 'toes':
-				point, dist = ((0.1, 0, 0),), 0.1
-			if v == '45':
-				dist, elev = 0.35, -45
-			if v == '60':
-				dist, elev = 0.35, -60
-			_R, _T = look_at_view_transform(dist=dist, elev=elev, azim=azim, up=((1, 0, 0),), at=point)
-			R[n], T[n] = _R, _T
-		return R, T
+		"""One pose per name in NAMED_VIEWS (a name or a list of names)."""
+		names = [view_kw] if isinstance(view_kw, str) else list(view_kw)
+		for v in names:
+			assert v in self.NAMED_VIEWS, f'View description `{view_kw}` not understood'
+		dist, elev, azim, at = zip(*(self.NAMED_VIEWS[v] for v in names))
+		return self._poses(np.array(dist), np.array(elev), np.array(azim), at=np.array(at, dtype=np.float64))
 
 	def combine_views(self, R1, T1, R2, T2):
 		return torch.cat([R1, R2], dim=0), torch.cat([T1, T2], dim=0)

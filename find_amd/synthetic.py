@@ -102,13 +102,17 @@ def surface_draws(n_meshes, n_samples, n_faces, seed=0, device='cuda', areas=Non
 	return face.to(torch.int32).to(device), uv.to(device)
 
 
-def scan_labels(n_items, scans_per_foot=2):
+def scan_labels(n_items, scans_per_foot=2, n_val=2):
 	"""Label strings as Foot3DDataset.get_keys / get_all_keys produce them (reference src/data/dataset.py:176-198): every scan is
 	'<foot>-<scan>'; shape / tex codes are shared by the scans of one foot, pose / reg codes are unique per scan.
-	Returns (foot id per item, scan name per item, latent_labels dict for the model incl. two validation scans of one foot)."""
+	Returns (foot id per item, scan name per item, latent_labels dict for the model incl. n_val validation scans of the feet 9000, 9001, ...:
+	labels['pose_val'] lists them, scan i belongs to foot 9000 + i // scans_per_foot)."""
 	feet = [f'{i // scans_per_foot:04d}' for i in range(n_items)]
 	names = [f'{feet[i]}-{chr(65 + i % scans_per_foot)}' for i in range(n_items)]
 	uniq = list(dict.fromkeys(feet))
+	feet_val = [f'{9000 + i // scans_per_foot:04d}' for i in range(n_val)]
+	names_val = [f'{feet_val[i]}-{chr(65 + i % scans_per_foot)}' for i in range(n_val)]
+	uniq_val = list(dict.fromkeys(feet_val))
 	labels = dict(shape=list(uniq), tex=list(uniq), pose=list(names), reg=list(names),
-				  shape_val=['9000'], tex_val=['9000'], pose_val=['9000-A', '9000-B'], reg_val=['9000-A', '9000-B'])
+				  shape_val=list(uniq_val), tex_val=list(uniq_val), pose_val=list(names_val), reg_val=list(names_val))
 	return feet, names, labels

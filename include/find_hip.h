@@ -94,7 +94,13 @@ typedef struct find_mlp_params {
 	                       * BASELINE.json configs[4]; no reference counterpart) -- per call, so two models in one process may differ */
 } find_mlp_params;
 
-/* Gradient outputs, same shapes as the corresponding weights; every buffer is OVERWRITTEN. */
+/* Gradient outputs, same shapes as the corresponding weights; every buffer given is OVERWRITTEN.
+ * Which buffers may be NULL (what autograd's needs_input_grad asks for on the FIND path):
+ *   - a head whose upstream gradient (d_disp / d_col) is NULL contributes nothing: its weight-gradient and latent-gradient pointers may be
+ *     NULL (nothing is written); given, they receive exact zeros;
+ *   - ALL weight-gradient pointers NULL = frozen network (requires_grad False on every weight; stage 3 of src/train/train.py:217-224 steps
+ *     Adam(latent_params) only): the call stops at the heads' first layers and writes lat_disp / lat_col alone;
+ *   - anything in between is refused (FIND_EINVAL). */
 typedef struct find_mlp_grads {
 	float* trunk_w[FIND_MAX_LAYERS];
 	float* trunk_b[FIND_MAX_LAYERS];
@@ -355,7 +361,8 @@ int find_render_fwd(const find_render_params* rp, const float* verts, const int3
 					const float* vert_colors, const float* R, const float* T, int64_t n_meshes, int64_t n_views,
 					int64_t n_verts, int64_t n_faces, float* mask, float* image, int32_t* pix_to_face, float* zbuf,
 					void* ws, int64_t ws_bytes, void* stream);
-/* d_mask / d_image upstream grads (either NULL); `mask` is the forward's soft silhouette (required with d_mask).
+/* d_mask / d_image upstream grads (either NULL); `mask` is the forward's soft silhouette (required with d_mask; the kernel reads the
+ * alpha product the forward saved in ws beside it -- 1 - mask is zero wherever the mask has rounded to 1).
  * d_verts (n_meshes,n_verts,3) and d_vert_colors (same, may be NULL) are OVERWRITTEN.  ws must be the forward workspace,
  * untouched since find_render_fwd (it holds the projected faces and the nearest-fragment buffers). */
 int find_render_bwd(const find_render_params* rp, const float* verts, const int32_t* faces, int64_t faces_batch,

@@ -215,6 +215,42 @@ static inline void normalize3(float* v) {
 	v[0] /= l; v[1] /= l; v[2] /= l;
 }
 
+/* ---------------------------------------------------------------- softmax blend of K fragments (A.4)
+ * The in-repo statement of the formula is FootRenderer's own softmax_blend (src/model/renderer.py:23-72, the C-channel version of
+ * PyTorch3D's softmax_rgb_blend): p_k = sigmoid(-d_k / sigma) on valid slots, z_inv_k = (zfar - z_k) / (zfar - znear) on valid slots,
+ * weights p_k exp((z_inv_k - max z_inv) / gamma), background weight delta = max(exp((eps - max z_inv) / gamma), eps), eps = 1e-10,
+ * max z_inv clamped from below by eps.  PINNED: tests/test_oracle_pins.py runs this function on fragments the imported reference
+ * function blended (tests/golden/blend.npz).  colors: K x C per pixel; out: C. */
+static inline void softmax_blend_pixel(const int32_t* pf, const float* d, const float* z, const float* colors, int K, int C, float sigma, float gamma,
+									   float znear, float zfar, const float* background, float* out) {
+	const float eps = 1e-10f;
+	float z_inv_max = 0.f;   /* z_inv * mask: empty slots contribute 0 to the maximum, as in the reference */
+	for (int k = 0; k < K; ++k)
+		if (pf[k] >= 0) z_inv_max = fmaxf(z_inv_max, (zfar - z[k]) / (zfar - znear));
+	z_inv_max = fmaxf(z_inv_max, eps);
+	const float delta = fmaxf(expf((eps - z_inv_max) / gamma), eps);
+	float den = delta;
+	for (int c = 0; c < C; ++c) out[c] = delta * background[c];
+	for (int k = 0; k < K; ++k) {
+		if (pf[k] < 0) continue;
+		const float prob = 1.0f / (1.0f + expf(d[k] / sigma));
+		const float z_inv = (zfar - z[k]) / (zfar - znear);
+		const float wnum = prob * expf((z_inv - z_inv_max) / gamma);
+		den += wnum;
+		for (int c = 0; c < C; ++c) out[c] += wnum * colors[(size_t)k * C + c];
+	}
+	for (int c = 0; c < C; ++c) out[c] /= den;
+}
+
+/* colors (n_pix, K, C) -> out (n_pix, C): softmax_blend over whole fragment buffers (test entry point) */
+void ref_softmax_blend(const int32_t* pix_to_face, const float* dists, const float* zbuf, const float* colors, int64_t n_pix, int K, int C, float sigma,
+					   float gamma, float znear, float zfar, const float* background, float* out) {
+#pragma omp parallel for
+	for (int64_t p = 0; p < n_pix; ++p)
+		softmax_blend_pixel(pix_to_face + p * K, dists + p * K, zbuf + p * K, colors + (size_t)p * K * C, K, C, sigma, gamma, znear, zfar, background,
+							out + p * C);
+}
+
 /* ---------------------------------------------------------------- Phong + softmax_rgb_blend with K = 1 (A.4)
  * Fragments come from ref_rasterize(K=1, blur 0, no clip).  verts/normals/colors are WORLD-space per mesh.
  * cam_center (n_views,3) = -T @ R^T.  image (n_img,H,W,3). */
@@ -227,8 +263,7 @@ void ref_phong_blend(const render_params* rp, const int32_t* pix_to_face, const 
 		const int im = (int)(p / ((int64_t)H * W));
 		const int mesh = im / n_views, view = im % n_views;
 		float* o = image + p * 3;
-		const int pf = pix_to_face[p];
-		const float eps = 1e-10f;
+		const int32_t pf = pix_to_face[p];
 		if (pf < 0) {
 			/* no face: weights are zero, pixel = delta*bg/delta */
 			o[0] = rp->background[0]; o[1] = rp->background[1]; o[2] = rp->background[2];
@@ -254,16 +289,9 @@ void ref_phong_blend(const render_params* rp, const int32_t* pix_to_face, const 
 		const float r[3] = {-l[0] + 2.f * cosang * n[0], -l[1] + 2.f * cosang * n[1], -l[2] + 2.f * cosang * n[2]};
 		float al = fmaxf(vdir[0] * r[0] + vdir[1] * r[1] + vdir[2] * r[2], 0.f) * (cosang > 0.f ? 1.f : 0.f);
 		const float spec = rp->specular * powf(al, rp->shininess);
-		/* blending.py softmax_rgb_blend, K = 1 */
-		const float prob = 1.0f / (1.0f + expf(dists[p] / rp->rgb_sigma));
-		const float z_inv = (rp->zfar - zbuf[p]) / (rp->zfar - rp->znear);
-		const float z_inv_max = fmaxf(z_inv, eps);
-		const float wnum = prob * expf((z_inv - z_inv_max) / rp->rgb_gamma);
-		const float delta = fmaxf(expf((eps - z_inv_max) / rp->rgb_gamma), eps);
-		const float den = wnum + delta;
-		for (int c = 0; c < 3; ++c) {
-			const float col = (rp->ambient + diff) * tex[c] + spec;
-			o[c] = (wnum * col + delta * rp->background[c]) / den;
-		}
+		/* softmax blend of the one fragment (K = 1, renderer.py:119-128 raster_settings) */
+		float col[3];
+		for (int c = 0; c < 3; ++c) col[c] = (rp->ambient + diff) * tex[c] + spec;
+		softmax_blend_pixel(&pf, dists + p, zbuf + p, col, 1, 3, rp->rgb_sigma, rp->rgb_gamma, rp->znear, rp->zfar, rp->background, o);
 	}
 }

@@ -8,7 +8,9 @@ Two layers:
     PyTorch3D's hand-written rasteriser backward equals the true derivative of these formulas (the point-segment
     distance treats the clamped projection parameter as constant, which is exact by the envelope theorem).
 
-PARITY UNPINNED (PyTorch3D absent, no reference tests): anchored by tests/test_oracle_raster.py."""
+PARITY: the blend (softmax_blend, silhouette alpha) is PINNED to the reference's own softmax_blend (src/model/renderer.py:23-72, imported
+and run by tests/golden/make_golden_pins.py -> tests/golden/blend.npz; tests/test_oracle_pins.py).  The rasteriser, the Phong shading and
+the projection stay UNPINNED (PyTorch3D absent, no reference tests): anchored by tests/test_oracle_raster.py."""
 import ctypes
 import math
 import os
@@ -101,6 +103,18 @@ def silhouette(p2f, dists, sigma=1e-4):
 	mask = np.empty(p2f.shape[:-1], np.float32)
 	lib().ref_silhouette(_p(p2f), _p(dists), ctypes.c_int64(mask.size), K, ctypes.c_float(sigma), _p(mask))
 	return mask
+
+
+def softmax_blend(p2f, dists, zbuf, colors, sigma=1e-4, gamma=1e-4, znear=0.02, zfar=100.0, background=(1., 1., 1.)):
+	"""FootRenderer's softmax_blend (src/model/renderer.py:23-72) over fragment buffers: p2f / dists / zbuf (..., K), colors (..., K, C)
+	-> (..., C).  The same C function blends the K = 1 fragments of render(); pinned by tests/golden/blend.npz."""
+	p2f, dists, zbuf, colors = _i32(p2f), _f32(dists), _f32(zbuf), _f32(colors)
+	K, C = p2f.shape[-1], colors.shape[-1]
+	out = np.empty(p2f.shape[:-1] + (C,), np.float32)
+	bg = _f32(background)
+	lib().ref_softmax_blend(_p(p2f), _p(dists), _p(zbuf), _p(colors), ctypes.c_int64(out.size // C), K, C, ctypes.c_float(sigma), ctypes.c_float(gamma),
+							ctypes.c_float(znear), ctypes.c_float(zfar), _p(bg), _p(out))
+	return out
 
 
 def vertex_normals(verts, faces):
@@ -253,16 +267,20 @@ def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views):
 	al = torch.relu((vd * r).sum(-1)) * (cosang > 0)
 	spec = rp.specular * al ** rp.shininess
 	col = (rp.ambient + diff).unsqueeze(-1) * tex + spec.unsqueeze(-1)
-	eps = 1e-10
-	prob = torch.sigmoid(-dist / rp.rgb_sigma) * valid
-	z_inv = (rp.zfar - pz) / (rp.zfar - rp.znear) * valid
-	z_inv_max = z_inv.max(dim=-1, keepdim=True).values.clamp(min=eps)
-	wnum = prob * torch.exp((z_inv - z_inv_max) / rp.rgb_gamma)
-	delta = torch.exp((eps - z_inv_max) / rp.rgb_gamma).clamp(min=eps)
-	den = wnum.sum(-1, keepdim=True) + delta
-	bg = torch.tensor(list(rp.background), dtype=verts.dtype)
-	img = ((wnum.unsqueeze(-1) * col).sum(-2) + delta * bg) / den
+	img = torch_softmax_blend(col, dist, pz, valid, rp.rgb_sigma, rp.rgb_gamma, rp.znear, rp.zfar, torch.tensor(list(rp.background), dtype=verts.dtype))
 	return img.reshape(N, n_views, H, W, 3)
+
+
+def torch_softmax_blend(col, dist, pz, valid, sigma, gamma, znear, zfar, background):
+	"""Differentiable softmax blend (renderer.py:46-70): col (..., K, C), dist / pz / valid (..., K) -> (..., C).  Pinned by blend.npz."""
+	eps = 1e-10
+	prob = torch.sigmoid(-dist / sigma) * valid
+	z_inv = (zfar - pz) / (zfar - znear) * valid
+	z_inv_max = z_inv.max(dim=-1, keepdim=True).values.clamp(min=eps)
+	wnum = prob * torch.exp((z_inv - z_inv_max) / gamma)
+	delta = torch.exp((eps - z_inv_max) / gamma).clamp(min=eps)
+	den = wnum.sum(-1, keepdim=True) + delta
+	return ((wnum.unsqueeze(-1) * col).sum(-2) + delta * background) / den
 
 
 def torch_mask(rp, verts, faces, R, T, p2f, n_views):

@@ -168,8 +168,9 @@ def test_only_col_gradient_skips_disp_head(golden_main):
 	lat = {k: _t(golden_main[f'fwd/d/{k}']).requires_grad_(True) for k in ['shapevec', 'texvec', 'posevec']}
 	res = m(pos, **lat)
 	(res['col'] ** 2).sum().backward()
-	assert m.mlp_disp[0].weight.grad.abs().max().item() == 0.0
-	assert lat['shapevec'].grad.abs().max().item() == 0.0
+	# a head nothing reads gets NO gradient, as in the reference (pinned: tests/golden/texture_loss.npz 'no_grad') -- not a tensor of zeros
+	assert all(p.grad is None for p in m.mlp_disp.parameters())
+	assert lat['shapevec'].grad is None and lat['posevec'].grad is None
 	assert m.mlp_col[0].weight.grad.abs().max().item() > 0.0
 	# oracle check of the col-only gradient
 	sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and k.split('.')[0] in ('base', 'mlp_col'))
@@ -179,7 +180,7 @@ def test_only_col_gradient_skips_disp_head(golden_main):
 	for k in ['base.0.weight', 'base.8.bias', 'mlp_col.0.weight', 'mlp_col.6.weight']:
 		ref = sd[k].grad
 		got = dict(m.named_parameters())[k].grad.cpu()
-		assert (got - ref).abs().max().item() < TOL * max(1.0, ref.abs().max().item()), k
+		assert (got - ref).abs().max().item() < TOL * ref.abs().max().item(), k   # relative to the tensor's largest entry
 
 
 def test_registration_forward_backward_vs_oracle():
@@ -475,7 +476,7 @@ def test_two_passes_in_one_backward_fold_their_weight_gradients(golden_main):
 @pytest.mark.parametrize('shape', [(2, 300), (16, 1000), (1, 6890)])
 def test_colour_head_alone_equals_the_full_forward(golden_main, shape):
 	"""model(..., want=('col',)) -- what the texture loss asks for -- skips the displacement head in the forward: same colours, same
-	gradients as the full forward differentiated through its colour output only, exact zeros for the displacement head's parameters."""
+	gradients as the full forward differentiated through its colour output only, none for the displacement head's parameters."""
 	m = _model_from_golden(golden_main)
 	n, v = shape
 	g = torch.Generator().manual_seed(n * 1000 + v)
@@ -495,8 +496,7 @@ def test_colour_head_alone_equals_the_full_forward(golden_main, shape):
 	assert set(g0) == set(g1)
 	for k in g0:
 		assert (g0[k] - g1[k]).abs().max().item() <= 1e-6 * max(1e-3, g0[k].abs().max().item()), k
-		if k.startswith('mlp_disp'):
-			assert float(g1[k].abs().max()) == 0.0
+		assert not k.startswith('mlp_disp')
 	for k in l0:
 		assert (l0[k] is None) == (l1[k] is None)
 		if l0[k] is not None:

@@ -109,12 +109,12 @@ def test_train_3d_loss_set_matches_oracle():
 		got = getattr(mwl.model, name).data.grad.cpu()
 		want = lat[k].grad
 		s = max(1e-3, want.abs().max().item())
-		assert (got - want).abs().max().item() < 2e-4 * s, (k, (got - want).abs().max().item(), s)   # measured 1e-5 (nearest-neighbour picks are identical)
+		assert (got - want).abs().max().item() < 1e-4 * s, (k, (got - want).abs().max().item(), s)   # measured 1e-5 (nearest-neighbour picks are identical)
 	for k in ['base.0.weight', 'base.4.bias', 'mlp_disp.2.weight', 'mlp_disp.6.weight', 'mlp_col.0.weight', 'mlp_col.6.bias']:
 		got = dict(mwl.model.named_parameters())[k].grad.cpu()
 		want = sd[k].grad
 		s = max(1e-3, want.abs().max().item())
-		assert (got - want).abs().max().item() < 2e-4 * s, (k, (got - want).abs().max().item(), s)   # measured 1e-5 (nearest-neighbour picks are identical)
+		assert (got - want).abs().max().item() < 1e-4 * s, (k, (got - want).abs().max().item(), s)   # measured 1e-5 (nearest-neighbour picks are identical)
 
 
 def test_z_cutoff_variants_match_oracle():
@@ -158,12 +158,35 @@ def test_render_losses_match_oracle():
 	sil = float(((pr['mask'] - gt['mask']) ** 2).mean()) * 5.0
 	pix = float(((pr['image'] * pr['mask'][..., None] - gt['image'] * gt['mask'][..., None]) ** 2).mean()) * 1.0
 	assert abs(losses['loss_sil'].item() - sil) < 1e-4 * max(1.0, sil), (losses['loss_sil'].item(), sil)
-	assert abs(losses['loss_pix'].item() - pix) < 2e-4 * max(1.0, pix), (losses['loss_pix'].item(), pix)
-	# gradients reach the registration, the latents and the network through both render losses
+	assert abs(losses['loss_pix'].item() - pix) < 1e-4 * max(1.0, pix), (losses['loss_pix'].item(), pix)
+	# gradients through both render losses against autograd through the oracle: the MLP on torch-CPU, the differentiable restatement of
+	# the fragment math (render_ref.torch_mask / torch_phong_image) on the discrete face selection of the oracle's own rasteriser
 	for name in ['reg', 'shapevec', 'texvec', 'posevec']:
 		g = getattr(mwl.model, name).data.grad
 		assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0, name
-	assert mwl.model.base[0].weight.grad.abs().max().item() > 0
+	rp = render_ref.default_params(64)
+	ro = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	vproj = render_ref.project(rp, ro['verts'].detach().numpy(), R.numpy(), T.numpy())
+	p2f_k, _, _, _ = render_ref.rasterize(vproj, tf.numpy(), 2, 64, 64, 100, rp.sil_blur_radius)
+	p2f_1, _, _, _ = render_ref.rasterize(vproj, tf.numpy(), 2, 64, 64, 1, 0.0)
+	om = render_ref.torch_mask(rp, ro['verts'], tf, R, T, torch.from_numpy(p2f_k).long(), 2)
+	oi = render_ref.torch_phong_image(rp, ro['verts'], ro['col'], tf, R, T, torch.from_numpy(p2f_1).long(), 2)
+	gm, gi = torch.from_numpy(gt['mask']), torch.from_numpy(gt['image'])
+	ol = ((om - gm) ** 2).mean() * 5.0 + ((oi * om.unsqueeze(-1) - gi * gm.unsqueeze(-1)) ** 2).mean() * 1.0
+	assert abs(ol.item() - loss.item()) < 1e-4 * max(1.0, abs(ol.item()))
+	ol.backward()
+	worst = 0.0
+	for k in ['shapevec', 'texvec', 'posevec', 'reg']:
+		got, want = getattr(mwl.model, k).data.grad.cpu(), lat[k].grad
+		err = (got - want).abs().max().item() / max(1e-6, want.abs().max().item())
+		worst = max(worst, err)
+		assert err < 1e-4, (k, err)
+	for k in ['base.0.weight', 'base.4.bias', 'mlp_disp.2.weight', 'mlp_disp.6.weight', 'mlp_col.0.weight', 'mlp_col.6.bias']:
+		got, want = dict(mwl.model.named_parameters())[k].grad.cpu(), sd[k].grad
+		err = (got - want).abs().max().item() / max(1e-6, want.abs().max().item())
+		worst = max(worst, err)
+		assert err < 1e-4, (k, err)
+	print(f'render losses: worst gradient error {worst:.2e} of the tensor maximum')
 
 
 def test_gt_render_on_the_second_stream_changes_nothing():

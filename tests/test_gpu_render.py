@@ -231,28 +231,37 @@ def test_silhouette_backward_with_k_overflow_vs_oracle_autograd():
 	R, T = torch.from_numpy(R), torch.from_numpy(T)
 	vg = verts.clone().cuda().requires_grad_(True)
 	(mask, _, _, _), params = _render_gpu(vg, f, None, R, T, size, want_image=False)
-	gt = torch.rand(mask.shape, generator=torch.Generator().manual_seed(2))
-	loss = ((mask - gt.cuda()) ** 2).mean()
-	loss.backward()
 	rp = render_ref.default_params(size)
 	vproj = render_ref.project(rp, verts.numpy(), R.numpy(), T.numpy())
-	p2f, _, _, _ = render_ref.rasterize(vproj, f.numpy(), 1, size, size, 100, rp.sil_blur_radius)
+	# Which face is the 100th nearest?  Where the 100th and the 101st candidate of a pixel have depths that agree to rounding, the answer
+	# depends on the last bits of the interpolated depth (thousands of quarter-pixel faces per pixel here) and two correct implementations
+	# may keep different faces.  Those pixels are found in the oracle's own K = 101 fragments and taken out of the loss on BOTH sides;
+	# everywhere else mask and gradient must agree to the north_star tolerance.
+	p2f101, z101, _, _ = render_ref.rasterize(vproj, f.numpy(), 1, size, size, 101, rp.sil_blur_radius)
+	p2f = np.ascontiguousarray(p2f101[..., :100])
 	assert (p2f[..., 99] >= 0).mean() > 0.05  # the K-buffer really is full on a good share of the pixels
+	z99, z100 = z101[..., 99].astype(np.float64), z101[..., 100].astype(np.float64)
+	DEPTH_TIE = 4e-6   # relative; ~30 ulp of the fp32 depth: the interpolation is a dozen roundings on either side
+	tie = (p2f101[..., 100] >= 0) & (z100 - z99 <= DEPTH_TIE * z99)
+	tie = torch.from_numpy(tie.reshape(mask.shape))
+	print('depth-tie pixels: %d of %d (%d with a full K-buffer)' % (int(tie.sum()), tie.numel(), int((p2f[..., 99] >= 0).sum())))
+	assert tie.float().mean().item() < 0.02
+	w = (~tie).float()
+	gt = torch.rand(mask.shape, generator=torch.Generator().manual_seed(2))
+	loss = (((mask - gt.cuda()) ** 2) * w.cuda()).mean()
+	loss.backward()
 	vr = verts.clone().requires_grad_(True)
 	rm = render_ref.torch_mask(rp, vr, f, R, T, torch.from_numpy(p2f).long(), 1)
-	# which face is the 100th nearest is decided by depths that differ in the last bits between the two implementations
-	# (thousands of quarter-pixel faces per pixel here), so a few pixels may swap one low-weight candidate: bound the
-	# number and the size of such differences instead of demanding 1e-4 everywhere
 	dm = (mask.detach().cpu() - rm.detach()).abs()
-	print('mask: max diff %.2e, pixels over 1e-4: %d of %d' % (dm.max().item(), int((dm > TOL).sum()), dm.numel()))
-	assert dm.max().item() < 5e-3 and (dm > TOL).float().mean().item() < 0.01
-	rl = ((rm - gt) ** 2).mean()
+	print('mask: max diff outside the ties %.2e, inside %.2e' % ((dm * w).max().item(), (dm * (1 - w)).max().item()))
+	assert (dm * w).max().item() < TOL
+	rl = (((rm - gt) ** 2) * w).mean()
 	rl.backward()
 	scale = vr.grad.abs().max().item()
 	assert scale > 0
 	err = (vg.grad.cpu() - vr.grad).abs()
 	print('grad: max err %.2e of scale %.2e' % (err.max().item(), scale))
-	assert err.max().item() < 2e-2 * scale, (err.max().item(), scale)
+	assert err.max().item() < TOL * scale, (err.max().item(), scale)
 
 
 def test_forward_edge_cases_vs_oracle():

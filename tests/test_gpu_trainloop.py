@@ -1,0 +1,324 @@
+"""The loops around the step, driven the way the reference drives them on cfgs/train_3d.yaml:
+
+* train_network's keyword dictionary for epoch 0 of stages 2 and 3 (src/train/train.py:52-70: save_renders and render_foot are ON at
+  epoch 0 because a checkpoint is saved there and --no_rendering is off), fed through the inner bodies of Trainer.train_epoch
+  (src/train/trainer.py:96-123) and Trainer.val_epoch (:150-163);
+* stage 3, latent refinement (train.py:217-224: val_only -> only val_epoch runs, is_train=False, the `*_val` tables, Adam(latent_params)):
+  losses and the gradients of the addressed val rows against the oracle's composition, with the network's weights trainable (as the
+  reference leaves them) and frozen (latents-only backward);
+* find_amd.trainer.Trainer: the same epochs as HIP-graph replays and eagerly, same parameters afterwards."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom_ref, mlp_ref
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_train3d import FixedDraws, ITEM, ROWS, _oracle_inputs, _setup   # noqa: E402
+
+VAL_ROWS = dict(shapevec=0, texvec=0, posevec=1, reg=1)   # scan 9000-B of foot 9000 (synthetic.scan_labels)
+
+
+def _train3d_opts(opts):
+	"""cfgs/train_3d.yaml: COMMON_ARGS.copy_over_masking + the FIND experiment's switches (the loss flags are set by _setup)."""
+	opts.set_option('copy_over_masking', True)
+	opts.set_option('reg', True)
+	opts.set_option('latent_epochs', 1000)
+	return opts
+
+
+def _val_batch(gv, gf, gc, i=0, scan='9000-B'):
+	from find_amd.structures import Meshes, TexturesVertex
+	return dict(mesh=Meshes(gv[i:i + 1].contiguous(), gf, TexturesVertex(gc[i:i + 1].contiguous())), idx=torch.tensor([1], device='cuda'),
+				name=[scan], shape=['9000'], tex=['9000'], pose=[scan], reg=[scan])
+
+
+def _fill_val_tables(m, seed=5):
+	from find_amd import synthetic
+	lat = synthetic.latents(2, seed=seed, device='cuda')
+	with torch.no_grad():
+		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+			t = getattr(m, k + '_val').data
+			t.copy_(lat[k][:t.shape[0]])
+
+
+def _draws(n_verts, gt_verts, seed=9):
+	g = torch.Generator().manual_seed(seed)
+	F_gt, F_t = 2 * (gt_verts - 2), 2 * (n_verts - 2)
+	return [(torch.randint(0, F_gt, (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			(torch.randint(0, F_t, (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			(torch.randint(0, F_gt, (1, 1000), generator=g).cuda(), torch.rand(1, 1000, 2, generator=g).cuda())]
+
+
+def test_reference_call_sequence_epoch0_of_stages_2_and_3(tmp_path):
+	"""No keyword the reference passes on train_3d.yaml is refused; the PNG strip is written and holds the rendered images; the losses
+	are those of the same step without rendering."""
+	from PIL import Image
+	from find_amd import optim
+	from find_amd.trainer import stage_model_kwargs
+	from find_amd.train_utils import batch_to_device, sample_latent_vectors
+	n_verts = gt_verts = 1002
+	mwl, opts, batch_of, (gv, gf, gc), optim_network = _setup(n_verts, gt_verts)
+	opts = _train3d_opts(opts)
+	m = mwl.model
+	_fill_val_tables(m)
+	optim_latent = optim.Adam(m.latent_params, lr=opts.lr_latent)
+	draws = _draws(n_verts, gt_verts)
+
+	# ---- stage 2, epoch 0 (train.py:211-215 -> train_network(num_epochs=net_epochs, save_every=net_save_every))
+	epoch = 0
+	model_kwargs, save_model = stage_model_kwargs(opts, epoch, opts.net_epochs, opts.net_save_every, render_dir=str(tmp_path))
+	assert save_model and model_kwargs['save_renders'] and model_kwargs['render_foot']   # a checkpoint epoch with rendering on
+	assert model_kwargs['copy_mask_out'] is True and model_kwargs['mask_out_pred_faces'] is False and model_kwargs['gt_z_cutoff'] is None
+	os.makedirs(model_kwargs['render_dir'], exist_ok=True)
+	# Trainer.train_epoch's body (trainer.py:93-123)
+	model_kwargs['is_train'] = True
+	batch = batch_of(ITEM)
+	batch.update(**sample_latent_vectors(batch, m.latent_vectors_train))
+	batch = batch_to_device(batch, 'cuda')
+	[o.zero_grad() for o in [optim_network]]
+	np.random.seed(11)
+	with FixedDraws(draws):
+		loss, loss_dict = mwl(batch, epoch, opts=opts, **model_kwargs)
+	assert not (loss == 0)
+	loss.backward()
+	[o.step() for o in [optim_network]]
+	assert set(loss_dict) == {'loss_chamf', 'loss_smooth', 'loss_tex'}
+	png = os.path.join(model_kwargs['render_dir'], f'{epoch:04d}_{ITEM:02d}.png')
+	assert os.path.isfile(png)
+	strip = np.asarray(Image.open(png))
+	M, H = opts.num_views, 256
+	assert strip.shape == (M * H, 2 * H, 3) and strip.dtype == np.uint8   # views top to bottom, GT | prediction
+
+	# the same step without any rendering gives the same losses (fresh model: the optimiser has stepped the first one)
+	mwl2, opts2, batch_of2, _, _ = _setup(n_verts, gt_verts)
+	b2 = batch_of2(ITEM)
+	b2.update(**sample_latent_vectors(b2, mwl2.model.latent_vectors_train))
+	with FixedDraws(draws):
+		loss2, ld2 = mwl2(b2, epoch, opts=opts2, **opts2.net_train_kwargs(), is_train=True)
+	assert torch.equal(loss.detach(), loss2.detach())
+	for k in loss_dict:
+		assert torch.equal(loss_dict[k].detach(), ld2[k].detach()), k
+	# ... and the strip is the images return_renders hands out for the same camera draws: 8 bits by truncation of 255 * value
+	np.random.seed(11)
+	with FixedDraws(draws):
+		_, _, rdr = mwl2(b2, epoch, opts=opts2, **opts2.net_train_kwargs(), render_foot=True, return_renders=True, copy_mask_out=True)
+	want = np.hstack([np.vstack(rdr[k]['image'].detach().reshape(-1, H, H, 3).cpu().numpy()) for k in ('gt', 'pred')])
+	want = (want * 255).astype(np.uint8)
+	assert (strip.astype(int) - want.astype(int)).__abs__().max() <= 1   # (the two models differ by nothing: same seeds, same draws)
+	assert strip[:, :H].min() < 255 and strip[:, H:].min() < 255            # both columns show a foot, not a white page
+
+	# ---- stage 3, epoch 0 (train.py:217-224: val_only=True -> train_epoch is skipped, val_epoch runs with render_dir .../val)
+	model_kwargs, save_model = stage_model_kwargs(opts, 0, opts.latent_epochs, opts.latent_save_every, render_dir=str(tmp_path))
+	model_kwargs['render_dir'] = os.path.join(str(tmp_path), 'val')
+	os.makedirs(model_kwargs['render_dir'], exist_ok=True)
+	assert model_kwargs['save_renders'] and model_kwargs['render_foot']
+	# Trainer.val_epoch's body (trainer.py:147-163)
+	model_kwargs['is_train'] = False
+	batch = _val_batch(gv, gf, gc)
+	batch.update(**sample_latent_vectors(batch, m.latent_vectors_val))
+	batch = batch_to_device(batch, 'cuda')
+	assert set(k for k in batch if k.endswith('_val')) == {'shapevec_val', 'posevec_val', 'texvec_val', 'reg_val'}
+	before = {n: p.detach().clone() for n, p in m.named_parameters()}
+	optim_latent.zero_grad()
+	loss, loss_dict = mwl(batch, 0, opts=opts, **model_kwargs)
+	loss.backward()
+	optim_latent.step()
+	assert os.path.isfile(os.path.join(model_kwargs['render_dir'], '0000_01.png'))
+	after = dict(m.named_parameters())
+	# Adam(latent_params) moves the addressed val rows of shape / tex / pose, nothing of the network, nothing of the train tables, no reg row
+	for k, r in VAL_ROWS.items():
+		n = f'{k}_val.data'
+		if k == 'reg':
+			assert torch.equal(after[n], before[n])
+		else:
+			assert not torch.equal(after[n][r], before[n][r]), n
+	for n in ('base.2.weight', 'mlp_disp.0.weight', 'mlp_col.6.bias', 'shapevec.data', 'posevec.data', 'reg.data'):
+		assert torch.equal(after[n], before[n]), n
+
+
+def _val_oracle(mwl, gv, gf, gc, draws_cpu, item=0):
+	m = mwl.model
+	sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col'))
+		  for k, v in m.state_dict().items()}
+	lat = {k: getattr(m, k + '_val').data.detach().cpu()[r:r + 1].clone().requires_grad_(True) for k, r in VAL_ROWS.items()}
+	B, tv, tf = m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
+	(fi_gt, uv_gt), (fi_pr, uv_pr), (fi_tx, uv_tx) = draws_cpu
+	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	gvc, gfc, gcc = gv[item:item + 1].cpu(), gf.cpu(), gc[item:item + 1].cpu()
+	gt_s = geom_ref.sample_points(gvc, gfc, fi_gt, uv_gt)
+	pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
+	tx_p, tx_c = geom_ref.sample_points(gvc, gfc, fi_tx, uv_tx, attr=gcc)
+	col = mlp_ref.mlp_forward(sd, B, tx_p, lat['shapevec'], lat['texvec'], lat['posevec'])['col']
+	mask = (tx_c < 1).any(dim=-1, keepdim=True).expand(-1, -1, 3)
+	ref = {'loss_chamf': geom_ref.chamfer_distance(pr_s, gt_s) * 10000., 'loss_smooth': geom_ref.mesh_smoothness(res['verts'], tf) * 1000.,
+		   'loss_tex': (torch.nn.functional.mse_loss(col, tx_c, reduction='none') * mask).mean()}
+	return sd, lat, ref
+
+
+def _check_val_rows(m, lat, tol):
+	worst = 0.0
+	for k, r in VAL_ROWS.items():
+		g = getattr(m, k + '_val').data.grad
+		assert g is not None, k
+		g = g.cpu()
+		want = lat[k].grad[0]
+		s = max(1e-3, want.abs().max().item())
+		err = (g[r] - want).abs().max().item() / s
+		worst = max(worst, err)
+		assert err < tol, (k, err)
+		others = torch.cat([g[:r], g[r + 1:]])
+		assert others.numel() == 0 or others.abs().max().item() == 0.0, k
+	return worst
+
+
+def test_latent_refinement_stage_step_matches_oracle():
+	"""Stage 3 at full size: mwl(batch, epoch, opts, is_train=False, **net_train_kwargs) on a 6890-vertex template and a 10 002-vertex scan,
+	losses and the gradients of the addressed shapevec_val / texvec_val / posevec_val / reg_val rows against the oracle at 1e-4; then the
+	same step with the network frozen (requires_grad False: find_mlp_bwd's latents-only path) -- identical latent gradients to the bit
+	pattern the full backward gives up to summation order, no weight gradient -- and Adam(latent_params)."""
+	from find_amd import optim
+	from find_amd.train_utils import sample_latent_vectors
+	from test_gpu_pipeline import DrawRecorder
+	mwl, opts, batch_of, (gv, gf, gc), _ = _setup()
+	m = mwl.model
+	_fill_val_tables(m)
+	opt = optim.Adam(m.latent_params, lr=1e-4)
+	batch = _val_batch(gv, gf, gc)
+	batch.update(sample_latent_vectors(batch, m.latent_vectors_val))
+	for k, r in VAL_ROWS.items():
+		assert torch.equal(batch[f'{k}_val'], getattr(m, k + '_val').data[r:r + 1]), k
+	opt.zero_grad(set_to_none=True)
+	for p in m.parameters():
+		p.grad = None
+	with DrawRecorder() as rec:
+		loss, losses = mwl(batch, 0, opts, is_train=False, **opts.net_train_kwargs())
+	loss.backward()
+	draws_cpu = rec.chamfer_and_texture()
+	sd, lat, ref = _val_oracle(mwl, gv, gf, gc, draws_cpu)
+	for k in ref:
+		assert abs(losses[k].item() - ref[k].item()) < 1e-4 * max(1.0, abs(ref[k].item())), (k, losses[k].item(), ref[k].item())
+	sum(ref.values()).backward()
+	worst = _check_val_rows(m, lat, 1e-4)
+	# the reference leaves the network trainable in this stage (nothing freezes it; only the optimiser ignores it): its weights get gradients
+	for k in ['base.0.weight', 'mlp_disp.2.weight', 'mlp_col.0.weight']:
+		got, want = dict(m.named_parameters())[k].grad.cpu(), sd[k].grad
+		err = (got - want).abs().max().item() / max(1e-3, want.abs().max().item())
+		worst = max(worst, err)
+		assert err < 1e-4, (k, err)
+	# the train tables are not part of this step
+	assert m.shapevec.data.grad is None and m.reg.data.grad is None
+	full = {k: getattr(m, k + '_val').data.grad.clone() for k in VAL_ROWS}
+	print(f'latent-stage step: worst gradient error {worst:.2e} of the tensor maximum')
+
+	# ---- frozen network: same draws, latents-only backward
+	weights = [p for seq in (m.base, m.mlp_disp, m.mlp_col) for p in seq.parameters()]
+	for p in weights:
+		p.requires_grad_(False)
+	for p in m.parameters():   # (reg_val is not among latent_params: opt.zero_grad() alone would leave its gradient to accumulate)
+		p.grad = None
+	dev_draws = [(a.cuda(), b.cuda()) for a, b in draws_cpu]
+	batch.update(sample_latent_vectors(batch, m.latent_vectors_val))   # (a fresh lookup: the first backward freed the graph of the old rows)
+	with FixedDraws(dev_draws):
+		loss_f, losses_f = mwl(batch, 0, opts, is_train=False, **opts.net_train_kwargs())
+	loss_f.backward()
+	assert abs(loss_f.item() - loss.item()) < 1e-6 * max(1.0, abs(loss.item()))
+	assert all(p.grad is None for p in weights)
+	for k in VAL_ROWS:
+		g = getattr(m, k + '_val').data.grad
+		s = max(1e-3, full[k].abs().max().item())
+		assert (g - full[k]).abs().max().item() / s < 2e-5, k   # (summation order of the per-foot column sums)
+	_check_val_rows(m, lat, 1e-4)
+	before = {k: getattr(m, k + '_val').data.detach().clone() for k in VAL_ROWS}
+	opt.step()
+	for k, r in VAL_ROWS.items():
+		moved = not torch.equal(getattr(m, k + '_val').data[r], before[k][r])
+		assert moved == (k != 'reg'), k
+
+
+def test_frozen_network_backward_at_batch_16_matches_full_backward():
+	"""The latents-only path on the shared-template layout (16 feet, one trunk evaluation) and on per-foot positions (the texture pass):
+	latent gradients equal those of the full backward."""
+	from find_amd import synthetic
+	m = synthetic.make_model(1002, train_size=16, val_size=2, device='cuda')
+	lat = synthetic.latents(16, seed=3, device='cuda')
+	g = torch.Generator().manual_seed(4)
+	pos16 = (torch.randn(16, 700, 3, generator=g) * 0.05).cuda()
+	for pos in (m.template_verts.data, pos16):
+		grads = []
+		for frozen in (False, True):
+			for p in m.parameters():
+				p.grad = None
+			for seq in (m.base, m.mlp_disp, m.mlp_col):
+				for p in seq.parameters():
+					p.requires_grad_(not frozen)
+			lv = {k: v.clone().requires_grad_(True) for k, v in lat.items() if k != 'reg'}
+			res = m(pos, shapevec=lv['shapevec'], texvec=lv['texvec'], posevec=lv['posevec'])
+			w = torch.linspace(0.5, 1.5, res['disp'].numel(), device='cuda').view_as(res['disp'])
+			((res['disp'] * w).sum() + (res['col'] ** 2 * w).sum()).backward()
+			grads.append({k: v.grad.clone() for k, v in lv.items()})
+			if frozen:
+				assert all(p.grad is None for p in m.base.parameters())
+		for k in grads[0]:
+			s = grads[0][k].abs().max().item()
+			assert s > 0
+			assert (grads[0][k] - grads[1][k]).abs().max().item() / s < 2e-5, (k, tuple(pos.shape))
+
+
+def _trainer_run(graph, tmp_path, epochs=(0, 1, 2)):
+	from find_amd import optim
+	from find_amd.trainer import Trainer, stage_model_kwargs
+	n_verts = gt_verts = 1002
+	mwl, opts, batch_of, (gv, gf, gc), _ = _setup(n_verts, gt_verts, capturable=True)
+	opts = _train3d_opts(opts)
+	opts.set_option('net_epochs', 3)
+	opts.set_option('net_save_every', 2)      # epoch 0 and the last one save (and render); epoch 1 does not
+	opts.set_option('num_views', 2)
+	m = mwl.model
+	_fill_val_tables(m)
+	optim_network = optim.Adam(m.main_params, lr=5e-4, capturable=True)
+	optim_val = optim.Adam(m.latent_params, lr=1e-3, capturable=True)
+	loader = [batch_of(i) for i in (0, 3, 1, 2)]          # scans of varying label rows, one per step (batch_size_train = 1)
+	val_loader = [_val_batch(gv, gf, gc, 0, '9000-A'), _val_batch(gv, gf, gc, 1, '9000-B')]
+	tr = Trainer([optim_network], mwl, loader, val_loader, opts, latent_vectors_train=m.latent_vectors_train,
+				 latent_vectors_val=m.latent_vectors_val, val_optim=optim_val, device='cuda', graph=graph)
+	draws = _draws(n_verts, gt_verts)
+	modes, msgs = [], []
+	with FixedDraws(draws):
+		for epoch in epochs:
+			kw, save_model = stage_model_kwargs(opts, epoch, opts.net_epochs, opts.net_save_every, render_dir=str(tmp_path / str(graph)))
+			np.random.seed(100 + epoch)
+			msgs.append(tr.train_epoch(epoch, save_model=save_model, model_kwargs=dict(kw)))
+			modes.append(tr.last_mode)
+			kw['render_dir'] = str(tmp_path / str(graph) / 'val')
+			msg, res = tr.val_epoch(epoch, model_kwargs=dict(kw))
+			modes.append(tr.last_mode)
+			assert set(res) == {'Loss', 'chamf', 'smooth', 'tex'}
+	torch.cuda.synchronize()
+	return tr, {n: p.detach().clone() for n, p in m.named_parameters()}, modes
+
+
+def test_trainer_graph_replays_equal_eager_epochs(tmp_path):
+	"""find_amd.trainer.Trainer over label-addressed one-scan batches: checkpoint epochs (save_renders) run eagerly, the others as HIP-graph
+	replays; parameters and logged losses equal those of the all-eager loop."""
+	tr_g, p_g, modes_g = _trainer_run('auto', tmp_path)
+	tr_e, p_e, modes_e = _trainer_run(False, tmp_path)
+	assert modes_e == ['eager'] * 6
+	assert modes_g == ['eager', 'eager', 'graph', 'graph', 'eager', 'eager'], modes_g   # epochs 0 and 2 save a checkpoint and render
+	assert os.path.isfile(tmp_path / 'auto' / 'train' / '0000_00.png') and os.path.isfile(tmp_path / 'auto' / 'val' / '0002_01.png')
+	assert not os.path.exists(tmp_path / 'auto' / 'train' / '0001_00.png')
+	lr, n_steps = 1e-3, 3 * 4 + 3 * 2
+	for n in p_e:
+		d = (p_g[n] - p_e[n]).abs().max().item()
+		assert d < 0.02 * lr * n_steps, (n, d)   # bound as in test_graphed_step_equals_eager_steps (Adam amplifies 1e-7 summation noise)
+	for epoch in (0, 1, 2):
+		for part in ('train_loss', 'val_loss'):
+			a, b = tr_g.log[epoch][part], tr_e.log[epoch][part]
+			assert set(a) == set(b) and ('Loss' in a)
+			for k in a:
+				assert len(a[k]) == len(b[k]) == (4 if part == 'train_loss' else 2)
+				np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=1e-6)
+	assert set(tr_g.log[0]['train_loss']) == {'Loss', 'Chamf', 'Smooth', 'Tex'}   # pretty_print_loss keys (trainer.py:14-16,126)

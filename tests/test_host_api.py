@@ -195,7 +195,9 @@ def test_opts_defaults_and_weights():
 	from find_amd.opts import Opts
 	o = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True)
 	assert (o.weight_chamf, o.weight_smooth, o.weight_tex, o.weight_sil, o.weight_pix) == (10000., 1000., 1., 5., 1.)  # opts.py:97-99
-	assert o.num_views == 5 and o.net_train_kwargs()['chamf'] and not o.net_train_kwargs()['render_foot']
+	assert o.num_views == 5 and o.net_train_kwargs()['chamf'] and not o.net_train_kwargs()['sil']
+	# exactly the ten keys of the reference (opts.py:207-215): train_network adds the render / masking keys itself (train.py:58-70)
+	assert set(o.net_train_kwargs()) == {'chamf', 'smooth', 'texture', 'pix', 'sil', 'vgg_perc', 'restyle_perc_lat', 'restyle_perc_feat', 'restyle_perc_cluster', 'cont_pose'}
 	with pytest.raises(AssertionError):
 		o.set_option('not_a_flag', 1)
 	assert not o.use_restyle()
