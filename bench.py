@@ -93,7 +93,7 @@ def set_cpu_threads(n):
 		pass
 
 
-def best_of_cpu(one, repeats=5, counts=(16, 32, 64, 128, None), budget_s=30.0):
+def best_of_cpu(one, repeats=5, counts=(16, 32, 64, 128, None), budget_s=16.0):
 	"""Time `one()` (returns seconds) on the host the way SURVEY 8d asks: every thread count of a probe {16, 32, 64, 128, all} once after a
 	warm-up, then the best count `repeats` times; returns (best seconds, cores used, description).  torch-CPU does not scale to every
 	hardware thread of a big host on GEMMs this small, and a fixed count would flatter the GPU/CPU ratio.  Bounded: the probe stops
@@ -194,6 +194,11 @@ class Run:
 			sys.stdout.flush()
 			torch.distributed.barrier()
 			torch.distributed.destroy_process_group()
+
+
+def note(msg):
+	"""Progress to stderr (which record is running: a fault in one of them is then attributable)."""
+	print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
 def line(value, ms, run, steps, warmup, config, **extra):
@@ -646,7 +651,7 @@ def brief(rec, *keys):
 	return out
 
 
-def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True):
+def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True, only=None):
 	"""The reference's literal batch size (batch_size_train = batch_size_val = 1, opts.py:40-41) with label-addressed latents: 16 scans of 8
 	feet visited round-robin, one scan per step -- the three stages of train.py (registration, network, latent refinement), the network and
 	latent stages also as one HIP-graph replay per step, the latent stage also with the network frozen."""
@@ -655,6 +660,9 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True):
 				('latent', True, 'train3d_b1_latent_stage_frozen')]
 	cpu_net = None
 	for stage, frozen, key in variants:
+		if only and key not in only:
+			continue
+		note(f'record {key}')
 		su = train3d_setup(run, 16, 1, stage=stage, labels=True, dp=False, frozen=frozen)
 		ms = run.timed(su['step'], steps, warmup)
 		# host time to enqueue one step with an empty queue: is the step GPU-bound?
@@ -681,6 +689,7 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True):
 		recs[key]['host_enqueue_ms_per_step'] = rec['host_enqueue_ms_per_step']
 		if stage != 'reg' and graph:
 			try:
+				note(f'record {key}_graph')
 				recs[key + '_graph'] = train3d_b1_graph(run, steps, warmup, stage=stage, frozen=frozen)
 				if 'cpu_baseline' in rec:
 					recs[key + '_graph']['x_cpu_baseline'] = recs[key + '_graph']['value'] / rec['cpu_baseline']['value']
@@ -719,6 +728,7 @@ def main():
 	ap.add_argument('--no-records', action='store_true', help='skip the nested records of the other configurations')
 	ap.add_argument('--train3d', action='store_true', help='(default) the headline line: the reference training configuration')
 	ap.add_argument('--train3d-b1', action='store_true', help='instead of the headline line: only the batch-1 train_3d records')
+	ap.add_argument('--b1-only', default='', help='with --train3d-b1: comma-separated record names to run (diagnosis)')
 	ap.add_argument('--c2', action='store_true', help='instead of the headline line: BASELINE configs[1] (16 feet x 6890-vertex template, MLP fwd+bwd); round 1\'s headline')
 	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
 	ap.add_argument('--c5', action='store_true', help='BASELINE configs[4] geometry: the C2 workload on the 50 002-vertex dense template (fp32 unless --fp16)')
@@ -756,12 +766,13 @@ def main():
 			emit(out)
 		return run.finish()
 	if args.train3d_b1:
-		recs = train3d_b1_records(run, with_cpu, graph=not args.no_graph)
+		recs = train3d_b1_records(run, with_cpu, graph=not args.no_graph, only=set(args.b1_only.split(',')) if args.b1_only else None)
 		if run.rank == 0:
 			emit(recs)
 		return run.finish()
 
 	# ---- headline: train_3d.yaml network-stage step, 16 feet per GPU
+	note('headline')
 	su = train3d_setup(run, N_FEET, N_FEET, stage='net', labels=False, seed=run.rank)
 	ms = run.timed(su['step'], args.steps, args.warmup)
 	if run.rank == 0:
@@ -783,9 +794,13 @@ def main():
 	if run.world == 1 and not args.headline_only and not args.no_records:
 		recs = {}
 		recs.update(train3d_b1_records(run, with_cpu, graph=not args.no_graph))
+		note('record c2')
 		recs['c2'] = brief(c2_record(run, 30, 5, with_cpu=with_cpu), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed', 'step_tflops_reference_equiv')
+		note('record c3')
 		recs['c3'] = brief(c3_record(run, 20, 3, with_cpu))
+		note('record c4_rank_share')
 		recs['c4_rank_share'] = brief(c3_record(run, 10, 3, False, c4=True))
+		note('record c5')
 		recs['c5_fp32'] = brief(c2_record(run, 10, 3, n_verts=50002), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed')
 		recs['c5_fp16'] = brief(c2_record(run, 10, 3, n_verts=50002, fp16=True), 'step_tflops_executed')
 		out['records'] = recs
