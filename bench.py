@@ -100,19 +100,22 @@ def best_of_cpu(one, repeats=5, counts=(16, 32, 64, 128, None), budget_s=16.0):
 	widening once `budget_s` seconds have gone."""
 	avail = host_threads()
 	cand = sorted({min(avail, c if c is not None else avail) for c in counts})
+	before = torch.get_num_threads()
 	probe, t_start = {}, time.perf_counter()
 	for c in cand:
 		set_cpu_threads(c)
 		one()
 		probe[c] = one()
-		if time.perf_counter() - t_start > budget_s / 2:
+		# (wider is not tried once it has become clearly slower -- 256 threads took 20 s per step where 16 took 0.6 -- or the budget is half gone)
+		if probe[c] > 1.5 * min(probe.values()) or time.perf_counter() - t_start > budget_s / 2:
 			break
 	cores = min(probe, key=probe.get)
 	set_cpu_threads(cores)
 	times = [probe[cores]]
 	while len(times) < repeats and time.perf_counter() - t_start < budget_s:
 		times.append(one())
-	return min(times), cores, (f'best of {len(times)} with {cores} threads (probe over {sorted(probe)} threads: '
+	set_cpu_threads(before)   # the host-bound batch-1 records that follow are timed with the process as it was
+	return min(times), cores, (f'best of {len(times)} with {cores} threads (probe over {sorted(probe)} of {cand} threads, stopped where wider got slower: '
 							   + ', '.join(f'{c}: {probe[c] * 1e3:.0f} ms' for c in sorted(probe)) + f'; host exposes {avail} hardware threads)')
 
 
