@@ -1,6 +1,6 @@
 #!/bin/bash
 # Matrix-pipe / wait / LDS counters of dw2 (fp32 dW), gemm5 and dw3 (fp16 mode) at the C2 shape, one counter set per pass.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_kernels
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/pmc_kernels
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-side traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) of the fp16-mode Linear (gemm5), and of the weight-gradient
 # launches in both modes (dw2 / dw3 + slab reduce), at the C2 shape.  Run from the repo root through gpurun.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_traffic
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/pmc_traffic
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   export FIND_TUNING=mlp_f16=1

@@ -2,7 +2,8 @@
 # Rasteriser evidence at the C3 render shape (16 feet x 4 views @256^2, silhouette only): kernel durations, HBM-side traffic
 # (FETCH_SIZE / WRITE_SIZE in separate passes), VALU / wave occupancy / LDS counters of raster_tile_kernel and sil_bwd_kernel.
 # usage: bash tools/prof_raster.sh <outdir-name> [quick]
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/$1; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/tools/prof_render.py 256 0 > $O/trace.log 2>&1
 if [ "$2" != "quick" ]; then
 i=0

@@ -2,7 +2,8 @@
 # Collect the round's profile evidence on the GPU box (run from the repo root through gpurun):
 #   1. rocprofv3 --kernel-trace --stats of bench.py (same command the bench line comes from)
 #   2. PMC passes for the dominant kernel (find_linear_relu_fwd at the C2 shape), one counter set per pass
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/round
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1
 i=0

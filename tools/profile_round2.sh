@@ -8,7 +8,8 @@
 #   2d. the bench command itself (headline + the isolated loop its `roofline` times) under the tracer: tools/roofline_loop_stats.py reads the
 #       timed launches back from the trace (their average must agree with roofline.avg_kernel_ms of the same run, roofline_line.json)
 #   3. PMC passes of the dominant kernel (find_linear_relu_fwd at the C2 shape): MFMA busy / traffic
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r02; mkdir -p $O
 cd $R
 timeout 900 python3 bench.py > $O/bench_line.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp

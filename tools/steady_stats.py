@@ -14,11 +14,15 @@ for r in rows:
 	by[r['Kernel_Name']].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
 out = []
 total = 0.0
+once = []   # kernels launched less than once per step (set-up: stream probes, topology tables): not part of a steady step
 for name, iv in by.items():
 	per_step = len(iv) / (steps + warmup)
-	keep = iv[-max(1, int(round(per_step * steps))):] if per_step >= 1 else iv
+	if per_step < 1:
+		once.append((name, len(iv), sum(e - s for s, e in iv) / 1e3))
+		continue
+	keep = iv[-max(1, int(round(per_step * steps))):]
 	d = [(e - s) / 1e3 for s, e in keep]
-	us_step = sum(d) / steps if per_step >= 1 else sum(d) / (steps + warmup)
+	us_step = sum(d) / steps
 	out.append((name, per_step, sum(d) / len(d), min(d), max(d), us_step))
 	total += us_step
 # span of the steady steps: first kept launch to last end
@@ -28,4 +32,6 @@ w = csv.writer(sys.stdout)
 w.writerow(['kernel', 'calls_per_step', 'avg_us', 'min_us', 'max_us', 'us_per_step', 'pct_of_kernel_time'])
 for name, ps, avg, mn, mx, us in sorted(out, key=lambda t: -t[5]):
 	w.writerow([name[:120], f'{ps:.2f}', f'{avg:.1f}', f'{mn:.1f}', f'{mx:.1f}', f'{us:.1f}', f'{100 * us / total:.1f}'])
+for name, n, us in once:
+	w.writerow(['# not in the steady step (fewer than one launch per step)', name[:100], f'{n} launches', f'{us:.1f} us in total'])
 w.writerow(['# steady steps', steps, 'warm-up steps dropped', warmup, 'sum of kernel time per step (us)', f'{total:.1f}', f'wall span per step (us): {span / steps:.1f}'])
