@@ -7,16 +7,25 @@
 //
 // Design (HBM/VALU-bound, no MFMA): the K=100 fragment buffers PyTorch3D materialises (2.8 kB/pixel) never exist.
 //   1. project_kernel   : world -> (x_ndc, y_ndc, z_view) per (image, vertex)                       [coalesced stream]
-//   2. face_setup_kernel: per (image, face) cull + 48-B face record + tile-bbox packed in one uint32
-//   3. raster_tile_kernel: persistent workgroups take 16x16-pixel tiles from an atomic counter (covered tiles cost far more
-//      than empty ones).  The packed bboxes are scanned 256 faces at a time (4 B/face, L2-resident), hits are
-//      ballot-compacted IN FACE ORDER into LDS (deterministic), their records staged in LDS; each wave owns an 8x8-pixel
-//      quadrant and evaluates only the faces whose blurred bbox touches it; pixels keep the silhouette product and the
-//      nearest inside fragment in registers.  Silhouette candidates are also appended to a per-workgroup scratch so that a
-//      pixel with more than faces_per_pixel of them keeps exactly the K nearest in depth (lane-parallel bisection; the
-//      K-th depth is saved for the backward).  The tail shades the nearest fragment (Phong + blend), writes mask / image.
-//   4. backward: silhouette gradient is FACE-centric (one thread walks the blurred bbox of its face and accumulates the
-//      six NDC gradients in registers: no per-fragment atomics); projection backward is a deterministic sum over views.
+//   2. face_setup_kernel: per (image, face) cull + 48-B face record + the 8x8-pixel tiles its blurred bbox touches, packed in one
+//      uint32 + the nearest depth it can contribute; per image the depth range and the largest depth extent of a face
+//   3. bin_kernel       : one wave per 8x8-pixel tile builds the tile's face list (two-level scan of the packed bboxes: runs of 64
+//      consecutive faces first) and sorts it, stably, by DEPTH SLAB (255 slabs over the image's depth range, none thinner than the
+//      deepest face); lists go to a pool, tiles to queues by list length (crowded first); empty tiles get their background here
+//   4. raster_kernel    : persistent waves take tiles from the queues; a wave stages 64 face records at a time in LDS and every lane
+//      evaluates them for its own pixel -- no workgroup barrier anywhere.  Faces arrive front to back, so a pixel that already holds
+//      faces_per_pixel candidates in front of everything still to come is FINISHED, and the wave leaves the list when all its pixels
+//      are (an interior pixel of a closed surface never looks at the far side).  Candidates (depth, 1 - p) go to the lane's own
+//      contiguous run of a scratch through an LDS ring; a pixel with more than K of them selects the K nearest by a radix search on
+//      its own list (the K-th depth is saved for the backward).  The tail shades the nearest inside fragment, writes mask / image.
+//   5. tie_fix_kernel   : PyTorch3D keeps, among candidates of EQUAL depth at the K-th place, those of lower face index (insertion
+//      order).  Lists are in depth order, not face order, so pixels where candidates tied at the K-th depth were left out are
+//      queued and re-evaluated here with face ids at hand (a wave per pixel): exact K-buffer semantics, and the id of the last
+//      face kept goes to the backward.
+//   6. backward: silhouette gradient is FACE-centric (lanes walk the blurred bbox of their face and accumulate the six NDC gradients
+//      in registers: no per-fragment atomics); projection backward is a deterministic sum over views.
+// Every kernel evaluates a (pixel, face) pair with the SAME rounding (eval_frag is compiled without fp contraction, its fused
+// multiply-adds are written out): the depth a candidate had in the forward is the depth the fix-up and the backward recompute.
 // Conventions: SURVEY.md Appendix A.2-A.4 (row-vector transforms, NDC +x left / +y up, image = mesh*n_views + view).
 #include <type_traits>
 
@@ -26,34 +35,56 @@ namespace find {
 int g_raster_ablate = 0;
 namespace render {
 
-constexpr int TS_WG = 16;       // tile edge in pixels: one workgroup per tile, a quadrant per wave (raster_tile_kernel<4>) ...
-constexpr int TS_WAVE = 8;      // ... or one wave per tile (raster_tile_kernel<1>: find_debug_raster_ablate bit 128, measured slower)
+constexpr int T8 = 8;             // tile edge in pixels: one wave per tile
 constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
 constexpr int KU = 16;            // list entries in flight per lane in the K-nearest passes (they are L2-latency-bound)
 constexpr int KN_CAP = 4096;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1]); the pole of a 10 002-vertex lat-long scan @256^2 collects ~2000
 constexpr int RING = 8;           // candidates a lane collects in LDS before it writes them out: 2 x 32 contiguous bytes per flush
-constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 per CU: 95 VGPRs, 38 KB LDS); each owns 256 x KN_CAP x 8 B of scratch
+constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 independent waves each); each owns 256 x KN_CAP x 8 B of scratch
+constexpr int BIN_CAP = 2048;     // list entries a binning wave keeps (and sorts) in LDS; a longer list goes out in face order, without the early exit
+constexpr int N_SLABS = 255;      // depth slabs per image (8 bits of a list entry; the other 24 are the face index)
+constexpr int N_QUEUES = 24;      // tile queues by log2(list length), the longest lists first
+constexpr int CURSOR_STRIDE = 32;  // ints between two counters of the cursor array
+constexpr uint32_t LIST_UNSORTED = 1u << 30;
+constexpr uint32_t FACE_MASK = 0x00FFFFFFu;
 
+struct Fix {      // a pixel whose K-th depth is shared by more candidates than fit: resolved by tie_fix_kernel
+	int32_t pix;      // (img * H + y) * W + x
+	uint32_t zk;      // bits of the K-th depth
+	int32_t keep;     // how many of the candidates at that depth belong to the K nearest
+	float a_lt;       // product of (1 - p) over the candidates in front of it
+};
+
+struct FaceRec;
 struct Ws {
 	float* vproj;     // (n_img, V, 3)
-	float4* frec;     // (n_img, F, 3) float4: [x0 y0 x1 y1][x2 y2 z0 z1][z2 - - -]
-	uint32_t* tb;     // (n_img, F) packed tile bbox
-	uint32_t* tbb;    // (n_img, ceil(F / 64)) packed tile bbox of every run of 64 consecutive faces
+	float4* frec;     // (n_img, F, 3) float4: [x0 y0 x1 y1][x2 y2 z0 z1][z2 - - -]   (backward kernels)
+	struct FaceRec* recs;  // (n_img, F) the same face with everything the fragment math needs per face (80 B), read wave-uniformly by the rasteriser
+	uint32_t* rz;     // (n_img, ceil(F / 64), 4) per run of 64 faces: bits of the smallest / largest fzmin, of the largest depth extent
+	uint32_t* tb;     // (n_img, F) packed bbox in 8-pixel tiles: x0 | x1 << 8 | y0 << 16 | y1 << 24 (TB_EMPTY: culled)
+	uint32_t* tbb;    // (n_img, ceil(F / 64)) the same for every run of 64 consecutive faces
+	float* fzmin;     // (n_img, F) nearest depth a face can contribute (min vertex depth, not below 0)
+	int32_t* zinfo;   // (n_img, 8): [0] bits of the smallest fzmin, [1] of the largest, [2] of the largest depth extent of a face, [4..7] tile bbox of all faces
 	float* normals;   // (n_meshes, V, 3) area-weighted vertex normals (world)
 	int32_t* p2f;     // (n_img, H, W) nearest inside face (local id) or -1   [saved for backward]
 	float* bary;      // (n_img, H, W, 3) its perspective-correct barycentrics
+	float* frag;      // (n_img, H, W, 8) [w0 w1 w2 z | d - - -] of that fragment, between the rasteriser and shade_kernel
 	float* d_vproj;   // (n_img, V, 3) backward accumulator
 	float* d_normals; // (n_meshes, V, 3) backward accumulator
 	float* raw_normals; // (n_meshes, V, 3) un-normalised vertex-normal sums (backward)
-	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tile counter
-	float* zthr;      // (n_img, H, W) depth of the K-th nearest silhouette candidate (+inf: every candidate counts)  [backward]
+	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tiles taken from the queues, [6] pool cursor, [7] fix-up entries, [8..] diagnostics
+	int32_t* qn;      // [0..N_QUEUES) tiles per list-length class, [32..32+N_QUEUES) fill cursors of the classes, [62] tiles with a list
+	int32_t* cursor;  // (n_img) entries handed out of each image's part of the pool
+	float* zthr;      // (n_img, H, W) depth bound of the K nearest silhouette candidates (+inf: every candidate counts; negative: -depth, ties at it resolved by tie_face)  [backward]
 	float* alpha;     // (n_img, H, W) prod (1 - p_k) over the blended candidates  [backward: 1 - mask has lost it wherever the mask rounds to 1]
+	int32_t* tie_face; // (n_img, H, W) last face kept among those tied at the K-th depth (valid where zthr < 0)  [backward]
 	float2* scratch;  // (raster workgroups, 2, 256, KN_CAP) per-pixel candidate lists of the tile in flight: depths, then 1 - p; one contiguous run per pixel
-	int32_t* tile_any; // (n_img, tiles) 1 = some face's blurred bbox touches the tile
-	int32_t* tile_cnt; // (n_img, tiles) estimate of how many do (sampled)
-	int32_t* tile_order; // (n_img * tiles) tile ids, the tiles with the most faces first
-	int64_t raster_wgs;
+	int2* tinfo;      // (n_img, tiles) list of a tile: x = offset into pool, y = length | LIST_UNSORTED, or -1: no room in the pool (the rasteriser scans the faces itself)
+	uint32_t* pool;   // list entries: slab << 24 | face
+	int32_t* order;   // (n_img * tiles) ids of the tiles that have a list, the longest lists first
+	Fix* fix;         // (n_img * H * W) fix-up queue
+	int64_t pool_cap, n_tiles, raster_wgs;
 	int64_t bytes;
 };
 
@@ -62,24 +93,39 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	const int64_t n_img = n_meshes * n_views;
 	const int64_t px = n_img * rp->image_h * rp->image_w;
 	o->flags = c.take<int32_t>(64);
+	o->qn = c.take<int32_t>(64);
+	// per image: entries handed out of its part of the pool, tiles of its bbox handed out -- one counter per 128-byte line (atomics on
+	// one line are served one after the other, ~50 ns each: 64 counters packed into two lines were the slowest thing in the binning kernel)
+	o->cursor = c.take<int32_t>(2 * n_img * CURSOR_STRIDE);
 	o->vproj = c.take<float>(n_img * V * 3);
 	o->frec = c.take<float4>(n_img * F * 3);
+	o->recs = reinterpret_cast<FaceRec*>(c.take<float4>(n_img * F * 5));
+	o->rz = c.take<uint32_t>(n_img * cdiv(F, 64) * 4);
 	o->tb = c.take<uint32_t>(n_img * F);
 	o->tbb = c.take<uint32_t>(n_img * cdiv(F, 64));
+	o->fzmin = c.take<float>(n_img * F);
+	o->zinfo = c.take<int32_t>(n_img * 8);
 	o->normals = c.take<float>(n_meshes * V * 3);
 	o->p2f = c.take<int32_t>(px);
 	o->bary = c.take<float>(px * 3);
+	o->frag = c.take<float>(px * 8);
 	o->d_vproj = c.take<float>(n_img * V * 3);
 	o->d_normals = c.take<float>(n_meshes * V * 3);
 	o->raw_normals = c.take<float>(n_meshes * V * 3);
 	o->zthr = c.take<float>(px);
 	o->alpha = c.take<float>(px);
-	const int64_t tiles = n_img * cdiv(rp->image_w, TS_WAVE) * cdiv(rp->image_h, TS_WAVE);   // (the finer of the two tilings)
-	o->raster_wgs = std::min<int64_t>(tiles, RASTER_WGS);
+	o->tie_face = c.take<int32_t>(px);
+	o->n_tiles = n_img * cdiv(rp->image_w, T8) * cdiv(rp->image_h, T8);
+	o->raster_wgs = std::min<int64_t>(cdiv(o->n_tiles, 4), RASTER_WGS);
 	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
-	o->tile_any = c.take<int32_t>(2 * tiles);
-	o->tile_cnt = o->tile_any + tiles;
-	o->tile_order = c.take<int32_t>(tiles);
+	o->tinfo = c.take<int2>(o->n_tiles);
+	// a face of ~1 pixel with the silhouette's blur margin touches ~4.5 tiles at 256^2 and ~10 at 512^2; a tile that finds the pool
+	// full is rasterised from the face arrays directly (slower, never wrong)
+	// (every image has its own part of the pool and its own cursor: one cursor for all was the hottest address of the launch)
+	o->pool_cap = std::min<int64_t>(F * 16 + (1 << 14), ((int64_t)1 << 30) / n_img);
+	o->pool = c.take<uint32_t>(o->pool_cap * n_img);
+	o->order = c.take<int32_t>(o->n_tiles);
+	o->fix = c.take<Fix>(px);
 	o->bytes = c.off;
 }
 
@@ -130,8 +176,12 @@ __global__ void project_bwd_kernel(const float* __restrict__ verts, const float*
 }
 
 // ------------------------------------------------------------------------------------------------ 2. face setup
+// (pixel, face) arithmetic below is compiled WITHOUT floating-point contraction and its fused multiply-adds are explicit: the
+// compiler may otherwise fuse the same expression differently in the rasteriser, the tie fix-up and the backward, and a candidate's
+// depth is compared bit for bit between them.
 __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
-	return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+#pragma clang fp contract(off)
+	return __builtin_fmaf(px - ax, by - ay, -((py - ay) * (bx - ax)));
 }
 
 // pixel index range [lo, hi] whose centres 1-(2i+1)/S may fall in NDC [cmin, cmax] (one pixel of slack; exact test per pixel)
@@ -142,85 +192,37 @@ __device__ __forceinline__ void pix_range(float cmin, float cmax, int S, int* lo
 	*hi = min((int)ceilf(b) + 1, S - 1);
 }
 
-__global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
-								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
-								  float4* __restrict__ frec, uint32_t* __restrict__ tb, uint32_t* __restrict__ tbb, int32_t* __restrict__ flags,
-								  int32_t* __restrict__ tile_any, int32_t* __restrict__ tile_cnt, int tiles_x, int tiles_per_img, int TS) {
-	const int img = blockIdx.y;
-	const int f = blockIdx.x * blockDim.x + threadIdx.x;
-	const int mesh = img / n_views;
-	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)min(f, F - 1) * 3;
-	uint32_t packed = TB_EMPTY;
-	const int64_t o = (int64_t)img * F + f;
-	if (f < F && fp[0] >= 0) {
-		const float* vp = vproj + (int64_t)img * V * 3;
-		const float x0 = vp[3 * fp[0]], y0 = vp[3 * fp[0] + 1], z0 = vp[3 * fp[0] + 2];
-		const float x1 = vp[3 * fp[1]], y1 = vp[3 * fp[1] + 1], z1 = vp[3 * fp[1] + 2];
-		const float x2 = vp[3 * fp[2]], y2 = vp[3 * fp[2] + 1], z2 = vp[3 * fp[2] + 2];
-		frec[o * 3 + 0] = make_float4(x0, y0, x1, y1);
-		frec[o * 3 + 1] = make_float4(x2, y2, z0, z1);
-		frec[o * 3 + 2] = make_float4(z2, 0.f, 0.f, 0.f);
-		const bool all_behind = z0 < z_clip && z1 < z_clip && z2 < z_clip;
-		const bool any_behind = z0 < z_clip || z1 < z_clip || z2 < z_clip;
-		if (any_behind && !all_behind) atomicAdd(&flags[0], 1);  // straddling the clip plane: PyTorch3D would clip it (clip.py)
-		const float zmax = fmaxf(z0, fmaxf(z1, z2));
-		const float area = edge_fn(x0, y0, x1, y1, x2, y2);
-		const bool degenerate = area <= KEPS && area >= -KEPS;
-		if (!all_behind && !(zmax < 0.f) && !degenerate) {
-			const float br = sqrtf(blur_radius);
-			int xlo, xhi, ylo, yhi;
-			pix_range(fminf(x0, fminf(x1, x2)) - br, fmaxf(x0, fmaxf(x1, x2)) + br, W, &xlo, &xhi);
-			pix_range(fminf(y0, fminf(y1, y2)) - br, fmaxf(y0, fmaxf(y1, y2)) + br, H, &ylo, &yhi);
-			if (xlo <= xhi && ylo <= yhi) {
-				packed = (uint32_t)(xlo / TS) | ((uint32_t)(xhi / TS) << 8) | ((uint32_t)(ylo / TS) << 16) | ((uint32_t)(yhi / TS) << 24);
-				// count the faces of every tile this face can touch: the rasteriser skips the scan of a tile with none (most of an image)
-				// and takes the crowded tiles first (tile_order_kernel)
-				for (int ty = ylo / TS; ty <= yhi / TS; ++ty)
-					for (int tx = xlo / TS; tx <= xhi / TS; ++tx) {
-						const int64_t ti = (int64_t)img * tiles_per_img + ty * tiles_x + tx;
-						if (tile_any[ti] == 0) tile_any[ti] = 1;  // benign race: every writer stores 1
-						// how MANY faces touch the tile is estimated from every 16th face (a cost estimate for the tile order: an atomic
-						// per face and tile serialises on the crowded tiles and made this kernel 20x slower)
-						if ((f & 15) == 0) atomicAdd(tile_cnt + ti, 16);
-					}
-			}
-		}
-	}
-	if (f < F) tb[o] = packed;
-	// the tile bbox of the wave's 64 consecutive faces: the rasteriser tests these first and only opens the runs that reach its tile
-	// (faces that are neighbours in the index are neighbours on the surface in any mesh that was not shuffled on purpose)
-	int bx0 = packed & 255, bx1 = (packed >> 8) & 255, by0 = (packed >> 16) & 255, by1 = packed >> 24;
-	if (packed == TB_EMPTY) { bx0 = 255; bx1 = 0; by0 = 255; by1 = 0; }
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		bx0 = min(bx0, __shfl_xor(bx0, d, 64)); bx1 = max(bx1, __shfl_xor(bx1, d, 64));
-		by0 = min(by0, __shfl_xor(by0, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
-	}
-	if ((threadIdx.x & 63) == 0 && f < F)
-		tbb[(int64_t)img * ((F + 63) / 64) + f / 64] = bx0 > bx1 ? TB_EMPTY : ((uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24));
+// the same range without the pixel of slack (a hundredth of a pixel instead: far above the rounding of the two expressions): which
+// tiles a face is listed in
+__device__ __forceinline__ void pix_range_tight(float cmin, float cmax, int S, int* lo, int* hi) {
+	const float a = ((1.0f - cmax) * S - 1.0f) * 0.5f;
+	const float b = ((1.0f - cmin) * S - 1.0f) * 0.5f;
+	*lo = max((int)ceilf(a - 0.01f), 0);
+	*hi = min((int)floorf(b + 0.01f), S - 1);
 }
 
 
 // ------------------------------------------------------------------------------------------------ shared fragment math
-struct FaceRec {  // staged in LDS, one per candidate (80 bytes)
-	float x0, y0, x1, y1, x2, y2, z0, z1, z2;
-	float xmin, xmax, ymin, ymax;  // blurred NDC bbox
-	float inv_area;
-	float il01, il02, il12;        // 1 / |edge|^2 (0 for a degenerate edge: the projection parameter is then 1, as PyTorch3D)
-	int f;
-	int pad[2];
+struct FaceRec {  // 80 bytes = five 16-byte pieces; written once per (image, face) by face_setup_kernel
+	float x0, y0, x1, y1;
+	float x2, y2, z0, z1;
+	float z2, inv_area, il01, il02;   // il: 1 / |edge|^2 (0 for a degenerate edge: the projection parameter is then 1, as PyTorch3D)
+	float il12; int f; int pad[2];
+	float xmin, xmax, ymin, ymax;     // blurred NDC bbox
 };
+static_assert(sizeof(FaceRec) == 80, "FaceRec is read as 20 dwords");
 
 __device__ __forceinline__ float edge_inv_len2(float ax, float ay, float bx, float by) {
+#pragma clang fp contract(off)
 	const float dx = bx - ax, dy = by - ay;
-	const float l2 = dx * dx + dy * dy;
+	const float l2 = __builtin_fmaf(dx, dx, dy * dy);
 	return l2 > KEPS ? 1.0f / l2 : 0.0f;
 }
 
 // Everything that is per face (not per pixel) is computed here, once: the per-pixel fragment math below then has no IEEE
 // division left (a v_rcp_f32 for the two normalisations).
-__device__ __forceinline__ void make_rec(const float4* fr, int f, float br, FaceRec* r) {
-	const float4 a = fr[0], b = fr[1], c = fr[2];
+__device__ __forceinline__ void make_rec(const float4 a, const float4 b, const float4 c, int f, float br, FaceRec* r) {
+#pragma clang fp contract(off)
 	r->x0 = a.x; r->y0 = a.y; r->x1 = a.z; r->y1 = a.w; r->x2 = b.x; r->y2 = b.y; r->z0 = b.z; r->z1 = b.w; r->z2 = c.x;
 	r->xmin = fminf(a.x, fminf(a.z, b.x)) - br; r->xmax = fmaxf(a.x, fmaxf(a.z, b.x)) + br;
 	r->ymin = fminf(a.y, fminf(a.w, b.y)) - br; r->ymax = fmaxf(a.y, fmaxf(a.w, b.y)) + br;
@@ -231,15 +233,22 @@ __device__ __forceinline__ void make_rec(const float4* fr, int f, float br, Face
 	r->f = f;
 	r->pad[0] = r->pad[1] = 0;
 }
+__device__ __forceinline__ void make_rec(const float4* fr, int f, float br, FaceRec* r) { make_rec(fr[0], fr[1], fr[2], f, br, r); }
+__device__ __forceinline__ void store_rec(FaceRec* dst, const FaceRec& r) {
+	float4* d = reinterpret_cast<float4*>(dst);
+	d[0] = make_float4(r.x0, r.y0, r.x1, r.y1); d[1] = make_float4(r.x2, r.y2, r.z0, r.z1); d[2] = make_float4(r.z2, r.inv_area, r.il01, r.il02);
+	d[3] = make_float4(r.il12, __int_as_float(r.f), 0.f, 0.f); d[4] = make_float4(r.xmin, r.xmax, r.ymin, r.ymax);
+}
 
 // squared distance to segment ab; also returns the clamped parameter (PointLineDistanceForward); il = 1/|ab|^2 or 0
 __device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float il, float* t_out) {
+#pragma clang fp contract(off)
 	const float bax = bx - ax, bay = by - ay;
 	float t = 1.0f;
-	if (il > 0.f) t = fminf(fmaxf((bax * (px - ax) + bay * (py - ay)) * il, 0.f), 1.f);
-	const float qx = ax + t * bax - px, qy = ay + t * bay - py;
+	if (il > 0.f) t = fminf(fmaxf(__builtin_fmaf(bax, px - ax, bay * (py - ay)) * il, 0.f), 1.f);
+	const float qx = __builtin_fmaf(t, bax, ax) - px, qy = __builtin_fmaf(t, bay, ay) - py;
 	*t_out = t;
-	return qx * qx + qy * qy;
+	return __builtin_fmaf(qx, qx, qy * qy);
 }
 
 struct Frag {
@@ -254,8 +263,15 @@ struct Frag {
 
 // geometry_utils: barycentric, perspective correction, clip, depth, point-triangle distance.  Returns false when the
 // pixel is outside the blurred bbox.
+__device__ __forceinline__ void eval_core(const FaceRec& r, float px, float py, Frag* o);
 __device__ __forceinline__ bool eval_frag(const FaceRec& r, float px, float py, Frag* o) {
 	if (px > r.xmax || px < r.xmin || py > r.ymax || py < r.ymin) return false;
+	eval_core(r, px, py, o);
+	return true;
+}
+// the same for a pixel already known to lie inside the blurred bbox (the rasteriser tests 64 pixels against it first)
+__device__ __forceinline__ void eval_core(const FaceRec& r, float px, float py, Frag* o) {
+#pragma clang fp contract(off)
 	float w0 = edge_fn(px, py, r.x1, r.y1, r.x2, r.y2) * r.inv_area;
 	float w1 = edge_fn(px, py, r.x2, r.y2, r.x0, r.y0) * r.inv_area;
 	float w2 = edge_fn(px, py, r.x0, r.y0, r.x1, r.y1) * r.inv_area;
@@ -267,8 +283,8 @@ __device__ __forceinline__ bool eval_frag(const FaceRec& r, float px, float py, 
 	float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
 	const float isum = __builtin_amdgcn_rcpf(fmaxf(c0 + c1 + c2, 1e-5f));
 	c0 *= isum; c1 *= isum; c2 *= isum;
-	o->pz_clip = c0 * r.z0 + c1 * r.z1 + c2 * r.z2;
-	o->pz = w0 * r.z0 + w1 * r.z1 + w2 * r.z2;
+	o->pz_clip = __builtin_fmaf(c2, r.z2, __builtin_fmaf(c1, r.z1, c0 * r.z0));
+	o->pz = __builtin_fmaf(w2, r.z2, __builtin_fmaf(w1, r.z1, w0 * r.z0));
 	float ta, tb, tc;
 	const float e01 = seg_dist(px, py, r.x0, r.y0, r.x1, r.y1, r.il01, &ta);
 	const float e02 = seg_dist(px, py, r.x0, r.y0, r.x2, r.y2, r.il02, &tb);
@@ -276,12 +292,110 @@ __device__ __forceinline__ bool eval_frag(const FaceRec& r, float px, float py, 
 	if (e01 <= e02 && e01 <= e12) { o->dist = e01; o->edge = 0; o->t = ta; }
 	else if (e02 <= e01 && e02 <= e12) { o->dist = e02; o->edge = 1; o->t = tb; }
 	else { o->dist = e12; o->edge = 2; o->t = tc; }
-	return true;
 }
+
+__device__ __forceinline__ float silhouette_prob(float signed_dist, float inv_sigma) { return 1.0f / (1.0f + __expf(signed_dist * inv_sigma)); }
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 	const float l = fmaxf(sqrtf(x * x + y * y + z * z), 1e-6f);
 	x /= l; y /= l; z /= l;
+}
+
+// per (image, face): cull, the records (backward: 48 B; forward: the full 80 B), the tiles its blurred bbox touches, its nearest depth;
+// per run of 64 faces: their common tile bbox and depth statistics (zinfo_kernel folds those into the image's)
+__global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
+								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
+								  float4* __restrict__ frec, FaceRec* __restrict__ recs, uint32_t* __restrict__ tb, uint32_t* __restrict__ tbb,
+								  float* __restrict__ fzmin, uint32_t* __restrict__ rz, int32_t* __restrict__ flags) {
+	const int img = blockIdx.y;
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	const int mesh = img / n_views;
+	const int32_t* fp = faces + (int64_t)mesh * faces_mesh_stride + (int64_t)min(f, F - 1) * 3;
+	uint32_t packed = TB_EMPTY;
+	const int64_t o = (int64_t)img * F + f;
+	float zmn = 0.f, zext = 0.f;
+	if (f < F && fp[0] >= 0) {
+		const float* vp = vproj + (int64_t)img * V * 3;
+		const float x0 = vp[3 * fp[0]], y0 = vp[3 * fp[0] + 1], z0 = vp[3 * fp[0] + 2];
+		const float x1 = vp[3 * fp[1]], y1 = vp[3 * fp[1] + 1], z1 = vp[3 * fp[1] + 2];
+		const float x2 = vp[3 * fp[2]], y2 = vp[3 * fp[2] + 1], z2 = vp[3 * fp[2] + 2];
+		const float4 ra = make_float4(x0, y0, x1, y1), rb = make_float4(x2, y2, z0, z1), rc = make_float4(z2, 0.f, 0.f, 0.f);
+		frec[o * 3 + 0] = ra; frec[o * 3 + 1] = rb; frec[o * 3 + 2] = rc;
+		const float br = sqrtf(blur_radius);
+		FaceRec r;
+		make_rec(ra, rb, rc, f, br, &r);
+		store_rec(recs + o, r);
+		const bool all_behind = z0 < z_clip && z1 < z_clip && z2 < z_clip;
+		const bool any_behind = z0 < z_clip || z1 < z_clip || z2 < z_clip;
+		if (any_behind && !all_behind) atomicAdd(&flags[0], 1);  // straddling the clip plane: PyTorch3D would clip it (clip.py)
+		const float zmax = fmaxf(z0, fmaxf(z1, z2));
+		const float area = edge_fn(x0, y0, x1, y1, x2, y2);
+		const bool degenerate = area <= KEPS && area >= -KEPS;
+		if (!all_behind && !(zmax < 0.f) && !degenerate) {
+			int xlo, xhi, ylo, yhi;
+			pix_range_tight(r.xmin, r.xmax, W, &xlo, &xhi);
+			pix_range_tight(r.ymin, r.ymax, H, &ylo, &yhi);
+			if (xlo <= xhi && ylo <= yhi) {
+				packed = (uint32_t)(xlo / T8) | ((uint32_t)(xhi / T8) << 8) | ((uint32_t)(ylo / T8) << 16) | ((uint32_t)(yhi / T8) << 24);
+				// a fragment's depth is a convex mix of the three vertex depths (clipped or inside barycentrics) and is dropped below 0
+				zmn = fmaxf(fminf(z0, fminf(z1, z2)), 0.f);
+				zext = zmax - zmn;
+			}
+		}
+	}
+	if (f < F) { tb[o] = packed; fzmin[o] = zmn; }
+	// per wave: the tile bbox of its 64 consecutive faces (the binning waves test these first and only open the runs that reach their
+	// tile: faces that are neighbours in the index are neighbours on the surface in any mesh that was not shuffled on purpose), and
+	// their depth statistics
+	const bool live = packed != TB_EMPTY;
+	int bx0 = packed & 255, bx1 = (packed >> 8) & 255, by0 = (packed >> 16) & 255, by1 = packed >> 24;
+	if (!live) { bx0 = 255; bx1 = 0; by0 = 255; by1 = 0; }
+	uint32_t zlo = live ? __float_as_uint(zmn) : 0xFFFFFFFFu, zhi = live ? __float_as_uint(zmn) : 0u, zex = live ? __float_as_uint(zext) : 0u;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		bx0 = min(bx0, __shfl_xor(bx0, d, 64)); bx1 = max(bx1, __shfl_xor(bx1, d, 64));
+		by0 = min(by0, __shfl_xor(by0, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+		zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, d, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, d, 64));
+		zex = max(zex, (uint32_t)__shfl_xor((int)zex, d, 64));
+	}
+	if ((threadIdx.x & 63) == 0 && f < F) {
+		const int64_t ro = (int64_t)img * ((F + 63) / 64) + f / 64;
+		tbb[ro] = bx0 > bx1 ? TB_EMPTY : ((uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24));
+		rz[ro * 4] = zlo; rz[ro * 4 + 1] = zhi; rz[ro * 4 + 2] = zex; rz[ro * 4 + 3] = 0u;
+	}
+}
+
+// one workgroup per image: depth range of its faces, their largest depth extent, the tile bbox of all of them
+__global__ __launch_bounds__(256) void zinfo_kernel(const uint32_t* __restrict__ tbb, const uint32_t* __restrict__ rz, int n_runs, int32_t* __restrict__ zinfo) {
+	__shared__ uint32_t red[4][8];
+	const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t zlo = 0xFFFFFFFFu, zhi = 0u, zex = 0u;
+	int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;
+	for (int r = threadIdx.x; r < n_runs; r += 256) {
+		const int64_t ro = (int64_t)img * n_runs + r;
+		const uint32_t t = tbb[ro];
+		if (t == TB_EMPTY) continue;
+		zlo = min(zlo, rz[ro * 4]); zhi = max(zhi, rz[ro * 4 + 1]); zex = max(zex, rz[ro * 4 + 2]);
+		bx0 = min(bx0, (int)(t & 255)); bx1 = max(bx1, (int)((t >> 8) & 255)); by0 = min(by0, (int)((t >> 16) & 255)); by1 = max(by1, (int)(t >> 24));
+	}
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		zlo = min(zlo, (uint32_t)__shfl_xor((int)zlo, d, 64)); zhi = max(zhi, (uint32_t)__shfl_xor((int)zhi, d, 64)); zex = max(zex, (uint32_t)__shfl_xor((int)zex, d, 64));
+		bx0 = min(bx0, __shfl_xor(bx0, d, 64)); bx1 = max(bx1, __shfl_xor(bx1, d, 64)); by0 = min(by0, __shfl_xor(by0, d, 64)); by1 = max(by1, __shfl_xor(by1, d, 64));
+	}
+	if (lane == 0) { red[wave][0] = zlo; red[wave][1] = zhi; red[wave][2] = zex; red[wave][4] = (uint32_t)bx0; red[wave][5] = (uint32_t)bx1; red[wave][6] = (uint32_t)by0; red[wave][7] = (uint32_t)by1; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int32_t* z = zinfo + img * 8;
+		z[0] = (int32_t)min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+		z[1] = (int32_t)max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+		z[2] = (int32_t)max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+		z[3] = 0;
+		z[4] = min(min((int)red[0][4], (int)red[1][4]), min((int)red[2][4], (int)red[3][4]));
+		z[5] = max(max((int)red[0][5], (int)red[1][5]), max((int)red[2][5], (int)red[3][5]));
+		z[6] = min(min((int)red[0][6], (int)red[1][6]), min((int)red[2][6], (int)red[3][6]));
+		z[7] = max(max((int)red[0][7], (int)red[1][7]), max((int)red[2][7], (int)red[3][7]));
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ vertex normals
@@ -311,41 +425,13 @@ __global__ void normals_normalize_kernel(float* __restrict__ normals, int64_t n)
 	normals[i * 3] = x; normals[i * 3 + 1] = y; normals[i * 3 + 2] = z;
 }
 
-// ------------------------------------------------------------------------------------------------ tile order
-// The persistent rasteriser takes tiles from a queue, and a tile's cost grows with the faces that touch it (a pole of the mesh:
-// > 1000 candidates per pixel; most of an image: none).  Taken in image order, the expensive tiles of the last images arrive when
-// nothing is left to overlap them with -- the average wave was alive for 63 % of the kernel (SQ_WAVE_CYCLES / waves / duration).
-// Longest-processing-time-first: bucket the tiles by log2(face count), crowded buckets first.  One workgroup, counting sort.
-constexpr int ORDER_BUCKETS = 24;
-__global__ __launch_bounds__(1024) void tile_order_kernel(const int32_t* __restrict__ tile_any, const int32_t* __restrict__ tile_cnt, int total,
-														   int32_t* __restrict__ order) {
-	__shared__ int hist[ORDER_BUCKETS];
-	__shared__ int start[ORDER_BUCKETS];
-	const int tid = threadIdx.x;
-	if (tid < ORDER_BUCKETS) hist[tid] = 0;
-	__syncthreads();
-	// crowded -> small index; touched tiles whose faces all escaped the sample sit just in front of the empty ones
-	auto bucket = [&](int t) {
-		if (tile_any[t] == 0) return ORDER_BUCKETS - 1;
-		const int c = tile_cnt[t];
-		return c <= 0 ? ORDER_BUCKETS - 2 : max(0, ORDER_BUCKETS - 3 - (31 - __builtin_clz(c)));
-	};
-	for (int t = tid; t < total; t += 1024) atomicAdd(&hist[bucket(t)], 1);
-	__syncthreads();
-	if (tid == 0) {
-		int acc = 0;
-		for (int b = 0; b < ORDER_BUCKETS; ++b) { start[b] = acc; acc += hist[b]; }
-	}
-	__syncthreads();
-	for (int t = tid; t < total; t += 1024) order[atomicAdd(&start[bucket(t)], 1)] = t;  // order inside a bucket does not matter
-}
-
-// ------------------------------------------------------------------------------------------------ 3. tile rasteriser
+// ------------------------------------------------------------------------------------------------ 3. binning
 struct TileArgs {
 	find_render_params rp;
-	const float4* frec;
 	const uint32_t* tb;
 	const uint32_t* tbb;     // per run of 64 faces
+	const float* fzmin;
+	const int32_t* zinfo;
 	const int32_t* faces;
 	int64_t faces_mesh_stride;
 	const float* verts;      // world (n_meshes,V,3)
@@ -359,75 +445,321 @@ struct TileArgs {
 	float* zbuf_out;         // or null
 	int32_t* p2f_ws;         // local ids for backward
 	float* bary_ws;
+	float* frag_ws;          // (n_img,H,W,8) nearest inside fragment: barycentrics, depth, signed distance (rasteriser -> shade_kernel)
 	int32_t* flags;
+	int32_t* qn;
+	int32_t* cursor;
+	float* zthr;
+	float* alpha_ws;
+	int32_t* tie_face;
+	float2* scratch;
+	int2* tinfo;
+	uint32_t* pool;
+	int32_t* order;
+	Fix* fix;
+	int64_t pool_cap;
+	int tiles_per_img, total_tiles;
+	int ablate;              // profiling only (find_debug_raster_ablate): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 8 no early exit, 64 counters
+};
+
+__device__ __forceinline__ bool tile_hit(uint32_t t, int tile_x, int tile_y) {
+	const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
+	return tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;  // (TB_EMPTY: tx0 = 255 > tx1 = 0)
+}
+
+// depth slabs of an image: lower edge of the first slab and the slab width.  No slab is thinner than the deepest face plus a margin far
+// above the rounding of a fragment's depth: a fragment of a face whose nearest depth lies in slab s lies in front of slab s + 2.
+__device__ __forceinline__ void slab_layout(const int32_t* zi, float* zlo, float* w) {
+	const float lo = __uint_as_float((uint32_t)zi[0]), hi = __uint_as_float((uint32_t)zi[1]), ext = __uint_as_float((uint32_t)zi[2]);
+	*zlo = lo;
+	*w = fmaxf((hi - lo) * (1.0f / (N_SLABS - 1)), ext + 1e-4f * hi + 1e-12f);
+}
+__device__ __forceinline__ int slab_of(float zmin, float zlo, float inv_w) { return min(N_SLABS - 1, max(0, (int)((zmin - zlo) * inv_w))); }
+// every face of slab s (and later) has its fragments behind this depth; a little short of the slab's lower edge, for the rounding of both sides
+__device__ __forceinline__ float slab_front(int s, float zlo, float w) { return (zlo + (float)s * w) * (1.0f - 2e-6f); }
+
+// One wave: its LDS operations execute in order, so all a "barrier" has to do is keep the compiler from moving LDS accesses across it and
+// wait for the LDS counter.  (NOT an acquire / release fence: those also wait for the wave's outstanding GLOBAL stores -- the list
+// entries on their way to the pool, the candidate pieces on their way to the scratch -- microseconds each, twice per 64 faces.)
+__device__ __forceinline__ void wave_lds_sync() {
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// One wave per 8x8-pixel tile, four independent waves per workgroup (no barrier).  The wave scans the packed bboxes on two levels --
+// the runs of 64 consecutive faces, then the faces of the runs that reach its tile, four runs' loads in flight together: the scan is
+// bound by the latency of these loads, not by their 4 B per face -- and appends the hits, in face order, to its list in LDS; sorts the
+// list by depth slab on its way to the pool (a stable counting sort: faces keep their index order inside a slab, so the list -- and with
+// it every sum the rasteriser forms -- is the same in every run); and queues the tile by the length of its list.  A tile no face reaches gets its background right here.
+__device__ __forceinline__ void write_background(const TileArgs& a, int img, int tile_x, int tile_y, int lane) {
+	const int H = a.rp.image_h, W = a.rp.image_w;
+	const int xi = tile_x * T8 + (lane & 7), yi = tile_y * T8 + (lane >> 3);
+	if (xi < W && yi < H) {
+		const int64_t pix = ((int64_t)img * H + yi) * W + xi;
+		if (a.mask) { a.mask[pix] = 0.0f; a.zthr[pix] = INFINITY; a.alpha_ws[pix] = 1.0f; }
+		if (a.p2f_ws) a.p2f_ws[pix] = -1;
+		if (a.p2f_out) a.p2f_out[pix] = -1;
+		if (a.zbuf_out) a.zbuf_out[pix] = -1.0f;
+		if (a.image) { float* o = a.image + pix * 3; o[0] = a.rp.background[0]; o[1] = a.rp.background[1]; o[2] = a.rp.background[2]; }
+	}
+}
+
+__device__ __forceinline__ void bin_tile(const TileArgs& a, uint32_t* src, int* hist, int* runs, int img, int t, int tile_x, int tile_y, int lane,
+										  unsigned long long lt, int F, int n_runs) {
+	const int32_t* zi = a.zinfo + img * 8;
+	const int t_id = img * a.tiles_per_img + t;
+	int n = 0;
+	float zlo = 0.f, w = 1.f;
+	slab_layout(zi, &zlo, &w);
+	const float inv_w = 1.0f / w;
+	const uint32_t* tbbp = a.tbb + (int64_t)img * n_runs;
+	const uint32_t* tbp = a.tb + (int64_t)img * F;
+	const float* fzp = a.fzmin + (int64_t)img * F;
+	// scan: fn(entry, position) for every face whose tile bbox holds this tile, in face order; returns the count.  Two levels, both with
+	// their loads in flight together (the scan is a chain of memory latencies, not of bytes): the bboxes of 256 runs of 64 faces, four
+	// per lane; then the faces of the runs that reach the tile, eight runs per turn.
+	auto scan = [&](auto&& fn) __attribute__((always_inline)) {
+		int cnt = 0;
+		for (int rb0 = 0; rb0 < n_runs; rb0 += 256) {
+			uint32_t t4[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) { const int r = rb0 + u * 64 + lane; t4[u] = r < n_runs ? tbbp[r] : TB_EMPTY; }
+			int nr = 0;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const bool h = tile_hit(t4[u], tile_x, tile_y);
+				const unsigned long long hm = __ballot(h);
+				if (h) runs[nr + (int)__popcll(hm & lt)] = rb0 + u * 64 + lane;
+				nr += (int)__popcll(hm);
+			}
+			wave_lds_sync();
+			for (int j0 = 0; j0 < nr; j0 += 8) {
+				uint32_t tv[8]; float zv[8]; int fi[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					fi[u] = j0 + u < nr ? runs[j0 + u] * 64 + lane : -1;
+					const bool ok = fi[u] >= 0 && fi[u] < F;
+					tv[u] = ok ? tbp[fi[u]] : TB_EMPTY; zv[u] = ok ? fzp[fi[u]] : 0.f;
+				}
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					if (j0 + u >= nr) break;   // uniform
+					const bool h = tile_hit(tv[u], tile_x, tile_y);
+					const unsigned long long hm = __ballot(h);
+					if (h) fn((uint32_t)fi[u] | ((uint32_t)slab_of(zv[u], zlo, inv_w) << 24), cnt + (int)__popcll(hm & lt));
+					cnt += (int)__popcll(hm);
+				}
+			}
+			wave_lds_sync();
+		}
+		return cnt;
+	};
+	if (!(a.ablate & 32)) n = scan([&](uint32_t e, int pos) { if (pos < BIN_CAP) src[pos] = e; });
+	if (n == 0) {
+		// nothing can touch this tile: its outputs are the background
+		if (lane == 0) a.tinfo[t_id] = make_int2(0, 0);
+		write_background(a, img, tile_x, tile_y, lane);
+		return;
+	}
+	int off = 0;
+	if (lane == 0) off = atomicAdd(&a.cursor[img * CURSOR_STRIDE], n);
+	off = __shfl(off, 0, 64);
+	const bool room = (int64_t)off + n <= a.pool_cap && off >= 0;
+	uint32_t* const pool = a.pool + (int64_t)img * a.pool_cap;
+	uint32_t mode = 0;
+	if (!room) {
+		if (lane == 0) a.tinfo[t_id] = make_int2(0, -1);
+	} else if (n > BIN_CAP || (a.ablate & 16)) {
+		// (a pole of a dense mesh on a small image: thousands of faces in one tile) the list goes out as the scan finds it
+		scan([&](uint32_t e, int pos) { pool[off + pos] = e; });
+		mode = LIST_UNSORTED;
+	} else {
+		// stable counting sort by slab, LDS -> pool: slab histogram, running offsets, then 64 entries at a time -- an entry's place is its
+		// slab's offset plus the entries of the same slab among the lanes below it (the lanes of one slab find each other with a ballot
+		// per slab bit), and the lowest lane of every slab moves the offset on for the next 64
+		for (int i = lane; i < 256; i += 64) hist[i] = 0;
+		wave_lds_sync();
+		for (int i = lane; i < n; i += 64) __hip_atomic_fetch_add(&hist[src[i] >> 24], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		wave_lds_sync();
+		{
+			// exclusive prefix over the 256 bins: four consecutive bins per lane, then across the lanes
+			int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+			const int own = h0 + h1 + h2 + h3;
+			int inc = own;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) { const int t2 = __shfl_up(inc, d, 64); if (lane >= d) inc += t2; }
+			const int ex = inc - own;
+			hist[4 * lane] = ex; hist[4 * lane + 1] = ex + h0; hist[4 * lane + 2] = ex + h0 + h1; hist[4 * lane + 3] = ex + h0 + h1 + h2;
+		}
+		wave_lds_sync();
+		for (int i0 = 0; i0 < n; i0 += 64) {
+			const int i = i0 + lane;
+			const bool live = i < n;
+			const uint32_t e = src[min(i, n - 1)];
+			const uint32_t sl = e >> 24;
+			unsigned long long same = __ballot(live);
+#pragma unroll
+			for (int bit = 0; bit < 8; ++bit) {
+				const unsigned long long bm = __ballot((sl >> bit) & 1u);
+				same &= ((sl >> bit) & 1u) ? bm : ~bm;
+			}
+			if (live) {
+				const int base = hist[sl];
+				pool[off + base + (int)__popcll(same & lt)] = e;
+			}
+			wave_lds_sync();
+			if (live && (same & lt) == 0ull) hist[sl] += (int)__popcll(same);
+			wave_lds_sync();
+		}
+	}
+	if (lane == 0 && room) a.tinfo[t_id] = make_int2(off, (int)((uint32_t)n | mode));
+}
+
+// background of every tile outside its image's tile bbox (one wave per tile; the tiles inside are bin_kernel's)
+__global__ __launch_bounds__(256) void outside_kernel(const TileArgs a) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int img = blockIdx.y, t = blockIdx.x * 4 + wave;
+	if (t >= a.tiles_per_img) return;
+	const int tile_x = t % a.tiles_x, tile_y = t / a.tiles_x;
+	const int32_t* zi = a.zinfo + img * 8;
+	if (tile_x >= zi[4] && tile_x <= zi[5] && tile_y >= zi[6] && tile_y <= zi[7]) return;
+	if (lane == 0) a.tinfo[img * a.tiles_per_img + t] = make_int2(0, 0);
+	write_background(a, img, tile_x, tile_y, lane);
+}
+
+__global__ __launch_bounds__(256) void bin_kernel(const TileArgs a, int n_img) {
+	__shared__ uint32_t la[4][BIN_CAP];
+	__shared__ int lh[4][256];
+	__shared__ int lr[4][256];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const int F = a.F, n_runs = (F + 63) >> 6;
+	// Persistent waves: a plain one-wave-per-tile launch left three quarters of the wave slots to tiles that have nothing to do (most of an
+	// image is empty, and a workgroup's slots stay taken until its busiest wave is through).  Every wave starts at an image of its own and
+	// takes the tiles of that image's bbox from the image's counter, then moves on to the next image that still has some.
+	int img = (blockIdx.x * 4 + wave) % n_img;
+	for (int visited = 0; visited < n_img;) {
+		const int32_t* zi = a.zinfo + img * 8;
+		const int bx0 = zi[4], bx1 = zi[5], by0 = zi[6], by1 = zi[7];
+		const int nbx = bx1 - bx0 + 1, n_in = bx1 >= bx0 ? nbx * (by1 - by0 + 1) : 0;
+		int tq = n_in;
+		if (lane == 0 && *reinterpret_cast<volatile int32_t*>(a.cursor + (n_img + img) * CURSOR_STRIDE) < n_in) tq = atomicAdd(&a.cursor[(n_img + img) * CURSOR_STRIDE], 1);
+		tq = __builtin_amdgcn_readfirstlane(tq);
+		if (tq >= n_in) { img = img + 1 == n_img ? 0 : img + 1; ++visited; continue; }
+		visited = 0;
+		const int tile_x = bx0 + tq % nbx, tile_y = by0 + tq / nbx;
+		const int t = tile_y * a.tiles_x + tile_x;
+		bin_tile(a, la[wave], lh[wave], lr[wave], img, t, tile_x, tile_y, lane, lt, F, n_runs);
+	}
+}
+
+// Tiles with a list, the longest lists first (a tile's cost grows with its list; taken in image order, the expensive tiles of the last
+// images arrived when nothing was left to overlap them with): a counting sort by log2(length) in two launches.  Workgroups count their
+// 1024 tiles per class in LDS and add the counts to the global ones; then every workgroup reserves, per class, a range for its own
+// tiles behind the ranges reserved before it and writes them there (the order inside a class does not matter: tiles are independent).
+__device__ __forceinline__ int list_class(int2 ti) {   // 0 = longest; -1: no list
+	if (ti.y == 0) return -1;
+	if (ti.y < 0) return 0;   // no room in the pool: the rasteriser walks every face of the image
+	const int n = (int)((uint32_t)ti.y & ~LIST_UNSORTED);
+	return max(0, N_QUEUES - 1 - (31 - __builtin_clz(n)));
+}
+__global__ __launch_bounds__(1024) void order_count_kernel(const int2* __restrict__ tinfo, int n_tiles, int32_t* __restrict__ qn) {
+	__shared__ int h[N_QUEUES];
+	if (threadIdx.x < N_QUEUES) h[threadIdx.x] = 0;
+	__syncthreads();
+	const int t = blockIdx.x * 1024 + threadIdx.x;
+	const int c = t < n_tiles ? list_class(tinfo[t]) : -1;
+	if (c >= 0) atomicAdd(&h[c], 1);
+	__syncthreads();
+	if (threadIdx.x < N_QUEUES && h[threadIdx.x]) atomicAdd(&qn[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(1024) void order_fill_kernel(const int2* __restrict__ tinfo, int n_tiles, int32_t* __restrict__ qn, int32_t* __restrict__ order) {
+	__shared__ int h[N_QUEUES];
+	__shared__ int base[N_QUEUES];
+	if (threadIdx.x < N_QUEUES) h[threadIdx.x] = 0;
+	__syncthreads();
+	const int t = blockIdx.x * 1024 + threadIdx.x;
+	const int c = t < n_tiles ? list_class(tinfo[t]) : -1;
+	int rank = 0;
+	if (c >= 0) rank = atomicAdd(&h[c], 1);
+	__syncthreads();
+	if (threadIdx.x < N_QUEUES) {
+		int start = 0;
+		for (int q = 0; q < threadIdx.x; ++q) start += qn[q];
+		base[threadIdx.x] = start + (h[threadIdx.x] ? atomicAdd(&qn[32 + threadIdx.x], h[threadIdx.x]) : 0);
+		if (blockIdx.x == 0 && threadIdx.x == N_QUEUES - 1) qn[62] = start + qn[N_QUEUES - 1];
+	}
+	__syncthreads();
+	if (c >= 0) order[base[c] + rank] = t;
+}
+
+// ------------------------------------------------------------------------------------------------ 4. rasteriser
+// Persistent waves, each a worker of its own: tile from the queues -> list from the pool, 64 faces at a time (the next 64 records are on
+// their way from memory while these are evaluated) -> every lane evaluates the staged records for its own pixel.  Silhouette candidates
+// multiply into the pixel's alpha and are appended (depth, 1 - p) to the lane's own contiguous run of the workgroup's scratch through an
+// LDS ring (whole 32-byte pieces, written once).  The list is in depth-slab order: after a batch, every face still to come lies behind
+// `front`, so a pixel that holds K candidates in front of `front` has its K nearest, and a pixel whose nearest inside fragment lies in
+// front of it has its colour -- the wave leaves the list when every pixel is finished.  A pixel that ends with more than K candidates
+// finds the K-th smallest depth of its list by a lane-parallel radix search and blends the K nearest; where candidates tied at that depth
+// were left out the pixel is queued for tie_fix_kernel (PyTorch3D's K-buffer keeps the lower face indices: needs ids, which lists omit).
+struct RasterArgs {   // (what the rasteriser's loop needs and no more: the shading tail and its dozen pointers live in shade_kernel)
+	float sil_blur_radius, sil_sigma;
+	int sil_faces_per_pixel, image_h, image_w;
+	const uint32_t* tb;
+	const int32_t* zinfo;
+	const int2* tinfo;
+	int F, tiles_x, tiles_per_img;
+	int64_t pool_cap;
+	float* mask;
+	int32_t* p2f_ws;      // null: no colour pass
+	float* frag_ws;
+	int32_t* flags;
+	const int32_t* qn;
 	float* zthr;
 	float* alpha_ws;
 	float2* scratch;
-	const int32_t* tile_any;
-	const int32_t* tile_order;
-	int tiles_per_img, total_tiles;
-	int ablate;              // profiling only (find_debug_raster_ablate): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math
+	Fix* fix;
+	int ablate;
 };
 
-// Persistent: workgroups take (image, tile) pairs from an atomic counter.  Silhouette candidates of every pixel are also
-// appended, in face order, to the workgroup's scratch (depth, 1 - p): a pixel that ends with more than faces_per_pixel
-// candidates is resolved at the end of its tile by its own wave -- rank by depth, ties to the earlier face (PyTorch3D's
-// insertion into the per-pixel K-buffer), blend the K nearest, record the K-th depth for the backward pass.
-//
-// NW = waves that share a tile.  NW = 4 (what find_render_fwd launches): a 16x16 tile per workgroup, one 8x8 quadrant per wave, the tile's
-// face list and records built together (workgroup barriers between the phases).  NW = 1 (find_debug_raster_ablate bit 128): every wave is
-// its own worker on 8x8 tiles -- own list, own records, own queue slot, no workgroup barrier anywhere.  The reason to try it: with NW = 4
-// the waves of a tile meet at a barrier after every batch of 256 faces, and the longest quadrant loop of a batch is 1.79 x the mean of the
-// four at C3 (1.43 x per whole tile; diagnostic counters [26] - [28]).  Measured (same faces per pixel, values equal to rounding): 2.03 against 1.78 ms at 256^2,
-// 6.27 against 4.25 ms at 512^2 -- four times the tiles means four times the scans and record stagings, each a chain of dependent loads
-// that a lone wave cannot overlap with anything, and that costs more than the barriers did.  Kept as a switch, not as the default.
-template <int NW>
-__global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
-	constexpr int TSZ = NW == 4 ? 16 : 8;   // tile edge
-	constexpr int GB = NW * 64;             // threads of a group = faces per batch
-	constexpr int NG = 4 / NW;              // groups per workgroup
-	constexpr int LPR = 4;                  // face-bbox loads a lane keeps in flight per scan round (12 for NW = 1: slower still)
-	__shared__ int list[NG][2 * GB];
-	__shared__ FaceRec rec[NG][GB];
-	__shared__ int wcount2[NG][2][4];
-	__shared__ int runs[NG][GB];
-	__shared__ int wit[4];
-	__shared__ int s_tile[NG];
+typedef float v4f __attribute__((ext_vector_type(4)));
+// a face's record through the scalar cache: the address is wave-uniform, the 80 bytes land in SGPRs (constant address space: the loads
+// are selected as s_load whatever else the kernel stores; the records were written by an earlier kernel)
+__device__ __forceinline__ FaceRec load_rec_uniform(const FaceRec* base, int f) {
+	typedef const __attribute__((address_space(4))) v4f* cv4;
+	const unsigned long long addr = (unsigned long long)(base + f);
+	// (the compiler cannot see that a value loaded from a uniform address is uniform: told so explicitly, or the s_loads become vector loads)
+	const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr), hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+	cv4 q = (cv4)(((unsigned long long)hi << 32) | lo);
+	const v4f q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+	FaceRec r;
+	r.x0 = q0.x; r.y0 = q0.y; r.x1 = q0.z; r.y1 = q0.w; r.x2 = q1.x; r.y2 = q1.y; r.z0 = q1.z; r.z1 = q1.w;
+	r.z2 = q2.x; r.inv_area = q2.y; r.il01 = q2.z; r.il02 = q2.w; r.il12 = q3.x; r.f = __float_as_int(q3.y); r.pad[0] = r.pad[1] = 0;
+	r.xmin = q4.x; r.xmax = q4.y; r.ymin = q4.z; r.ymax = q4.w;
+	return r;
+}
+
+template <bool want_sil, bool want_rgb>
+__global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ pool_all,
+													  const int32_t* __restrict__ order) {
+	__shared__ __attribute__((aligned(16))) FaceRec rec[4][64];   // the batch in flight (the K-nearest search's counters live on top of it afterwards)
 	// write-combining rings of the candidate lists: [slot][thread], so that a wave's appends (different slots per lane) never conflict
 	__shared__ float ring_z[RING][256];
 	__shared__ float ring_q[RING][256];
 
-	const int H = a.rp.image_h, W = a.rp.image_w;
+	const int H = a.image_h, W = a.image_w;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int g = NW == 4 ? 0 : wave, wg = NW == 4 ? wave : 0, gtid = NW == 4 ? tid : lane;   // group, wave inside it, thread inside it
-	// barrier of the group: the workgroup's, or -- one wave: its LDS operations execute in order -- only a fence for the compiler
-	auto gsync = [&]() {
-		if constexpr (NW == 4) {
-			__syncthreads();
-		} else {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		}
-	};
-	auto wtotal = [&](int par) {
-		int t = 0;
-#pragma unroll
-		for (int w = 0; w < NW; ++w) t += wcount2[g][par][w];
-		return t;
-	};
-	const float blur = a.rp.sil_blur_radius, br = sqrtf(blur);
-	const float inv_sigma = 1.0f / a.rp.sil_sigma;
-	const int K = a.rp.sil_faces_per_pixel;
-	const bool want_sil = a.mask != nullptr;
-	const bool want_rgb = a.image != nullptr || a.p2f_out != nullptr || a.zbuf_out != nullptr;
+	const float blur = a.sil_blur_radius;
+	const float inv_sigma = 1.0f / a.sil_sigma;
+	const int K = a.sil_faces_per_pixel;
+	const bool early = !(a.ablate & 8);
+	const int n_order = a.qn[62];
 	// Candidate lists: every pixel (thread) owns ONE contiguous run of KN_CAP depths and one of KN_CAP (1 - p) values.  A lane collects
 	// RING candidates in LDS and writes them out as whole 32-byte pieces (two 16-byte stores per array): the lists reach memory as
-	// full sectors, once.  (First version: entry i of all 256 pixels interleaved, one 4-byte store per candidate -- lanes of a wave sit
-	// at different i, so every store dirtied its own line: 5.3 GB written and 2.9 GB read per C3 launch for 0.5 GB of list data.)
+	// full sectors, once.
 	float* const scr_z = reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256) + tid * KN_CAP;
 	float* const scr_q = scr_z + KN_CAP * 256;
-	auto flush_ring = [&](int base, int valid) {   // ring -> list entries [base, base + RING); slots >= valid become (+inf, 1): never selected
+	auto flush_ring = [&](int base, int valid) __attribute__((always_inline)) {   // ring -> list entries [base, base + RING); slots >= valid become (+inf, 1): never selected
 		float zv[RING], qv[RING];
 #pragma unroll
 		for (int u = 0; u < RING; ++u) {
@@ -442,157 +774,142 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 	};
 
 	for (;;) {
-		if (gtid == 0) s_tile[g] = atomicAdd(&a.flags[3], 1);
-		gsync();
-		const int t_q = s_tile[g];
-		gsync();
-		if (t_q >= a.total_tiles) break;
-		const int t_id = a.tile_order[t_q];
+		int t_q = 0;
+		if (lane == 0) t_q = atomicAdd(&a.flags[3], 1);
+		t_q = __builtin_amdgcn_readfirstlane(t_q);
+		if (t_q >= n_order) break;
+		const int t_id = __builtin_amdgcn_readfirstlane(order[t_q]);
 		const int img = t_id / a.tiles_per_img, tile = t_id - img * a.tiles_per_img;
 		const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-		// wave w owns the 8x8-pixel quadrant (w&1, w>>1) of the tile: faces are culled per wave against that quadrant
-		const int qx0 = tile_x * TSZ + (wg & 1) * 8, qy0 = tile_y * TSZ + (wg >> 1) * 8;
-		const int xi = qx0 + (lane & 7), yi = qy0 + (lane >> 3);
+		const int xi = tile_x * T8 + (lane & 7), yi = tile_y * T8 + (lane >> 3);
 		const bool in_img = xi < W && yi < H;
 		const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
 		const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
-		// NDC extent of the quadrant's pixel centres (x and y decrease with the pixel index)
-		const float q_xhi = 1.0f - (2.0f * qx0 + 1.0f) / (float)W, q_xlo = 1.0f - (2.0f * (qx0 + 7) + 1.0f) / (float)W;
-		const float q_yhi = 1.0f - (2.0f * qy0 + 1.0f) / (float)H, q_ylo = 1.0f - (2.0f * (qy0 + 7) + 1.0f) / (float)H;
+		int2 ti = a.tinfo[t_id];
+		ti.x = __builtin_amdgcn_readfirstlane(ti.x); ti.y = __builtin_amdgcn_readfirstlane(ti.y);
+		const bool binned = ti.y >= 0;
+		const int n_list = binned ? (int)((uint32_t)ti.y & ~LIST_UNSORTED) : a.F;
+		const bool sorted = binned && !((uint32_t)ti.y & LIST_UNSORTED);
+		float zlo = 0.f, sw = 1.f;
+		slab_layout(a.zinfo + img * 8, &zlo, &sw);
+		const uint32_t* tbp = a.tb + (int64_t)img * a.F;
+		const FaceRec* rp_img = recs + (int64_t)img * a.F;
+		const uint32_t* lp = pool_all + (int64_t)img * a.pool_cap + ti.x;
 
 		float alpha = 1.0f, z_lo = INFINITY, z_hi = 0.0f;
-		int cnt = 0;
-		int n_eval = 0, n_eval_prev = 0;   // diagnostics (ablate bit 64): (pixel, face) tests this lane ran
+		int cnt = 0, c_lt = 0, c_a = 0, c_b = 0;   // candidates in front of `front`, within one slab behind it, further back (never beyond two)
+		int n_eval = 0;
 		float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
 		int bf = -1;
+		float front = 0.0f, front1 = 0.0f;   // every face not yet evaluated has its fragments behind `front`; front1: one slab further
+		int s_front = -2;                   // slab whose lower edge `front` is
+		bool stopped = false;               // the wave left the list early
 
-		const uint32_t* tbp = a.tb + (int64_t)img * a.F;
-		const float4* frp = a.frec + (int64_t)img * a.F * 3;
-
-		auto shade_batch = [&](int nb) {
-			// stage the records of list[0 .. nb) in LDS
-			if (gtid < nb) make_rec(frp + (int64_t)list[g][gtid] * 3, list[g][gtid], br, &rec[g][gtid]);
-			gsync();
-			// candidates of this wave's quadrant: bbox-vs-quadrant test by 64 lanes at a time, then a scalar loop over the set
-			// bits (increasing k: the order of the alpha product and of the candidate lists is that of the face list).
-			// (Measured and dropped in round 2: 16-lane groups owning 4x4-pixel blocks, each walking its own mask of faces in the same
-			// instruction stream -- 45 % of the lane-level tests produce a candidate instead of 26 %, 141 M tests instead of 245 M at C3, and
-			// the render is no faster, 1.87 against 1.80 ms: the loop runs for the longest of the four masks, and in the tiles that decide the
-			// kernel's duration -- the rim, the poles -- that is the quadrant's whole list.)
-			for (int kb = 0; kb < nb; kb += 64) {
-				bool ov = false;
-				if (kb + lane < nb) {
-					const FaceRec& rr = rec[g][kb + lane];
-					ov = !(q_xlo > rr.xmax || q_xhi < rr.xmin || q_ylo > rr.ymax || q_yhi < rr.ymin);
-				}
-				unsigned long long qm = __ballot(ov);
-				while (qm) {
-					const int k = kb + __builtin_ctzll(qm);
-					qm &= qm - 1;
-					Frag fr;
+		// entry of this lane in batch b: face index (or -1); *slab0: the slab of the batch's first entry
+		auto entry = [&](int b, int* slab0) __attribute__((always_inline)) -> int {
+			const int i = b * 64 + lane;
+			int f = -1;
+			uint32_t e0 = 0u;
+			if (binned) {
+				if (i < n_list) f = (int)(lp[i] & FACE_MASK);
+				if (b * 64 < n_list) e0 = lp[b * 64];
+			} else if (i < n_list && tile_hit(tbp[i], tile_x, tile_y)) {
+				f = i;   // no room in the pool for this tile's list: every face of the image, tested here
+			}
+			*slab0 = (int)(e0 >> 24);
+			return f;
+		};
+		const int n_batches = (n_list + 63) >> 6;
+		int slab_next = 0, slab_cur = 0;
+		int f_cur = entry(0, &slab_cur);
+		int f_next = n_batches > 1 ? entry(1, &slab_next) : -1;
+		for (int b = 0; b < n_batches; ++b) {
+			const bool more = b + 1 < n_batches;
+			const int slab_after = slab_next;
+			const int f_lane = f_cur;
+			if (more) {
+				f_cur = f_next;
+				f_next = b + 2 < n_batches ? entry(b + 2, &slab_next) : -1;   // (the entries two batches ahead are on their way while this one is evaluated)
+			}
+			// a pixel that holds its K nearest (and its colour) in front of everything from this batch on needs nothing more
+			const bool fin = !in_img || ((!want_sil || c_lt >= K) && (!want_rgb || bz < front));
+			const bool need = (early ? !fin : in_img) && !(a.ablate & 4);
+			// What is still to come AFTER this batch lies behind the lower edge of the next batch's first slab.  The candidates seen so far
+			// come from faces of slabs up to that one, so none lies two slabs behind the old edge: when the edge moves by one slab, those
+			// within a slab of the old one are now in front, the rest are within a slab of the new one; by more, all are in front.
+			if (!more) { c_lt += c_a + c_b; c_a = c_b = 0; front = front1 = INFINITY; }
+			else if (sorted && slab_after > s_front) {
+				if (slab_after == s_front + 1) { c_lt += c_a; c_a = c_b; } else { c_lt += c_a + c_b; c_a = 0; }
+				c_b = 0;
+				s_front = slab_after;
+				front = slab_front(slab_after, zlo, sw); front1 = slab_front(slab_after + 1, zlo, sw);
+			}
+			// stage the batch: every lane copies its face's 80-byte record to LDS (five 16-byte pieces), then every lane reads all of them
+			if (f_lane >= 0) {
+				const float4* src = reinterpret_cast<const float4*>(rp_img + f_lane);
+				float4* dst = reinterpret_cast<float4*>(&rec[wave][lane]);
+				const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
+				dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3; dst[4] = q4;
+			}
+			wave_lds_sync();
+			unsigned long long m = __ballot(f_lane >= 0);
+			while (m) {   // two faces per turn: one's LDS reads overlap the other's math
+				const int k0 = __builtin_ctzll(m);
+				m &= m - 1;
+				const bool two = m != 0ull;
+				const int k1 = two ? __builtin_ctzll(m) : k0;
+				if (two) m &= m - 1;
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					if (u == 1 && !two) break;   // uniform
+					const FaceRec& rk = rec[wave][u ? k1 : k0];
+					// nobody who still needs faces lies inside this one's bbox: next (the far side of a closed surface goes by like this)
+					const bool inb = need & (px <= rk.xmax) & (px >= rk.xmin) & (py <= rk.ymax) & (py >= rk.ymin);
+					if (__ballot(inb) == 0ull) continue;
 					if (a.ablate & 64) ++n_eval;
-					if ((a.ablate & 4) || !in_img || !eval_frag(rec[g][k], px, py, &fr)) continue;
-					if (want_sil && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur)) {
-						const float sd = fr.inside ? -fr.dist : fr.dist;
-						const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
-						alpha *= (1.0f - prob);
-						if (cnt < KN_CAP && !(a.ablate & 1)) {
-							const int slot = cnt & (RING - 1);
-							ring_z[slot][tid] = fr.pz_clip; ring_q[slot][tid] = 1.0f - prob;
-							if (slot == RING - 1) flush_ring(cnt - (RING - 1), RING);
+					Frag fr;
+					eval_core(rk, px, py, &fr);   // (every lane: the ones outside the bbox compute along and are masked out below)
+					if (want_sil) {
+						const bool cand = inb & (fr.pz_clip >= 0.f) & (fr.inside | (fr.dist < blur));
+						if (cand) {
+							const float prob = silhouette_prob(fr.inside ? -fr.dist : fr.dist, inv_sigma);
+							alpha *= (1.0f - prob);
+							if (cnt < KN_CAP && !(a.ablate & 1)) {
+								const int slot = cnt & (RING - 1);
+								ring_z[slot][tid] = fr.pz_clip; ring_q[slot][tid] = 1.0f - prob;
+								if (slot == RING - 1) flush_ring(cnt - (RING - 1), RING);
+							}
+							++cnt;
+							c_lt += fr.pz_clip < front ? 1 : 0;
+							c_a += (fr.pz_clip >= front) & (fr.pz_clip < front1) ? 1 : 0;
+							c_b += fr.pz_clip >= front1 ? 1 : 0;
+							z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bounds of the radix search)
 						}
-						++cnt;
-						z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bisection bounds)
 					}
-					if (want_rgb && fr.inside && fr.pz >= 0.f && fr.pz < bz) {
-						bz = fr.pz; bf = rec[g][k].f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
-					}
-				}
-			}
-			gsync();
-			if (NW == 4 && (a.ablate & 64)) {   // diagnostics [28]: sum over BATCHES of the longest quadrant loop (the barrier above waits for it)
-				if (lane == 0) wit[wave] = n_eval - n_eval_prev;
-				n_eval_prev = n_eval;
-				__syncthreads();
-				if (tid == 0) atomicAdd(&a.flags[28], max(max(wit[0], wit[1]), max(wit[2], wit[3])));
-				__syncthreads();
-			}
-		};
-
-		const int nF = a.tile_any[t_id] ? a.F : 0;  // nothing can touch this tile: straight to the background write
-		// Two-level scan of the packed tile bboxes.  Level 1: the bboxes of the runs of 64 consecutive faces (face_setup_kernel), 256 runs
-		// per round, compacted in order into `runs`.  Level 2: the faces of the runs that reach this tile, 16 runs = 1024 faces per
-		// round: the four loads of a thread are in flight together (the scan is bound by the latency of this load, not by its bytes),
-		// then four ordered compactions -- ballot per wave, exclusive offsets across the waves through LDS (one barrier each: the wave
-		// counts alternate between two sets), the running length kept in a register.  Runs and faces stay in index order, so the
-		// candidate order is the face order whichever runs were skipped.  (One level -- every tile reading every face's bbox -- was
-		// 14 rounds per tile at 13 776 faces; a 16 x 16 tile is reached by a tenth of the runs of a mesh with coherent face order.)
-		int nl = 0;   // == n_list, replicated in every thread
-		int par = 0;
-		const int n_runs = (nF + 63) >> 6;
-		const uint32_t* tbbp = a.tbb + (int64_t)img * ((a.F + 63) >> 6);
-		auto tile_hit = [&](uint32_t t) {
-			const int tx0 = t & 255, tx1 = (t >> 8) & 255, ty0 = (t >> 16) & 255, ty1 = t >> 24;
-			return tile_x >= tx0 && tile_x <= tx1 && tile_y >= ty0 && tile_y <= ty1;  // (TB_EMPTY: tx0 = 255 > tx1 = 0)
-		};
-		for (int rbase = 0; rbase < n_runs; rbase += GB) {
-			int n_hit;
-			{
-				const bool rh = rbase + gtid < n_runs && tile_hit(tbbp[rbase + gtid]);
-				const unsigned long long m = __ballot(rh);
-				if (lane == 0) wcount2[g][par][wg] = __popcll(m);
-				gsync();
-				int off = 0;
-				for (int w = 0; w < wg; ++w) off += wcount2[g][par][w];
-				if (rh) runs[g][off + __popcll(m & ((1ull << lane) - 1ull))] = rbase + gtid;
-				n_hit = wtotal(par);
-				par ^= 1;
-				gsync();
-			}
-			for (int j0 = 0; j0 < n_hit; j0 += LPR * NW) {
-				uint32_t tbv[LPR];
-				int fidx[LPR];
-#pragma unroll
-				for (int r = 0; r < LPR; ++r) {
-					const int j = j0 + r * NW + wg;
-					fidx[r] = j < n_hit ? runs[g][j] * 64 + lane : nF;
-					tbv[r] = fidx[r] < nF ? tbp[fidx[r]] : TB_EMPTY;
-				}
-#pragma unroll
-				for (int r = 0; r < LPR; ++r) {
-					if (j0 + r * NW >= n_hit) break;  // uniform
-					const bool hit = tile_hit(tbv[r]);
-					const unsigned long long m = __ballot(hit);
-					if (lane == 0) wcount2[g][par][wg] = __popcll(m);
-					gsync();
-					int off = nl;
-					for (int w = 0; w < wg; ++w) off += wcount2[g][par][w];
-					if (hit) list[g][off + __popcll(m & ((1ull << lane) - 1ull))] = fidx[r];
-					nl += wtotal(par);
-					par ^= 1;
-					if (nl >= GB) {  // uniform
-						gsync();
-						shade_batch(GB);
-						const int rest = nl - GB;
-						int moved = 0;
-						if (gtid < rest) moved = list[g][GB + gtid];
-						gsync();
-						if (gtid < rest) list[g][gtid] = moved;
-						nl = rest;
-						gsync();
+					if (want_rgb) {
+						// nearest inside fragment; equal depths: the lower face index (PyTorch3D's insertion order)
+						if (inb & fr.inside & (fr.pz >= 0.f) & ((fr.pz < bz) | ((fr.pz == bz) & (rk.f < bf)))) {
+							bz = fr.pz; bf = rk.f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
+						}
 					}
 				}
 			}
-			gsync();   // `runs` is rewritten by the next round
+			wave_lds_sync();   // the records are overwritten by the next batch
+			if (early && more) {
+				const bool fin2 = !in_img || ((!want_sil || c_lt >= K) && (!want_rgb || bz < front));
+				if (__ballot(!fin2) == 0ull) { stopped = true; break; }
+			}
 		}
-		if (nl > 0) { gsync(); shade_batch(nl); }
 
 		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
 		// lane finds the K-th smallest depth of its OWN list (16-byte reads of its contiguous run) by a radix search
 		// on the integer image of the depth (non-negative floats order like their bit patterns) with one counting pass per
-		// step, then blends, in face order, the candidates in front of it and as many of those AT it as still fit.
+		// step, then blends the candidates in front of it and as many of those AT it as still fit.
 		float thr = INFINITY;
 		if (want_sil) {
+			// a wave that left early has candidates it never looked at behind `front`: its pixels hold >= K in front of it, and the bound
+			// handed to the backward must keep those out even when the pixel holds exactly K
+			if (stopped && in_img) thr = front;
 			const bool over = in_img && cnt > K && !(a.ablate & 2);
 			const unsigned long long ov_all = __ballot(over);
 			if (ov_all) {
@@ -606,12 +923,6 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					atomicAdd(&a.flags[4], (int)__popcll(ov_all));
 					atomicMax(&a.flags[5], wave_max_cnt);
 					if (trunc) atomicAdd(&a.flags[1], (int)__popcll(trunc));
-				}
-				const long long kt0 = (a.ablate & 64) ? wall_clock64() : 0;
-				if ((a.ablate & 64) && lane == 0) {  // profiling: waves by their longest list, [8 + log2 bucket]; [20] sum of longest lists
-					atomicAdd(&a.flags[8 + min(7, max(0, 31 - __builtin_clz(max(wave_max_cnt, 1)) - 6))], 1);
-					atomicAdd(&a.flags[20], wave_max_cnt);
-					atomicAdd(&a.flags[21], (int)__popcll(ov_all));
 				}
 				if (over && cnt <= KN_CAP) {
 					// the candidates still in the ring join the list, padded to a whole piece with (+inf, 1) entries that no pass selects
@@ -643,18 +954,18 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 					// (z - lo) >> shift into 32 bins in ONE read of the list and keeps the bin
 					// that holds the K-th; once that bin has at most 4 candidates they are fetched and ranked directly.
 					int c_lo = 0;
-					// the lane's 32 counters (16 bits each) live in LDS, on top of the face records nobody needs any more in this tile:
-					// hist[w * GB + gtid], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
-					unsigned* const hist = reinterpret_cast<unsigned*>(rec[g]) + gtid;
+					// the lane's 32 counters (16 bits each) live in LDS:
+					// hist[w * 64 + lane], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
+					unsigned* const hist = reinterpret_cast<unsigned*>(rec[wave]) + lane;
 					while (lo < hi) {
 						const unsigned span = hi - lo;
 						const int shift = span < 32u ? 0 : (27 - __builtin_clz(span));  // (span >> shift) <= 31
 #pragma unroll
-						for (int w = 0; w < 16; ++w) hist[w * GB] = 0u;
+						for (int w = 0; w < 16; ++w) hist[w * 64] = 0u;
 						scan_z([&](unsigned zb) {
 							if (zb < lo || zb > hi) return;
 							const unsigned bin = (zb - lo) >> shift;
-							__hip_atomic_fetch_add(hist + (bin >> 1) * GB, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							__hip_atomic_fetch_add(hist + (bin >> 1) * 64, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 						});
 						// the bin that holds the (K - c_lo)-th candidate of the range
 						const int need = K - c_lo;
@@ -662,7 +973,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						bool found = false;
 #pragma unroll
 						for (int w = 0; w < 16; ++w) {
-							const unsigned hw = hist[w * GB];
+							const unsigned hw = hist[w * 64];
 #pragma unroll
 							for (int h = 0; h < 2; ++h) {
 								const int cb = (int)((hw >> (h * 16)) & 0xFFFFu);
@@ -679,13 +990,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						if (in_sel <= 4) {
 							// fetch the (at most 4) candidates of the bin and take the (K - c_lo)-th smallest of them
 							unsigned c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
-							int m = 0;
+							int mm = 0;
 							scan_z([&](unsigned zb) {
 								// (selects, not an if-chain: the compiler turned that into a four-element array in scratch)
 								const bool in = zb >= lo && zb <= hi;
-								c0 = (in && m == 0) ? zb : c0; c1 = (in && m == 1) ? zb : c1;
-								c2 = (in && m == 2) ? zb : c2; c3 = (in && m == 3) ? zb : c3;
-								m += in ? 1 : 0;
+								c0 = (in && mm == 0) ? zb : c0; c1 = (in && mm == 1) ? zb : c1;
+								c2 = (in && mm == 2) ? zb : c2; c3 = (in && mm == 3) ? zb : c3;
+								mm += in ? 1 : 0;
 							});
 							// sort the four (absent ones are +max) and index
 							unsigned t;
@@ -702,16 +1013,17 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 						}
 					}
 					// lo = bits of the K-th smallest depth, c_lo = candidates strictly in front of it
-					int ties = K - c_lo;  // candidates AT the K-th depth that are kept: the earliest ones (PyTorch3D's insertion order)
-					float asel = 1.0f;
+					const int keep = K - c_lo;   // how many of the candidates AT the K-th depth belong to the K nearest
+					int ties = keep;
+					float a_lt = 1.0f, a_tie = 1.0f;
 					unsigned nxt = 0x7F800000u;   // bits of the nearest depth BEHIND the K-th
 					bool excess = false;          // more candidates at the K-th depth than are kept
 					{
 						auto take = [&](float z, float q) {
 							const unsigned zb = __float_as_uint(z + 0.0f);
-							if (zb < lo) asel *= q;
+							if (zb < lo) a_lt *= q;
 							else if (zb == lo) {
-								if (ties > 0) { asel *= q; --ties; }
+								if (ties > 0) { a_tie *= q; --ties; }
 								else excess = true;
 							} else nxt = min(nxt, zb);
 						};
@@ -730,17 +1042,19 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 							take(zv.x, qv.x); take(zv.y, qv.y); take(zv.z, qv.z); take(zv.w, qv.w);
 						}
 					}
-					alpha = asel;
-					// What the backward compares a candidate's depth with.  It recomputes that depth in another kernel, and the compiler is free
-					// to contract the same expression differently there: with the K-th depth itself as the bound, the K-th candidate fell on
-					// the wrong side of its own depth in about half of the overflow pixels (2.5e-3 of the gradient's scale on a dense mesh at
-					// 64^2).  The bound is the MIDPOINT between the K-th depth and the next one behind it -- any rounding difference smaller
-					// than half that gap selects the same K candidates -- and the K-th depth itself only where candidates tied AT it were
-					// left out (the backward then takes every tied one: the one case it cannot tell apart without face ids in the lists).
+					alpha = a_lt * a_tie;
+					// The bound the backward compares a candidate's depth with: the MIDPOINT between the K-th depth and the next one behind it
+					// (never beyond `front` where the wave left early: what it did not look at lies behind that).  Where candidates tied AT
+					// the K-th depth were left out, which of them stay is decided by face index: tie_fix_kernel rewrites this pixel.
 					const float zk = __uint_as_float(lo);
-					thr = excess ? zk : 0.5f * (zk + __uint_as_float(nxt));
+					thr = fminf(0.5f * (zk + __uint_as_float(nxt)), stopped ? front : INFINITY);
+					if (excess) {
+						thr = zk;   // provisional (every tied candidate): replaced by -zk and the face id of the last one kept
+						Fix fx;
+						fx.pix = (int32_t)(((int64_t)img * H + yi) * W + xi); fx.zk = lo; fx.keep = keep; fx.a_lt = a_lt;
+						a.fix[atomicAdd(&a.flags[7], 1)] = fx;
+					}
 				}
-				if ((a.ablate & 64) && lane == 0) atomicAdd(&a.flags[22], (int)((wall_clock64() - kt0) >> 4));  // K-pass time of the wave, 16-tick units (100 MHz)
 			}
 		}
 
@@ -749,17 +1063,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) { te += __shfl_xor(te, d, 64); tc += __shfl_xor(tc, d, 64); }
 			if (lane == 0 && te) { atomicAdd(&a.flags[24], (te + 32) >> 6); atomicAdd(&a.flags[25], (tc + 32) >> 6); }
-			// [26] sum over tiles of the LONGEST of the four quadrants' face loops, [27] sum over tiles of all four: 4 x [26] / [27] is how
-			// much longer the tile's waves stay in the fragment phase than their own work needs (the others wait at the barrier)
-			if constexpr (NW == 4) {
-				if (lane == 0) wit[wave] = n_eval;
-				__syncthreads();
-				if (tid == 0) {
-					atomicAdd(&a.flags[26], max(max(wit[0], wit[1]), max(wit[2], wit[3])));
-					atomicAdd(&a.flags[27], wit[0] + wit[1] + wit[2] + wit[3]);
-				}
-				__syncthreads();
-			}
+			if (lane == 0 && stopped) atomicAdd(&a.flags[26], 1);   // [26] tiles left early
 		}
 		if (in_img) {
 			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
@@ -768,60 +1072,151 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 				a.zthr[pix] = thr;
 				a.alpha_ws[pix] = alpha;
 			}
-			if (want_rgb) {
-				if (a.p2f_ws) {
-					a.p2f_ws[pix] = bf;
-					a.bary_ws[pix * 3 + 0] = bw0; a.bary_ws[pix * 3 + 1] = bw1; a.bary_ws[pix * 3 + 2] = bw2;
-				}
-				if (a.p2f_out) a.p2f_out[pix] = bf < 0 ? -1 : img * a.F + bf;
-				if (a.zbuf_out) a.zbuf_out[pix] = bf < 0 ? -1.0f : bz;
-				if (a.image) {
-					float* o = a.image + pix * 3;
-					if (bf < 0) {
-						o[0] = a.rp.background[0]; o[1] = a.rp.background[1]; o[2] = a.rp.background[2];
-					} else {
-						const int mesh = img / a.n_views, view = img - mesh * a.n_views;
-						const int32_t* fp = a.faces + (int64_t)mesh * a.faces_mesh_stride + (int64_t)bf * 3;
-						const float bw[3] = {bw0, bw1, bw2};
-						float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
-#pragma unroll
-						for (int k = 0; k < 3; ++k) {
-							const int64_t vo = ((int64_t)mesh * a.V + fp[k]) * 3;
-#pragma unroll
-							for (int c = 0; c < 3; ++c) {
-								pos[c] += bw[k] * a.verts[vo + c];
-								nrm[c] += bw[k] * a.normals[vo + c];
-								tex[c] += bw[k] * a.colors[vo + c];
-							}
-						}
-						float nx = nrm[0], ny = nrm[1], nz = nrm[2];
-						normalize3(nx, ny, nz);
-						float lx = a.rp.light_pos[0] - pos[0], ly = a.rp.light_pos[1] - pos[1], lz = a.rp.light_pos[2] - pos[2];
-						normalize3(lx, ly, lz);
-						const float cosang = nx * lx + ny * ly + nz * lz;
-						const float diff = a.rp.diffuse * fmaxf(cosang, 0.f);
-						float vx = a.cam[view * 3] - pos[0], vy = a.cam[view * 3 + 1] - pos[1], vz = a.cam[view * 3 + 2] - pos[2];
-						normalize3(vx, vy, vz);
-						const float rx = -lx + 2.f * cosang * nx, ry = -ly + 2.f * cosang * ny, rz = -lz + 2.f * cosang * nz;
-						const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
-						const float spec = a.rp.specular * powf(al, a.rp.shininess);
-						const float eps = 1e-10f;
-						const float prob = 1.0f / (1.0f + __expf(bd / a.rp.rgb_sigma));
-						const float z_inv = (a.rp.zfar - bz) / (a.rp.zfar - a.rp.znear);
-						const float z_inv_max = fmaxf(z_inv, eps);
-						const float wnum = prob * __expf((z_inv - z_inv_max) / a.rp.rgb_gamma);
-						const float delta = fmaxf(__expf((eps - z_inv_max) / a.rp.rgb_gamma), eps);
-						const float den = wnum + delta;
-#pragma unroll
-						for (int c = 0; c < 3; ++c) {
-							const float col = (a.rp.ambient + diff) * tex[c] + spec;
-							o[c] = (wnum * col + delta * a.rp.background[c]) / den;
-						}
-					}
-				}
+			if (want_rgb) {   // the nearest inside fragment: shade_kernel turns it into the pixel's colour
+				a.p2f_ws[pix] = bf;
+				*reinterpret_cast<float4*>(a.frag_ws + pix * 8) = make_float4(bw0, bw1, bw2, bz);
+				a.frag_ws[pix * 8 + 4] = bd;
 			}
 		}
-		gsync();  // the next tile reuses list / rec / scratch
+		wave_lds_sync();  // the next tile reuses the rings
+	}
+}
+
+// Phong shading + softmax blend (K = 1) of every pixel's nearest inside fragment, the user-visible pix_to_face / zbuf, and the
+// barycentrics the RGB backward reads: one thread per pixel of the tiles that have a list (the others got their background from bin_kernel).
+__global__ __launch_bounds__(256) void shade_kernel(const TileArgs a) {
+	const int H = a.rp.image_h, W = a.rp.image_w;
+	const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (pix >= (int64_t)a.total_tiles / a.tiles_per_img * H * W) return;
+	const int xi = (int)(pix % W), yi = (int)((pix / W) % H), img = (int)(pix / ((int64_t)W * H));
+	if (a.tinfo[img * a.tiles_per_img + (yi / T8) * a.tiles_x + xi / T8].y == 0) return;
+	const int bf = a.p2f_ws[pix];
+	const float4 fw = *reinterpret_cast<const float4*>(a.frag_ws + pix * 8);
+	const float bw0 = fw.x, bw1 = fw.y, bw2 = fw.z, bz = fw.w, bd = a.frag_ws[pix * 8 + 4];
+	a.bary_ws[pix * 3 + 0] = bw0; a.bary_ws[pix * 3 + 1] = bw1; a.bary_ws[pix * 3 + 2] = bw2;
+	if (a.p2f_out) a.p2f_out[pix] = bf < 0 ? -1 : img * a.F + bf;
+	if (a.zbuf_out) a.zbuf_out[pix] = bf < 0 ? -1.0f : bz;
+	if (!a.image) return;
+	float* o = a.image + pix * 3;
+	if (bf < 0) {
+		o[0] = a.rp.background[0]; o[1] = a.rp.background[1]; o[2] = a.rp.background[2];
+		return;
+	}
+	const int mesh = img / a.n_views, view = img - mesh * a.n_views;
+	const int32_t* fp = a.faces + (int64_t)mesh * a.faces_mesh_stride + (int64_t)bf * 3;
+	const float bw[3] = {bw0, bw1, bw2};
+	float pos[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, tex[3] = {0, 0, 0};
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const int64_t vo = ((int64_t)mesh * a.V + fp[k]) * 3;
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			pos[c] += bw[k] * a.verts[vo + c];
+			nrm[c] += bw[k] * a.normals[vo + c];
+			tex[c] += bw[k] * a.colors[vo + c];
+		}
+	}
+	float nx = nrm[0], ny = nrm[1], nz = nrm[2];
+	normalize3(nx, ny, nz);
+	float lx = a.rp.light_pos[0] - pos[0], ly = a.rp.light_pos[1] - pos[1], lz = a.rp.light_pos[2] - pos[2];
+	normalize3(lx, ly, lz);
+	const float cosang = nx * lx + ny * ly + nz * lz;
+	const float diff = a.rp.diffuse * fmaxf(cosang, 0.f);
+	float vx = a.cam[view * 3] - pos[0], vy = a.cam[view * 3 + 1] - pos[1], vz = a.cam[view * 3 + 2] - pos[2];
+	normalize3(vx, vy, vz);
+	const float rx = -lx + 2.f * cosang * nx, ry = -ly + 2.f * cosang * ny, rz = -lz + 2.f * cosang * nz;
+	const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (cosang > 0.f ? 1.f : 0.f);
+	const float spec = a.rp.specular * powf(al, a.rp.shininess);
+	const float eps = 1e-10f;
+	const float prob = 1.0f / (1.0f + __expf(bd / a.rp.rgb_sigma));
+	const float z_inv = (a.rp.zfar - bz) / (a.rp.zfar - a.rp.znear);
+	const float z_inv_max = fmaxf(z_inv, eps);
+	const float wnum = prob * __expf((z_inv - z_inv_max) / a.rp.rgb_gamma);
+	const float delta = fmaxf(__expf((eps - z_inv_max) / a.rp.rgb_gamma), eps);
+	const float den = wnum + delta;
+#pragma unroll
+	for (int c = 0; c < 3; ++c) {
+		const float col = (a.rp.ambient + diff) * tex[c] + spec;
+		o[c] = (wnum * col + delta * a.rp.background[c]) / den;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ 5. ties at the K-th depth
+// PyTorch3D inserts fragments into a pixel's K-buffer in face order and a later fragment of EQUAL depth does not displace an earlier
+// one: of the candidates tied at the K-th depth, the `keep` lowest face indices stay.  (Ties are not exotic: a pixel outside a fan of
+// faces that share their nearest vertex gets that vertex's depth from every one of them.)  One wave per queued pixel walks the tile's
+// list with the face ids at hand, collects the candidates whose depth equals the K-th to the bit -- the same eval_frag, the same
+// rounding --, keeps the `keep` lowest ids and rewrites mask, alpha, the bound (negated: "ties at this depth are decided by
+// tie_face") and the id of the last face kept.
+__global__ __launch_bounds__(256) void tie_fix_kernel(const TileArgs a, const FaceRec* __restrict__ recs) {
+	constexpr int TIE_CAP = 128;
+	__shared__ int tf[4][TIE_CAP];
+	__shared__ float tq[4][TIE_CAP];
+	__shared__ float ts[4][TIE_CAP];
+	const int H = a.rp.image_h, W = a.rp.image_w;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const float blur = a.rp.sil_blur_radius;
+	const float inv_sigma = 1.0f / a.rp.sil_sigma;
+	const int n_fix = a.flags[7];
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	for (int i = blockIdx.x * 4 + wave; i < n_fix; i += gridDim.x * 4) {
+		const Fix fx = a.fix[i];
+		const int xi = fx.pix % W, yi = (fx.pix / W) % H, img = fx.pix / (W * H);
+		const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
+		const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+		const int tile_x = xi / T8, tile_y = yi / T8;
+		const int2 ti = a.tinfo[img * a.tiles_per_img + tile_y * a.tiles_x + tile_x];
+		const bool binned = ti.y >= 0;
+		const int n_list = binned ? (int)((uint32_t)ti.y & ~LIST_UNSORTED) : a.F;
+		const uint32_t* tbp = a.tb + (int64_t)img * a.F;
+		const uint32_t* lp = a.pool + (int64_t)img * a.pool_cap + ti.x;
+		int n_t = 0;
+		for (int i0 = 0; i0 < n_list; i0 += 64) {
+			const int j = i0 + lane;
+			int f = -1;
+			if (j < n_list) {
+				if (binned) f = (int)(lp[j] & FACE_MASK);
+				else if (tile_hit(tbp[j], tile_x, tile_y)) f = j;
+			}
+			bool tied = false;
+			float q = 1.0f;
+			if (f >= 0) {
+				const FaceRec r = recs[(int64_t)img * a.F + f];
+				Frag fr;
+				if (eval_frag(r, px, py, &fr) && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur) && __float_as_uint(fr.pz_clip + 0.0f) == fx.zk) {
+					tied = true;
+					q = 1.0f - silhouette_prob(fr.inside ? -fr.dist : fr.dist, inv_sigma);
+				}
+			}
+			const unsigned long long m = __ballot(tied);
+			const int pos = n_t + (int)__popcll(m & lt);
+			if (tied && pos < TIE_CAP) { tf[wave][pos] = f; tq[wave][pos] = q; }
+			n_t += (int)__popcll(m);
+		}
+		wave_lds_sync();
+		n_t = min(n_t, TIE_CAP);   // (more than TIE_CAP faces of one depth at one pixel: the first TIE_CAP in list order stand for all)
+		// rank by face id; the `keep` lowest, multiplied in id order
+		int last = -1;
+		for (int j = lane; j < n_t; j += 64) {
+			const int fj = tf[wave][j];
+			int rank = 0;
+			for (int k = 0; k < n_t; ++k) rank += tf[wave][k] < fj;
+			ts[wave][rank] = tq[wave][j];
+			if (rank == fx.keep - 1) last = fj;
+		}
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) last = max(last, __shfl_xor(last, d, 64));
+		wave_lds_sync();
+		if (lane == 0) {
+			float al = fx.a_lt;
+			const int nk = min(fx.keep, n_t);
+			for (int k = 0; k < nk; ++k) al *= ts[wave][k];
+			a.mask[fx.pix] = 1.0f - al;
+			a.alpha_ws[fx.pix] = al;
+			a.zthr[fx.pix] = -__uint_as_float(fx.zk);
+			a.tie_face[fx.pix] = last;
+		}
+		wave_lds_sync();
 	}
 }
 
@@ -834,19 +1229,18 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const TileArgs a) {
 // (PointTriangleDistanceBackward: nearest edge only, projection parameter treated as constant), butterfly-reduce them, and
 // lane 0 issues the six atomics.
 template <int LPF>
-__global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params rp, const float4* __restrict__ frec, const uint32_t* __restrict__ tb,
+__global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params rp, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ tb,
 													   const int32_t* __restrict__ faces, int64_t faces_mesh_stride, int n_views, int V, int F,
 													   const float* __restrict__ alpha_ws, const float* __restrict__ d_mask, const float* __restrict__ zthr,
-													   float* __restrict__ d_vproj) {
+													   const int32_t* __restrict__ tie_face, float* __restrict__ d_vproj) {
 	const int img = blockIdx.y;
 	const int sub = threadIdx.x & (LPF - 1);
 	const int f = blockIdx.x * (256 / LPF) + threadIdx.x / LPF;
 	const int64_t o = (int64_t)img * F + min(f, F - 1);
 	const bool act = f < F && tb[o] != TB_EMPTY;
 	const int H = rp.image_h, W = rp.image_w;
-	const float blur = rp.sil_blur_radius, br = sqrtf(blur);
-	FaceRec r;
-	make_rec(frec + o * 3, f, br, &r);
+	const float blur = rp.sil_blur_radius;
+	const FaceRec r = recs[o];
 	int xlo, xhi, ylo, yhi;
 	pix_range(r.xmin, r.xmax, W, &xlo, &xhi);
 	pix_range(r.ymin, r.ymax, H, &ylo, &yhi);
@@ -864,16 +1258,19 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 	};
 	int yi = 0, xi = 0;
 	float g = 0.f, zt = 0.f, mk = 0.f;
+	int64_t pix_cur = 0;
 	if (sub < npx) {
-		const int64_t pix = pixel_of(sub, &yi, &xi);
-		g = d_mask[pix]; zt = zthr[pix]; mk = alpha_ws[pix];
+		pix_cur = pixel_of(sub, &yi, &xi);
+		g = d_mask[pix_cur]; zt = zthr[pix_cur]; mk = alpha_ws[pix_cur];
 	}
 	for (int pi = sub; pi < npx; pi += LPF) {
 		const int cy = yi, cx = xi;
-		const float cg = g, czt = zt, cmk = mk;
+		const float cg = g, cmk = mk;
+		float czt = zt;
+		const int64_t cpix = pix_cur;
 		if (pi + LPF < npx) {
-			const int64_t pix = pixel_of(pi + LPF, &yi, &xi);
-			g = d_mask[pix]; zt = zthr[pix]; mk = alpha_ws[pix];
+			pix_cur = pixel_of(pi + LPF, &yi, &xi);
+			g = d_mask[pix_cur]; zt = zthr[pix_cur]; mk = alpha_ws[pix_cur];
 		}
 		const float py = 1.0f - (2.0f * cy + 1.0f) / (float)H;
 		{
@@ -882,7 +1279,13 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			Frag fr;
 			if (!eval_frag(r, px, py, &fr)) continue;
 			if (!(fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur))) continue;
-			if (fr.pz_clip > czt) continue;  // pixel with more than K candidates: this one is not among the K nearest
+			// pixel with more than K candidates: is this one among the K nearest?  (a negative bound: candidates tied AT that depth were
+			// sorted out by face index in the forward, tie_fix_kernel: those up to tie_face stay)
+			if (czt < 0.f) {
+				czt = -czt;
+				if (fr.pz_clip == czt && f > tie_face[cpix]) continue;
+			}
+			if (fr.pz_clip > czt) continue;
 			const float sd = fr.inside ? -fr.dist : fr.dist;
 			const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
 			const float alpha = cmk;
@@ -1181,7 +1584,7 @@ static int check_params(const find_render_params* rp, int64_t n_meshes, int64_t 
 	FIND_REQUIRE(rp != nullptr, "find_render: params is NULL");
 	FIND_REQUIRE(rp->image_h >= 1 && rp->image_w >= 1 && rp->image_h <= 2048 && rp->image_w <= 2048, "find_render: image size out of range (1 .. 2048: tile coordinates are packed in 8 bits)");
 	FIND_REQUIRE(n_meshes >= 1 && n_views >= 1 && n_views <= 256 && n_meshes * n_views < 65536, "find_render: bad batch (%lld meshes x %lld views)", (long long)n_meshes, (long long)n_views);
-	FIND_REQUIRE(V >= 1 && F >= 1 && V < (1ll << 28) && F < (1ll << 28), "find_render: bad mesh size");
+	FIND_REQUIRE(V >= 1 && F >= 1 && V < (1ll << 28) && F < (1ll << 24), "find_render: bad mesh size (a tile list entry holds the face index in 24 bits)");
 	FIND_REQUIRE(rp->sil_sigma > 0.f && rp->rgb_sigma > 0.f && rp->rgb_gamma > 0.f && rp->zfar > rp->znear, "find_render: bad blend parameters");
 	return FIND_OK;
 }
@@ -1212,16 +1615,15 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	const int V = (int)n_verts, F = (int)n_faces, H = rp->image_h, W = rp->image_w;
 	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
 	const float sc = 1.0f / tanf(rp->fov_deg * 3.14159265358979323846f / 180.0f * 0.5f);
-	(void)hipMemsetAsync(w.flags, 0, 64 * sizeof(int32_t), s);
+	(void)hipMemsetAsync(w.flags, 0, (64 + 64) * sizeof(int32_t) + 2 * n_img * CURSOR_STRIDE * sizeof(int32_t), s);   // flags, the class counts behind them, the pool cursors behind those
 	hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv(V, 256), (unsigned)n_img), dim3(256), 0, s, verts, R, T, sc, (int)n_views, V, w.vproj);
-	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one scan serves both
+	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one set of lists serves both
 	const float blur = mask ? rp->sil_blur_radius : 0.0f;
-	const bool per_wg = (find::g_raster_ablate & 128) == 0;   // bit 128: one wave per 8x8 tile (measured slower, see raster_tile_kernel)
-	const int TS = per_wg ? TS_WG : TS_WAVE;
-	const int tiles_x = (int)cdiv(W, TS), tiles_per_img = tiles_x * (int)cdiv(H, TS);
-	(void)hipMemsetAsync(w.tile_any, 0, 2 * n_img * cdiv(W, TS_WAVE) * cdiv(H, TS_WAVE) * sizeof(int32_t), s);   // flags and counts (both arrays, sized for the finer tiling)
+	const int tiles_x = (int)cdiv(W, T8), tiles_per_img = tiles_x * (int)cdiv(H, T8);
+	const int n_runs = (int)cdiv(F, 64);
 	hipLaunchKernelGGL(face_setup_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_img), dim3(256), 0, s, w.vproj, faces, fstride, (int)n_views, V, F, H, W,
-					   blur, rp->z_clip, w.frec, w.tb, w.tbb, w.flags, w.tile_any, w.tile_cnt, tiles_x, tiles_per_img, TS);
+					   blur, rp->z_clip, w.frec, w.recs, w.tb, w.tbb, w.fzmin, w.rz, w.flags);
+	hipLaunchKernelGGL(zinfo_kernel, dim3((unsigned)n_img), dim3(256), 0, s, w.tbb, w.rz, n_runs, w.zinfo);
 	if (image) {
 		(void)hipMemsetAsync(w.normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);
 		hipLaunchKernelGGL(normals_scatter_kernel, dim3((unsigned)cdiv(F, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, fstride, V, F, w.normals);
@@ -1232,17 +1634,30 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	TileArgs a;
 	memset(&a, 0, sizeof(a));
 	a.rp = *rp;
-	a.frec = w.frec; a.tb = w.tb; a.tbb = w.tbb; a.faces = faces; a.faces_mesh_stride = fstride;
+	a.tb = w.tb; a.tbb = w.tbb; a.fzmin = w.fzmin; a.zinfo = w.zinfo; a.faces = faces; a.faces_mesh_stride = fstride;
 	a.verts = verts; a.normals = w.normals; a.colors = vert_colors; a.cam = cam;
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = tiles_x;
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
-	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.flags = w.flags;
-	a.zthr = w.zthr; a.alpha_ws = w.alpha; a.scratch = w.scratch; a.tile_any = w.tile_any; a.tile_order = w.tile_order;
+	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.frag_ws = w.frag; a.flags = w.flags; a.qn = w.qn; a.cursor = w.cursor;
+	a.zthr = w.zthr; a.alpha_ws = w.alpha; a.tie_face = w.tie_face; a.scratch = w.scratch;
+	a.tinfo = w.tinfo; a.pool = w.pool; a.order = w.order; a.fix = w.fix; a.pool_cap = w.pool_cap;
 	a.tiles_per_img = tiles_per_img; a.total_tiles = (int)(a.tiles_per_img * n_img);
-	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, w.tile_any, w.tile_cnt, a.total_tiles, w.tile_order);
 	a.ablate = find::g_raster_ablate;
-	if (per_wg) hipLaunchKernelGGL(raster_tile_kernel<4>, dim3((unsigned)std::min<int64_t>(a.total_tiles, w.raster_wgs)), dim3(256), 0, s, a);
-	else hipLaunchKernelGGL(raster_tile_kernel<1>, dim3((unsigned)std::min<int64_t>(cdiv(a.total_tiles, 4), w.raster_wgs)), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(outside_kernel, dim3((unsigned)cdiv(tiles_per_img, 4), (unsigned)n_img), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(bin_kernel, dim3((unsigned)std::min<int64_t>(cdiv(a.total_tiles, 4), 1024)), dim3(256), 0, s, a, (int)n_img);
+	hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)cdiv(a.total_tiles, 1024)), dim3(1024), 0, s, w.tinfo, a.total_tiles, w.qn);
+	hipLaunchKernelGGL(order_fill_kernel, dim3((unsigned)cdiv(a.total_tiles, 1024)), dim3(1024), 0, s, w.tinfo, a.total_tiles, w.qn, w.order);
+	RasterArgs ra;
+	memset(&ra, 0, sizeof(ra));
+	ra.sil_blur_radius = rp->sil_blur_radius; ra.sil_sigma = rp->sil_sigma; ra.sil_faces_per_pixel = rp->sil_faces_per_pixel; ra.image_h = H; ra.image_w = W;
+	ra.tb = w.tb; ra.zinfo = w.zinfo; ra.tinfo = w.tinfo; ra.F = F; ra.tiles_x = tiles_x; ra.tiles_per_img = tiles_per_img; ra.pool_cap = w.pool_cap;
+	ra.mask = mask; ra.p2f_ws = a.p2f_ws; ra.frag_ws = w.frag; ra.flags = w.flags; ra.qn = w.qn; ra.zthr = w.zthr; ra.alpha_ws = w.alpha;
+	ra.scratch = w.scratch; ra.fix = w.fix; ra.ablate = a.ablate;
+	if (mask && a.p2f_ws) hipLaunchKernelGGL((raster_kernel<true, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
+	else if (mask) hipLaunchKernelGGL((raster_kernel<true, false>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
+	else hipLaunchKernelGGL((raster_kernel<false, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
+	if (a.p2f_ws) hipLaunchKernelGGL(shade_kernel, dim3((unsigned)cdiv(n_img * H * W, 256)), dim3(256), 0, s, a);
+	if (mask) hipLaunchKernelGGL(tie_fix_kernel, dim3(256), dim3(256), 0, s, a, w.recs);
 	FIND_LAUNCH_CHECK("find_render_fwd");
 	return FIND_OK;
 }
@@ -1274,14 +1689,14 @@ extern "C" int find_render_bwd(const find_render_params* rp, const float* verts,
 		const float side = 2.0f * sqrtf(rp->sil_blur_radius) * 0.5f * (float)std::max(H, W) + 2.0f;
 		// (8 lanes per face up to ~12 x 12 pixels, 16 up to ~25 x 25 -- 512^2: 17.5 x 17.5, measured 1 % of the C4 step better than 32 --, 32 above)
 		if (side * side > 640.0f)
-			hipLaunchKernelGGL(sil_bwd_kernel<32>, dim3((unsigned)cdiv(F, 8), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-							   w.alpha, d_mask, w.zthr, w.d_vproj);
+			hipLaunchKernelGGL(sil_bwd_kernel<32>, dim3((unsigned)cdiv(F, 8), (unsigned)n_img), dim3(256), 0, s, *rp, w.recs, w.tb, faces, fstride, (int)n_views, V, F,
+							   w.alpha, d_mask, w.zthr, w.tie_face, w.d_vproj);
 		else if (side * side > 160.0f)
-			hipLaunchKernelGGL(sil_bwd_kernel<16>, dim3((unsigned)cdiv(F, 16), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-							   w.alpha, d_mask, w.zthr, w.d_vproj);
+			hipLaunchKernelGGL(sil_bwd_kernel<16>, dim3((unsigned)cdiv(F, 16), (unsigned)n_img), dim3(256), 0, s, *rp, w.recs, w.tb, faces, fstride, (int)n_views, V, F,
+							   w.alpha, d_mask, w.zthr, w.tie_face, w.d_vproj);
 		else
-			hipLaunchKernelGGL(sil_bwd_kernel<8>, dim3((unsigned)cdiv(F, 32), (unsigned)n_img), dim3(256), 0, s, *rp, w.frec, w.tb, faces, fstride, (int)n_views, V, F,
-						   w.alpha, d_mask, w.zthr, w.d_vproj);
+			hipLaunchKernelGGL(sil_bwd_kernel<8>, dim3((unsigned)cdiv(F, 32), (unsigned)n_img), dim3(256), 0, s, *rp, w.recs, w.tb, faces, fstride, (int)n_views, V, F,
+						   w.alpha, d_mask, w.zthr, w.tie_face, w.d_vproj);
 	}
 	if (d_image) {
 		(void)hipMemsetAsync(w.d_normals, 0, n_meshes * n_verts * 3 * sizeof(float), s);

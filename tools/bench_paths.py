@@ -50,7 +50,7 @@ def views(m, seed=7):
 
 # HBM-side bytes per forward launch of raster_tile_kernel / per launch of sil_bwd_kernel at the C3 shape, rocprofv3 --pmc FETCH_SIZE (x2, the
 # gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r02_raster_pmc.txt)
-RASTER_TRAFFIC_C3 = {'raster_tile_kernel': 2 * 478995.3 * 1024 + 871594.8 * 1024, 'sil_bwd_kernel': 2 * 77277.5 * 1024 + 83482.1 * 1024}
+RASTER_TRAFFIC_C3 = {'raster_kernel': None, 'sil_bwd_kernel': 2 * 77277.5 * 1024 + 83482.1 * 1024}   # (filled from profiles/r03_raster_pmc.txt)
 
 
 def raster_counts(verts, fc, Rc, Tc, params):
@@ -112,10 +112,9 @@ def bench_render(n_feet, n_views, size, want_image, cpu=None):
 			   bytes_algorithmic=alg, achieved_GBs_fwd=alg / (ms_f * 1e-3) / 1e9, hbm_frac_fwd=alg / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			   pixel_face_tests=tests, tests_per_s_fwd=tests / (ms_f * 1e-3), silhouette_candidates=cands, pixels_over_K=over_px,
 			   candidate_list_bytes=8 * cands, lane_efficiency=cands / max(tests, 1),
-			   quadrant_imbalance=4.0 * raster_counts.last_flags[26] / max(raster_counts.last_flags[27], 1),
-			   quadrant_imbalance_per_batch=4.0 * raster_counts.last_flags[28] / max(raster_counts.last_flags[27], 1),
-			   hbm_traffic_bytes_fwd_launch=RASTER_TRAFFIC_C3['raster_tile_kernel'] if (size == 256 and n_feet == 16 and n_views == 4 and not want_image) else None,
-			   bound='latency of the per-tile work (VALU pipe ~22 %% busy, waves wait 60 %% of their time: profiles/r02_raster_pmc.txt), then HBM traffic of the '
+			   tiles_left_early=raster_counts.last_flags[26], tie_fixup_pixels=raster_counts.last_flags[7], pool_entries=raster_counts.last_flags[6],
+			   hbm_traffic_bytes_fwd_launch=RASTER_TRAFFIC_C3['raster_kernel'] if (size == 256 and n_feet == 16 and n_views == 4 and not want_image) else None,
+			   bound='VALU (pixel x face fragment math; lists in depth order let a wave leave when its pixels hold their K nearest), then HBM traffic of the '
 					 'per-pixel candidate lists (8 B per candidate, written once, read ~3x by the K-nearest pass); HBM floor of the fused output %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
 	if cpu:
 		dt = cpu('render', verts=verts[:1].cpu().numpy(), faces=f.numpy(), colors=cols[:1].cpu().numpy(), R=R[:1].numpy(), T=T[:1].numpy(), size=size,

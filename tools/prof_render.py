@@ -14,6 +14,9 @@ rng = np.random.RandomState(7)
 R, T = look_at_view_transform(dist=np.full(4, 0.3), elev=rng.uniform(-90, 90, 4), azim=rng.uniform(-90, 90, 4), up=((1, 0, 0),))
 R, T, fc = R.cuda(), T.cuda(), f.cuda()
 params = FR.make_params(size)
+if len(sys.argv) > 3:
+	from find_amd import _lib
+	_lib.set_tuning('raster_ablate', int(sys.argv[3]))
 gt = torch.rand(16, 4, size, size, generator=g).cuda()
 for _ in range(6):
 	vg = verts.detach().requires_grad_(True)
