@@ -94,9 +94,9 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	const int64_t px = n_img * rp->image_h * rp->image_w;
 	o->flags = c.take<int32_t>(64);
 	o->qn = c.take<int32_t>(64);
-	// per image: entries handed out of its part of the pool, tiles of its bbox handed out -- one counter per 128-byte line (atomics on
-	// one line are served one after the other, ~50 ns each: 64 counters packed into two lines were the slowest thing in the binning kernel)
-	o->cursor = c.take<int32_t>(2 * n_img * CURSOR_STRIDE);
+	// per image: entries handed out of its part of the pool -- one counter per 128-byte line (atomics on one line are served one after
+	// the other, ~50 ns each: 64 counters packed into two lines were the slowest thing in the binning kernel, 260 us)
+	o->cursor = c.take<int32_t>(n_img * CURSOR_STRIDE);
 	o->vproj = c.take<float>(n_img * V * 3);
 	o->frec = c.take<float4>(n_img * F * 3);
 	o->recs = reinterpret_cast<FaceRec*>(c.take<float4>(n_img * F * 5));
@@ -627,6 +627,10 @@ __global__ __launch_bounds__(256) void outside_kernel(const TileArgs a) {
 	write_background(a, img, tile_x, tile_y, lane);
 }
 
+// Persistent waves: a plain one-wave-per-tile launch leaves three quarters of the wave slots to tiles that have nothing to do (most of an
+// image is empty, and a workgroup's slots stay taken until its busiest wave is through: 260 us against 120).  The waves are dealt out to
+// the images (wave w: image w mod n_img), and the waves of an image stride over the tiles of its bbox -- no counter to ask (a counter per
+// image cost 90 us in atomics alone).
 __global__ __launch_bounds__(256) void bin_kernel(const TileArgs a, int n_img) {
 	__shared__ uint32_t la[4][BIN_CAP];
 	__shared__ int lh[4][256];
@@ -634,22 +638,17 @@ __global__ __launch_bounds__(256) void bin_kernel(const TileArgs a, int n_img) {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	const int F = a.F, n_runs = (F + 63) >> 6;
-	// Persistent waves: a plain one-wave-per-tile launch left three quarters of the wave slots to tiles that have nothing to do (most of an
-	// image is empty, and a workgroup's slots stay taken until its busiest wave is through).  Every wave starts at an image of its own and
-	// takes the tiles of that image's bbox from the image's counter, then moves on to the next image that still has some.
-	int img = (blockIdx.x * 4 + wave) % n_img;
-	for (int visited = 0; visited < n_img;) {
+	const int gw = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
+	// images handled by this wave: gw mod n_img, and -- more images than waves -- every n_waves-th after it
+	for (int img = gw % n_img; img < n_img; img += max(n_waves, n_img)) {
 		const int32_t* zi = a.zinfo + img * 8;
 		const int bx0 = zi[4], bx1 = zi[5], by0 = zi[6], by1 = zi[7];
 		const int nbx = bx1 - bx0 + 1, n_in = bx1 >= bx0 ? nbx * (by1 - by0 + 1) : 0;
-		int tq = n_in;
-		if (lane == 0 && *reinterpret_cast<volatile int32_t*>(a.cursor + (n_img + img) * CURSOR_STRIDE) < n_in) tq = atomicAdd(&a.cursor[(n_img + img) * CURSOR_STRIDE], 1);
-		tq = __builtin_amdgcn_readfirstlane(tq);
-		if (tq >= n_in) { img = img + 1 == n_img ? 0 : img + 1; ++visited; continue; }
-		visited = 0;
-		const int tile_x = bx0 + tq % nbx, tile_y = by0 + tq / nbx;
-		const int t = tile_y * a.tiles_x + tile_x;
-		bin_tile(a, la[wave], lh[wave], lr[wave], img, t, tile_x, tile_y, lane, lt, F, n_runs);
+		const int per_img = max(n_waves / n_img, 1);   // waves that share this image
+		for (int tq = gw / n_img; tq < n_in; tq += per_img) {
+			const int tile_x = bx0 + tq % nbx, tile_y = by0 + tq / nbx;
+			bin_tile(a, la[wave], lh[wave], lr[wave], img, tile_y * a.tiles_x + tile_x, tile_x, tile_y, lane, lt, F, n_runs);
+		}
 	}
 }
 
@@ -773,6 +772,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 		}
 	};
 
+	// (Measured and dropped: every wave's first tile by its own number instead of from the counter -- the 4096 first requests queue up
+	// for ~48 us on that one address -- made the kernel 0.4 ms SLOWER: the staggered start spreads the longest lists, which all sit at
+	// the head of the order, over time and over the CUs.)
 	for (;;) {
 		int t_q = 0;
 		if (lane == 0) t_q = atomicAdd(&a.flags[3], 1);
@@ -1615,7 +1617,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	const int V = (int)n_verts, F = (int)n_faces, H = rp->image_h, W = rp->image_w;
 	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
 	const float sc = 1.0f / tanf(rp->fov_deg * 3.14159265358979323846f / 180.0f * 0.5f);
-	(void)hipMemsetAsync(w.flags, 0, (64 + 64) * sizeof(int32_t) + 2 * n_img * CURSOR_STRIDE * sizeof(int32_t), s);   // flags, the class counts behind them, the pool cursors behind those
+	(void)hipMemsetAsync(w.flags, 0, (64 + 64) * sizeof(int32_t) + n_img * CURSOR_STRIDE * sizeof(int32_t), s);   // flags, the class counts behind them, the pool cursors behind those
 	hipLaunchKernelGGL(project_kernel, dim3((unsigned)cdiv(V, 256), (unsigned)n_img), dim3(256), 0, s, verts, R, T, sc, (int)n_views, V, w.vproj);
 	// the silhouette's blur margin is a superset of the RGB pass's (blur 0); one set of lists serves both
 	const float blur = mask ? rp->sil_blur_radius : 0.0f;
@@ -1644,7 +1646,7 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.tiles_per_img = tiles_per_img; a.total_tiles = (int)(a.tiles_per_img * n_img);
 	a.ablate = find::g_raster_ablate;
 	hipLaunchKernelGGL(outside_kernel, dim3((unsigned)cdiv(tiles_per_img, 4), (unsigned)n_img), dim3(256), 0, s, a);
-	hipLaunchKernelGGL(bin_kernel, dim3((unsigned)std::min<int64_t>(cdiv(a.total_tiles, 4), 1024)), dim3(256), 0, s, a, (int)n_img);
+	hipLaunchKernelGGL(bin_kernel, dim3((unsigned)std::max<int64_t>(std::min<int64_t>(cdiv(a.total_tiles, 4), 1024), cdiv(n_img, 4))), dim3(256), 0, s, a, (int)n_img);
 	hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)cdiv(a.total_tiles, 1024)), dim3(1024), 0, s, w.tinfo, a.total_tiles, w.qn);
 	hipLaunchKernelGGL(order_fill_kernel, dim3((unsigned)cdiv(a.total_tiles, 1024)), dim3(1024), 0, s, w.tinfo, a.total_tiles, w.qn, w.order);
 	RasterArgs ra;
