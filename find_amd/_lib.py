@@ -55,6 +55,7 @@ PROTOTYPES = {
 	'find_debug_stream_groups': (c_int, [_P, _P, _P]),
 	'find_ctx_set': (c_int, [_P, c_char_p, _I]),
 	'find_ctx_get': (c_int, [_P, c_char_p, POINTER(c_int64)]),
+	'find_ctx_join': (c_int, [_P, _P]),
 	'find_debug_raster_ablate': (c_int, [_I]),
 	'find_mlp_ws_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I, c_int]),
 	'find_mlp_fwd': (c_int, [_P, POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, c_int, _P]),

@@ -154,6 +154,9 @@ struct find_ctx {
 	int next = 0;
 	int events_per_call_max = 0;
 	bool attr_done[K_COUNT] = {};
+	int defer_join = 0;           // knob, read by the next find_mlp_bwd: leave the weight-gradient side streams running behind the call (find_hip.h)
+	hipEvent_t pend_ev[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};   // end of the deferred work on each side stream
+	bool pend[N_SIDE] = {};       // side stream k carries deferred work nobody has waited for yet
 	// set per call
 	bool f16 = false;
 };
@@ -289,9 +292,18 @@ struct Fork {
 		order(c->side[from], c->side[to]);
 	}
 	int join() {
+		// (also what an earlier call left running there: find_ctx.pend -- streams are FIFO, waiting for this call's end covers it)
+		for (int k = 0; k < N_SIDE; ++k)
+			if ((on && used[k]) || (c->pend[k] && !capturing)) { order(c->side[k], s); used[k] = false; c->pend[k] = false; }
+		c->events_per_call_max = std::max(c->events_per_call_max, n_ev);
+		return rc;
+	}
+	// instead of join(): the side streams this call touched keep running behind it; whoever needs their results waits for pend_ev
+	// (find_ctx_join, or the join() of a later call).  Only the caller may know that nothing reads them before that.
+	int defer() {
 		if (on)
 			for (int k = 0; k < N_SIDE; ++k)
-				if (used[k]) { order(c->side[k], s); used[k] = false; }
+				if (used[k]) { fail(hipEventRecord(c->pend_ev[k], c->side[k]), "hipEventRecord"); c->pend[k] = true; used[k] = false; }
 		c->events_per_call_max = std::max(c->events_per_call_max, n_ev);
 		return rc;
 	}
@@ -919,7 +931,7 @@ static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, const fl
 }
 
 static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const Dims& d, const FwdWs& w, const BwdWs& b, const float* pos,
-						const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col, const find_mlp_grads* g) {
+						const float* lat_disp, const float* lat_col, const float* d_disp, const float* d_col, const find_mlp_grads* g, bool defer) {
 	hipStream_t s = fk.s;
 	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
@@ -1108,8 +1120,17 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		auto head_wgrads = [&](int nl, float* const* act, float* const* dzbuf, int cur_last, float* const* gw, float* const* gb, const float* w0full, int ld0,
 							   const float* lat, int L, float* S, float* glat) -> int {
 			for (int l = nl - 1; l >= 1; --l) FIND_TRY(one(dzbuf[nl - 1 - l], act[l - 1], V * W, n_feet, gw[l], W, gb[l], nullptr));
-			FIND_TRY(one(dzbuf[cur_last], hl, hl_stride, n_feet, gw[0], ld0, gb[0], (L > 0) ? S : nullptr));
-			if (L > 0) lats[nlat++] = Lat{w0full, ld0, lat, L, S, glat, gw[0]};
+			if (defer && L > 0) {
+				// the weight gradients stay behind on the side streams: the latent gradients -- an OUTPUT autograd hands to whatever comes
+				// next -- are formed on the caller's stream, from per-foot column sums of their own (no slab reduce to wait for)
+				float* ps = (gw == g->disp_w) ? b.pS : b.pS2;
+				hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur_last], (int)n_feet, (int)V, (float*)nullptr, ps);
+				hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, s, ps, b.nblk_fs, (int)n_feet, S);
+				hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0], (float*)nullptr);
+				FIND_LAUNCH_CHECK("latent gradients (deferred join)");
+			}
+			FIND_TRY(one(dzbuf[cur_last], hl, hl_stride, n_feet, gw[0], ld0, gb[0], (L > 0 && !defer) ? S : nullptr));
+			if (L > 0 && !defer) lats[nlat++] = Lat{w0full, ld0, lat, L, S, glat, gw[0]};
 			return FIND_OK;
 		};
 		if (act_d) FIND_TRY(head_wgrads(p->n_disp, w.D, b.dzD, cd2, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp));
@@ -1352,11 +1373,30 @@ extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* 
 	}
 	c->f16 = call_f16(c, p);
 	Fork fk(c, reinterpret_cast<hipStream_t>(stream), c->bwd_streams != 0);
-	const int rc = mlp_bwd_body(c, fk, p, d, w, b, pos, lat_disp, lat_col, d_disp, d_col, g);
+	// "defer_join" (one call: the knob is taken down here): the weight gradients of a small per-foot call -- the texture pass of a
+	// train_3d step, 0.28 ms of grouped and Fourier-layer weight gradients that nothing reads until the main pass adds its own -- keep
+	// running on the side streams while the caller's stream goes on; find_ctx_join (or the join of the next call) waits for them.
+	// The caller keeps scratch, workspace and gradient buffers alive until then.  Not under stream capture, not for the large-call paths.
+	const bool defer = c->defer_join != 0 && fk.on && !fk.capturing && !d.shared && use_fused(c, d.V, d.feet_t) && p->pe_size > 0 && g->trunk_w[0] != nullptr;
+	c->defer_join = 0;
+	const int rc = mlp_bwd_body(c, fk, p, d, w, b, pos, lat_disp, lat_col, d_disp, d_col, g, defer);
 	// join on EVERY path: the caller's stream continues only after every side stream this call touched has finished, so scratch,
 	// workspace and gradient buffers may be freed (stream-ordered) as soon as the call returns -- also after an error
-	const int rj = fk.join();
+	const int rj = (defer && rc == FIND_OK) ? fk.defer() : fk.join();
 	return rc != FIND_OK ? rc : rj;
+}
+
+// Make `stream` wait for the side-stream work an earlier find_mlp_bwd left running ("defer_join").  Returns 1 if there was any, 0 if not.
+extern "C" int find_ctx_join(find_ctx* c, void* stream) {
+	FIND_TRY(check_ctx(c, "find_ctx_join"));
+	int any = 0;
+	for (int k = 0; k < N_SIDE; ++k)
+		if (c->pend[k]) {
+			FIND_HIP_OK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->pend_ev[k], 0), "hipStreamWaitEvent");
+			c->pend[k] = false;
+			any = 1;
+		}
+	return any ? 1 : FIND_OK;
 }
 
 // ------------------------------------------------------------------------------------------- streams and hardware queues
@@ -1502,6 +1542,8 @@ extern "C" int find_ctx_create(int device, find_ctx** out) {
 		if ((e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreateWithFlags", e);
 	for (c->n_events = 0; c->n_events < N_EVENTS; ++c->n_events)
 		if ((e = hipEventCreateWithFlags(&c->ev[c->n_events], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", e);
+	for (int i = 0; i < N_SIDE; ++i)
+		if ((e = hipEventCreateWithFlags(&c->pend_ev[i], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", e);
 	FIND_HIP_OK(hipSetDevice(prev), "hipSetDevice");
 	*out = c;
 	return FIND_OK;
@@ -1525,7 +1567,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };
 }  // namespace
 
@@ -1557,6 +1599,7 @@ extern "C" int find_ctx_set(find_ctx* c, const char* key, int64_t value) {
 extern "C" int find_ctx_get(const find_ctx* c, const char* key, int64_t* value) {
 	FIND_REQUIRE(c != nullptr && key != nullptr && value != nullptr, "find_ctx_get: NULL argument");
 	if (strcmp(key, "num_cus") == 0) { *value = c->num_cus; return FIND_OK; }
+	if (strcmp(key, "pending") == 0) { *value = (c->pend[0] || c->pend[1] || c->pend[2] || c->pend[3]) ? 1 : 0; return FIND_OK; }
 	if (strcmp(key, "lds_bytes") == 0) { *value = c->lds_bytes; return FIND_OK; }
 	if (strcmp(key, "device") == 0) { *value = c->device; return FIND_OK; }
 	if (strcmp(key, "events_per_call_max") == 0) { *value = c->events_per_call_max; return FIND_OK; }

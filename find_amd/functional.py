@@ -123,7 +123,7 @@ class _MLP(torch.autograd.Function):
 
 	@staticmethod
 	def forward(ctx, spec, pos, lat_disp, lat_col, B, avg_col, *weights):
-		spec, heads = spec if isinstance(spec, tuple) else (spec, 3)   # heads: bit 0 = displacement, bit 1 = colour
+		spec, heads, defer = spec if isinstance(spec, tuple) else (spec, 3, False)   # heads: bit 0 = displacement, bit 1 = colour
 		if len(weights) != spec.n_weights:
 			raise RuntimeError(f'find_amd.mlp: expected {spec.n_weights} weight tensors, got {len(weights)}')
 		_require_gpu(pos, lat_disp, lat_col, B, avg_col, *weights)
@@ -169,6 +169,7 @@ class _MLP(torch.autograd.Function):
 			ctx.dims = (pos_batch, n_feet, V)
 			ctx.ws = ws
 			ctx.leaves = leaves
+			ctx.defer = bool(defer)
 			# an output nothing reads hands None to backward, not a tensor of zeros: the main pass of a train_3d.yaml step never reads its
 			# colours (no pixel loss), and a materialised zero gradient sent the whole colour head through its backward on zeros
 			ctx.set_materialize_grads(False)
@@ -232,9 +233,25 @@ class _MLP(torch.autograd.Function):
 		G.lat_col = ptr(g_lat_col)
 		sb = L.find_mlp_bwd_scratch_bytes(ctypes.byref(p), pos_batch, n_feet, V)
 		scratch = _ws(sb, pos.device)
-		check(L.find_mlp_bwd(_lib.ctx(pos.device), ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
+		# Deferred join (find_hip.h: "defer_join"): this call's weight gradients may keep running on the context's side streams while
+		# autograd goes on to the next node -- the texture pass's are 0.28 ms that nothing reads before the main pass folds its own into
+		# them.  Safe only while nobody else can touch them first: leaf weights without an existing .grad (AccumulateGrad then just
+		# adopts the tensor: no kernel), no double backward, the first MLP backward of the task; every buffer the side streams still use
+		# is kept alive until the join, which happens at the end of the next find_mlp_bwd or -- at the latest -- when backward() ends.
+		h = _lib.ctx(pos.device)
+		defer = (DEFER_WGRAD_JOIN and ctx.defer and can_park and not fold and idx and all(w.grad is None for w in weights))
+		if defer:
+			check(L.find_ctx_set(h, b'defer_join', 1), 'find_ctx_set(defer_join)')
+		check(L.find_mlp_bwd(h, ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
 							 ptr(ctx.ws), ctx.ws.numel(), ptr(scratch), scratch.numel(), ctypes.byref(G),
 							 current_stream(pos.device)), 'find_mlp_bwd')
+		if defer and _lib.get_tuning('pending', pos.device):
+			# (the gradients by their BASE buffers: a second reference to a gradient tensor itself would make AccumulateGrad copy it -- on
+			# this stream, while the side streams are still writing it -- instead of adopting it)
+			bases = {id(g._base): g._base for g in grads if g is not None and g._base is not None}
+			_hold_until_join(pos.device, [scratch, ctx.ws, g_disp, g_col, pos, lat_disp, lat_col, *weights, *bases.values()])
+		elif _DEFERRED:
+			_join_deferred()   # (this call's own join has waited for what an earlier one left running: its buffers may go)
 		if fold:
 			# add into the parked gradients where the first call parked one; a weight it had nothing for gets this call's gradient as its own
 			slots = pending[1]
@@ -250,6 +267,27 @@ class _MLP(torch.autograd.Function):
 		return (None, None, g_lat_disp, g_lat_col, None, None, *grads)
 
 
+import os as _os
+DEFER_WGRAD_JOIN = _os.environ.get('FIND_DEFER_WGRADS', '1') != '0'   # switch for A/B runs
+_DEFERRED = {}   # device -> tensors the side streams of a deferred find_mlp_bwd may still be using
+
+
+def _hold_until_join(device, tensors):
+	first = not _DEFERRED
+	_DEFERRED.setdefault(device, []).extend(t for t in tensors if t is not None)
+	if first:
+		# the latest moment: the end of this backward pass, on the thread and stream that run it
+		torch.autograd.Variable._execution_engine.queue_callback(_join_deferred)
+
+
+def _join_deferred():
+	"""Make the current stream of every device with deferred weight-gradient work wait for it, then let the buffers go."""
+	L = _lib.lib()
+	for device in list(_DEFERRED):
+		check(min(L.find_ctx_join(_lib.ctx(device), current_stream(device)), 0), 'find_ctx_join')
+	_DEFERRED.clear()
+
+
 _PENDING_WGRADS = {}   # weight data_ptrs -> (autograd graph-task id, [(flat buffer, offset)] of the gradients the first backward of that task handed to
                         # the engine, the stream they were produced on)
 
@@ -259,15 +297,17 @@ def _graph_task_id():
 	return int(f()) if f is not None else -1
 
 
-def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights, want=('disp', 'col')):
+def mlp(spec, pos, lat_disp, lat_col, B, avg_col, weights, want=('disp', 'col'), defer_wgrad_join=False):
 	"""Fused Fourier-PE + trunk + heads.  pos (1|N, V, 3); lat_disp (N, Ld)|None; lat_col (N, Lc)|None;
 	weights: flat list [trunk w,b ..., disp w,b ..., col w,b ...] in reference state_dict order.
 	Returns disp (N,V,3), col (N,V,3)   (reference: NeuralDisplacementField.forward, model.py:393-453); a head that `want` does not
-	name is not evaluated and comes back as None (its parameters then get no gradient from this call, as a head nothing reads)."""
+	name is not evaluated and comes back as None (its parameters then get no gradient from this call, as a head nothing reads).
+	defer_wgrad_join: this call's backward may return before its weight-gradient kernels have finished (see _MLP.backward); for a small
+	per-foot call whose weight gradients nothing reads before a later MLP backward or the end of the pass: FIND's texture term."""
 	heads = (1 if 'disp' in want else 0) | (2 if 'col' in want else 0)
 	if heads == 0:
 		raise ValueError("find_amd.mlp: want must name 'disp', 'col' or both")
-	return _MLP.apply((spec, heads), pos, lat_disp, lat_col, B, avg_col, *weights)
+	return _MLP.apply((spec, heads, defer_wgrad_join), pos, lat_disp, lat_col, B, avg_col, *weights)
 
 
 # ----------------------------------------------------------------------------------------------- registration

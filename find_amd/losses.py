@@ -65,7 +65,8 @@ class TextureLossGTSpace(nn.Module):
 		shapevec = shapevec if shapevec is not None else batch.get('shapevec', None)
 		posevec = posevec if posevec is not None else batch.get('posevec', None)
 		# (only the colour head is read below: a model that can skip the displacement head does)
-		only_col = dict(want=('col',)) if 'want' in getattr(getattr(model.forward, '__code__', None), 'co_varnames', ()) else {}
+		# (... and its weight gradients may trail behind the rest of the backward pass: nothing reads them before the pass ends)
+		only_col = dict(want=('col',), defer_wgrad_join=True) if 'want' in getattr(getattr(model.forward, '__code__', None), 'co_varnames', ()) else {}
 		res = model(sampled_verts.detach(), texvec=texvec, shapevec=shapevec, posevec=posevec, **only_col)
 		# F.mse_loss(reduction='none') * mask, .mean() with mask = any(gt < 1) per point (losses.py:43,55-57), as one kernel
 		return FN.masked_mse(res['col'], sampled_gt_colours)

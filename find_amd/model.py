@@ -380,10 +380,11 @@ class NeuralDisplacementField(Model):
 		return vecs[0] if len(vecs) == 1 else torch.cat(vecs, dim=-1)
 
 	# ------------------------------------------------------------------ reference API
-	def forward(self, pos, shapevec=None, texvec=None, posevec=None, want=('disp', 'col')):
+	def forward(self, pos, shapevec=None, texvec=None, posevec=None, want=('disp', 'col'), defer_wgrad_join=False):
 		"""pos [B|1, V, 3]; shapevec/texvec/posevec [B, L] -> dict(disp [B,V,3], col [B,V,3])   (model.py:393-453).
 		A batch-1 `pos` with batched latents is evaluated once through the trunk and shared by every foot.
-		`want` (not in the reference, which always evaluates both heads): the heads to evaluate -- the texture loss reads 'col' only."""
+		`want` (not in the reference, which always evaluates both heads): the heads to evaluate -- the texture loss reads 'col' only;
+		defer_wgrad_join: see find_amd.functional.mlp."""
 		if self.onnx_mode:
 			raise NotImplementedError('onnx_mode (web export) is out of scope')
 		if pos.dim() != 3 or pos.shape[-1] != self.input_dim:
@@ -398,7 +399,7 @@ class NeuralDisplacementField(Model):
 		enc = self.encoder[0] if len(self.encoder) else None
 		B = enc.B(pos.device) if enc is not None else None
 		avg = self.avg_col if self.use_avg_colour else None
-		disp, col = FN.mlp(self._spec, pos, lat_disp, lat_col, B, avg, self._weights(), want=want)
+		disp, col = FN.mlp(self._spec, pos, lat_disp, lat_col, B, avg, self._weights(), want=want, defer_wgrad_join=defer_wgrad_join)
 		return {k: v for k, v in (('disp', disp), ('col', col)) if v is not None}
 
 	def get_meshes(self, shapevec=None, reg=None, texvec=None, posevec=None, no_displacement=False, include_texture=True):

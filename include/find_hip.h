@@ -131,6 +131,10 @@ int find_mlp_bwd(find_ctx* ctx, const find_mlp_params* p, const float* pos, int6
 				 const void* ws, int64_t ws_bytes, void* scratch, int64_t scratch_bytes,
 				 const find_mlp_grads* grads, void* stream);
 
+/* Make `stream` wait for weight-gradient work a find_mlp_bwd left running under the "defer_join" knob.  Returns 1 if there was any,
+ * 0 if not, a negative code on error. */
+int find_ctx_join(find_ctx* ctx, void* stream);
+
 /* One hidden layer  y = relu(x @ w^T + b)  with x (n_feet*n_pts, 256), w (256,256), b (256): the dominant kernel
  * of the path (nn.Linear + nn.ReLU pairs built at src/model/model.py:255-257, 353-356, 362-365).  Exposed so the
  * kernel can be timed and checked in isolation; find_mlp_fwd launches the same kernel.  w must be 16-byte aligned. */
@@ -158,6 +162,11 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "bind_streams"    1 (default) = the first call that forks picks the four side streams among a dozen candidates by probing which
  *                     hardware queue each one shares (see find_debug_stream_groups); 0 = keep them as created
  *   "r_queue"         which side stream's hardware queue the slab-reduce stream shares: 0 = Q, 1 = T1, 2 = T2 (default, measured best)
+ *   "defer_join"      1 = the NEXT find_mlp_bwd, if it is a small per-foot call (the fused-chain path: the texture pass of a train_3d step),
+ *                     returns with its weight-gradient kernels still running on the context's side streams; its latent gradients are
+ *                     complete on the caller's stream.  The weight-gradient buffers, `scratch` and `ws` of that call must stay untouched
+ *                     until find_ctx_join() -- or the end of a later find_mlp_bwd on this context -- has made the reader's stream wait.
+ *                     The knob resets itself with the call.  Ignored under stream capture and for the large-call paths.
  *   "mlp_f16"         default precision for calls whose find_mlp_params.precision is 0, and the precision of find_linear_relu_fwd /
  *                     find_linear_wgrad: 1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to
  *                     fp16, fp32 accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES

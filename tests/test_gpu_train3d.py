@@ -233,11 +233,10 @@ def test_graphed_step_equals_eager_steps():
 	start = dict(_setup(n_verts, gt_verts)[0].model.named_parameters())
 	lr, n_steps = 5e-4, len(order)
 	for n, p in eager.items():
-		d = (graph[n].detach() - p).abs().max().item()
-		moved = (p - start[n].detach()).abs().max().item()
-		# Adam's update lr * m / (sqrt(v) + eps) is scale-free: a weight whose gradient is a cancellation of many terms sees the 1e-7
-		# summation-order noise of the atomics in the sampling backward as a visible fraction of its step (two EAGER runs differ the same
-		# way), and the capturable path forms its bias corrections in fp32.  Bound: 4 % of the distance the steps can move a weight
-		# (measured 2.7 % over six steps).
-		assert d < 0.04 * lr * n_steps, (n, d, moved)
+		# Adam's update lr * m / (sqrt(v) + eps) is scale-free: an element whose gradient is rounding noise (float atomics in the sampling
+		# backward: two EAGER runs differ the same way) moves by lr * sign(noise) per step, and the capturable path forms its bias corrections
+		# in fp32.  So: all but a thousandth of the elements agree to 1e-5, none is further apart than a few such flips.
+		d = (graph[n].detach() - p).abs()
+		assert (d > 1e-5).float().mean().item() < 1e-3, (n, (d > 1e-5).float().mean().item())
+		assert d.max().item() < 0.1 * lr * n_steps, (n, d.max().item())
 	assert not torch.equal(eager['base.2.weight'], _setup(n_verts, gt_verts)[0].model.base[2].weight.detach())   # the steps did move the weights

@@ -312,8 +312,13 @@ def test_trainer_graph_replays_equal_eager_epochs(tmp_path):
 	assert not os.path.exists(tmp_path / 'auto' / 'train' / '0001_00.png')
 	lr, n_steps = 1e-3, 3 * 4 + 3 * 2
 	for n in p_e:
-		d = (p_g[n] - p_e[n]).abs().max().item()
-		assert d < 0.04 * lr * n_steps, (n, d)   # bound as in test_graphed_step_equals_eager_steps (Adam amplifies 1e-7 summation noise; measured 2.5 %)
+		# Two runs of the SAME loop are not bit-identical (float atomics in the sampling backward), and Adam's first steps move an element by
+		# lr * sign(gradient) whatever the gradient's size: an element whose gradient is rounding noise may end a step of lr apart.  So: all but
+		# a thousandth of the elements agree to 1e-5, and none is further apart than a few such flips (tools/check_defer.py: two eager runs differ
+		# by 2e-6 most of the time and by 7.5e-4 -- one element -- now and then).
+		d = (p_g[n] - p_e[n]).abs()
+		assert (d > 1e-5).float().mean().item() < 1e-3, (n, (d > 1e-5).float().mean().item())
+		assert d.max().item() < 0.1 * lr * n_steps, (n, d.max().item())
 	for epoch in (0, 1, 2):
 		for part in ('train_loss', 'val_loss'):
 			a, b = tr_g.log[epoch][part], tr_e.log[epoch][part]
