@@ -42,6 +42,8 @@ TERMS = (
 
 # the GT render on a second stream beside the predicted one (ModelWithLoss._render_gt); FIND_OVERLAP_GT_RENDER=0 turns it off
 OVERLAP_GT_RENDER = os.environ.get('FIND_OVERLAP_GT_RENDER', '1') != '0'
+# the Chamfer term on that second stream beside the texture term's MLP pass (ModelWithLoss.forward); FIND_OVERLAP_CHAMFER=0 turns it off
+OVERLAP_CHAMFER = os.environ.get('FIND_OVERLAP_CHAMFER', '1') != '0'
 _SECOND_STREAMS = {}
 
 
@@ -224,11 +226,27 @@ class ModelWithLoss(nn.Module):
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
 
 		raw, weights = {}, []
-		for term in TERMS:
-			if not enabled[term.flag] or (term.needs_3d and not supervise_3d) or (term.needs_render and not rendering):
-				continue
-			raw[term.key] = getattr(self, term.fn)(st)
+		active = [t for t in TERMS if enabled[t.flag] and not (t.needs_3d and not supervise_3d) and not (t.needs_render and not rendering)]
+		# The Chamfer term -- surface sampling and a brute-force nearest-neighbour search: packed fp32 VALU work, no matrix pipe -- beside the
+		# texture term's MLP pass (matrix pipe) on a second stream: they want different halves of a CU.  Autograd replays each term's
+		# backward on the stream of its forward, so the two backward halves overlap as well.  Not under stream capture.
+		dev = torch.device(batch['mesh'].device) if 'mesh' in batch else None
+		aside = None
+		if (OVERLAP_CHAMFER and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
+				and any(t.flag == 'chamf' for t in active) and any(t.flag == 'texture' for t in active)):
+			aside = _second_stream(dev)
+		for term in active:
+			if aside is not None and term.flag == 'chamf':
+				main = torch.cuda.current_stream(dev)
+				aside.wait_stream(main)
+				with torch.cuda.stream(aside):
+					raw[term.key] = getattr(self, term.fn)(st)
+				raw[term.key].record_stream(main)   # allocated on the second stream, read on this one
+			else:
+				raw[term.key] = getattr(self, term.fn)(st)
 			weights.append(float(getattr(opts, term.weight)))
+		if aside is not None:
+			torch.cuda.current_stream(dev).wait_stream(aside)
 		if save_renders:
 			self._save_renders(st, render_dir)
 		# losses[k] = raw * opts.weight_k, loss = sum(losses.values())   (model.py:1157-1163): one launch for all terms (find_weighted_terms_*)

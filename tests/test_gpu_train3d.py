@@ -235,8 +235,8 @@ def test_graphed_step_equals_eager_steps():
 	for n, p in eager.items():
 		# Adam's update lr * m / (sqrt(v) + eps) is scale-free: an element whose gradient is rounding noise (float atomics in the sampling
 		# backward: two EAGER runs differ the same way) moves by lr * sign(noise) per step, and the capturable path forms its bias corrections
-		# in fp32.  So: all but a thousandth of the elements agree to 1e-5, none is further apart than a few such flips.
+		# in fp32.  So: all but a thousandth of the elements agree to a tenth of one step (lr), none is further apart than a few such flips.
 		d = (graph[n].detach() - p).abs()
-		assert (d > 1e-5).float().mean().item() < 1e-3, (n, (d > 1e-5).float().mean().item())
+		assert (d > 0.1 * lr).float().mean().item() < 1e-3, (n, (d > 0.1 * lr).float().mean().item())
 		assert d.max().item() < 0.1 * lr * n_steps, (n, d.max().item())
 	assert not torch.equal(eager['base.2.weight'], _setup(n_verts, gt_verts)[0].model.base[2].weight.detach())   # the steps did move the weights

@@ -317,7 +317,7 @@ def test_trainer_graph_replays_equal_eager_epochs(tmp_path):
 		# a thousandth of the elements agree to 1e-5, and none is further apart than a few such flips (tools/check_defer.py: two eager runs differ
 		# by 2e-6 most of the time and by 7.5e-4 -- one element -- now and then).
 		d = (p_g[n] - p_e[n]).abs()
-		assert (d > 1e-5).float().mean().item() < 1e-3, (n, (d > 1e-5).float().mean().item())
+		assert (d > 0.1 * lr).float().mean().item() < 1e-3, (n, (d > 0.1 * lr).float().mean().item())
 		assert d.max().item() < 0.1 * lr * n_steps, (n, d.max().item())
 	for epoch in (0, 1, 2):
 		for part in ('train_loss', 'val_loss'):
