@@ -2,6 +2,7 @@
 // Replaces NeuralDisplacementField.forward (reference src/model/model.py:393-453) and its autograd backward.
 #include "mlp_dw2.h"
 #include "mlp_dw4.h"
+#include "mlp_dwpe.h"
 #include "mlp_gemm5.h"
 #include "mlp_dw3.h"
 #include "mlp_gemm4.h"
@@ -128,6 +129,7 @@ struct find_ctx {
 	int64_t gemm4_min_units = 1024;
 	int gemm4_small = 64;         // column-quarter gemm4 for launches of at least this many 32-row units (0: never)
 	int dw_pe_target = 256;       // workgroups of the Fourier layer's weight-gradient launch (one round over the chip)
+	int dw_pe_lds_free = 1;       // Fourier layer's weight gradient: 1 = dwpe_kernel (no LDS, one frequency per lane), 0 = dw_kernel<AMODE_PE> (round 1, LDS-staged)
 	int dw2_min_cps = 8;          // at least this many 16-row chunks per dw2 workgroup (4: 2.257, 8: 2.243, 12: 2.266 ms/step at C2)
 	int bwd_streams = 1;          // weight gradients on the side streams
 	int fwd_streams = 1;          // colour head on a side stream beside the displacement head
@@ -826,20 +828,24 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 		FIND_LAUNCH_CHECK("reduce_w_kernel");
 		return FIND_OK;
 	}
-	// Fourier layer: the inputs are regenerated from the positions (register-staged kernel, nkt k-tiles per split -- keep the
-	// launch within one round of workgroups over the chip)
+	// Fourier layer: the inputs are regenerated from the positions.  dwpe_kernel (mlp_dwpe.h; pe >= 32): one k-tile of workgroups per 128
+	// frequencies, slabs of 2 pe + 32 columns; dw_kernel<AMODE_PE> (round 1, "dw_pe_lds_free" = 0): nkt k-tiles, slabs of 256 nkt columns.
+	// Either way the launch stays within one round of workgroups over the chip.
+	const bool lds_free = c->dw_pe_lds_free != 0 && p->pe_size >= 32;
+	const int nkt_launch = lds_free ? (int)cdiv(p->pe_size, 128) : nkt;
 	int spf, cps;
-	split_policy(feet, V, &spf, &cps, std::min<int64_t>(128, std::max<int64_t>(16, c->dw_pe_target / nkt)));
+	split_policy(feet, V, &spf, &cps, std::min<int64_t>(128, std::max<int64_t>(16, c->dw_pe_target / nkt_launch)));
 	DwArgs a;
 	memset(&a, 0, sizeof(a));
 	a.dz = dz; a.dz_foot_stride = V * W;
 	a.x = x; a.x_foot_stride = x_foot_stride; a.ldx = W;
 	a.pos = pos; a.pos_foot_stride = pos_foot_stride; a.Bm = p->B; a.pe = p->pe_size;
-	a.V = (int)V; a.spf = spf; a.cps = cps; a.Kp = nkt * 256;
+	a.V = (int)V; a.spf = spf; a.cps = cps; a.Kp = lds_free ? 2 * p->pe_size + 32 : nkt * 256;
 	a.pw = b.pw; a.pb = pbuf;
 	a.all_blocks = (c->ablate & 32) ? 1 : 0;
 	const int nsplit = (int)(feet * spf);
-	hipLaunchKernelGGL((dw_kernel<AMODE_PE>), dim3((unsigned)nkt, (unsigned)nsplit), dim3(512), 0, s, a);
+	if (lds_free) hipLaunchKernelGGL(dwpe_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
+	else hipLaunchKernelGGL((dw_kernel<AMODE_PE>), dim3((unsigned)nkt, (unsigned)nsplit), dim3(512), 0, s, a);
 	FIND_LAUNCH_CHECK("dw_kernel");
 	ReduceWArgs r;
 	memset(&r, 0, sizeof(r));
@@ -1565,7 +1571,7 @@ namespace {
 struct Knob { const char* key; int find_ctx::*field; int64_t lo, hi; };
 const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
-	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
+	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
 	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };

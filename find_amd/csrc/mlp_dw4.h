@@ -69,6 +69,9 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 			const int tt = min(t, last);
 			ra[t] = *reinterpret_cast<const float4*>(zp + (int64_t)tt * 512);
 			rb[t] = *reinterpret_cast<const bvec*>(xp + (int64_t)tt * 512);
+			// (in program order: left to the scheduler, the slots the loop reads first were loaded last, and the wait counter of the loop's first step
+			//  -- the merge of this path and the back edge -- became vmcnt(2): every load in flight drained once per eight k-pairs.  Round 3.)
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		for (int t0 = 0; t0 < nkp; t0 += 8) {
 #pragma unroll

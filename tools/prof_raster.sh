@@ -25,7 +25,7 @@ for d in sorted(glob.glob(O+'/pmc_*/')):
 	for f in glob.glob(d+'*/*counter_collection.csv'):
 		agg=collections.defaultdict(list)
 		for r in csv.DictReader(open(f)):
-			for pat in ('raster_kernel','bin_kernel','sil_bwd_kernel'):
+			for pat in ('raster_kernel','bin_kernel','sil_bwd_kernel','tie_fix_kernel','face_setup_kernel'):
 				if pat in r['Kernel_Name']:
 					agg[(pat,r['Counter_Name'])].append(float(r['Counter_Value']))
 		for (pat,c),v in sorted(agg.items()):
