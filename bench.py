@@ -313,17 +313,23 @@ def train3d_setup(run, n_items, batch_size, stage='net', labels=False, seed=0, d
 	return dict(mwl=mwl, step=step, gt=(gv, gf, gc), opts=opts, opt=opt, batches=batches, flags=flags)
 
 
-def train3d_executed_flops(n_feet, n_verts=None, n_tex=1000, stage='net', frozen=False):
+def train3d_executed_flops(n_feet, n_verts=None, n_tex=1000, stage='net', frozen=False, lazy_col=None):
 	"""Flops this build executes for one train_3d.yaml step (2 x multiply-accumulates of every Linear layer, forward and backward; the
 	loss kernels are not GEMM work and are left out).  Main pass: template rows shared by the feet of a batch (trunk and the heads' first
 	layers once per TEMPLATE vertex, the later head layers per foot-vertex); its colour head runs forward only (nothing of a 3-D-loss step
-	reads the colours of the predicted mesh, so autograd never enters it -- as in the reference).  Texture pass (net / latent stages): n_tex
-	samples per foot at per-foot positions, colour head only.  frozen: the latents-only backward (no trunk, no weight gradients)."""
+	reads the colours of the predicted mesh, so autograd never enters it -- as in the reference) or, with lazy_col (the product's default
+	since round 3: find_amd.model_with_loss.LAZY_COLOURS), not at all.  Texture pass (net / latent stages): n_tex samples per foot at
+	per-foot positions, colour head only.  frozen: the latents-only backward (no trunk, no weight gradients)."""
+	if lazy_col is None:
+		import find_amd.model_with_loss as MWL
+		lazy_col = MWL.LAZY_COLOURS
 	V = n_verts or N_VERTS
 	L = 256 * 256
 	first, out = 515 * 256, 3 * 256
 	nV = n_feet * V
 	mac = V * (first + 4 * L) + V * 2 * L + nV * (4 * L + 2 * out)                       # main forward
+	if lazy_col:
+		mac -= V * L + nV * (2 * L + out)                                                 # ... without the template pass's colour head
 	if frozen:
 		mac += nV * (out + 2 * L)                                                         # disp head: output layer dX, two hidden dX
 	else:
@@ -702,6 +708,25 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True, only=Non
 	return recs
 
 
+def eager_colour_head_record(run, steps, warmup):
+	"""The headline step with the template pass's colour head evaluated in the forward pass, as the reference does (its output is dropped:
+	nothing on a 3-D-loss step reads it) -- what the product ran until round 3, and the reference's own operation count."""
+	import find_amd.model_with_loss as MWL
+	prev = MWL.LAZY_COLOURS
+	MWL.LAZY_COLOURS = False
+	try:
+		su = train3d_setup(run, N_FEET, N_FEET, stage='net', labels=False, seed=run.rank)
+		ms = run.timed(su['step'], steps, warmup)
+		fl = train3d_executed_flops(N_FEET, lazy_col=False)
+	finally:
+		MWL.LAZY_COLOURS = prev
+	rec = line(run.world * N_FEET * N_VERTS / (ms * 1e-3), ms, run, steps, warmup,
+			   {'workload': train3d_workload(N_FEET, 'net', False) + "; the template pass's colour head evaluated eagerly (FIND_LAZY_COLOURS=0)",
+				'flops_executed_per_step': fl, 'step_tflops_executed': fl / (ms * 1e-3) / 1e12,
+				'step_frac_of_fp32_mfma_peak_executed': fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS})
+	return brief(rec, 'flops_executed_per_step', 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed')
+
+
 def train3d_b1_graph(run, steps, warmup, stage='net', frozen=False):
 	"""The batch-1 step as ONE HIP graph (find_amd/graph.py): sampling, forward, backward and the fused Adam step captured once,
 	replayed per step with the scan copied into the graph's static buffers -- the host enqueues one graph instead of a few hundred kernels.
@@ -783,8 +808,10 @@ def main():
 		cfg = {'workload': train3d_workload(N_FEET, 'net', False), 'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{run.world}',
 			   'flops_executed_per_step': fl, 'step_tflops_executed': fl / (ms * 1e-3) / 1e12,
 			   'step_frac_of_fp32_mfma_peak_executed': fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-			   'flops_note': 'Linear-layer flops of the step as executed (bench.py: train3d_executed_flops): shared-template main pass whose colour head runs '
-							 'forward only (no loss of this configuration reads it; autograd never enters it, as in the reference) + the 16 x 1000-sample texture pass',
+			   'flops_note': 'Linear-layer flops of the step as executed (bench.py: train3d_executed_flops): shared-template main pass without its colour head '
+							 '(no loss of this configuration reads the colours of the predicted mesh: the head is evaluated when res["col"] / meshes.textures is first '
+							 'read, model.get_meshes(lazy_colours=True); the reference computes it and drops it -- records.train3d_b16_eager_colour_head times that) '
+							 '+ the 16 x 1000-sample texture pass',
 			   'reference_config': 'cfgs/train_3d.yaml:17-27 (chamf_loss, smooth_loss, texture_loss, use_pose_code, use_latent_labels); '
 								   'src/train/opts.py:40 batch_size_train=1 -> records.train3d_b1; 16 feet per GPU is the data-parallel shard of SURVEY 8e'}
 		out = line(run.world * N_FEET * N_VERTS / (ms * 1e-3), ms, run, args.steps, args.warmup, cfg)
@@ -796,6 +823,8 @@ def main():
 	del su
 	if run.world == 1 and not args.headline_only and not args.no_records:
 		recs = {}
+		note('record train3d_b16_eager_colour_head')
+		recs['train3d_b16_eager_colour_head'] = eager_colour_head_record(run, args.steps, args.warmup)
 		recs.update(train3d_b1_records(run, with_cpu, graph=not args.no_graph))
 		note('record c2')
 		recs['c2'] = brief(c2_record(run, 30, 5, with_cpu=with_cpu), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed', 'step_tflops_reference_equiv')

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import functional as FN
-from .structures import Meshes, TexturesVertex, extend_template
+from .structures import LazyTexturesVertex, Meshes, TexturesVertex, extend_template
 
 nn = torch.nn
 
@@ -218,6 +218,21 @@ def _average_template_colour(verts, faces, faces_uvs, verts_uvs, image, num_samp
 	return cols[0, :, 0, :].mean(dim=1)
 
 
+class _LazyColours(dict):
+	"""get_meshes' result when the colour head is deferred: res['col'] runs the head on first access (and keeps the value)."""
+
+	def __init__(self, res, thunk):
+		super().__init__(res)
+		self._thunk = thunk
+
+	def __missing__(self, key):
+		if key != 'col' or self._thunk is None:
+			raise KeyError(key)
+		self['col'] = self._thunk()
+		self._thunk = None
+		return dict.__getitem__(self, 'col')
+
+
 class NeuralDisplacementField(Model):
 	"""Template mesh + Fourier PE + trunk MLP + displacement / colour heads + per-instance latent tables
 	(reference model.py:206-534)."""
@@ -402,33 +417,43 @@ class NeuralDisplacementField(Model):
 		disp, col = FN.mlp(self._spec, pos, lat_disp, lat_col, B, avg, self._weights(), want=want, defer_wgrad_join=defer_wgrad_join)
 		return {k: v for k, v in (('disp', disp), ('col', col)) if v is not None}
 
-	def get_meshes(self, shapevec=None, reg=None, texvec=None, posevec=None, no_displacement=False, include_texture=True):
+	def get_meshes(self, shapevec=None, reg=None, texvec=None, posevec=None, no_displacement=False, include_texture=True, lazy_colours=False):
 		"""Evaluate the field at every template vertex, apply the learned similarity registration and return
-		dict(meshes, offsets, verts, disp, col)   (model.py:455-504)."""
+		dict(meshes, offsets, verts, disp, col)   (model.py:455-504).
+		lazy_colours (not in the reference): the colour head is evaluated when `col` / `meshes.textures` is first READ instead of here --
+		ModelWithLoss asks for this on steps that render nothing (chamf / smooth / texture read the vertices only; the texture term queries
+		the field at its own samples), where the reference computes the template's colours and drops them.  Same values either way."""
 		N = 0 if shapevec is None else shapevec.shape[0]
 		meshes = extend_template(self.template_mesh, N=N)
 		tv = self.template_verts.data  # (1, V, 3): the trunk is evaluated once for all N feet
-		res = self(tv, shapevec=shapevec, texvec=texvec, posevec=posevec)
-		offsets, col = res['disp'], res['col']
+		if not self.use_texvec:
+			# (the reference falls back to self.template_tex here, model.py:500 -- an attribute its constructor never assigns (the lines that
+			# built it are commented out, model.py:288-295): upstream raises AttributeError on this path as well)
+			raise NotImplementedError('use_texvec=False: the template-texture fallback of get_meshes does not exist upstream either (model.py:288-295, 500)')
+		if lazy_colours:
+			res = _LazyColours(self(tv, shapevec=shapevec, texvec=texvec, posevec=posevec, want=('disp',)),
+							   lambda: self(tv, shapevec=shapevec, texvec=texvec, posevec=posevec, want=('col',))['col'])
+		else:
+			res = self(tv, shapevec=shapevec, texvec=texvec, posevec=posevec)
+		offsets = res['disp']
 		if reg is not None:
 			X = FN.register_points(tv, offsets, reg)
 		else:
 			X = tv + offsets
 		if not no_displacement:
 			meshes = meshes.update_padded(X)
-		if self.use_texvec:
-			meshes.textures = TexturesVertex(col[..., :3])
+		if lazy_colours:
+			meshes.textures = LazyTexturesVertex(lambda: res['col'][..., :3])
 		else:
-			# (the reference falls back to self.template_tex here, model.py:500 -- an attribute its constructor never assigns (the lines that
-			# built it are commented out, model.py:288-295): upstream raises AttributeError on this path as well)
-			raise NotImplementedError('use_texvec=False: the template-texture fallback of get_meshes does not exist upstream either (model.py:288-295, 500)')
-		return dict(meshes=meshes, offsets=offsets, verts=X, **res)
+			meshes.textures = TexturesVertex(res['col'][..., :3])
+		res.update(meshes=meshes, offsets=offsets, verts=X)
+		return res
 
-	def get_meshes_from_batch(self, batch, is_train=True, no_displacement=False):
+	def get_meshes_from_batch(self, batch, is_train=True, no_displacement=False, lazy_colours=False):
 		sfx = 'train' if is_train else 'val'
 		return self.get_meshes(shapevec=batch.get(f'shapevec_{sfx}', None), reg=batch.get(f'reg_{sfx}', None),
 							   texvec=batch.get(f'texvec_{sfx}', None), posevec=batch.get(f'posevec_{sfx}', None),
-							   include_texture=True, no_displacement=no_displacement)
+							   include_texture=True, no_displacement=no_displacement, lazy_colours=lazy_colours)
 
 	def reset_weights(self):
 		"""Zero the last displacement layer so the initial mesh equals the template (model.py:516-518)."""

@@ -44,6 +44,7 @@ TERMS = (
 OVERLAP_GT_RENDER = os.environ.get('FIND_OVERLAP_GT_RENDER', '1') != '0'
 # the Chamfer term on that second stream beside the texture term's MLP pass (ModelWithLoss.forward); FIND_OVERLAP_CHAMFER=0 turns it off
 OVERLAP_CHAMFER = os.environ.get('FIND_OVERLAP_CHAMFER', '1') != '0'
+LAZY_COLOURS = os.environ.get('FIND_LAZY_COLOURS', '1') != '0'       # switch for A/B runs and for the bench record with the reference's eager colour head
 _SECOND_STREAMS = {}
 
 
@@ -212,11 +213,13 @@ class ModelWithLoss(nn.Module):
 		st = _Step()
 		st.batch, st.epoch, st.opts, st.is_train = batch, epoch, opts, is_train
 		st.use_z_cutoff, st.gt_z_cutoff = use_z_cutoff, gt_z_cutoff
-		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement)
-		st.pred = st.gt = None
 		# train_network asks for renders whenever a checkpoint is saved (train.py:58-66: save_renders at epoch 0, every *_save_every epochs
 		# and on the last one), with or without a render loss: `if render_foot or save_renders` (model.py:1057)
 		rendering = bool(render_foot or save_renders)
+		# The colours of the predicted mesh are read by the renderer only: a step that renders nothing leaves the colour head of the template
+		# pass to whoever reads res['col'] / meshes.textures first (model.get_meshes: lazy_colours) -- nobody, on the 3-D-loss stages.
+		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement, **(dict(lazy_colours=True) if LAZY_COLOURS and not rendering else {}))
+		st.pred = st.gt = None
 		if rendering:
 			# the images (shading, vertex normals) are rendered only when something reads them: the pixel loss, the caller or the PNG (the
 			# reference renders them regardless, renderer.py:290-291; nothing downstream can tell)

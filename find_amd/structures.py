@@ -42,6 +42,27 @@ class TexturesVertex:
 		return self._feat.shape[0]
 
 
+class LazyTexturesVertex(TexturesVertex):
+	"""Per-vertex colours that are evaluated when first read (find_amd.model.get_meshes(lazy_colours=True)): a 3-D-loss step never looks
+	at the colours of the predicted mesh, a caller who does gets them as from TexturesVertex."""
+
+	def __init__(self, thunk):
+		self._thunk, self._value = thunk, None
+
+	@property
+	def _feat(self):
+		if self._value is None:
+			self._value = self._thunk()
+			self._thunk = None
+			if self._value.dim() != 3:
+				raise ValueError('TexturesVertex expects (N, V, C) features')
+		return self._value
+
+	@property
+	def evaluated(self):
+		return self._value is not None
+
+
 class TexturesUV:
 	"""UV-mapped textures -- pytorch3d.renderer.TexturesUV subset used by the reference for GT scans (src/data/dataset.py:263-271):
 	maps (N, H, W, 3), faces_uvs (N, F, 3) indices into verts_uvs (N, Vt, 2).  Sampling = find_amd.functional_render.uv_sample

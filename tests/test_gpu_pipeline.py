@@ -304,3 +304,57 @@ def test_loss_weights_are_applied_and_flags_respected():
 	assert abs(l2.item() - 2 * l1.item()) < 1e-5 * abs(l2.item())
 	with pytest.raises(NotImplementedError):
 		mwl(batch, 0, opts, vgg_perc=True)
+
+
+def test_lazy_colour_head_changes_no_number_and_answers_a_reader():
+	"""A step that renders nothing defers the colour head of the template pass (model.get_meshes(lazy_colours=True)): losses and every
+	gradient are those of the eager evaluation (the reference's, model.py:455-504; the losses bit for bit), nothing is computed until somebody reads
+	res['col'] / meshes.textures, and a reader gets the eager values."""
+	import find_amd.model_with_loss as MWL
+	from find_amd.structures import LazyTexturesVertex
+	from find_amd.train_utils import sample_latent_vectors
+	from test_gpu_train3d import FixedDraws
+	mwl, opts, batch, (gv, gf, gc) = _setup()
+	F_gt, F_t = gf.shape[0], mwl.model.template_faces.shape[1]
+	g = torch.Generator().manual_seed(3)
+	n = gv.shape[0]
+	draws = [(torch.randint(0, F_gt, (n, 5000), generator=g).cuda(), torch.rand(n, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, F_t, (n, 5000), generator=g).cuda(), torch.rand(n, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, F_gt, (n, 1000), generator=g).cuda(), torch.rand(n, 1000, 2, generator=g).cuda())]
+	out = {}
+	prev = MWL.LAZY_COLOURS
+	try:
+		for lazy in (False, True):
+			MWL.LAZY_COLOURS = lazy
+			mwl.zero_grad(set_to_none=True)
+			batch.update(sample_latent_vectors(batch, mwl.model.latent_vectors_train))   # (a fresh gather node per backward pass)
+			with FixedDraws(draws):
+				loss, losses = mwl(batch, 0, opts, chamf=True, smooth=True, texture=True)
+			loss.backward()
+			torch.cuda.synchronize()
+			out[lazy] = (loss.detach().clone(), {k: v.detach().clone() for k, v in losses.items()},
+						 {k: p.grad.detach().clone() for k, p in mwl.model.named_parameters() if p.grad is not None})
+	finally:
+		MWL.LAZY_COLOURS = prev
+	assert torch.equal(out[True][0], out[False][0])
+	assert all(torch.equal(out[True][1][k], out[False][1][k]) for k in out[False][1])
+	assert set(out[True][2]) == set(out[False][2])
+	for k in out[False][2]:
+		# (equal up to the order of the weight-gradient partial sums: a one-head call splits its rows differently from a two-head call)
+		a, b = out[True][2][k], out[False][2][k]
+		assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1e-12), k
+	# ---- a reader of the deferred head
+	lat = {k: batch[f'{k}_train'] for k in ('shapevec', 'reg', 'texvec', 'posevec')}
+	with torch.no_grad():
+		eager = mwl.model.get_meshes(**lat)
+		lazy = mwl.model.get_meshes(**lat, lazy_colours=True)
+	assert isinstance(lazy['meshes'].textures, LazyTexturesVertex) and not lazy['meshes'].textures.evaluated and 'col' not in lazy.keys()
+	assert torch.equal(lazy['verts'], eager['verts']) and torch.equal(lazy['disp'], eager['disp'])
+	assert torch.equal(lazy['meshes'].textures.verts_features_padded(), eager['meshes'].textures.verts_features_padded())
+	assert lazy['meshes'].textures.evaluated and torch.equal(lazy['col'], eager['col'])
+	# a rendering step asks for both heads up front: the pixel loss differentiates through the colours
+	mwl.zero_grad(set_to_none=True)
+	batch.update(sample_latent_vectors(batch, mwl.model.latent_vectors_train))
+	loss, losses = mwl(batch, 0, opts, chamf=False, smooth=False, texture=False, pix=True, sil=True, render_foot=True)
+	loss.backward()
+	assert mwl.model.mlp_col[0].weight.grad is not None and mwl.model.mlp_col[0].weight.grad.abs().max().item() > 0
