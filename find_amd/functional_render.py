@@ -1,6 +1,8 @@
 """torch.autograd binding of the HIP renderer (find_render_fwd / find_render_bwd).  GPU only, no fallback."""
+import atexit
 import ctypes
 import math
+import warnings
 
 import torch
 
@@ -32,33 +34,48 @@ def make_params(image_size=256, faces_per_pixel=100, background=(1., 1., 1.), li
 # ---------------------------------------------------------------------------------------------- render watchdog
 # PyTorch3D clips faces that straddle the z-clip plane (znear / 2, renderer.py:231-234) into 1-2 triangles; this rasteriser does not:
 # it counts them (find_render_flags) and, like the pixels that collect more than 4096 silhouette candidates, they make the result differ
-# from the reference.  Neither occurs with FIND's cameras (0.3 m from a <= 0.15 m object; view_from('toes') leaves 0.06 m), so instead
-# of an implementation nobody exercises, a render that hits either case FAILS: the two counters travel to a pinned host buffer behind
-# the launch and are looked at when they have arrived -- at the next render call, or in check_render_flags() -- so the check costs no
-# synchronisation.  FLAG_POLICY: 'async' (default), 'sync' (wait and raise in the same call: tests), 'ignore'.
-FLAG_POLICY = 'async'
-_pending = []   # (event, pinned int32[2], description)
+# from the reference.  Neither occurs with FIND's cameras (0.3 m from a <= 0.15 m object; view_from('toes') leaves 0.06 m).  A render
+# that hits either case is REPORTED: the two counters travel to a pinned host slot behind the launch and are looked at when they have
+# arrived -- at the next render call, in check_render_flags(), at an epoch boundary of find_amd.trainer.Trainer, or when the interpreter
+# exits -- so the check costs no synchronisation.  FLAG_POLICY:
+#   'warn'   (default) warnings.warn with the description of the render: a close-up visualisation must not end a training run;
+#   'strict' the same look-up raises RuntimeError (in whichever later call finds the counters);   'async' = 'strict' (rounds 1-2 name)
+#   'sync'   wait for the counters and raise in the same call (tests);   'ignore' no bookkeeping at all.
+FLAG_POLICY = 'warn'
+_RING = 64
+_pending = []   # (event, slot, description, policy at the time of the render)
+_slots = None   # one pinned int32[_RING][2] buffer, reused: slot i is free when no pending entry holds it
+_free = []
 
 
-def _raise_if_flagged(vals, what):
-	if vals[0] > 0 or vals[1] > 0:
-		raise RuntimeError(f'find_amd.render: {what}: {vals[0]} face(s) straddle the z-clip plane (PyTorch3D would clip them; this rasteriser '
-						   f'does not) and {vals[1]} pixel(s) collected more than 4096 silhouette candidates (K-nearest rule not applied): the '
-						   'result would differ from the reference.  Move the camera, or set functional_render.FLAG_POLICY = "ignore".')
+def _report(vals, what, policy):
+	if vals[0] <= 0 and vals[1] <= 0:
+		return
+	msg = (f'find_amd.render: {what}: {vals[0]} face(s) straddle the z-clip plane (PyTorch3D would clip them; this rasteriser '
+		   f'does not) and {vals[1]} pixel(s) collected more than 4096 silhouette candidates (K-nearest rule not applied): the '
+		   'result differs from the reference.  Move the camera; functional_render.FLAG_POLICY = "strict" / "ignore" changes this report.')
+	if policy == 'warn':
+		warnings.warn(msg, RuntimeWarning, stacklevel=3)
+	else:
+		raise RuntimeError(msg)
 
 
 def check_render_flags(wait=False):
-	"""Look at the counters of earlier renders that have arrived (all of them with wait=True); raises RuntimeError on the first bad one."""
+	"""Look at the counters of earlier renders that have arrived (all of them with wait=True): a warning per bad render under the
+	'warn' policy, RuntimeError on the first bad one under 'strict' / 'sync'."""
 	global _pending
 	keep = []
+	i = -1
 	try:
-		for i, (ev, host, what) in enumerate(_pending):
+		for i, (ev, slot, what, policy) in enumerate(_pending):
 			if wait:
 				ev.synchronize()
 			if ev.query():
-				_raise_if_flagged(host.tolist(), what)
+				vals = _slots[slot].tolist()
+				_free.append(slot)
+				_report(vals, what, policy)
 			else:
-				keep.append((ev, host, what))
+				keep.append((ev, slot, what, policy))
 	except RuntimeError:
 		keep += _pending[i + 1:]
 		raise
@@ -67,18 +84,33 @@ def check_render_flags(wait=False):
 
 
 def _watch(ws, what):
+	global _slots
 	if FLAG_POLICY == 'ignore' or torch.cuda.is_current_stream_capturing():
 		return
 	check_render_flags()
-	host = torch.empty(2, dtype=torch.int32).pin_memory()
-	host.copy_(ws[:8].view(torch.int32), non_blocking=True)
+	if not _free and _slots is not None:   # nobody ever looked and the ring is full: do it now rather than grow without bound
+		check_render_flags(wait=True)
+	if _slots is None:
+		_slots = torch.zeros(_RING, 2, dtype=torch.int32).pin_memory()
+		_free.extend(range(_RING))
+		atexit.register(_flush_at_exit)
+	slot = _free.pop()
+	_slots[slot].copy_(ws[:8].view(torch.int32), non_blocking=True)
 	ev = torch.cuda.Event()
 	ev.record()
-	_pending.append((ev, host, what))
-	if len(_pending) > 64:   # nobody ever looked: do it now rather than grow without bound
-		check_render_flags(wait=True)
+	_pending.append((ev, slot, what, 'strict' if FLAG_POLICY == 'async' else FLAG_POLICY))
 	if FLAG_POLICY == 'sync':
 		check_render_flags(wait=True)
+
+
+def _flush_at_exit():
+	"""The renders nobody looked at again: report them before the interpreter goes (a bad last render used to pass unseen)."""
+	try:
+		check_render_flags(wait=True)
+	except RuntimeError as e:   # 'strict': nothing left to abort, say it
+		warnings.warn(str(e), RuntimeWarning)
+	except Exception:           # (the device may be gone already)
+		pass
 
 
 class _Render(torch.autograd.Function):

@@ -53,6 +53,13 @@ class Adam(torch.optim.Optimizer):
 		super().load_state_dict(state_dict)
 		self._cache = {}
 
+	def state_dict(self):
+		"""torch's layout.  capturable: the tensors of a bucket share ONE device step counter inside the optimiser (_prepare); what is handed
+		out holds a copy per parameter, as torch's does -- no aliasing in a checkpoint, and a later step() does not move a saved count."""
+		sd = super().state_dict()
+		sd['state'] = {k: ({**st, 'step': st['step'].clone()} if torch.is_tensor(st.get('step')) else dict(st)) for k, st in sd['state'].items()}
+		return sd
+
 	def _prepare(self, gi, ps):
 		"""Per-group launch tables, rebuilt only when the set of parameters with a gradient (or the state) changes: the pointer
 		arrays of parameters and moments are stable across steps, only the gradients' addresses move."""

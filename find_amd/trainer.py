@@ -136,6 +136,10 @@ class Trainer:
 	def _epoch_done(self):
 		if self._stream is not None:
 			torch.cuda.current_stream(self.device).wait_stream(self._stream)
+		# the render watchdog's counters of this epoch (functional_render.FLAG_POLICY: a warning per bad render by default): the epoch's
+		# losses were read on the host just before, so they have all arrived
+		from . import functional_render as FR
+		FR.check_render_flags(wait=True)
 
 	def _graphed_step(self, optims, latent_vectors, model_kwargs):
 		from .graph import GraphedStep

@@ -101,3 +101,22 @@ def test_adam_capturable_matches_default_path():
 		assert float(sa['state'][k]['step']) == float(sb['state'][k]['step']) == 8.0
 		assert sb['state'][k]['step'].is_cuda and not sa['state'][k]['step'].is_cuda
 		assert torch.allclose(sa['state'][k]['exp_avg_sq'], sb['state'][k]['exp_avg_sq'])
+	# the capturable optimiser keeps one counter per bucket inside; a state_dict holds a copy per parameter (no aliasing, no later movement)
+	steps = [sb['state'][k]['step'] for k in sb['state']]
+	assert len({t.data_ptr() for t in steps}) == len(steps)
+	for p, gr in zip(pb, grads[0]):
+		p.grad = gr.cuda()
+	ob.step()
+	torch.cuda.synchronize()
+	assert all(float(t) == 8.0 for t in steps) and float(ob.state_dict()['state'][0]['step']) == 9.0
+	# ... and loads back into a fresh optimiser that continues the same trajectory
+	ps2 = [torch.nn.Parameter(t.detach().clone()) for t in pb]
+	o2 = optim.Adam(ps2, lr=5e-4, weight_decay=1e-3, capturable=True)
+	import copy
+	o2.load_state_dict(copy.deepcopy(ob.state_dict()))   # (torch's load_state_dict keeps tensors that already have the right dtype and device: the moments would be shared)
+	for q, p, gr in zip(ps2, pb, grads[1]):
+		q.grad = gr.cuda(); p.grad = gr.cuda()
+	o2.step(); ob.step()
+	torch.cuda.synchronize()
+	for q, p in zip(ps2, pb):
+		assert torch.equal(q, p)

@@ -324,7 +324,7 @@ def _edge_cases_body(size, verts, faces, cols, R, T):
 def test_toes_view_matches_oracle_and_straddling_faces_fail_loudly():
 	"""view_from('toes') (renderer.py:192), the closest camera the reference defines, against the oracle; then a camera pushed INTO the
 	mesh: faces straddle the z-clip plane, PyTorch3D would clip them, this rasteriser does not -- the render must fail (checked
-	synchronously here; by default the counters are looked at one call later, functional_render.FLAG_POLICY)."""
+	synchronously here; by default the counters are looked at one call later and a bad render WARNS, functional_render.FLAG_POLICY)."""
 	from find_amd import functional_render as FR
 	from find_amd import synthetic
 	from find_amd.renderer import FootRenderer
@@ -344,10 +344,20 @@ def test_toes_view_matches_oracle_and_straddling_faces_fail_loudly():
 		Rb, Tb = camera_ref.look_at_view_transform(dist=0.02, elev=0.0, azim=0.0, up=((1, 0, 0),))
 		with pytest.raises(RuntimeError, match='straddle the z-clip plane'):
 			_render_gpu(verts, f, None, torch.from_numpy(Rb), torch.from_numpy(Tb), 64, want_image=False)
-		FR.FLAG_POLICY = 'async'   # the default: the bad render returns, the NEXT call (or an explicit check) reports it
+		FR.FLAG_POLICY = 'strict'   # the bad render returns, the NEXT call (or an explicit check) raises
 		_render_gpu(verts, f, None, torch.from_numpy(Rb), torch.from_numpy(Tb), 64, want_image=False)
 		with pytest.raises(RuntimeError, match='straddle the z-clip plane'):
 			FR.check_render_flags(wait=True)
+		FR.FLAG_POLICY = 'warn'     # the default: the same look-up warns, with the description of the render, and training goes on
+		_render_gpu(verts, f, None, torch.from_numpy(Rb), torch.from_numpy(Tb), 64, want_image=False)
+		with pytest.warns(RuntimeWarning, match='1 meshes x 1 views @64x64.*straddle the z-clip plane'):
+			FR.check_render_flags(wait=True)
+		# the pinned slots are a ring of 64, reused: 200 renders nobody looks at in between neither grow it nor lose a report
+		with pytest.warns(RuntimeWarning, match='straddle the z-clip plane'):
+			for _ in range(200):
+				_render_gpu(verts, f, None, torch.from_numpy(Rb), torch.from_numpy(Tb), 64, want_image=False)
+			FR.check_render_flags(wait=True)
+		assert FR._slots.shape[0] == 64 and len(FR._free) == 64 and not FR._pending
 	finally:
 		FR.FLAG_POLICY = prev
 		try:
