@@ -294,7 +294,9 @@ __device__ __forceinline__ void eval_core(const FaceRec& r, float px, float py, 
 	else { o->dist = e12; o->edge = 2; o->t = tc; }
 }
 
-__device__ __forceinline__ float silhouette_prob(float signed_dist, float inv_sigma) { return 1.0f / (1.0f + __expf(signed_dist * inv_sigma)); }
+// sigmoid(-d / sigma).  The reciprocal is the hardware's (1 ulp) rather than an IEEE division (ten instructions in the innermost loop of the
+// rasteriser and of its backward); forward and backward call this one function.
+__device__ __forceinline__ float silhouette_prob(float signed_dist, float inv_sigma) { return __builtin_amdgcn_rcpf(1.0f + __expf(signed_dist * inv_sigma)); }
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 	const float l = fmaxf(sqrtf(x * x + y * y + z * z), 1e-6f);
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			}
 			if (fr.pz_clip > czt) continue;
 			const float sd = fr.inside ? -fr.dist : fr.dist;
-			const float prob = 1.0f / (1.0f + __expf(sd * inv_sigma));
+			const float prob = silhouette_prob(sd, inv_sigma);
 			const float alpha = cmk;
 			// gradient w.r.t. the UNSIGNED distance: sign * dmask/dd
 			const float gd = (fr.inside ? -1.0f : 1.0f) * (-cg * alpha * prob * inv_sigma);

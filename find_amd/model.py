@@ -97,6 +97,9 @@ class LatentVector(nn.Module):
 					raise IndexError(f'LatentVector {self.name}: index {lo if lo < -self.data.shape[0] else hi} is out of range for {self.data.shape[0]} rows')
 			# (a device index is not read back: the gather kernel answers an out-of-range row with NaNs instead of a host synchronisation)
 			return FN.latent_gather(self.data, idx.to(device=self.data.device, dtype=torch.int64))
+		# a table that lives on the host (a model being built or inspected on the CPU: tests/test_host_api.py, checkpoint tools) or an index of
+		# another shape: plain indexing.  Not a compute fall-back -- every kernel-backed op downstream (FN.mlp, register_points, the losses)
+		# raises on CPU tensors, so a training step cannot run through here by accident.
 		return self.data[idx]
 
 	def _label_rows(self, labels):
