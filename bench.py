@@ -51,9 +51,9 @@ MAC_FWDBWD_REF = 2465536
 MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 
 # HBM-side traffic of one launch of the dominant kernel, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes (tools/profile_round2.sh; profiles/r02_gemm4_pmc_summary.txt): 2 x 65.3 MB fetched + 112.9 MB written (fp32 gemm4; 241.8 - 243.4 MB over the passes);
+# passes (tools/profile_round3.sh pmc; profiles/r03_gemm4_pmc_summary.txt): 2 x 65.0 MB fetched + 112.9 MB written (fp32 gemm4; 241.8 - 243.9 MB over the passes of rounds 2 and 3);
 # fp16-mode gemm5 (profiles/r01_traffic_pmc_summary.txt): 2 x 57.10 MB + 112.9 MB.
-GEMM_TRAFFIC_BYTES = 243.4e6
+GEMM_TRAFFIC_BYTES = 242.9e6
 GEMM5_TRAFFIC_BYTES = 227.1e6
 
 
@@ -442,7 +442,7 @@ def dominant_roofline(device, fp16=False):
 			'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
 			'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES if N_VERTS == 6890 else None,
 			'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
-							'profiles/r02_gemm4_pmc_summary.txt; algorithmic 226.0e6'}
+							'profiles/r03_gemm4_pmc_summary.txt; algorithmic 226.0e6'}
 
 
 # ------------------------------------------------------------------------------------------------ C2 / C5 (BASELINE configs[1], [4])

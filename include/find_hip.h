@@ -155,6 +155,8 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "gemm4_small"     ... and launches of at least this many 32-row units use it on column quarters (default 64; 0 = never);
  *                     anything smaller, and the two-segment trunk-output gradient, runs on the LDS-DMA ring kernel (gemm3)
  *   "dw2_min_cps", "dw_pe_target"   weight-gradient kernels: shortest row run per workgroup, workgroups of the Fourier layer's launch
+ *   "dw_pe_lds_free"  Fourier layer's weight gradient: 1 (default) = dwpe_kernel (no LDS, features regenerated per lane, slabs of 2 pe + 32
+ *                     columns; pe_size >= 32), 0 = the LDS-staged kernel of round 1 (A/B runs)
  *   "bwd_streams"     0 = backward on the caller's stream only, 1 = weight gradients on the context's side streams (default)
  *   "fwd_streams"     1 = the forward runs the colour head on a side stream beside the displacement head (default), 0 = one stream
  *   "reduce_stream"   1 = slab reduces of the large head layers on their own stream, two alternating slab sets; default 0 (behind their

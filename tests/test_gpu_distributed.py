@@ -223,16 +223,25 @@ def test_one_rank_rccl_step_keeps_the_stream_layout_and_the_step_time():
 	import sys
 	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 	env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
-	res = {}
-	for mode in ('plain', 'dp'):
-		r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dp_one_rank.py'), '60', mode], capture_output=True, text=True, env=env, timeout=400, cwd=root)
-		assert r.returncode == 0, (mode, r.stdout[-1500:], r.stderr[-1500:])
-		groups = [int(x) for x in re.search(r'\[caller, Q, T1, T2, R\] = \[([^\]]*)\]', r.stdout).group(1).split(',')]
-		ms = [float(x) for x in re.findall(rf'{mode}: ([0-9.]+) ms/step', r.stdout)]
-		assert len(ms) == 2, r.stdout
-		res[mode] = (groups, min(ms))
-	for mode, (g, _) in res.items():
-		assert g[1] != g[0] and g[2] != g[0] and g[3] != g[0], f'{mode}: a side stream shares the hardware queue of the caller: {g}'
-	ratio = res['dp'][1] / res['plain'][1]
-	print(f"one-rank RCCL step {res['dp'][1]:.3f} ms against {res['plain'][1]:.3f} ms plain: x{ratio:.3f}; queue groups {res['dp'][0]} / {res['plain'][0]}")
+	def measure():
+		res = {}
+		for mode in ('plain', 'dp'):
+			r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dp_one_rank.py'), '60', mode], capture_output=True, text=True, env=env, timeout=400, cwd=root)
+			assert r.returncode == 0, (mode, r.stdout[-1500:], r.stderr[-1500:])
+			groups = [int(x) for x in re.search(r'\[caller, Q, T1, T2, R\] = \[([^\]]*)\]', r.stdout).group(1).split(',')]
+			ms = [float(x) for x in re.findall(rf'{mode}: ([0-9.]+) ms/step', r.stdout)]
+			assert len(ms) == 2, r.stdout
+			res[mode] = (groups, min(ms))
+		return res
+
+	# A layout regression is there in every run (3.47 against 3.25 ms, every time); a box whose host was busy for one of the two processes is
+	# not (seen once in a full-suite run: x1.47, x1.01-1.02 in the runs before and after): up to three attempts, every one printed.
+	for attempt in range(3):
+		res = measure()
+		for mode, (g, _) in res.items():
+			assert g[1] != g[0] and g[2] != g[0] and g[3] != g[0], f'{mode}: a side stream shares the hardware queue of the caller: {g}'
+		ratio = res['dp'][1] / res['plain'][1]
+		print(f"one-rank RCCL step {res['dp'][1]:.3f} ms against {res['plain'][1]:.3f} ms plain: x{ratio:.3f}; queue groups {res['dp'][0]} / {res['plain'][0]}")
+		if ratio < 1.05:
+			break
 	assert ratio < 1.05, (res, ratio)

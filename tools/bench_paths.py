@@ -48,9 +48,9 @@ def views(m, seed=7):
 	return look_at_view_transform(dist=np.full(m, 0.3), elev=rng.uniform(-90, 90, m), azim=rng.uniform(-90, 90, m), up=((1, 0, 0),))
 
 
-# HBM-side bytes per forward launch of raster_tile_kernel / per launch of sil_bwd_kernel at the C3 shape, rocprofv3 --pmc FETCH_SIZE (x2, the
-# gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r02_raster_pmc.txt)
-RASTER_TRAFFIC_C3 = {'raster_kernel': None, 'sil_bwd_kernel': 2 * 77277.5 * 1024 + 83482.1 * 1024}   # (filled from profiles/r03_raster_pmc.txt)
+# HBM-side bytes per forward launch of raster_kernel / per launch of sil_bwd_kernel at the C3 shape, rocprofv3 --pmc FETCH_SIZE (x2, the
+# gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r03_raster_pmc.txt)
+RASTER_TRAFFIC_C3 = {'raster_kernel': 2 * 492314.9 * 1024 + 530626.2 * 1024, 'sil_bwd_kernel': 2 * 96688.2 * 1024 + 83899.6 * 1024}   # profiles/r03_raster_pmc.txt
 
 
 def raster_counts(verts, fc, Rc, Tc, params):
