@@ -281,3 +281,30 @@ def test_no_kernel_sits_between_256_and_512_registers():
 					assert n <= 256 or n == 512 or any(k in kernel for k in allowed), f'{kernel}: {n} registers per lane'
 	assert seen > 30
 	shutil.rmtree(d, ignore_errors=True)
+
+
+def test_lazy_colour_containers_evaluate_once_and_only_when_read():
+	"""structures.LazyTexturesVertex / model._LazyColours (get_meshes(lazy_colours=True)): nothing runs until the colours are read, the
+	thunk runs once, and the container then behaves like TexturesVertex / a plain dict."""
+	import torch
+	from find_amd.model import _LazyColours
+	from find_amd.structures import LazyTexturesVertex, TexturesVertex
+	calls = []
+
+	def thunk():
+		calls.append(1)
+		return torch.arange(2 * 5 * 3, dtype=torch.float32).reshape(2, 5, 3)
+
+	t = LazyTexturesVertex(thunk)
+	assert isinstance(t, TexturesVertex) and not t.evaluated and not calls
+	assert t.verts_features_padded().shape == (2, 5, 3) and t.evaluated and len(calls) == 1
+	assert len(t) == 2 and t.extend(3).verts_features_padded().shape == (6, 5, 3) and t[1].verts_features_padded().shape == (1, 5, 3)
+	assert torch.equal(t.clone().verts_features_padded(), t.detach().verts_features_padded()) and len(calls) == 1
+	with pytest.raises(ValueError):
+		LazyTexturesVertex(lambda: torch.zeros(5, 3)).verts_features_padded()
+	res = _LazyColours(dict(disp=torch.zeros(1)), thunk)
+	assert 'col' not in res and set(res) == {'disp'} and len(calls) == 1
+	assert res['col'].shape == (2, 5, 3) and len(calls) == 2 and 'col' in res
+	assert res['col'] is res['col'] and len(calls) == 2
+	with pytest.raises(KeyError):
+		res['nope']
