@@ -42,6 +42,7 @@ N_FEET = 16
 N_VERTS = 6890
 N_GT_VERTS = 10002
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SUSTAINED_FP32_MFMA_TFLOPS = 146.9  # measured: tools/mfma_peak.hip, registers only, one wave per SIMD (profiles/r03_mfma_peak.txt)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable by a streaming kernel)
 METRIC = 'deformed vertices x rendered views / sec (fwd+bwd)'
 UNIT = 'vertices*views/s'
@@ -442,7 +443,10 @@ def dominant_roofline(device, fp16=False):
 			'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
 			'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES if N_VERTS == 6890 else None,
 			'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), '
-							'profiles/r03_gemm4_pmc_summary.txt; algorithmic 226.0e6'}
+							'profiles/r03_gemm4_pmc_summary.txt; algorithmic 226.0e6',
+			# `peak` is the guide's 2.4 GHz figure; a loop of nothing but back-to-back v_mfma_f32_32x32x2_f32 (tools/mfma_peak.hip, 64.0 cycles per
+			# instruction and SIMD) sustains 146.9 TFLOP/s on this part: the clock under fp32 MFMA load settles at 2.24 GHz (profiles/r03_mfma_peak.txt)
+			'sustained_mfma_tflops_measured': SUSTAINED_FP32_MFMA_TFLOPS, 'frac_of_sustained': ach / SUSTAINED_FP32_MFMA_TFLOPS}
 
 
 # ------------------------------------------------------------------------------------------------ C2 / C5 (BASELINE configs[1], [4])
