@@ -2,7 +2,7 @@
 # Round 3 evidence -> gpurun_out/r03/ (copy what is to be judged into profiles/).  Usage: tools/profile_round3.sh [headline|b1|roofline|pmc ...]
 #   headline  rocprofv3 --kernel-trace --stats of the headline loop alone (bench.py --headline-only): kernel stats, steady-state statistics
 #             (warm-up launches dropped), per-step statistics cut at the optimiser kernel, one step launch by launch
-#   b1        the same for the batch-1 records (bench.py --train3d-b1 --no-graph)
+#   b1        the same for the batch-1 network-stage record (bench.py --train3d-b1 --b1-only train3d_b1 --no-graph)
 #   roofline  the bench command itself (headline + the isolated loop its `roofline` object times) under the tracer: the timed launches read back
 #   pmc       PMC passes of the dominant kernel (find_linear_relu_fwd at the C2 shape): MFMA busy / FETCH_SIZE / WRITE_SIZE, one counter set per run
 set -eu
@@ -19,7 +19,7 @@ for w in $what; do
     cp "$O"/headline/*/*kernel_stats.csv "$O/headline_kernel_stats.csv"
     head -16 "$O/headline_steady_kernel_stats.csv" | cut -c1-150; tail -1 "$O/headline_step_stats.csv" ;;
   b1)
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$O/b1" -- python3 "$R/bench.py" --train3d-b1 --no-graph --no-cpu-baseline > "$O/b1_line.json" 2> "$O/b1.err"
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$O/b1" -- python3 "$R/bench.py" --train3d-b1 --b1-only train3d_b1 --no-graph --no-cpu-baseline > "$O/b1_line.json" 2> "$O/b1.err"
     python3 "$R/tools/step_stats.py" "$O"/b1/*/*kernel_trace.csv adam_kernel 200 > "$O/b1_step_stats.csv"; tail -1 "$O/b1_step_stats.csv" ;;
   roofline)
     rocprofv3 --kernel-trace --stats --output-format csv -d "$O/roofline" -- python3 "$R/bench.py" --no-records --no-cpu-baseline > "$O/roofline_line.json" 2> "$O/roofline.err"
