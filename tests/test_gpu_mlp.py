@@ -645,3 +645,51 @@ def test_side_streams_are_bound_to_queues_beside_the_callers():
 	finally:
 		_lib.check(L.find_ctx_destroy(h), 'find_ctx_destroy')
 	del clutter
+
+
+def test_deferred_weight_gradient_join_changes_no_gradient_and_is_joined_when_backward_returns(golden_main):
+	"""The texture pass asks for its weight gradients to trail the backward (defer_wgrad_join=True -> find_ctx "defer_join"): the
+	gradients read on the caller's stream right after backward() -- no device synchronisation in between -- equal those of the run that
+	joins inside the call (bit for bit but for the latent-derived sums, below), are bit-identical from run to run, nothing is left pending on the context, and the second pass still folds into the first's gradients."""
+	from find_amd import _lib
+	from find_amd import functional as FN
+	m = _model_from_golden(golden_main)
+	g = torch.Generator().manual_seed(11)
+	n_feet = 4
+	lat = {k: torch.randn(n_feet, 100, generator=g).cuda() * 0.1 for k in ['shapevec', 'texvec', 'posevec']}
+	pos_main = (torch.rand(1, 6890, 3, generator=g) * 0.2).cuda()          # template pass: shared trunk, displacement head read
+	pos_tex = (torch.rand(n_feet, 1000, 3, generator=g) * 0.2).cuda()      # texture pass: per-foot samples, colour head only
+	prev = FN.DEFER_WGRAD_JOIN
+	out = {}
+	try:
+		for defer in (False, True, True):
+			FN.DEFER_WGRAD_JOIN = defer
+			m.zero_grad(set_to_none=True)
+			FN._PENDING_WGRADS.clear()
+			lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+			main = m(pos_main, **lv, want=('disp',))
+			tex = m(pos_tex, **lv, want=('col',), defer_wgrad_join=True)
+			((main['disp'] ** 2).sum() + (tex['col'] ** 2).sum()).backward()
+			got = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}   # (clones on the caller's stream, no synchronise before)
+			got.update({f'lat/{k}': v.grad.clone() for k, v in lv.items()})
+			assert _lib.get_tuning('pending', pos_main.device) == 0
+			torch.cuda.synchronize()
+			if defer in out:
+				for n in got:
+					assert torch.equal(got[n], out[defer][n]), (defer, n)   # run to run
+			out[defer] = got
+	finally:
+		FN.DEFER_WGRAD_JOIN = prev
+	assert set(out[True]) == set(out[False]) and len(out[True]) >= 26
+	# Bit for bit, except what is built from the per-foot column sums of the colour head's first-layer gradient -- the latent columns of that
+	# layer's weight gradient and the latent gradients: the deferred path takes those sums from the foot-sum kernel on the caller's stream, the
+	# other from the weight-gradient slabs (another order of the same additions).
+	for n in out[False]:
+		a, b = out[True][n], out[False][n]
+		if n.startswith('lat/'):
+			assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item(), n
+		elif n in ('mlp_col.0.weight', 'mlp_disp.0.weight'):
+			assert torch.equal(a[:, :256], b[:, :256]), n
+			assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item(), n
+		else:
+			assert torch.equal(a, b), n
