@@ -461,7 +461,7 @@ struct TileArgs {
 	Fix* fix;
 	int64_t pool_cap;
 	int tiles_per_img, total_tiles;
-	int ablate;              // profiling only (find_debug_raster_ablate): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 8 no early exit, 64 counters
+	int ablate;              // profiling only (find_debug_raster_ablate): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 8 no early exit, 16 lists unsorted, 32 no scan, 64 counters, 256 tiny list pool
 };
 
 __device__ __forceinline__ bool tile_hit(uint32_t t, int tile_x, int tile_y) {
@@ -566,7 +566,9 @@ __device__ __forceinline__ void bin_tile(const TileArgs& a, uint32_t* src, int* 
 	int off = 0;
 	if (lane == 0) off = atomicAdd(&a.cursor[img * CURSOR_STRIDE], n);
 	off = __shfl(off, 0, 64);
-	const bool room = (int64_t)off + n <= a.pool_cap && off >= 0;
+	// (bit 256 of the profiling switch shrinks the pool to 512 entries per image: nearly every tile then takes the no-room path -- the rasteriser
+	//  scans the faces itself --, which real scenes reach only with faces tens of tiles wide: tests/test_gpu_render.py compares the two)
+	const bool room = (int64_t)off + n <= ((a.ablate & 256) ? (int64_t)512 : a.pool_cap) && off >= 0;
 	uint32_t* const pool = a.pool + (int64_t)img * a.pool_cap;
 	uint32_t mode = 0;
 	if (!room) {

@@ -371,7 +371,7 @@ def test_early_exit_and_list_order_change_nothing():
 	holds its K nearest candidates in front of everything still to come.  With the exit switched off (find_debug_raster_ablate bit 8) and
 	with the lists left in face order (bit 16: no slab sort, hence no exit either) the SAME pixels must come out: the same face in front,
 	the same K-nearest set behind every mask value (products of the same factors in another order: equal to rounding), the same
-	bound for the backward -- on a dense mesh at a small size, where every covered pixel has more than K candidates and ties at the K-th
+	bound for the backward; and likewise when a tile finds no room in the list pool and scans the faces itself (bit 256: a pool of 512 entries) -- on a dense mesh at a small size, where every covered pixel has more than K candidates and ties at the K-th
 	depth are common (tie_fix_kernel)."""
 	from find_amd import _lib, functional_render as FR, synthetic
 	from find_amd.cameras import look_at_view_transform
@@ -382,7 +382,7 @@ def test_early_exit_and_list_order_change_nothing():
 	R, T = look_at_view_transform(dist=np.full(3, 0.3), elev=np.array([10.0, -60.0, 85.0]), azim=np.array([20.0, -80.0, 0.0]), up=((1, 0, 0),))
 	params = FR.make_params(96)
 	out = {}
-	for bits in (0, 8, 16):
+	for bits in (0, 8, 16, 256):
 		_lib.set_tuning('raster_ablate', bits)
 		try:
 			vg = verts.clone().requires_grad_(True)
@@ -394,7 +394,7 @@ def test_early_exit_and_list_order_change_nothing():
 			_lib.set_tuning('raster_ablate', 0)
 	m0, i0, p0, z0, g0 = out[0]
 	assert float((m0 > 0.5).float().mean()) > 0.05
-	for bits in (8, 16):
+	for bits in (8, 16, 256):
 		m1, i1, p1, z1, g1 = out[bits]
 		assert torch.equal(p0, p1) and torch.equal(z0, z1), bits   # the same face, the same depth (the same rounding) in front of every pixel
 		assert (m0 - m1).abs().max().item() < 2e-6, bits
