@@ -217,6 +217,36 @@ def test_full_template_mask_vs_oracle_with_k_overflow():
 	assert err.max() < TOL, (err.max(), int((err > TOL).sum()))
 
 
+def test_lists_longer_than_the_binning_buffer_and_the_pole_of_a_scan_vs_oracle():
+	"""Tiles whose face list outgrows the binning wave's LDS buffer (BIN_CAP = 2048 entries: the list then goes out in face order, no
+	depth-slab sort, no early exit) come about naturally with a dense mesh on a small image: the 50 002-vertex template at 64^2 puts
+	several thousand faces into every covered tile and hundreds of candidates on every covered pixel; and the pole of a lat-long GT scan
+	turned towards the camera is the fan the tie fix-up exists for (every face of the fan shares the pole's depth).  Masks against the
+	oracle's K-nearest blend at the north_star tolerance, outside provable depth ties at the K-th place (as in the gradient test below)."""
+	from find_amd import synthetic
+	size = 64
+	rp = render_ref.default_params(size)
+	for n_verts, elev, azim in ((50002, 25.0, -40.0), (10002, 0.0, 0.0)):
+		v, f = synthetic.template(n_verts)
+		verts = v[None].clone()
+		# (elev 0, azim 0): the camera sits on the +z axis and looks straight at the pole of the lat-long grid
+		R, T = camera_ref.look_at_view_transform(dist=np.full(1, 0.3), elev=np.array([elev]), azim=np.array([azim]), up=((1, 0, 0),))
+		R, T = torch.from_numpy(R), torch.from_numpy(T)
+		(mask, _, _, _), _ = _render_gpu(verts, f, None, R, T, size, want_image=False)
+		vproj = render_ref.project(rp, verts.numpy(), R.numpy(), T.numpy())
+		p2f101, z101, _, _ = render_ref.rasterize(vproj, f.numpy(), 1, size, size, 101, rp.sil_blur_radius)
+		full = p2f101[..., 99] >= 0
+		assert full.mean() > 0.05, full.mean()
+		z99, z100 = z101[..., 99].astype(np.float64), z101[..., 100].astype(np.float64)
+		tie = ((p2f101[..., 100] >= 0) & (z100 - z99 <= 4e-6 * z99)).reshape(mask.shape)
+		ref = render_ref.render(verts.numpy(), f.numpy(), None, R.numpy(), T.numpy(), image_size=size, want_image=False)
+		err = np.abs(mask.cpu().numpy() - ref['mask'])
+		print(f'{n_verts} vertices @{size}: {int(full.sum())} pixels with a full K-buffer, {int(tie.sum())} depth ties at the K-th place; '
+			  f'max |mask - oracle| outside them {err[~tie].max():.2e}, inside {err[tie].max() if tie.any() else 0.0:.2e}')
+		assert err[~tie].max() < TOL
+		assert tie.mean() < 0.15   # (the denser mesh: 7 % of the pixels; 6890 vertices at this size: 1-2 %)
+
+
 def test_silhouette_backward_with_k_overflow_vs_oracle_autograd():
 	"""Dense mesh on a small image (6890-vertex template @64^2: most silhouette pixels see far more than 100 candidates):
 	the gradient must flow only through the K nearest candidates of such pixels, as autograd through the oracle's K = 100
