@@ -294,6 +294,63 @@ __device__ __forceinline__ void eval_core(const FaceRec& r, float px, float py, 
 	else { o->dist = e12; o->edge = 2; o->t = tc; }
 }
 
+// ---- the same fragment math for TWO faces at once (the rasteriser's inner loop): every quantity is a pair (face a, face b) in the two
+// halves of a 64-bit register pair, so the multiplies, adds and fused multiply-adds are packed instructions (v_pk_*_f32: one issue slot for
+// both faces) -- the pipe that bounds the rasteriser.  Operation for operation the expressions of eval_core / seg_dist above, in the same
+// order, without contraction: each half is bit-identical to eval_core on that face (the tie fix-up and the backward recompute depths with
+// eval_core and compare them to the bit; tests/test_gpu_render.py).  Maxima, compares, selects and reciprocals have no packed form.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Frag2 {
+	v2f w0, w1, w2, pz_clip, pz, dist;
+	bool inside_a, inside_b;
+};
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f max2(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
+__device__ __forceinline__ v2f rcp2(v2f a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f edge_fn2(v2f px, v2f py, v2f ax, v2f ay, v2f bx, v2f by) {
+#pragma clang fp contract(off)
+	return fma2(px - ax, by - ay, -((py - ay) * (bx - ax)));
+}
+__device__ __forceinline__ v2f seg_dist2(v2f px, v2f py, v2f ax, v2f ay, v2f bx, v2f by, v2f il) {
+#pragma clang fp contract(off)
+	const v2f bax = bx - ax, bay = by - ay;
+	const v2f u = fma2(bax, px - ax, bay * (py - ay)) * il;
+	v2f t;
+	t.x = il.x > 0.f ? fminf(fmaxf(u.x, 0.f), 1.f) : 1.0f;
+	t.y = il.y > 0.f ? fminf(fmaxf(u.y, 0.f), 1.f) : 1.0f;
+	const v2f qx = fma2(t, bax, ax) - px, qy = fma2(t, bay, ay) - py;
+	return fma2(qx, qx, qy * qy);
+}
+// blk: the pair's 40 floats in LDS, field j of face a at [2 j], of face b at [2 j + 1] (FaceRec's dword order)
+__device__ __forceinline__ void eval_pair(const float* blk, float pxs, float pys, Frag2* o) {
+#pragma clang fp contract(off)
+	const float4 r0 = *reinterpret_cast<const float4*>(blk), r1 = *reinterpret_cast<const float4*>(blk + 4), r2 = *reinterpret_cast<const float4*>(blk + 8);
+	const float4 r3 = *reinterpret_cast<const float4*>(blk + 12), r4 = *reinterpret_cast<const float4*>(blk + 16), r5 = *reinterpret_cast<const float4*>(blk + 20);
+	const float4 r6 = *reinterpret_cast<const float4*>(blk + 24);
+	const v2f x0 = {r0.x, r0.y}, y0 = {r0.z, r0.w}, x1 = {r1.x, r1.y}, y1 = {r1.z, r1.w}, x2 = {r2.x, r2.y}, y2 = {r2.z, r2.w};
+	const v2f z0 = {r3.x, r3.y}, z1 = {r3.z, r3.w}, z2 = {r4.x, r4.y}, ia = {r4.z, r4.w}, il01 = {r5.x, r5.y}, il02 = {r5.z, r5.w}, il12 = {r6.x, r6.y};
+	const v2f px = {pxs, pxs}, py = {pys, pys};
+	v2f w0 = edge_fn2(px, py, x1, y1, x2, y2) * ia;
+	v2f w1 = edge_fn2(px, py, x2, y2, x0, y0) * ia;
+	v2f w2 = edge_fn2(px, py, x0, y0, x1, y1) * ia;
+	const v2f t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+	const v2f iden = rcp2(max2(t0 + t1 + t2, KEPS));
+	w0 = t0 * iden; w1 = t1 * iden; w2 = t2 * iden;
+	o->w0 = w0; o->w1 = w1; o->w2 = w2;
+	o->inside_a = w0.x > 0.f && w1.x > 0.f && w2.x > 0.f;
+	o->inside_b = w0.y > 0.f && w1.y > 0.f && w2.y > 0.f;
+	v2f c0 = max2(w0, 0.f), c1 = max2(w1, 0.f), c2 = max2(w2, 0.f);
+	const v2f isum = rcp2(max2(c0 + c1 + c2, 1e-5f));
+	c0 *= isum; c1 *= isum; c2 *= isum;
+	o->pz_clip = fma2(c2, z2, fma2(c1, z1, c0 * z0));
+	o->pz = fma2(w2, z2, fma2(w1, z1, w0 * z0));
+	const v2f e01 = seg_dist2(px, py, x0, y0, x1, y1, il01);
+	const v2f e02 = seg_dist2(px, py, x0, y0, x2, y2, il02);
+	const v2f e12 = seg_dist2(px, py, x1, y1, x2, y2, il12);
+	// (the value eval_core's three-way choice ends up with is the smallest of the three)
+	o->dist = v2f{fminf(fminf(e01.x, e02.x), e12.x), fminf(fminf(e01.y, e02.y), e12.y)};
+}
+
 // sigmoid(-d / sigma).  The reciprocal is the hardware's (1 ulp) rather than an IEEE division (ten instructions in the innermost loop of the
 // rasteriser and of its backward); forward and backward call this one function.
 __device__ __forceinline__ float silhouette_prob(float signed_dist, float inv_sigma) { return __builtin_amdgcn_rcpf(1.0f + __expf(signed_dist * inv_sigma)); }
@@ -745,7 +802,9 @@ __device__ __forceinline__ FaceRec load_rec_uniform(const FaceRec* base, int f) 
 template <bool want_sil, bool want_rgb>
 __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ pool_all,
 													  const int32_t* __restrict__ order) {
-	__shared__ __attribute__((aligned(16))) FaceRec rec[4][64];   // the batch in flight (the K-nearest search's counters live on top of it afterwards)
+	// the batch in flight, as PAIRS of faces: 32 blocks of 40 floats per wave, field j of the pair's faces at [2 j], [2 j + 1] (eval_pair);
+	// the K-nearest search's counters live on top of it afterwards
+	__shared__ __attribute__((aligned(16))) float rec[4][64 * 20];
 	// write-combining rings of the candidate lists: [slot][thread], so that a wave's appends (different slots per lane) never conflict
 	__shared__ float ring_z[RING][256];
 	__shared__ float ring_q[RING][256];
@@ -850,52 +909,60 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 				s_front = slab_after;
 				front = slab_front(slab_after, zlo, sw); front1 = slab_front(slab_after + 1, zlo, sw);
 			}
-			// stage the batch: every lane copies its face's 80-byte record to LDS (five 16-byte pieces), then every lane reads all of them
+			// stage the batch: the faces present are packed to the front (the no-room path tests every face of the image: most lanes hold
+			// none) and every lane scatters its face's 20 dwords into its half of a pair block; then every lane reads all the blocks
+			const unsigned long long m_have = __ballot(f_lane >= 0);
+			const int nb = (int)__popcll(m_have);
 			if (f_lane >= 0) {
+				const int pos = (int)__popcll(m_have & ((1ull << lane) - 1ull));
 				const float4* src = reinterpret_cast<const float4*>(rp_img + f_lane);
-				float4* dst = reinterpret_cast<float4*>(&rec[wave][lane]);
 				const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
-				dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3; dst[4] = q4;
+				float* d = &rec[wave][(pos >> 1) * 40 + (pos & 1)];
+				d[0] = q0.x; d[2] = q0.y; d[4] = q0.z; d[6] = q0.w; d[8] = q1.x; d[10] = q1.y; d[12] = q1.z; d[14] = q1.w;
+				d[16] = q2.x; d[18] = q2.y; d[20] = q2.z; d[22] = q2.w; d[24] = q3.x; d[26] = q3.y;
+				d[32] = q4.x; d[34] = q4.y; d[36] = q4.z; d[38] = q4.w;
 			}
 			wave_lds_sync();
-			unsigned long long m = __ballot(f_lane >= 0);
-			while (m) {   // two faces per turn: one's LDS reads overlap the other's math
-				const int k0 = __builtin_ctzll(m);
-				m &= m - 1;
-				const bool two = m != 0ull;
-				const int k1 = two ? __builtin_ctzll(m) : k0;
-				if (two) m &= m - 1;
+			for (int t = 0; 2 * t < nb; ++t) {   // two faces per turn, in packed arithmetic
+				const float* blk = &rec[wave][t * 40];
+				const bool two = 2 * t + 1 < nb;   // (an odd batch: the last block's second half is stale, and masked out)
+				// nobody who still needs faces lies inside either bbox: next (the far side of a closed surface goes by like this)
+				const float4 bx4 = *reinterpret_cast<const float4*>(blk + 32), by4 = *reinterpret_cast<const float4*>(blk + 36);
+				const bool inb_a = need & (px <= bx4.z) & (px >= bx4.x) & (py <= by4.z) & (py >= by4.x);
+				const bool inb_b = two & need & (px <= bx4.w) & (px >= bx4.y) & (py <= by4.w) & (py >= by4.y);
+				if (__ballot(inb_a | inb_b) == 0ull) continue;
+				if (a.ablate & 64) n_eval += two ? 2 : 1;
+				Frag2 fr2;
+				eval_pair(blk, px, py, &fr2);   // (every lane: the ones outside the bboxes compute along and are masked out below)
+				const float2 fid = *reinterpret_cast<const float2*>(blk + 26);   // the two face indices
 #pragma unroll
 				for (int u = 0; u < 2; ++u) {
-					if (u == 1 && !two) break;   // uniform
-					const FaceRec& rk = rec[wave][u ? k1 : k0];
-					// nobody who still needs faces lies inside this one's bbox: next (the far side of a closed surface goes by like this)
-					const bool inb = need & (px <= rk.xmax) & (px >= rk.xmin) & (py <= rk.ymax) & (py >= rk.ymin);
-					if (__ballot(inb) == 0ull) continue;
-					if (a.ablate & 64) ++n_eval;
-					Frag fr;
-					eval_core(rk, px, py, &fr);   // (every lane: the ones outside the bbox compute along and are masked out below)
+					const bool inb = u ? inb_b : inb_a;
+					const bool f_inside = u ? fr2.inside_b : fr2.inside_a;
+					const float f_pzc = u ? fr2.pz_clip.y : fr2.pz_clip.x, f_pz = u ? fr2.pz.y : fr2.pz.x, f_dist = u ? fr2.dist.y : fr2.dist.x;
 					if (want_sil) {
-						const bool cand = inb & (fr.pz_clip >= 0.f) & (fr.inside | (fr.dist < blur));
+						const bool cand = inb & (f_pzc >= 0.f) & (f_inside | (f_dist < blur));
 						if (cand) {
-							const float prob = silhouette_prob(fr.inside ? -fr.dist : fr.dist, inv_sigma);
+							const float prob = silhouette_prob(f_inside ? -f_dist : f_dist, inv_sigma);
 							alpha *= (1.0f - prob);
 							if (cnt < KN_CAP && !(a.ablate & 1)) {
 								const int slot = cnt & (RING - 1);
-								ring_z[slot][tid] = fr.pz_clip; ring_q[slot][tid] = 1.0f - prob;
+								ring_z[slot][tid] = f_pzc; ring_q[slot][tid] = 1.0f - prob;
 								if (slot == RING - 1) flush_ring(cnt - (RING - 1), RING);
 							}
 							++cnt;
-							c_lt += fr.pz_clip < front ? 1 : 0;
-							c_a += (fr.pz_clip >= front) & (fr.pz_clip < front1) ? 1 : 0;
-							c_b += fr.pz_clip >= front1 ? 1 : 0;
-							z_lo = fminf(z_lo, fr.pz_clip); z_hi = fmaxf(z_hi, fr.pz_clip);  // depth range of the candidates (bounds of the radix search)
+							c_lt += f_pzc < front ? 1 : 0;
+							c_a += (f_pzc >= front) & (f_pzc < front1) ? 1 : 0;
+							c_b += f_pzc >= front1 ? 1 : 0;
+							z_lo = fminf(z_lo, f_pzc); z_hi = fmaxf(z_hi, f_pzc);  // depth range of the candidates (bounds of the radix search)
 						}
 					}
 					if (want_rgb) {
 						// nearest inside fragment; equal depths: the lower face index (PyTorch3D's insertion order)
-						if (inb & fr.inside & (fr.pz >= 0.f) & ((fr.pz < bz) | ((fr.pz == bz) & (rk.f < bf)))) {
-							bz = fr.pz; bf = rk.f; bd = -fr.dist; bw0 = fr.w0; bw1 = fr.w1; bw2 = fr.w2;
+						const int f_id = __float_as_int(u ? fid.y : fid.x);
+						if (inb & f_inside & (f_pz >= 0.f) & ((f_pz < bz) | ((f_pz == bz) & (f_id < bf)))) {
+							bz = f_pz; bf = f_id; bd = -f_dist;
+							bw0 = u ? fr2.w0.y : fr2.w0.x; bw1 = u ? fr2.w1.y : fr2.w1.x; bw2 = u ? fr2.w2.y : fr2.w2.x;
 						}
 					}
 				}
@@ -962,7 +1029,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 					int c_lo = 0;
 					// the lane's 32 counters (16 bits each) live in LDS:
 					// hist[w * 64 + lane], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
-					unsigned* const hist = reinterpret_cast<unsigned*>(rec[wave]) + lane;
+					unsigned* const hist = reinterpret_cast<unsigned*>(&rec[wave][0]) + lane;
 					while (lo < hi) {
 						const unsigned span = hi - lo;
 						const int shift = span < 32u ? 0 : (27 - __builtin_clz(span));  // (span >> shift) <= 31
