@@ -188,10 +188,22 @@ __global__ __launch_bounds__(NW * 64) void gemm4_kernel(const Gemm2Args g) {
 				if constexpr (EPI == EPI_MASK) {
 					if (ni + 1 < NI) load_mask(ni + 1, mv[(ni + 1) & 1]);
 				}
+				// (bias: one packed add for two accumulator registers -- a non-MFMA instruction costs the SIMD's other wave a matrix-pipe issue slot;
+				//  there is no packed maximum for the ReLU)
+				typedef float v2f __attribute__((ext_vector_type(2)));
+				float vals[16];
+#pragma unroll
+				for (int r = 0; r < 16; r += 2) {
+					if constexpr (EPI == EPI_BIAS_RELU) {
+						const v2f t = v2f{acc[ni][r], acc[ni][r + 1]} + v2f{bv[ni], bv[ni]};
+						vals[r] = fmaxf(t.x, 0.f); vals[r + 1] = fmaxf(t.y, 0.f);
+					} else {
+						vals[r] = acc[ni][r]; vals[r + 1] = acc[ni][r + 1];
+					}
+				}
 #pragma unroll
 				for (int r = 0; r < 16; ++r) {
-					float val = acc[ni][r];
-					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv[ni], 0.f);
+					float val = vals[r];
 					if constexpr (EPI == EPI_MASK) val = (mv[ni & 1][r] > 0.f) ? val : 0.f;
 					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0);
 				}
