@@ -1324,31 +1324,41 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 	// The three per-pixel values (upstream gradient, K-th depth, mask) are requested together and ONE PIXEL AHEAD of the math: asked for
 	// one after the other behind the tests that need them, a lane's ~10 pixels were ~30 memory latencies in a row.  773 -> 730 us at C3;
 	// the rest is the fragment math itself (79 M pixel x face evaluations; without the six atomics per face the kernel takes 721 us).
-	auto pixel_of = [&](int pi, int* yi, int* xi) -> int64_t {
-		const int ry = pi / bw;
-		*yi = ylo + ry; *xi = xlo + (pi - ry * bw);
-		return ((int64_t)img * H + *yi) * W + *xi;
-	};
-	int yi = 0, xi = 0;
+	// A lane walks pixels sub, sub + LPF, ... of the bbox in row-major order: the step is (LPF / bw rows, LPF % bw columns) -- ONE integer
+	// division per face instead of one per pixel --, per-pixel addresses are 32-bit offsets from the image's base (H, W <= 2048), and the NDC
+	// coordinate of a pixel centre, 1 - (2 i + 1) / S, is a multiplication where S is a power of two (the same value to the bit; the
+	// rasteriser divides): the address and coordinate arithmetic was ~70 of the ~330 instructions of an iteration.
+	const int bws = max(bw, 1);
+	const int step_y = LPF / bws, step_x = LPF - step_y * bws;
+	const int64_t base = (int64_t)img * H * W;
+	const float* const dm = d_mask + base;
+	const float* const zth = zthr + base;
+	const float* const alw = alpha_ws + base;
+	const int32_t* const tf = tie_face + base;
+	const bool w_p2 = (W & (W - 1)) == 0, h_p2 = (H & (H - 1)) == 0;
+	const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
+	int yi = ylo + sub / bws, xi = xlo + sub % bws;
 	float g = 0.f, zt = 0.f, mk = 0.f;
-	int64_t pix_cur = 0;
+	int off_cur = 0;
 	if (sub < npx) {
-		pix_cur = pixel_of(sub, &yi, &xi);
-		g = d_mask[pix_cur]; zt = zthr[pix_cur]; mk = alpha_ws[pix_cur];
+		off_cur = yi * W + xi;
+		g = dm[off_cur]; zt = zth[off_cur]; mk = alw[off_cur];
 	}
 	for (int pi = sub; pi < npx; pi += LPF) {
 		const int cy = yi, cx = xi;
 		const float cg = g, cmk = mk;
 		float czt = zt;
-		const int64_t cpix = pix_cur;
+		const int coff = off_cur;
 		if (pi + LPF < npx) {
-			pix_cur = pixel_of(pi + LPF, &yi, &xi);
-			g = d_mask[pix_cur]; zt = zthr[pix_cur]; mk = alpha_ws[pix_cur];
+			xi += step_x; yi += step_y;
+			if (xi > xhi) { xi -= bws; ++yi; }
+			off_cur = yi * W + xi;
+			g = dm[off_cur]; zt = zth[off_cur]; mk = alw[off_cur];
 		}
-		const float py = 1.0f - (2.0f * cy + 1.0f) / (float)H;
+		const float py = h_p2 ? 1.0f - (2.0f * cy + 1.0f) * inv_h : 1.0f - (2.0f * cy + 1.0f) / (float)H;
 		{
 			if (cg == 0.f) continue;
-			const float px = 1.0f - (2.0f * cx + 1.0f) / (float)W;
+			const float px = w_p2 ? 1.0f - (2.0f * cx + 1.0f) * inv_w : 1.0f - (2.0f * cx + 1.0f) / (float)W;
 			Frag fr;
 			if (!eval_frag(r, px, py, &fr)) continue;
 			if (!(fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur))) continue;
@@ -1356,7 +1366,7 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			// sorted out by face index in the forward, tie_fix_kernel: those up to tie_face stay)
 			if (czt < 0.f) {
 				czt = -czt;
-				if (fr.pz_clip == czt && f > tie_face[cpix]) continue;
+				if (fr.pz_clip == czt && f > tf[coff]) continue;
 			}
 			if (fr.pz_clip > czt) continue;
 			const float sd = fr.inside ? -fr.dist : fr.dist;
