@@ -1448,14 +1448,18 @@ __device__ __forceinline__ void rgb_pixel_grad(const find_render_params& rp, con
 	}
 	// ---- forward recompute
 	const float nl = fmaxf(sqrtf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]), 1e-6f);
-	const float n[3] = {nrm[0] / nl, nrm[1] / nl, nrm[2] / nl};
+	// (one division per denominator, then multiplications: an IEEE division is ten instructions, and there were thirty of them per pixel)
+	const float inv_nl = 1.0f / nl;
+	const float n[3] = {nrm[0] * inv_nl, nrm[1] * inv_nl, nrm[2] * inv_nl};
 	float Lv[3] = {rp.light_pos[0] - pos[0], rp.light_pos[1] - pos[1], rp.light_pos[2] - pos[2]};
 	const float ll = fmaxf(sqrtf(Lv[0] * Lv[0] + Lv[1] * Lv[1] + Lv[2] * Lv[2]), 1e-6f);
-	const float l[3] = {Lv[0] / ll, Lv[1] / ll, Lv[2] / ll};
+	const float inv_ll = 1.0f / ll;
+	const float l[3] = {Lv[0] * inv_ll, Lv[1] * inv_ll, Lv[2] * inv_ll};
 	const float cosang = n[0] * l[0] + n[1] * l[1] + n[2] * l[2];
 	float Vv[3] = {cam[view * 3] - pos[0], cam[view * 3 + 1] - pos[1], cam[view * 3 + 2] - pos[2]};
 	const float vl = fmaxf(sqrtf(Vv[0] * Vv[0] + Vv[1] * Vv[1] + Vv[2] * Vv[2]), 1e-6f);
-	const float vd[3] = {Vv[0] / vl, Vv[1] / vl, Vv[2] / vl};
+	const float inv_vl = 1.0f / vl;
+	const float vd[3] = {Vv[0] * inv_vl, Vv[1] * inv_vl, Vv[2] * inv_vl};
 	const float r[3] = {-l[0] + 2.f * cosang * n[0], -l[1] + 2.f * cosang * n[1], -l[2] + 2.f * cosang * n[2]};
 	const float vr = vd[0] * r[0] + vd[1] * r[1] + vd[2] * r[2];
 	const bool lit = cosang > 0.f;
@@ -1477,14 +1481,14 @@ __device__ __forceinline__ void rgb_pixel_grad(const find_render_params& rp, con
 	// cos = n . l
 	for (int c = 0; c < 3; ++c) { d_n[c] += d_cos * l[c]; d_l[c] += d_cos * n[c]; }
 	// normalisations  x/|x|:  d_x = (d_u - u (u . d_u)) / |x|
-	auto unnorm = [](const float* u, const float* du, float len, float* dx) {
+	auto unnorm = [](const float* u, const float* du, float inv_len, float* dx) {
 		const float dot = u[0] * du[0] + u[1] * du[1] + u[2] * du[2];
-		for (int c = 0; c < 3; ++c) dx[c] = (du[c] - u[c] * dot) / len;
+		for (int c = 0; c < 3; ++c) dx[c] = (du[c] - u[c] * dot) * inv_len;
 	};
 	float d_nrm[3], d_Lv[3], d_Vv[3];
-	unnorm(n, d_n, nl, d_nrm);
-	unnorm(l, d_l, ll, d_Lv);
-	unnorm(vd, d_vd, vl, d_Vv);
+	unnorm(n, d_n, inv_nl, d_nrm);
+	unnorm(l, d_l, inv_ll, d_Lv);
+	unnorm(vd, d_vd, inv_vl, d_Vv);
 	float d_pos[3];
 	for (int c = 0; c < 3; ++c) d_pos[c] = -d_Lv[c] - d_Vv[c];
 	// ---- interpolation: x = sum_k bw_k X_k
@@ -1505,19 +1509,21 @@ __device__ __forceinline__ void rgb_pixel_grad(const find_render_params& rp, con
 	const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W, py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
 	const float area = edge_fn(x2, y2, x0, y0, x1, y1) + KEPS;
 	const float e0 = edge_fn(px, py, x1, y1, x2, y2), e1 = edge_fn(px, py, x2, y2, x0, y0), e2 = edge_fn(px, py, x0, y0, x1, y1);
-	const float w0 = e0 / area, w1 = e1 / area, w2 = e2 / area;
+	const float inv_area = 1.0f / area;
+	const float w0 = e0 * inv_area, w1 = e1 * inv_area, w2 = e2 * inv_area;
 	const float t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
 	const float den = t0 + t1 + t2;
 	if (!(den > KEPS)) return;  // (degenerate fragment: only the interpolation part contributes)
-	const float sdb = (d_bw[0] * t0 + d_bw[1] * t1 + d_bw[2] * t2) / den;
-	const float d_t0 = (d_bw[0] - sdb) / den, d_t1 = (d_bw[1] - sdb) / den, d_t2 = (d_bw[2] - sdb) / den;
+	const float inv_den = 1.0f / den;
+	const float sdb = (d_bw[0] * t0 + d_bw[1] * t1 + d_bw[2] * t2) * inv_den;
+	const float d_t0 = (d_bw[0] - sdb) * inv_den, d_t1 = (d_bw[1] - sdb) * inv_den, d_t2 = (d_bw[2] - sdb) * inv_den;
 	const float d_w0 = d_t0 * z1 * z2, d_w1 = d_t1 * z0 * z2, d_w2 = d_t2 * z0 * z1;
 	const float d_z0 = d_t1 * w1 * z2 + d_t2 * z1 * w2;
 	const float d_z1 = d_t0 * w0 * z2 + d_t2 * z0 * w2;
 	const float d_z2 = d_t0 * w0 * z1 + d_t1 * z0 * w1;
 	// w_i = e_i / area
-	const float d_e0 = d_w0 / area, d_e1 = d_w1 / area, d_e2 = d_w2 / area;
-	const float d_area = -(d_w0 * w0 + d_w1 * w1 + d_w2 * w2) / area;
+	const float d_e0 = d_w0 * inv_area, d_e1 = d_w1 * inv_area, d_e2 = d_w2 * inv_area;
+	const float d_area = -(d_w0 * w0 + d_w1 * w1 + d_w2 * w2) * inv_area;
 	// edge(p,a,b) = (px-ax)(by-ay) - (py-ay)(bx-ax):  d/da = (-(by-ay)+(py-ay), (px-ax)-(bx-ax)) ... written out per vertex
 	float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f;
 	auto edge_bwd = [](float qx, float qy, float ax, float ay, float bx, float by, float ge, float& gax, float& gay, float& gbx, float& gby) {
