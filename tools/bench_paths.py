@@ -50,7 +50,7 @@ def views(m, seed=7):
 
 # HBM-side bytes per forward launch of raster_kernel / per launch of sil_bwd_kernel at the C3 shape, rocprofv3 --pmc FETCH_SIZE (x2, the
 # gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r03_raster_pmc.txt)
-RASTER_TRAFFIC_C3 = {'raster_kernel': 2 * 510313.9 * 1024 + 533396.1 * 1024, 'sil_bwd_kernel': 2 * 96688.2 * 1024 + 83899.6 * 1024}   # profiles/r03_raster_pmc.txt
+RASTER_TRAFFIC_C3 = {'raster_kernel': 2 * 511493.6 * 1024 + 533171.5 * 1024, 'sil_bwd_kernel': 2 * 96658.4 * 1024 + 83899.6 * 1024}   # profiles/r03_raster_pmc.txt
 
 
 def raster_counts(verts, fc, Rc, Tc, params):
