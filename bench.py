@@ -173,7 +173,30 @@ class Run:
 		if self.world > 1:
 			torch.distributed.barrier()
 
-	def timed(self, step, steps, warmup):
+	PRIME_S = 0.6   # see timed()
+
+	def timed(self, step, steps, warmup, prime=True):
+		"""W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides (the driver's contract).  Before
+		the warm-up the workload is PRIMED -- untimed steps for PRIME_S seconds: a process that starts on an idle GPU finds it at its idle
+		clocks, and the part takes a few hundred milliseconds of load to come up to speed (the headline measured straight after start-up on
+		a fresh box: 3.64 ms per step; the same build one record later in the same process: 2.19); a step count cannot express that, a
+		warm-up of 5 steps is 11 ms.  What is timed is unchanged: K steps of the steady state.  `--no-prime` switches it off."""
+		if prime and Run.PRIME_S > 0:
+			# (a step of the data-parallel run holds a collective: every rank must take the same number of priming steps -- eight to measure,
+			#  then the largest estimate of any rank)
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			for _ in range(8):
+				step()
+			torch.cuda.synchronize()
+			n = max(0, int(Run.PRIME_S / max((time.perf_counter() - t0) / 8, 1e-5)) - 8)
+			if self.world > 1:
+				t = torch.tensor([n], device=self.dev, dtype=torch.int64)
+				torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+				n = int(t.item())
+			for _ in range(min(n, 4096)):
+				step()
+			torch.cuda.synchronize()
 		for _ in range(warmup):
 			step()
 		self.barrier()
@@ -207,7 +230,8 @@ def note(msg):
 
 def line(value, ms, run, steps, warmup, config, **extra):
 	out = {'metric': METRIC, 'value': value, 'unit': UNIT, 'n_gpus': run.world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms,
-		   'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_label(), 'data': 'synthetic', 'config': config}
+		   'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype_label(), 'data': 'synthetic', 'config': config,
+		   'prime_s': Run.PRIME_S}   # untimed steady-state priming before the W warm-up steps (Run.timed)
 	out.update(extra)
 	return out
 
@@ -755,6 +779,7 @@ def main():
 	ap.add_argument('--steps', type=int, default=30)
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
+	ap.add_argument('--no-prime', action='store_true', help='no untimed priming phase before the warm-up steps (Run.timed): measures a cold GPU')
 	ap.add_argument('--headline-only', action='store_true', help='only the timed headline loop (no records, no CPU leg, no isolated kernel loop): the command to put under rocprofv3')
 	ap.add_argument('--no-graph', action='store_true', help='skip the HIP-graph variant of the batch-1 record')
 	ap.add_argument('--no-records', action='store_true', help='skip the nested records of the other configurations')
@@ -773,6 +798,8 @@ def main():
 	if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
 		raise SystemExit(spawn_ranks(sys.argv[1:], args.gpus))
 
+	if args.no_prime:
+		Run.PRIME_S = 0.0
 	with_cpu = not args.no_cpu_baseline and not args.headline_only
 	if args.subpaths:
 		return subpaths(with_cpu)
