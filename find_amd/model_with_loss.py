@@ -216,14 +216,15 @@ class ModelWithLoss(nn.Module):
 		# train_network asks for renders whenever a checkpoint is saved (train.py:58-66: save_renders at epoch 0, every *_save_every epochs
 		# and on the last one), with or without a render loss: `if render_foot or save_renders` (model.py:1057)
 		rendering = bool(render_foot or save_renders)
-		# The colours of the predicted mesh are read by the renderer only: a step that renders nothing leaves the colour head of the template
-		# pass to whoever reads res['col'] / meshes.textures first (model.get_meshes: lazy_colours) -- nobody, on the 3-D-loss stages.
-		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement, **(dict(lazy_colours=True) if LAZY_COLOURS and not rendering else {}))
+		# the images (shading, vertex normals) are rendered only when something reads them: the pixel loss, the caller or the PNG (the
+		# reference renders them regardless, renderer.py:290-291; nothing downstream can tell)
+		images = rendering and bool(pix or return_renders or save_renders)
+		# The colours of the predicted mesh are read by the image render only: a step that renders no image -- nothing at all, or silhouettes
+		# alone -- leaves the colour head of the template pass to whoever reads res['col'] / meshes.textures first (model.get_meshes:
+		# lazy_colours): nobody, on the 3-D-loss stages and on a silhouette-loss step.
+		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement, **(dict(lazy_colours=True) if LAZY_COLOURS and not images else {}))
 		st.pred = st.gt = None
 		if rendering:
-			# the images (shading, vertex normals) are rendered only when something reads them: the pixel loss, the caller or the PNG (the
-			# reference renders them regardless, renderer.py:290-291; nothing downstream can tell)
-			images = bool(pix or return_renders or save_renders)
 			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None), images)
 			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images, mask_image=bool(return_renders or save_renders))
 		supervise_3d = self._supervise_3d(batch, opts, is_train)
