@@ -99,7 +99,8 @@ class FootRenderer(nn.Module):
 				raise NotImplementedError('return_images needs TexturesVertex or TexturesUV textures')
 			colors = tex.verts_features_padded()[..., :3]
 		want_soft = return_mask and (mask_with_grad or not return_images)
-		want_frags = mask_out_faces or return_depth
+		# (pix_to_face is read below only to hide faces: when the caller names some, or for UV textures' (0,0)-UV convention)
+		want_frags = (mask_out_faces and (masked_faces is not None or uv_tex)) or return_depth
 		if not (return_images or want_soft or want_frags):
 			return dict()
 		if return_images and uv_tex:
