@@ -177,26 +177,31 @@ class Run:
 
 	def timed(self, step, steps, warmup, prime=True):
 		"""W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides (the driver's contract).  Before
-		the warm-up the workload is PRIMED -- untimed steps for PRIME_S seconds: a process that starts on an idle GPU finds it at its idle
+		the warm-up the workload is PRIMED -- untimed steps for at least PRIME_S seconds, until the step time has settled: a process that starts on an idle GPU finds it at its idle
 		clocks, and the part takes a few hundred milliseconds of load to come up to speed (the headline measured straight after start-up on
 		a fresh box: 3.64 ms per step; the same build one record later in the same process: 2.19); a step count cannot express that, a
 		warm-up of 5 steps is 11 ms.  What is timed is unchanged: K steps of the steady state.  `--no-prime` switches it off."""
 		if prime and Run.PRIME_S > 0:
-			# (a step of the data-parallel run holds a collective: every rank must take the same number of priming steps -- eight to measure,
-			#  then the largest estimate of any rank)
-			torch.cuda.synchronize()
-			t0 = time.perf_counter()
-			for _ in range(8):
-				step()
-			torch.cuda.synchronize()
-			n = max(0, int(Run.PRIME_S / max((time.perf_counter() - t0) / 8, 1e-5)) - 8)
-			if self.world > 1:
-				t = torch.tensor([n], device=self.dev, dtype=torch.int64)
-				torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-				n = int(t.item())
-			for _ in range(min(n, 4096)):
-				step()
-			torch.cuda.synchronize()
+			# batches of eight steps until at least PRIME_S seconds have gone by AND two consecutive batches agree within 5 % (at most
+			# 8 x PRIME_S: the first process on a fresh box also pays first-use costs -- allocator growth, queue probing, module loads --
+			# for a few dozen steps).  A step of the data-parallel run holds a collective: the ranks agree on every "go on".
+			prev, total = None, 0.0
+			while True:
+				torch.cuda.synchronize()
+				t0 = time.perf_counter()
+				for _ in range(8):
+					step()
+				torch.cuda.synchronize()
+				dt = time.perf_counter() - t0
+				total += dt
+				done = (total >= Run.PRIME_S and prev is not None and abs(dt - prev) <= 0.05 * prev) or total >= 8 * Run.PRIME_S
+				if self.world > 1:
+					t = torch.tensor([int(done)], device=self.dev, dtype=torch.int64)
+					torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+					done = bool(t.item())
+				if done:
+					break
+				prev = dt
 		for _ in range(warmup):
 			step()
 		self.barrier()
