@@ -1375,15 +1375,15 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			// gradient w.r.t. the UNSIGNED distance: sign * dmask/dd
 			const float gd = (fr.inside ? -1.0f : 1.0f) * (-cg * alpha * prob * inv_sigma);
 			// nearest edge (a,b), q = a + t (b - a):  d = |q - p|^2,  dd/da = 2 (1-t) (q - p),  dd/db = 2 t (q - p)
-			float ax, ay, bx, by;
-			if (fr.edge == 0) { ax = r.x0; ay = r.y0; bx = r.x1; by = r.y1; }
-			else if (fr.edge == 1) { ax = r.x0; ay = r.y0; bx = r.x2; by = r.y2; }
-			else { ax = r.x1; ay = r.y1; bx = r.x2; by = r.y2; }
+			// (selects, no branches: edge 0: a = v0, b = v1;  edge 1: a = v0, b = v2;  edge 2: a = v1, b = v2)
+			const bool e0 = fr.edge == 0, e2 = fr.edge == 2;
+			const float ax = e2 ? r.x1 : r.x0, ay = e2 ? r.y1 : r.y0, bx = e0 ? r.x1 : r.x2, by = e0 ? r.y1 : r.y2;
 			const float qx = ax + fr.t * (bx - ax) - px, qy = ay + fr.t * (by - ay) - py;
 			const float ga = gd * 2.0f * (1.0f - fr.t), gb = gd * 2.0f * fr.t;
-			if (fr.edge == 0) { g0x += ga * qx; g0y += ga * qy; g1x += gb * qx; g1y += gb * qy; }
-			else if (fr.edge == 1) { g0x += ga * qx; g0y += ga * qy; g2x += gb * qx; g2y += gb * qy; }
-			else { g1x += ga * qx; g1y += ga * qy; g2x += gb * qx; g2y += gb * qy; }
+			const float wax = ga * qx, way = ga * qy, wbx = gb * qx, wby = gb * qy;
+			g0x += e2 ? 0.f : wax; g0y += e2 ? 0.f : way;
+			g1x += e0 ? wbx : (e2 ? wax : 0.f); g1y += e0 ? wby : (e2 ? way : 0.f);
+			g2x += e0 ? 0.f : wbx; g2y += e0 ? 0.f : wby;
 		}
 	}
 #pragma unroll
