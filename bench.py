@@ -729,6 +729,9 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True, only=Non
 			rec['cpu_baseline'] = dict(cpu_net, sample=cpu_net['sample'] + ' [the network-stage timing: a latent-stage step is the same op sequence on the val rows]')
 		recs[key] = brief(rec, 'step_tflops_executed')
 		recs[key]['host_enqueue_ms_per_step'] = rec['host_enqueue_ms_per_step']
+		if stage != 'reg':
+			recs[key]['note'] = ('eager loop: bound by the host (host_enqueue_ms_per_step, box to box 1.2 - 1.8 ms); find_amd.trainer.Trainer runs this step as '
+								 f'ONE HIP-graph replay: records.{key}_graph')
 		if stage != 'reg' and graph:
 			try:
 				note(f'record {key}_graph')
