@@ -647,6 +647,45 @@ def test_side_streams_are_bound_to_queues_beside_the_callers():
 	del clutter
 
 
+def test_unbound_side_streams_give_the_same_gradients():
+	"""The fall-back layout of the side streams -- `bind_streams` = 0: the four streams as HIP created them, some of them on the caller's
+	hardware queue (what the probe leaves when every candidate shares a queue) -- changes the schedule, never a number: a full-size
+	backward through a context of that kind is bit-identical to the one through the default context."""
+	import ctypes
+	from find_amd import _lib, synthetic
+	L = _lib.lib()
+	dev = torch.cuda.current_device()
+	model = synthetic.make_model(6890, train_size=4, val_size=1, device='cuda')
+	lat = synthetic.latents(4, seed=3, device='cuda')
+
+	def grads():
+		model.zero_grad(set_to_none=True)
+		lv = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+		res = model.get_meshes(shapevec=lv['shapevec'], reg=lv['reg'], texvec=lv['texvec'], posevec=lv['posevec'])
+		((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()).backward()
+		torch.cuda.synchronize()
+		out = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+		out.update({f'lat/{k}': v.grad.clone() for k, v in lv.items()})
+		return out
+
+	want = grads()
+	h = ctypes.c_void_p()
+	_lib.check(L.find_ctx_create(dev, ctypes.byref(h)), 'find_ctx_create')
+	try:
+		_lib.check(L.find_ctx_set(h, b'bind_streams', 0), 'find_ctx_set(bind_streams)')
+		prev = _lib._ctx.get(dev)
+		_lib._ctx[dev] = h
+		try:
+			got = grads()
+		finally:
+			_lib._ctx[dev] = prev
+	finally:
+		_lib.check(L.find_ctx_destroy(h), 'find_ctx_destroy')
+	assert set(got) == set(want) and len(want) >= 30
+	for n in want:
+		assert torch.equal(got[n], want[n]), n
+
+
 def test_deferred_weight_gradient_join_changes_no_gradient_and_is_joined_when_backward_returns(golden_main):
 	"""The texture pass asks for its weight gradients to trail the backward (defer_wgrad_join=True -> find_ctx "defer_join"): the
 	gradients read on the caller's stream right after backward() -- no device synchronisation in between -- equal those of the run that
