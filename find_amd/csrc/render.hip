@@ -819,8 +819,13 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 	// Candidate lists: every pixel (thread) owns ONE contiguous run of KN_CAP depths and one of KN_CAP (1 - p) values.  A lane collects
 	// RING candidates in LDS and writes them out as whole 32-byte pieces (two 16-byte stores per array): the lists reach memory as
 	// full sectors, once.
-	float* const scr_z = reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256) + tid * KN_CAP;
-	float* const scr_q = scr_z + KN_CAP * 256;
+	// Layout of a wave's lists: 32-byte piece k of lane l at piece index k * 64 + l -- the pieces of the 64 lanes side by side.  Lanes of
+	// a tile fill their pieces at about the same pace, so L2 completes 128-byte lines out of four lanes' pieces before it evicts them, and
+	// the K-nearest pass reads "16 bytes of every lane's piece k" as one coalesced 2-KB access (a lane-contiguous run of KN_CAP entries
+	// per lane put every 32-byte piece into a DRAM row of its own and every list read into 64 different lines).
+	float4* const wz4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256) + wave * (KN_CAP * 64));
+	float4* const wq4 = wz4 + KN_CAP * 256 / 4;
+	auto lidx = [&](int j) __attribute__((always_inline)) { return ((j >> 1) * 64 + lane) * 2 + (j & 1); };   // 16-byte word j of this lane's list
 	auto flush_ring = [&](int base, int valid) __attribute__((always_inline)) {   // ring -> list entries [base, base + RING); slots >= valid become (+inf, 1): never selected
 		float zv[RING], qv[RING];
 #pragma unroll
@@ -830,8 +835,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 		}
 #pragma unroll
 		for (int u = 0; u < RING; u += 4) {
-			*reinterpret_cast<float4*>(scr_z + base + u) = make_float4(zv[u], zv[u + 1], zv[u + 2], zv[u + 3]);
-			*reinterpret_cast<float4*>(scr_q + base + u) = make_float4(qv[u], qv[u + 1], qv[u + 2], qv[u + 3]);
+			wz4[lidx((base + u) >> 2)] = make_float4(zv[u], zv[u + 1], zv[u + 2], zv[u + 3]);
+			wq4[lidx((base + u) >> 2)] = make_float4(qv[u], qv[u + 1], qv[u + 2], qv[u + 3]);
 		}
 	};
 
@@ -1000,8 +1005,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 				if (over && cnt <= KN_CAP) {
 					// the candidates still in the ring join the list, padded to a whole piece with (+inf, 1) entries that no pass selects
 					if (cnt & (RING - 1)) flush_ring(cnt & ~(RING - 1), cnt & (RING - 1));
-					const float4* z4 = reinterpret_cast<const float4*>(scr_z);
-					const float4* q4 = reinterpret_cast<const float4*>(scr_q);
+					const float4* z4 = wz4;
+					const float4* q4 = wq4;
 					const int n4 = (cnt + 3) >> 2;   // 16-byte pieces to read (the padding of the last one is inert)
 					// one pass over the lane's depths, KU entries in flight, fn(bits of the depth)
 					auto scan_z = [&](auto&& fn) {
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 						for (; i + KU / 4 <= n4; i += KU / 4) {
 							float4 v[KU / 4];
 #pragma unroll
-							for (int u = 0; u < KU / 4; ++u) v[u] = z4[i + u];
+							for (int u = 0; u < KU / 4; ++u) v[u] = z4[lidx(i + u)];
 #pragma unroll
 							for (int u = 0; u < KU / 4; ++u) {
 								fn(__float_as_uint(v[u].x + 0.0f)); fn(__float_as_uint(v[u].y + 0.0f));
@@ -1017,7 +1022,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 							}
 						}
 						for (; i < n4; ++i) {
-							const float4 v = z4[i];
+							const float4 v = z4[lidx(i)];
 							fn(__float_as_uint(v.x + 0.0f)); fn(__float_as_uint(v.y + 0.0f)); fn(__float_as_uint(v.z + 0.0f)); fn(__float_as_uint(v.w + 0.0f));
 						}
 					};
@@ -1104,14 +1109,14 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 						for (; i + KU / 4 <= n4; i += KU / 4) {
 							float4 zv[KU / 4], qv[KU / 4];
 #pragma unroll
-							for (int u = 0; u < KU / 4; ++u) { zv[u] = z4[i + u]; qv[u] = q4[i + u]; }
+							for (int u = 0; u < KU / 4; ++u) { zv[u] = z4[lidx(i + u)]; qv[u] = q4[lidx(i + u)]; }
 #pragma unroll
 							for (int u = 0; u < KU / 4; ++u) {
 								take(zv[u].x, qv[u].x); take(zv[u].y, qv[u].y); take(zv[u].z, qv[u].z); take(zv[u].w, qv[u].w);
 							}
 						}
 						for (; i < n4; ++i) {
-							const float4 zv = z4[i], qv = q4[i];
+							const float4 zv = z4[lidx(i)], qv = q4[lidx(i)];
 							take(zv.x, qv.x); take(zv.y, qv.y); take(zv.z, qv.z); take(zv.w, qv.w);
 						}
 					}
