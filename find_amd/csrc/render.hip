@@ -16,7 +16,7 @@
 //      evaluates them for its own pixel -- no workgroup barrier anywhere.  Faces arrive front to back, so a pixel that already holds
 //      faces_per_pixel candidates in front of everything still to come is FINISHED, and the wave leaves the list when all its pixels
 //      are (an interior pixel of a closed surface never looks at the far side).  Candidates (depth, 1 - p) go to the lane's own
-//      contiguous run of a scratch through an LDS ring; a pixel with more than K of them selects the K nearest by a radix search on
+//      list in the wave's scratch (32-byte pieces, the 64 lanes' pieces side by side) through an LDS ring; a pixel with more than K of them selects the K nearest by a radix search on
 //      its own list (the K-th depth is saved for the backward).  The tail shades the nearest inside fragment, writes mask / image.
 //   5. tie_fix_kernel   : PyTorch3D keeps, among candidates of EQUAL depth at the K-th place, those of lower face index (insertion
 //      order).  Lists are in depth order, not face order, so pixels where candidates tied at the K-th depth were left out are
@@ -756,8 +756,8 @@ __global__ __launch_bounds__(1024) void order_fill_kernel(const int2* __restrict
 // ------------------------------------------------------------------------------------------------ 4. rasteriser
 // Persistent waves, each a worker of its own: tile from the queues -> list from the pool, 64 faces at a time (the next 64 records are on
 // their way from memory while these are evaluated) -> every lane evaluates the staged records for its own pixel.  Silhouette candidates
-// multiply into the pixel's alpha and are appended (depth, 1 - p) to the lane's own contiguous run of the workgroup's scratch through an
-// LDS ring (whole 32-byte pieces, written once).  The list is in depth-slab order: after a batch, every face still to come lies behind
+// multiply into the pixel's alpha and are appended (depth, 1 - p) to the lane's own list in the wave's scratch through an
+// LDS ring (whole 32-byte pieces, written once; piece k of the 64 lanes side by side).  The list is in depth-slab order: after a batch, every face still to come lies behind
 // `front`, so a pixel that holds K candidates in front of `front` has its K nearest, and a pixel whose nearest inside fragment lies in
 // front of it has its colour -- the wave leaves the list when every pixel is finished.  A pixel that ends with more than K candidates
 // finds the K-th smallest depth of its list by a lane-parallel radix search and blends the K nearest; where candidates tied at that depth
@@ -816,9 +816,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 	const int K = a.sil_faces_per_pixel;
 	const bool early = !(a.ablate & 8);
 	const int n_order = a.qn[62];
-	// Candidate lists: every pixel (thread) owns ONE contiguous run of KN_CAP depths and one of KN_CAP (1 - p) values.  A lane collects
-	// RING candidates in LDS and writes them out as whole 32-byte pieces (two 16-byte stores per array): the lists reach memory as
-	// full sectors, once.
+	// Candidate lists: every pixel (thread) owns up to KN_CAP depths and KN_CAP (1 - p) values.  A lane collects RING candidates in LDS and
+	// writes them out as whole 32-byte pieces (two 16-byte stores per array): the lists reach memory as full sectors, once.
 	// Layout of a wave's lists: 32-byte piece k of lane l at piece index k * 64 + l -- the pieces of the 64 lanes side by side.  Lanes of
 	// a tile fill their pieces at about the same pace, so L2 completes 128-byte lines out of four lanes' pieces before it evicts them, and
 	// the K-nearest pass reads "16 bytes of every lane's piece k" as one coalesced 2-KB access (a lane-contiguous run of KN_CAP entries
