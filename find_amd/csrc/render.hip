@@ -79,7 +79,7 @@ struct Ws {
 	float* zthr;      // (n_img, H, W) depth bound of the K nearest silhouette candidates (+inf: every candidate counts; negative: -depth, ties at it resolved by tie_face)  [backward]
 	float* alpha;     // (n_img, H, W) prod (1 - p_k) over the blended candidates  [backward: 1 - mask has lost it wherever the mask rounds to 1]
 	int32_t* tie_face; // (n_img, H, W) last face kept among those tied at the K-th depth (valid where zthr < 0)  [backward]
-	float2* scratch;  // (raster workgroups, 2, 256, KN_CAP) per-pixel candidate lists of the tile in flight: depths, then 1 - p; one contiguous run per pixel
+	float2* scratch;  // (raster workgroups, 2, 256, KN_CAP) per-pixel candidate lists of the tile in flight: depths, then 1 - p; per wave, 32-byte piece k of lane l at piece index 64 k + l
 	int2* tinfo;      // (n_img, tiles) list of a tile: x = offset into pool, y = length | LIST_UNSORTED, or -1: no room in the pool (the rasteriser scans the faces itself)
 	uint32_t* pool;   // list entries: slab << 24 | face
 	int32_t* order;   // (n_img * tiles) ids of the tiles that have a list, the longest lists first
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 		}
 
 		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
-		// lane finds the K-th smallest depth of its OWN list (16-byte reads of its contiguous run) by a radix search
+		// lane finds the K-th smallest depth of its OWN list (16-byte reads of its pieces) by a radix search
 		// on the integer image of the depth (non-negative floats order like their bit patterns) with one counting pass per
 		// step, then blends the candidates in front of it and as many of those AT it as still fit.
 		float thr = INFINITY;
