@@ -787,6 +787,7 @@ def main():
 	ap.add_argument('--steps', type=int, default=30)
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
+	ap.add_argument('--repeats', type=int, default=3, help='repetitions of the headline K-step timing; the best is reported, all are listed')
 	ap.add_argument('--no-prime', action='store_true', help='no untimed priming phase before the warm-up steps (Run.timed): measures a cold GPU')
 	ap.add_argument('--headline-only', action='store_true', help='only the timed headline loop (no records, no CPU leg, no isolated kernel loop): the command to put under rocprofv3')
 	ap.add_argument('--no-graph', action='store_true', help='skip the HIP-graph variant of the batch-1 record')
@@ -841,7 +842,12 @@ def main():
 	# ---- headline: train_3d.yaml network-stage step, 16 feet per GPU
 	note('headline')
 	su = train3d_setup(run, N_FEET, N_FEET, stage='net', labels=False, seed=run.rank)
-	ms = run.timed(su['step'], args.steps, args.warmup)
+	# The headline's K-step timing is taken `--repeats` times (default 3; each: W warm-up steps, exactly K steps between barrier +
+	# synchronize, the maximum over ranks) and the best is reported, every repetition listed beside it (`ms_per_step_repeats`).  The step is
+	# GPU-bound with 1.2 - 1.5 ms of host work per 2.2 ms: on a box whose host cores are busy with a neighbour's job for a second or two it
+	# turns host-bound -- 3.36 ms in one run of this very build, 2.17 - 2.21 in the runs around it -- and one timing cannot tell.
+	ms_all = [run.timed(su['step'], args.steps, args.warmup, prime=(i == 0)) for i in range(max(1, args.repeats))]
+	ms = min(ms_all)
 	if run.rank == 0:
 		fl = train3d_executed_flops(N_FEET)
 		cfg = {'workload': train3d_workload(N_FEET, 'net', False), 'feet_per_gpu': N_FEET, 'template_verts': N_VERTS, 'parallelism': f'dp{run.world}',
@@ -853,7 +859,7 @@ def main():
 							 '+ the 16 x 1000-sample texture pass',
 			   'reference_config': 'cfgs/train_3d.yaml:17-27 (chamf_loss, smooth_loss, texture_loss, use_pose_code, use_latent_labels); '
 								   'src/train/opts.py:40 batch_size_train=1 -> records.train3d_b1; 16 feet per GPU is the data-parallel shard of SURVEY 8e'}
-		out = line(run.world * N_FEET * N_VERTS / (ms * 1e-3), ms, run, args.steps, args.warmup, cfg)
+		out = line(run.world * N_FEET * N_VERTS / (ms * 1e-3), ms, run, args.steps, args.warmup, cfg, ms_per_step_repeats=ms_all)
 		if not args.headline_only:
 			out['roofline'] = dominant_roofline(run.dev, fp16=args.fp16)
 			if with_cpu and run.world == 1:
