@@ -302,7 +302,8 @@ def test_lazy_colour_containers_evaluate_once_and_only_when_read():
 	assert torch.equal(t.clone().verts_features_padded(), t.detach().verts_features_padded()) and len(calls) == 1
 	with pytest.raises(ValueError):
 		LazyTexturesVertex(lambda: torch.zeros(5, 3)).verts_features_padded()
-	res = _LazyColours(dict(disp=torch.zeros(1)), thunk)
+	from find_amd.model import _Once
+	res = _LazyColours(dict(disp=torch.zeros(1)), _Once(thunk))
 	assert 'col' not in res and set(res) == {'disp'} and len(calls) == 1
 	assert res['col'].shape == (2, 5, 3) and len(calls) == 2 and 'col' in res
 	assert res['col'] is res['col'] and len(calls) == 2
