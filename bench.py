@@ -177,10 +177,10 @@ class Run:
 
 	def timed(self, step, steps, warmup, prime=True):
 		"""W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides (the driver's contract).  Before
-		the warm-up the workload is PRIMED -- untimed steps for at least PRIME_S seconds, until the step time has settled: a process that starts on an idle GPU finds it at its idle
-		clocks, and the part takes a few hundred milliseconds of load to come up to speed (the headline measured straight after start-up on
-		a fresh box: 3.64 ms per step; the same build one record later in the same process: 2.19); a step count cannot express that, a
-		warm-up of 5 steps is 11 ms.  What is timed is unchanged: K steps of the steady state.  `--no-prime` switches it off."""
+		the warm-up the workload is PRIMED -- untimed steps for at least PRIME_S seconds, until the step time has settled -- so that first-use
+		costs of a fresh process (allocator growth, queue probing, module loads) are behind it whatever W is.  What is timed is unchanged:
+		K steps of the steady state.  `--no-prime` switches it off.  (what looked like a cold-start effect when this was added was
+		a reference cycle in the product, found by the repeats and fixed.)"""
 		if prime and Run.PRIME_S > 0:
 			# batches of eight steps until at least PRIME_S seconds have gone by AND two consecutive batches agree within 5 % (at most
 			# 8 x PRIME_S: the first process on a fresh box also pays first-use costs -- allocator growth, queue probing, module loads --
@@ -843,9 +843,9 @@ def main():
 	note('headline')
 	su = train3d_setup(run, N_FEET, N_FEET, stage='net', labels=False, seed=run.rank)
 	# The headline's K-step timing is taken `--repeats` times (default 3; each: W warm-up steps, exactly K steps between barrier +
-	# synchronize, the maximum over ranks) and the best is reported, every repetition listed beside it (`ms_per_step_repeats`).  The step is
-	# GPU-bound with 1.2 - 1.5 ms of host work per 2.2 ms: on a box whose host cores are busy with a neighbour's job for a second or two it
-	# turns host-bound -- 3.36 ms in one run of this very build, 2.17 - 2.21 in the runs around it -- and one timing cannot tell.
+	# synchronize, the maximum over ranks) and the best is reported, every repetition listed beside it (`ms_per_step_repeats`): a step whose
+	# host work is 1.2 - 1.5 ms of its 2.2 ms is sensitive to whatever else the host does, and a run that drifts (2.19, 2.35, 3.94 ms: a
+	# memory leak) shows in the list where one timing would just have been "slow".
 	ms_all = [run.timed(su['step'], args.steps, args.warmup, prime=(i == 0)) for i in range(max(1, args.repeats))]
 	ms = min(ms_all)
 	if run.rank == 0:
