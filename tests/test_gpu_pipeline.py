@@ -367,20 +367,23 @@ def test_a_step_leaves_nothing_to_the_cyclic_garbage_collector():
 	memory per step and a long loop slowed down by half)."""
 	import gc
 	from find_amd.train_utils import sample_latent_vectors
+	from find_amd import functional_render as FR
 	mwl, opts, batch, _ = _setup()
-	held = []
-	gc.collect()
-	gc.disable()
-	try:
-		for _ in range(5):
-			mwl.zero_grad(set_to_none=True)
-			b = dict(batch)
-			b.update(sample_latent_vectors(b, mwl.model.latent_vectors_train))
-			loss, losses = mwl(b, 0, opts, chamf=True, smooth=True, texture=True)
-			loss.backward()
-			del loss, losses, b
-			torch.cuda.synchronize()
-			held.append(torch.cuda.memory_allocated())
-	finally:
-		gc.enable()
-	assert held[4] == held[3] == held[2], held
+	for flags in (dict(chamf=True, smooth=True, texture=True), dict(sil=True, render_foot=True), dict(sil=True, pix=True, chamf=True, render_foot=True)):
+		held = []
+		gc.collect()
+		gc.disable()
+		try:
+			for _ in range(5):
+				mwl.zero_grad(set_to_none=True)
+				b = dict(batch)
+				b.update(sample_latent_vectors(b, mwl.model.latent_vectors_train))
+				loss, losses = mwl(b, 0, opts, **flags)
+				loss.backward()
+				del loss, losses, b
+				torch.cuda.synchronize()
+				FR.check_render_flags(wait=True)   # (the watchdog's pending entries are host-side)
+				held.append(torch.cuda.memory_allocated())
+		finally:
+			gc.enable()
+		assert held[4] == held[3] == held[2], (flags, held)
