@@ -195,7 +195,8 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
 /* Process-wide profiling switch of the rasteriser (diagnosis only; bits 1, 2, 4 and 32 make the render WRONG):
  * bits 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 32 no bbox scan in the binning pass, 64 statistics in the flags;
  * bits with unchanged results (tests/test_gpu_render.py compares them): 8 no early exit of finished pixels / tiles, 16 tile lists left in
- * face order (no depth-slab sort), 256 a list pool of 512 entries per image (tiles without room scan the faces themselves). */
+ * face order (no depth-slab sort), 256 a list pool of 512 entries per image (tiles without room scan the faces themselves);
+ * and of find_chamfer_fwd's neighbour search: 512 all pairs at every size, 1024 the uniform grid from 64 points per cloud on (geom.hip). */
 int find_debug_raster_ablate(int64_t bits);
 
 /* ------------------------------------------------------------------------------------------------

@@ -359,3 +359,52 @@ def test_image_mse_vs_torch(shape):
 	assert (am2.grad * 3.0 - am.grad).abs().max().item() < 1e-5 * max(1e-6, am.grad.abs().max().item()) + 1e-12
 	with pytest.raises(RuntimeError):
 		FN.image_mse(img.cuda(), gimg.cuda()[:, :, :-1])
+
+
+def test_chamfer_through_the_grid_equals_brute_force_bit_for_bit():
+	"""Large clouds (the evaluation's 10 000 samples) go through a uniform grid over the targets (nn_grid_*_kernel) instead of all pairs;
+	here the grid is switched on for every size (bit 1024 of the profiling switch) and off (bit 512).  The answer must be
+	the brute-force kernel's to the bit -- loss and both gradients -- on inputs chosen to stress the search: surface-like clouds (the FIND
+	case), a Gaussian blob, everything in one cell, duplicates (ties: the lowest index wins), queries far outside the targets' bounding box
+	(the cubes grow to the whole grid), ragged lengths incl. an empty cloud, and the eval size."""
+	from find_amd import _lib
+	from find_amd import functional as FN
+	g = torch.Generator().manual_seed(77)
+
+	def sphere(n, p, r=0.1, noise=1e-3):
+		v = torch.randn(n, p, 3, generator=g)
+		return v / v.norm(dim=-1, keepdim=True) * r + noise * torch.randn(n, p, 3, generator=g)
+
+	cases = []
+	cases.append(('surface', sphere(3, 5000), sphere(3, 5000), None, None))
+	cases.append(('blob', torch.randn(2, 4000, 3, generator=g) * 0.05, torch.randn(2, 3000, 3, generator=g) * 0.05, None, None))
+	y1 = torch.randn(1, 2500, 3, generator=g) * 1e-6 + 0.3   # all targets in one cell of their own tiny box; queries elsewhere
+	cases.append(('one cell', torch.randn(1, 2500, 3, generator=g), y1, None, None))
+	xd, yd = sphere(1, 3000), sphere(1, 3000)
+	yd[0, 100:200] = yd[0, 0:100]          # duplicated targets
+	xd[0, :50] = yd[0, 100:150]            # queries exactly on duplicated targets (distance 0 to two indices)
+	cases.append(('duplicates', xd, yd, None, None))
+	xo = sphere(1, 2100)
+	xo[0, :64] = xo[0, :64] * 50.0 + 3.0   # queries far outside the targets' box
+	cases.append(('outliers', xo, sphere(1, 2100), None, None))
+	cases.append(('ragged', sphere(3, 4096), sphere(3, 2048), torch.tensor([4096, 0, 2500], dtype=torch.int64), torch.tensor([2048, 1000, 0], dtype=torch.int64)))
+	cases.append(('eval size', sphere(1, 10000), sphere(1, 10000, noise=2e-3), None, None))
+	for name, x, y, xl, yl in cases:
+		out = []
+		for brute in (False, True):
+			_lib.set_tuning('raster_ablate', 512 if brute else 1024)
+			try:
+				xg, yg = x.clone().cuda().requires_grad_(True), y.clone().cuda().requires_grad_(True)
+				loss, _ = FN.chamfer_distance(xg, yg, None if xl is None else xl.cuda(), None if yl is None else yl.cuda())
+				loss.backward()
+				torch.cuda.synchronize()
+				out.append((loss.detach().clone(), xg.grad.clone(), yg.grad.clone()))
+			finally:
+				_lib.set_tuning('raster_ablate', 0)
+		(l0, gx0, gy0), (l1, gx1, gy1) = out
+		assert torch.equal(l0, l1), (name, l0.item(), l1.item())
+		# (a cloud's gradient holds a float-atomic scatter -- its role as the other direction's target --: sums of the same addends in
+		#  another order.  A different neighbour anywhere, also between duplicates, moves a whole addend to another row.)
+		assert (gx0 - gx1).abs().max().item() <= 1e-6 * max(gx1.abs().max().item(), 1e-12), name
+		assert (gy0 - gy1).abs().max().item() <= 1e-6 * max(gy1.abs().max().item(), 1e-12), name
+		assert torch.isfinite(l0).all()

@@ -386,4 +386,5 @@ def test_a_step_leaves_nothing_to_the_cyclic_garbage_collector():
 				held.append(torch.cuda.memory_allocated())
 		finally:
 			gc.enable()
-		assert held[4] == held[3] == held[2], (flags, held)
+		# (a leak grows by a step's memory EVERY step -- 27 MB here with the old cycle; workspace buffers that two steps take turns with do not)
+		assert held[4] - held[2] < 2 ** 20 and held[3] - held[1] < 2 ** 20, (flags, held)
