@@ -916,7 +916,8 @@ __global__ __launch_bounds__(256) void nn_grid_query_kernel(const GridQueryArgs 
 	const float qx = q[0], qy = q[1], qz = q[2];
 	const float ox = box[0], oy = box[1], oz = box[2], ivx = box[3], ivy = box[4], ivz = box[5];
 	const float clx = 1.0f / ivx, cly = 1.0f / ivy, clz = 1.0f / ivz;
-	const int cx = min(max((int)((qx - ox) * ivx), 0), NG - 1), cy = min(max((int)((qy - oy) * ivy), 0), NG - 1), cz = min(max((int)((qz - oz) * ivz), 0), NG - 1);
+	const float rx = qx - ox, ry = qy - oy, rz = qz - oz;
+	const int cx = min(max((int)(rx * ivx), 0), NG - 1), cy = min(max((int)(ry * ivy), 0), NG - 1), cz = min(max((int)(rz * ivz), 0), NG - 1);
 	unsigned long long best = ~0ull;
 	auto scan_row = [&](int z, int yy, int x0, int x1) {   // cells (x0..x1, yy, z): contiguous in the sorted order
 		const int c = (z * NG + yy) * NG;
@@ -941,13 +942,18 @@ __global__ __launch_bounds__(256) void nn_grid_query_kernel(const GridQueryArgs 
 		if (x0 == 0 && x1 == NG - 1 && y0 == 0 && y1 == NG - 1 && z0 == 0 && z1 == NG - 1) break;   // the whole grid
 		// anything not scanned yet lies beyond a face of the cube that is inside the grid: at least `gap` away along that axis
 		float gap = INFINITY;
-		// (cell assignment and face positions are rounded: a ten-thousandth of a cell is far more margin than that needs)
-		if (cx - r > 0) gap = fminf(gap, qx - (ox + (cx - r) * clx) - 1e-4f * clx);
-		if (cx + r < NG - 1) gap = fminf(gap, (ox + (cx + r + 1) * clx) - qx - 1e-4f * clx);
-		if (cy - r > 0) gap = fminf(gap, qy - (oy + (cy - r) * cly) - 1e-4f * cly);
-		if (cy + r < NG - 1) gap = fminf(gap, (oy + (cy + r + 1) * cly) - qy - 1e-4f * cly);
-		if (cz - r > 0) gap = fminf(gap, qz - (oz + (cz - r) * clz) - 1e-4f * clz);
-		if (cz + r < NG - 1) gap = fminf(gap, (oz + (cz + r + 1) * clz) - qz - 1e-4f * clz);
+		// Distances to the cube's faces are formed RELATIVE to the box origin (q - o once, then minus k cells): in absolute coordinates
+		// one ulp of an origin far from zero (a scan in millimetres placed a metre away) would exceed any fixed share of a cell.  The
+		// margin covers the rounding of q - o and t - o on both sides of a cell boundary: a ten-thousandth of a cell plus a few ulps of
+		// the larger of |origin| and |query|.
+		const float mx = 1e-4f * clx + 6e-7f * fmaxf(fabsf(ox), fabsf(qx)), my = 1e-4f * cly + 6e-7f * fmaxf(fabsf(oy), fabsf(qy)),
+					mz = 1e-4f * clz + 6e-7f * fmaxf(fabsf(oz), fabsf(qz));
+		if (cx - r > 0) gap = fminf(gap, rx - (cx - r) * clx - mx);
+		if (cx + r < NG - 1) gap = fminf(gap, (cx + r + 1) * clx - rx - mx);
+		if (cy - r > 0) gap = fminf(gap, ry - (cy - r) * cly - my);
+		if (cy + r < NG - 1) gap = fminf(gap, (cy + r + 1) * cly - ry - my);
+		if (cz - r > 0) gap = fminf(gap, rz - (cz - r) * clz - mz);
+		if (cz + r < NG - 1) gap = fminf(gap, (cz + r + 1) * clz - rz - mz);
 		gap = fmaxf(gap, 0.f);
 		if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) < gap * gap * 0.9999f) break;
 	}

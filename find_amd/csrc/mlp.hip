@@ -4,6 +4,7 @@
 #include "mlp_dw4.h"
 #include "mlp_dwpe.h"
 #include "mlp_gemm5.h"
+#include "mlp_gemm6.h"
 #include "mlp_dw3.h"
 #include "mlp_gemm4.h"
 #include "mlp_fused.h"
@@ -114,7 +115,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_DW2, K_DW3, K_FUSED, K_FUSED2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_DW2, K_DW3, K_FUSED, K_FUSED2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -137,6 +138,7 @@ struct find_ctx {
 	                              // gradient needed (its reduce only got a CU when a ring workgroup retired); with dw4_kernel the reduce behind its
 	                              // launch on Q is 0.6 - 0.9 % faster (train_3d 3.245 -> 3.225 ms, C2 2.220 -> 2.199), so off by default
 	int gemm5_min_units = 1024;
+	int gemm6_min_units = 1024;
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which
 	                              // round 2 showed to be about registers, not LDS (see "Co-residence" below); off by default now
@@ -161,6 +163,7 @@ struct find_ctx {
 	bool pend[N_SIDE] = {};       // side stream k carries deferred work nobody has waited for yet
 	// set per call
 	bool f16 = false;
+	bool x3 = false;              // this call runs its 256 -> 256 layers as bf16x3 (fp32-faithful on the bf16 matrix pipe, mlp_gemm6.h)
 };
 
 namespace find {
@@ -374,6 +377,25 @@ static int launch_gemm5(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, 
 	return launch_gemm5_t<EPI_NONE>(c, a, feet, s);
 }
 
+template <int EPI>
+static int launch_gemm6_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
+	int lds = 0;
+	const int rc = prepare_kernel(c, K_GEMM6_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2), &gemm6_kernel<EPI>, GEMM6_LDS, &lds);
+	if (rc != FIND_OK) return rc;
+	a.tiles_per_foot = (int)cdiv(a.V, 32);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	constexpr int G = 8 * (8 / G6_NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
+	const int grid = std::max(G, (c->num_cus / G) * G);
+	hipLaunchKernelGGL((gemm6_kernel<EPI>), dim3(grid), dim3(GEMM6_NW * 64), lds, s, a);
+	return FIND_OK;
+}
+
+static int launch_gemm6(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) return launch_gemm6_t<EPI_BIAS_RELU>(c, a, feet, s);
+	if (epi == EPI_MASK) return launch_gemm6_t<EPI_MASK>(c, a, feet, s);
+	return launch_gemm6_t<EPI_NONE>(c, a, feet, s);
+}
+
 static int launch_gemm3(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (epi == EPI_BIAS_RELU) return launch_gemm3_t<64, EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK) return launch_gemm3_t<64, EPI_MASK>(c, a, feet, s);
@@ -399,6 +421,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	const bool k256 = b.nseg == 1 && b.nchunk == 8;
 	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
 	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s);
+	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm6(c, epi, b, feet, s);
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
 	return launch_gemm3(c, epi, b, feet, s);
@@ -468,7 +491,8 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 	*spf = (int)cdiv(cpf, *cps);
 }
 
-static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 != 0); }
+static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 == 1); }
+static bool call_x3(const find_ctx* c, const find_mlp_params* p) { return p->precision == 3 || (p->precision == 0 && c->mlp_f16 == 2); }
 
 static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const Dims& d, const FwdWs& w, const float* pos, const float* lat_disp,
 						const float* lat_col, float* disp, float* col) {
@@ -643,7 +667,7 @@ extern "C" int find_mlp_fwd(find_ctx* c, const find_mlp_params* p, const float* 
 	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_fwd: lat_disp pointer does not match params.lat_disp=%d", p->lat_disp);
 	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_fwd: lat_col pointer does not match params.lat_col=%d", p->lat_col);
 	FIND_REQUIRE(disp || col, "find_mlp_fwd: both outputs NULL");
-	FIND_REQUIRE(p->precision >= 0 && p->precision <= 2, "find_mlp_fwd: params.precision must be 0 (context default), 1 (fp32) or 2 (fp16), got %d", p->precision);
+	FIND_REQUIRE(p->precision >= 0 && p->precision <= 3, "find_mlp_fwd: params.precision must be 0 (context default), 1 (fp32 MFMA), 2 (fp16) or 3 (bf16x3), got %d", p->precision);
 	FwdWs w;
 	carve_fwd(p, d, save_for_bwd != 0, ws, &w);
 	if (ws_bytes < w.bytes) {
@@ -651,6 +675,7 @@ extern "C" int find_mlp_fwd(find_ctx* c, const find_mlp_params* p, const float* 
 		return FIND_EWORKSPACE;
 	}
 	c->f16 = call_f16(c, p);
+	c->x3 = call_x3(c, p);
 	Fork fk(c, reinterpret_cast<hipStream_t>(stream), c->fwd_streams != 0);
 	const int rc = mlp_fwd_body(c, fk, p, d, w, pos, lat_disp, lat_col, disp, col);
 	const int rj = fk.join();   // on every path: the caller may free `ws` right after an error return
@@ -662,7 +687,8 @@ extern "C" int find_linear_relu_fwd(find_ctx* c, const float* x, const float* w,
 	FIND_REQUIRE(x && w && b && y, "find_linear_relu_fwd: NULL argument");
 	FIND_REQUIRE(n_feet >= 1 && n_pts >= 1 && n_feet < (1 << 16), "find_linear_relu_fwd: bad sizes");
 	FIND_REQUIRE(aligned16(w) && aligned16(x), "find_linear_relu_fwd: x and w must be 16-byte aligned");
-	c->f16 = c->mlp_f16 != 0;
+	c->f16 = c->mlp_f16 == 1;
+	c->x3 = c->mlp_f16 == 2;
 	FIND_TRY(linear_fwd(c, x, n_pts * W, w, W, b, 0, y, n_pts, n_feet, reinterpret_cast<hipStream_t>(stream)));
 	FIND_LAUNCH_CHECK("find_linear_relu_fwd");
 	return FIND_OK;
@@ -1329,7 +1355,8 @@ extern "C" int find_linear_wgrad(find_ctx* c, const float* dz, const float* x, i
 	memset(&b, 0, sizeof(b));
 	b.pw = static_cast<float*>(scratch);
 	b.pb = b.pw + wgrad_slabs(n_feet) * W * W;
-	c->f16 = c->mlp_f16 != 0;
+	c->f16 = c->mlp_f16 == 1;
+	c->x3 = c->mlp_f16 == 2;
 	FIND_TRY(weight_grad(c, nullptr, dz, x, n_pts * W, nullptr, 0, nullptr, 1, n_feet, n_pts, b, dw, W, W, 0, db, nullptr, reinterpret_cast<hipStream_t>(stream)));
 	FIND_LAUNCH_CHECK("find_linear_wgrad");
 	return FIND_OK;
@@ -1354,7 +1381,7 @@ extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* 
 	FIND_REQUIRE(pos && ws && scratch && g, "find_mlp_bwd: NULL argument");
 	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
 	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
-	FIND_REQUIRE(p->precision >= 0 && p->precision <= 2, "find_mlp_bwd: params.precision must be 0, 1 or 2 (got %d)", p->precision);
+	FIND_REQUIRE(p->precision >= 0 && p->precision <= 3, "find_mlp_bwd: params.precision must be 0, 1, 2 or 3 (got %d)", p->precision);
 	{
 		// weight-gradient buffers: all of them (a head without an upstream gradient may leave its own out: nothing is written for it), or
 		// none at all (frozen network: latent gradients only)
@@ -1378,6 +1405,7 @@ extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* 
 		return FIND_EWORKSPACE;
 	}
 	c->f16 = call_f16(c, p);
+	c->x3 = call_x3(c, p);
 	Fork fk(c, reinterpret_cast<hipStream_t>(stream), c->bwd_streams != 0);
 	// "defer_join" (one call: the knob is taken down here): the weight gradients of a small per-foot call -- the texture pass of a
 	// train_3d step, 0.28 ms of grouped and Fourier-layer weight gradients that nothing reads until the main pass adds its own -- keep
@@ -1573,7 +1601,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };
 }  // namespace
 

@@ -18,7 +18,8 @@ def init_from_env(backend=None):
 		os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 		os.environ.setdefault('MASTER_PORT', '29500')
 		if backend is None:
-			backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+			# FIND_DIST_BACKEND=gloo: diagnostic runs of the multi-rank code path on fewer GPUs than ranks (gloo stages device tensors through the host)
+			backend = os.environ.get('FIND_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
 		if backend == 'nccl':
 			torch.cuda.set_device(local)
 		dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -81,8 +82,12 @@ class GradBucket:
 			functional.unregister_grad_arena(self)
 			self.arena = False
 
-	def allreduce_(self):
+	def allreduce_(self, async_op=False):
+		"""Average the gradients over the ranks: ONE collective on the flat bucket.  async_op=True issues it and returns -- the caller goes on
+		enqueueing work that does not read the gradients and calls wait() before the optimiser step (RCCL runs the collective on its own
+		stream behind everything the current stream held at the call; wait() makes the current stream wait for it, the host never blocks)."""
 		self.taken = [False] * len(self.params)
+		self._pending = None
 		if not (dist.is_available() and dist.is_initialized()):
 			return
 		world = dist.get_world_size(self.group)
@@ -97,11 +102,21 @@ class GradBucket:
 			torch._foreach_zero_([v for _, v in missing])
 		if src:
 			torch._foreach_copy_(dst, src)
-		if dist.get_backend(self.group) == 'nccl':
-			dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-		else:
-			dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-			self.flat.div_(world)
+		avg = dist.get_backend(self.group) == 'nccl'   # RCCL averages in place; gloo has no AVG: sum, then divide
+		work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+		self._pending = (work, None if avg else world, src, dst, missing)
+		if not async_op:
+			self.wait()
+
+	def wait(self):
+		"""Finish the collective allreduce_(async_op=True) issued: afterwards every parameter's .grad holds the average."""
+		pend, self._pending = getattr(self, '_pending', None), None
+		if pend is None:
+			return
+		work, div, src, dst, missing = pend
+		work.wait()
+		if div is not None:
+			self.flat.div_(div)
 		if src:  # copy back in one multi-tensor launch (a per-parameter loop is ~30 tiny kernels per step)
 			torch._foreach_copy_(src, dst)
 		for p, v in missing:

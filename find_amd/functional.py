@@ -212,8 +212,12 @@ class _MLP(torch.autograd.Function):
 		key = tuple(w.data_ptr() for w in weights)
 		pending = _PENDING_WGRADS.get(key)
 		can_park = ctx.leaves and not torch.is_grad_enabled() and task >= 0 and all(ctx.needs_input_grad[6:])
-		# (same stream only: the sum must be ordered with whatever reads the parked gradients next)
-		fold = (pending is not None and can_park and pending[0] == task and pending[2] == torch.cuda.current_stream(pos.device))
+		# (on the stream that produced the parked gradients, or -- the texture term on a stream of its own beside the main pass,
+		# model_with_loss.TEXTURE_STREAM -- on another one: the sum then waits for the event recorded behind the first call, and the
+		# stream that called backward() waits for this one when the pass ends, _join_cross)
+		cur = torch.cuda.current_stream(pos.device)
+		fold = pending is not None and can_park and pending[0] == task
+		cross = fold and pending[2] != cur
 		g_lat_disp = torch.empty_like(lat_disp) if (lat_disp is not None and g_disp is not None and ctx.needs_input_grad[2]) else None
 		g_lat_col = torch.empty_like(lat_col) if (lat_col is not None and g_col is not None and ctx.needs_input_grad[3]) else None
 		if not idx and g_lat_disp is None and g_lat_col is None:
@@ -239,7 +243,10 @@ class _MLP(torch.autograd.Function):
 		# adopts the tensor: no kernel), no double backward, the first MLP backward of the task; every buffer the side streams still use
 		# is kept alive until the join, which happens at the end of the next find_mlp_bwd or -- at the latest -- when backward() ends.
 		h = _lib.ctx(pos.device)
-		defer = (DEFER_WGRAD_JOIN and ctx.defer and can_park and not fold and idx and all(w.grad is None for w in weights))
+		# (... and nobody is TOLD about them first: a tensor hook or a post-accumulate-grad hook on a weight would read its gradient as
+		# soon as this node returns -- the texture pass alone in a graph, hooks of a wrapper such as DDP --)
+		defer = (DEFER_WGRAD_JOIN and ctx.defer and can_park and not fold and (pending is None or pending[0] != task) and idx
+				 and all(w.grad is None and not w._backward_hooks and not getattr(w, '_post_accumulate_grad_hooks', None) for w in weights))
 		if defer:
 			check(L.find_ctx_set(h, b'defer_join', 1), 'find_ctx_set(defer_join)')
 		check(L.find_mlp_bwd(h, ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),
@@ -256,6 +263,9 @@ class _MLP(torch.autograd.Function):
 			# add into the parked gradients where the first call parked one; a weight it had nothing for gets this call's gradient as its own
 			slots = pending[1]
 			both = [i for i in idx if slots[i] is not None]
+			if cross:
+				cur.wait_event(pending[3])
+				_sync_at_end_of_backward(cur)
 			if both:
 				torch._foreach_add_([slots[i][0][slots[i][1]:slots[i][1] + grads[i].numel()].view(grads[i].shape) for i in both], [grads[i] for i in both])
 			out = [None if slots[i] is not None else grads[i] for i in range(len(weights))]
@@ -263,7 +273,9 @@ class _MLP(torch.autograd.Function):
 		_PENDING_WGRADS.clear()
 		if can_park and idx and all(grads[i]._base is not None and grads[i]._base.dim() == 1 for i in idx):
 			# (where the gradients live, not the tensors themselves: autograd adopts a gradient as .grad only while nothing else holds it)
-			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) if g is not None else None for g in grads], torch.cuda.current_stream(pos.device))
+			done = torch.cuda.Event()
+			done.record(cur)   # (behind the join of this call's side streams: the gradients are complete where this event sits)
+			_PENDING_WGRADS[key] = (task, [(g._base, g.storage_offset()) if g is not None else None for g in grads], cur, done)
 		return (None, None, g_lat_disp, g_lat_col, None, None, *grads)
 
 
@@ -272,10 +284,19 @@ DEFER_WGRAD_JOIN = _os.environ.get('FIND_DEFER_WGRADS', '1') != '0'   # switch f
 _DEFERRED = {}   # device -> tensors the side streams of a deferred find_mlp_bwd may still be using
 
 
+_DEFERRED_TASK = [None]   # the autograd graph task whose end-of-pass callback will join what _DEFERRED holds
+
+
 def _hold_until_join(device, tensors):
+	task = _graph_task_id()
+	if _DEFERRED and _DEFERRED_TASK[0] != task:
+		# leftovers of a pass that never reached its end-of-pass callback (an exception between the deferred call and the end of that
+		# backward()): join them here -- the callback is queued PER GRAPH TASK, a pass that defers always ends with a join
+		_join_deferred()
 	first = not _DEFERRED
 	_DEFERRED.setdefault(device, []).extend(t for t in tensors if t is not None)
 	if first:
+		_DEFERRED_TASK[0] = task
 		# the latest moment: the end of this backward pass, on the thread and stream that run it
 		torch.autograd.Variable._execution_engine.queue_callback(_join_deferred)
 
@@ -286,6 +307,24 @@ def _join_deferred():
 	for device in list(_DEFERRED):
 		check(min(L.find_ctx_join(_lib.ctx(device), current_stream(device)), 0), 'find_ctx_join')
 	_DEFERRED.clear()
+
+
+_CROSS_STREAMS = []   # streams other than the backward() caller's that hold the last word on a parked gradient of this pass
+
+
+def _sync_at_end_of_backward(stream):
+	if not _CROSS_STREAMS:
+		torch.autograd.Variable._execution_engine.queue_callback(_join_cross)   # runs on the caller's stream when the pass ends
+	if stream not in _CROSS_STREAMS:
+		_CROSS_STREAMS.append(stream)
+
+
+def _join_cross():
+	try:
+		for s in _CROSS_STREAMS:
+			torch.cuda.current_stream(s.device).wait_stream(s)
+	finally:
+		_CROSS_STREAMS.clear()
 
 
 _PENDING_WGRADS = {}   # weight data_ptrs -> (autograd graph-task id, [(flat buffer, offset)] of the gradients the first backward of that task handed to

@@ -60,10 +60,29 @@ def _report(vals, what, policy):
 		raise RuntimeError(msg)
 
 
+_cap_flags = {}     # device -> int32[2]: the counters of renders replayed from a HIP graph, summed on the device
+_cap_used = set()
+
+
+def _check_captured():
+	"""Renders inside a captured step cannot hand their counters to a pinned slot per call; they ADD them to one static device slot
+	(part of the graph, so every replay adds), read back here -- one device-to-host copy, at an epoch boundary (Trainer._epoch_done) or
+	an explicit check_render_flags(wait=True)."""
+	for dev in list(_cap_used):
+		t = _cap_flags[dev]
+		vals = t.tolist()
+		_cap_used.discard(dev)
+		if vals[0] > 0 or vals[1] > 0:
+			t.zero_()
+			_report(vals, 'renders replayed from a HIP graph since the last check', 'warn' if FLAG_POLICY == 'warn' else 'strict')
+
+
 def check_render_flags(wait=False):
 	"""Look at the counters of earlier renders that have arrived (all of them with wait=True): a warning per bad render under the
 	'warn' policy, RuntimeError on the first bad one under 'strict' / 'sync'."""
 	global _pending
+	if wait and _cap_used and FLAG_POLICY != 'ignore':
+		_check_captured()
 	keep = []
 	i = -1
 	try:
@@ -85,8 +104,17 @@ def check_render_flags(wait=False):
 
 def _watch(ws, what):
 	global _slots
-	if FLAG_POLICY == 'ignore' or torch.cuda.is_current_stream_capturing():
+	if FLAG_POLICY == 'ignore':
 		return
+	dev = ws.device
+	if torch.cuda.is_current_stream_capturing():
+		t = _cap_flags.get(dev)   # (allocated by the eager warm-up step that precedes every capture; nothing may be allocated for good in here)
+		if t is not None:
+			t.add_(ws[:8].view(torch.int32))
+			_cap_used.add(dev)
+		return
+	if dev not in _cap_flags:
+		_cap_flags[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
 	check_render_flags()
 	if not _free and _slots is not None:   # nobody ever looked and the ring is full: do it now rather than grow without bound
 		check_render_flags(wait=True)

@@ -169,6 +169,8 @@ class GraphedStep:
 			return loss, losses
 
 		self._load(st, batch)
+		if st.views_host is not None:
+			st.views_fresh = True   # (that _load consumed the flag without drawing: the captured poses serve the first REPLAY, so N calls make N draws -- ADVICE r3)
 		snap = self._snapshot()
 		if self.stream is None:
 			self.stream = torch.cuda.Stream(device=dev)

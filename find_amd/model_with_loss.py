@@ -44,6 +44,9 @@ TERMS = (
 OVERLAP_GT_RENDER = os.environ.get('FIND_OVERLAP_GT_RENDER', '1') != '0'
 # the Chamfer term on that second stream beside the texture term's MLP pass (ModelWithLoss.forward); FIND_OVERLAP_CHAMFER=0 turns it off
 OVERLAP_CHAMFER = os.environ.get('FIND_OVERLAP_CHAMFER', '1') != '0'
+# the texture term (GT surface samples -> colour field -> masked MSE: a chain of its own, it reads nothing of the main pass) on the second
+# stream from the START of the step, beside the main pass; FIND_TEXTURE_STREAM=0 turns it off
+TEXTURE_STREAM = os.environ.get('FIND_TEXTURE_STREAM', '0') != '0'
 LAZY_COLOURS = os.environ.get('FIND_LAZY_COLOURS', '1') != '0'       # switch for A/B runs and for the bench record with the reference's eager colour head
 _SECOND_STREAMS = {}
 
@@ -222,25 +225,38 @@ class ModelWithLoss(nn.Module):
 		# The colours of the predicted mesh are read by the image render only: a step that renders no image -- nothing at all, or silhouettes
 		# alone -- leaves the colour head of the template pass to whoever reads res['col'] / meshes.textures first (model.get_meshes:
 		# lazy_colours): nobody, on the 3-D-loss stages and on a silhouette-loss step.
+		dev = torch.device(batch['mesh'].device) if 'mesh' in batch else None
+		supervise_3d = self._supervise_3d(batch, opts, is_train)
+		# The texture term depends on the batch alone (GT scan, latent rows), not on the predicted mesh: issued first, on the second stream,
+		# its MLP pass (matrix pipe) fills the holes of the main pass (sampling, nearest neighbours, smoothness, registration: no matrix
+		# pipe) and the other way round -- forward and, since autograd replays a node on its forward's stream, backward.
+		early = {}
+		tex_side = None
+		if (TEXTURE_STREAM and texture and supervise_3d and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()):
+			tex_side = _second_stream(dev)
+			main = torch.cuda.current_stream(dev)
+			tex_side.wait_stream(main)   # (the latent rows of the batch were gathered on this stream)
+			with torch.cuda.stream(tex_side):
+				early['loss_tex'] = self._raw_texture(st)
+			early['loss_tex'].record_stream(main)
 		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement, **(dict(lazy_colours=True) if LAZY_COLOURS and not images else {}))
 		st.pred = st.gt = None
 		if rendering:
 			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None), images)
 			st.pred = self._render_pred(st, st.gt, R, T, side, copy_mask_out, images, mask_image=bool(return_renders or save_renders))
-		supervise_3d = self._supervise_3d(batch, opts, is_train)
-
 		raw, weights = {}, []
 		active = [t for t in TERMS if enabled[t.flag] and not (t.needs_3d and not supervise_3d) and not (t.needs_render and not rendering)]
 		# The Chamfer term -- surface sampling and a brute-force nearest-neighbour search: packed fp32 VALU work, no matrix pipe -- beside the
 		# texture term's MLP pass (matrix pipe) on a second stream: they want different halves of a CU.  Autograd replays each term's
 		# backward on the stream of its forward, so the two backward halves overlap as well.  Not under stream capture.
-		dev = torch.device(batch['mesh'].device) if 'mesh' in batch else None
 		aside = None
-		if (OVERLAP_CHAMFER and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
+		if (OVERLAP_CHAMFER and tex_side is None and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
 				and any(t.flag == 'chamf' for t in active) and any(t.flag == 'texture' for t in active)):
 			aside = _second_stream(dev)
 		for term in active:
-			if aside is not None and term.flag == 'chamf':
+			if term.key in early:
+				raw[term.key] = early[term.key]
+			elif aside is not None and term.flag == 'chamf':
 				main = torch.cuda.current_stream(dev)
 				aside.wait_stream(main)
 				with torch.cuda.stream(aside):
@@ -251,6 +267,8 @@ class ModelWithLoss(nn.Module):
 			weights.append(float(getattr(opts, term.weight)))
 		if aside is not None:
 			torch.cuda.current_stream(dev).wait_stream(aside)
+		if tex_side is not None:
+			torch.cuda.current_stream(dev).wait_stream(tex_side)
 		if save_renders:
 			self._save_renders(st, render_dir)
 		# losses[k] = raw * opts.weight_k, loss = sum(losses.values())   (model.py:1157-1163): one launch for all terms (find_weighted_terms_*)

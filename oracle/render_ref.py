@@ -178,26 +178,33 @@ def torch_project(verts, R, T, fov_deg=60.0):
 	return out.reshape(-1, verts.shape[1], 3)
 
 
-def torch_fragments(vproj, faces, p2f, n_views, H, W, clip_bary, perspective_correct=True):
-	"""Differentiably recompute (zbuf, bary, signed dists) of the fragments selected in p2f (n_img,H,W,K) (packed ids)."""
+def torch_fragments(vproj, faces, p2f, n_views, H, W, clip_bary, perspective_correct=True, pixels=None):
+	"""Differentiably recompute (zbuf, bary, signed dists) of the fragments selected in p2f (packed ids).
+	Dense form: p2f (n_img,H,W,K), every pixel.  Compact form (pixels=(img, yi, xi), three (P,) index tensors): p2f (P,K), only those
+	pixels -- the full-size tests hand over the covered pixels only (a foot fills a fifth of the image; the rest has no fragment)."""
 	n_img, V, _ = vproj.shape
-	K = p2f.shape[-1]
 	faces = faces.long()
 	F = faces.shape[-2]
 	valid = p2f >= 0
-	img = torch.arange(n_img).view(n_img, 1, 1, 1).expand_as(p2f)
+	if pixels is None:
+		img = torch.arange(n_img).view(n_img, 1, 1, 1).expand_as(p2f)
+		yy = (1.0 - (2.0 * torch.arange(H, dtype=vproj.dtype) + 1.0) / H).view(1, H, 1, 1)
+		xx = (1.0 - (2.0 * torch.arange(W, dtype=vproj.dtype) + 1.0) / W).view(1, 1, W, 1)
+		px, py = xx.expand(p2f.shape), yy.expand(p2f.shape)
+	else:
+		pi, pyi, pxi = pixels
+		img = pi.view(-1, 1).expand_as(p2f)
+		py = (1.0 - (2.0 * pyi.to(vproj.dtype) + 1.0) / H).view(-1, 1).expand(p2f.shape)
+		px = (1.0 - (2.0 * pxi.to(vproj.dtype) + 1.0) / W).view(-1, 1).expand(p2f.shape)
 	f = (p2f - img * F).clamp(min=0)
 	if faces.dim() == 2:
-		fv = faces[f]  # (n_img,H,W,K,3)
+		fv = faces[f]  # (..., K, 3)
 	else:
 		fv = faces[(img // n_views), f]
-	vsel = vproj[img.unsqueeze(-1).expand_as(fv), fv]  # (n_img,H,W,K,3 verts,3 comps)
+	vsel = vproj[img.unsqueeze(-1).expand_as(fv), fv]  # (..., K, 3 verts, 3 comps)
 	x0, y0, z0 = vsel[..., 0, 0], vsel[..., 0, 1], vsel[..., 0, 2]
 	x1, y1, z1 = vsel[..., 1, 0], vsel[..., 1, 1], vsel[..., 1, 2]
 	x2, y2, z2 = vsel[..., 2, 0], vsel[..., 2, 1], vsel[..., 2, 2]
-	yy = (1.0 - (2.0 * torch.arange(H, dtype=vproj.dtype) + 1.0) / H).view(1, H, 1, 1)
-	xx = (1.0 - (2.0 * torch.arange(W, dtype=vproj.dtype) + 1.0) / W).view(1, 1, W, 1)
-	px, py = xx.expand_as(x0), yy.expand_as(x0)
 	area = _edge(x2, y2, x0, y0, x1, y1) + 1e-8
 	w0 = _edge(px, py, x1, y1, x2, y2) / area
 	w1 = _edge(px, py, x2, y2, x0, y0) / area
@@ -217,6 +224,12 @@ def torch_fragments(vproj, faces, p2f, n_views, H, W, clip_bary, perspective_cor
 	dist = torch.where(inside, -d, d)
 	bary = torch.stack([c0, c1, c2], dim=-1)
 	return pz, bary, dist, valid, fv
+
+
+def covered_pixels(p2f):
+	"""(img, yi, xi) index tensors of the pixels of a dense (n_img,H,W,K) selection that hold at least one fragment (slot 0: the
+	fragments of a pixel are sorted, empty slots last)."""
+	return torch.nonzero(p2f[..., 0] >= 0, as_tuple=True)
 
 
 def torch_silhouette(dist, valid, sigma=1e-4):
@@ -239,18 +252,27 @@ def torch_vertex_normals(verts, faces):
 	return torch.stack(out)
 
 
-def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views):
-	"""Differentiable K=1 Phong image given the hard selection p2f1 (n_img,H,W,1)."""
+def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views, compact=False):
+	"""Differentiable K=1 Phong image given the hard selection p2f1 (n_img,H,W,1).  compact: evaluate the covered pixels only (the others
+	are background exactly: no fragment, weights zero) -- same numbers, a fraction of the memory at 256^2 / 512^2."""
 	N, V, _ = verts.shape
 	H, W = rp.image_h, rp.image_w
 	vproj = torch_project(verts, R, T, rp.fov_deg)
-	pz, bary, dist, valid, fv = torch_fragments(vproj, faces, p2f1, n_views, H, W, clip_bary=False)
 	n_img = vproj.shape[0]
-	mesh = (torch.arange(n_img) // n_views).view(n_img, 1, 1, 1, 1).expand_as(fv)
+	bg = torch.tensor(list(rp.background), dtype=verts.dtype)
+	if compact:
+		pix = covered_pixels(p2f1)
+		sel = p2f1[pix]                                   # (P, 1)
+		pz, bary, dist, valid, fv = torch_fragments(vproj, faces, sel, n_views, H, W, clip_bary=False, pixels=pix)
+		img_of = pix[0].view(-1, 1, 1)
+	else:
+		pz, bary, dist, valid, fv = torch_fragments(vproj, faces, p2f1, n_views, H, W, clip_bary=False)
+		img_of = torch.arange(n_img).view(n_img, 1, 1, 1, 1)
+	mesh = (img_of // n_views).expand_as(fv)
 	nrm = torch_vertex_normals(verts, faces)
 
 	def interp(attr):
-		return (bary.unsqueeze(-1) * attr[mesh, fv]).sum(dim=-2)  # (n_img,H,W,1,3)
+		return (bary.unsqueeze(-1) * attr[mesh, fv]).sum(dim=-2)  # (..., 1, 3)
 
 	pos, nn, tex = interp(verts), interp(nrm), interp(colors)
 	n = nn / nn.norm(dim=-1, keepdim=True).clamp(min=1e-6)
@@ -260,14 +282,17 @@ def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views):
 	cosang = (n * l).sum(-1)
 	diff = rp.diffuse * torch.relu(cosang)
 	cc = -torch.einsum('mj,mij->mi', T, R)  # camera centres
-	view = (torch.arange(n_img) % n_views)
-	vd = cc[view].view(n_img, 1, 1, 1, 3) - pos
+	view = (img_of % n_views).reshape(img_of.shape[:-1])  # (..., 1)
+	vd = cc[view] - pos
 	vd = vd / vd.norm(dim=-1, keepdim=True).clamp(min=1e-6)
 	r = -l + 2 * cosang.unsqueeze(-1) * n
 	al = torch.relu((vd * r).sum(-1)) * (cosang > 0)
 	spec = rp.specular * al ** rp.shininess
 	col = (rp.ambient + diff).unsqueeze(-1) * tex + spec.unsqueeze(-1)
-	img = torch_softmax_blend(col, dist, pz, valid, rp.rgb_sigma, rp.rgb_gamma, rp.znear, rp.zfar, torch.tensor(list(rp.background), dtype=verts.dtype))
+	img = torch_softmax_blend(col, dist, pz, valid, rp.rgb_sigma, rp.rgb_gamma, rp.znear, rp.zfar, bg)
+	if compact:
+		full = bg.expand(n_img, H, W, 3).clone()
+		img = full.index_put(pix, img)
 	return img.reshape(N, n_views, H, W, 3)
 
 
@@ -283,9 +308,16 @@ def torch_softmax_blend(col, dist, pz, valid, sigma, gamma, znear, zfar, backgro
 	return ((wnum.unsqueeze(-1) * col).sum(-2) + delta * background) / den
 
 
-def torch_mask(rp, verts, faces, R, T, p2f, n_views):
-	"""Differentiable soft silhouette given the K-fragment selection p2f (n_img,H,W,K)."""
+def torch_mask(rp, verts, faces, R, T, p2f, n_views, compact=False):
+	"""Differentiable soft silhouette given the K-fragment selection p2f (n_img,H,W,K).  compact: the covered pixels only (an empty
+	pixel's mask is 1 - prod(1) = 0 exactly)."""
 	N = verts.shape[0]
 	vproj = torch_project(verts, R, T, rp.fov_deg)
+	if compact:
+		pix = covered_pixels(p2f)
+		pz, bary, dist, valid, fv = torch_fragments(vproj, faces, p2f[pix], n_views, rp.image_h, rp.image_w, clip_bary=True, pixels=pix)
+		m = torch_silhouette(dist, valid, rp.sil_sigma)
+		out = torch.zeros(vproj.shape[0], rp.image_h, rp.image_w, dtype=verts.dtype).index_put(pix, m)
+		return out.reshape(N, n_views, rp.image_h, rp.image_w)
 	pz, bary, dist, valid, fv = torch_fragments(vproj, faces, p2f, n_views, rp.image_h, rp.image_w, clip_bary=True)
 	return torch_silhouette(dist, valid, rp.sil_sigma).reshape(N, n_views, rp.image_h, rp.image_w)

@@ -37,7 +37,14 @@ def _worker(rank, world, port, q):
 	bucket = fd.GradBucket(params)
 	loss = ((net(X[lo:hi]) + table[lo:hi].sum(1, keepdim=True) - Y[lo:hi]) ** 2).mean()  # batch-mean loss, as every FIND loss
 	loss.backward()
-	bucket.allreduce_()
+	if rank == 0:
+		bucket.allreduce_()
+	else:   # the issue-now / wait-before-the-step form must be the same collective
+		bucket.allreduce_(async_op=True)
+		assert bucket._pending is not None
+		bucket.wait()
+	assert bucket._pending is None
+	bucket.wait()   # (nothing pending: a no-op)
 	grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
 	q.put((rank, w0.numpy().copy(), grads.numpy().copy(), (lo, hi)))  # numpy: plain pickles (tensors would travel as shm handles)
 	dist.barrier()

@@ -33,3 +33,26 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 	assert rf['traffic'] is None or rf['traffic'] > 0
 	cb = d['cpu_baseline']
 	assert cb['value'] > 0 and cb['unit'] == d['unit'] and cb['cores'] >= 1 and cb['kind'] in ('reference', 'port') and isinstance(cb['sample'], str)
+
+
+def test_two_rank_bench_path_runs_end_to_end_on_one_gpu():
+	"""First execution of everything `bench.py --gpus N` does for N > 1 before the driver's own: spawn_ranks (fresh child
+	processes with the launcher's environment; the parent never touches the GPU), init_from_env, the parameter broadcast, the gradient
+	arena bucket + one all-reduce per step, the priming phase's cross-rank "go on" all-reduce, barrier-bracketed timing with the MAX over
+	ranks, rank 0 alone printing the line.  FIND_BENCH_SHARE_GPU=1 puts both ranks on device 0 with gloo as the transport (this box has
+	one GPU; RCCL itself runs in tests/test_gpu_distributed.py) -- the code path is the one the 8-GPU run takes."""
+	env = dict(os.environ, FIND_BENCH_SHARE_GPU='1')
+	for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+		env.pop(k, None)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-records'],
+					   capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr[-3000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+	assert len(lines) == 1, r.stdout[-2000:]
+	d = json.loads(lines[0])
+	assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak'
+	assert d['config']['parallelism'] == 'dp2' and d['config']['feet_per_gpu'] == 16
+	# whole-job aggregate: both ranks' feet over the slowest rank's time
+	assert abs(d['value'] - 2 * 16 * 6890 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+	assert 'cpu_baseline' not in d and 'records' not in d   # rank 0 at N = 1 only
+	assert d['roofline']['frac'] > 0.3

@@ -389,6 +389,11 @@ def test_chamfer_through_the_grid_equals_brute_force_bit_for_bit():
 	cases.append(('outliers', xo, sphere(1, 2100), None, None))
 	cases.append(('ragged', sphere(3, 4096), sphere(3, 2048), torch.tensor([4096, 0, 2500], dtype=torch.int64), torch.tensor([2048, 1000, 0], dtype=torch.int64)))
 	cases.append(('eval size', sphere(1, 10000), sphere(1, 10000, noise=2e-3), None, None))
+	# clouds far from the origin against their extent (un-normalised scans placed a long way off): one ulp of the box origin is
+	# a good share of a cell there, and the gap test must not let a cube stop before a nearer target outside it
+	off = torch.tensor([50.0, -120.0, 7.0])
+	cases.append(('far from the origin', sphere(2, 9000) + off, sphere(2, 9000, noise=2e-3) + off, None, None))
+	cases.append(('far from the origin, flat', sphere(1, 6000, r=0.02) * torch.tensor([1.0, 1.0, 0.01]) + 300.0, sphere(1, 6000, r=0.02) * torch.tensor([1.0, 1.0, 0.01]) + 300.0, None, None))
 	for name, x, y, xl, yl in cases:
 		out = []
 		for brute in (False, True):

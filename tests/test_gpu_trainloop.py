@@ -327,3 +327,159 @@ def test_trainer_graph_replays_equal_eager_epochs(tmp_path):
 				assert len(a[k]) == len(b[k]) == (4 if part == 'train_loss' else 2)
 				np.testing.assert_allclose(a[k], b[k], rtol=2e-3, atol=1e-6)
 	assert set(tr_g.log[0]['train_loss']) == {'Loss', 'Chamf', 'Smooth', 'Tex'}   # pretty_print_loss keys (trainer.py:14-16,126)
+
+
+# ------------------------------------------------------------------------------------------------ stage 1: registration
+def _reg_stage_kwargs(opts):
+	"""train.py:201: model_kwargs = dict(chamf=True, smooth=False, gt_z_cutoff=args.gt_z_cutoff)."""
+	return dict(chamf=True, smooth=False, gt_z_cutoff=opts.gt_z_cutoff)
+
+
+@pytest.mark.parametrize('gt_z_cutoff', [None, 0.01])
+def test_registration_stage_val_epoch_step_matches_oracle(gt_z_cutoff):
+	"""Stage 1's val_epoch body (train.py:197-209 -> trainer.py:150-163) at full size: is_train=False, chamf only, gt_z_cutoff as the stage
+	passes it (None by default, opts.py:145; 0.01 cuts the synthetic scan at a third of its height: the ragged-cloud Chamfer of
+	losses.py:79-85), val_optim = SGD(reg_params, momentum 0.9).  Loss and the gradient of the addressed reg_val row against the oracle at
+	1e-4; after the step that row is reg_val - lr * grad (first momentum step), nothing else has moved."""
+	from find_amd import optim
+	from find_amd.train_utils import sample_latent_vectors
+	from test_gpu_pipeline import DrawRecorder
+	mwl, opts, batch_of, (gv, gf, gc), _ = _setup(stage='reg', seed=1)
+	opts.set_option('gt_z_cutoff', gt_z_cutoff)
+	m = mwl.model
+	_fill_val_tables(m)
+	lr = 1e-3
+	optim_reg = optim.SGD(m.reg_params, lr=lr, momentum=0.9)
+	model_kwargs = _reg_stage_kwargs(opts)
+	model_kwargs['is_train'] = False
+	batch = _val_batch(gv, gf, gc)
+	batch.update(**sample_latent_vectors(batch, m.latent_vectors_val))
+	before = {n: p.detach().clone() for n, p in m.named_parameters()}
+	optim_reg.zero_grad()
+	with DrawRecorder() as rec:
+		loss, loss_dict = mwl(batch, 0, opts=opts, **model_kwargs)
+	assert set(loss_dict) == {'loss_chamf'}
+	loss.backward()
+	optim_reg.step()
+	(fi_gt, uv_gt), (fi_pr, uv_pr) = rec.draws
+	sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+	lat = {k: before[f'{k}_val.data'][r:r + 1].cpu().clone().requires_grad_(k == 'reg') for k, r in VAL_ROWS.items()}
+	B, tv, tf = m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
+	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
+	gt_s = geom_ref.sample_points(gv[:1].cpu(), gf.cpu(), fi_gt, uv_gt)
+	pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
+	if gt_z_cutoff is not None:
+		keep = gt_s[0, :, 2] <= gt_z_cutoff
+		assert 0.1 < keep.float().mean().item() < 0.9
+		gt_s = gt_s[:, keep]
+	rl = geom_ref.chamfer_distance(pr_s, gt_s) * 10000.
+	assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item())), (loss.item(), rl.item())
+	rl.backward()
+	g = lat['reg'].grad[0]
+	r = VAL_ROWS['reg']
+	got = m.reg_val.data.grad[r].cpu()
+	assert (got - g).abs().max().item() < 1e-4 * g.abs().max().item(), (got, g)
+	want = before['reg_val.data'][r].cpu() - lr * g
+	step = (lr * g).abs().max().item()
+	assert step > 0 and (m.reg_val.data[r].detach().cpu() - want).abs().max().item() < 1e-3 * step + 1e-7
+	for n, p in m.named_parameters():
+		if n == 'reg_val.data':
+			keep_rows = [i for i in range(p.shape[0]) if i != r]
+			assert torch.equal(p[keep_rows], before[n][keep_rows])
+		else:
+			assert torch.equal(p, before[n]), n   # the train rows, the other val tables and the network: not this stage's business
+
+
+def _reg_trainer_run(graph, gt_z_cutoff, epochs=3):
+	from find_amd import optim
+	from find_amd.trainer import Trainer
+	n_verts = gt_verts = 1002
+	mwl, opts, batch_of, (gv, gf, gc), _ = _setup(n_verts, gt_verts, stage='reg', seed=2)
+	opts.set_option('gt_z_cutoff', gt_z_cutoff)
+	m = mwl.model
+	_fill_val_tables(m)
+	optim_reg = optim.SGD(m.reg_params, lr=1e-3, momentum=0.9)
+	loader = [batch_of(i) for i in (0, 3, 1, 2)]
+	val_loader = [_val_batch(gv, gf, gc, 0, '9000-A'), _val_batch(gv, gf, gc, 1, '9000-B')]
+	# train.py:183-186: trainer_reg = Trainer([optim_reg], ..., val_optim=optim_reg)
+	tr = Trainer([optim_reg], mwl, loader, val_loader, opts, latent_vectors_train=m.latent_vectors_train, latent_vectors_val=m.latent_vectors_val,
+				 val_optim=optim_reg, device='cuda', graph=graph)
+	draws = _draws(n_verts, gt_verts)
+	modes = []
+	with FixedDraws(draws):
+		for epoch in range(epochs):
+			model_kwargs = _reg_stage_kwargs(opts)
+			tr.train_epoch(epoch, model_kwargs=dict(model_kwargs))
+			modes.append(tr.last_mode)
+			msg, res = tr.val_epoch(epoch, model_kwargs=dict(model_kwargs))
+			modes.append(tr.last_mode)
+			assert set(res) == {'Loss', 'chamf'}
+	torch.cuda.synchronize()
+	return tr, {n: p.detach().clone() for n, p in m.named_parameters()}, modes, {n: p.detach().clone() for n, p in _setup(n_verts, gt_verts, stage='reg', seed=2)[0].model.named_parameters()}
+
+
+@pytest.mark.parametrize('gt_z_cutoff', [None, 0.01])
+def test_registration_stage_trainer_graph_equals_eager(gt_z_cutoff):
+	"""Stage 1 through find_amd.trainer.Trainer as train.py:197-209 drives it -- train_epoch and val_epoch per epoch, ONE SGD(reg_params)
+	as both optimisers: every epoch is HIP-graph replays by default (no PNG is ever written in this stage) and leaves the registration
+	rows where the eager loop leaves them; only `reg` / `reg_val` move."""
+	tr_g, p_g, modes_g, start = _reg_trainer_run('auto', gt_z_cutoff)
+	tr_e, p_e, modes_e, _ = _reg_trainer_run(False, gt_z_cutoff)
+	assert modes_g == ['graph'] * 6 and modes_e == ['eager'] * 6
+	for n in p_e:
+		if n in ('reg.data', 'reg_val.data'):
+			moved = (p_e[n] - start[n]).abs().max().item()
+			assert moved > 0, n
+			# SGD is linear in the gradient: the two loops differ by the float-atomic noise of the sampling backward, not by flips
+			assert (p_g[n] - p_e[n]).abs().max().item() < 1e-3 * moved, (n, (p_g[n] - p_e[n]).abs().max().item(), moved)
+		elif not n.endswith('_val.data'):   # (the other val tables were filled by _fill_val_tables after `start` was taken)
+			assert torch.equal(p_g[n], start[n]) and torch.equal(p_e[n], start[n]), n
+		else:
+			assert torch.equal(p_g[n], p_e[n]), n
+	for epoch in range(3):
+		for part, cnt in (('train_loss', 4), ('val_loss', 2)):
+			a, b = tr_g.log[epoch][part], tr_e.log[epoch][part]
+			assert set(a) == set(b) == {'Loss', 'Chamf'}
+			for k in a:
+				assert len(a[k]) == len(b[k]) == cnt
+				np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=1e-7)
+	# the losses go down: the stage registers
+	assert np.mean(tr_g.log[2]['train_loss']['Loss']) < np.mean(tr_g.log[0]['train_loss']['Loss'])
+
+
+def test_render_watchdog_sees_the_renders_of_a_captured_step():
+	"""Graph replay is the Trainer's default, and a captured render cannot hand its counters to a pinned slot per call (no host work inside
+	a replay): it adds them to one static device slot instead, read back at the epoch boundary (functional_render._check_captured;
+	ADVICE r3: graph epochs used to go unchecked).  A camera inside the mesh -- faces straddle the z-clip plane -- must be reported for a
+	replayed step exactly as for an eager one, and a clean step must stay silent."""
+	import warnings
+	from find_amd import functional_render as FR
+	from find_amd import optim
+	from find_amd.cameras import look_at_view_transform
+	from find_amd.graph import GraphedStep
+	from find_amd.renderer import FootRenderer
+	prev = FR.FLAG_POLICY
+	FR.FLAG_POLICY = 'warn'
+	try:
+		FR.check_render_flags(wait=True)
+		for dist, bad in ((0.3, False), (0.02, True)):
+			mwl, opts, batch_of, _, _ = _setup(1002, 1002, capturable=True)   # (a model per capture: the first one's static loss keeps its graph alive)
+			mwl.rdr = FootRenderer(image_size=64, device='cuda')
+			R, T = look_at_view_transform(dist=np.full(2, dist), elev=np.array([0.0, 30.0]), azim=np.array([0.0, 40.0]), up=((1, 0, 0),))
+			opt = optim.Adam(mwl.model.main_params, lr=1e-5, capturable=True)
+			gs = GraphedStep(mwl, opts, [opt], warmup=1, sil=True, render_foot=True, views=(R.cuda(), T.cuda()))
+			with warnings.catch_warnings(record=True) as wlist:
+				warnings.simplefilter('always')
+				for i in (0, 1, 2):
+					gs(batch_of(i))
+				FR.check_render_flags(wait=True)
+			hits = [w for w in wlist if 'straddle the z-clip plane' in str(w.message)]
+			assert bool(hits) == bad, (dist, [str(w.message)[:80] for w in wlist])
+			if bad:
+				assert any('replayed from a HIP graph' in str(w.message) for w in hits)
+	finally:
+		FR.FLAG_POLICY = prev
+		try:
+			FR.check_render_flags(wait=True)
+		except RuntimeError:
+			pass
