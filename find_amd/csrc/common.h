@@ -55,6 +55,12 @@ struct Carver {
 		if (_rc != FIND_OK) return _rc;            \
 	} while (0)
 
+// Workgroup barrier for data exchanged through LDS ONLY: waits for this wave's LDS operations, not for its global loads and stores.
+// (__syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: in a loop that keeps global loads in flight across iterations -- the
+// prefetch of a software pipeline -- it drains them at every barrier and exposes the whole memory latency once per iteration: a quarter
+// of gemm7's time and more of dw6's before this.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Wave-level sum over 64 lanes (result valid in every lane).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

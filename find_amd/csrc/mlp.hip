@@ -5,7 +5,9 @@
 #include "mlp_dwpe.h"
 #include "mlp_gemm5.h"
 #include "mlp_gemm6.h"
+#include "mlp_gemm7.h"
 #include "mlp_dw3.h"
+#include "mlp_dw6.h"
 #include "mlp_gemm4.h"
 #include "mlp_fused.h"
 
@@ -115,7 +117,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_DW2, K_DW3, K_FUSED, K_FUSED2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -139,6 +141,7 @@ struct find_ctx {
 	                              // launch on Q is 0.6 - 0.9 % faster (train_3d 3.245 -> 3.225 ms, C2 2.220 -> 2.199), so off by default
 	int gemm5_min_units = 1024;
 	int gemm6_min_units = 1024;
+	int gemm7 = 1;                // bf16x3 Linear kernel: 1 = gemm7 (W in registers, activations through LDS), 0 = gemm6 (W planes in LDS; kept for A/B)
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which
 	                              // round 2 showed to be about registers, not LDS (see "Co-residence" below); off by default now
@@ -386,8 +389,44 @@ static int launch_gemm6_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	constexpr int G = 8 * (8 / G6_NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
 	const int grid = std::max(G, (c->num_cus / G) * G);
+	if constexpr (EPI == EPI_BIAS_RELU) {
+		const int abl = (c->ablate >> 5) & 7;   // profiling only (tools/ablate_x3.py)
+		if (abl) {
+#define FIND_G6_ABL(N) case N: { FIND_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm6_kernel<EPI, N>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes), "hipFuncSetAttribute"); \
+			hipLaunchKernelGGL((gemm6_kernel<EPI, N>), dim3(grid), dim3(GEMM6_NW * 64), lds, s, a); return FIND_OK; }
+			switch (abl) { FIND_G6_ABL(1) FIND_G6_ABL(2) FIND_G6_ABL(3) FIND_G6_ABL(4) FIND_G6_ABL(5) FIND_G6_ABL(6) FIND_G6_ABL(7) }
+#undef FIND_G6_ABL
+		}
+	}
 	hipLaunchKernelGGL((gemm6_kernel<EPI>), dim3(grid), dim3(GEMM6_NW * 64), lds, s, a);
 	return FIND_OK;
+}
+
+template <int EPI>
+static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
+	int lds = 0;
+	const int rc = prepare_kernel(c, K_GEMM7_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2), &gemm7_kernel<EPI>, GEMM7_LDS, &lds);
+	if (rc != FIND_OK) return rc;
+	a.tiles_per_foot = (int)cdiv(a.V, 32);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	const int grid = std::max(16, (c->num_cus / 16) * 16);   // the two column halves of a row range sit 8 blocks apart (same XCD)
+	if constexpr (EPI == EPI_BIAS_RELU) {
+		const int abl = (c->ablate >> 5) & 15;   // profiling only (tools/ablate_x3.py)
+		if (abl) {
+#define FIND_G7_ABL(N) case N: { FIND_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm7_kernel<EPI, N>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes), "hipFuncSetAttribute"); \
+			hipLaunchKernelGGL((gemm7_kernel<EPI, N>), dim3(grid), dim3(GEMM7_NW * 64), lds, s, a); return FIND_OK; }
+			switch (abl) { FIND_G7_ABL(1) FIND_G7_ABL(2) FIND_G7_ABL(4) FIND_G7_ABL(8) FIND_G7_ABL(3) FIND_G7_ABL(7) FIND_G7_ABL(15) FIND_G7_ABL(12) FIND_G7_ABL(14) }
+#undef FIND_G7_ABL
+		}
+	}
+	hipLaunchKernelGGL((gemm7_kernel<EPI>), dim3(grid), dim3(GEMM7_NW * 64), lds, s, a);
+	return FIND_OK;
+}
+
+static int launch_gemm7(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU) return launch_gemm7_t<EPI_BIAS_RELU>(c, a, feet, s);
+	if (epi == EPI_MASK) return launch_gemm7_t<EPI_MASK>(c, a, feet, s);
+	return launch_gemm7_t<EPI_NONE>(c, a, feet, s);
 }
 
 static int launch_gemm6(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
@@ -421,7 +460,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	const bool k256 = b.nseg == 1 && b.nchunk == 8;
 	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
 	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s);
-	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm6(c, epi, b, feet, s);
+	if (c->x3 && k256 && units >= c->gemm6_min_units) return c->gemm7 ? launch_gemm7(c, epi, b, feet, s) : launch_gemm6(c, epi, b, feet, s);
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
 	return launch_gemm3(c, epi, b, feet, s);
@@ -818,6 +857,21 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			d3.V = (int)V; d3.chunks_per_foot = cpf64; d3.spf = spf; d3.cps = cps3; d3.pw = b.pw; d3.pb = pbuf;
 			hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);
 			FIND_LAUNCH_CHECK("dw3_kernel");
+		} else if (c->x3 && cdiv(V, 32) * feet >= c->gemm6_min_units) {
+			// bf16x3: 16-row chunks, rows past the end of a foot zero-filled by the kernel; few, long runs (slab traffic)
+			const int cpf16 = (int)cdiv(V, 16);
+			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
+			const int cps6 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(c->dw2_min_cps, cpf16));
+			spf = (int)cdiv(cpf16, cps6);
+			nmain = (int)(feet * spf);
+			int lds = 0;
+			FIND_TRY(prepare_kernel(c, K_DW6, &dw6_kernel, DW6_LDS, &lds));
+			Dw3Args d6;
+			memset(&d6, 0, sizeof(d6));
+			d6.dz = dz; d6.dz_foot_stride = V * W; d6.x = x; d6.x_foot_stride = x_foot_stride;
+			d6.V = (int)V; d6.chunks_per_foot = cpf16; d6.spf = spf; d6.cps = cps6; d6.pw = b.pw; d6.pb = pbuf;
+			hipLaunchKernelGGL(dw6_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);
+			FIND_LAUNCH_CHECK("dw6_kernel");
 		} else {
 			// LDS-DMA kernel: every foot's rows cut into spf contiguous runs of 16-row chunks, the <= 15 leftover rows
 			// folded into the foot's last run
@@ -1601,7 +1655,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"gemm7", &find_ctx::gemm7, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };
 }  // namespace
 

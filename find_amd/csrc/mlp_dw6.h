@@ -1,0 +1,188 @@
+// dw6_kernel: weight gradient  dW[n,k] = sum_rows dZ[row,n] * X[row,k]  in fp32-faithful arithmetic on the bf16 matrix pipe
+// ("bf16x3", mlp_gemm6.h says why the six products a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) of the exact three-way bf16
+// splits carry less error than one fp32 multiplication).  Both operands are activations here, so both are split on the way in.
+// dw3's skeleton (the contraction runs over ROWS: the operands are transposed on their way into LDS), resized for six planes:
+//   * one 4-wave workgroup owns the full 256 x 256 output (256 accumulator registers per lane) over a run of 16-row chunks of ONE
+//     foot; partial tiles go to dw2's slabs and reduce_w_kernel, per-foot bias sums likewise (fp32 sums of the dZ values as loaded);
+//   * staging: wave w stages operand (w >> 1), rows 8 (w & 1) .. +7 of the chunk: lane c loads the float4 at columns 4c .. 4c+3 of
+//     each of its eight rows (a row is read by 64 lanes as one contiguous KB), splits every (row j, row j+1) pair of a column into
+//     its three packed bf16 pairs (split_pair: 9 instructions per pair) and writes, per column and plane, the 8 rows as ONE 16-byte
+//     LDS word.  LDS layout per plane and operand: [column'][16 rows] bf16 = 32 B per column, column' = column ^ ((column >> 2) & 7):
+//     the 64 lanes of a fragment read still cover one contiguous KB, the 8 lanes of a write phase hit 8 different bank groups;
+//   * an MFMA k-step is the whole 16-row chunk: lane (i, h) reads rows 8h .. 8h+7 of column 32 t + i of every plane with one
+//     ds_read_b128; 16 blocks x 6 products = 96 MFMAs per wave and chunk (3072 matrix-pipe cycles) against ~150 VALU instructions
+//     of splitting, 12 LDS writes and 24 LDS reads;
+//   * two chunk buffers (2 x 48 KB): the chunk after the one being multiplied is loaded, split and stored under the MFMAs; one
+//     barrier per chunk.
+// Rows past the end of a foot are zero-filled at load time (no tail path): chunks_per_foot = ceil(V / 16).
+#pragma once
+#include "mlp_dw3.h"
+#include "mlp_gemm6.h"
+
+namespace find {
+namespace mlp {
+
+constexpr int DW6_PLANE = 256 * 32;             // one plane of one operand of one chunk: 256 columns x 16 rows bf16 = 8 KB
+constexpr int DW6_OPER = 3 * DW6_PLANE;         // 24 KB
+constexpr int DW6_BUF = 2 * DW6_OPER;           // dZ then X: 48 KB
+constexpr int DW6_LDS = 2 * DW6_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 102 400 B
+
+__global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
+	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 256 fp32 accumulators in AGPRs + ~150 VGPRs: more than 256 registers (see the macro)
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float* red = reinterpret_cast<float*>(smem + 2 * DW6_BUF);
+
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wn = wave >> 1, wk = wave & 1;
+	const int li = lane & 31, fh = lane >> 5;
+	const int split = blockIdx.x;
+	const int foot = split / g.spf;
+	const int sidx = split - foot * g.spf;
+	const int q0 = sidx * g.cps;
+	const int q1 = min(q0 + g.cps, g.chunks_per_foot);
+	float* const pw = g.pw + (int64_t)split * 65536;
+	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
+	// staging role of this wave: operand sop (0 = dZ, 1 = X), row group srg (rows 8 srg .. +7 of a chunk)
+	const int sop = wave >> 1, srg = wave & 1;
+	const float* const sfoot = sop == 0 ? g.dz + (int64_t)foot * g.dz_foot_stride : g.x + (int64_t)foot * g.x_foot_stride;
+
+	f32x16 acc[4][4];
+#pragma unroll
+	for (int a = 0; a < 4; ++a)
+#pragma unroll
+		for (int b = 0; b < 4; ++b)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+	float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+	const float bias_w = (g.pb != nullptr && (wave >> 1) == 0) ? 1.f : 0.f;   // only the waves that stage dZ sum bias gradients
+
+	// Staging registers: two chunks in flight -- rows j of the wave's row group, columns 4 lane .. +3; a load is consumed two chunks later
+	// (HBM latency under load is 1-2 us, a chunk takes ~1.4).  (Loads through inline asm with hand-counted waits gave wrong results here:
+	// mlp_gemm7.h.)
+	// Buffer loads: the descriptor's size is the foot's valid bytes, so rows past its end come back as zeros from the bounds check.
+	typedef unsigned u4 __attribute__((ext_vector_type(4)));
+	typedef int i4 __attribute__((ext_vector_type(4)));
+	u4 st[2][8];
+	const int c4 = lane * 4;
+	const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(sfoot)), 0, g.V * 1024, 0x00020000);
+	auto load_chunk = [&](int q, u4 (&set)[8]) {
+		const int r0 = q * 16 + 8 * srg;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			set[j] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, c4 * 4, (r0 + j) * 1024, 0);
+		}
+	};
+#define FIND_DW6_WAIT(set, n) ((void)0)
+	auto comp = [](const u4& v, int e) -> float { return __uint_as_float(e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w))); };
+	// column 4 lane + e lands at column' = (4 lane + e) ^ (lane & 7)
+	const int wbase = sop * DW6_OPER + srg * 16;
+	// one column (e) of the staged rows: split, write the three planes; the bias sums count a chunk once (keep = 0 for a repeated store)
+	auto store_part = [&](char* buf, const u4 (&st)[8], int e, float keep) {
+		u32x4 p1, p2, p3;
+#pragma unroll
+		for (int jj = 0; jj < 4; ++jj) {
+			const Split2 s = split_pair(f32x2{comp(st[2 * jj], e), comp(st[2 * jj + 1], e)});
+			p1[jj] = s.p1; p2[jj] = s.p2; p3[jj] = s.p3;
+		}
+		char* dst = buf + wbase + (((c4 + e) ^ (lane & 7)) * 32);
+		*reinterpret_cast<u32x4*>(dst) = p1;
+		*reinterpret_cast<u32x4*>(dst + DW6_PLANE) = p2;
+		*reinterpret_cast<u32x4*>(dst + 2 * DW6_PLANE) = p3;
+		{   // (branch-free: the waves that stage X add with keep = 0)
+			float t = 0.f;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) t += comp(st[j], e);
+			if (e == 0) bsum.x += keep * t; else if (e == 1) bsum.y += keep * t; else if (e == 2) bsum.z += keep * t; else bsum.w += keep * t;
+		}
+	};
+	// fragment addresses: dZ column wn*128 + 32 ti + li, X column wk*128 + 32 tj + li; (column >> 2) & 7 == (li >> 2) & 7 for all of them
+	const int ci = (li ^ ((li >> 2) & 7)) * 32 + fh * 16;
+	const int za = (wn * 128) * 32 + ci;
+	const int xa = DW6_OPER + (wk * 128) * 32 + ci;
+	auto frag = [&](const char* buf, int base, int t, int p) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(buf + base + p * DW6_PLANE + t * (32 * 32)); };
+
+	if (q0 < q1) {
+		load_chunk(q0, st[0]);
+		load_chunk(min(q0 + 1, q1 - 1), st[1]);
+		FIND_DW6_WAIT(st[0], 8);
+#pragma unroll
+		for (int e = 0; e < 4; ++e) store_part(smem, st[0], e, bias_w);
+		load_chunk(min(q0 + 2, q1 - 1), st[0]);
+		lds_barrier();
+		int cb = 0;
+		// One basic block per chunk -- no branch inside: a repeated store goes to the buffer nobody reads any more, a repeated load re-reads
+		// the run's last chunk -- so that the instruction order can be prescribed: while the matrix pipe runs the 24 products of column
+		// block tj, the wave splits and stores column e = tj of the NEXT chunk's rows (`set`: in registers for the last two chunks), then
+		// refills `set` with the chunk three ahead.
+		auto chunk_body = [&](int q, u4 (&set)[8]) {
+			const char* buf = smem + cb * DW6_BUF;
+			char* other = smem + (cb ^ 1) * DW6_BUF;   // its readers finished before the last barrier
+			const float keep = (q + 1 < q1) ? bias_w : 0.f;
+			bf16x8 a1[4], a2[4], a3[4], b1[2], b2[2], b3[2];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { a1[i] = frag(buf, za, i, 0); a2[i] = frag(buf, za, i, 1); a3[i] = frag(buf, za, i, 2); }
+			b1[0] = frag(buf, xa, 0, 0); b2[0] = frag(buf, xa, 0, 1); b3[0] = frag(buf, xa, 0, 2);
+			FIND_DW6_WAIT(set, 8);   // (behind this chunk's eight loads: the eight of the chunk after it)
+			__builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
+#pragma unroll
+			for (int tj = 0; tj < 4; ++tj) {
+				const int cu = tj & 1, nx = cu ^ 1;
+				if (tj + 1 < 4) { b1[nx] = frag(buf, xa, tj + 1, 0); b2[nx] = frag(buf, xa, tj + 1, 1); b3[nx] = frag(buf, xa, tj + 1, 2); }
+				store_part(other, set, tj, keep);
+				// smallest terms first
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ti], b1[cu], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ti], b3[cu], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ti], b2[cu], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ti], b1[cu], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ti], b2[cu], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ti], b1[cu], acc[ti][tj], 0, 0, 0);
+				if (tj + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+				for (int i = 0; i < 24; ++i) {
+					__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+					__builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+				}
+				__builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+			}
+			load_chunk(min(q + 3, q1 - 1), set);   // three chunks ahead: consumed two iterations from now
+			lds_barrier();   // (not __syncthreads: that would wait for the loads just issued)
+			cb ^= 1;
+		};
+		for (int q = q0; q < q1; q += 2) {
+			chunk_body(q, st[1]);
+			if (q + 1 < q1) chunk_body(q + 1, st[0]);
+		}
+	}
+
+	// ---- epilogue: tile (ti, tj) element (r, lane) is n = wn*128 + 32ti + (r&3) + 8(r>>2) + 4fh, k = wk*128 + 32tj + li
+	{
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(pw)), 0, 65536 * 4, 0x00020000);
+		const int voff = ((wn * 128 + 4 * fh) * 256 + wk * 128 + li) * 4;
+#pragma unroll
+		for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+			for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					const float f = acc[ti][tj][r];
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(f), rsrc, voff + ((r & 3) * 256 + tj * 32) * 4, ((ti * 32 + 8 * (r >> 2)) * 256) * 4, 0);
+				}
+	}
+	if (pb) {
+		__syncthreads();
+		*reinterpret_cast<float4*>(&red[wave * 256 + lane * 4]) = bsum;   // (waves 2, 3 staged X: zeros)
+		__syncthreads();
+		pb[tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+	}
+}
+
+}  // namespace mlp
+}  // namespace find

@@ -61,7 +61,9 @@ __device__ __forceinline__ void split3(const float4& lo, const float4& hi, bf16x
 	p3 = __builtin_bit_cast(bf16x8, u32x4{q0.p3, q1.p3, q2.p3, q3.p3});
 }
 
-template <int EPI>
+// ABL: profiling only (tools/ablate_x3.py): 1 = no split arithmetic, 2 = no LDS fragment reads after a unit's first, 4 = no A loads after the
+// prologue -- compile-time, so that the measured loop keeps its basic blocks
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GEMM6_NW * 64) void gemm6_kernel(const Gemm2Args g) {
 	constexpr int NI = G6_NI;
 	constexpr int NCG = 8 / NI;  // column groups
@@ -133,36 +135,56 @@ __global__ __launch_bounds__(GEMM6_NW * 64) void gemm6_kernel(const Gemm2Args g)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 
+		// Software pipeline over the unit's 16 k-steps (step s = chunk s >> 1, half s & 1): while the matrix pipe runs the twelve products
+		// of step s, the wave splits the A values of step s + 1 and its B fragments arrive from LDS.  The instruction ORDER is prescribed
+		// (sched_group_barrier: LDS reads first, then one MFMA followed by three VALU instructions, twelve times): left alone, the
+		// scheduler emits the 36 VALU instructions of a split in one run and the MFMAs in another, and neither hides the other.
+		bf16x8 a1[2], a2[2], a3[2], b1[2][NI], b2[2][NI], b3[2][NI];
+		split3(areg[0][0], areg[0][1], a1[0], a2[0], a3[0]);
 #pragma unroll
-		for (int c = 0; c < 8; ++c) {
-			{  // A prefetch: chunk c+PD of this unit, or chunk c+PD-8 of the wave's next unit
+		for (int ni = 0; ni < NI; ++ni) { b1[0][ni] = load_b(0, 0, 0, ni); b2[0][ni] = load_b(1, 0, 0, ni); b3[0][ni] = load_b(2, 0, 0, ni); }
+#pragma unroll
+		for (int s = 0; s < 16; ++s) {
+			const int c = s >> 1, m = s & 1, cu = s & 1, nx = cu ^ 1;
+			if (m == 0 && !(ABL & 4)) {  // A prefetch: chunk c+PD of this unit, or chunk c+PD-8 of the wave's next unit
 				const int pc = c + GEMM4_PD;
 				const float4* src = (pc < 8) ? cur + pc * 8 : nxt + (pc - 8) * 8;
 #pragma unroll
 				for (int q = 0; q < 4; ++q) areg[pc & 3][q] = src[q];
 			}
-			__builtin_amdgcn_sched_barrier(0);
+			if (s + 1 < 16) {
+				const int c1 = (s + 1) >> 1, m1 = (s + 1) & 1;
+				if constexpr (!(ABL & 2)) {
 #pragma unroll
-			for (int m = 0; m < 2; ++m) {
-				bf16x8 a1, a2, a3;
-				split3(areg[c & 3][2 * m], areg[c & 3][2 * m + 1], a1, a2, a3);
-				bf16x8 b1[NI], b2[NI], b3[NI];
+					for (int ni = 0; ni < NI; ++ni) { b1[nx][ni] = load_b(0, c1, m1, ni); b2[nx][ni] = load_b(1, c1, m1, ni); b3[nx][ni] = load_b(2, c1, m1, ni); }
+				} else {
 #pragma unroll
-				for (int ni = 0; ni < NI; ++ni) { b1[ni] = load_b(0, c, m, ni); b2[ni] = load_b(1, c, m, ni); b3[ni] = load_b(2, c, m, ni); }
-				// smallest terms first: what the accumulator rounds away is then the least it can be
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[ni], acc[ni], 0, 0, 0);
-#pragma unroll
-				for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[ni], acc[ni], 0, 0, 0);
+					for (int ni = 0; ni < NI; ++ni) { b1[nx][ni] = b1[cu][ni]; b2[nx][ni] = b2[cu][ni]; b3[nx][ni] = b3[cu][ni]; }
+				}
+				if constexpr (!(ABL & 1)) split3(areg[c1 & 3][2 * m1], areg[c1 & 3][2 * m1 + 1], a1[nx], a2[nx], a3[nx]);
+				else { a1[nx] = __builtin_bit_cast(bf16x8, areg[c1 & 3][2 * m1]); a2[nx] = __builtin_bit_cast(bf16x8, areg[c1 & 3][2 * m1 + 1]); a3[nx] = a1[cu]; }
 			}
+			// smallest terms first: what the accumulator rounds away is then the least it can be
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[cu], b1[cu][ni], acc[ni], 0, 0, 0);
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[cu], b3[cu][ni], acc[ni], 0, 0, 0);
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[cu], b2[cu][ni], acc[ni], 0, 0, 0);
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[cu], b1[cu][ni], acc[ni], 0, 0, 0);
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[cu], b2[cu][ni], acc[ni], 0, 0, 0);
+#pragma unroll
+			for (int ni = 0; ni < NI; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[cu], b1[cu][ni], acc[ni], 0, 0, 0);
+			if (m == 0) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // the four global loads of the chunk prefetch
+			__builtin_amdgcn_sched_group_barrier(0x100, 3 * NI, 0);            // next step's B fragments
+#pragma unroll
+			for (int i = 0; i < 6 * NI; ++i) {
+				__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+				__builtin_amdgcn_sched_group_barrier(0x002, 3, 0);             // three VALU instructions of the next step's split
+			}
+			__builtin_amdgcn_sched_barrier(0);
 		}
 
 		// ---- epilogue (as gemm4): element (r, lane) of block ni = row (r&3) + 8(r>>2) + 4fh, column col0 + 32ni + li

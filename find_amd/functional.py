@@ -87,14 +87,14 @@ class MLPSpec:
 		self.n_trunk, self.n_disp, self.n_col = n_trunk, n_disp, n_col
 		self.pe_size, self.lat_disp, self.lat_col = pe_size, lat_disp, lat_col
 		self.in_dim, self.width = in_dim, width
-		self.precision = precision   # None: the process default (set_mlp_precision); 'fp32' / 'fp16': this model only
+		self.precision = precision   # None: the process default (set_mlp_precision); 'fp32' / 'bf16x3' / 'fp16': this model only
 
 	@property
 	def n_weights(self):
 		return 2 * (self.n_trunk + self.n_disp + 1 + self.n_col + 1)
 
 
-_PRECISION_CODE = {None: 0, 'fp32': 1, 'fp16': 2}
+_PRECISION_CODE = {None: 0, 'fp32': 1, 'fp16': 2, 'bf16x3': 3}
 
 
 def _fill_params(spec, B, avg_col, weights):
@@ -931,13 +931,21 @@ def mesh_smoothness_loss(verts, topo, w_edge=10.0, w_lap=0.1):
 	return _SmoothLoss.apply(verts, topo, float(w_edge), float(w_lap))
 
 
-_MLP_PRECISION = 'fp32'
+# Default arithmetic of the 256 -> 256 layers: 'bf16x3' (fp32-faithful on the bf16 matrix pipe; set_mlp_precision below says what that is);
+# FIND_MLP_PRECISION=fp32 selects the fp32 MFMA kernels (A/B runs, the bench's comparison record)
+_MLP_PRECISION = _os.environ.get('FIND_MLP_PRECISION', 'bf16x3')
+if _MLP_PRECISION not in ('fp32', 'fp16', 'bf16x3'):
+	raise ValueError(f"FIND_MLP_PRECISION: 'fp32', 'bf16x3' or 'fp16', got {_MLP_PRECISION!r}")
 
 
 def set_mlp_precision(precision):
 	"""Default arithmetic of the MLP's 256 -> 256 layers (forward, the dX chain and the weight gradients) for every model whose MLPSpec
 	names no precision of its own (model.set_mlp_precision / MLPSpec.precision); also the mode of the isolated-kernel entry points.
-	'fp32' (default): exact fp32 MFMA -- the reference's arithmetic (no AMP anywhere in FIND) and the parity path.
+	'fp32': fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the reference's arithmetic (no AMP anywhere in FIND).
+	'bf16x3': fp32-FAITHFUL arithmetic on the bf16 matrix pipe (csrc/mlp_gemm6.h, mlp_dw6.h): every fp32 operand is split EXACTLY into three
+	bf16 pieces and the six products of relative size >= 2^-18 are accumulated in fp32; what is left out is <= 2^-26 of a product, a quarter
+	of one fp32 rounding, so results are as close to the float64 product as the fp32 MFMA's (tests/test_gpu_mlp_bf16x3.py) at 6/16 of its
+	matrix-pipe time.  Tensors stay fp32; covers the large launches of the 256 -> 256 layers (forward, dX, weight gradients).
 	'fp16': both MFMA operands rounded to fp16, fp32 accumulation and fp32 tensors in memory (BASELINE.json configs[4], "fp16 MLP
 	with MFMA tiles"); layer outputs then differ from fp32 by ~1e-3 relative.  Covers the forward Linear layers, the dX chain and the
 	weight gradients of the 256 -> 256 layers (gemm5_kernel, dw3_kernel) where a launch has at least 1024 32-row units -- smaller
@@ -947,9 +955,9 @@ def set_mlp_precision(precision):
 	O(1) and its dZ O(1e-6 .. 1e-1), but a loss scaled far outside that is the caller's responsibility.  The precision travels with
 	each call (find_mlp_params.precision): a backward always runs in the arithmetic of its forward.  Returns the previous setting."""
 	global _MLP_PRECISION
-	if precision not in ('fp32', 'fp16'):
-		raise ValueError(f"set_mlp_precision: 'fp32' or 'fp16', got {precision!r}")
-	_lib.set_tuning('mlp_f16', int(precision == 'fp16'))   # the isolated-kernel entry points (find_linear_*) read the context's knob
+	if precision not in ('fp32', 'fp16', 'bf16x3'):
+		raise ValueError(f"set_mlp_precision: 'fp32', 'bf16x3' or 'fp16', got {precision!r}")
+	_lib.set_tuning('mlp_f16', {'fp32': 0, 'fp16': 1, 'bf16x3': 2}[precision])   # the isolated-kernel entry points (find_linear_*) read the context's knob
 	prev, _MLP_PRECISION = _MLP_PRECISION, precision
 	return prev
 

@@ -391,8 +391,8 @@ class NeuralDisplacementField(Model):
 	def set_mlp_precision(self, precision):
 		"""Arithmetic of THIS model's 256 -> 256 layers: 'fp32', 'fp16' (opt-in, find_amd.functional.set_mlp_precision for what it
 		means) or None = follow the process default.  Two models in one process may differ."""
-		if precision not in (None, 'fp32', 'fp16'):
-			raise ValueError(f"set_mlp_precision: None, 'fp32' or 'fp16', got {precision!r}")
+		if precision not in (None, 'fp32', 'fp16', 'bf16x3'):
+			raise ValueError(f"set_mlp_precision: None, 'fp32', 'bf16x3' or 'fp16', got {precision!r}")
 		self._spec.precision = precision
 
 	def _rebuild_template_mesh(self):

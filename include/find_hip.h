@@ -89,9 +89,16 @@ typedef struct find_mlp_params {
 	const float* col_w[FIND_MAX_LAYERS];
 	const float* col_b[FIND_MAX_LAYERS];
 	const float* avg_col; /* (3) added to the colour output when non-NULL (use_avg_colour, model.py:446-447) */
-	int32_t precision;    /* arithmetic of the 256 -> 256 layers: 0 = the context's "mlp_f16" knob (default fp32), 1 = fp32 (the
-	                       * reference's arithmetic, the parity path), 2 = fp16 MFMA operands with fp32 accumulation (opt-in,
-	                       * BASELINE.json configs[4]; no reference counterpart) -- per call, so two models in one process may differ */
+	int32_t precision;    /* arithmetic of the 256 -> 256 layers, per call (two models in one process may differ):
+	                       *   0 = the context's "mlp_f16" knob;
+	                       *   1 = fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic;
+	                       *   2 = fp16 MFMA operands (rounded to 11 bits) with fp32 accumulation: opt-in, BASELINE.json configs[4], no reference
+	                       *       counterpart, ~1e-3 relative per layer;
+	                       *   3 = bf16x3: every fp32 operand split EXACTLY into three bf16 pieces, the six products of relative size >= 2^-18
+	                       *       on the bf16 matrix pipe, fp32 accumulation -- what is left out is <= 2^-26 of a product (a quarter of one fp32
+	                       *       rounding), so results are as close to the float64 product as mode 1's (tests/test_gpu_mlp_bf16x3.py) at
+	                       *       6/16 of its matrix-pipe time; the default of the Python surface (find_amd.functional.set_mlp_precision).
+	                       *       Large launches only (>= "gemm6_min_units" 32-row units); smaller ones run mode 1's kernels */
 } find_mlp_params;
 
 /* Gradient outputs, same shapes as the corresponding weights; every buffer given is OVERWRITTEN.
@@ -173,7 +180,10 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *                     find_linear_wgrad: 1 = the K = 256 Linear layers (forward, dX and dW) run on the fp16 matrix pipe: operands rounded to
  *                     fp16, fp32 accumulation, fp32 tensors (gemm5_kernel, dw3_kernel; BASELINE.json configs[4]).  Default 0: this knob DOES
  *                     change results (~1e-3 relative per layer); the Python surface is find_amd.functional.set_mlp_precision
+ *                     2 = bf16x3 (find_mlp_params.precision 3: fp32-faithful, gemm7_kernel / dw6_kernel)
  *   "gemm5_min_units" in fp16 mode, launches of fewer 32-row units than this stay on the fp32 kernels (default 1024)
+ *   "gemm6_min_units" the same threshold for the bf16x3 kernels (default 1024)
+ *   "gemm7"           bf16x3 Linear kernel: 1 = gemm7 (weights in registers, activations through LDS; default), 0 = gemm6 (weight planes in LDS)
  *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
  *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped
  *                     launch + one grouped reduce; 0 = one launch per layer at every size

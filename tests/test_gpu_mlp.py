@@ -534,15 +534,16 @@ def test_latent_gather_many_and_weighted_terms():
 	assert [round(r.grad.item(), 4) for r in raws] == [20000.0, 2000.0, 3.0]
 
 
-@pytest.mark.parametrize('n_feet,variant', [(16, 'dw4'), (1, 'dw4'), (16, 'dw2_whole_file'), (16, 'fp16')])
+@pytest.mark.parametrize('n_feet,variant', [(16, 'bf16x3'), (16, 'dw4'), (1, 'dw4'), (16, 'dw2_whole_file'), (16, 'fp16')])
 def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet, variant):
 	"""The stress configuration that made round 1's rare fault happen in every pass (mlp.hip, 'Co-residence fault'): the slab reduces are
 	replaced by an LDS-free, slow kernel ("reduce_exclusive" = 2), so that reduces of earlier layers stay resident on the CUs beside the
 	weight-gradient kernels of later layers.  The victims were waves with the full accumulator set in a 300-328 register allocation (dw2_kernel as round 1
-	had it: ~6 wrong weight gradients per pass).  Every weight-gradient kernel the product can select -- dw4 (<= 256 registers, the default), dw2
-	with the whole register file claimed, the fp16 mode's dw3 likewise -- must give bit-identical gradients in every pass, with and
-	without the LDS reservation."""
+	had it: ~6 wrong weight gradients per pass).  Every weight-gradient kernel the product can select -- the default bf16x3 arithmetic's dw6 (whole
+	register file claimed) beside gemm7 (<= 256 registers), the fp32-MFMA path's dw4 (<= 256 registers), dw2 with the whole register file claimed, the
+	fp16 mode's dw3 likewise -- must give bit-identical gradients in every pass, with and without the LDS reservation."""
 	from find_amd import _lib, synthetic
+	from find_amd import functional as F
 	dev = torch.device('cuda:0')
 	model = synthetic.make_model(6890, train_size=n_feet, val_size=2, device=dev)
 	lat = synthetic.latents(n_feet, seed=0, device=dev)
@@ -559,7 +560,7 @@ def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet, variant)
 	assert _lib.get_tuning('dw_lds_free') == 1 and _lib.get_tuning('lds_exclusive') == 0
 	_lib.set_tuning('reduce_exclusive', 2)
 	_lib.set_tuning('dw_lds_free', 0 if variant == 'dw2_whole_file' else 1)
-	_lib.set_tuning('mlp_f16', int(variant == 'fp16'))
+	prev_prec = F.set_mlp_precision({'fp16': 'fp16', 'bf16x3': 'bf16x3'}.get(variant, 'fp32'))
 	try:
 		for excl in (0, 1):
 			_lib.set_tuning('lds_exclusive', excl)
@@ -572,7 +573,7 @@ def test_backward_is_bit_reproducible_under_co_residence_stress(n_feet, variant)
 		_lib.set_tuning('reduce_exclusive', 0)
 		_lib.set_tuning('lds_exclusive', 0)
 		_lib.set_tuning('dw_lds_free', 1)
-		_lib.set_tuning('mlp_f16', 0)
+		F.set_mlp_precision(prev_prec)
 
 
 @pytest.mark.parametrize('shape', [(16, 1000), (9, 1000), (5, 2100)])

@@ -11,6 +11,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def fp32_baseline():
+	"""The comparisons of this file are against the fp32-MFMA kernels, whatever the process default is (bf16x3 since round 4)."""
+	from find_amd import functional as F
+	prev = F.set_mlp_precision('fp32')
+	try:
+		yield
+	finally:
+		F.set_mlp_precision(prev)
+
+
 @pytest.fixture
 def fp16_mode():
 	"""fp16 mode with gemm5 forced for every row count (by default launches of fewer than 1024 32-row units stay on the fp32 kernels,

@@ -232,17 +232,22 @@ def test_sample_latent_vectors_by_label_and_index():
 
 
 def test_mlp_precision_switch_round_trip():
-	"""set_mlp_precision only flips a host-side switch of the library (no GPU needed); fp32 is the default."""
+	"""set_mlp_precision only flips a host-side switch of the library (no GPU needed); bf16x3 -- fp32-faithful arithmetic on the bf16 matrix
+	pipe -- is the default, FIND_MLP_PRECISION overrides it for a process."""
+	import os
 	from find_amd import functional as F
-	assert F.get_mlp_precision() == 'fp32'
-	assert F.set_mlp_precision('fp16') == 'fp32'
+	default = os.environ.get('FIND_MLP_PRECISION', 'bf16x3')
+	assert F.get_mlp_precision() == default
+	assert F.set_mlp_precision('fp16') == default
 	try:
 		assert F.get_mlp_precision() == 'fp16'
-	finally:
 		assert F.set_mlp_precision('fp32') == 'fp16'
+		assert F.set_mlp_precision('bf16x3') == 'fp32'
+	finally:
+		F.set_mlp_precision(default)
 	with pytest.raises(ValueError):
 		F.set_mlp_precision('bf16')
-	assert F.get_mlp_precision() == 'fp32'
+	assert F.get_mlp_precision() == default
 
 
 def test_no_kernel_sits_between_256_and_512_registers():

@@ -50,6 +50,22 @@ def run(mode, name):
 
 
 y4 = run(0, 'gemm4 (fp32 MFMA)')
-y6 = run(2, 'gemm6 (bf16x3)')
+_lib.set_tuning('gemm7', 0)
+y6 = run(2, 'gemm6 (bf16x3, W in LDS)')
+_lib.set_tuning('gemm7', 1)
+y7 = run(2, 'gemm7 (bf16x3, W in regs)')
+print('gemm7 vs gemm6: max |diff| %.3e' % (y7 - y6).abs().max().item())
 y5 = run(1, 'gemm5 (fp16 operands)')
 print('gemm6 vs gemm4: max |diff| %.3e' % (y6 - y4).abs().max().item())
+
+if os.environ.get('FIND_DBG'):
+	_lib.set_tuning('mlp_f16', 2)
+	dbg = torch.zeros(256 * 4, dtype=torch.int64, device='cuda')
+	_lib.set_tuning('dbg', dbg.data_ptr())
+	_lib.check(L.find_linear_relu_fwd(_lib.ctx(), _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), n_feet, n_pts, _lib.ptr(y), ctypes.c_void_p(s.cuda_stream)), 'lin')
+	torch.cuda.synchronize()
+	_lib.set_tuning('dbg', 0); _lib.set_tuning('mlp_f16', 0)
+	d = dbg.view(256, 4).double().cpu() * 10.0   # 100 MHz ticks -> ns
+	print('gemm7 per workgroup (wave 0), ns: total %.0f (min %.0f max %.0f); at the barrier %.0f (%.1f%%), k loop %.0f (%.1f%%), epilogue %.0f (%.1f%%)' % (
+		d[:, 0].mean(), d[:, 0].min(), d[:, 0].max(), d[:, 1].mean(), 100 * d[:, 1].sum() / d[:, 0].sum(), d[:, 3].mean(), 100 * d[:, 3].sum() / d[:, 0].sum(),
+		d[:, 2].mean(), 100 * d[:, 2].sum() / d[:, 0].sum()))
