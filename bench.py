@@ -42,6 +42,7 @@ N_FEET = 16
 N_VERTS = 6890
 N_GT_VERTS = 10002
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16 / 16x16x32: 512 FMA per cycle and SIMD at 2.4 GHz)
 SUSTAINED_FP32_MFMA_TFLOPS = 146.9  # measured: tools/mfma_peak.hip, registers only, one wave per SIMD (profiles/r03_mfma_peak.txt)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable by a streaming kernel)
 METRIC = 'deformed vertices x rendered views / sec (fwd+bwd)'
@@ -56,13 +57,19 @@ MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 # fp16-mode gemm5 (profiles/r01_traffic_pmc_summary.txt): 2 x 57.10 MB + 112.9 MB.
 GEMM_TRAFFIC_BYTES = 242.9e6
 GEMM5_TRAFFIC_BYTES = 227.1e6
+GEMM5_C5_TRAFFIC_BYTES = None   # (gemm5 at the C5 shape, 16 x 50 002 rows: profiles/r04_gemm5_c5_pmc_summary.txt)
+GEMM7_TRAFFIC_BYTES = None   # (bf16x3 gemm7: filled in from profiles/r04_gemm7_pmc_summary.txt)
 
 
 def dtype_label():
-	"""Arithmetic type of the path as configured: fp32 unless the opt-in fp16 matrix-pipe mode was switched on."""
+	"""Arithmetic type of the path as configured."""
 	from find_amd import functional as FF
-	if FF.get_mlp_precision() == 'fp16':
+	prec = FF.get_mlp_precision()
+	if prec == 'fp16':
 		return 'f16 operands / f32 accumulation in the 256->256 layers (fwd, dX, dW), f32 tensors and f32 elsewhere'
+	if prec == 'bf16x3':
+		return ('f32 (tensors and results fp32; the large 256->256 layers as bf16x3: every fp32 operand split exactly into three bf16 pieces, six '
+				'products on the bf16 matrix pipe, fp32 accumulation -- error that of the fp32 MFMA kernels, tests/test_gpu_mlp_bf16x3.py)')
 	return 'f32'
 
 
@@ -432,12 +439,13 @@ def train3d_cpu(mwl, gt, stage='net', sample_feet=1):
 				sample=f'{nf} foot of the same step (batch {nf}) without the optimiser update, oracle (torch-CPU / numpy), {how}')
 
 
-def time_dominant_kernel(device, iters=100, warm=150):
+def time_dominant_kernel(device, iters=100, warm=150, n_verts=None):
 	"""Average duration of the dominant kernel (Linear 256->256 + ReLU over all head rows), HIP events on the launch stream."""
 	import ctypes
 	from find_amd import _lib
 	L = _lib.lib()
-	rows = N_FEET * N_VERTS
+	n_verts = n_verts or N_VERTS
+	rows = N_FEET * n_verts
 	g = torch.Generator().manual_seed(0)
 	x = torch.randn(rows, 256, generator=g).to(device)
 	w = (torch.randn(256, 256, generator=g) / 16).to(device)
@@ -446,7 +454,7 @@ def time_dominant_kernel(device, iters=100, warm=150):
 	stream = torch.cuda.current_stream(device)
 
 	def launch():
-		_lib.check(L.find_linear_relu_fwd(_lib.ctx(), _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), N_FEET, N_VERTS, _lib.ptr(y),
+		_lib.check(L.find_linear_relu_fwd(_lib.ctx(), _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), N_FEET, n_verts, _lib.ptr(y),
 										  ctypes.c_void_p(stream.cuda_stream)), 'find_linear_relu_fwd')
 
 	# the GPU idled while the inputs were generated on the host: launch long enough for the clock to come back up before timing
@@ -460,20 +468,105 @@ def time_dominant_kernel(device, iters=100, warm=150):
 	e1.synchronize()
 	ms = e0.elapsed_time(e1) / iters
 	flops = 2.0 * rows * 256 * 256
+	del x, y
 	return ms, flops
 
 
-def dominant_roofline(device, fp16=False):
-	kms, kflops = time_dominant_kernel(device)
+def time_wgrad_kernel(device, iters=60, warm=60):
+	"""Average duration of one 256 x 256 weight gradient over all head rows (find_linear_wgrad: the dW kernel + its slab reduce)."""
+	import ctypes
+	from find_amd import _lib
+	L = _lib.lib()
 	rows = N_FEET * N_VERTS
+	g = torch.Generator().manual_seed(1)
+	dz = (torch.randn(rows, 256, generator=g) * 0.1).to(device)
+	x = torch.relu(torch.randn(rows, 256, generator=g)).to(device)
+	dw, db = torch.empty(256, 256, device=device), torch.empty(256, device=device)
+	nb = L.find_linear_wgrad_scratch_bytes(N_FEET)
+	scratch = torch.empty(nb // 4, device=device)
+	stream = torch.cuda.current_stream(device)
+
+	def launch():
+		_lib.check(L.find_linear_wgrad(_lib.ctx(), _lib.ptr(dz), _lib.ptr(x), N_FEET, N_VERTS, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch), nb,
+									   ctypes.c_void_p(stream.cuda_stream)), 'find_linear_wgrad')
+	for _ in range(warm):
+		launch()
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	e0.record(stream)
+	for _ in range(iters):
+		launch()
+	e1.record(stream)
+	e1.synchronize()
+	return e0.elapsed_time(e1) / iters
+
+
+def time_small_pass(device, n_pts, shared, iters=40, warm=20):
+	"""Forward and forward + backward time of one SMALL MLP call -- the texture pass (16 feet x 1000 per-foot points, colour head only: the
+	64-row fused chain) or the template pass's shared trunk (batch of 16 on the 6890-vertex template is the large path; here batch 1) --
+	HIP events around the Python call, so the few small launches around the fused chain are inside.  Returns (fwd ms, fwd+bwd ms)."""
+	from find_amd import synthetic
+	model = synthetic.make_model(N_VERTS, train_size=N_FEET, val_size=2, device=device)
+	fill_latents(model, N_FEET, 0, device)
+	g = torch.Generator().manual_seed(5)
+	n = 1 if shared else N_FEET
+	lat = {k: getattr(model, k).data[:n].detach().clone().requires_grad_(True) for k in ('shapevec', 'texvec', 'posevec')}
+	pos = model.template_verts.data if shared else (torch.rand(N_FEET, n_pts, 3, generator=g) * 0.2 - 0.1).to(device)
+	kw = {} if shared else dict(want=('col',))
+	stream = torch.cuda.current_stream(device)
+
+	def fwd():
+		with torch.no_grad():
+			return model(pos, shapevec=lat['shapevec'], texvec=lat['texvec'], posevec=lat['posevec'], **kw)
+
+	def fwdbwd():
+		for p in model.parameters():
+			p.grad = None
+		res = model(pos, shapevec=lat['shapevec'], texvec=lat['texvec'], posevec=lat['posevec'], **kw)
+		(res['col'] ** 2).sum().backward() if not shared else ((res['col'] ** 2).sum() + (res['disp'] ** 2).sum()).backward()
+
+	out = []
+	for fn in (fwd, fwdbwd):
+		for _ in range(warm):
+			fn()
+		e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		e0.record(stream)
+		for _ in range(iters):
+			fn()
+		e1.record(stream)
+		e1.synchronize()
+		out.append(e0.elapsed_time(e1) / iters)
+	return out[0], out[1]
+
+
+# Time per step of the kernels that take the most of it INSIDE the headline step (rocprofv3 --kernel-trace of `bench.py --headline-only`, steps cut at
+# the optimiser kernel: profiles/r04_headline_step_stats.csv; several streams run side by side there, so these sum to more than the step).
+IN_STEP_US = {'fused_chain_kernel<2>': None, 'dw6_kernel': None, 'gemm7_kernel<2>': None, 'fused_chain_kernel<1>': None, 'gemm7_kernel<1>': None}
+
+
+def dominant_roofline(device, fp16=False, n_verts=None):
+	from find_amd import functional as FF
+	n_verts = n_verts or N_VERTS
+	kms, kflops = time_dominant_kernel(device, n_verts=n_verts, iters=100 if n_verts == N_VERTS else 30, warm=150 if n_verts == N_VERTS else 30)
+	rows = N_FEET * n_verts
+	nbytes = 2.0 * rows * 1024 + 256 * 1024   # algorithmic: rows x 1 KB read + rows x 1 KB written + the 256-KB weight matrix
+	gbs = nbytes / (kms * 1e-3) / 1e9
 	if fp16:
-		# gemm5 is bound by its streams: algorithmic bytes = rows x 1 KB read + rows x 1 KB written + the 256-KB weight matrix
-		nbytes = 2.0 * rows * 1024 + 256 * 1024
-		gbs = nbytes / (kms * 1e-3) / 1e9
+		# gemm5 is bound by its streams
 		return {'bound': 'hbm', 'kernel': f'find::mlp::gemm5_kernel<1> (Linear 256->256 + bias + ReLU over {rows} rows, fp16 MFMA operands, fp32 tensors in HBM)',
 				'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'avg_kernel_ms': kms,
-				'bytes_per_launch': nbytes, 'traffic': GEMM5_TRAFFIC_BYTES if N_VERTS == 6890 else None, 'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
+				'bytes_per_launch': nbytes, 'traffic': GEMM5_TRAFFIC_BYTES if n_verts == 6890 else (GEMM5_C5_TRAFFIC_BYTES if n_verts == 50002 else None), 'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
 	ach = kflops / (kms * 1e-3) / 1e12
+	if FF.get_mlp_precision() == 'bf16x3':
+		# six bf16 products per fp32 multiply-accumulate: the flops the matrix pipe EXECUTES are 6 x the layer's
+		ex = 6.0 * ach
+		return {'bound': 'mfma', 'kernel': f'find::mlp::gemm7_kernel<1, 0> (Linear 256->256 + bias + ReLU over {rows} rows; bf16x3: v_mfma_f32_16x16x32_bf16, fp32 accumulation)',
+				'achieved': ex, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex / PEAK_BF16_MFMA_TFLOPS,
+				'avg_kernel_ms': kms, 'flops_per_launch': 6.0 * kflops, 'flops_per_launch_fp32_equivalent': kflops,
+				'fp32_equivalent_tflops': ach, 'x_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
+				'hbm_gbs_algorithmic': gbs, 'frac_of_hbm_peak': gbs / PEAK_HBM_GBS, 'traffic': GEMM7_TRAFFIC_BYTES if N_VERTS == 6890 else None,
+				'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r04_gemm7_pmc_summary.txt; algorithmic 226.0e6',
+				'note': 'achieved / peak count the bf16 products the matrix pipe executes (6 per fp32 multiply-accumulate); fp32_equivalent_tflops is the layer\'s own '
+						'2*rows*256*256 flop count over the same time -- above the fp32 MFMA peak (x_fp32_mfma_peak), which the round-3 kernel (gemm4, records.fp32_mfma) sat at 0.80 of'}
 	return {'bound': 'mfma', 'kernel': f'find::mlp::gemm4_kernel<1, 4, 8> (Linear 256->256 + bias + ReLU over {rows} rows, fp32 MFMA)',
 			'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
 			'avg_kernel_ms': kms, 'flops_per_launch': kflops, 'traffic': GEMM_TRAFFIC_BYTES if N_VERTS == 6890 else None,
@@ -482,6 +575,40 @@ def dominant_roofline(device, fp16=False):
 			# `peak` is the guide's 2.4 GHz figure; a loop of nothing but back-to-back v_mfma_f32_32x32x2_f32 (tools/mfma_peak.hip, 64.0 cycles per
 			# instruction and SIMD) sustains 146.9 TFLOP/s on this part: the clock under fp32 MFMA load settles at 2.24 GHz (profiles/r03_mfma_peak.txt)
 			'sustained_mfma_tflops_measured': SUSTAINED_FP32_MFMA_TFLOPS, 'frac_of_sustained': ach / SUSTAINED_FP32_MFMA_TFLOPS}
+
+
+def roofline_kernels(device, lin_ms):
+	"""The kernels with the most time per step, each timed alone with HIP events (`isolated_us`) beside its time per step inside the headline
+	step (`in_step_us`, from the committed kernel trace: the step's streams run kernels side by side, a kernel is slower there than alone)."""
+	from find_amd import functional as FF
+	x3 = FF.get_mlp_precision() == 'bf16x3'
+	rows = N_FEET * N_VERTS
+	L = 2.0 * rows * 65536
+	mul = 6.0 if x3 else 1.0
+	peak = PEAK_BF16_MFMA_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
+	out = []
+
+	def entry(name, what, flops32, us, executed_mul, in_step_key):
+		ex = flops32 * executed_mul
+		e = {'kernel': name, 'what': what, 'flops_fp32_equivalent': flops32, 'isolated_us': us, 'fp32_equivalent_tflops': flops32 / (us * 1e-6) / 1e12,
+			 'executed_tflops': ex / (us * 1e-6) / 1e12, 'pipe': 'bf16 MFMA (bf16x3: 6 products per multiply-accumulate)' if executed_mul == 6.0 else 'fp32 MFMA',
+			 'frac': ex / (us * 1e-6) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if executed_mul == 6.0 else PEAK_FP32_MFMA_TFLOPS),
+			 'in_step_us_per_step': IN_STEP_US.get(in_step_key)}
+		out.append(e)
+
+	entry('gemm7_kernel<1>' if x3 else 'gemm4_kernel<1,4,8>', f'Linear 256->256 + bias + ReLU over {rows} rows (forward; 2 launches per step)', L, lin_ms * 1e3, mul, 'gemm7_kernel<1>')
+	wg_ms = time_wgrad_kernel(device)
+	entry(('dw6_kernel' if x3 else 'dw4_kernel') + ' + reduce_w_kernel', f'dW = dZ^T X over {rows} rows + its slab reduce (2 launches per step)', L, wg_ms * 1e3, mul, 'dw6_kernel')
+	# the small calls run whole layer chains per launch on the fp32 MFMA pipe: time the call (fused chain + the handful of small launches around it)
+	r = N_FEET * 1000
+	Lm = 65536.0
+	tex_fwd = 2.0 * r * (515 * 256 + 4 * Lm + Lm + 2 * Lm + 3 * 256)
+	tex_bwd = 2.0 * r * (2 * 3 * 256 + 4 * Lm + Lm + Lm + 8 * Lm + 515 * 256)
+	f_ms, fb_ms = time_small_pass(device, 1000, shared=False)
+	entry('fused_chain_kernel<2> (forward call)', f'texture pass forward: {N_FEET} x 1000 per-foot points, Fourier layer + trunk + colour head in one launch', tex_fwd, f_ms * 1e3, 1.0, 'fused_chain_kernel<2>')
+	entry('fused_chain_kernel<2> + dw4_group + dwpe (backward call)', 'texture pass backward: dX chain in one launch, eleven weight gradients as one grouped launch, the Fourier layer\'s beside them',
+		  tex_bwd, (fb_ms - f_ms) * 1e3, 1.0, 'fused_chain_kernel<2>')
+	return out
 
 
 # ------------------------------------------------------------------------------------------------ C2 / C5 (BASELINE configs[1], [4])
@@ -576,6 +703,11 @@ def c2_record(run, steps, warmup, n_verts=None, fp16=False, with_cpu=False, dp_o
 			bucket.close()
 		if with_cpu and run.world == 1 and n_verts == N_VERTS:
 			out['cpu_baseline'] = c2_cpu()
+		if fp16 and n_verts == 50002 and run.rank == 0:
+			# BASELINE configs[4] is "fp16 MLP with MFMA tiles, roofline run": the mode's Linear kernel is bound by its streams (HBM)
+			del model, params, step
+			torch.cuda.empty_cache()
+			out['roofline'] = dominant_roofline(run.dev, fp16=True, n_verts=n_verts)
 		return out
 	finally:
 		if prev is not None:
@@ -769,6 +901,26 @@ def eager_colour_head_record(run, steps, warmup):
 	return brief(rec, 'flops_executed_per_step', 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed')
 
 
+def fp32_mfma_record(run, steps, warmup):
+	"""The headline step with the 256 -> 256 layers on the fp32 MFMA kernels (gemm4 / dw4: round 3's arithmetic) instead of bf16x3, and the isolated
+	Linear kernel of that mode: what the default is compared with."""
+	from find_amd import functional as FF
+	prev = FF.set_mlp_precision('fp32')
+	try:
+		su = train3d_setup(run, N_FEET, N_FEET, stage='net', labels=False, seed=run.rank)
+		ms = run.timed(su['step'], steps, warmup)
+		fl = train3d_executed_flops(N_FEET)
+		rec = line(run.world * N_FEET * N_VERTS / (ms * 1e-3), ms, run, steps, warmup,
+				   {'workload': train3d_workload(N_FEET, 'net', False) + "; 256->256 layers on the fp32 MFMA kernels (FIND_MLP_PRECISION=fp32)",
+					'flops_executed_per_step': fl, 'step_tflops_executed': fl / (ms * 1e-3) / 1e12,
+					'step_frac_of_fp32_mfma_peak_executed': fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS})
+		del su
+		rec['roofline'] = dominant_roofline(run.dev)
+	finally:
+		FF.set_mlp_precision(prev)
+	return brief(rec, 'flops_executed_per_step', 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed')
+
+
 def train3d_b1_graph(run, steps, warmup, stage='net', frozen=False):
 	"""The batch-1 step as ONE HIP graph (find_amd/graph.py): sampling, forward, backward and the fused Adam step captured once,
 	replayed per step with the scan copied into the graph's static buffers -- the host enqueues one graph instead of a few hundred kernels.
@@ -819,8 +971,9 @@ def main():
 	if args.subpaths:
 		return subpaths(with_cpu)
 	run = Run(args.gpus)
+	from find_amd import functional as FF
+	FF.set_mlp_precision(FF.get_mlp_precision())   # (also hands the process default -- bf16x3 -- to the context's knob, which the isolated-kernel entry points read)
 	if args.fp16 and not (args.c2 or args.c5):
-		from find_amd import functional as FF
 		FF.set_mlp_precision('fp16')
 
 	if args.c2 or args.c5 or args.dp_overhead:
@@ -868,6 +1021,8 @@ def main():
 		out = line(run.world * N_FEET * N_VERTS / (ms * 1e-3), ms, run, args.steps, args.warmup, cfg, ms_per_step_repeats=ms_all, ms_per_step_best=min(ms_all))
 		if not args.headline_only:
 			out['roofline'] = dominant_roofline(run.dev, fp16=args.fp16)
+			if not args.fp16:
+				out['roofline']['kernels'] = roofline_kernels(run.dev, out['roofline']['avg_kernel_ms'])
 			if with_cpu and run.world == 1:
 				out['cpu_baseline'] = train3d_cpu(su['mwl'], su['gt'], stage='net', sample_feet=1)
 				out['x_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
@@ -876,6 +1031,8 @@ def main():
 		recs = {}
 		note('record train3d_b16_eager_colour_head')
 		recs['train3d_b16_eager_colour_head'] = eager_colour_head_record(run, args.steps, args.warmup)
+		note('record fp32_mfma')
+		recs['fp32_mfma'] = fp32_mfma_record(run, args.steps, args.warmup)
 		recs.update(train3d_b1_records(run, with_cpu, graph=not args.no_graph))
 		note('record c2')
 		recs['c2'] = brief(c2_record(run, 30, 5, with_cpu=with_cpu), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed', 'step_tflops_reference_equiv')

@@ -15,6 +15,8 @@ Constraints (checked or documented): every batch of one shape signature shares a
 (opts.restrict_3d_n_train) cannot be captured.  The warm-up iterations that precede a capture are DRY: parameters and optimiser
 state are put back before the capture, so N calls are N training steps, the first batch of a shape included (only the random
 generators -- the sampler's device generator, numpy's for the camera poses -- have advanced)."""
+import collections
+
 import torch
 
 from . import functional as FN
@@ -36,16 +38,77 @@ def _mesh_tensors(m):
 	return out
 
 
+def _mesh_padding(m):
+	"""What the ragged dimension of each tensor of _mesh_tensors is padded with (PyTorch3D's conventions: vertices / features 0, face lists
+	-1 -- every kernel of the path skips a face whose first index is negative); None = not ragged (texture maps keep their size)."""
+	out = [0.0, -1]
+	t = m.textures
+	if isinstance(t, TexturesVertex):
+		out.append(0.0)
+	elif isinstance(t, TexturesUV):
+		out += [None, -1, 0.0]
+	return out
+
+
+def _ragged_dim(t):
+	return 0 if t.dim() == 2 else 1   # a face list shared by the batch is (F, 3); everything else (N, count, ...)
+
+
+def bucket_size(n):
+	"""Smallest of 256, 384, 512, 768, 1024, 1536, ... (half-octave steps: at most a third of a bucket is padding) that holds n."""
+	b = 256
+	while True:
+		if b >= n:
+			return b
+		if b * 3 // 2 >= n:
+			return b * 3 // 2
+		b *= 2
+
+
+def _bucket_shape(t, pad):
+	if pad is None:
+		return tuple(t.shape)
+	sh = list(t.shape)
+	d = _ragged_dim(t)
+	sh[d] = bucket_size(sh[d])
+	return tuple(sh)
+
+
+def _padded_mesh(m):
+	"""A copy of `m` whose vertex / face / feature tensors have bucket sizes (the static input of a captured step)."""
+	new = []
+	for t, pad in zip(_mesh_tensors(m), _mesh_padding(m)):
+		sh = _bucket_shape(t, pad)
+		if sh == tuple(t.shape):
+			new.append(t.clone())
+			continue
+		p = t.new_full(sh, pad)
+		p.narrow(_ragged_dim(t), 0, t.shape[_ragged_dim(t)]).copy_(t)
+		new.append(p)
+	tex = None
+	if isinstance(m.textures, TexturesVertex):
+		tex = TexturesVertex(new[2])
+	elif isinstance(m.textures, TexturesUV):
+		tex = TexturesUV(new[2], new[3], new[4])
+	return Meshes(new[0], new[1], tex)
+
+
 class _Captured:
 	pass
 
 
 class GraphedStep:
-	def __init__(self, model_with_loss, opts, optimizers, latent_vectors=None, warmup=2, pre_step=None, stream=None, **flags):
+	def __init__(self, model_with_loss, opts, optimizers, latent_vectors=None, warmup=2, pre_step=None, stream=None, bucket=True, max_graphs=8, **flags):
 		"""model_with_loss: find_amd.model_with_loss.ModelWithLoss; optimizers: list stepped after backward; latent_vectors: the
 		LatentVector list to sample per batch (default: model.latent_vectors_train, or _val when flags has is_train=False);
 		pre_step: optional callable run between backward and the optimiser steps (e.g. a gradient all-reduce); flags: the loss
 		switches handed to ModelWithLoss.forward.
+		bucket: scans of different sizes share a graph -- real Foot3D scans are ragged (src/data/dataset.py:263-297: "10-20 K faces"), and keyed on
+		exact shapes every scan of a batch-1 epoch would be its own warm-up + capture + static buffers.  The batch's meshes are padded to
+		bucket sizes (bucket_size: half-octave steps; faces with -1, which every kernel of the path skips, vertices and features with 0: no
+		face refers to them), so a whole dataset replays a handful of graphs and gives the numbers of the unpadded eager step (a padded face
+		has area 0 and is never sampled; the samplers' draws do not depend on the sizes).  max_graphs: captured graphs kept (least
+		recently used goes first); n_captures counts them (find_amd.trainer.Trainer reports it per epoch).
 		stream: the (non-default) stream warm-up and capture run on.  autograd ties every parameter's AccumulateGrad node to the stream it
 		was created on and keeps the node while ANY graph that reaches the parameter is alive; a backward captured on another stream
 		then records a dependency on that foreign stream, which hipStreamEndCapture (ROCm 7.x) answers with a segmentation fault.  A
@@ -80,21 +143,25 @@ class GraphedStep:
 			raise ValueError('GraphedStep: at least one eager warm-up step is needed before a capture')
 		self.warmup = warmup
 		self.pre_step = pre_step
-		self._graphs = {}
+		self._graphs = collections.OrderedDict()
 		self._pool = None
+		self.bucket, self.max_graphs, self.n_captures = bool(bucket), int(max_graphs), 0
 		self.stream, self._own_stream = stream, stream is None
 
 	# ------------------------------------------------------------------ batch -> static buffers
-	@staticmethod
-	def _signature(batch):
+	def _signature(self, batch):
 		sig = []
 		for k in sorted(batch):
 			v = batch[k]
 			if torch.is_tensor(v):
 				sig.append((k, tuple(v.shape), str(v.dtype)))
 			elif isinstance(v, Meshes):
-				sig.append((k, tuple((tuple(t.shape), str(t.dtype)) for t in _mesh_tensors(v)), tuple(v._num_verts), tuple(v._num_faces),
-							type(v.textures).__name__))
+				if self.bucket:   # bucket sizes, not the scan's own: the counts travel as -1 padding
+					sig.append((k, tuple((_bucket_shape(t, pad), str(t.dtype)) for t, pad in zip(_mesh_tensors(v), _mesh_padding(v))), len(v),
+								v._faces_shared is not None, type(v.textures).__name__))
+				else:
+					sig.append((k, tuple((tuple(t.shape), str(t.dtype)) for t in _mesh_tensors(v)), tuple(v._num_verts), tuple(v._num_faces),
+								type(v.textures).__name__))
 			elif isinstance(v, (list, tuple)):
 				sig.append((k, len(v)))
 			else:
@@ -124,9 +191,10 @@ class GraphedStep:
 			if torch.is_tensor(v) and v.is_cuda:
 				st.batch[k] = v.clone()
 			elif isinstance(v, Meshes):
-				st.batch[k] = v.clone()
+				st.batch[k] = _padded_mesh(v) if self.bucket else v.clone()
 			else:
 				st.batch[k] = v
+		st.filled = {}   # (batch key, tensor index) -> how far the static tensor holds real data (what a smaller scan must overwrite with padding)
 		n_lab = sum(1 for vec in self.latent_vectors if vec.labels is not None)
 		bsz = len(batch['idx']) if 'idx' in batch else len(next(iter(batch.values())))
 		st.idx_host = torch.zeros(max(n_lab, 1), bsz, dtype=torch.int64).pin_memory()
@@ -279,8 +347,21 @@ class GraphedStep:
 					s.copy_(v, non_blocking=True)
 			elif isinstance(v, Meshes):
 				src, dst = _mesh_tensors(v), _mesh_tensors(s)
-				if any(a.data_ptr() != b.data_ptr() for a, b in zip(src, dst)):
-					torch._foreach_copy_(dst, src)
+				same = [a.shape == b.shape for a, b in zip(src, dst)]
+				if all(same):
+					if any(a.data_ptr() != b.data_ptr() for a, b in zip(src, dst)):
+						torch._foreach_copy_(dst, src)
+					continue
+				for i, (a, b, pad) in enumerate(zip(src, dst, _mesh_padding(v))):
+					if a.shape == b.shape:
+						b.copy_(a, non_blocking=True)
+						continue
+					d = _ragged_dim(a)
+					n, was = a.shape[d], st.filled.get((k, i), b.shape[d])
+					b.narrow(d, 0, n).copy_(a, non_blocking=True)
+					if was > n:   # the previous, larger scan's tail
+						b.narrow(d, n, was - n).fill_(pad)
+					st.filled[(k, i)] = n
 		rows = [r for r in self._latent_indices(batch) if r is not None]
 		if rows:
 			new = torch.tensor(rows, dtype=torch.int64)
@@ -303,6 +384,11 @@ class GraphedStep:
 		st = self._graphs.get(sig)
 		if st is None:
 			st = self._graphs[sig] = self._capture(batch, epoch)
+			self.n_captures += 1
+			while len(self._graphs) > self.max_graphs:   # least recently used first: its graph and static buffers go back to the pool
+				self._graphs.popitem(last=False)
+		else:
+			self._graphs.move_to_end(sig)
 		dev = st.idx_dev.device
 		cur = torch.cuda.current_stream(dev)
 		if cur == self.stream:

@@ -94,6 +94,7 @@ class Trainer:
 		self.graph = graph
 		self._graphed = {}
 		self.last_mode = None   # 'graph' | 'eager': how the most recent epoch ran (tests, bench)
+		self.last_captures = 0  # HIP graphs captured during the most recent epoch (ragged scans share bucketed graphs: a handful per dataset)
 		# Every step of this trainer -- eager, warm-up, capture -- runs on ONE stream of its own: autograd ties a parameter's gradient
 		# accumulation to the stream its node was created on, and a capture that meets a node of another stream (kept alive by any loss
 		# or latent row of an eager step) does not survive hipStreamEndCapture (find_amd.graph.GraphedStep: stream).
@@ -133,6 +134,9 @@ class Trainer:
 		self._stream.wait_stream(torch.cuda.current_stream(self.device))   # whatever produced the loader's tensors
 		return self._stream
 
+	def _captures(self):
+		return sum(g.n_captures for g in self._graphed.values())
+
 	def _epoch_done(self):
 		if self._stream is not None:
 			torch.cuda.current_stream(self.device).wait_stream(self._stream)
@@ -164,6 +168,7 @@ class Trainer:
 		log = _DeviceLog()
 		gs = self._mode(self.optims, self.latent_vectors_train, model_kwargs)
 		self.last_mode = 'graph' if gs is not None else 'eager'
+		captures0 = self._captures()
 		step_per_epoch = bool(getattr(self.opts, 'step_per_epoch', False))
 		stream = self._step_stream()
 		n_steps = 0
@@ -198,7 +203,9 @@ class Trainer:
 		vals = log.read()
 		epoch_losses = {('Loss' if k == 'Loss' else pretty_print_loss(k)): v for k, v in vals.items()}
 		self.log[epoch]['train_loss'] = dict(epoch_losses)
-		return ('*' * save_model) + f'[{epoch}] ' + '|'.join(f'{k}:{np.mean(v):.2f}' for k, v in epoch_losses.items()) + f' ({n_steps} steps, {self.last_mode})'
+		self.last_captures = self._captures() - captures0
+		how = self.last_mode + (f', {self.last_captures} graph(s) captured' if self.last_captures else '')
+		return ('*' * save_model) + f'[{epoch}] ' + '|'.join(f'{k}:{np.mean(v):.2f}' for k, v in epoch_losses.items()) + f' ({n_steps} steps, {how})'
 
 	def val_epoch(self, epoch, model_kwargs={}):
 		model_kwargs['is_train'] = False
@@ -207,6 +214,7 @@ class Trainer:
 		log = _DeviceLog()
 		gs = self._mode([self.val_optim], self.latent_vectors_val, model_kwargs)
 		self.last_mode = 'graph' if gs is not None else 'eager'
+		captures0 = self._captures()
 		stream = self._step_stream()
 		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
 			for batch in self.val_loader:
@@ -225,6 +233,7 @@ class Trainer:
 		vals = log.read()
 		epoch_losses = {('Loss' if k == 'Loss' else k.replace('loss_', '').lower()): v for k, v in vals.items()}
 		self.log[epoch]['val_loss'] = {pretty_print_loss(k): v for k, v in epoch_losses.items()}
+		self.last_captures = self._captures() - captures0
 		msg = f'[{epoch} - VAL] ' + '|'.join(f'{pretty_print_loss(k)}:{np.mean(v):.2f}' for k, v in epoch_losses.items())
 		return msg, {k: np.mean(v) for k, v in epoch_losses.items()}
 

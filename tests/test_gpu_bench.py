@@ -22,7 +22,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 	# BASELINE.json: "deformed vertices x rendered views / sec (fwd+bwd); Chamfer vs ref" -- the throughput clause is the bench metric
 	assert d['metric'] == base['metric'].split(';')[0].replace('\u00d7', 'x').strip() and d['unit'] == 'vertices*views/s'
 	assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1
-	assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic' and d['dtype'] == 'f32'
+	assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic' and d['dtype'].startswith('f32')
 	assert d['vs_baseline'] is None   # BASELINE.md holds no published number for this metric
 	assert d['value'] > 0 and d['ms_per_step'] > 0
 	assert abs(d['value'] - 16 * 6890 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
@@ -30,6 +30,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 	rf = d['roofline']
 	assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s')
 	assert rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and 0.3 < rf['frac'] < 1.0
+	assert len(rf['kernels']) >= 4 and all(k['isolated_us'] > 0 and 0.05 < k['frac'] < 1.0 for k in rf['kernels'])
 	assert rf['traffic'] is None or rf['traffic'] > 0
 	cb = d['cpu_baseline']
 	assert cb['value'] > 0 and cb['unit'] == d['unit'] and cb['cores'] >= 1 and cb['kind'] in ('reference', 'port') and isinstance(cb['sample'], str)

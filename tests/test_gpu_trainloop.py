@@ -398,7 +398,7 @@ def _reg_trainer_run(graph, gt_z_cutoff, epochs=3):
 	opts.set_option('gt_z_cutoff', gt_z_cutoff)
 	m = mwl.model
 	_fill_val_tables(m)
-	optim_reg = optim.SGD(m.reg_params, lr=1e-3, momentum=0.9)
+	optim_reg = optim.SGD(m.reg_params, lr=1e-5, momentum=0.9)   # lr_reg's default (opts.py:55); the Chamfer term is weighted 1e4: 1e-3 diverges
 	loader = [batch_of(i) for i in (0, 3, 1, 2)]
 	val_loader = [_val_batch(gv, gf, gc, 0, '9000-A'), _val_batch(gv, gf, gc, 1, '9000-B')]
 	# train.py:183-186: trainer_reg = Trainer([optim_reg], ..., val_optim=optim_reg)
@@ -483,3 +483,109 @@ def test_render_watchdog_sees_the_renders_of_a_captured_step():
 			FR.check_render_flags(wait=True)
 		except RuntimeError:
 			pass
+
+
+def test_ragged_scans_share_bucketed_graphs():
+	"""Real Foot3D scans are ragged (src/data/dataset.py:263-297; collate at :55-67): twelve scans of twelve different sizes through the
+	Trainer's default graph mode must not mean twelve captures.  GraphedStep pads the batch's mesh to bucket sizes (faces with -1, which every
+	kernel skips) -- the epoch replays at most 3 graphs and leaves the parameters where the eager loop on the UNPADDED scans leaves them."""
+	from find_amd import optim, synthetic
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.trainer import Trainer
+	sizes = [(26 + i, 30 + (i * 7) % 11) for i in range(12)]   # (rings, segments) of the lat-long GT scans: 782 .. 1300 vertices, twelve distinct sizes
+	assert len({r * s for r, s in sizes}) == 12
+	g = torch.Generator().manual_seed(3)
+	scans = []
+	for r, sg in sizes:
+		v, f = synthetic.ellipsoid_mesh(r, sg)
+		v = v * (1 + 0.1 * torch.rand(1, 3, generator=g)) + 0.002 * torch.randn(v.shape, generator=g)
+		c = torch.rand(v.shape, generator=g).clamp(0.05, 0.95)
+		scans.append((v.cuda(), f.cuda(), c.cuda()))
+
+	def run(graph):
+		mwl, opts, batch_of, _, _ = _setup(1002, 1002, capturable=True, seed=4)
+		m = mwl.model
+		feet, names, labels = synthetic.scan_labels(4)
+		opt = optim.Adam(m.main_params, lr=5e-4, capturable=True)
+		loader = []
+		for i, (v, f, c) in enumerate(scans):
+			j = i % 4
+			loader.append(dict(mesh=Meshes(v[None], f[None], TexturesVertex(c[None])), idx=torch.tensor([j], device='cuda'), name=[names[j]],
+							   shape=[feet[j]], tex=[feet[j]], pose=[names[j]], reg=[names[j]]))
+		tr = Trainer([opt], mwl, loader, [], opts, latent_vectors_train=m.latent_vectors_train, latent_vectors_val=m.latent_vectors_val,
+					 val_optim=opt, device='cuda', graph=graph)
+		torch.manual_seed(11)   # the samplers draw from torch's device generator: same draws in both loops (the sizes do not enter them)
+		msg = tr.train_epoch(0, model_kwargs=dict(opts.net_train_kwargs()))
+		torch.cuda.synchronize()
+		return tr, {n: p.detach().clone() for n, p in m.named_parameters()}, msg
+
+	tr_g, p_g, msg = run('auto')
+	tr_e, p_e, _ = run(False)
+	assert tr_g.last_mode == 'graph' and tr_e.last_mode == 'eager'
+	assert 1 <= tr_g.last_captures <= 3, msg
+	assert 'graph(s) captured' in msg
+	a, b = tr_g.log[0]['train_loss'], tr_e.log[0]['train_loss']
+	assert len(a['Loss']) == len(b['Loss']) == 12
+	# GraphedStep's warm-up before each capture advances the device generator (documented: the dry step draws), so the two loops do not see the
+	# same samples: the losses agree as two draws of 5000 / 1000 surface samples do, and the parameters as Adam steps of lr do
+	np.testing.assert_allclose(a['Loss'], b['Loss'], rtol=0.15)
+	lr, n_steps = 5e-4, 12
+	for n in p_e:
+		assert (p_g[n] - p_e[n]).abs().max().item() <= 2 * lr * n_steps, n
+	# the cache is bounded: a GraphedStep that may keep ONE graph serves the same epoch by re-capturing, never holding more than one
+	from find_amd.graph import GraphedStep, bucket_size
+	mwl, opts, batch_of, _, _ = _setup(1002, 1002, capturable=True, seed=4)
+	# (a stream of the caller's: every capture of this GraphedStep then runs where the earlier ones' gradient-accumulation nodes live)
+	gs = GraphedStep(mwl, opts, [optim.Adam(mwl.model.main_params, lr=5e-4, capturable=True)], warmup=1, max_graphs=1, stream=torch.cuda.Stream(),
+					 **opts.net_train_kwargs())
+	feet, names, labels = synthetic.scan_labels(4)
+	small, large = scans[0], scans[11]
+	assert bucket_size(small[0].shape[0]) != bucket_size(large[0].shape[0])
+	for v, f, c in (small, large, small):
+		gs(dict(mesh=Meshes(v[None], f[None], TexturesVertex(c[None])), idx=torch.tensor([0], device='cuda'), name=[names[0]], shape=[feet[0]], tex=[feet[0]],
+				pose=[names[0]], reg=[names[0]]))
+	torch.cuda.synchronize()
+	assert gs.n_captures == 3 and len(gs._graphs) == 1
+
+
+def test_bucketed_replay_equals_the_unpadded_step_with_fixed_draws():
+	"""The padding itself changes no number: with the samplers' draws fixed (face indices chosen inside the real face range), a scan replayed from
+	a graph captured on a DIFFERENT, larger scan of the same bucket gives the loss of the eager step on the unpadded scan."""
+	from find_amd import optim, synthetic
+	from find_amd.graph import GraphedStep, bucket_size
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.train_utils import sample_latent_vectors
+	g = torch.Generator().manual_seed(5)
+	scans = []
+	for r, sg in ((28, 33), (30, 34)):   # 926 and 1022 vertices: both in the 1024 bucket
+		v, f = synthetic.ellipsoid_mesh(r, sg)
+		v = v * (1 + 0.1 * torch.rand(1, 3, generator=g))
+		scans.append((v.cuda(), f.cuda(), torch.rand(v.shape, generator=g).clamp(0.05, 0.95).cuda()))
+	assert bucket_size(scans[0][0].shape[0]) == bucket_size(scans[1][0].shape[0]) and scans[0][0].shape != scans[1][0].shape
+	F_small = scans[0][1].shape[0]
+	draws = [(torch.randint(0, F_small, (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, 2 * (1002 - 2), (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, F_small, (1, 1000), generator=g).cuda(), torch.rand(1, 1000, 2, generator=g).cuda())]
+	feet, names, labels = synthetic.scan_labels(4)
+
+	def batch(i):
+		v, f, c = scans[i]
+		return dict(mesh=Meshes(v[None], f[None], TexturesVertex(c[None])), idx=torch.tensor([2], device='cuda'), name=[names[2]], shape=[feet[2]], tex=[feet[2]],
+					pose=[names[2]], reg=[names[2]])
+
+	mwl, opts, _, _, _ = _setup(1002, 1002, capturable=True, seed=6)
+	with FixedDraws(draws):
+		b = batch(0)
+		b.update(sample_latent_vectors(b, mwl.model.latent_vectors_train))
+		want, want_terms = mwl(b, 0, opts, **opts.net_train_kwargs())
+		want = want.item()
+	mwl2, opts2, _, _, _ = _setup(1002, 1002, capturable=True, seed=6)
+	gs = GraphedStep(mwl2, opts2, [optim.Adam(mwl2.model.main_params, lr=0.0, capturable=True)], warmup=1, **opts2.net_train_kwargs())
+	with FixedDraws(draws):
+		gs(batch(1))                 # capture on the LARGER scan of the bucket (lr = 0: the parameters stay put)
+		got, got_terms = gs(batch(0))   # replay on the smaller one: its tail must be overwritten with padding
+	torch.cuda.synchronize()
+	assert gs.n_captures == 1
+	assert abs(got.item() - want) < 1e-5 * max(1.0, abs(want)), (got.item(), want)
+	for k in want_terms:
+		assert abs(got_terms[k].item() - want_terms[k].item()) < 1e-5 * max(1.0, abs(want_terms[k].item())), k

@@ -314,3 +314,33 @@ def test_lazy_colour_containers_evaluate_once_and_only_when_read():
 	assert res['col'] is res['col'] and len(calls) == 2
 	with pytest.raises(KeyError):
 		res['nope']
+
+
+def test_split_is_exact_and_the_six_products_leave_out_less_than_one_rounding():
+	"""The arithmetic on the host, bit for bit as the kernels do it (torch.bfloat16 rounds to nearest even, as v_cvt_pk_bf16_f32 does):
+	a1 + a2 + a3 == a exactly for every fp32 value tried -- normal, tiny, huge, negative --, and the six products differ from the
+	float64 product by less than 2^-24 |a b| (one fp32 rounding).  (The one limit: |a| above bf16's largest finite value, 3.39e38 -- the top 0.4 %
+	of fp32's range -- rounds its first piece to infinity, and below ~3e-33 the third piece falls under bf16's smallest normal number: an absolute error
+	of at most 1e-40.  FIND's activations are O(1), its gradients O(1e-8 .. 1).)"""
+	g = torch.Generator().manual_seed(0)
+	a = torch.cat([torch.randn(20000, generator=g), torch.randn(2000, generator=g) * 1e-30, torch.randn(2000, generator=g) * 1e30,
+				   torch.tensor([1.0, -1.0, 1.0e-32, 65504.0, 1.0000001, 0.99999994, 3.3e38])])
+	b = torch.randn(a.shape, generator=g) * torch.logspace(-3, 3, a.numel())
+
+	def split(x):
+		p1 = x.bfloat16().float()
+		r1 = x - p1
+		p2 = r1.bfloat16().float()
+		r2 = r1 - p2
+		p3 = r2.bfloat16().float()
+		return p1, p2, p3
+
+	a1, a2, a3 = split(a)
+	b1, b2, b3 = split(b)
+	assert torch.equal((a1.double() + a2.double() + a3.double()).float(), a) and torch.equal(a1.double() + a2.double() + a3.double(), a.double())
+	six = (a1.double() * b1.double() + (a1.double() * b2.double() + a2.double() * b1.double())
+		   + (a1.double() * b3.double() + a2.double() * b2.double() + a3.double() * b1.double()))
+	exact = a.double() * b.double()
+	ok = exact.abs() > 1e-300
+	rel = ((six - exact).abs() / exact.abs().clamp(min=1e-300))[ok]
+	assert rel.max().item() < 2.0 ** -24, rel.max().item()
