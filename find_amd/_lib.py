@@ -206,5 +206,14 @@ def ptr(t):
 
 
 def current_stream(device):
+	"""hipStream_t of torch's current stream on `device`, as the C-ABI wants it.  (torch.cuda.current_stream() builds a Stream object every
+	time -- 10 us, fifteen times per training step; the raw handle comes from the same C call without it.)"""
 	import torch
-	return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+	if isinstance(device, torch.device):
+		idx = device.index if device.index is not None else torch.cuda.current_device()
+	elif isinstance(device, int):
+		idx = device
+	else:
+		idx = torch.device(device).index
+		idx = torch.cuda.current_device() if idx is None else idx
+	return c_void_p(torch._C._cuda_getCurrentRawStream(idx))
