@@ -9,7 +9,7 @@
 //   * THE ACTIVATIONS GO THROUGH LDS ONCE PER WORKGROUP.  The 8 waves of a workgroup (two per SIMD; 128 columns: the two column halves
 //     of the same rows run 8 blocks apart, on the same XCD) take a 32-row unit together: every wave loads whole rows (64 lanes x 16 B =
 //     one contiguous KB per instruction), each thread splits the 16 values it loaded -- every element is split ONCE per workgroup --
-//     and writes the three bf16 planes row-major into LDS (rows padded to 528 B: the fragment reads are conflict-free); the MFMA column
+//     and writes the three bf16 planes row-major into LDS (rows padded to 544 B: the fragment reads are conflict-free); the MFMA column
 //     operands are then 6 ds_read_b128 per k-step and wave (v_mfma_f32_16x16x32_bf16: two 16-row blocks x three planes);
 //   * two unit buffers (2 x 50 KB): the unit after the one being multiplied is split and stored, the one three units ahead is loaded
 //     and the block of the previous unit is stored UNDER the MFMAs of the current one, a piece behind every other MFMA (written down in
@@ -29,10 +29,11 @@ namespace mlp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int G7_ROW = 528;                    // bytes per activation row of one plane in LDS: 256 bf16 + 16 B of padding
-constexpr int G7_PLANE = 32 * G7_ROW;          // 16 896 B
-constexpr int G7_BUF = 3 * G7_PLANE;           // 50 688 B
-constexpr int GEMM7_LDS = 2 * G7_BUF;          // 101 376 B
+constexpr int G7_ROW = 544;                    // bytes per activation row of one plane in LDS: 256 bf16 + 32 B of padding (tools/lds_b128_probe.hip:
+                                               // the 16-row x 4-quarter fragment reads cost 8.3 cycles at a stride of 528 B, 7.2 -- conflict-free -- at 544)
+constexpr int G7_PLANE = 32 * G7_ROW;          // 17 408 B
+constexpr int G7_BUF = 3 * G7_PLANE;           // 52 224 B
+constexpr int GEMM7_LDS = 2 * G7_BUF;          // 104 448 B
 constexpr int GEMM7_NW = 8;
 
 // ABL: profiling only (tools/ablate_x3.py; results are wrong under every bit): 1 = no split / LDS writes, 2 = no fragment reads after a unit's
