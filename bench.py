@@ -186,6 +186,13 @@ class Run:
 	PRIME_S = 0.6   # see timed()
 
 	def timed(self, step, steps, warmup, prime=True):
+		"""_timed() with the backward passes on this thread, as find_amd.trainer.Trainer runs its loops (train_utils.backward_on_this_thread:
+		autograd's worker thread costs the host 0.5 ms per step and made the eager loop host-bound; FIND_AUTOGRAD_THREADS=1 for torch's default)."""
+		from find_amd.train_utils import backward_on_this_thread
+		with backward_on_this_thread():
+			return self._timed(step, steps, warmup, prime)
+
+	def _timed(self, step, steps, warmup, prime=True):
 		"""W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides (the driver's contract).  Before
 		the warm-up the workload is PRIMED -- untimed steps for at least PRIME_S seconds, until the step time has settled -- so that first-use
 		costs of a fresh process (allocator growth, queue probing, module loads) are behind it whatever W is.  What is timed is unchanged:
@@ -848,11 +855,13 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True, only=Non
 		ms = run.timed(su['step'], steps, warmup)
 		# host time to enqueue one step with an empty queue: is the step GPU-bound?
 		ts = []
-		for _ in range(20):
-			torch.cuda.synchronize()
-			t0 = time.perf_counter()
-			su['step']()
-			ts.append(time.perf_counter() - t0)
+		from find_amd.train_utils import backward_on_this_thread
+		with backward_on_this_thread():
+			for _ in range(20):
+				torch.cuda.synchronize()
+				t0 = time.perf_counter()
+				su['step']()
+				ts.append(time.perf_counter() - t0)
 		torch.cuda.synchronize()
 		fl = train3d_executed_flops(1, stage=stage, frozen=frozen)
 		rec = line(N_VERTS / (ms * 1e-3), ms, run, steps, warmup, {'workload': train3d_workload(1, stage, True, frozen), 'flops_executed_per_step': fl,
@@ -868,7 +877,7 @@ def train3d_b1_records(run, with_cpu, steps=300, warmup=30, graph=True, only=Non
 			rec['cpu_baseline'] = dict(cpu_net, sample=cpu_net['sample'] + ' [the network-stage timing: a latent-stage step is the same op sequence on the val rows]')
 		recs[key] = brief(rec, 'step_tflops_executed')
 		recs[key]['host_enqueue_ms_per_step'] = rec['host_enqueue_ms_per_step']
-		recs[key]['note'] = ('eager loop: bound by the host (host_enqueue_ms_per_step, box to box 1.0 - 1.8 ms); find_amd.trainer.Trainer runs this step as '
+		recs[key]['note'] = ('eager loop: bound by the host where host_enqueue_ms_per_step exceeds the replay time; find_amd.trainer.Trainer runs this step as '
 							 f'ONE HIP-graph replay: records.{key}_graph')
 		if graph:
 			try:

@@ -1,5 +1,21 @@
 """Caller-side helpers the reference keeps in src/train/trainer.py, mirrored so a step can be driven without the
 reference tree: latent-row sampling (trainer.py:29-46) and batch_to_device (trainer.py:19-26).  Host Python only."""
+import contextlib
+import os
+
+
+def backward_on_this_thread():
+	"""Context for a training loop: `loss.backward()` runs its nodes on the CALLING thread instead of handing them to autograd's per-device
+	worker thread.  The results are the same; what changes is the host's time.  A FIND step is ~100 short launches and its backward is a
+	dozen Python autograd functions: on the worker thread every one of them pays a hand-over of the interpreter lock between two threads,
+	and the pass starts with a wake-up during which the GPU drains (tools/host_ab.py, headline step of 16 feet: host time to enqueue a step
+	2.0 - 2.2 ms with the worker thread, 1.35 - 1.55 ms without -- the eager loop goes from host-bound to GPU-bound).  find_amd.trainer.Trainer
+	and bench.py run their steps inside it; a maintainer who keeps the reference's own loop wraps it the same way.
+	FIND_AUTOGRAD_THREADS=1 keeps torch's default."""
+	import torch
+	if os.environ.get('FIND_AUTOGRAD_THREADS', '0') == '1':
+		return contextlib.nullcontext()
+	return torch.autograd.set_multithreading_enabled(False)
 
 
 def batch_to_device(batch, device='cuda'):

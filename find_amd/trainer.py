@@ -17,7 +17,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from .train_utils import batch_to_device, sample_latent_vectors
+from .train_utils import backward_on_this_thread, batch_to_device, sample_latent_vectors
 
 
 def pretty_print_loss(loss_key: str):
@@ -172,7 +172,7 @@ class Trainer:
 		step_per_epoch = bool(getattr(self.opts, 'step_per_epoch', False))
 		stream = self._step_stream()
 		n_steps = 0
-		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), backward_on_this_thread():
 			[o.zero_grad() for o in self.optims]
 			for _ in range(self.n_repeat):
 				for batch in self.train_loader:
@@ -216,7 +216,7 @@ class Trainer:
 		self.last_mode = 'graph' if gs is not None else 'eager'
 		captures0 = self._captures()
 		stream = self._step_stream()
-		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), backward_on_this_thread():
 			for batch in self.val_loader:
 				if gs is not None:
 					loss, loss_dict = gs(batch_to_device(batch, self.device), epoch)
