@@ -53,6 +53,7 @@ PROTOTYPES = {
 	'find_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
 	'find_ctx_destroy': (c_int, [_P]),
 	'find_debug_stream_groups': (c_int, [_P, _P, _P]),
+	'find_ctx_stream_beside': (c_int, [_P, _P, _P, c_int32, c_int32, _P]),
 	'find_ctx_set': (c_int, [_P, c_char_p, _I]),
 	'find_ctx_get': (c_int, [_P, c_char_p, POINTER(c_int64)]),
 	'find_ctx_join': (c_int, [_P, _P]),

@@ -1551,6 +1551,28 @@ extern "C" int find_debug_stream_groups(find_ctx* c, void* caller_stream, int32_
 	return FIND_OK;
 }
 
+namespace find { namespace mlp { static int bind_side_streams(find_ctx* c, hipStream_t caller); } }
+
+// A caller's second stream that fits the context's layout: the first of `cands` that runs BESIDE caller_stream and shares the hardware queue
+// of side stream `role` (0 = Q: the large head layers' weight gradients -- busy only during the main pass's backward).  With four hardware
+// queues a fifth stream always shares one; which one decides what its work waits behind (find_hip.h).  *index = -1: none of them does.
+extern "C" int find_ctx_stream_beside(find_ctx* c, void* caller_stream, void* const* cands, int32_t n, int32_t role, int32_t* index) {
+	FIND_TRY(check_ctx(c, "find_ctx_stream_beside"));
+	FIND_REQUIRE(cands != nullptr && index != nullptr && n >= 0 && role >= 0 && role < N_SIDE, "find_ctx_stream_beside: bad arguments (role 0..%d)", N_SIDE - 1);
+	hipStream_t caller = reinterpret_cast<hipStream_t>(caller_stream);
+	if (!c->side_bound && c->bind_streams) (void)find::mlp::bind_side_streams(c, caller);
+	*index = -1;
+	for (int i = 0; i < n; ++i) {
+		hipStream_t s = reinterpret_cast<hipStream_t>(cands[i]);
+		bool beside_caller = false, beside_role = true;
+		FIND_TRY(runs_beside(caller, s, c->ev[0], c->ev[1], &beside_caller));
+		if (!beside_caller) continue;
+		FIND_TRY(runs_beside(c->side[role], s, c->ev[0], c->ev[1], &beside_role));
+		if (!beside_role) { *index = i; break; }
+	}
+	return FIND_OK;
+}
+
 // The layout the step was tuned with (and gets in a process that creates nothing else first): the large weight gradients (Q) and the two
 // small-launch streams (T1, T2) each on a queue of their own, none of them the caller's, and the slab reduces (R) behind T2's queue.
 // After torch.distributed has created RCCL's streams the same four hipStreamCreate calls put R on the CALLER's queue -- the reduces then

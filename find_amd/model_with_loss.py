@@ -52,35 +52,37 @@ _SECOND_STREAMS = {}
 
 
 def _second_stream(device):
-	"""A stream whose launches really run beside the current stream's.  HIP multiplexes streams onto a few hardware queues (four by
-	default; raising GPU_MAX_HW_QUEUES makes every step here SLOWER, bench.py 3.25 -> 4.6 ms: the sharing is part of how the MLP's side
-	streams are laid out), and two streams on one queue run in order -- which queue a new stream lands on depends on what else the
-	process has created (inside bench.py's full run the first candidate shared the main stream's queue and the overlap was lost).  So:
-	try a few streams once, with a spinning kernel on the current stream, and keep the first whose work finishes while that one spins."""
+	"""A stream whose launches really run beside the current stream's -- and wait behind as little as possible.  HIP multiplexes streams
+	onto a few hardware queues (four by default; raising GPU_MAX_HW_QUEUES makes every step here SLOWER, bench.py 3.25 -> 4.6 ms: the
+	sharing is part of how the MLP's side streams are laid out), and two streams on one queue run in order -- which queue a new stream
+	lands on depends on what else the process has created.  The MLP context's three side streams hold the other three queues, so this
+	stream shares one of them: find_ctx_stream_beside picks, among a dozen candidates, one on the queue of the context's Q stream (the
+	large head layers' weight gradients: idle until the main pass's backward).  On T1's queue -- where the first candidate that "ran
+	beside the caller" used to land -- the Chamfer backward waited ~0.2 ms behind the texture pass's weight gradients: headline step
+	2.05 -> 1.98 ms.  FIND_SECOND_STREAM_ROLE = 0..3 (Q, T1, T2, R) for experiments, -1 = the old rule (first stream beside the caller)."""
 	s = _SECOND_STREAMS.get(device)
 	if s is not None:
 		return s
+	import ctypes
+	from . import _lib
 	main = torch.cuda.current_stream(device)
-	probe = torch.zeros(64, device=device)
-	cands = [torch.cuda.Stream(device=device) for _ in range(6)]
-	pick = cands[0]
-	try:
-		for c in cands:
-			torch.cuda.synchronize(device)
-			spun, done = torch.cuda.Event(), torch.cuda.Event()
-			torch.cuda._sleep(4_000_000)   # ~2 ms on the current stream
-			spun.record(main)
-			with torch.cuda.stream(c):
-				probe.add_(1.0)
-				done.record(c)
-			done.synchronize()
-			beside = not spun.query()
-			torch.cuda.synchronize(device)
-			if beside:
-				pick = c
-				break
-	except (RuntimeError, AttributeError):   # (no spin kernel in this build of torch: any stream will do, the overlap may be lost)
-		pass
+	cands = [torch.cuda.Stream(device=device) for _ in range(12)]
+	role = int(os.environ.get('FIND_SECOND_STREAM_ROLE', '0'))
+	index = ctypes.c_int32(-1)
+	arr = (ctypes.c_void_p * len(cands))(*[c.cuda_stream for c in cands])
+	with torch.cuda.device(device):
+		torch.cuda.synchronize(device)
+		if role >= 0:
+			_lib.check(_lib.lib().find_ctx_stream_beside(_lib.ctx(), ctypes.c_void_p(main.cuda_stream), arr, len(cands), role, ctypes.byref(index)),
+					   'find_ctx_stream_beside')
+		if index.value < 0:   # (no candidate on that queue, or the old rule asked for: any stream that runs beside the caller's)
+			for r in (1, 2, 3, 0):
+				_lib.check(_lib.lib().find_ctx_stream_beside(_lib.ctx(), ctypes.c_void_p(main.cuda_stream), arr, len(cands), r, ctypes.byref(index)),
+						   'find_ctx_stream_beside')
+				if index.value >= 0:
+					break
+		torch.cuda.synchronize(device)
+	pick = cands[max(0, index.value)]
 	_SECOND_STREAMS[device] = pick
 	return pick
 

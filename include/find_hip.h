@@ -55,6 +55,13 @@ int find_ctx_destroy(find_ctx* ctx);
  * onto GPU_MAX_HW_QUEUES queues in creation order; two streams on one queue run in order).  groups[0] = 0 is the caller's stream,
  * groups[1 + k] side stream k; equal numbers = same queue.  Synchronises the streams it probes (~0.3 ms per probe). */
 int find_debug_stream_groups(find_ctx* ctx, void* caller_stream, int32_t* groups /* [5] */);
+/* A second stream for the CALLER's own concurrent work (find_amd.model_with_loss: the Chamfer term beside the texture term's MLP pass, the
+ * GT render beside the predicted one) that fits the context's stream layout: *index = the first of the n candidate streams that runs beside
+ * `caller_stream` AND shares the hardware queue of side stream `role` (0 = Q, 1 = T1, 2 = T2, 3 = R), -1 if none does.  With four hardware
+ * queues a fifth stream always shares one with somebody, and its work runs in order behind whatever that stream was given first: on T1's
+ * queue the Chamfer backward waited ~0.2 ms behind the texture pass's weight gradients; Q is idle until the main pass's backward.
+ * Binds the side streams first if that has not happened yet; synchronises the streams it probes. */
+int find_ctx_stream_beside(find_ctx* ctx, void* caller_stream, void* const* candidates, int32_t n, int32_t role, int32_t* index);
 /* Knobs (see the list at find_ctx_set below); find_ctx_get reads the current value, plus the read-only
  * "num_cus", "lds_bytes", "device", "events_per_call_max" (largest event count one MLP call has used so far). */
 int find_ctx_set(find_ctx* ctx, const char* key, int64_t value);
