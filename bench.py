@@ -57,8 +57,8 @@ MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 # fp16-mode gemm5 (profiles/r01_traffic_pmc_summary.txt): 2 x 57.10 MB + 112.9 MB.
 GEMM_TRAFFIC_BYTES = 242.9e6
 GEMM5_TRAFFIC_BYTES = 227.1e6
-GEMM5_C5_TRAFFIC_BYTES = None   # (gemm5 at the C5 shape, 16 x 50 002 rows: profiles/r04_gemm5_c5_pmc_summary.txt)
-GEMM7_TRAFFIC_BYTES = None   # (bf16x3 gemm7: filled in from profiles/r04_gemm7_pmc_summary.txt)
+GEMM5_C5_TRAFFIC_BYTES = None   # (gemm5 at the C5 shape, 16 x 50 002 rows: no PMC pass taken; at the headline shape 1.005 x algorithmic, profiles/r01_traffic_pmc_summary.txt)
+GEMM7_TRAFFIC_BYTES = 222.8e6   # bf16x3 gemm7 at the headline shape: 2 x 56 265.5 KB (FETCH_SIZE, gfx950 correction) + 110 240 KB (WRITE_SIZE), profiles/r04_gemm7_pmc_summary.txt
 
 
 def dtype_label():
@@ -547,7 +547,8 @@ def time_small_pass(device, n_pts, shared, iters=40, warm=20):
 
 # Time per step of the kernels that take the most of it INSIDE the headline step (rocprofv3 --kernel-trace of `bench.py --headline-only`, steps cut at
 # the optimiser kernel: profiles/r04_headline_step_stats.csv; several streams run side by side there, so these sum to more than the step).
-IN_STEP_US = {'fused_chain_kernel<2>': None, 'dw6_kernel': None, 'gemm7_kernel<2>': None, 'fused_chain_kernel<1>': None, 'gemm7_kernel<1>': None}
+# time per step inside the headline step (profiles/r04_headline_step_stats.csv: us_per_step, all launches of the kernel in a step, side streams running)
+IN_STEP_US = {'fused_chain_kernel<2>': 417.8, 'dw6_kernel': 277.5, 'gemm7_kernel<2>': 232.6, 'fused_chain_kernel<1>': 217.7, 'gemm7_kernel<1>': 157.8}
 
 
 def dominant_roofline(device, fp16=False, n_verts=None):
