@@ -10,6 +10,7 @@
 #include "mlp_dw6.h"
 #include "mlp_gemm4.h"
 #include "mlp_fused.h"
+#include "mlp_fused6.h"
 
 namespace find {
 namespace mlp {
@@ -67,6 +68,13 @@ static int check_weights(const find_mlp_params* p) {
 }
 
 // Forward workspace.  With save=false the hidden activations ping-pong between two buffers per stage.
+// 16-k steps of the weight stream a chain of this model can need at most (forward: Fourier layer + trunk + both heads; backward: both
+// heads + the two-operand trunk-output product + trunk), and the bytes of its fragment-ordered planes (mlp_fused6.h)
+static int64_t chain_w6_bytes(const find_mlp_params* p) {
+	const int64_t steps = 2 * (KP0 / KC + 1) + 16 * (int64_t)(p->n_trunk + p->n_disp + p->n_col + 4);
+	return 8 * steps * F6_STEP_BYTES;
+}
+
 struct FwdWs {
 	float* w0p;   // (256, KP0) layer-0 weight in padded PE order
 	float* wd0;   // (256,256) main block of mlp_disp.0.weight
@@ -80,6 +88,7 @@ struct FwdWs {
 	float* zc;
 	float* hp;    // shared template: (V,256) product of the trunk output with a head's first-layer weight (no bias), reused per head
 	float* hp2;
+	void* w6;     // fused6_kernel: the chain's weights as fragment-ordered bf16 planes (chain_w6_bytes)
 	int64_t bytes;
 };
 
@@ -94,6 +103,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 	o->zc = c.take<float>(d.rows_h * 3);
 	o->hp = (d.shared && d.n_feet > 1) ? c.take<float>(d.V * W) : nullptr;
 	o->hp2 = (d.shared && d.n_feet > 1) ? c.take<float>(d.V * W) : nullptr;   // the colour head's copy: the heads run on two streams
+	o->w6 = c.take<char>(chain_w6_bytes(p));
 	float* pt[2] = {nullptr, nullptr};
 	float* pd[2] = {nullptr, nullptr};
 	float* pc[2] = {nullptr, nullptr};
@@ -117,7 +127,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -151,6 +161,7 @@ struct find_ctx {
 	                              // reproducers of the co-residence fault: 2 = dw4_wide_kernel (no LDS, 328 registers), 3 = dw2_repro_kernel (312 registers)
 	int group_spf = 0;            // grouped weight gradients: splits per foot (0 = cost model of group_geometry)
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
+	int fused6 = 1;               // knob: bf16x3 calls run their chains on fused6_kernel (0: the fp32-MFMA chain, as the other precisions)
 	// internal streams / events
 	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
 	bool side_bound = false;      // the side streams have been chosen against the hardware queue of a caller's stream (bind_side_streams)
@@ -481,17 +492,44 @@ struct Chain {
 	}
 };
 
-static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s) {
+static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s, void* w6 = nullptr, int64_t w6_bytes = 0) {
 	// more 32-row blocks than CUs: 64-row tiles (one round of workgroups instead of two, half the weight staging per MFMA)
 	const int nt = (cdiv(V, 32) * feet > c->num_cus && !(c->ablate & 128)) ? 2 : 1;
 	int lds = 0;
-	if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED2, &fused_chain_kernel<2>, fused_lds(2), &lds, false));
-	else FIND_TRY(prepare_kernel(c, K_FUSED, &fused_chain_kernel<1>, fused_lds(1), &lds, false));   // no LDS-DMA in this kernel: no reservation
 	ch.a.V = (int)V;
 	ch.a.tiles_per_foot = (int)cdiv(V, 32 * nt);
 	ch.a.ntiles = (int)(ch.a.tiles_per_foot * feet);
 	ch.a.ablate = c->ablate;
 	const int grid = std::min(ch.a.ntiles, c->num_cus);
+	if (c->x3 && c->fused6 && w6 != nullptr) {
+		// bf16x3: the chain's weights as fragment-ordered bf16 planes (one small launch), then the chain on the bf16 matrix pipe
+		SplitWArgs sa;
+		memset(&sa, 0, sizeof(sa));
+		int maxn = 0;
+		for (int i = 0; i < ch.a.n_steps; ++i) {
+			const FusedStep& st = ch.a.step[i];
+			if (st.kind != FS_GEMM) continue;
+			const int n = 2 * st.nchunk;
+			sa.job[sa.njobs++] = SplitWJob{st.w, st.ldw, n, sa.total};
+			sa.total += n;
+			maxn = std::max(maxn, n);
+		}
+		if (sa.njobs > 0 && 8 * (int64_t)sa.total * F6_STEP_BYTES <= w6_bytes) {
+			sa.dst = reinterpret_cast<u32x4*>(w6);
+			hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(8 * maxn * 64, 256), (unsigned)sa.njobs), dim3(256), 0, s, sa);
+			FIND_LAUNCH_CHECK("split_w_kernel");
+			ch.a.w6 = w6;
+			ch.a.total_steps = sa.total;
+			if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED6_2, &fused6_kernel<2>, fused6_lds(2), &lds, false));
+			else FIND_TRY(prepare_kernel(c, K_FUSED6, &fused6_kernel<1>, fused6_lds(1), &lds, false));
+			if (nt == 2) hipLaunchKernelGGL(fused6_kernel<2>, dim3(ch.a.ntiles), dim3(FUSED_NW * 64), lds, s, ch.a);   // (one tile per workgroup)
+			else hipLaunchKernelGGL(fused6_kernel<1>, dim3(ch.a.ntiles), dim3(FUSED_NW * 64), lds, s, ch.a);
+			FIND_LAUNCH_CHECK("fused6_kernel");
+			return FIND_OK;
+		}
+	}
+	if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED2, &fused_chain_kernel<2>, fused_lds(2), &lds, false));
+	else FIND_TRY(prepare_kernel(c, K_FUSED, &fused_chain_kernel<1>, fused_lds(1), &lds, false));   // no LDS-DMA in this kernel: no reservation
 	if (nt == 2) hipLaunchKernelGGL(fused_chain_kernel<2>, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
 	else hipLaunchKernelGGL(fused_chain_kernel<1>, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
 	FIND_LAUNCH_CHECK("fused_chain_kernel");
@@ -599,7 +637,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			if (disp) head(0, w.D, p->n_disp, w.wd0, bias_d0, bstride_d, p->disp_w, p->disp_b, w.zd, disp, false);
 			if (col) head(1, w.C, p->n_col, w.wc0, bias_c0, bstride_c, p->col_w, p->col_b, w.zc, col, disp != nullptr);
 		}
-		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, w.w6, chain_w6_bytes(p)));
 		if (fused_heads) return FIND_OK;
 	} else {
 		GemmArgs a = gemm_args_zero();
@@ -762,6 +800,7 @@ struct BwdWs {
 	float* grp_pw;   // small calls: slabs of the grouped weight-gradient launch, [job][slab][256][256], then the bias rows [job][slab][256]
 	int64_t grp_slabs;  // slabs per job
 	int grp_jobs;
+	void* w6;        // fused6_kernel: the dX chain's weights as fragment-ordered bf16 planes
 	int64_t bytes;
 };
 
@@ -803,6 +842,7 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	// (also without a shared template: the latents-only backward of a frozen network takes its per-foot column sums this way)
 	o->pS = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
 	o->pS2 = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
+	o->w6 = c.take<char>(chain_w6_bytes(p));
 	o->grp_pw = nullptr; o->grp_slabs = 0; o->grp_jobs = 0;
 	if (cdiv(d.V, 32) * d.feet_t <= GROUP_MAX_UNITS) {
 		// (a shared trunk groups its own layers only: the heads' layers there have n_feet times the rows and keep their own launches)
@@ -1129,7 +1169,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			};
 			if (want_c) head_chain(p->n_col, w.C, b.dzC, b.Ct, cc);
 			if (want_d) head_chain(p->n_disp, w.D, b.dzD, b.Dt, cd);
-			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		} else {
 			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzD[cd], b.Dt[l], w.D[l - 1], b.dzD[cd + 1], V, n_feet, s)); cd += 1; }
 			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzC[cc], b.Ct[l], w.C[l - 1], b.dzC[cc + 1], V, n_feet, s)); cc += 1; }
@@ -1181,7 +1221,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[ct2 + 1]; st.to_lds = 1;
 			ct2 += 1;
 		}
-		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		// weight gradients: all inputs exist now.  fp32: every 256 x 256 layer in ONE grouped launch (+ one grouped slab reduce) on a side
 		// stream, the Fourier layer on another; the opt-in fp16 mode keeps its per-layer dw3 launches.
 		const bool grouped = !c->f16 && b.grp_pw != nullptr;
@@ -1328,7 +1368,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			FusedStep& st = ch.gemm(b.Tt[l], W, W / KC);
 			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[p->n_trunk - l]; st.to_lds = 1;
 		}
-		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s));
+		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		// the trunk's weight gradients: all their inputs exist now -- one grouped launch + one grouped reduce (fp32), as in the small-call path
 		const bool grouped = !c->f16 && b.grp_pw != nullptr;
 		WgradGroup G;
@@ -1677,7 +1717,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"gemm7", &find_ctx::gemm7, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"gemm7", &find_ctx::gemm7, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };
 }  // namespace
 

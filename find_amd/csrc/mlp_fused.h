@@ -66,6 +66,8 @@ struct FusedArgs {
 	int tiles_per_foot;
 	int ntiles;
 	int ablate;               // profiling only: 1 no W staging (loads + LDS stores), 2 no MFMAs, 4 no epilogue, 8 no Fourier features
+	const void* w6;           // fused6_kernel (mlp_fused6.h): the chain's weights as fragment-ordered bf16 planes, [8 waves][total_steps][3][64] x 16 B
+	int total_steps;          //   16-k steps of all GEMM steps of the chain
 };
 
 constexpr int FX_LD = 260;                       // X row stride (floats)

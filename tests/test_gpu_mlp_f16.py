@@ -63,7 +63,9 @@ def test_linear_relu_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 	assert 1e-4 < np.abs(got - full).max() < 5e-2
 
 
-def _run_model(n_feet, n_verts, shared):
+def _run_model(n_feet, n_verts, shared, backward_precision=None):
+	"""backward_precision: run the BACKWARD of every MLP call in this arithmetic whatever the forward ran in (the precision code saved on the
+	autograd node is replaced): same saved activations, hence the same ReLU masks, on both sides of a comparison."""
 	from find_amd import synthetic
 	dev = torch.device('cuda:0')
 	model = synthetic.make_model(n_verts if shared else 1002, train_size=n_feet, val_size=1, device=dev)   # (free points need no template of their size)
@@ -80,6 +82,19 @@ def _run_model(n_feet, n_verts, shared):
 		res = model(pos, shapevec=lv['shapevec'], texvec=lv['texvec'], posevec=lv['posevec'])
 		out = torch.cat([res['disp'], res['col']], -1)
 	wgt = torch.linspace(0.5, 1.5, out.numel(), device=dev).reshape(out.shape)
+	if backward_precision is not None:
+		from find_amd import functional as FF
+		code, seen, todo, hit = FF._PRECISION_CODE[backward_precision], set(), [out.grad_fn], 0
+		while todo:
+			fn = todo.pop()
+			if fn is None or fn in seen:
+				continue
+			seen.add(fn)
+			if hasattr(fn, 'precision'):
+				fn.precision = code
+				hit += 1
+			todo.extend(f for f, _ in fn.next_functions)
+		assert hit >= 1
 	(out * wgt).sum().backward()
 	torch.cuda.synchronize()
 	grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
