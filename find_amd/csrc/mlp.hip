@@ -480,6 +480,9 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 // ---- fused chains (mlp_fused.h): one launch takes every 32-row tile through a list of layers
 struct Chain {
 	FusedArgs a;
+	int nt = 1;             // 32-row blocks per tile (chain_prepare)
+	bool x3 = false;        // runs on fused6_kernel: its weights have been split (chain_prepare)
+	bool prepared = false;
 	Chain() { memset(&a, 0, sizeof(a)); }
 	FusedStep& add() { return a.step[a.n_steps++]; }
 	bool full(int more) const { return a.n_steps + more > FUSED_MAX_STEPS; }
@@ -492,15 +495,19 @@ struct Chain {
 	}
 };
 
-static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s, void* w6 = nullptr, int64_t w6_bytes = 0) {
+// A chain runs in two halves: chain_prepare fixes the tile geometry and -- bf16x3 -- launches split_w_kernel (it needs the weights only, so a
+// caller may issue it long before the chain's inputs exist: the shared trunk's backward chain does, right behind the transposes, instead of
+// between the large weight-gradient kernels, where this 5-us launch waited 90 us for a free CU on the step's critical path); chain_launch
+// starts the chain itself.
+static int chain_prepare(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s, void* w6, int64_t w6_bytes) {
 	// more 32-row blocks than CUs: 64-row tiles (one round of workgroups instead of two, half the weight staging per MFMA)
-	const int nt = (cdiv(V, 32) * feet > c->num_cus && !(c->ablate & 128)) ? 2 : 1;
-	int lds = 0;
+	ch.nt = (cdiv(V, 32) * feet > c->num_cus && !(c->ablate & 128)) ? 2 : 1;
 	ch.a.V = (int)V;
-	ch.a.tiles_per_foot = (int)cdiv(V, 32 * nt);
+	ch.a.tiles_per_foot = (int)cdiv(V, 32 * ch.nt);
 	ch.a.ntiles = (int)(ch.a.tiles_per_foot * feet);
 	ch.a.ablate = c->ablate;
-	const int grid = std::min(ch.a.ntiles, c->num_cus);
+	ch.x3 = false;
+	ch.prepared = true;
 	if (c->x3 && c->fused6 && w6 != nullptr) {
 		// bf16x3: the chain's weights as fragment-ordered bf16 planes (one small launch), then the chain on the bf16 matrix pipe
 		SplitWArgs sa;
@@ -520,20 +527,35 @@ static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStre
 			FIND_LAUNCH_CHECK("split_w_kernel");
 			ch.a.w6 = w6;
 			ch.a.total_steps = sa.total;
-			if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED6_2, &fused6_kernel<2>, fused6_lds(2), &lds, false));
-			else FIND_TRY(prepare_kernel(c, K_FUSED6, &fused6_kernel<1>, fused6_lds(1), &lds, false));
-			if (nt == 2) hipLaunchKernelGGL(fused6_kernel<2>, dim3(ch.a.ntiles), dim3(FUSED_NW * 64), lds, s, ch.a);   // (one tile per workgroup)
-			else hipLaunchKernelGGL(fused6_kernel<1>, dim3(ch.a.ntiles), dim3(FUSED_NW * 64), lds, s, ch.a);
-			FIND_LAUNCH_CHECK("fused6_kernel");
-			return FIND_OK;
+			ch.x3 = true;
 		}
 	}
+	return FIND_OK;
+}
+
+static int chain_launch(find_ctx* c, Chain& ch, hipStream_t s) {
+	const int nt = ch.nt;
+	int lds = 0;
+	if (ch.x3) {
+		if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED6_2, &fused6_kernel<2>, fused6_lds(2), &lds, false));
+		else FIND_TRY(prepare_kernel(c, K_FUSED6, &fused6_kernel<1>, fused6_lds(1), &lds, false));
+		if (nt == 2) hipLaunchKernelGGL(fused6_kernel<2>, dim3(ch.a.ntiles), dim3(FUSED_NW * 64), lds, s, ch.a);   // (one tile per workgroup)
+		else hipLaunchKernelGGL(fused6_kernel<1>, dim3(ch.a.ntiles), dim3(FUSED_NW * 64), lds, s, ch.a);
+		FIND_LAUNCH_CHECK("fused6_kernel");
+		return FIND_OK;
+	}
+	const int grid = std::min(ch.a.ntiles, c->num_cus);
 	if (nt == 2) FIND_TRY(prepare_kernel(c, K_FUSED2, &fused_chain_kernel<2>, fused_lds(2), &lds, false));
 	else FIND_TRY(prepare_kernel(c, K_FUSED, &fused_chain_kernel<1>, fused_lds(1), &lds, false));   // no LDS-DMA in this kernel: no reservation
 	if (nt == 2) hipLaunchKernelGGL(fused_chain_kernel<2>, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
 	else hipLaunchKernelGGL(fused_chain_kernel<1>, dim3(grid), dim3(FUSED_NW * 64), lds, s, ch.a);
 	FIND_LAUNCH_CHECK("fused_chain_kernel");
 	return FIND_OK;
+}
+
+static int launch_chain(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStream_t s, void* w6 = nullptr, int64_t w6_bytes = 0) {
+	if (!ch.prepared) FIND_TRY(chain_prepare(c, ch, V, feet, s, w6, w6_bytes));
+	return chain_launch(c, ch, s);
 }
 
 static bool use_fused(const find_ctx* c, int64_t V, int64_t feet) {
@@ -1151,6 +1173,25 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 
 	const bool fused = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	// The trunk's dX chain of a call whose heads are large (the shared template of a batch: launched far below, behind the heads' GEMMs) is
+	// put together HERE, so that its weights are split (chain_prepare) before the large kernels fill the chip.
+	Chain tch;
+	if (fused && !frozen && d.shared) {
+		const float* Wt[2]; int nb = 0;
+		if (act_d) Wt[nb++] = b.Dt[0];
+		if (act_c) Wt[nb++] = b.Ct[0];
+		for (int i = 0; i < nb; ++i) {
+			FusedStep& st = tch.gemm(Wt[i], W, W / KC, hl /* patched below: the head's foot-summed first-layer dZ */);
+			st.accum = i > 0;
+			if (i + 1 < nb) { st.keep = 1; continue; }
+			st.mask = 1; st.aux = hl; st.dst = b.dzT[0]; st.to_lds = 1;
+		}
+		for (int l = p->n_trunk - 1; l >= 1; --l) {
+			FusedStep& st = tch.gemm(b.Tt[l], W, W / KC);
+			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[p->n_trunk - l]; st.to_lds = 1;
+		}
+		FIND_TRY(chain_prepare(c, tch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
+	}
 	if (frozen) {
 		// ---- latents only.  d loss / d latent[foot] = (sum_v dZ0[foot, v]) . W0[:, 256:]: the heads' dX chains down to their first layers,
 		// per-foot column sums, one small product per head.  Nothing reaches the trunk, no weight gradient is formed: at the reference's
@@ -1354,20 +1395,9 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	// dX chain.  With few trunk rows (the shared template) all of it is one fused launch; the weight gradients follow on T1 / T2.
 	int ct = 0;
 	if (fused) {
-		Chain ch;
-		const float* A[2]; const float* Wt[2]; int nb = 0;
-		if (act_d) { A[nb] = d.shared ? b.zsD : b.dzD[cd]; Wt[nb] = b.Dt[0]; ++nb; }
-		if (act_c) { A[nb] = d.shared ? b.zsC : b.dzC[cc]; Wt[nb] = b.Ct[0]; ++nb; }
-		for (int i = 0; i < nb; ++i) {
-			FusedStep& st = ch.gemm(Wt[i], W, W / KC, A[i]);
-			st.accum = i > 0;
-			if (i + 1 < nb) { st.keep = 1; continue; }
-			st.mask = 1; st.aux = hl; st.dst = b.dzT[0]; st.to_lds = 1;
-		}
-		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			FusedStep& st = ch.gemm(b.Tt[l], W, W / KC);
-			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[p->n_trunk - l]; st.to_lds = 1;
-		}
+		Chain& ch = tch;   // (built, and its weights split, right behind the transposes: see there)
+		for (int i = 0, k = 0; i < ch.a.n_steps && k < 2; ++i)   // the first steps read the heads' (foot-summed) first-layer dZ
+			if (ch.a.step[i].src_kind == FS_SRC_GLOBAL) { ch.a.step[i].src = (k == 0 && act_d) ? (d.shared ? b.zsD : b.dzD[cd]) : (d.shared ? b.zsC : b.dzC[cc]); ++k; }
 		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		// the trunk's weight gradients: all their inputs exist now -- one grouped launch + one grouped reduce (fp32), as in the small-call path
 		const bool grouped = !c->f16 && b.grp_pw != nullptr;
