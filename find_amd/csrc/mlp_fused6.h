@@ -19,6 +19,7 @@
 //     per layer); a step that reloads rows this workgroup stored itself (the colour head re-reading the trunk output) keeps the full one.
 // Fourier features, 256 -> 3 output steps (on the reconstructed fp32 tile: p1 + p2 + p3 is exact), two-operand sums, masks: as in mlp_fused.h.
 #pragma once
+#include "mlp_dwpe.h"
 #include "mlp_fused.h"
 #include "mlp_gemm6.h"
 
@@ -94,10 +95,14 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 		u32x4 r0a, r0b, r0c, r1a, r1b, r1c, r2a, r2b, r2c, r3a, r3b, r3c;
 #define F6_WLOAD(slot)                                                                          \
 		do {                                                                                    \
-			const u32x4* _p = wstream + (int64_t)min(t_pf, total - 1) * 192;                    \
-			slot##a = _p[0]; slot##b = _p[64]; slot##c = _p[128];                               \
+			if (!(g.ablate & 1) || t_pf < 4) {                                                  \
+				const u32x4* _p = wstream + (int64_t)min(t_pf, total - 1) * 192;                \
+				slot##a = _p[0]; slot##b = _p[64]; slot##c = _p[128];                           \
+			}                                                                                   \
 			++t_pf;                                                                             \
 		} while (0)
+		// (g.ablate -- profiling only, results are wrong under every bit: 1 no weight loads after the first four steps, 2 no MFMAs, 4 no epilogue,
+		// 8 no Fourier features; tools/fused_micro.py)
 		F6_WLOAD(r0); F6_WLOAD(r1); F6_WLOAD(r2); F6_WLOAD(r3);
 		__builtin_amdgcn_sched_barrier(0);
 
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 		struct { const float *w, *bias, *src, *aux; float *dst, *dst2; int nchunk, bias_foot_stride, kind, src_kind, relu, mask, keep, accum, to_lds, head; } s;
 		int si = 0, c = 0, nsteps = 0;
 		bool setup = true;
+
 		while (true) {
 			if (setup) {
 				bool done = false;
@@ -186,38 +192,41 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 				setup = false;
 			}
 
-			if (s.src_kind == FS_SRC_PE && (c & 15) == 0) {
+			if (s.src_kind == FS_SRC_PE && (c & 15) == 0 && !(g.ablate & 8)) {
 				// regenerate the tile with the Fourier features of k-tile c / 16; a thread fills 16 columns of one row
 				if (c > 0) lds_barrier();   // the previous k-tile has been consumed by every wave
-				const int seg = tid & 15;
+				// The padded order (mlp_kernels.h: pe_value) alternates 32-column chunks: sin of 32 features, cos of the SAME 32, ..., then
+				// [x y z 0 ...], zeros.  A thread takes 8 features of one (sin, cos) chunk pair: one argument and one branch-free evaluation
+				// (sincospi_poly: the device library's sinpif / cospif polynomials) give both values.
+				const int seg = tid & 15, m = seg >> 2, jf = (seg & 3) * 8;
 #pragma unroll
 				for (int rt = 0; rt < NT; ++rt) {
 					const int row = rt * 32 + (tid >> 4);
 					const float* pp = g.pos + (int64_t)foot * g.pos_foot_stride + (int64_t)(v0 + min(row, valid - 1)) * 3;
 					const float px = pp[0], py = pp[1], pz = pp[2];
-					// chunk cc of the padded order (mlp_kernels.h: pe_value): sin of 32 features, cos of the same 32, ..., [x y z 0 ...], zeros
-					const int cc = (c >> 4) * 8 + (seg >> 1), nsc = g.pe >> 4, j0 = (seg & 1) * 16;
-					const int off = row * F6_ROW + ((seg >> 1) * 32 + j0) * 2;
-					if (cc < nsc) {
-						const float* b0 = Bl + (cc >> 1) * 32 + j0;
-						const bool is_cos = cc & 1;
+					const int cs = (c >> 4) * 8 + 2 * m, nsc = g.pe >> 4;   // the pair's sin chunk (the cos chunk follows it); nsc sin / cos chunks in all
+					const int offs = row * F6_ROW + (2 * m * 32 + jf) * 2, offc = offs + 64;
+					if (cs < nsc) {
+						const float* b0 = Bl + (cs >> 1) * 32 + jf;
 #pragma unroll 1
-						for (int j = 0; j < 16; j += 4) {   // (four at a time: sixteen interleaved sinpif / cospif evaluations cost ~100 registers)
-							float xr[4];
+						for (int j = 0; j < 8; j += 4) {   // (four at a time: register pressure)
+							float sv[4], cv[4];
 #pragma unroll
 							for (int e = 0; e < 4; ++e) {
 								const float t = 2.0f * fmaf(pz, b0[2 * g.pe + j + e], fmaf(py, b0[g.pe + j + e], px * b0[j + e]));
-								xr[e] = is_cos ? cospif(t) : sinpif(t);
+								sincospi_poly(t, sv[e], cv[e]);
 							}
-							const Split2 q0 = split_pair(f32x2{xr[0], xr[1]}), q1 = split_pair(f32x2{xr[2], xr[3]});
-							F6_PUT4(off + j * 2, q0, q1);
+							const Split2 s0 = split_pair(f32x2{sv[0], sv[1]}), s1 = split_pair(f32x2{sv[2], sv[3]});
+							F6_PUT4(offs + j * 2, s0, s1);
+							const Split2 c0 = split_pair(f32x2{cv[0], cv[1]}), c1 = split_pair(f32x2{cv[2], cv[3]});
+							F6_PUT4(offc + j * 2, c0, c1);
 						}
 					} else {
-						const bool xyz = cc == nsc && j0 == 0;
+						const bool xyz = cs == nsc && jf == 0;
 						const Split2 q0 = split_pair(f32x2{xyz ? px : 0.f, xyz ? py : 0.f}), q1 = split_pair(f32x2{xyz ? pz : 0.f, 0.f});
 						const Split2 z = split_pair(f32x2{0.f, 0.f});
-						F6_PUT4(off, q0, q1);
-						F6_PUT4(off + 8, z, z); F6_PUT4(off + 16, z, z); F6_PUT4(off + 24, z, z);
+						F6_PUT4(offs, q0, q1); F6_PUT4(offs + 8, z, z);
+						F6_PUT4(offc, z, z); F6_PUT4(offc + 8, z, z);
 					}
 				}
 				lds_barrier();
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 				do {                                                                                                    \
 					const bf16x8 w1 = __builtin_bit_cast(bf16x8, slot##a), w2 = __builtin_bit_cast(bf16x8, slot##b),    \
 								 w3 = __builtin_bit_cast(bf16x8, slot##c);                                              \
+					if (g.ablate & 2) { acc[0][0] += __builtin_bit_cast(float, slot##a[0]) + __builtin_bit_cast(float, __builtin_bit_cast(u32x4, x1[buf][0])[0]); } else \
 					_Pragma("unroll") for (int rt = 0; rt < NT; ++rt) {                                                 \
 						acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1[buf][rt], acc[rt], 0, 0, 0);           \
 						acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2[buf][rt], acc[rt], 0, 0, 0);           \
@@ -273,13 +283,13 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 			if (c < nsteps) continue;
 
 			// ---- the step's last k-step is through
-			if (!s.keep) {
+			if (!s.keep && !(g.ablate & 4)) {
 				// epilogue: lane (row li of block rt, half lh) holds columns wave * 32 + 8 q + 4 lh .. + 3 in acc[rt][4 q .. 4 q + 3]
 				lds_barrier();   // every wave has multiplied its last step: nobody reads the tile any more
 				const int n0 = wave * 32 + 4 * lh;
 				// buffer loads / stores: the descriptor's size = the tile's valid bytes, so rows past the end of a foot are dropped by the bounds check
 				const int voff = (li * W + n0) * 4;
-				const float* bp = s.bias + (int64_t)foot * s.bias_foot_stride + n0;
+				const float* bp = s.bias + (int64_t)foot * s.bias_foot_stride + n0;   // (requested at the step's start instead: no gain, 16 registers)
 				const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr((s.mask ? s.aux : s.w) + row0 * W)), 0, s.mask ? valid * W * 4 : 0, 0x00020000);
 				const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr((s.dst ? s.dst : s.w) + row0 * W)), 0, s.dst ? valid * W * 4 : 0, 0x00020000);
 				// one 32-row block at a time

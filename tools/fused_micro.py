@@ -7,10 +7,17 @@ from find_amd import _lib, synthetic
 dev = torch.device('cuda:0')
 model = synthetic.make_model(6890, train_size=1, val_size=1, device=dev)
 lat = synthetic.latents(1, seed=0, device=dev)
+tex = len(sys.argv) > 1 and sys.argv[1] == 'tex'   # the texture pass's shape instead: 16 x 1000 per-foot points, colour head (64-row tiles)
+if tex:
+	model = synthetic.make_model(6890, train_size=16, val_size=1, device=dev)
+	lat = synthetic.latents(16, seed=0, device=dev)
+	pos = (torch.rand(16, 1000, 3, device=dev) * 0.2 - 0.1)
 def fwd():
 	with torch.no_grad():
+		if tex:
+			return model(pos, shapevec=lat['shapevec'], texvec=lat['texvec'], posevec=lat['posevec'], want=('col',))
 		return model.get_meshes(shapevec=lat['shapevec'], reg=lat['reg'], texvec=lat['texvec'], posevec=lat['posevec'])
-for ab in (0, 1, 2, 3, 4, 8, 15, 0):
+for ab in (0, 0, 1, 2, 3, 4, 8, 6, 14, 15, 0):
 	_lib.set_tuning('ablate', ab)
 	for _ in range(10): fwd()
 	torch.cuda.synchronize()
