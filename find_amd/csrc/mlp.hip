@@ -161,6 +161,7 @@ struct find_ctx {
 	                              // reproducers of the co-residence fault: 2 = dw4_wide_kernel (no LDS, 328 registers), 3 = dw2_repro_kernel (312 registers)
 	int group_spf = 0;            // grouped weight gradients: splits per foot (0 = cost model of group_geometry)
 	int fused_max_units = 512;    // chains of layers over at most this many 32-row tiles run as ONE fused_chain_kernel launch (0: never)
+	int dw6_wgs = 0;              // knob: workgroups (= slabs) of a dw6 launch; 0 = one per CU, half that beside the dX chain (weight_grad)
 	int fused6 = 1;               // knob: bf16x3 calls run their chains on fused6_kernel (0: the fp32-MFMA chain, as the other precisions)
 	// internal streams / events
 	hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
@@ -922,7 +923,11 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 		} else if (c->x3 && cdiv(V, 32) * feet >= c->gemm6_min_units) {
 			// bf16x3: 16-row chunks, rows past the end of a foot zero-filled by the kernel; few, long runs (slab traffic)
 			const int cpf16 = (int)cdiv(V, 16);
-			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
+			// Workgroups = slabs: one per CU when the launch has the chip to itself; HALF that inside a backward with side streams -- there it
+			// runs beside the dX GEMMs of the next layer, which take the other CUs anyway, and half the slabs are half the reduce's traffic
+			// (64 -> 32 MB per layer: headline step 1.76 -> 1.71 ms on one box; 96 and 64 workgroups are slower again)
+			const int wgs6 = c->dw6_wgs > 0 ? c->dw6_wgs : ((fk && fk->on) ? std::max(1, c->num_cus / 2) : c->num_cus);
+			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(wgs6, feet)));
 			const int cps6 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(c->dw2_min_cps, cpf16));
 			spf = (int)cdiv(cpf16, cps6);
 			nmain = (int)(feet * spf);
@@ -1747,7 +1752,7 @@ const Knob KNOBS[] = {
 	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"gemm7", &find_ctx::gemm7, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 4096}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"gemm7", &find_ctx::gemm7, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };
 }  // namespace
 

@@ -95,14 +95,12 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 		u32x4 r0a, r0b, r0c, r1a, r1b, r1c, r2a, r2b, r2c, r3a, r3b, r3c;
 #define F6_WLOAD(slot)                                                                          \
 		do {                                                                                    \
-			if (!(g.ablate & 1) || t_pf < 4) {                                                  \
-				const u32x4* _p = wstream + (int64_t)min(t_pf, total - 1) * 192;                \
-				slot##a = _p[0]; slot##b = _p[64]; slot##c = _p[128];                           \
-			}                                                                                   \
+			const u32x4* _p = wstream + (int64_t)min(t_pf, total - 1) * 192;                    \
+			slot##a = _p[0]; slot##b = _p[64]; slot##c = _p[128];                               \
 			++t_pf;                                                                             \
 		} while (0)
-		// (g.ablate -- profiling only, results are wrong under every bit: 1 no weight loads after the first four steps, 2 no MFMAs, 4 no epilogue,
-		// 8 no Fourier features; tools/fused_micro.py)
+		// (g.ablate -- profiling only, results are wrong under either bit: 4 no epilogue, 8 no Fourier features; tools/fused_micro.py.  Bits inside
+		// the k-step loop -- no weight loads, no MFMAs -- were taken out again: their tests alone cost the step 2.5 %)
 		F6_WLOAD(r0); F6_WLOAD(r1); F6_WLOAD(r2); F6_WLOAD(r3);
 		__builtin_amdgcn_sched_barrier(0);
 
@@ -248,7 +246,6 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 				do {                                                                                                    \
 					const bf16x8 w1 = __builtin_bit_cast(bf16x8, slot##a), w2 = __builtin_bit_cast(bf16x8, slot##b),    \
 								 w3 = __builtin_bit_cast(bf16x8, slot##c);                                              \
-					if (g.ablate & 2) { acc[0][0] += __builtin_bit_cast(float, slot##a[0]) + __builtin_bit_cast(float, __builtin_bit_cast(u32x4, x1[buf][0])[0]); } else \
 					_Pragma("unroll") for (int rt = 0; rt < NT; ++rt) {                                                 \
 						acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1[buf][rt], acc[rt], 0, 0, 0);           \
 						acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2[buf][rt], acc[rt], 0, 0, 0);           \
