@@ -548,7 +548,7 @@ def time_small_pass(device, n_pts, shared, iters=40, warm=20):
 # Time per step of the kernels that take the most of it INSIDE the headline step (rocprofv3 --kernel-trace of `bench.py --headline-only`, steps cut at
 # the optimiser kernel: profiles/r04_headline_step_stats.csv; several streams run side by side there, so these sum to more than the step).
 # time per step inside the headline step (profiles/r04_headline_step_stats.csv: us_per_step, all launches of the kernel in a step, side streams running)
-IN_STEP_US = {'fused_chain_kernel<2>': 417.8, 'dw6_kernel': 277.5, 'gemm7_kernel<2>': 232.6, 'fused_chain_kernel<1>': 217.7, 'gemm7_kernel<1>': 157.8}
+IN_STEP_US = {'fused6_kernel<2>': 221.2, 'dw6_kernel': 362.0, 'gemm7_kernel<2>': 225.8, 'fused6_kernel<1>': 129.0, 'gemm7_kernel<1>': 153.1, 'dwpe_kernel': 228.1, 'dw4_group_kernel': 219.0}
 
 
 def dominant_roofline(device, fp16=False, n_verts=None):
@@ -607,15 +607,20 @@ def roofline_kernels(device, lin_ms):
 	entry('gemm7_kernel<1>' if x3 else 'gemm4_kernel<1,4,8>', f'Linear 256->256 + bias + ReLU over {rows} rows (forward; 2 launches per step)', L, lin_ms * 1e3, mul, 'gemm7_kernel<1>')
 	wg_ms = time_wgrad_kernel(device)
 	entry(('dw6_kernel' if x3 else 'dw4_kernel') + ' + reduce_w_kernel', f'dW = dZ^T X over {rows} rows + its slab reduce (2 launches per step)', L, wg_ms * 1e3, mul, 'dw6_kernel')
-	# the small calls run whole layer chains per launch on the fp32 MFMA pipe: time the call (fused chain + the handful of small launches around it)
+	# the small calls run whole layer chains per launch (bf16x3: fused6_kernel on the bf16 pipe; fp32: fused_chain_kernel): time the call (the chain
+	# + the handful of small launches around it: repack, latent bias, weight split, head output)
 	r = N_FEET * 1000
 	Lm = 65536.0
 	tex_fwd = 2.0 * r * (515 * 256 + 4 * Lm + Lm + 2 * Lm + 3 * 256)
 	tex_bwd = 2.0 * r * (2 * 3 * 256 + 4 * Lm + Lm + Lm + 8 * Lm + 515 * 256)
 	f_ms, fb_ms = time_small_pass(device, 1000, shared=False)
-	entry('fused_chain_kernel<2> (forward call)', f'texture pass forward: {N_FEET} x 1000 per-foot points, Fourier layer + trunk + colour head in one launch', tex_fwd, f_ms * 1e3, 1.0, 'fused_chain_kernel<2>')
-	entry('fused_chain_kernel<2> + dw4_group + dwpe (backward call)', 'texture pass backward: dX chain in one launch, eleven weight gradients as one grouped launch, the Fourier layer\'s beside them',
-		  tex_bwd, (fb_ms - f_ms) * 1e3, 1.0, 'fused_chain_kernel<2>')
+	chain = 'fused6_kernel<2>' if x3 else 'fused_chain_kernel<2>'
+	entry(chain + ' (forward call)', f'texture pass forward: {N_FEET} x 1000 per-foot points, Fourier layer + trunk + colour head in one launch (+ repack, latent bias, '
+		  'weight split, 3-wide output around it)', tex_fwd, f_ms * 1e3, mul, chain)
+	# the backward call mixes pipes under bf16x3 (dX chain: bf16x3; the grouped weight gradients dw4_group and the Fourier layer's dwpe: fp32 MFMA): priced
+	# against the fp32 MFMA peak in the layer's own flop count
+	entry(chain + ' + dw4_group + dwpe (backward call)', 'texture pass backward: dX chain in one launch' + (' (bf16x3)' if x3 else '') + ', seven weight gradients as one grouped '
+		  'launch and the Fourier layer\'s beside them (fp32 MFMA); frac = fp32-equivalent flops against the fp32 MFMA peak', tex_bwd, (fb_ms - f_ms) * 1e3, 1.0, chain)
 	return out
 
 
