@@ -105,7 +105,9 @@ typedef struct find_mlp_params {
 	                       *       on the bf16 matrix pipe, fp32 accumulation -- what is left out is <= 2^-26 of a product (a quarter of one fp32
 	                       *       rounding), so results are as close to the float64 product as mode 1's (tests/test_gpu_mlp_bf16x3.py) at
 	                       *       6/16 of its matrix-pipe time; the default of the Python surface (find_amd.functional.set_mlp_precision).
-	                       *       Large launches only (>= "gemm6_min_units" 32-row units); smaller ones run mode 1's kernels */
+	                       *       Launches of >= "gemm6_min_units" 32-row units (gemm7_kernel / dw6_kernel) and the fused layer chains of small calls
+	                       *       (fused6_kernel); what lies in between, the grouped weight gradients of small calls and the Fourier layer's run
+	                       *       mode 1's kernels */
 } find_mlp_params;
 
 /* Gradient outputs, same shapes as the corresponding weights; every buffer given is OVERWRITTEN.
@@ -194,6 +196,10 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
  *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped
  *                     launch + one grouped reduce; 0 = one launch per layer at every size
+ *   "fused6"          bf16x3 calls run their chains on fused6_kernel (weights pre-split by split_w_kernel into the call's workspace; default 1);
+ *                     0 = fused_chain_kernel (fp32 MFMA), as the other precisions
+ *   "dw6_wgs"         workgroups (= 256 x 256 slabs) of a dw6_kernel launch: 0 (default) = one per CU, half that inside a backward whose side
+ *                     streams are on (it runs beside the next layer's dX GEMM; half the slabs are half the reduce's traffic)
  *   "dw_lds_free"     kernel of the 256 x 256 weight gradients: 1 = dw4_kernel (operands straight from global memory, no LDS, <= 256
  *                     registers; default), 0 = dw2_kernel (LDS-DMA ring, the whole register file of its SIMDs claimed).  2 / 3 =
  *                     dw4_wide_kernel / dw2_repro_kernel: waves of 328 / 312 registers, the reproducers of the co-residence fault
