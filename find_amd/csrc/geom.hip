@@ -193,11 +193,24 @@ __global__ __launch_bounds__(1024) void masked_mse_fwd_kernel(const float* __res
 															   float* __restrict__ loss) {
 	__shared__ float red[16];
 	float s = 0.f;
-	for (int64_t i = threadIdx.x; i < n_pts; i += 1024) {
-		const float t0 = target[i * 3], t1 = target[i * 3 + 1], t2 = target[i * 3 + 2];
-		if (t0 < 1.f || t1 < 1.f || t2 < 1.f) {
-			const float a = pred[i * 3] - t0, b = pred[i * 3 + 1] - t1, c = pred[i * 3 + 2] - t2;
-			s += a * a + b * b + c * c;
+	// eight points per thread in flight (the loop as written first -- load, test, add, next -- paid a memory round trip per point: 14.6 us for the
+	// texture pass's 16 000 points, on the step's critical path between the forward and the backward); the order of the additions is unchanged
+	constexpr int U = 8;
+	for (int64_t i0 = threadIdx.x; i0 < n_pts; i0 += 1024 * U) {
+		float t[U][3], q[U][3];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t i = i0 + (int64_t)u * 1024;
+			const bool in = i < n_pts;
+#pragma unroll
+			for (int c = 0; c < 3; ++c) { t[u][c] = in ? target[i * 3 + c] : 1.f; q[u][c] = in ? pred[i * 3 + c] : 1.f; }
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			if (i0 + (int64_t)u * 1024 < n_pts && (t[u][0] < 1.f || t[u][1] < 1.f || t[u][2] < 1.f)) {
+				const float a = q[u][0] - t[u][0], b = q[u][1] - t[u][1], c = q[u][2] - t[u][2];
+				s += a * a + b * b + c * c;
+			}
 		}
 	}
 	s = wave_sum(s);
