@@ -409,7 +409,10 @@ def test_chamfer_through_the_grid_equals_brute_force_bit_for_bit():
 		(l0, gx0, gy0), (l1, gx1, gy1) = out
 		assert torch.equal(l0, l1), (name, l0.item(), l1.item())
 		# (a cloud's gradient holds a float-atomic scatter -- its role as the other direction's target --: sums of the same addends in
-		#  another order.  A different neighbour anywhere, also between duplicates, moves a whole addend to another row.)
-		assert (gx0 - gx1).abs().max().item() <= 1e-6 * max(gx1.abs().max().item(), 1e-12), name
-		assert (gy0 - gy1).abs().max().item() <= 1e-6 * max(gy1.abs().max().item(), 1e-12), name
+		#  another order.  A different neighbour anywhere, also between duplicates, moves a whole addend to another row.
+		#  The bound is that of a float sum in another order -- up to a few hundred addends with mixed signs land on one row in the
+		#  'one cell' and 'outliers' cases (2 500 queries scattered onto near-coincident targets): 3e-5 of the largest entry; at 1e-6 the
+		#  'one cell' case failed one run in five, between two runs of the SAME kernel -- while one misplaced addend is 1e-2 or more.)
+		assert (gx0 - gx1).abs().max().item() <= 3e-5 * max(gx1.abs().max().item(), 1e-12), name
+		assert (gy0 - gy1).abs().max().item() <= 3e-5 * max(gy1.abs().max().item(), 1e-12), name
 		assert torch.isfinite(l0).all()
