@@ -690,7 +690,10 @@ def c2_record(run, steps, warmup, n_verts=None, fp16=False, with_cpu=False, dp_o
 		model, params, step = build_step(run.dev, seed=run.rank, n_verts=n_verts)
 		bucket = None
 		if dp_overhead and run.world == 1:
-			torch.distributed.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1)
+			with socket.socket() as _s:   # (a free port, not a fixed one: TIME_WAIT of a run a minute ago)
+				_s.bind(('127.0.0.1', 0))
+				_port = _s.getsockname()[1]
+			torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_port}', rank=0, world_size=1)
 			bucket = fdist.GradBucket(params)
 		if run.world > 1:
 			fdist.broadcast_parameters([p for p in model.parameters() if p.is_floating_point()])

@@ -11,7 +11,11 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 run = bench.Run(1)
 mode = sys.argv[2] if len(sys.argv) > 2 else 'dp'
 if mode in ('dp', 'pg_only'):
-	torch.distributed.init_process_group('nccl', init_method='tcp://127.0.0.1:29534', rank=0, world_size=1)
+	import socket
+	with socket.socket() as _s:   # (a free port: a fixed one is still in TIME_WAIT when this tool runs twice within a minute -- the store then waits for its time-out)
+		_s.bind(('127.0.0.1', 0))
+		_port = _s.getsockname()[1]
+	torch.distributed.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_port}', rank=0, world_size=1)
 	t = torch.ones(4, device=run.dev)
 	torch.distributed.all_reduce(t)
 	torch.cuda.synchronize()
