@@ -615,11 +615,12 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const float* bias_d0 = p->disp_b[0];
 	const float* bias_c0 = p->col_b[0];
 	int64_t bstride_d = 0, bstride_c = 0;
-	if (p->lat_disp > 0) {
+	// (only for the heads this call evaluates: the template pass of a 3-D-loss step leaves the colour head out, the texture pass the other one)
+	if (p->lat_disp > 0 && disp != nullptr) {
 		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4, (unsigned)n_feet), dim3(256), 0, s, p->disp_w[0], ld_d0, p->disp_b[0], lat_disp, p->lat_disp, w.fbd);
 		bias_d0 = w.fbd; bstride_d = W;
 	}
-	if (p->lat_col > 0) {
+	if (p->lat_col > 0 && col != nullptr) {
 		hipLaunchKernelGGL(latent_bias_kernel, dim3(W / 4, (unsigned)n_feet), dim3(256), 0, s, p->col_w[0], ld_c0, p->col_b[0], lat_col, p->lat_col, w.fbc);
 		bias_c0 = w.fbc; bstride_c = W;
 	}
