@@ -548,7 +548,7 @@ def time_small_pass(device, n_pts, shared, iters=40, warm=20):
 # Time per step of the kernels that take the most of it INSIDE the headline step (rocprofv3 --kernel-trace of `bench.py --headline-only`, steps cut at
 # the optimiser kernel: profiles/r04_headline_step_stats.csv; several streams run side by side there, so these sum to more than the step).
 # time per step inside the headline step (profiles/r04_headline_step_stats.csv: us_per_step, all launches of the kernel in a step, side streams running)
-IN_STEP_US = {'fused6_kernel<2>': 221.3, 'dw6_kernel': 352.7, 'gemm7_kernel<2>': 219.3, 'fused6_kernel<1>': 127.4, 'gemm7_kernel<1>': 153.2, 'dwpe_kernel': 230.7, 'dw4_group_kernel': 220.9}
+IN_STEP_US = {'fused6_kernel<2>': 267.9, 'dw6_kernel': 364.4, 'gemm7_kernel<2>': 227.0, 'fused6_kernel<1>': 130.6, 'gemm7_kernel<1>': 155.5, 'dwpe_kernel': 209.9, 'dw4_group_kernel': 199.6}
 
 
 def dominant_roofline(device, fp16=False, n_verts=None):
