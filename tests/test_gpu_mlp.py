@@ -648,6 +648,38 @@ def test_side_streams_are_bound_to_queues_beside_the_callers():
 	del clutter
 
 
+def test_stream_beside_picks_a_stream_on_the_asked_hardware_queue():
+	"""find_ctx_stream_beside (what ModelWithLoss's second stream is chosen with): among a dozen candidate streams the one returned runs
+	beside the caller's stream and shares the hardware queue of the asked side stream -- checked against find_debug_stream_groups with the
+	candidate put in the caller's place --; bad arguments are refused; ModelWithLoss's own pick sits on Q's queue."""
+	import ctypes
+	from find_amd import _lib
+	from find_amd.model_with_loss import _second_stream
+	L = _lib.lib()
+	dev = torch.device('cuda', torch.cuda.current_device())
+	h = _lib.ctx(dev)
+	main = torch.cuda.current_stream(dev)
+	cands = [torch.cuda.Stream(device=dev) for _ in range(12)]
+	arr = (ctypes.c_void_p * len(cands))(*[c.cuda_stream for c in cands])
+	idx = ctypes.c_int32(-7)
+	for role in (0, 1, 2):
+		_lib.check(L.find_ctx_stream_beside(h, ctypes.c_void_p(main.cuda_stream), arr, len(cands), role, ctypes.byref(idx)), 'find_ctx_stream_beside')
+		assert 0 <= idx.value < len(cands), (role, idx.value)   # (twelve streams over four hardware queues: every queue is met)
+		g = (ctypes.c_int32 * 5)()
+		_lib.check(L.find_debug_stream_groups(h, ctypes.c_void_p(cands[idx.value].cuda_stream), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+		assert g[1 + role] == g[0], (role, list(g))                 # the candidate (group 0 here) shares side stream `role`'s queue
+		g2 = (ctypes.c_int32 * 5)()
+		_lib.check(L.find_debug_stream_groups(h, ctypes.c_void_p(main.cuda_stream), ctypes.cast(g2, ctypes.c_void_p)), 'find_debug_stream_groups')
+		assert g2[1 + role] != g2[0]                                 # ... which is not the caller's
+	assert L.find_ctx_stream_beside(h, ctypes.c_void_p(main.cuda_stream), arr, len(cands), 9, ctypes.byref(idx)) != 0
+	assert L.find_ctx_stream_beside(h, ctypes.c_void_p(main.cuda_stream), None, len(cands), 0, ctypes.byref(idx)) != 0
+	side = _second_stream(dev)
+	g = (ctypes.c_int32 * 5)()
+	_lib.check(L.find_debug_stream_groups(h, ctypes.c_void_p(side.cuda_stream), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+	assert g[1] == g[0], list(g)   # Q's queue
+	torch.cuda.synchronize()
+
+
 def test_unbound_side_streams_give_the_same_gradients():
 	"""The fall-back layout of the side streams -- `bind_streams` = 0: the four streams as HIP created them, some of them on the caller's
 	hardware queue (what the probe leaves when every candidate shares a queue) -- changes the schedule, never a number: a full-size

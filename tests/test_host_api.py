@@ -344,3 +344,23 @@ def test_split_is_exact_and_the_six_products_leave_out_less_than_one_rounding():
 	ok = exact.abs() > 1e-300
 	rel = ((six - exact).abs() / exact.abs().clamp(min=1e-300))[ok]
 	assert rel.max().item() < 2.0 ** -24, rel.max().item()
+
+
+def test_backward_on_this_thread_is_a_scoped_switch(monkeypatch):
+	"""train_utils.backward_on_this_thread: inside the context autograd runs backward passes on the calling thread (a hook sees the caller's
+	thread id), outside it the default is back; FIND_AUTOGRAD_THREADS=1 leaves torch's default alone."""
+	import threading
+	import torch
+	from find_amd.train_utils import backward_on_this_thread
+	assert torch.autograd.is_multithreading_enabled()
+	seen = []
+	x = torch.ones(3, requires_grad=True)
+	x.register_hook(lambda g: seen.append(threading.get_ident()))
+	with backward_on_this_thread():
+		assert not torch.autograd.is_multithreading_enabled()
+		(x * 2).sum().backward()
+	assert torch.autograd.is_multithreading_enabled()
+	assert seen == [threading.get_ident()]
+	monkeypatch.setenv('FIND_AUTOGRAD_THREADS', '1')
+	with backward_on_this_thread():
+		assert torch.autograd.is_multithreading_enabled()
