@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 #define FIND_DW6_WAIT(set, n) ((void)0)
 	auto comp = [](const u4& v, int e) -> float { return __uint_as_float(e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w))); };
 	// column 4 lane + e lands at column' = (4 lane + e) ^ (lane & 7)
-	const int wbase = sop * DW6_OPER + srg * 16;
+	// the 16-byte row half of a column is swapped with the other one where bit 4 of the column is set (tools/lds_b128_probe2.hip: with the
+	// halves in place the fragment reads cost 9.6 cycles and the writes 16, swapped 7.6 - 8.0 and 13.2; conflict-free reads are 7.2)
+	const int wbase_h = sop * DW6_OPER + (srg ^ ((lane >> 2) & 1)) * 16;   // column 4 lane + e: bit 4 = bit 2 of the lane
 	// one column (e) of the staged rows: split, write the three planes; the bias sums count a chunk once (keep = 0 for a repeated store)
 	auto store_part = [&](char* buf, const u4 (&st)[8], int e, float keep) {
 		u32x4 p1, p2, p3;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 			const Split2 s = split_pair(f32x2{comp(st[2 * jj], e), comp(st[2 * jj + 1], e)});
 			p1[jj] = s.p1; p2[jj] = s.p2; p3[jj] = s.p3;
 		}
-		char* dst = buf + wbase + (((c4 + e) ^ (lane & 7)) * 32);
+		char* dst = buf + wbase_h + (((c4 + e) ^ (lane & 7)) * 32);
 		*reinterpret_cast<u32x4*>(dst) = p1;
 		*reinterpret_cast<u32x4*>(dst + DW6_PLANE) = p2;
 		*reinterpret_cast<u32x4*>(dst + 2 * DW6_PLANE) = p3;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 		}
 	};
 	// fragment addresses: dZ column wn*128 + 32 ti + li, X column wk*128 + 32 tj + li; (column >> 2) & 7 == (li >> 2) & 7 for all of them
-	const int ci = (li ^ ((li >> 2) & 7)) * 32 + fh * 16;
+	const int ci = (li ^ ((li >> 2) & 7)) * 32 + (fh ^ ((li >> 4) & 1)) * 16;   // (column 32 t + li: bit 4 = bit 4 of li)
 	const int za = (wn * 128) * 32 + ci;
 	const int xa = DW6_OPER + (wk * 128) * 32 + ci;
 	auto frag = [&](const char* buf, int base, int t, int p) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(buf + base + p * DW6_PLANE + t * (32 * 32)); };
