@@ -532,23 +532,25 @@ def time_small_pass(device, n_pts, shared, iters=40, warm=20):
 		(res['col'] ** 2).sum().backward() if not shared else ((res['col'] ** 2).sum() + (res['disp'] ** 2).sum()).backward()
 
 	out = []
-	for fn in (fwd, fwdbwd):
-		for _ in range(warm):
-			fn()
-		e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-		e0.record(stream)
-		for _ in range(iters):
-			fn()
-		e1.record(stream)
-		e1.synchronize()
-		out.append(e0.elapsed_time(e1) / iters)
+	from find_amd.train_utils import backward_on_this_thread
+	with backward_on_this_thread():   # (as the step runs it: with autograd's worker thread this loop measures the host)
+		for fn in (fwd, fwdbwd):
+			for _ in range(warm):
+				fn()
+			e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+			e0.record(stream)
+			for _ in range(iters):
+				fn()
+			e1.record(stream)
+			e1.synchronize()
+			out.append(e0.elapsed_time(e1) / iters)
 	return out[0], out[1]
 
 
 # Time per step of the kernels that take the most of it INSIDE the headline step (rocprofv3 --kernel-trace of `bench.py --headline-only`, steps cut at
 # the optimiser kernel: profiles/r04_headline_step_stats.csv; several streams run side by side there, so these sum to more than the step).
 # time per step inside the headline step (profiles/r04_headline_step_stats.csv: us_per_step, all launches of the kernel in a step, side streams running)
-IN_STEP_US = {'fused6_kernel<2>': 267.9, 'dw6_kernel': 364.4, 'gemm7_kernel<2>': 227.0, 'fused6_kernel<1>': 130.6, 'gemm7_kernel<1>': 155.5, 'dwpe_kernel': 209.9, 'dw4_group_kernel': 199.6}
+IN_STEP_US = {'fused6_kernel<2>': 249.6, 'dw6_kernel': 351.4, 'gemm7_kernel<2>': 221.8, 'fused6_kernel<1>': 130.0, 'gemm7_kernel<1>': 155.3, 'dwpe_kernel': 215.2, 'dw4_group_kernel': 200.2}
 
 
 def dominant_roofline(device, fp16=False, n_verts=None):
