@@ -75,8 +75,23 @@ def _grads_like(tensors):
 			n += (tensors[i].numel() + 3) & ~3
 		flat = torch.empty(n, dtype=tensors[rest[0]].dtype, device=tensors[rest[0]].device)
 		for i, o in zip(rest, offs):
-			out[i] = flat[o:o + tensors[i].numel()].view(tensors[i].shape)
+			shape = tensors[i].shape
+			out[i] = flat.as_strided(shape, _contiguous_strides(shape), o)   # (one op per tensor: slice + view were two; ._base is `flat` either way)
 	return out
+
+
+_STRIDES = {}
+
+
+def _contiguous_strides(shape):
+	st = _STRIDES.get(shape)
+	if st is None:
+		acc, rev = 1, []
+		for d in reversed(shape):
+			rev.append(acc)
+			acc *= d
+		st = _STRIDES[shape] = tuple(reversed(rev))
+	return st
 
 
 # ----------------------------------------------------------------------------------------------- MLP

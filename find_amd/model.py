@@ -399,12 +399,21 @@ class NeuralDisplacementField(Model):
 		self.template_mesh = Meshes(verts=self.template_verts.data, faces=self.template_faces.data[0])
 
 	def _weights(self):
-		ws = []
-		for seq in (self.base, self.mlp_disp, self.mlp_col):
-			for layer in seq:
-				if isinstance(layer, nn.Linear):
-					ws += [layer.weight, layer.bias]
+		# (the Parameter objects, collected once: walking the three Sequentials cost 25 us per call -- twice per step at batch 1, where the
+		# step is bound by the host; .to() / load_state_dict keep the objects, _apply below drops the list anyway)
+		ws = self.__dict__.get('_wlist')
+		if ws is None:
+			ws = []
+			for seq in (self.base, self.mlp_disp, self.mlp_col):
+				for layer in seq:
+					if isinstance(layer, nn.Linear):
+						ws += [layer.weight, layer.bias]
+			self.__dict__['_wlist'] = ws
 		return ws
+
+	def _apply(self, fn, *args, **kwargs):
+		self.__dict__.pop('_wlist', None)
+		return super()._apply(fn, *args, **kwargs)
 
 	@staticmethod
 	def _cat_latents(*vecs):
