@@ -951,6 +951,9 @@ def mesh_smoothness_loss(verts, topo, w_edge=10.0, w_lap=0.1):
 _MLP_PRECISION = _os.environ.get('FIND_MLP_PRECISION', 'bf16x3')
 if _MLP_PRECISION not in ('fp32', 'fp16', 'bf16x3'):
 	raise ValueError(f"FIND_MLP_PRECISION: 'fp32', 'bf16x3' or 'fp16', got {_MLP_PRECISION!r}")
+# the isolated-kernel entry points (find_linear_*) read the CONTEXT's knob: every context is created with the process default (the
+# knob used to stay at fp32 until someone called set_mlp_precision, so get_mlp_precision() and those entry points could disagree)
+_lib._TUNING_DEFAULTS.setdefault('mlp_f16', {'fp32': 0, 'fp16': 1, 'bf16x3': 2}[_MLP_PRECISION])
 
 
 def set_mlp_precision(precision):

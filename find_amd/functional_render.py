@@ -67,14 +67,21 @@ _cap_used = set()
 def _check_captured():
 	"""Renders inside a captured step cannot hand their counters to a pinned slot per call; they ADD them to one static device slot
 	(part of the graph, so every replay adds), read back here -- one device-to-host copy, at an epoch boundary (Trainer._epoch_done) or
-	an explicit check_render_flags(wait=True)."""
+	an explicit check_render_flags(wait=True).  A device stays registered once a capture has used its slot (`_watch` runs only
+	while a stream CAPTURES, so a device taken off the list after the first check was never looked at again and the watchdog of the
+	Trainer's default mode ended with epoch 0).  The read and the reset are ordered against whatever stream replays the graphs by
+	synchronising the device on both sides -- once per epoch."""
+	bad = None
 	for dev in list(_cap_used):
 		t = _cap_flags[dev]
+		torch.cuda.synchronize(dev)
 		vals = t.tolist()
-		_cap_used.discard(dev)
 		if vals[0] > 0 or vals[1] > 0:
 			t.zero_()
-			_report(vals, 'renders replayed from a HIP graph since the last check', 'warn' if FLAG_POLICY == 'warn' else 'strict')
+			torch.cuda.synchronize(dev)
+			bad = bad or vals
+	if bad is not None:
+		_report(bad, 'renders replayed from a HIP graph since the last check', 'warn' if FLAG_POLICY == 'warn' else 'strict')
 
 
 def check_render_flags(wait=False):

@@ -351,10 +351,17 @@ class GraphedStep:
 				if all(same):
 					if any(a.data_ptr() != b.data_ptr() for a, b in zip(src, dst)):
 						torch._foreach_copy_(dst, src)
+					# (a scan that fills its bucket exactly: the static tensors are full NOW -- ADVICE r4: with `filled` left at the previous,
+					# smaller scan's size the next mid-sized scan skipped the tail fill and kept this scan's last faces)
+					for i, b in enumerate(dst):
+						if (k, i) in st.filled:
+							st.filled[(k, i)] = b.shape[_ragged_dim(b)]
 					continue
 				for i, (a, b, pad) in enumerate(zip(src, dst, _mesh_padding(v))):
 					if a.shape == b.shape:
 						b.copy_(a, non_blocking=True)
+						if (k, i) in st.filled:
+							st.filled[(k, i)] = b.shape[_ragged_dim(b)]
 						continue
 					d = _ragged_dim(a)
 					n, was = a.shape[d], st.filled.get((k, i), b.shape[d])

@@ -399,21 +399,42 @@ class NeuralDisplacementField(Model):
 		self.template_mesh = Meshes(verts=self.template_verts.data, faces=self.template_faces.data[0])
 
 	def _weights(self):
-		# (the Parameter objects, collected once: walking the three Sequentials cost 25 us per call -- twice per step at batch 1, where the
-		# step is bound by the host; .to() / load_state_dict keep the objects, _apply below drops the list anyway)
-		ws = self.__dict__.get('_wlist')
-		if ws is None:
-			ws = []
-			for seq in (self.base, self.mlp_disp, self.mlp_col):
-				for layer in seq:
-					if isinstance(layer, nn.Linear):
-						ws += [layer.weight, layer.bias]
-			self.__dict__['_wlist'] = ws
+		"""The MLP's Parameter objects in kernel order.  Collected once (walking the three Sequentials cost 25 us per call -- twice per step
+		at batch 1, where the step is bound by the host) and VALIDATED on every call by identity: each cached (container, layer, weight, bias)
+		must still be what the module tree holds, so a replaced Parameter (`load_state_dict(assign=True)`, `layer.weight = nn.Parameter(...)`,
+		torch.__future__.set_overwrite_module_params_on_conversion), a replaced layer or a replaced Sequential rebuilds the list instead of
+		feeding the kernels tensors the optimiser no longer holds."""
+		c = self.__dict__.get('_wlist')
+		if c is not None:
+			ws, checks, seqs = c
+			mods = self._modules
+			ok = mods['base'] is seqs[0] and mods['mlp_disp'] is seqs[1] and mods['mlp_col'] is seqs[2]
+			if ok:
+				for i, (md, key, layer, pd) in enumerate(checks):
+					if md.get(key) is not layer or pd.get('weight') is not ws[2 * i] or pd.get('bias') is not ws[2 * i + 1]:
+						ok = False
+						break
+				ok = ok and sum(len(q) for q in seqs) == self.__dict__['_wcount']
+			if ok:
+				return ws
+		ws, checks = [], []
+		seqs = (self.base, self.mlp_disp, self.mlp_col)
+		for seq in seqs:
+			for key, layer in seq._modules.items():
+				if isinstance(layer, nn.Linear):
+					ws += [layer.weight, layer.bias]
+					checks.append((seq._modules, key, layer, layer._parameters))
+		self.__dict__['_wlist'] = (ws, checks, seqs)
+		self.__dict__['_wcount'] = sum(len(q) for q in seqs)
 		return ws
 
 	def _apply(self, fn, *args, **kwargs):
+		# (one override: drops the cached weight list -- conversions may replace Parameter objects -- AND re-points the template mesh at the
+		# converted template tensors; round 4 had two definitions of this method and the second silently replaced the first)
 		self.__dict__.pop('_wlist', None)
-		return super()._apply(fn, *args, **kwargs)
+		out = super()._apply(fn, *args, **kwargs)
+		self._rebuild_template_mesh()
+		return out
 
 	@staticmethod
 	def _cat_latents(*vecs):
@@ -502,10 +523,5 @@ class NeuralDisplacementField(Model):
 
 	def to(self, device):
 		out = super().to(device)
-		self._rebuild_template_mesh()
-		return out
-
-	def _apply(self, fn, *a, **kw):
-		out = super()._apply(fn, *a, **kw)
 		self._rebuild_template_mesh()
 		return out

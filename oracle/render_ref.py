@@ -226,10 +226,16 @@ def torch_fragments(vproj, faces, p2f, n_views, H, W, clip_bary, perspective_cor
 	return pz, bary, dist, valid, fv
 
 
-def covered_pixels(p2f):
+def covered_pixels(p2f, order=None):
 	"""(img, yi, xi) index tensors of the pixels of a dense (n_img,H,W,K) selection that hold at least one fragment (slot 0: the
-	fragments of a pixel are sorted, empty slots last)."""
-	return torch.nonzero(p2f[..., 0] >= 0, as_tuple=True)
+	fragments of a pixel are sorted, empty slots last).  order: 'reverse' or an int seed -- the same pixels in another order (the gradient
+	scatter then sums each vertex's contributions in another order: how the full-size tests measure the summation-order term of fp32)."""
+	pix = torch.nonzero(p2f[..., 0] >= 0, as_tuple=True)
+	if order is None:
+		return pix
+	n = pix[0].shape[0]
+	perm = torch.arange(n - 1, -1, -1) if order == 'reverse' else torch.randperm(n, generator=torch.Generator().manual_seed(int(order)))
+	return tuple(p[perm] for p in pix)
 
 
 def torch_silhouette(dist, valid, sigma=1e-4):
@@ -252,7 +258,7 @@ def torch_vertex_normals(verts, faces):
 	return torch.stack(out)
 
 
-def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views, compact=False):
+def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views, compact=False, order=None):
 	"""Differentiable K=1 Phong image given the hard selection p2f1 (n_img,H,W,1).  compact: evaluate the covered pixels only (the others
 	are background exactly: no fragment, weights zero) -- same numbers, a fraction of the memory at 256^2 / 512^2."""
 	N, V, _ = verts.shape
@@ -261,7 +267,7 @@ def torch_phong_image(rp, verts, colors, faces, R, T, p2f1, n_views, compact=Fal
 	n_img = vproj.shape[0]
 	bg = torch.tensor(list(rp.background), dtype=verts.dtype)
 	if compact:
-		pix = covered_pixels(p2f1)
+		pix = covered_pixels(p2f1, order)
 		sel = p2f1[pix]                                   # (P, 1)
 		pz, bary, dist, valid, fv = torch_fragments(vproj, faces, sel, n_views, H, W, clip_bary=False, pixels=pix)
 		img_of = pix[0].view(-1, 1, 1)
@@ -308,13 +314,13 @@ def torch_softmax_blend(col, dist, pz, valid, sigma, gamma, znear, zfar, backgro
 	return ((wnum.unsqueeze(-1) * col).sum(-2) + delta * background) / den
 
 
-def torch_mask(rp, verts, faces, R, T, p2f, n_views, compact=False):
+def torch_mask(rp, verts, faces, R, T, p2f, n_views, compact=False, order=None):
 	"""Differentiable soft silhouette given the K-fragment selection p2f (n_img,H,W,K).  compact: the covered pixels only (an empty
 	pixel's mask is 1 - prod(1) = 0 exactly)."""
 	N = verts.shape[0]
 	vproj = torch_project(verts, R, T, rp.fov_deg)
 	if compact:
-		pix = covered_pixels(p2f)
+		pix = covered_pixels(p2f, order)
 		pz, bary, dist, valid, fv = torch_fragments(vproj, faces, p2f[pix], n_views, rp.image_h, rp.image_w, clip_bary=True, pixels=pix)
 		m = torch_silhouette(dist, valid, rp.sil_sigma)
 		out = torch.zeros(vproj.shape[0], rp.image_h, rp.image_w, dtype=verts.dtype).index_put(pix, m)

@@ -93,6 +93,7 @@ def main():
 		'c': (1, 1, 1),
 		'd': (3, 37, 3),
 		'e': (16, 1, 16),
+		'f': (1, 1000, 1),   # SURVEY G3 / BASELINE configs[0]: a single foot on a 1k-vertex template (appended last: the seeded stream of a-e is unchanged)
 	}
 	for name, (Bp, V, Bl) in cases.items():
 		pos = synth_positions(gen, Bp, V)
@@ -103,7 +104,7 @@ def main():
 			out[f'fwd/{name}/{k}'] = v.numpy().copy()
 
 	# G4: autograd gradients of sum(disp^2)+sum(col^2) wrt every parameter and latent, cases a (general) and b (broadcast)
-	for name in ['a', 'b', 'd']:
+	for name in ['a', 'b', 'd', 'f']:
 		pos = torch.from_numpy(out[f'fwd/{name}/pos'])
 		lats = {k: torch.from_numpy(out[f'fwd/{name}/{k}']).clone().requires_grad_(True)
 				for k in ['shapevec', 'texvec', 'posevec']}

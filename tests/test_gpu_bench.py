@@ -30,10 +30,47 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 	rf = d['roofline']
 	assert rf['bound'] in ('hbm', 'mfma') and rf['unit'] in ('GB/s', 'TFLOP/s')
 	assert rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and 0.3 < rf['frac'] < 1.0
-	assert len(rf['kernels']) >= 4 and all(k['isolated_us'] > 0 and 0.05 < k['frac'] < 1.0 for k in rf['kernels'])
 	assert rf['traffic'] is None or rf['traffic'] > 0
+	assert rf['avg_kernel_ms'] > 0 and rf['flops_per_launch'] > 0 and 'kernels' not in rf   # the per-kernel table lives in bench_records.json
+	assert len(lines[0]) < 4096 and d['dtype'] == 'f32' and len(d['dtype_note']) < 200 and len(d['config']['workload']) <= 200
+	full = json.load(open(os.path.join(ROOT, d['records_file'])))
+	assert full['line']['value'] == d['value']
+	ks = full['roofline_kernels']
+	assert len(ks) >= 4 and all(k['isolated_us'] > 0 and 0.05 < k['frac'] < 1.0 for k in ks)
 	cb = d['cpu_baseline']
 	assert cb['value'] > 0 and cb['unit'] == d['unit'] and cb['cores'] >= 1 and cb['kind'] in ('reference', 'port') and isinstance(cb['sample'], str)
+
+
+@pytest.mark.timeout(1200)
+def test_the_drivers_exact_command_gives_one_short_parsable_line():
+	"""round 4's line was 20.5 kB (15 nested records) and the driver could not parse it.  This runs the command the driver
+	runs -- records on -- and holds the line to what a parser with a small buffer can take: stdout is ONE line under 4 kB that carries the
+	contract fields, the records travel as name -> [ms_per_step, steps] on the line, in full in bench_records.json and as one short JSON
+	line each on stderr."""
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5'],
+					   capture_output=True, text=True, timeout=1100, cwd=ROOT)
+	assert r.returncode == 0, r.stderr[-2000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+	assert len(lines) == 1, r.stdout[-2000:]
+	assert len(lines[0]) < 4096, len(lines[0])
+	d = json.loads(lines[0])
+	assert d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1 and d['dtype'] == 'f32'
+	for k in ('metric', 'value', 'unit', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'data', 'config', 'roofline', 'cpu_baseline'):
+		assert k in d, k
+	for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_kernel_ms', 'flops_per_launch', 'traffic'):
+		assert k in d['roofline'], k
+	for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+		assert k in d['cpu_baseline'], k
+	assert len(d['config']['workload']) <= 200 and 'records_error' not in d
+	names = {'train3d_b16_eager_colour_head', 'fp32_mfma', 'train3d_b1', 'train3d_b1_graph', 'c2', 'c3', 'c4_rank_share', 'c5_fp32', 'c5_fp16'}
+	assert names <= set(d['records']), sorted(d['records'])
+	assert all(len(v) == 2 and v[0] > 0 and v[1] > 0 for v in d['records'].values())
+	full = json.load(open(os.path.join(ROOT, d['records_file'])))
+	assert set(full['records']) >= names and full['records']['c5_fp16']['roofline']['bound'] == 'hbm'
+	# one short line per record on stderr
+	rec_lines = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"record"')]
+	assert {x['record'] for x in rec_lines} >= names
+	assert all(len(ln) <= 1024 for ln in r.stderr.splitlines() if ln.startswith('{"record"'))
 
 
 def test_two_rank_bench_path_runs_end_to_end_on_one_gpu():
@@ -57,3 +94,9 @@ def test_two_rank_bench_path_runs_end_to_end_on_one_gpu():
 	assert abs(d['value'] - 2 * 16 * 6890 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
 	assert 'cpu_baseline' not in d and 'records' not in d   # rank 0 at N = 1 only
 	assert d['roofline']['frac'] > 0.3
+	# the line says what the exchange step saw: the process group's own world size, one entry per rank, the bucket, its time
+	c = d['collective']
+	assert c['backend'] == 'gloo' and c['world_size'] == 2 and len(c['ranks_devices']) == 2 and c['ranks_devices'][0].startswith('0:cuda:0')
+	assert 3.4e6 < c['bucket_bytes'] < 4.0e6 and c['allreduce_us_per_step'] > 0
+	assert c['distinct_devices'] == 1   # (both ranks share device 0 in this test; the driver's run must show N)
+	assert len(lines[0]) < 4096

@@ -31,7 +31,7 @@ def test_library_loads_and_reports_gfx950():
 	assert L.find_build_arch() == b'gfx950'
 
 
-@pytest.mark.parametrize('case', list('abcde'))
+@pytest.mark.parametrize('case', list('abcdef'))
 def test_forward_matches_reference_golden(golden_main, case):
 	m = _model_from_golden(golden_main)
 	g = {k: _t(golden_main[f'fwd/{case}/{k}']) for k in ['pos', 'shapevec', 'texvec', 'posevec', 'disp', 'col']}
@@ -44,7 +44,7 @@ def test_forward_matches_reference_golden(golden_main, case):
 	assert ed < 2e-5 and ec < 2e-5, f'fp32 MFMA path unexpectedly loose: {ed} {ec}'
 
 
-@pytest.mark.parametrize('case', list('abd'))
+@pytest.mark.parametrize('case', list('abdf'))
 def test_backward_matches_reference_golden(golden_main, case):
 	m = _model_from_golden(golden_main)
 	lat = {k: _t(golden_main[f'fwd/{case}/{k}']).requires_grad_(True) for k in ['shapevec', 'texvec', 'posevec']}
@@ -765,3 +765,23 @@ def test_deferred_weight_gradient_join_changes_no_gradient_and_is_joined_when_ba
 			assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item(), n
 		else:
 			assert torch.equal(a, b), n
+
+
+def test_forward_and_backward_use_a_replaced_parameter_object(golden_main):
+	"""the kernels read the module tree's CURRENT Parameters.  Replace one object (not its data) after a first call has
+	cached the weight list: the next forward must equal the oracle's on the new weights and the gradient must land on the new object."""
+	m = _model_from_golden(golden_main)
+	g = {k: _t(golden_main[f'fwd/a/{k}']) for k in ['pos', 'shapevec', 'texvec', 'posevec']}
+	with torch.no_grad():
+		before = m(g['pos'], shapevec=g['shapevec'], texvec=g['texvec'], posevec=g['posevec'])
+	gen = torch.Generator().manual_seed(3)
+	old = m.mlp_col[2].weight
+	new = torch.nn.Parameter((torch.randn(256, 256, generator=gen) / 16).cuda())
+	m.mlp_col[2].weight = new
+	res = m(g['pos'], shapevec=g['shapevec'], texvec=g['texvec'], posevec=g['posevec'])
+	sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+	ref = mlp_ref.mlp_forward(sd, m.encoder[0]._B, g['pos'].cpu(), g['shapevec'].cpu(), g['texvec'].cpu(), g['posevec'].cpu())
+	assert (res['col'].detach().cpu() - ref['col']).abs().max().item() < TOL
+	assert (res['col'].detach() - before['col']).abs().max().item() > 1e-3   # (the replacement matters)
+	(res['col'] ** 2).sum().backward()
+	assert new.grad is not None and float(new.grad.abs().max()) > 0 and old.grad is None

@@ -135,7 +135,7 @@ def test_model_bf16x3_equals_fp32_mfma_to_summation_order(every_size, n_feet, n_
 		  f'on the same activations, {worst_e2e:.1e} end to end')
 
 
-@pytest.mark.parametrize('case', list('abcde'))
+@pytest.mark.parametrize('case', list('abcdef'))
 def test_forward_matches_reference_golden_under_bf16x3(every_size, golden_main, case):
 	"""The reference's own forward (tests/golden/mlp_main.npz, generated by importing NeuralDisplacementField) with EVERY 256 -> 256 layer
 	on the bf16x3 kernels, whatever its size: the same 2e-5 bound the fp32-MFMA path is held to (tests/test_gpu_mlp.py)."""
@@ -151,10 +151,11 @@ def test_forward_matches_reference_golden_under_bf16x3(every_size, golden_main, 
 	assert ed < 2e-5 and ec < 2e-5, (case, ed, ec)
 
 
-def test_backward_matches_reference_golden_under_bf16x3(every_size, golden_main):
-	"""... and its gradients (autograd through the reference model: loss, latents, every weight tensor of case 'b')."""
+@pytest.mark.parametrize('case', ['b', 'f'])
+def test_backward_matches_reference_golden_under_bf16x3(every_size, golden_main, case):
+	"""... and its gradients (autograd through the reference model: loss, latents, every weight tensor of case 'b' -- 16 feet on one
+	1000-vertex template -- and 'f', BASELINE configs[0]'s single foot on a 1k-vertex template)."""
 	from test_gpu_mlp import _model_from_golden, _t
-	case = 'b'
 	m = _model_from_golden(golden_main)
 	lat = {k: _t(golden_main[f'fwd/{case}/{k}']).requires_grad_(True) for k in ['shapevec', 'texvec', 'posevec']}
 	res = m(_t(golden_main[f'fwd/{case}/pos']), **lat)

@@ -477,6 +477,17 @@ def test_render_watchdog_sees_the_renders_of_a_captured_step():
 			assert bool(hits) == bad, (dist, [str(w.message)[:80] for w in wlist])
 			if bad:
 				assert any('replayed from a HIP graph' in str(w.message) for w in hits)
+			# the check above must not be the last one -- `_watch` registers a device only while a stream CAPTURES, so a device taken
+			# off the list at the first epoch boundary was never read again.  More replays, a second boundary: reported again (and clean stays clean).
+			with warnings.catch_warnings(record=True) as wlist:
+				warnings.simplefilter('always')
+				FR.check_render_flags(wait=True)
+				assert not [w for w in wlist if 'straddle' in str(w.message)]   # (the counters were reset by the first check)
+				for i in (1, 2):
+					gs(batch_of(i))
+				FR.check_render_flags(wait=True)
+			hits = [w for w in wlist if 'replayed from a HIP graph' in str(w.message)]
+			assert bool(hits) == bad, (dist, 'second epoch boundary')
 	finally:
 		FR.FLAG_POLICY = prev
 		try:
@@ -589,3 +600,50 @@ def test_bucketed_replay_equals_the_unpadded_step_with_fixed_draws():
 	assert abs(got.item() - want) < 1e-5 * max(1.0, abs(want)), (got.item(), want)
 	for k in want_terms:
 		assert abs(got_terms[k].item() - want_terms[k].item()) < 1e-5 * max(1.0, abs(want_terms[k].item())), k
+
+
+def test_a_scan_that_fills_its_bucket_exactly_leaves_no_stale_faces_behind():
+	"""ADVICE r4 (graph.py `_load`): smaller scan, then a scan whose face count EQUALS the bucket size, then a mid-sized one.  The exact-size scan
+	is copied whole; round 4 did not record that the static tensors were full afterwards, so the mid-sized scan skipped the tail fill and
+	the graph kept sampling (and rendering) the previous scan's last faces.  The static GT mesh after every load must be the scan padded
+	with -1 faces / zero features, and the replayed loss must equal the eager step's on the unpadded scan (fixed draws)."""
+	from find_amd import optim, synthetic
+	from find_amd.graph import GraphedStep, bucket_size
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.train_utils import sample_latent_vectors
+	g = torch.Generator().manual_seed(8)
+	v, f = synthetic.ellipsoid_mesh(24, 32)     # 770 vertices, 1536 faces = a bucket size exactly
+	assert f.shape[0] == 1536 == bucket_size(1536)
+	v = (v * (1 + 0.1 * torch.rand(1, 3, generator=g))).cuda()
+	c = torch.rand(v.shape, generator=g).clamp(0.05, 0.95).cuda()
+	f = f[torch.randperm(f.shape[0], generator=g)].cuda()   # (so that a prefix of the face list is a mesh with holes all over, not a capless one)
+	counts = [1400, 1536, 1500, 1536, 1300]
+	feet, names, labels = synthetic.scan_labels(4)
+
+	def batch(n):
+		return dict(mesh=Meshes(v[None], f[None, :n].contiguous(), TexturesVertex(c[None])), idx=torch.tensor([1], device='cuda'), name=[names[1]], shape=[feet[1]],
+					tex=[feet[1]], pose=[names[1]], reg=[names[1]])
+
+	draws = [(torch.randint(0, 1300, (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, 2 * (1002 - 2), (1, 5000), generator=g).cuda(), torch.rand(1, 5000, 2, generator=g).cuda()),
+			 (torch.randint(0, 1300, (1, 1000), generator=g).cuda(), torch.rand(1, 1000, 2, generator=g).cuda())]
+	mwl, opts, _, _, _ = _setup(1002, 1002, capturable=True, seed=6)
+	gs = GraphedStep(mwl, opts, [optim.Adam(mwl.model.main_params, lr=0.0, capturable=True)], warmup=1, **opts.net_train_kwargs())
+	with FixedDraws(draws):
+		for n in counts:
+			got, _ = gs(batch(n))
+			torch.cuda.synchronize()
+			st = next(iter(gs._graphs.values()))
+			sf = st.batch['mesh'].faces_padded()
+			sf = sf if sf.dim() == 2 else sf[0]
+			assert sf.shape[0] == 1536
+			assert torch.equal(sf[:n].long(), f[:n].long()), n
+			assert bool((sf[n:] == -1).all()), f'{int((sf[n:] != -1).any(dim=-1).sum())} stale face(s) behind a scan of {n} faces'
+	assert gs.n_captures == 1
+	# the replay of the last (smallest) scan against the eager step on the unpadded scan
+	mwl2, opts2, _, _, _ = _setup(1002, 1002, capturable=True, seed=6)
+	with FixedDraws(draws):
+		b = batch(counts[-1])
+		b.update(sample_latent_vectors(b, mwl2.model.latent_vectors_train))
+		want, _ = mwl2(b, 0, opts2, **opts2.net_train_kwargs())
+	assert abs(got.item() - want.item()) < 1e-5 * max(1.0, abs(want.item())), (got.item(), want.item())

@@ -26,7 +26,7 @@ def test_fourier_B_matches_reference(golden_main):
 def test_forward_cases(golden_main):
 	sd = _sd(golden_main)
 	B = torch.from_numpy(golden_main['B'])
-	for name in 'abcde':
+	for name in 'abcdef':
 		g = {k: torch.from_numpy(golden_main[f'fwd/{name}/{k}']) for k in ['pos', 'shapevec', 'texvec', 'posevec', 'disp', 'col']}
 		with torch.no_grad():
 			res = mlp_ref.mlp_forward(sd, B, g['pos'], g['shapevec'], g['texvec'], g['posevec'])

@@ -261,3 +261,61 @@ def test_toes_view_stays_in_front_of_the_clip_plane():
 	assert vp[..., 2].min() > 0.059
 	p2f, zb, _, _ = render_ref.rasterize(vp, f.numpy(), 1, 32, 32, 1, 0.0)
 	assert (p2f >= 0).mean() > 0.3 and zb[p2f >= 0].min() > 0.059
+
+
+def test_compact_fragment_form_equals_the_dense_form():
+	"""The full-size GPU parity tests (tests/test_gpu_fullsize.py) use only the oracle's COMPACT form -- covered pixels only -- of torch_mask /
+	torch_phong_image (VERDICT r4 weak 1 iv: nothing asserted that it IS the dense form).  A 32^2 scene of two feet x two views: masks,
+	images and every gradient (vertices, colours) must be bit-equal; per-pixel arithmetic is elementwise, so leaving empty pixels out may not
+	change one bit of the others, and an empty pixel is exactly background / zero with zero gradient."""
+	from find_amd import synthetic
+	rp = render_ref.default_params(32)
+	v, f = synthetic.ellipsoid_mesh(9, 12)
+	g = torch.Generator().manual_seed(2)
+	verts = torch.stack([v * (1 + 0.1 * torch.rand(1, 3, generator=g)) for _ in range(2)]).float()
+	cols = torch.rand(2, v.shape[0], 3, generator=g)
+	R, T = camera_ref.look_at_view_transform(dist=np.full(2, 0.3), elev=np.array([20., -50.]), azim=np.array([30., -70.]), up=((1, 0, 0),))
+	Rt, Tt = torch.from_numpy(R), torch.from_numpy(T)
+	vp = render_ref.project(rp, verts.numpy(), R, T)
+	res = {}
+	for K, blur in ((100, rp.sil_blur_radius), (1, 0.0)):
+		p2f = torch.from_numpy(render_ref.rasterize(vp, f.numpy(), 2, 32, 32, K, blur)[0]).long()
+		assert 0.05 < float((p2f[..., 0] >= 0).float().mean()) < 0.9     # some pixels covered, some empty: both branches of the compaction run
+		for compact in (False, True):
+			vv, cc = verts.clone().requires_grad_(True), cols.clone().requires_grad_(True)
+			if K == 100:
+				out = render_ref.torch_mask(rp, vv, f, Rt, Tt, p2f, 2, compact=compact)
+				w = torch.rand(out.shape, generator=torch.Generator().manual_seed(5))
+				(out * w).sum().backward()
+				res[K, compact] = (out.detach(), vv.grad)
+			else:
+				out = render_ref.torch_phong_image(rp, vv, cc, f, Rt, Tt, p2f, 2, compact=compact)
+				w = torch.rand(out.shape, generator=torch.Generator().manual_seed(6))
+				(out * w).sum().backward()
+				res[K, compact] = (out.detach(), vv.grad, cc.grad)
+		# forward: bit-equal (elementwise arithmetic per pixel; an empty pixel is background / zero exactly)
+		assert torch.equal(res[K, False][0], res[K, True][0]), K
+		# gradients: the same per-fragment terms, scattered to the vertices by index_add over another row set -- torch's CPU scatter sums in
+		# an order that depends on the tensor's shape, so fp32 sums agree to rounding (measured 6e-6 of the largest entry) ...
+		for a, b in zip(res[K, False][1:], res[K, True][1:]):
+			assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), (K, float((a - b).abs().max()), float(a.abs().max()))
+	# ... and in float64 to 1e-13: the two forms are the same function, not two approximations of it
+	p2f = torch.from_numpy(render_ref.rasterize(vp, f.numpy(), 2, 32, 32, 100, rp.sil_blur_radius)[0]).long()
+	p2f1 = torch.from_numpy(render_ref.rasterize(vp, f.numpy(), 2, 32, 32, 1, 0.0)[0]).long()
+	g64 = {}
+	for compact in (False, True):
+		vv, cc = verts.double().requires_grad_(True), cols.double().requires_grad_(True)
+		m = render_ref.torch_mask(rp, vv, f, Rt.double(), Tt.double(), p2f, 2, compact=compact)
+		im = render_ref.torch_phong_image(rp, vv, cc, f, Rt.double(), Tt.double(), p2f1, 2, compact=compact)
+		((m ** 2).sum() + (im ** 3).sum()).backward()
+		g64[compact] = (m.detach(), im.detach(), vv.grad, cc.grad)
+	for a, b in zip(g64[False], g64[True]):
+		assert float((a - b).abs().max()) <= 1e-13 * max(1.0, float(a.abs().max()))
+	# and the fragments themselves: the compact rows are the dense rows of the covered pixels
+	p2f = torch.from_numpy(render_ref.rasterize(vp, f.numpy(), 2, 32, 32, 100, rp.sil_blur_radius)[0]).long()
+	vpt = render_ref.torch_project(verts, Rt, Tt, rp.fov_deg)
+	pix = render_ref.covered_pixels(p2f)
+	dense = render_ref.torch_fragments(vpt, f, p2f, 2, 32, 32, clip_bary=True)
+	comp = render_ref.torch_fragments(vpt, f, p2f[pix], 2, 32, 32, clip_bary=True, pixels=pix)
+	for a, b in zip(dense[:4], comp[:4]):
+		assert torch.equal(a[pix], b)
