@@ -47,12 +47,15 @@ constexpr int N_QUEUES = 24;      // tile queues by log2(list length), the longe
 constexpr int CURSOR_STRIDE = 32;  // ints between two counters of the cursor array
 constexpr uint32_t LIST_UNSORTED = 1u << 30;
 constexpr uint32_t FACE_MASK = 0x00FFFFFFu;
+constexpr int REC_F4 = 8;         // 16-byte pieces of a face record (FaceRec)
+constexpr int REC_DW = 32;        // its dwords
+constexpr int PAIR_STRIDE = 68;   // floats between two pair blocks of the rasteriser's LDS staging: 2 x REC_DW + 4 (a stride of 64 dwords put every block on the same two banks: 32-way conflicts on the staging writes)
 
 struct FaceRec;
 struct Ws {
 	float* vproj;     // (n_img, V, 3)
 	float4* frec;     // (n_img, F, 3) float4: [x0 y0 x1 y1][x2 y2 z0 z1][z2 - - -]   (backward kernels)
-	struct FaceRec* recs;  // (n_img, F) the same face with everything the fragment math needs per face (80 B), read wave-uniformly by the rasteriser
+	struct FaceRec* recs;  // (n_img, F) the same face as the affine forms of the fragment math (128 B), staged through LDS by the rasteriser
 	uint32_t* rz;     // (n_img, ceil(F / 64), 4) per run of 64 faces: bits of the smallest / largest fzmin, of the largest depth extent
 	uint32_t* tb;     // (n_img, F) packed bbox in 8-pixel tiles: x0 | x1 << 8 | y0 << 16 | y1 << 24 (TB_EMPTY: culled)
 	uint32_t* tbb;    // (n_img, ceil(F / 64)) the same for every run of 64 consecutive faces
@@ -90,7 +93,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->cursor = c.take<int32_t>(n_img * CURSOR_STRIDE);
 	o->vproj = c.take<float>(n_img * V * 3);
 	o->frec = c.take<float4>(n_img * F * 3);
-	o->recs = reinterpret_cast<FaceRec*>(c.take<float4>(n_img * F * 5));
+	o->recs = reinterpret_cast<FaceRec*>(c.take<float4>(n_img * F * REC_F4));
 	o->rz = c.take<uint32_t>(n_img * cdiv(F, 64) * 4);
 	o->tb = c.take<uint32_t>(n_img * F);
 	o->tbb = c.take<uint32_t>(n_img * cdiv(F, 64));
@@ -193,52 +196,74 @@ __device__ __forceinline__ void pix_range_tight(float cmin, float cmax, int S, i
 
 
 // ------------------------------------------------------------------------------------------------ shared fragment math
-struct FaceRec {  // 80 bytes = five 16-byte pieces; written once per (image, face) by face_setup_kernel
-	float x0, y0, x1, y1;
-	float x2, y2, z0, z1;
-	float z2, inv_area, il01, il02;   // il: 1 / |edge|^2 (0 for a degenerate edge: the projection parameter is then 1, as PyTorch3D)
-	float il12; int f; int pad[2];
+// Everything of the (pixel, face) arithmetic that does not depend on the pixel is computed ONCE per (image, face), in double, by
+// face_setup_kernel, as AFFINE FORMS in d = p - v0 (round 5; rounds 1-4 kept vertices, 1 / area and 1 / |edge|^2 and rebuilt the edge
+// functions per pixel: ~100 multiply-add-class operations per pixel and face, ~60 now):
+//   perspective-weighted barycentric numerators   t_i(p) = e_i(p) / area * z_j z_k = Tix dx + Tiy dy (+ T0c: e_1 and e_2 vanish at v0)
+//   projection parameters on the three edges       u_k(p) = (p - a_k) . (b_k - a_k) / |b_k - a_k|^2 = Ukx dx + Uky dy + Ukc
+//                                                  (a degenerate edge: U = 0, Uc = 1 -- the parameter is then 1, the far end, as PyTorch3D)
+// with the origin at the face's own first vertex the forms lose nothing against the difference form (|d| is the blurred bbox's size, not
+// the NDC coordinate: tools-free check in DESIGN 4.2).  PyTorch3D's order of operations -- w_i = e_i / area, then t_i = w_i z_j z_k,
+// w'_i = t_i / max(sum t, eps), clipped c_i = max(w'_i, 0) / max(sum, 1e-5), depth = sum c_i z_i, squared distance to the nearest of the
+// three segments with the parameter clamped to [0, 1] -- is unchanged from t_i on.
+struct FaceRec {  // 128 bytes = eight 16-byte pieces; written once per (image, face) by face_setup_kernel
+	float ox, oy, x1, y1;     // v0 (NDC); v1 - v0
+	float x2, y2, ex, ey;     // v2 - v0; v2 - v1
+	float z0, z1, z2, T0c;
+	float T0x, T0y, T1x, T1y;
+	float T2x, T2y, U0x, U0y; // edge 0: v0 v1
+	float U0c, U1x, U1y, U1c; // edge 1: v0 v2
+	float U2x, U2y, U2c; int f;   // edge 2: v1 v2;  f: the face index (the rasteriser's staging puts the list entry here: slab << 24 | face)
 	float xmin, xmax, ymin, ymax;     // blurred NDC bbox
 };
-static_assert(sizeof(FaceRec) == 80, "FaceRec is read as 20 dwords");
+static_assert(sizeof(FaceRec) == 128, "FaceRec is read as 32 dwords");
 
-__device__ __forceinline__ float edge_inv_len2(float ax, float ay, float bx, float by) {
+// (pixel, face) arithmetic below is compiled WITHOUT floating-point contraction and its fused multiply-adds are explicit: the
+// compiler may otherwise fuse the same expression differently in the rasteriser's two sweeps and the backward, and a candidate's
+// depth is compared bit for bit between them.
+__device__ __forceinline__ float sqlen_f32(float dx, float dy) {
 #pragma clang fp contract(off)
-	const float dx = bx - ax, dy = by - ay;
-	const float l2 = __builtin_fmaf(dx, dx, dy * dy);
-	return l2 > KEPS ? 1.0f / l2 : 0.0f;
+	const float a = dx * dx, b = dy * dy;
+	return a + b;
 }
-
-// Everything that is per face (not per pixel) is computed here, once: the per-pixel fragment math below then has no IEEE
-// division left (a v_rcp_f32 for the two normalisations).
-__device__ __forceinline__ void make_rec(const float4 a, const float4 b, const float4 c, int f, float br, FaceRec* r) {
-#pragma clang fp contract(off)
-	r->x0 = a.x; r->y0 = a.y; r->x1 = a.z; r->y1 = a.w; r->x2 = b.x; r->y2 = b.y; r->z0 = b.z; r->z1 = b.w; r->z2 = c.x;
-	r->xmin = fminf(a.x, fminf(a.z, b.x)) - br; r->xmax = fmaxf(a.x, fmaxf(a.z, b.x)) + br;
-	r->ymin = fminf(a.y, fminf(a.w, b.y)) - br; r->ymax = fmaxf(a.y, fmaxf(a.w, b.y)) + br;
-	r->inv_area = 1.0f / (edge_fn(b.x, b.y, a.x, a.y, a.z, a.w) + KEPS);
-	r->il01 = edge_inv_len2(a.x, a.y, a.z, a.w);
-	r->il02 = edge_inv_len2(a.x, a.y, b.x, b.y);
-	r->il12 = edge_inv_len2(a.z, a.w, b.x, b.y);
+__device__ __forceinline__ void make_rec(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2, float z2, int f, float br, FaceRec* r) {
+	// double: differences of fp32 coordinates are exact, products and quotients correctly rounded once
+	const double X1 = (double)x1 - x0, Y1 = (double)y1 - y0, X2 = (double)x2 - x0, Y2 = (double)y2 - y0, EX = (double)x2 - x1, EY = (double)y2 - y1;
+	const double area = X2 * Y1 - Y2 * X1;                 // edge(v2; v0, v1)
+	const double ia = 1.0 / (area + (double)KEPS);
+	const double k0 = ia * (double)z1 * (double)z2, k1 = ia * (double)z0 * (double)z2, k2 = ia * (double)z0 * (double)z1;
+	r->ox = x0; r->oy = y0; r->x1 = (float)X1; r->y1 = (float)Y1; r->x2 = (float)X2; r->y2 = (float)Y2; r->ex = (float)EX; r->ey = (float)EY;
+	r->z0 = z0; r->z1 = z1; r->z2 = z2;
+	// e_0(p) = edge(p; v1, v2) = EY dx - EX dy + area;  e_1(p) = edge(p; v2, v0) = -Y2 dx + X2 dy;  e_2(p) = edge(p; v0, v1) = Y1 dx - X1 dy
+	r->T0x = (float)(EY * k0); r->T0y = (float)(-EX * k0); r->T0c = (float)(area * k0);
+	r->T1x = (float)(-Y2 * k1); r->T1y = (float)(X2 * k1);
+	r->T2x = (float)(Y1 * k2); r->T2y = (float)(-X1 * k2);
+	const double l01 = X1 * X1 + Y1 * Y1, l02 = X2 * X2 + Y2 * Y2, l12 = EX * EX + EY * EY;
+	// "degenerate" is a threshold decision (PyTorch3D: squared length <= 1e-8 in fp32) and not a continuous quantity: the ring edges at the
+	// poles of a 50 002-vertex lat-long template @64^2 are 1e-4 long, right AT it.  Decided in the reference's own arithmetic -- fp32
+	// differences, fp32 products, fp32 sum, no contraction -- so that the same edges take the far-end branch on both sides.
+	const float f01 = sqlen_f32(x1 - x0, y1 - y0), f02 = sqlen_f32(x2 - x0, y2 - y0), f12 = sqlen_f32(x2 - x1, y2 - y1);
+	const bool d01 = f01 <= KEPS, d02 = f02 <= KEPS, d12 = f12 <= KEPS;
+	r->U0x = d01 ? 0.f : (float)(X1 / l01); r->U0y = d01 ? 0.f : (float)(Y1 / l01); r->U0c = d01 ? 1.f : 0.f;
+	r->U1x = d02 ? 0.f : (float)(X2 / l02); r->U1y = d02 ? 0.f : (float)(Y2 / l02); r->U1c = d02 ? 1.f : 0.f;
+	r->U2x = d12 ? 0.f : (float)(EX / l12); r->U2y = d12 ? 0.f : (float)(EY / l12); r->U2c = d12 ? 1.f : (float)(-(X1 * EX + Y1 * EY) / l12);
 	r->f = f;
-	r->pad[0] = r->pad[1] = 0;
+	r->xmin = fminf(x0, fminf(x1, x2)) - br; r->xmax = fmaxf(x0, fmaxf(x1, x2)) + br;
+	r->ymin = fminf(y0, fminf(y1, y2)) - br; r->ymax = fmaxf(y0, fmaxf(y1, y2)) + br;
 }
-__device__ __forceinline__ void make_rec(const float4* fr, int f, float br, FaceRec* r) { make_rec(fr[0], fr[1], fr[2], f, br, r); }
 __device__ __forceinline__ void store_rec(FaceRec* dst, const FaceRec& r) {
 	float4* d = reinterpret_cast<float4*>(dst);
-	d[0] = make_float4(r.x0, r.y0, r.x1, r.y1); d[1] = make_float4(r.x2, r.y2, r.z0, r.z1); d[2] = make_float4(r.z2, r.inv_area, r.il01, r.il02);
-	d[3] = make_float4(r.il12, __int_as_float(r.f), 0.f, 0.f); d[4] = make_float4(r.xmin, r.xmax, r.ymin, r.ymax);
+	d[0] = make_float4(r.ox, r.oy, r.x1, r.y1); d[1] = make_float4(r.x2, r.y2, r.ex, r.ey); d[2] = make_float4(r.z0, r.z1, r.z2, r.T0c);
+	d[3] = make_float4(r.T0x, r.T0y, r.T1x, r.T1y); d[4] = make_float4(r.T2x, r.T2y, r.U0x, r.U0y); d[5] = make_float4(r.U0c, r.U1x, r.U1y, r.U1c);
+	d[6] = make_float4(r.U2x, r.U2y, r.U2c, __int_as_float(r.f)); d[7] = make_float4(r.xmin, r.xmax, r.ymin, r.ymax);
 }
-
-// squared distance to segment ab; also returns the clamped parameter (PointLineDistanceForward); il = 1/|ab|^2 or 0
-__device__ __forceinline__ float seg_dist(float px, float py, float ax, float ay, float bx, float by, float il, float* t_out) {
-#pragma clang fp contract(off)
-	const float bax = bx - ax, bay = by - ay;
-	float t = 1.0f;
-	if (il > 0.f) t = fminf(fmaxf(__builtin_fmaf(bax, px - ax, bay * (py - ay)) * il, 0.f), 1.f);
-	const float qx = __builtin_fmaf(t, bax, ax) - px, qy = __builtin_fmaf(t, bay, ay) - py;
-	*t_out = t;
-	return __builtin_fmaf(qx, qx, qy * qy);
+__device__ __forceinline__ FaceRec load_rec(const float4* q, int swz = 0) {   // swz: piece k sits at k ^ swz (the second sweep's LDS layout)
+	const float4 q0 = q[0 ^ swz], q1 = q[1 ^ swz], q2 = q[2 ^ swz], q3 = q[3 ^ swz], q4 = q[4 ^ swz], q5 = q[5 ^ swz], q6 = q[6 ^ swz], q7 = q[7 ^ swz];
+	FaceRec r;
+	r.ox = q0.x; r.oy = q0.y; r.x1 = q0.z; r.y1 = q0.w; r.x2 = q1.x; r.y2 = q1.y; r.ex = q1.z; r.ey = q1.w; r.z0 = q2.x; r.z1 = q2.y; r.z2 = q2.z; r.T0c = q2.w;
+	r.T0x = q3.x; r.T0y = q3.y; r.T1x = q3.z; r.T1y = q3.w; r.T2x = q4.x; r.T2y = q4.y; r.U0x = q4.z; r.U0y = q4.w; r.U0c = q5.x; r.U1x = q5.y; r.U1y = q5.z; r.U1c = q5.w;
+	r.U2x = q6.x; r.U2y = q6.y; r.U2c = q6.z; r.f = __float_as_int(q6.w); r.xmin = q7.x; r.xmax = q7.y; r.ymin = q7.z; r.ymax = q7.w;
+	return r;
 }
 
 struct Frag {
@@ -249,6 +274,7 @@ struct Frag {
 	bool inside;
 	int edge;             // nearest edge: 0 = v0v1, 1 = v0v2, 2 = v1v2
 	float t;              // its clamped projection parameter
+	float qx, qy;         // nearest point of that edge minus the pixel (dist = qx^2 + qy^2)
 };
 
 // geometry_utils: barycentric, perspective correction, clip, depth, point-triangle distance.  Returns false when the
@@ -262,12 +288,12 @@ __device__ __forceinline__ bool eval_frag(const FaceRec& r, float px, float py, 
 // the same for a pixel already known to lie inside the blurred bbox (the rasteriser tests 64 pixels against it first)
 __device__ __forceinline__ void eval_core(const FaceRec& r, float px, float py, Frag* o) {
 #pragma clang fp contract(off)
-	float w0 = edge_fn(px, py, r.x1, r.y1, r.x2, r.y2) * r.inv_area;
-	float w1 = edge_fn(px, py, r.x2, r.y2, r.x0, r.y0) * r.inv_area;
-	float w2 = edge_fn(px, py, r.x0, r.y0, r.x1, r.y1) * r.inv_area;
-	const float t0 = w0 * r.z1 * r.z2, t1 = r.z0 * w1 * r.z2, t2 = r.z0 * r.z1 * w2;
+	const float dx = px - r.ox, dy = py - r.oy;
+	const float t0 = __builtin_fmaf(r.T0x, dx, __builtin_fmaf(r.T0y, dy, r.T0c));
+	const float t1 = __builtin_fmaf(r.T1x, dx, r.T1y * dy);
+	const float t2 = __builtin_fmaf(r.T2x, dx, r.T2y * dy);
 	const float iden = __builtin_amdgcn_rcpf(fmaxf(t0 + t1 + t2, KEPS));
-	w0 = t0 * iden; w1 = t1 * iden; w2 = t2 * iden;
+	const float w0 = t0 * iden, w1 = t1 * iden, w2 = t2 * iden;
 	o->w0 = w0; o->w1 = w1; o->w2 = w2;
 	o->inside = w0 > 0.f && w1 > 0.f && w2 > 0.f;
 	float c0 = fmaxf(w0, 0.f), c1 = fmaxf(w1, 0.f), c2 = fmaxf(w2, 0.f);
@@ -275,20 +301,23 @@ __device__ __forceinline__ void eval_core(const FaceRec& r, float px, float py, 
 	c0 *= isum; c1 *= isum; c2 *= isum;
 	o->pz_clip = __builtin_fmaf(c2, r.z2, __builtin_fmaf(c1, r.z1, c0 * r.z0));
 	o->pz = __builtin_fmaf(w2, r.z2, __builtin_fmaf(w1, r.z1, w0 * r.z0));
-	float ta, tb, tc;
-	const float e01 = seg_dist(px, py, r.x0, r.y0, r.x1, r.y1, r.il01, &ta);
-	const float e02 = seg_dist(px, py, r.x0, r.y0, r.x2, r.y2, r.il02, &tb);
-	const float e12 = seg_dist(px, py, r.x1, r.y1, r.x2, r.y2, r.il12, &tc);
-	if (e01 <= e02 && e01 <= e12) { o->dist = e01; o->edge = 0; o->t = ta; }
-	else if (e02 <= e01 && e02 <= e12) { o->dist = e02; o->edge = 1; o->t = tb; }
-	else { o->dist = e12; o->edge = 2; o->t = tc; }
+	const float ta = __builtin_amdgcn_fmed3f(__builtin_fmaf(r.U0x, dx, __builtin_fmaf(r.U0y, dy, r.U0c)), 0.f, 1.f);
+	const float tb = __builtin_amdgcn_fmed3f(__builtin_fmaf(r.U1x, dx, __builtin_fmaf(r.U1y, dy, r.U1c)), 0.f, 1.f);
+	const float tc = __builtin_amdgcn_fmed3f(__builtin_fmaf(r.U2x, dx, __builtin_fmaf(r.U2y, dy, r.U2c)), 0.f, 1.f);
+	const float ax = __builtin_fmaf(ta, r.x1, -dx), ay = __builtin_fmaf(ta, r.y1, -dy);
+	const float bx = __builtin_fmaf(tb, r.x2, -dx), by = __builtin_fmaf(tb, r.y2, -dy);
+	const float cx = __builtin_fmaf(tc, r.ex, r.x1 - dx), cy = __builtin_fmaf(tc, r.ey, r.y1 - dy);
+	const float e01 = __builtin_fmaf(ax, ax, ay * ay), e02 = __builtin_fmaf(bx, bx, by * by), e12 = __builtin_fmaf(cx, cx, cy * cy);
+	if (e01 <= e02 && e01 <= e12) { o->dist = e01; o->edge = 0; o->t = ta; o->qx = ax; o->qy = ay; }
+	else if (e02 <= e01 && e02 <= e12) { o->dist = e02; o->edge = 1; o->t = tb; o->qx = bx; o->qy = by; }
+	else { o->dist = e12; o->edge = 2; o->t = tc; o->qx = cx; o->qy = cy; }
 }
 
 // ---- the same fragment math for TWO faces at once (the rasteriser's inner loop): every quantity is a pair (face a, face b) in the two
 // halves of a 64-bit register pair, so the multiplies, adds and fused multiply-adds are packed instructions (v_pk_*_f32: one issue slot for
-// both faces) -- the pipe that bounds the rasteriser.  Operation for operation the expressions of eval_core / seg_dist above, in the same
-// order, without contraction: each half is bit-identical to eval_core on that face (the backward recomputes depths with
-// eval_core and compare them to the bit; tests/test_gpu_render.py).  Maxima, compares, selects and reciprocals have no packed form.
+// both faces).  Operation for operation the expressions of eval_core above, in the same order, without contraction: each half is
+// bit-identical to eval_core on that face (the second sweep and the backward recompute depths with eval_core and compare them to the bit;
+// tests/test_gpu_render.py).  Maxima, medians, compares, selects and reciprocals have no packed form.
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct Frag2 {
 	v2f w0, w1, w2, pz_clip, pz, dist;
@@ -297,35 +326,23 @@ struct Frag2 {
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f max2(v2f a, float b) { return v2f{fmaxf(a.x, b), fmaxf(a.y, b)}; }
 __device__ __forceinline__ v2f rcp2(v2f a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
-__device__ __forceinline__ v2f edge_fn2(v2f px, v2f py, v2f ax, v2f ay, v2f bx, v2f by) {
-#pragma clang fp contract(off)
-	return fma2(px - ax, by - ay, -((py - ay) * (bx - ax)));
-}
-__device__ __forceinline__ v2f seg_dist2(v2f px, v2f py, v2f ax, v2f ay, v2f bx, v2f by, v2f il) {
-#pragma clang fp contract(off)
-	const v2f bax = bx - ax, bay = by - ay;
-	const v2f u = fma2(bax, px - ax, bay * (py - ay)) * il;
-	v2f t;
-	t.x = il.x > 0.f ? fminf(fmaxf(u.x, 0.f), 1.f) : 1.0f;
-	t.y = il.y > 0.f ? fminf(fmaxf(u.y, 0.f), 1.f) : 1.0f;
-	const v2f qx = fma2(t, bax, ax) - px, qy = fma2(t, bay, ay) - py;
-	return fma2(qx, qx, qy * qy);
-}
-// blk: the pair's 40 floats in LDS, field j of face a at [2 j], of face b at [2 j + 1] (FaceRec's dword order)
+__device__ __forceinline__ v2f med2(v2f a) { return v2f{__builtin_amdgcn_fmed3f(a.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(a.y, 0.f, 1.f)}; }
+// blk: the pair's 64 floats in LDS, field j of face a at [2 j], of face b at [2 j + 1] (FaceRec's dword order)
 __device__ __forceinline__ void eval_pair(const float* blk, float pxs, float pys, Frag2* o) {
 #pragma clang fp contract(off)
-	const float4 r0 = *reinterpret_cast<const float4*>(blk), r1 = *reinterpret_cast<const float4*>(blk + 4), r2 = *reinterpret_cast<const float4*>(blk + 8);
-	const float4 r3 = *reinterpret_cast<const float4*>(blk + 12), r4 = *reinterpret_cast<const float4*>(blk + 16), r5 = *reinterpret_cast<const float4*>(blk + 20);
-	const float4 r6 = *reinterpret_cast<const float4*>(blk + 24);
-	const v2f x0 = {r0.x, r0.y}, y0 = {r0.z, r0.w}, x1 = {r1.x, r1.y}, y1 = {r1.z, r1.w}, x2 = {r2.x, r2.y}, y2 = {r2.z, r2.w};
-	const v2f z0 = {r3.x, r3.y}, z1 = {r3.z, r3.w}, z2 = {r4.x, r4.y}, ia = {r4.z, r4.w}, il01 = {r5.x, r5.y}, il02 = {r5.z, r5.w}, il12 = {r6.x, r6.y};
-	const v2f px = {pxs, pxs}, py = {pys, pys};
-	v2f w0 = edge_fn2(px, py, x1, y1, x2, y2) * ia;
-	v2f w1 = edge_fn2(px, py, x2, y2, x0, y0) * ia;
-	v2f w2 = edge_fn2(px, py, x0, y0, x1, y1) * ia;
-	const v2f t0 = w0 * z1 * z2, t1 = z0 * w1 * z2, t2 = z0 * z1 * w2;
+	const float4* b4 = reinterpret_cast<const float4*>(blk);
+	const float4 r0 = b4[0], r1 = b4[1], r2 = b4[2], r3 = b4[3], r4 = b4[4], r5 = b4[5], r6 = b4[6], r7 = b4[7], r8 = b4[8], r9 = b4[9], r10 = b4[10], r11 = b4[11];
+	const float4 r12 = b4[12], r13 = b4[13];
+	const v2f ox = {r0.x, r0.y}, oy = {r0.z, r0.w}, x1 = {r1.x, r1.y}, y1 = {r1.z, r1.w}, x2 = {r2.x, r2.y}, y2 = {r2.z, r2.w}, ex = {r3.x, r3.y}, ey = {r3.z, r3.w};
+	const v2f z0 = {r4.x, r4.y}, z1 = {r4.z, r4.w}, z2 = {r5.x, r5.y}, T0c = {r5.z, r5.w}, T0x = {r6.x, r6.y}, T0y = {r6.z, r6.w}, T1x = {r7.x, r7.y}, T1y = {r7.z, r7.w};
+	const v2f T2x = {r8.x, r8.y}, T2y = {r8.z, r8.w}, U0x = {r9.x, r9.y}, U0y = {r9.z, r9.w}, U0c = {r10.x, r10.y}, U1x = {r10.z, r10.w}, U1y = {r11.x, r11.y}, U1c = {r11.z, r11.w};
+	const v2f U2x = {r12.x, r12.y}, U2y = {r12.z, r12.w}, U2c = {r13.x, r13.y};
+	const v2f dx = v2f{pxs, pxs} - ox, dy = v2f{pys, pys} - oy;
+	const v2f t0 = fma2(T0x, dx, fma2(T0y, dy, T0c));
+	const v2f t1 = fma2(T1x, dx, T1y * dy);
+	const v2f t2 = fma2(T2x, dx, T2y * dy);
 	const v2f iden = rcp2(max2(t0 + t1 + t2, KEPS));
-	w0 = t0 * iden; w1 = t1 * iden; w2 = t2 * iden;
+	const v2f w0 = t0 * iden, w1 = t1 * iden, w2 = t2 * iden;
 	o->w0 = w0; o->w1 = w1; o->w2 = w2;
 	o->inside_a = w0.x > 0.f && w1.x > 0.f && w2.x > 0.f;
 	o->inside_b = w0.y > 0.f && w1.y > 0.f && w2.y > 0.f;
@@ -334,9 +351,13 @@ __device__ __forceinline__ void eval_pair(const float* blk, float pxs, float pys
 	c0 *= isum; c1 *= isum; c2 *= isum;
 	o->pz_clip = fma2(c2, z2, fma2(c1, z1, c0 * z0));
 	o->pz = fma2(w2, z2, fma2(w1, z1, w0 * z0));
-	const v2f e01 = seg_dist2(px, py, x0, y0, x1, y1, il01);
-	const v2f e02 = seg_dist2(px, py, x0, y0, x2, y2, il02);
-	const v2f e12 = seg_dist2(px, py, x1, y1, x2, y2, il12);
+	const v2f ta = med2(fma2(U0x, dx, fma2(U0y, dy, U0c)));
+	const v2f tb = med2(fma2(U1x, dx, fma2(U1y, dy, U1c)));
+	const v2f tc = med2(fma2(U2x, dx, fma2(U2y, dy, U2c)));
+	const v2f ax = fma2(ta, x1, -dx), ay = fma2(ta, y1, -dy);
+	const v2f bx = fma2(tb, x2, -dx), by = fma2(tb, y2, -dy);
+	const v2f cx = fma2(tc, ex, x1 - dx), cy = fma2(tc, ey, y1 - dy);
+	const v2f e01 = fma2(ax, ax, ay * ay), e02 = fma2(bx, bx, by * by), e12 = fma2(cx, cx, cy * cy);
 	// (the value eval_core's three-way choice ends up with is the smallest of the three)
 	o->dist = v2f{fminf(fminf(e01.x, e02.x), e12.x), fminf(fminf(e01.y, e02.y), e12.y)};
 }
@@ -350,7 +371,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 	x /= l; y /= l; z /= l;
 }
 
-// per (image, face): cull, the records (backward: 48 B; forward: the full 80 B), the tiles its blurred bbox touches, its nearest depth;
+// per (image, face): cull, the records (RGB backward: 48 B of raw vertices; fragment math: 128 B of affine forms), the tiles its blurred bbox touches, its nearest depth;
 // per run of 64 faces: their common tile bbox and depth statistics (zinfo_kernel folds those into the image's)
 __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
 								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
@@ -372,7 +393,7 @@ __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t
 		frec[o * 3 + 0] = ra; frec[o * 3 + 1] = rb; frec[o * 3 + 2] = rc;
 		const float br = sqrtf(blur_radius);
 		FaceRec r;
-		make_rec(ra, rb, rc, f, br, &r);
+		make_rec(x0, y0, z0, x1, y1, z1, x2, y2, z2, f, br, &r);
 		store_rec(recs + o, r);
 		const bool all_behind = z0 < z_clip && z1 < z_clip && z2 < z_clip;
 		const bool any_behind = z0 < z_clip || z1 < z_clip || z2 < z_clip;
@@ -780,13 +801,14 @@ struct RasterArgs {   // (what the rasteriser's loop needs and no more: the shad
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <bool want_sil, bool want_rgb>
-__global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ pool_all,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void raster_kernel(const RasterArgs a, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ pool_all,
 													  const int32_t* __restrict__ order) {
-	// the batch in flight, as PAIRS of faces: 32 blocks of 40 floats per wave, field j of the pair's faces at [2 j], [2 j + 1] (eval_pair);
-	// the radix search's counters live on top of it afterwards
-	__shared__ __attribute__((aligned(16))) float rec[4][64 * 20];
+	// the batch in flight, as PAIRS of faces: 32 blocks of 64 floats per wave, field j of the pair's faces at [2 j], [2 j + 1] (eval_pair);
+	// the second sweep stages flat records in it, the radix search's counters live on top of it afterwards
+	__shared__ __attribute__((aligned(16))) float rec[4][32 * PAIR_STRIDE];   // (>= 64 * REC_DW: the second sweep's flat records)
+	static_assert(32 * PAIR_STRIDE >= 64 * REC_DW, "the flat records of the second sweep share the pair blocks' space");
 	__shared__ unsigned band_n[4][192];   // second sweep: per pixel of the tile the band candidates delivered so far, bits of their smallest / largest depth
-	__shared__ unsigned item_q[4][128];   // second sweep: queue of (pixel, face) pairs waiting for evaluation
+	__shared__ unsigned short item_q[4][128];   // second sweep: queue of (pixel, face) pairs waiting for evaluation: pixel's lane << 8 | record
 
 	const int H = a.image_h, W = a.image_w;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -860,17 +882,19 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 			return e;
 		};
 		// stage a batch: the faces present are packed to the front (the no-room path tests every face of the image: most lanes hold none)
-		// and every lane scatters its face's 20 dwords into its half of a pair block; then every lane reads all the blocks.  Returns the count.
+		// and every lane scatters its face's 32 dwords into its half of a pair block; then every lane reads all the blocks.  Returns the count.
 		auto stage = [&](uint32_t e) __attribute__((always_inline)) -> int {
 			const unsigned long long m_have = __ballot(e != NONE);
 			if (e != NONE) {
 				const int pos = (int)__popcll(m_have & ((1ull << lane) - 1ull));
 				const float4* src = reinterpret_cast<const float4*>(rp_img + (e & FACE_MASK));
-				const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
-				float* d = &rec[wave][(pos >> 1) * 40 + (pos & 1)];
-				d[0] = q0.x; d[2] = q0.y; d[4] = q0.z; d[6] = q0.w; d[8] = q1.x; d[10] = q1.y; d[12] = q1.z; d[14] = q1.w;
-				d[16] = q2.x; d[18] = q2.y; d[20] = q2.z; d[22] = q2.w; d[24] = q3.x; d[26] = q3.y; d[28] = __int_as_float((int)(e >> 24));
-				d[32] = q4.x; d[34] = q4.y; d[36] = q4.z; d[38] = q4.w;
+				float4 q[REC_F4];
+#pragma unroll
+				for (int k = 0; k < REC_F4; ++k) q[k] = src[k];
+				q[6].w = __int_as_float((int)(e & FACE_MASK));   // (the record's own face index, as written by face_setup_kernel)
+				float* d = &rec[wave][(pos >> 1) * PAIR_STRIDE + (pos & 1)];
+#pragma unroll
+				for (int k = 0; k < REC_F4; ++k) { d[8 * k] = q[k].x; d[8 * k + 2] = q[k].y; d[8 * k + 4] = q[k].z; d[8 * k + 6] = q[k].w; }
 			}
 			wave_lds_sync();
 			return (int)__popcll(m_have);
@@ -932,17 +956,17 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 					else if ((chg >> (2 * t + 1)) & 3ull) s_new = __builtin_amdgcn_readlane(slab_v, 2 * t + 2);
 					if (s_new > s_front) RASTER_ADVANCE(s_new)
 				}
-				const float* blk = &rec[wave][t * 40];
+				const float* blk = &rec[wave][t * PAIR_STRIDE];
 				const bool two = 2 * t + 1 < nb;   // (an odd batch: the last block's second half is stale, and masked out)
 				// nobody who still needs faces lies inside either bbox: next (the far side of a closed surface goes by like this)
-				const float4 bx4 = *reinterpret_cast<const float4*>(blk + 32), by4 = *reinterpret_cast<const float4*>(blk + 36);
+				const float4 bx4 = *reinterpret_cast<const float4*>(blk + 56), by4 = *reinterpret_cast<const float4*>(blk + 60);
 				const bool inb_a = need & (px <= bx4.z) & (px >= bx4.x) & (py <= by4.z) & (py >= by4.x);
 				const bool inb_b = two & need & (px <= bx4.w) & (px >= bx4.y) & (py <= by4.w) & (py >= by4.y);
 				if (__ballot(inb_a | inb_b) == 0ull) continue;
 				if (a.ablate & 64) n_eval += two ? 2 : 1;
 				Frag2 fr2;
 				eval_pair(blk, px, py, &fr2);   // (every lane: the ones outside the bboxes compute along and are masked out below)
-				const float2 fid = *reinterpret_cast<const float2*>(blk + 26);   // the two face indices
+				const float2 fid = *reinterpret_cast<const float2*>(blk + 54);   // the two face indices
 #pragma unroll
 				for (int u = 0; u < 2; ++u) {
 					const bool inb = u ? inb_b : inb_a;
@@ -1010,24 +1034,24 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 				int n_eval2 = 0, n_staged2 = 0, n_items2 = 0;
 				// this lane's own slab range (an unsorted list carries no slabs: every face)
 				const int my_lo = sorted ? s_prev - 1 : -0x7FFFFFFF, my_hi = sorted ? s_at - 1 : 0x7FFFFFFF;
-				float* const recw = &rec[wave][0];                       // records of this sweep: FLAT, record j at [20 j]
+				float* const recw = &rec[wave][0];                       // records of this sweep: FLAT, piece k of record j at [REC_DW j + 4 (k ^ (j & 7))] (the swizzle spreads the 16-byte staging writes of neighbouring lanes over the banks)
 				unsigned* const bcnt = &band_n[wave][0];                 // [l]: band candidates of lane l's pixel so far; [64 + l], [128 + l]: bits of their smallest / largest depth
-				unsigned* const queue = &item_q[wave][0];                // ring of 128 items: pixel's lane << 8 | record
+				unsigned short* const queue = &item_q[wave][0];          // ring of 128 items
 				bcnt[lane] = 0u; bcnt[64 + lane] = 0x7F800000u; bcnt[128 + lane] = 0u;
 				int q_head = 0, q_n = 0;
 				for (int b = b_first; b <= b_last; ++b) {
 					int dummy;
 					uint32_t e = entry(b, &dummy);
 					if (sorted && e != NONE && ((int)(e >> 24) < s_lo || (int)(e >> 24) > s_hi)) e = NONE;   // only the faces of the slabs some hard pixel needs
-					// stage flat: 16-byte pieces of the record, its slab in the spare dword
+					// stage flat: the record's 16-byte pieces, the list entry (slab << 24 | face) in its id slot
 					const unsigned long long m_have = __ballot(e != NONE);
 					const int nb = (int)__popcll(m_have);
 					if (e != NONE) {
 						const int pos = (int)__popcll(m_have & ((1ull << lane) - 1ull));
 						const float4* src = reinterpret_cast<const float4*>(rp_img + (e & FACE_MASK));
-						const float4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
-						float4* d = reinterpret_cast<float4*>(recw + pos * 20);
-						d[0] = q0; d[1] = q1; d[2] = q2; d[3] = make_float4(q3.x, q3.y, __int_as_float((int)(e >> 24)), 0.f); d[4] = q4;
+						float4* d = reinterpret_cast<float4*>(recw + pos * REC_DW);
+#pragma unroll
+						for (int k = 0; k < REC_F4; ++k) { float4 q = src[k]; if (k == 6) q.w = __int_as_float((int)e); d[k ^ (pos & 7)] = q; }   // (the list entry in the id slot: slab << 24 | face)
 					}
 					wave_lds_sync();
 					n_staged2 += nb;
@@ -1035,12 +1059,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 					for (;;) {
 						// queue (pixel, face) pairs until 64 wait or the batch's faces are through
 						for (; j < nb && q_n < 64; ++j) {
-							const float4 bb = *reinterpret_cast<const float4*>(recw + j * 20 + 16);   // xmin xmax ymin ymax
-							const int sl = __float_as_int(recw[j * 20 + 14]);
+							const float4 bb = *reinterpret_cast<const float4*>(recw + j * REC_DW + 4 * (7 ^ (j & 7)));   // xmin xmax ymin ymax
+							const int sl = (int)((uint32_t)__float_as_int(recw[j * REC_DW + 4 * (6 ^ (j & 7)) + 3]) >> 24);
 							const bool want = hard & (sl >= my_lo) & (sl <= my_hi) & (px <= bb.y) & (px >= bb.x) & (py <= bb.w) & (py >= bb.z);
 							const unsigned long long wm = __ballot(want);
 							if (wm == 0ull) continue;
-							if (want) queue[(q_head + q_n + (int)__popcll(wm & ((1ull << lane) - 1ull))) & 127] = ((unsigned)lane << 8) | (unsigned)j;
+							if (want) queue[(q_head + q_n + (int)__popcll(wm & ((1ull << lane) - 1ull))) & 127] = (unsigned short)((lane << 8) | j);
 							q_n += (int)__popcll(wm);
 						}
 						if (q_n == 0) break;
@@ -1048,15 +1072,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 						// evaluate up to 64 of them, one per lane (the records are overwritten by the next batch: a batch drains its queue)
 						const int count = min(q_n, 64);
 						const bool act = lane < count;
-						const unsigned it = queue[(q_head + lane) & 127];
+						const unsigned it = (unsigned)queue[(q_head + lane) & 127];
 						const int hl = act ? (int)(it >> 8) : lane, jj = act ? (int)(it & 255u) : 0;
 						const int xh = tile_x * T8 + (hl & 7), yh = tile_y * T8 + (hl >> 3);
 						const float pxh = 1.0f - (2.0f * xh + 1.0f) / (float)W, pyh = 1.0f - (2.0f * yh + 1.0f) / (float)H;   // (the owner's px, py to the bit: the same expressions)
-						const float4* rj = reinterpret_cast<const float4*>(recw + jj * 20);
-						const float4 q0 = rj[0], q1 = rj[1], q2 = rj[2], q3 = rj[3];
-						FaceRec r;
-						r.x0 = q0.x; r.y0 = q0.y; r.x1 = q0.z; r.y1 = q0.w; r.x2 = q1.x; r.y2 = q1.y; r.z0 = q1.z; r.z1 = q1.w;
-						r.z2 = q2.x; r.inv_area = q2.y; r.il01 = q2.z; r.il02 = q2.w; r.il12 = q3.x; r.f = __float_as_int(q3.y);
+						FaceRec r = load_rec(reinterpret_cast<const float4*>(recw + jj * REC_DW), jj & 7);
+						r.f &= (int)FACE_MASK;
 						Frag fr;
 						eval_core(r, pxh, pyh, &fr);
 						// the band of the item's pixel lives in that pixel's lane
@@ -1409,8 +1430,7 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			// nearest edge (a,b), q = a + t (b - a):  d = |q - p|^2,  dd/da = 2 (1-t) (q - p),  dd/db = 2 t (q - p)
 			// (selects, no branches: edge 0: a = v0, b = v1;  edge 1: a = v0, b = v2;  edge 2: a = v1, b = v2)
 			const bool e0 = fr.edge == 0, e2 = fr.edge == 2;
-			const float ax = e2 ? r.x1 : r.x0, ay = e2 ? r.y1 : r.y0, bx = e0 ? r.x1 : r.x2, by = e0 ? r.y1 : r.y2;
-			const float qx = ax + fr.t * (bx - ax) - px, qy = ay + fr.t * (by - ay) - py;
+			const float qx = fr.qx, qy = fr.qy;   // (q - p comes with the fragment)
 			const float ga = gd * 2.0f * (1.0f - fr.t), gb = gd * 2.0f * fr.t;
 			const float wax = ga * qx, way = ga * qy, wbx = gb * qx, wby = gb * qy;
 			g0x += e2 ? 0.f : wax; g0y += e2 ? 0.f : way;
