@@ -367,7 +367,11 @@ def train3d_setup(run, n_items, batch_size, stage='net', labels=False, seed=0, d
 	bucket = None
 	if run.world > 1 and dp:
 		fdist.broadcast_parameters([p for p in m.parameters() if p.is_floating_point()])
-		bucket = fdist.GradBucket([p for p in m.parameters() if p.requires_grad])
+		# the MLP's weight gradients are complete when the main pass's MLP backward returns: their part of the bucket goes out there, under
+		# the loss-side tail of the backward (registration, latent scatter); the latent tables' part follows behind the backward
+		mlp_w = [p for seq in (m.base, m.mlp_disp, m.mlp_col) for p in seq.parameters()]
+		bucket = fdist.GradBucket([p for p in m.parameters() if p.requires_grad], early=mlp_w)
+		bucket.arm_early(m.base[0].weight)
 	flags = dict(chamf=True, smooth=net, texture=net)
 	if stage == 'reg':
 		flags = dict(chamf=True, smooth=False, gt_z_cutoff=opts.gt_z_cutoff)   # train.py:201, verbatim (gt_z_cutoff: None by default, opts.py:145)
@@ -384,8 +388,8 @@ def train3d_setup(run, n_items, batch_size, stage='net', labels=False, seed=0, d
 		loss, _ = mwl(b, 0, opts, **flags)
 		loss.backward()
 		if bucket is not None:
-			bucket.allreduce_(async_op=True)   # issued behind the backward's last kernel; nothing else of the step is independent of the gradients,
-			bucket.wait()                      # so the wait follows at once (the host does not block: stream-side dependency)
+			bucket.allreduce_(async_op=True)   # the latent tables' part (the weights' part left inside the backward: GradBucket.arm_early);
+			bucket.wait()                      # the optimiser needs both: the wait follows at once (stream-side dependency, the host does not block)
 		opt.step()
 		return loss
 
@@ -409,7 +413,8 @@ def train3d_setup(run, n_items, batch_size, stage='net', labels=False, seed=0, d
 			bucket.wait()
 		e1.record()
 		e1.synchronize()
-		return dict(backend=dist.get_backend(), world_size=dist.get_world_size(), bucket_bytes=bucket.numel * 4, op='AVG in place' if dist.get_backend() == 'nccl' else 'SUM + divide',
+		return dict(backend=dist.get_backend(), world_size=dist.get_world_size(), bucket_bytes=bucket.numel * 4, early_prefix_bytes=bucket.n_early * 4,
+					steps_with_early_prefix=bucket.early_issued, op='AVG in place' if dist.get_backend() == 'nccl' else 'SUM + divide',
 					allreduce_us_per_step=e0.elapsed_time(e1) / iters * 1e3, ranks_devices=[f"{r['rank']}:{r['device']}" + (f"@{r['pci_bus']}" if r['pci_bus'] is not None else '') for r in ranks],
 					distinct_devices=len({(r['device'], r['pci_bus'], r['uuid']) for r in ranks}))
 

@@ -15,17 +15,17 @@
 //   4. raster_kernel    : persistent waves take tiles from the queues; a wave stages 64 face records at a time in LDS and every lane
 //      evaluates them for its own pixel -- no workgroup barrier anywhere.  Faces arrive front to back, so a pixel that already holds
 //      faces_per_pixel candidates in front of everything still to come is FINISHED, and the wave leaves the list when all its pixels
-//      are (an interior pixel of a closed surface never looks at the far side).  No per-pixel candidate lists: a pixel keeps counts and
-//      products of (1 - p) per depth band in front of / behind the moving front; the band in which the count crosses K holds the K-th
-//      nearest, and only pixels with more than K candidates re-evaluate the few batches that reach that band, keep ITS candidates
-//      (depth, 1 - p, face id) in the wave's scratch and select by a radix search on the depth bits, ties at the K-th depth by face
-//      index (PyTorch3D keeps, among candidates of EQUAL depth at the K-th place, those of lower face index: insertion order).  The
-//      K-th depth bound (and the id of the last face kept among ties) is saved for the backward.  The tail hands the nearest inside
-//      fragment to shade_kernel, writes mask / alpha.
+//      are (an interior pixel of a closed surface never looks at the far side).  Candidates (depth, 1 - p) go to the lane's own
+//      list in the wave's scratch (32-byte pieces, the 64 lanes' pieces side by side) through an LDS ring; a pixel with more than K of them selects the K nearest by a radix search on
+//      its own list (the K-th depth is saved for the backward).  The tail shades the nearest inside fragment, writes mask / image.
+//   5. tie_fix_kernel   : PyTorch3D keeps, among candidates of EQUAL depth at the K-th place, those of lower face index (insertion
+//      order).  Lists are in depth order, not face order, so pixels where candidates tied at the K-th depth were left out are
+//      queued and re-evaluated here with face ids at hand (a wave per pixel): exact K-buffer semantics, and the id of the last
+//      face kept goes to the backward.
 //   6. backward: silhouette gradient is FACE-centric (lanes walk the blurred bbox of their face and accumulate the six NDC gradients
 //      in registers: no per-fragment atomics); projection backward is a deterministic sum over views.
 // Every kernel evaluates a (pixel, face) pair with the SAME rounding (eval_frag is compiled without fp contraction, its fused
-// multiply-adds are written out): the depth a candidate had in the forward is the depth the second sweep and the backward recompute.
+// multiply-adds are written out): the depth a candidate had in the forward is the depth the fix-up and the backward recompute.
 // Conventions: SURVEY.md Appendix A.2-A.4 (row-vector transforms, NDC +x left / +y up, image = mesh*n_views + view).
 #include <type_traits>
 
@@ -39,8 +39,9 @@ constexpr int T8 = 8;             // tile edge in pixels: one wave per tile
 constexpr float KEPS = 1e-8f;
 constexpr uint32_t TB_EMPTY = 0x000000FFu;  // tx0 = 255 > tx1 = 0
 constexpr int KU = 16;            // list entries in flight per lane in the K-nearest passes (they are L2-latency-bound)
-constexpr int KN_CAP = 4096;      // candidates of the crossing band kept per pixel for the K-nearest rule (more: unresolved, flags[1]); the pole of a 10 002-vertex lat-long scan @256^2 collects ~2000 in all
-constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 independent waves each); each owns 256 x KN_CAP x 12 B of scratch
+constexpr int KN_CAP = 4096;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1]); the pole of a 10 002-vertex lat-long scan @256^2 collects ~2000
+constexpr int RING = 8;           // candidates a lane collects in LDS before it writes them out: 2 x 32 contiguous bytes per flush
+constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 independent waves each); each owns 256 x KN_CAP x 8 B of scratch
 constexpr int BIN_CAP = 2048;     // list entries a binning wave keeps (and sorts) in LDS; a longer list goes out in face order, without the early exit
 constexpr int N_SLABS = 255;      // depth slabs per image (8 bits of a list entry; the other 24 are the face index)
 constexpr int N_QUEUES = 24;      // tile queues by log2(list length), the longest lists first
@@ -50,6 +51,13 @@ constexpr uint32_t FACE_MASK = 0x00FFFFFFu;
 constexpr int REC_F4 = 8;         // 16-byte pieces of a face record (FaceRec)
 constexpr int REC_DW = 32;        // its dwords
 constexpr int PAIR_STRIDE = 68;   // floats between two pair blocks of the rasteriser's LDS staging: 2 x REC_DW + 4 (a stride of 64 dwords put every block on the same two banks: 32-way conflicts on the staging writes)
+
+struct Fix {      // a pixel whose K-th depth is shared by more candidates than fit: resolved by tie_fix_kernel
+	int32_t pix;      // (img * H + y) * W + x
+	uint32_t zk;      // bits of the K-th depth
+	int32_t keep;     // how many of the candidates at that depth belong to the K nearest
+	float a_lt;       // product of (1 - p) over the candidates in front of it
+};
 
 struct FaceRec;
 struct Ws {
@@ -68,16 +76,17 @@ struct Ws {
 	float* d_vproj;   // (n_img, V, 3) backward accumulator
 	float* d_normals; // (n_meshes, V, 3) backward accumulator
 	float* raw_normals; // (n_meshes, V, 3) un-normalised vertex-normal sums (backward)
-	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tiles taken from the queues, [4] pixels that took the second sweep, [5] largest band, [6] pool cursor, [24..] diagnostics
+	int32_t* flags;   // [0] straddling faces seen, [1] overflow pixels left unresolved (> KN_CAP candidates), [3] tiles taken from the queues, [6] pool cursor, [7] fix-up entries, [8..] diagnostics
 	int32_t* qn;      // [0..N_QUEUES) tiles per list-length class, [32..32+N_QUEUES) fill cursors of the classes, [62] tiles with a list
 	int32_t* cursor;  // (n_img) entries handed out of each image's part of the pool
 	float* zthr;      // (n_img, H, W) depth bound of the K nearest silhouette candidates (+inf: every candidate counts; negative: -depth, ties at it resolved by tie_face)  [backward]
 	float* alpha;     // (n_img, H, W) prod (1 - p_k) over the blended candidates  [backward: 1 - mask has lost it wherever the mask rounds to 1]
 	int32_t* tie_face; // (n_img, H, W) last face kept among those tied at the K-th depth (valid where zthr < 0)  [backward]
-	float* scratch;   // (raster waves, 3, KN_CAP, 64) crossing-band candidates of the tile in flight: depths, 1 - p, face ids; entry j of lane l at [j * 64 + l]
+	float2* scratch;  // (raster workgroups, 2, 256, KN_CAP) per-pixel candidate lists of the tile in flight: depths, then 1 - p; per wave, 32-byte piece k of lane l at piece index 64 k + l
 	int2* tinfo;      // (n_img, tiles) list of a tile: x = offset into pool, y = length | LIST_UNSORTED, or -1: no room in the pool (the rasteriser scans the faces itself)
 	uint32_t* pool;   // list entries: slab << 24 | face
 	int32_t* order;   // (n_img * tiles) ids of the tiles that have a list, the longest lists first
+	Fix* fix;         // (n_img * H * W) fix-up queue
 	int64_t pool_cap, n_tiles, raster_wgs;
 	int64_t bytes;
 };
@@ -111,7 +120,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->tie_face = c.take<int32_t>(px);
 	o->n_tiles = n_img * cdiv(rp->image_w, T8) * cdiv(rp->image_h, T8);
 	o->raster_wgs = std::min<int64_t>(cdiv(o->n_tiles, 4), RASTER_WGS);
-	o->scratch = c.take<float>(o->raster_wgs * 4 * 3 * KN_CAP * 64);
+	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
 	o->tinfo = c.take<int2>(o->n_tiles);
 	// a face of ~1 pixel with the silhouette's blur margin touches ~4.5 tiles at 256^2 and ~10 at 512^2; a tile that finds the pool
 	// full is rasterised from the face arrays directly (slower, never wrong)
@@ -119,6 +128,7 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->pool_cap = std::min<int64_t>(F * 16 + (1 << 14), ((int64_t)1 << 30) / n_img);
 	o->pool = c.take<uint32_t>(o->pool_cap * n_img);
 	o->order = c.take<int32_t>(o->n_tiles);
+	o->fix = c.take<Fix>(px);
 	o->bytes = c.off;
 }
 
@@ -170,7 +180,7 @@ __global__ void project_bwd_kernel(const float* __restrict__ verts, const float*
 
 // ------------------------------------------------------------------------------------------------ 2. face setup
 // (pixel, face) arithmetic below is compiled WITHOUT floating-point contraction and its fused multiply-adds are explicit: the
-// compiler may otherwise fuse the same expression differently in the rasteriser's two sweeps and the backward, and a candidate's
+// compiler may otherwise fuse the same expression differently in the rasteriser, the tie fix-up and the backward, and a candidate's
 // depth is compared bit for bit between them.
 __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
 #pragma clang fp contract(off)
@@ -371,7 +381,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 	x /= l; y /= l; z /= l;
 }
 
-// per (image, face): cull, the records (RGB backward: 48 B of raw vertices; fragment math: 128 B of affine forms), the tiles its blurred bbox touches, its nearest depth;
+// per (image, face): cull, the records (backward: 48 B; forward: the full 80 B), the tiles its blurred bbox touches, its nearest depth;
 // per run of 64 faces: their common tile bbox and depth statistics (zinfo_kernel folds those into the image's)
 __global__ void face_setup_kernel(const float* __restrict__ vproj, const int32_t* __restrict__ faces, int64_t faces_mesh_stride,
 								  int n_views, int V, int F, int H, int W, float blur_radius, float z_clip,
@@ -522,9 +532,11 @@ struct TileArgs {
 	float* zthr;
 	float* alpha_ws;
 	int32_t* tie_face;
+	float2* scratch;
 	int2* tinfo;
 	uint32_t* pool;
 	int32_t* order;
+	Fix* fix;
 	int64_t pool_cap;
 	int tiles_per_img, total_tiles;
 	int ablate;              // profiling only (find_debug_raster_ablate): 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 8 no early exit, 16 lists unsorted, 32 no scan, 64 counters, 256 tiny list pool
@@ -548,7 +560,7 @@ __device__ __forceinline__ float slab_front(int s, float zlo, float w) { return 
 
 // One wave: its LDS operations execute in order, so all a "barrier" has to do is keep the compiler from moving LDS accesses across it and
 // wait for the LDS counter.  (NOT an acquire / release fence: those also wait for the wave's outstanding GLOBAL stores -- the list
-// entries on their way to the pool, the band candidates on their way to the scratch -- microseconds each, twice per 64 faces.)
+// entries on their way to the pool, the candidate pieces on their way to the scratch -- microseconds each, twice per 64 faces.)
 __device__ __forceinline__ void wave_lds_sync() {
 	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();
@@ -763,21 +775,14 @@ __global__ __launch_bounds__(1024) void order_fill_kernel(const int2* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ 4. rasteriser
-// Persistent waves, each a worker of its own: tile from the queues -> list from the pool, 64 faces at a time (the next 64 entries are on
-// their way from memory while these are evaluated) -> every lane evaluates the staged records for its own pixel.
-//
-// The K-nearest rule WITHOUT per-pixel candidate lists (round 5; rounds 2-4 appended every candidate -- depth, 1 - p: 8 B -- to a list in
-// scratch memory and searched it afterwards: 0.42 GB written and ~0.5 GB re-read per C3 launch, 1.7 GB at 512^2, a third to a half of the
-// kernel's time).  The list is in depth-slab order: while batch i is evaluated every face still to come lies behind `front` (F_i, the lower
-// edge of the next batch's first slab), so at the end of batch i the number of candidates in front of F_i, N_i, is FINAL.  A pixel keeps
-// counts and PRODUCTS of (1 - p) in three bands -- in front of F_i, within one slab behind it, further back (never beyond two) -- which
-// move up as the front moves.  N_i < K: those candidates all belong to the K nearest, their product is all that is needed of them.  The
-// first i with N_i >= K ("crossing") fixes the band [F_{i-1}, F_i) that holds the K-th nearest: N_i == K -- alpha is the product in front
-// of F_i, done; N_i > K -- the (K - N_{i-1})-th smallest depth of THAT BAND decides.  Only for those pixels a second sweep re-evaluates
-// the few batches whose slabs can reach their band (face ids at hand), writes the band's candidates (depth, 1 - p, face: a tenth of what
-// the lists held) to the lane's scratch, finds the rank by a radix search on the depth bits and resolves ties at the K-th depth by face
-// index right there (PyTorch3D's K-buffer keeps the lower indices: rounds 2-4 needed a fix-up kernel with a queue for that).
-// A pixel that never crosses has fewer than K candidates: alpha is the product of all of them.
+// Persistent waves, each a worker of its own: tile from the queues -> list from the pool, 64 faces at a time (the next 64 records are on
+// their way from memory while these are evaluated) -> every lane evaluates the staged records for its own pixel.  Silhouette candidates
+// multiply into the pixel's alpha and are appended (depth, 1 - p) to the lane's own list in the wave's scratch through an
+// LDS ring (whole 32-byte pieces, written once; piece k of the 64 lanes side by side).  The list is in depth-slab order: after a batch, every face still to come lies behind
+// `front`, so a pixel that holds K candidates in front of `front` has its K nearest, and a pixel whose nearest inside fragment lies in
+// front of it has its colour -- the wave leaves the list when every pixel is finished.  A pixel that ends with more than K candidates
+// finds the K-th smallest depth of its list by a lane-parallel radix search and blends the K nearest; where candidates tied at that depth
+// were left out the pixel is queued for tie_fix_kernel (PyTorch3D's K-buffer keeps the lower face indices: needs ids, which lists omit).
 struct RasterArgs {   // (what the rasteriser's loop needs and no more: the shading tail and its dozen pointers live in shade_kernel)
 	float sil_blur_radius, sil_sigma;
 	int sil_faces_per_pixel, image_h, image_w;
@@ -793,22 +798,21 @@ struct RasterArgs {   // (what the rasteriser's loop needs and no more: the shad
 	const int32_t* qn;
 	float* zthr;
 	float* alpha_ws;
-	int32_t* tie_face;
-	float* scratch;
+	float2* scratch;
+	Fix* fix;
 	int ablate;
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-
 template <bool want_sil, bool want_rgb>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void raster_kernel(const RasterArgs a, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ pool_all,
+__global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const FaceRec* __restrict__ recs, const uint32_t* __restrict__ pool_all,
 													  const int32_t* __restrict__ order) {
-	// the batch in flight, as PAIRS of faces: 32 blocks of 64 floats per wave, field j of the pair's faces at [2 j], [2 j + 1] (eval_pair);
-	// the second sweep stages flat records in it, the radix search's counters live on top of it afterwards
-	__shared__ __attribute__((aligned(16))) float rec[4][32 * PAIR_STRIDE];   // (>= 64 * REC_DW: the second sweep's flat records)
-	static_assert(32 * PAIR_STRIDE >= 64 * REC_DW, "the flat records of the second sweep share the pair blocks' space");
-	__shared__ unsigned band_n[4][192];   // second sweep: per pixel of the tile the band candidates delivered so far, bits of their smallest / largest depth
-	__shared__ unsigned short item_q[4][128];   // second sweep: queue of (pixel, face) pairs waiting for evaluation: pixel's lane << 8 | record
+	// the batch in flight, as PAIRS of faces: 32 blocks of 64 (+ 4: PAIR_STRIDE) floats per wave, field j of the pair's faces at [2 j], [2 j + 1]
+	// (eval_pair); the K-nearest search's counters live on top of it afterwards
+	__shared__ __attribute__((aligned(16))) float rec[4][32 * PAIR_STRIDE];
+	// write-combining rings of the candidate lists: [slot][thread], so that a wave's appends (different slots per lane) never conflict
+	__shared__ float ring_z[RING][256];
+	__shared__ float ring_q[RING][256];
 
 	const int H = a.image_h, W = a.image_w;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -817,13 +821,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 	const int K = a.sil_faces_per_pixel;
 	const bool early = !(a.ablate & 8);
 	const int n_order = a.qn[62];
-	// band candidates of the second sweep: entry j of lane l at [j * 64 + l] of the wave's three arrays (depth, 1 - p, face)
-	float* const wz0 = a.scratch + ((int64_t)blockIdx.x * 4 + wave) * (3 * (int64_t)KN_CAP * 64);
-	float* const wq0 = wz0 + KN_CAP * 64;
-	int* const wf0 = reinterpret_cast<int*>(wq0 + KN_CAP * 64);
-	float* const wz = wz0 + lane;   // this lane's column
-	float* const wq = wq0 + lane;
-	int* const wf = wf0 + lane;
+	// Candidate lists: every pixel (thread) owns up to KN_CAP depths and KN_CAP (1 - p) values.  A lane collects RING candidates in LDS and
+	// writes them out as whole 32-byte pieces (two 16-byte stores per array): the lists reach memory as full sectors, once.
+	// Layout of a wave's lists: 32-byte piece k of lane l at piece index k * 64 + l -- the pieces of the 64 lanes side by side.  Lanes of
+	// a tile fill their pieces at about the same pace, so L2 completes 128-byte lines out of four lanes' pieces before it evicts them, and
+	// the K-nearest pass reads "16 bytes of every lane's piece k" as one coalesced 2-KB access (a lane-contiguous run of KN_CAP entries
+	// per lane put every 32-byte piece into a DRAM row of its own and every list read into 64 different lines).
+	float4* const wz4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.scratch + (int64_t)blockIdx.x * KN_CAP * 256) + wave * (KN_CAP * 64));
+	float4* const wq4 = wz4 + KN_CAP * 256 / 4;
+	auto lidx = [&](int j) __attribute__((always_inline)) { return ((j >> 1) * 64 + lane) * 2 + (j & 1); };   // 16-byte word j of this lane's list
+	auto flush_ring = [&](int base, int valid) __attribute__((always_inline)) {   // ring -> list entries [base, base + RING); slots >= valid become (+inf, 1): never selected
+		float zv[RING], qv[RING];
+#pragma unroll
+		for (int u = 0; u < RING; ++u) {
+			zv[u] = u < valid ? ring_z[u][tid] : INFINITY;
+			qv[u] = u < valid ? ring_q[u][tid] : 1.0f;
+		}
+#pragma unroll
+		for (int u = 0; u < RING; u += 4) {
+			wz4[lidx((base + u) >> 2)] = make_float4(zv[u], zv[u + 1], zv[u + 2], zv[u + 3]);
+			wq4[lidx((base + u) >> 2)] = make_float4(qv[u], qv[u + 1], qv[u + 2], qv[u + 3]);
+		}
+	};
 
 	// (Measured and dropped: every wave's first tile by its own number instead of from the counter -- the 4096 first requests queue up
 	// for ~48 us on that one address -- made the kernel 0.4 ms SLOWER: the staggered start spreads the longest lists, which all sit at
@@ -851,111 +870,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 		const FaceRec* rp_img = recs + (int64_t)img * a.F;
 		const uint32_t* lp = pool_all + (int64_t)img * a.pool_cap + ti.x;
 
-		// silhouette state of this lane's pixel: candidates (count, product of 1 - p) in front of `front`, within one slab behind it, further back
-		int c_lt = 0, c_a = 0, c_b = 0;
-		float a_lt = 1.0f, a_a = 1.0f, a_b = 1.0f;
-		// the last batch end at which fewer than K lay in front of the front (N_{i-1}, their product, F_{i-1} and its slab) ...
-		int n_prev = 0, s_prev = -2;
-		float a_prev = 1.0f, f_prev = 0.0f;
-		// ... and the first at which K or more do: the crossing
-		bool crossed = false;
-		int n_at = 0, s_at = 0;
-		float a_at = 1.0f, f_at = INFINITY;
+		float alpha = 1.0f, z_lo = INFINITY, z_hi = 0.0f;
+		int cnt = 0, c_lt = 0, c_a = 0, c_b = 0;   // candidates in front of `front`, within one slab behind it, further back (never beyond two)
 		int n_eval = 0;
 		float bz = INFINITY, bd = 0.f, bw0 = 0.f, bw1 = 0.f, bw2 = 0.f;
 		int bf = -1;
 		float front = 0.0f, front1 = 0.0f;   // every face not yet evaluated has its fragments behind `front`; front1: one slab further
 		int s_front = -2;                   // slab whose lower edge `front` is
+		bool stopped = false;               // the wave left the list early
 
-		// entry of this lane in batch b: slab << 24 | face index (NONE: no face); *slab0: the slab of the batch's first entry
-		constexpr uint32_t NONE = 0xFFFFFFFFu;
-		auto entry = [&](int b, int* slab0) __attribute__((always_inline)) -> uint32_t {
+		// entry of this lane in batch b: face index (or -1); *slab0: the slab of the batch's first entry
+		auto entry = [&](int b, int* slab0) __attribute__((always_inline)) -> int {
 			const int i = b * 64 + lane;
-			uint32_t e = NONE, e0 = 0u;
+			int f = -1;
+			uint32_t e0 = 0u;
 			if (binned) {
-				if (i < n_list) e = lp[i];
+				if (i < n_list) f = (int)(lp[i] & FACE_MASK);
 				if (b * 64 < n_list) e0 = lp[b * 64];
 			} else if (i < n_list && tile_hit(tbp[i], tile_x, tile_y)) {
-				e = (uint32_t)i;   // no room in the pool for this tile's list: every face of the image, tested here (slab 0: no front to back order)
+				f = i;   // no room in the pool for this tile's list: every face of the image, tested here
 			}
 			*slab0 = (int)(e0 >> 24);
-			return e;
+			return f;
 		};
-		// stage a batch: the faces present are packed to the front (the no-room path tests every face of the image: most lanes hold none)
-		// and every lane scatters its face's 32 dwords into its half of a pair block; then every lane reads all the blocks.  Returns the count.
-		auto stage = [&](uint32_t e) __attribute__((always_inline)) -> int {
-			const unsigned long long m_have = __ballot(e != NONE);
-			if (e != NONE) {
+		const int n_batches = (n_list + 63) >> 6;
+		int slab_next = 0, slab_cur = 0;
+		int f_cur = entry(0, &slab_cur);
+		int f_next = n_batches > 1 ? entry(1, &slab_next) : -1;
+		for (int b = 0; b < n_batches; ++b) {
+			const bool more = b + 1 < n_batches;
+			const int slab_after = slab_next;
+			const int f_lane = f_cur;
+			if (more) {
+				f_cur = f_next;
+				f_next = b + 2 < n_batches ? entry(b + 2, &slab_next) : -1;   // (the entries two batches ahead are on their way while this one is evaluated)
+			}
+			// a pixel that holds its K nearest (and its colour) in front of everything from this batch on needs nothing more
+			const bool fin = !in_img || ((!want_sil || c_lt >= K) && (!want_rgb || bz < front));
+			const bool need = (early ? !fin : in_img) && !(a.ablate & 4);
+			// What is still to come AFTER this batch lies behind the lower edge of the next batch's first slab.  The candidates seen so far
+			// come from faces of slabs up to that one, so none lies two slabs behind the old edge: when the edge moves by one slab, those
+			// within a slab of the old one are now in front, the rest are within a slab of the new one; by more, all are in front.
+			if (!more) { c_lt += c_a + c_b; c_a = c_b = 0; front = front1 = INFINITY; }
+			else if (sorted && slab_after > s_front) {
+				if (slab_after == s_front + 1) { c_lt += c_a; c_a = c_b; } else { c_lt += c_a + c_b; c_a = 0; }
+				c_b = 0;
+				s_front = slab_after;
+				front = slab_front(slab_after, zlo, sw); front1 = slab_front(slab_after + 1, zlo, sw);
+			}
+			// stage the batch: the faces present are packed to the front (the no-room path tests every face of the image: most lanes hold
+			// none) and every lane scatters its face's 32 dwords into its half of a pair block; then every lane reads all the blocks
+			const unsigned long long m_have = __ballot(f_lane >= 0);
+			const int nb = (int)__popcll(m_have);
+			if (f_lane >= 0) {
 				const int pos = (int)__popcll(m_have & ((1ull << lane) - 1ull));
-				const float4* src = reinterpret_cast<const float4*>(rp_img + (e & FACE_MASK));
+				const float4* src = reinterpret_cast<const float4*>(rp_img + f_lane);
 				float4 q[REC_F4];
 #pragma unroll
 				for (int k = 0; k < REC_F4; ++k) q[k] = src[k];
-				q[6].w = __int_as_float((int)(e & FACE_MASK));   // (the record's own face index, as written by face_setup_kernel)
 				float* d = &rec[wave][(pos >> 1) * PAIR_STRIDE + (pos & 1)];
 #pragma unroll
 				for (int k = 0; k < REC_F4; ++k) { d[8 * k] = q[k].x; d[8 * k + 2] = q[k].y; d[8 * k + 4] = q[k].z; d[8 * k + 6] = q[k].w; }
 			}
 			wave_lds_sync();
-			return (int)__popcll(m_have);
-		};
-		// RASTER_CHECKPOINT: the count in front of the CURRENT front is final whenever this runs (before the front moves, at a batch end): the
-		// first time it reaches K is the crossing.  (A pixel that goes on for its colour after the crossing keeps counting: what the crossing
-		// recorded is frozen.)  RASTER_ADVANCE(s_new): what is still to come lies behind the lower edge of slab s_new (the slab of the first
-		// face not yet evaluated; N_SLABS + 1: nothing is).  The candidates seen so far come from faces of slabs up to that one, so none lies
-		// two slabs behind the old edge: when the edge moves by one slab, those within a slab of the old one are now in front, the rest are
-		// within a slab of the new one; by more, all are in front.
-		// (Macros, and selects on VALUES: as lambdas capturing by reference -- and with `if (now) { n_at = ...; }` -- the compiler formed
-		// stores through SELECTED ADDRESSES and kept this state in scratch memory, in the innermost loop.)
-#define RASTER_CHECKPOINT()                                                                                                                       \
-		if (want_sil) {                                                                                                                           \
-			const bool now_ = !crossed & (c_lt >= K);                                                                                             \
-			n_at = now_ ? c_lt : n_at; a_at = now_ ? a_lt : a_at; f_at = now_ ? front : f_at; s_at = now_ ? s_front : s_at;                      \
-			crossed |= now_;                                                                                                                      \
-			n_prev = crossed ? n_prev : c_lt; a_prev = crossed ? a_prev : a_lt; f_prev = crossed ? f_prev : front; s_prev = crossed ? s_prev : s_front; \
-		}
-#define RASTER_ADVANCE(s_new_)                                                                                                                    \
-		{                                                                                                                                         \
-			RASTER_CHECKPOINT();                                                                                                                  \
-			const int sn_ = (s_new_);                                                                                                             \
-			const bool one_ = sn_ == s_front + 1, end_ = sn_ > N_SLABS;                                                                          \
-			const int ca_ = c_a, cb_ = c_b;                                                                                                       \
-			const float aa_ = a_a, ab_ = a_b;                                                                                                     \
-			c_lt += one_ ? ca_ : ca_ + cb_; a_lt *= one_ ? aa_ : aa_ * ab_;                                                                       \
-			c_a = one_ ? cb_ : 0; a_a = one_ ? ab_ : 1.0f;                                                                                        \
-			c_b = 0; a_b = 1.0f;                                                                                                                  \
-			front = end_ ? INFINITY : slab_front(sn_, zlo, sw); front1 = end_ ? INFINITY : slab_front(sn_ + 1, zlo, sw);                          \
-			s_front = sn_;                                                                                                                        \
-		}
-		const int n_batches = (n_list + 63) >> 6;
-		int slab_next = 0, slab_cur = 0;
-		uint32_t e_cur = entry(0, &slab_cur);
-		uint32_t e_next = n_batches > 1 ? entry(1, &slab_next) : NONE;
-		for (int b = 0; b < n_batches; ++b) {
-			const bool more = b + 1 < n_batches;
-			const int slab_after = more ? (sorted ? slab_next : s_front) : N_SLABS + 1;   // slab of the first face after this batch
-			const uint32_t e_lane = e_cur;
-			if (more) {
-				e_cur = e_next;
-				e_next = b + 2 < n_batches ? entry(b + 2, &slab_next) : NONE;   // (the entries two batches ahead are on their way while this one is evaluated)
-			}
-			// a pixel that holds its K nearest (and its colour) in front of everything from this batch on needs nothing more
-			const bool fin = !in_img || ((!want_sil || c_lt >= K) && (!want_rgb || bz < front));
-			const bool need = (early ? !fin : in_img) && !(a.ablate & 4);
-			const int nb = stage(e_lane);
-			const int slab_v = (int)(e_lane >> 24);   // (sorted lists are binned: position in the batch = lane)
-			// positions of the batch at which a new slab begins (bit p: entry p starts one), plus the position behind the batch's last entry
-			const unsigned long long chg = sorted ? (__ballot(lane > 0 && lane < nb && slab_v != __shfl_up(slab_v, 1, 64)) | (nb < 64 ? 1ull << nb : 0ull)) : 0ull;
 			for (int t = 0; 2 * t < nb; ++t) {   // two faces per turn, in packed arithmetic
-				// the front moves with every PAIR behind which a new slab begins (round 5; per batch of 64 before): the faces behind this pair
-				// start at the slab of entry 2 t + 2 -- a band is then one slab wide, not one batch deep.  (Scalar bit tests per pair; the
-				// band bookkeeping runs only where a slab begins.)
-				{
-					int s_new = s_front;
-					if (2 * t + 2 >= nb) s_new = slab_after;
-					else if ((chg >> (2 * t + 1)) & 3ull) s_new = __builtin_amdgcn_readlane(slab_v, 2 * t + 2);
-					if (s_new > s_front) RASTER_ADVANCE(s_new)
-				}
 				const float* blk = &rec[wave][t * PAIR_STRIDE];
 				const bool two = 2 * t + 1 < nb;   // (an odd batch: the last block's second half is stale, and masked out)
 				// nobody who still needs faces lies inside either bbox: next (the far side of a closed surface goes by like this)
@@ -975,10 +953,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 					if (want_sil) {
 						const bool cand = inb & (f_pzc >= 0.f) & (f_inside | (f_dist < blur));
 						if (cand) {
-							const float q = 1.0f - silhouette_prob(f_inside ? -f_dist : f_dist, inv_sigma);
-							const bool lt = f_pzc < front, la = !lt & (f_pzc < front1), lb = !(lt | la);
-							c_lt += lt ? 1 : 0; c_a += la ? 1 : 0; c_b += lb ? 1 : 0;
-							a_lt *= lt ? q : 1.0f; a_a *= la ? q : 1.0f; a_b *= lb ? q : 1.0f;
+							const float prob = silhouette_prob(f_inside ? -f_dist : f_dist, inv_sigma);
+							alpha *= (1.0f - prob);
+							if (cnt < KN_CAP && !(a.ablate & 1)) {
+								const int slot = cnt & (RING - 1);
+								ring_z[slot][tid] = f_pzc; ring_q[slot][tid] = 1.0f - prob;
+								if (slot == RING - 1) flush_ring(cnt - (RING - 1), RING);
+							}
+							++cnt;
+							c_lt += f_pzc < front ? 1 : 0;
+							c_a += (f_pzc >= front) & (f_pzc < front1) ? 1 : 0;
+							c_b += f_pzc >= front1 ? 1 : 0;
+							z_lo = fminf(z_lo, f_pzc); z_hi = fmaxf(z_hi, f_pzc);  // depth range of the candidates (bounds of the radix search)
 						}
 					}
 					if (want_rgb) {
@@ -991,169 +977,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 					}
 				}
 			}
-			if (nb == 0 && slab_after > s_front) RASTER_ADVANCE(slab_after)   // (a batch of the no-room path in which no face reaches the tile)
 			wave_lds_sync();   // the records are overwritten by the next batch
-			RASTER_CHECKPOINT()
 			if (early && more) {
 				const bool fin2 = !in_img || ((!want_sil || c_lt >= K) && (!want_rgb || bz < front));
-				if (__ballot(!fin2) == 0ull) break;
+				if (__ballot(!fin2) == 0ull) { stopped = true; break; }
 			}
 		}
 
-#undef RASTER_ADVANCE
-#undef RASTER_CHECKPOINT
-		float alpha = 1.0f, thr = INFINITY;
-		int tie = -1;
+		// ---- K-nearest rule for the pixels that collected more than K candidates.  Lane-parallel and exact: every such
+		// lane finds the K-th smallest depth of its OWN list (16-byte reads of its pieces) by a radix search
+		// on the integer image of the depth (non-negative floats order like their bit patterns) with one counting pass per
+		// step, then blends the candidates in front of it and as many of those AT it as still fit.
+		float thr = INFINITY;
 		if (want_sil) {
-			alpha = a_lt * a_a * a_b;   // fewer than K candidates: all of them
-			if (crossed) {
-				// exactly K in front of f_at: their product, and the bound keeps everything from f_at on out of the backward.  More than K:
-				// provisional (what an unresolved pixel -- more band candidates than the scratch holds -- is left with)
-				alpha = a_at;
-				thr = __uint_as_float(__float_as_uint(f_at) - 1u);   // the largest float in front of f_at (FLT_MAX for +inf)
-			}
-			const bool hard = in_img && crossed && n_at > K && !(a.ablate & 2);
-			const unsigned long long hard_m = __ballot(hard);
-			if (hard_m) {
-				// ---- second sweep: the band candidates of the hard pixels.  Faces of slab s have their fragments in [edge of s, front of s + 2):
-				// a band [front of s_prev, front of s_at) is reached by the slabs s_prev - 1 .. s_at - 1.  A hard pixel needs a tenth of the
-				// tile's list (three slabs, inside its own blur margin), and the hard pixels of a tile need different tenths: evaluated tile-wide
-				// -- every lane its pixel, a face at a time -- the sweep cost half of the first one.  So the work is COMPACTED: the (pixel, face)
-				// pairs that pass the cheap tests (slab range, blurred bbox) are queued in LDS and evaluated 64 at a time, one pair per lane,
-				// whichever pixel and face it is; a candidate inside its pixel's band goes to that pixel's column of the wave's scratch.
-				int s_lo = hard ? s_prev - 1 : 0x7FFFFFFF, s_hi = hard ? s_at - 1 : -0x7FFFFFFF;
+			// a wave that left early has candidates it never looked at behind `front`: its pixels hold >= K in front of it, and the bound
+			// handed to the backward must keep those out even when the pixel holds exactly K
+			if (stopped && in_img) thr = front;
+			const bool over = in_img && cnt > K && !(a.ablate & 2);
+			const unsigned long long ov_all = __ballot(over);
+			if (ov_all) {
+				// (no fence: every lane reads back only the list it wrote itself -- same thread, same addresses, program order.  An
+				// agent-scope fence here costs 0.6 ms per C3 render: L2 write-back + L1 invalidate on a multi-XCD part.)
+				const unsigned long long trunc = __ballot(over && cnt > KN_CAP);
+				int wave_max_cnt = cnt;  // diagnostics: [5] largest candidate count seen
 #pragma unroll
-				for (int d = 1; d < 64; d <<= 1) { s_lo = min(s_lo, __shfl_xor(s_lo, d, 64)); s_hi = max(s_hi, __shfl_xor(s_hi, d, 64)); }
-				s_lo = __builtin_amdgcn_readfirstlane(s_lo); s_hi = __builtin_amdgcn_readfirstlane(s_hi);
-				int b_first = 0, b_last = n_batches - 1;
-				if (sorted) {   // (a sorted list has at most BIN_CAP / 64 = 32 batches: one lane per batch looks at its first entry)
-					const int s0 = lane < n_batches ? (int)(lp[lane * 64] >> 24) : 0x7FFFFFFF;
-					b_first = (int)__popcll(__ballot(lane >= 1 && lane < n_batches && s0 < s_lo));   // batch b goes by when batch b + 1 still starts in front of s_lo
-					b_last = (int)__popcll(__ballot(lane < n_batches && s0 <= s_hi)) - 1;
+				for (int d = 1; d < 64; d <<= 1) wave_max_cnt = max(wave_max_cnt, __shfl_xor(wave_max_cnt, d, 64));
+				if (lane == 0) {  // diagnostics: [4] pixels with more than K candidates; [1] of those, left unresolved
+					atomicAdd(&a.flags[4], (int)__popcll(ov_all));
+					atomicMax(&a.flags[5], wave_max_cnt);
+					if (trunc) atomicAdd(&a.flags[1], (int)__popcll(trunc));
 				}
-				int n_eval2 = 0, n_staged2 = 0, n_items2 = 0;
-				// this lane's own slab range (an unsorted list carries no slabs: every face)
-				const int my_lo = sorted ? s_prev - 1 : -0x7FFFFFFF, my_hi = sorted ? s_at - 1 : 0x7FFFFFFF;
-				float* const recw = &rec[wave][0];                       // records of this sweep: FLAT, piece k of record j at [REC_DW j + 4 (k ^ (j & 7))] (the swizzle spreads the 16-byte staging writes of neighbouring lanes over the banks)
-				unsigned* const bcnt = &band_n[wave][0];                 // [l]: band candidates of lane l's pixel so far; [64 + l], [128 + l]: bits of their smallest / largest depth
-				unsigned short* const queue = &item_q[wave][0];          // ring of 128 items
-				bcnt[lane] = 0u; bcnt[64 + lane] = 0x7F800000u; bcnt[128 + lane] = 0u;
-				int q_head = 0, q_n = 0;
-				for (int b = b_first; b <= b_last; ++b) {
-					int dummy;
-					uint32_t e = entry(b, &dummy);
-					if (sorted && e != NONE && ((int)(e >> 24) < s_lo || (int)(e >> 24) > s_hi)) e = NONE;   // only the faces of the slabs some hard pixel needs
-					// stage flat: the record's 16-byte pieces, the list entry (slab << 24 | face) in its id slot
-					const unsigned long long m_have = __ballot(e != NONE);
-					const int nb = (int)__popcll(m_have);
-					if (e != NONE) {
-						const int pos = (int)__popcll(m_have & ((1ull << lane) - 1ull));
-						const float4* src = reinterpret_cast<const float4*>(rp_img + (e & FACE_MASK));
-						float4* d = reinterpret_cast<float4*>(recw + pos * REC_DW);
+				if (over && cnt <= KN_CAP) {
+					// the candidates still in the ring join the list, padded to a whole piece with (+inf, 1) entries that no pass selects
+					if (cnt & (RING - 1)) flush_ring(cnt & ~(RING - 1), cnt & (RING - 1));
+					const float4* z4 = wz4;
+					const float4* q4 = wq4;
+					const int n4 = (cnt + 3) >> 2;   // 16-byte pieces to read (the padding of the last one is inert)
+					// one pass over the lane's depths, KU entries in flight, fn(bits of the depth)
+					auto scan_z = [&](auto&& fn) {
+						int i = 0;
+						for (; i + KU / 4 <= n4; i += KU / 4) {
+							float4 v[KU / 4];
 #pragma unroll
-						for (int k = 0; k < REC_F4; ++k) { float4 q = src[k]; if (k == 6) q.w = __int_as_float((int)e); d[k ^ (pos & 7)] = q; }   // (the list entry in the id slot: slab << 24 | face)
-					}
-					wave_lds_sync();
-					n_staged2 += nb;
-					int j = 0;
-					for (;;) {
-						// queue (pixel, face) pairs until 64 wait or the batch's faces are through
-						for (; j < nb && q_n < 64; ++j) {
-							const float4 bb = *reinterpret_cast<const float4*>(recw + j * REC_DW + 4 * (7 ^ (j & 7)));   // xmin xmax ymin ymax
-							const int sl = (int)((uint32_t)__float_as_int(recw[j * REC_DW + 4 * (6 ^ (j & 7)) + 3]) >> 24);
-							const bool want = hard & (sl >= my_lo) & (sl <= my_hi) & (px <= bb.y) & (px >= bb.x) & (py <= bb.w) & (py >= bb.z);
-							const unsigned long long wm = __ballot(want);
-							if (wm == 0ull) continue;
-							if (want) queue[(q_head + q_n + (int)__popcll(wm & ((1ull << lane) - 1ull))) & 127] = (unsigned short)((lane << 8) | j);
-							q_n += (int)__popcll(wm);
-						}
-						if (q_n == 0) break;
-						wave_lds_sync();
-						// evaluate up to 64 of them, one per lane (the records are overwritten by the next batch: a batch drains its queue)
-						const int count = min(q_n, 64);
-						const bool act = lane < count;
-						const unsigned it = (unsigned)queue[(q_head + lane) & 127];
-						const int hl = act ? (int)(it >> 8) : lane, jj = act ? (int)(it & 255u) : 0;
-						const int xh = tile_x * T8 + (hl & 7), yh = tile_y * T8 + (hl >> 3);
-						const float pxh = 1.0f - (2.0f * xh + 1.0f) / (float)W, pyh = 1.0f - (2.0f * yh + 1.0f) / (float)H;   // (the owner's px, py to the bit: the same expressions)
-						FaceRec r = load_rec(reinterpret_cast<const float4*>(recw + jj * REC_DW), jj & 7);
-						r.f &= (int)FACE_MASK;
-						Frag fr;
-						eval_core(r, pxh, pyh, &fr);
-						// the band of the item's pixel lives in that pixel's lane
-						const float lo_h = __shfl(f_prev, hl, 64), hi_h = __shfl(f_at, hl, 64);
-						const bool cand = act & (fr.pz_clip >= 0.f) & (fr.inside | (fr.dist < blur)) & (fr.pz_clip >= lo_h) & (fr.pz_clip < hi_h);
-						if (cand) {
-							// (lanes that deliver to the same pixel in one instruction are served in lane order: the slot order is the queue order)
-							const unsigned slot = __hip_atomic_fetch_add(&bcnt[hl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-							const unsigned zb = __float_as_uint(fr.pz_clip + 0.0f);
-							__hip_atomic_fetch_min(&bcnt[64 + hl], zb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-							__hip_atomic_fetch_max(&bcnt[128 + hl], zb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-							if (slot < (unsigned)KN_CAP && !(a.ablate & 1)) {
-								const int64_t o = (int64_t)slot * 64 + hl;
-								wz0[o] = fr.pz_clip;
-								wq0[o] = 1.0f - silhouette_prob(fr.inside ? -fr.dist : fr.dist, inv_sigma);
-								wf0[o] = r.f;
+							for (int u = 0; u < KU / 4; ++u) v[u] = z4[lidx(i + u)];
+#pragma unroll
+							for (int u = 0; u < KU / 4; ++u) {
+								fn(__float_as_uint(v[u].x + 0.0f)); fn(__float_as_uint(v[u].y + 0.0f));
+								fn(__float_as_uint(v[u].z + 0.0f)); fn(__float_as_uint(v[u].w + 0.0f));
 							}
 						}
-						n_items2 += count;
-						q_head = (q_head + count) & 127; q_n -= count;
-						++n_eval2;
-						wave_lds_sync();
-					}
-				}
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the band candidates other lanes delivered to this lane's column have left the wave
-				const int nbnd = (int)bcnt[lane];
-				const float z_lo = __uint_as_float(bcnt[64 + lane]), z_hi = __uint_as_float(bcnt[128 + lane]);
-				wave_lds_sync();
-				const int rank = K - n_prev;   // 1-based rank of the K-th nearest inside the band
-				const bool solve = hard && nbnd <= KN_CAP && nbnd > rank && !(a.ablate & 1);   // (nbnd == n_at - n_prev > rank by construction)
-				{
-					const unsigned long long trunc = __ballot(hard && nbnd > KN_CAP);
-					int wave_max = hard ? nbnd : 0;   // diagnostics: [5] largest band seen, [26] band candidates in all
-					if (a.ablate & 64) {
-						int tb2 = hard ? nbnd : 0;
-#pragma unroll
-						for (int d = 1; d < 64; d <<= 1) tb2 += __shfl_xor(tb2, d, 64);
-						if (lane == 0) atomicAdd(&a.flags[26], tb2);
-					}
-#pragma unroll
-					for (int d = 1; d < 64; d <<= 1) wave_max = max(wave_max, __shfl_xor(wave_max, d, 64));
-					if (lane == 0) {   // diagnostics: [4] pixels that needed the second sweep; [1] of those, left unresolved
-						atomicAdd(&a.flags[4], (int)__popcll(hard_m));
-						atomicMax(&a.flags[5], wave_max);
-						if (trunc) atomicAdd(&a.flags[1], (int)__popcll(trunc));
-						if (a.ablate & 64) {   // [27] second-sweep evaluations (64 pairs each), [28] tiles that took it, [29] (pixel, face) pairs queued, [30] faces staged, [31] the tiles' list lengths
-							atomicAdd(&a.flags[27], n_eval2); atomicAdd(&a.flags[28], 1); atomicAdd(&a.flags[29], n_items2); atomicAdd(&a.flags[30], n_staged2);
-							atomicAdd(&a.flags[31], n_list);
+						for (; i < n4; ++i) {
+							const float4 v = z4[lidx(i)];
+							fn(__float_as_uint(v.x + 0.0f)); fn(__float_as_uint(v.y + 0.0f)); fn(__float_as_uint(v.z + 0.0f)); fn(__float_as_uint(v.w + 0.0f));
 						}
-					}
-				}
-				if (solve) {
-					// (the column was written by other lanes of this wave, the stores have been waited for; the loads go past the CU's L1 -- sc1 --
-					// which may still hold this address from an earlier tile)
-					const int n = nbnd;
-					auto ldz = [&](int i) __attribute__((always_inline)) { return __hip_atomic_load(&wz[(int64_t)i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-					auto ldq = [&](int i) __attribute__((always_inline)) { return __hip_atomic_load(&wq[(int64_t)i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-					auto ldf = [&](int i) __attribute__((always_inline)) { return __hip_atomic_load(&wf[(int64_t)i * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-					auto scan_z = [&](auto&& fn) {   // one pass over the lane's band depths, KU loads in flight, fn(bits of the depth)
-						int i = 0;
-						for (; i + KU <= n; i += KU) {
-							float v[KU];
-#pragma unroll
-							for (int u = 0; u < KU; ++u) v[u] = ldz(i + u);
-#pragma unroll
-							for (int u = 0; u < KU; ++u) fn(__float_as_uint(v[u] + 0.0f));
-						}
-						for (; i < n; ++i) fn(__float_as_uint(ldz(i) + 0.0f));
 					};
 					unsigned lo = __float_as_uint(z_lo + 0.0f), hi = __float_as_uint(z_hi + 0.0f);
-					// Radix search for the rank-th smallest depth (non-negative floats order like their bit patterns).  Invariant: every band
-					// candidate lies in [lo, hi] or was counted in c_lo (in front of lo) or lies behind hi; the rank-th smallest is inside
-					// [lo, hi].  A level histograms (z - lo) >> shift into 32 bins in ONE read of the band and keeps the bin that holds the
-					// rank-th; once that bin has at most 4 candidates they are fetched and ranked directly.
+					// Radix search for the K-th smallest depth.  Invariant: every candidate lies in [lo, hi] or was counted in c_lo
+					// (candidates in front of lo) or lies behind hi; the K-th smallest is inside [lo, hi].  A level histograms
+					// (z - lo) >> shift into 32 bins in ONE read of the list and keeps the bin
+					// that holds the K-th; once that bin has at most 4 candidates they are fetched and ranked directly.
 					int c_lo = 0;
-					// the lane's 32 counters (16 bits each) live in LDS: hist[w * 64 + lane], w = bin >> 1
+					// the lane's 32 counters (16 bits each) live in LDS:
+					// hist[w * 64 + lane], w = bin >> 1.  One fire-and-forget ds_add per candidate instead of sixteen selects.
 					unsigned* const hist = reinterpret_cast<unsigned*>(&rec[wave][0]) + lane;
 					while (lo < hi) {
 						const unsigned span = hi - lo;
@@ -1165,7 +1050,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 							const unsigned bin = (zb - lo) >> shift;
 							__hip_atomic_fetch_add(hist + (bin >> 1) * 64, 1u << ((bin & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 						});
-						const int need_r = rank - c_lo;
+						// the bin that holds the (K - c_lo)-th candidate of the range
+						const int need = K - c_lo;
 						int acc = 0, sel = 31, in_sel = 0;
 						bool found = false;
 #pragma unroll
@@ -1175,7 +1061,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 							for (int h = 0; h < 2; ++h) {
 								const int cb = (int)((hw >> (h * 16)) & 0xFFFFu);
 								if (!found) {
-									if (acc + cb >= need_r) { sel = 2 * w + h; in_sel = cb; found = true; }
+									if (acc + cb >= need) { sel = 2 * w + h; in_sel = cb; found = true; }
 									else acc += cb;
 								}
 							}
@@ -1185,7 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 						hi = min(hi, lo + ((1u << shift) - 1u));
 						if (shift == 0) break;  // a single depth value is left
 						if (in_sel <= 4) {
-							// fetch the (at most 4) candidates of the bin and take the (rank - c_lo)-th smallest of them
+							// fetch the (at most 4) candidates of the bin and take the (K - c_lo)-th smallest of them
 							unsigned c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu;
 							int mm = 0;
 							scan_z([&](unsigned zb) {
@@ -1195,79 +1081,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 								c2 = (in && mm == 2) ? zb : c2; c3 = (in && mm == 3) ? zb : c3;
 								mm += in ? 1 : 0;
 							});
+							// sort the four (absent ones are +max) and index
 							unsigned t;
 							if (c0 > c1) { t = c0; c0 = c1; c1 = t; }
 							if (c2 > c3) { t = c2; c2 = c3; c3 = t; }
 							if (c0 > c2) { t = c0; c0 = c2; c2 = t; }
 							if (c1 > c3) { t = c1; c1 = c3; c3 = t; }
 							if (c1 > c2) { t = c1; c1 = c2; c2 = t; }
-							const int rnk = rank - c_lo;  // 1-based rank inside the bin
+							const int rnk = K - c_lo;  // 1-based rank inside the bin
 							const unsigned T = rnk == 1 ? c0 : (rnk == 2 ? c1 : (rnk == 3 ? c2 : c3));
 							c_lo += (c0 < T) + (c1 < T) + (c2 < T) + (c3 < T);
 							lo = hi = T;
 							break;
 						}
 					}
-					// lo = bits of the K-th nearest depth, c_lo = band candidates strictly in front of it
-					const int keep = rank - c_lo;   // how many of the candidates AT that depth belong to the K nearest (>= 1)
-					int n_tie = 0;
-					float a_sel = 1.0f, a_tie = 1.0f;
+					// lo = bits of the K-th smallest depth, c_lo = candidates strictly in front of it
+					const int keep = K - c_lo;   // how many of the candidates AT the K-th depth belong to the K nearest
+					int ties = keep;
+					float a_lt = 1.0f, a_tie = 1.0f;
 					unsigned nxt = 0x7F800000u;   // bits of the nearest depth BEHIND the K-th
+					bool excess = false;          // more candidates at the K-th depth than are kept
 					{
+						auto take = [&](float z, float q) {
+							const unsigned zb = __float_as_uint(z + 0.0f);
+							if (zb < lo) a_lt *= q;
+							else if (zb == lo) {
+								if (ties > 0) { a_tie *= q; --ties; }
+								else excess = true;
+							} else nxt = min(nxt, zb);
+						};
 						int i = 0;
-						for (; i + KU / 2 <= n; i += KU / 2) {
-							float zv[KU / 2], qv[KU / 2];
+						for (; i + KU / 4 <= n4; i += KU / 4) {
+							float4 zv[KU / 4], qv[KU / 4];
 #pragma unroll
-							for (int u = 0; u < KU / 2; ++u) { zv[u] = ldz(i + u); qv[u] = ldq(i + u); }
+							for (int u = 0; u < KU / 4; ++u) { zv[u] = z4[lidx(i + u)]; qv[u] = q4[lidx(i + u)]; }
 #pragma unroll
-							for (int u = 0; u < KU / 2; ++u) {
-								const unsigned zb = __float_as_uint(zv[u] + 0.0f);
-								a_sel *= zb < lo ? qv[u] : 1.0f; a_tie *= zb == lo ? qv[u] : 1.0f; n_tie += zb == lo ? 1 : 0;
-								nxt = zb > lo ? min(nxt, zb) : nxt;
+							for (int u = 0; u < KU / 4; ++u) {
+								take(zv[u].x, qv[u].x); take(zv[u].y, qv[u].y); take(zv[u].z, qv[u].z); take(zv[u].w, qv[u].w);
 							}
 						}
-						for (; i < n; ++i) {
-							const unsigned zb = __float_as_uint(ldz(i) + 0.0f);
-							const float qv = ldq(i);
-							a_sel *= zb < lo ? qv : 1.0f; a_tie *= zb == lo ? qv : 1.0f; n_tie += zb == lo ? 1 : 0;
-							nxt = zb > lo ? min(nxt, zb) : nxt;
+						for (; i < n4; ++i) {
+							const float4 zv = z4[lidx(i)], qv = q4[lidx(i)];
+							take(zv.x, qv.x); take(zv.y, qv.y); take(zv.z, qv.z); take(zv.w, qv.w);
 						}
 					}
+					alpha = a_lt * a_tie;
+					// The bound the backward compares a candidate's depth with: the MIDPOINT between the K-th depth and the next one behind it
+					// (never beyond `front` where the wave left early: what it did not look at lies behind that).  Where candidates tied AT
+					// the K-th depth were left out, which of them stay is decided by face index: tie_fix_kernel rewrites this pixel.
 					const float zk = __uint_as_float(lo);
-					if (n_tie <= keep) {
-						alpha = a_prev * a_sel * a_tie;
-						// the bound the backward compares a candidate's depth with: the MIDPOINT between the K-th depth and the next one behind it
-						// (in the band, else the band's far edge)
-						thr = fminf(0.5f * (zk + __uint_as_float(nxt)), thr);
-					} else {
-						// more candidates AT the K-th depth than fit: PyTorch3D's K-buffer keeps the lower face indices (insertion order; a later
-						// fragment of EQUAL depth does not displace an earlier one).  Ties are not exotic: a pixel outside a fan of faces that share
-						// their nearest vertex gets that vertex's depth from every one of them.  The `keep` lowest ids, multiplied in id order.
-						int last = -1;
-						float a_k = 1.0f;
-						for (int k = 0; k < keep; ++k) {
-							int best = 0x7FFFFFFF;
-							float bq = 1.0f;
-							for (int i = 0; i < n; ++i) {
-								if (__float_as_uint(ldz(i) + 0.0f) != lo) continue;
-								const int id = ldf(i);
-								if (id > last && id < best) { best = id; bq = ldq(i); }
-							}
-							last = best; a_k *= bq;
-						}
-						alpha = a_prev * a_sel * a_k;
-						thr = -zk;     // negative: "candidates tied at this depth are decided by tie_face" (the last face kept)
-						tie = last;
+					thr = fminf(0.5f * (zk + __uint_as_float(nxt)), stopped ? front : INFINITY);
+					if (excess) {
+						thr = zk;   // provisional (every tied candidate): replaced by -zk and the face id of the last one kept
+						Fix fx;
+						fx.pix = (int32_t)(((int64_t)img * H + yi) * W + xi); fx.zk = lo; fx.keep = keep; fx.a_lt = a_lt;
+						a.fix[atomicAdd(&a.flags[7], 1)] = fx;
 					}
 				}
 			}
 		}
 
-		if (a.ablate & 64) {  // diagnostics: [24] (pixel, face) tests issued (64-lane slots, in units of 64), [25] silhouette candidates seen (units of 64)
-			int te = n_eval, tc = in_img ? c_lt + c_a + c_b : 0;
+		if (a.ablate & 64) {  // diagnostics: [24] (pixel, face) tests issued (64-lane slots, in units of 64), [25] silhouette candidates (units of 64)
+			int te = n_eval, tc = in_img ? cnt : 0;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) { te += __shfl_xor(te, d, 64); tc += __shfl_xor(tc, d, 64); }
 			if (lane == 0 && te) { atomicAdd(&a.flags[24], (te + 32) >> 6); atomicAdd(&a.flags[25], (tc + 32) >> 6); }
+			if (lane == 0 && stopped) atomicAdd(&a.flags[26], 1);   // [26] tiles left early
 		}
 		if (in_img) {
 			const int64_t pix = ((int64_t)img * H + yi) * W + xi;
@@ -1275,7 +1154,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 				a.mask[pix] = 1.0f - alpha;
 				a.zthr[pix] = thr;
 				a.alpha_ws[pix] = alpha;
-				if (thr < 0.f) a.tie_face[pix] = tie;
 			}
 			if (want_rgb) {   // the nearest inside fragment: shade_kernel turns it into the pixel's colour
 				a.p2f_ws[pix] = bf;
@@ -1283,7 +1161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void r
 				a.frag_ws[pix * 8 + 4] = bd;
 			}
 		}
-		wave_lds_sync();  // the next tile reuses the record area
+		wave_lds_sync();  // the next tile reuses the rings
 	}
 }
 
@@ -1343,6 +1221,85 @@ __global__ __launch_bounds__(256) void shade_kernel(const TileArgs a) {
 	for (int c = 0; c < 3; ++c) {
 		const float col = (a.rp.ambient + diff) * tex[c] + spec;
 		o[c] = (wnum * col + delta * a.rp.background[c]) / den;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------ 5. ties at the K-th depth
+// PyTorch3D inserts fragments into a pixel's K-buffer in face order and a later fragment of EQUAL depth does not displace an earlier
+// one: of the candidates tied at the K-th depth, the `keep` lowest face indices stay.  (Ties are not exotic: a pixel outside a fan of
+// faces that share their nearest vertex gets that vertex's depth from every one of them.)  One wave per queued pixel walks the tile's
+// list with the face ids at hand, collects the candidates whose depth equals the K-th to the bit -- the same eval_frag, the same
+// rounding --, keeps the `keep` lowest ids and rewrites mask, alpha, the bound (negated: "ties at this depth are decided by
+// tie_face") and the id of the last face kept.
+__global__ __launch_bounds__(256) void tie_fix_kernel(const TileArgs a, const FaceRec* __restrict__ recs) {
+	constexpr int TIE_CAP = 128;
+	__shared__ int tf[4][TIE_CAP];
+	__shared__ float tq[4][TIE_CAP];
+	__shared__ float ts[4][TIE_CAP];
+	const int H = a.rp.image_h, W = a.rp.image_w;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const float blur = a.rp.sil_blur_radius;
+	const float inv_sigma = 1.0f / a.rp.sil_sigma;
+	const int n_fix = a.flags[7];
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	for (int i = blockIdx.x * 4 + wave; i < n_fix; i += gridDim.x * 4) {
+		const Fix fx = a.fix[i];
+		const int xi = fx.pix % W, yi = (fx.pix / W) % H, img = fx.pix / (W * H);
+		const float px = 1.0f - (2.0f * xi + 1.0f) / (float)W;
+		const float py = 1.0f - (2.0f * yi + 1.0f) / (float)H;
+		const int tile_x = xi / T8, tile_y = yi / T8;
+		const int2 ti = a.tinfo[img * a.tiles_per_img + tile_y * a.tiles_x + tile_x];
+		const bool binned = ti.y >= 0;
+		const int n_list = binned ? (int)((uint32_t)ti.y & ~LIST_UNSORTED) : a.F;
+		const uint32_t* tbp = a.tb + (int64_t)img * a.F;
+		const uint32_t* lp = a.pool + (int64_t)img * a.pool_cap + ti.x;
+		int n_t = 0;
+		for (int i0 = 0; i0 < n_list; i0 += 64) {
+			const int j = i0 + lane;
+			int f = -1;
+			if (j < n_list) {
+				if (binned) f = (int)(lp[j] & FACE_MASK);
+				else if (tile_hit(tbp[j], tile_x, tile_y)) f = j;
+			}
+			bool tied = false;
+			float q = 1.0f;
+			if (f >= 0) {
+				const FaceRec r = recs[(int64_t)img * a.F + f];
+				Frag fr;
+				if (eval_frag(r, px, py, &fr) && fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur) && __float_as_uint(fr.pz_clip + 0.0f) == fx.zk) {
+					tied = true;
+					q = 1.0f - silhouette_prob(fr.inside ? -fr.dist : fr.dist, inv_sigma);
+				}
+			}
+			const unsigned long long m = __ballot(tied);
+			const int pos = n_t + (int)__popcll(m & lt);
+			if (tied && pos < TIE_CAP) { tf[wave][pos] = f; tq[wave][pos] = q; }
+			n_t += (int)__popcll(m);
+		}
+		wave_lds_sync();
+		n_t = min(n_t, TIE_CAP);   // (more than TIE_CAP faces of one depth at one pixel: the first TIE_CAP in list order stand for all)
+		// rank by face id; the `keep` lowest, multiplied in id order
+		int last = -1;
+		for (int j = lane; j < n_t; j += 64) {
+			const int fj = tf[wave][j];
+			int rank = 0;
+			for (int k = 0; k < n_t; ++k) rank += tf[wave][k] < fj;
+			ts[wave][rank] = tq[wave][j];
+			if (rank == fx.keep - 1) last = fj;
+		}
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) last = max(last, __shfl_xor(last, d, 64));
+		wave_lds_sync();
+		if (lane == 0) {
+			float al = fx.a_lt;
+			const int nk = min(fx.keep, n_t);
+			for (int k = 0; k < nk; ++k) al *= ts[wave][k];
+			a.mask[fx.pix] = 1.0f - al;
+			a.alpha_ws[fx.pix] = al;
+			a.zthr[fx.pix] = -__uint_as_float(fx.zk);
+			a.tie_face[fx.pix] = last;
+		}
+		wave_lds_sync();
 	}
 }
 
@@ -1416,7 +1373,7 @@ __global__ __launch_bounds__(256) void sil_bwd_kernel(const find_render_params r
 			if (!eval_frag(r, px, py, &fr)) continue;
 			if (!(fr.pz_clip >= 0.f && (fr.inside || fr.dist < blur))) continue;
 			// pixel with more than K candidates: is this one among the K nearest?  (a negative bound: candidates tied AT that depth were
-			// sorted out by face index in the forward's second sweep: those up to tie_face stay)
+			// sorted out by face index in the forward, tie_fix_kernel: those up to tie_face stay)
 			if (czt < 0.f) {
 				czt = -czt;
 				if (fr.pz_clip == czt && f > tf[coff]) continue;
@@ -1780,8 +1737,8 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	a.n_views = (int)n_views; a.V = V; a.F = F; a.tiles_x = tiles_x;
 	a.mask = mask; a.image = image; a.p2f_out = pix_to_face; a.zbuf_out = zbuf;
 	a.p2f_ws = (image || pix_to_face || zbuf) ? w.p2f : nullptr; a.bary_ws = w.bary; a.frag_ws = w.frag; a.flags = w.flags; a.qn = w.qn; a.cursor = w.cursor;
-	a.zthr = w.zthr; a.alpha_ws = w.alpha; a.tie_face = w.tie_face;
-	a.tinfo = w.tinfo; a.pool = w.pool; a.order = w.order; a.pool_cap = w.pool_cap;
+	a.zthr = w.zthr; a.alpha_ws = w.alpha; a.tie_face = w.tie_face; a.scratch = w.scratch;
+	a.tinfo = w.tinfo; a.pool = w.pool; a.order = w.order; a.fix = w.fix; a.pool_cap = w.pool_cap;
 	a.tiles_per_img = tiles_per_img; a.total_tiles = (int)(a.tiles_per_img * n_img);
 	a.ablate = find::g_raster_ablate;
 	hipLaunchKernelGGL(outside_kernel, dim3((unsigned)cdiv(tiles_per_img, 4), (unsigned)n_img), dim3(256), 0, s, a);
@@ -1793,11 +1750,12 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	ra.sil_blur_radius = rp->sil_blur_radius; ra.sil_sigma = rp->sil_sigma; ra.sil_faces_per_pixel = rp->sil_faces_per_pixel; ra.image_h = H; ra.image_w = W;
 	ra.tb = w.tb; ra.zinfo = w.zinfo; ra.tinfo = w.tinfo; ra.F = F; ra.tiles_x = tiles_x; ra.tiles_per_img = tiles_per_img; ra.pool_cap = w.pool_cap;
 	ra.mask = mask; ra.p2f_ws = a.p2f_ws; ra.frag_ws = w.frag; ra.flags = w.flags; ra.qn = w.qn; ra.zthr = w.zthr; ra.alpha_ws = w.alpha;
-	ra.scratch = w.scratch; ra.tie_face = w.tie_face; ra.ablate = a.ablate;
+	ra.scratch = w.scratch; ra.fix = w.fix; ra.ablate = a.ablate;
 	if (mask && a.p2f_ws) hipLaunchKernelGGL((raster_kernel<true, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
 	else if (mask) hipLaunchKernelGGL((raster_kernel<true, false>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
 	else hipLaunchKernelGGL((raster_kernel<false, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
 	if (a.p2f_ws) hipLaunchKernelGGL(shade_kernel, dim3((unsigned)cdiv(n_img * H * W, 256)), dim3(256), 0, s, a);
+	if (mask) hipLaunchKernelGGL(tie_fix_kernel, dim3(256), dim3(256), 0, s, a, w.recs);
 	FIND_LAUNCH_CHECK("find_render_fwd");
 	return FIND_OK;
 }

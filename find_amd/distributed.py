@@ -43,8 +43,16 @@ class GradBucket:
 	(RCCL averages in place) -- no gather into the bucket and no scatter back.  A gradient that did not come out of the arena
 	(second backward of the same parameter in one step, CPU tensors, foreign autograd nodes) takes the copy path."""
 
-	def __init__(self, params, group=None, arena=None):
-		self.params = [p for p in params if p.requires_grad]
+	def __init__(self, params, group=None, arena=None, early=None):
+		"""early: parameters whose gradients are complete before the backward pass ends (FIND: the MLP's weights -- what follows their
+		last weight-gradient kernel is the loss-side tail: registration, latent scatter).  They are laid out FIRST in the flat buffer and
+		`arm_early()` hangs the collective over that prefix on the moment autograd accumulates the trigger parameter, so that it runs
+		under the rest of the backward; `allreduce_()` then only has the remainder to send."""
+		params = [p for p in params if p.requires_grad]
+		early = [p for p in (early or []) if p.requires_grad]
+		ids = {id(p) for p in early}
+		self.params = early + [p for p in params if id(p) not in ids]
+		self.n_early_params = len(early)
 		self.group = group
 		p0 = self.params[0]
 		self.offsets, o = [], 0
@@ -52,6 +60,12 @@ class GradBucket:
 			self.offsets.append(o)
 			o += (p.numel() + 3) & ~3  # 16-byte aligned slots; the padding stays zero
 		self.numel = o
+		self.n_early = self.offsets[self.n_early_params] if self.n_early_params < len(self.params) else o   # floats of the early prefix
+		if not early:
+			self.n_early = 0
+		self._early = None      # (work, divisor) of the prefix collective issued inside this step's backward
+		self._hook = None
+		self.early_issued = 0   # steps in which the prefix went out early (diagnostics / tests)
 		self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
 		self.views = [self._view(i) for i in range(len(self.params))]
 		self.taken = [False] * len(self.params)
@@ -76,7 +90,30 @@ class GradBucket:
 		self.taken[i] = True
 		return self._view(i)
 
+	def arm_early(self, trigger):
+		"""Issue the all-reduce of the early prefix when autograd has accumulated `trigger` -- a parameter every backward node that writes an
+		early gradient feeds (FIND: `base[0].weight`, which both MLP passes of a step reach: its AccumulateGrad node runs after the last of
+		them has returned, i.e. behind its last weight-gradient kernel on the stream).  The collective reads the arena, not `.grad`: it goes out
+		only if every early slot was handed to a backward kernel this step (else the prefix travels with the rest, as before)."""
+		if self.n_early == 0 or self._hook is not None:
+			return
+		trigger._find_hooks_are_stream_safe = True   # (find_amd.functional: this hook reads gradients only behind the stream's own work; deferred joins stay allowed)
+
+		def fire(_p):
+			if self._early is not None or not (dist.is_available() and dist.is_initialized()):
+				return
+			if not all(self.taken[:self.n_early_params]):
+				return
+			avg = dist.get_backend(self.group) == 'nccl'
+			work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+			self._early = (work, None if avg else dist.get_world_size(self.group))
+			self.early_issued += 1
+		self._hook = trigger.register_post_accumulate_grad_hook(fire)
+
 	def close(self):
+		if self._hook is not None:
+			self._hook.remove()
+			self._hook = None
 		if self.arena:
 			from . import functional
 			functional.unregister_grad_arena(self)
@@ -88,11 +125,13 @@ class GradBucket:
 		stream behind everything the current stream held at the call; wait() makes the current stream wait for it, the host never blocks)."""
 		self.taken = [False] * len(self.params)
 		self._pending = None
+		early, self._early = self._early, None
 		if not (dist.is_available() and dist.is_initialized()):
 			return
 		world = dist.get_world_size(self.group)
 		missing, src, dst = [], [], []
-		for p, v in zip(self.params, self.views):
+		lo = self.n_early_params if early is not None else 0   # (the early prefix is on its way already: every one of its slots came out of the arena)
+		for p, v in list(zip(self.params, self.views))[lo:]:
 			if p.grad is None:
 				missing.append((p, v))
 			elif p.grad.data_ptr() != v.data_ptr():
@@ -103,8 +142,9 @@ class GradBucket:
 		if src:
 			torch._foreach_copy_(dst, src)
 		avg = dist.get_backend(self.group) == 'nccl'   # RCCL averages in place; gloo has no AVG: sum, then divide
-		work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
-		self._pending = (work, None if avg else world, src, dst, missing)
+		rest = self.flat[self.n_early:] if early is not None else self.flat
+		work = dist.all_reduce(rest, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True) if rest.numel() else None
+		self._pending = (work, None if avg else world, src, dst, missing, early, rest)
 		if not async_op:
 			self.wait()
 
@@ -113,10 +153,15 @@ class GradBucket:
 		pend, self._pending = getattr(self, '_pending', None), None
 		if pend is None:
 			return
-		work, div, src, dst, missing = pend
-		work.wait()
-		if div is not None:
-			self.flat.div_(div)
+		work, div, src, dst, missing, early, rest = pend
+		if early is not None:
+			early[0].wait()
+			if early[1] is not None:
+				self.flat[:self.n_early].div_(early[1])
+		if work is not None:
+			work.wait()
+			if div is not None:
+				rest.div_(div)
 		if src:  # copy back in one multi-tensor launch (a per-parameter loop is ~30 tiny kernels per step)
 			torch._foreach_copy_(src, dst)
 		for p, v in missing:

@@ -261,7 +261,8 @@ class _MLP(torch.autograd.Function):
 		# (... and nobody is TOLD about them first: a tensor hook or a post-accumulate-grad hook on a weight would read its gradient as
 		# soon as this node returns -- the texture pass alone in a graph, hooks of a wrapper such as DDP --)
 		defer = (DEFER_WGRAD_JOIN and ctx.defer and can_park and not fold and (pending is None or pending[0] != task) and idx
-				 and all(w.grad is None and not w._backward_hooks and not getattr(w, '_post_accumulate_grad_hooks', None) for w in weights))
+				 and all(w.grad is None and not w._backward_hooks
+						 and (not getattr(w, '_post_accumulate_grad_hooks', None) or getattr(w, '_find_hooks_are_stream_safe', False)) for w in weights))
 		if defer:
 			check(L.find_ctx_set(h, b'defer_join', 1), 'find_ctx_set(defer_join)')
 		check(L.find_mlp_bwd(h, ctypes.byref(p), ptr(pos), pos_batch, n_feet, V, ptr(lat_disp), ptr(lat_col), ptr(g_disp), ptr(g_col),

@@ -57,10 +57,12 @@ def chamfer_distance(x, y, x_lengths=None, y_lengths=None):
 
 
 class TextureLossGTSpace(nn.Module):
-	def forward(self, model, batch: dict, num_samples=1000, shapevec=None, texvec=None, posevec=None) -> torch.Tensor:
-		"""Sample points + colours on the GT meshes, query the colour field there, masked L2 (reference losses.py:22-57)."""
+	def forward(self, model, batch: dict, num_samples=1000, shapevec=None, texvec=None, posevec=None, gt_samples=None) -> torch.Tensor:
+		"""Sample points + colours on the GT meshes, query the colour field there, masked L2 (reference losses.py:22-57).
+		gt_samples (not in the reference): (points, colours) already drawn on batch['mesh'] -- ModelWithLoss draws the GT samples of a step
+		before the main pass, beside it (they depend on the batch alone)."""
 		mesh_gt = batch['mesh']
-		sampled_verts, sampled_gt_colours = sample_points_from_meshes(mesh_gt, num_samples=num_samples, return_textures=True)
+		sampled_verts, sampled_gt_colours = gt_samples if gt_samples is not None else sample_points_from_meshes(mesh_gt, num_samples=num_samples, return_textures=True)
 		texvec = texvec if texvec is not None else batch.get('texvec', None)
 		shapevec = shapevec if shapevec is not None else batch.get('shapevec', None)
 		posevec = posevec if posevec is not None else batch.get('posevec', None)
@@ -73,9 +75,11 @@ class TextureLossGTSpace(nn.Module):
 
 
 class DisplacementLoss(nn.Module):
-	def forward(self, model, res, batch, epoch, num_samples=5000, z_cutoff=None, gt_z_cutoff=None):
-		"""Chamfer distance between surface samples of the GT and the predicted meshes (reference losses.py:59-90)."""
-		gt_samples = sample_points_from_meshes(batch['mesh'], num_samples=num_samples)
+	def forward(self, model, res, batch, epoch, num_samples=5000, z_cutoff=None, gt_z_cutoff=None, gt_samples=None):
+		"""Chamfer distance between surface samples of the GT and the predicted meshes (reference losses.py:59-90).
+		gt_samples (not in the reference): the GT samples, already drawn (see TextureLossGTSpace.forward)."""
+		if gt_samples is None:
+			gt_samples = sample_points_from_meshes(batch['mesh'], num_samples=num_samples)
 		pred_samples = sample_points_from_meshes(res['meshes'], num_samples=num_samples)
 		if z_cutoff is not None:
 			p, pl = _compact_by_mask(pred_samples, pred_samples[..., 2] <= z_cutoff)

@@ -12,6 +12,7 @@ from collections import namedtuple
 import torch
 
 from . import functional as FN
+from . import losses as _losses
 from .losses import DisplacementLoss, MeshSmoothnessLoss, SilhouetteLoss, TextureLossGTSpace
 from .model import NeuralDisplacementField
 from .renderer import FootRenderer
@@ -47,6 +48,8 @@ OVERLAP_CHAMFER = os.environ.get('FIND_OVERLAP_CHAMFER', '1') != '0'
 # the texture term (GT surface samples -> colour field -> masked MSE: a chain of its own, it reads nothing of the main pass) on the second
 # stream from the START of the step, beside the main pass; FIND_TEXTURE_STREAM=0 turns it off
 TEXTURE_STREAM = os.environ.get('FIND_TEXTURE_STREAM', '0') != '0'
+# the GT scans' surface samples drawn before the main pass, beside it (ModelWithLoss.forward); FIND_PRESAMPLE_GT=0: inside the loss terms, as the reference orders them
+PRESAMPLE_GT = os.environ.get('FIND_PRESAMPLE_GT', '1') != '0'
 LAZY_COLOURS = os.environ.get('FIND_LAZY_COLOURS', '1') != '0'       # switch for A/B runs and for the bench record with the reference's eager colour head
 _SECOND_STREAMS = {}
 
@@ -101,7 +104,7 @@ def model_from_opts(opts):
 
 class _Step:
 	"""What one forward() call has at hand while the registry is walked."""
-	__slots__ = ('batch', 'epoch', 'opts', 'res', 'is_train', 'use_z_cutoff', 'gt_z_cutoff', 'pred', 'gt')
+	__slots__ = ('batch', 'epoch', 'opts', 'res', 'is_train', 'use_z_cutoff', 'gt_z_cutoff', 'pred', 'gt', 'gt_chamf', 'gt_tex')
 
 
 class ModelWithLoss(nn.Module):
@@ -126,7 +129,8 @@ class ModelWithLoss(nn.Module):
 
 	# ------------------------------------------------------------------ raw losses, one per registry entry
 	def _raw_chamf(self, st):
-		return self.def_loss(self.model, st.res, st.batch, st.epoch, z_cutoff=0.07 if st.use_z_cutoff else None, gt_z_cutoff=st.gt_z_cutoff)['loss']
+		return self.def_loss(self.model, st.res, st.batch, st.epoch, z_cutoff=0.07 if st.use_z_cutoff else None, gt_z_cutoff=st.gt_z_cutoff,
+							 **(dict(gt_samples=st.gt_chamf) if st.gt_chamf is not None else {}))['loss']
 
 	def _raw_smooth(self, st):
 		return self.mesh_smooth_loss(st.res['meshes'])
@@ -134,7 +138,7 @@ class ModelWithLoss(nn.Module):
 	def _raw_texture(self, st):
 		sfx = 'train' if st.is_train else 'val'
 		codes = {k: st.batch.get(f'{k}_{sfx}', None) for k in ('shapevec', 'texvec', 'posevec')}
-		return self.col_loss(self.model, st.batch, **codes)
+		return self.col_loss(self.model, st.batch, **codes, **(dict(gt_samples=st.gt_tex) if st.gt_tex is not None else {}))
 
 	def _raw_pix(self, st):
 		# images are compared inside the silhouettes only (model.py:1101-1105): MSE(image * mask, gt image * gt mask), one pass each way
@@ -241,7 +245,31 @@ class ModelWithLoss(nn.Module):
 			with torch.cuda.stream(tex_side):
 				early['loss_tex'] = self._raw_texture(st)
 			early['loss_tex'].record_stream(main)
+		# The surface samples of the GT scans (Chamfer: 5000 per scan; texture: 1000 with colours) depend on the batch alone: drawn HERE, before
+		# the main pass and -- outside a capture -- on the second stream beside it (round 5: they used to sit between the main pass and the
+		# texture term's MLP pass, three short launches each on a chip the nearest-neighbour search was filling: 60 us for a 7-us kernel).
+		st.gt_chamf = st.gt_tex = None
+		pre_ev = None
+		if PRESAMPLE_GT and supervise_3d and (chamf or texture) and tex_side is None and 'mesh' in batch:
+			with_side = dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
+			side = _second_stream(dev) if with_side else None
+			if side is not None:
+				side.wait_stream(torch.cuda.current_stream(dev))
+			with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+				if chamf:
+					st.gt_chamf = _losses.sample_points_from_meshes(batch['mesh'], num_samples=5000)
+				if texture:
+					st.gt_tex = _losses.sample_points_from_meshes(batch['mesh'], num_samples=1000, return_textures=True)
+				if side is not None:
+					pre_ev = torch.cuda.Event()
+					pre_ev.record(side)
 		st.res = self.model.get_meshes_from_batch(batch, is_train=is_train, no_displacement=no_displacement, **(dict(lazy_colours=True) if LAZY_COLOURS and not images else {}))
+		if pre_ev is not None:
+			main = torch.cuda.current_stream(dev)
+			main.wait_event(pre_ev)   # (the texture term reads its samples on this stream)
+			for t in (st.gt_chamf, *(st.gt_tex or ())):
+				if torch.is_tensor(t):
+					t.record_stream(main)
 		st.pred = st.gt = None
 		if rendering:
 			st.gt, R, T, side = self._render_gt(st, views, batch.get('masked_faces', None), images)

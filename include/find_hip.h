@@ -221,7 +221,6 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  * face order (no depth-slab sort), 256 a list pool of 512 entries per image (tiles without room scan the faces themselves);
  * and of find_chamfer_fwd's neighbour search: 512 all pairs at every size, 1024 the uniform grid from 64 points per cloud on (geom.hip). */
 int find_debug_raster_ablate(int64_t bits);
-
 /* ------------------------------------------------------------------------------------------------
  * Latent-table lookup.  Replaces LatentVector.__getitem__ with a tensor of indices (src/model/model.py:131-152;
  * call sites src/model/model.py:360-372 get_meshes_from_batch) and the index_put its autograd runs backward.
@@ -411,6 +410,7 @@ int find_render_bwd(const find_render_params* rp, const float* verts, const int3
  * sil_faces_per_pixel keeps the K nearest in depth (ties to the earlier face, as PyTorch3D's per-pixel K-buffer);
  * only a pixel with more than 4096 candidates is not resolved -- all of its candidates stay blended. */
 int find_render_flags(const void* ws, int32_t* out2, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * UV textures.  Replaces pytorch3d TexturesUV.sample_textures as the reference uses it for GT scans

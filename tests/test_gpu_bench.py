@@ -98,5 +98,7 @@ def test_two_rank_bench_path_runs_end_to_end_on_one_gpu():
 	c = d['collective']
 	assert c['backend'] == 'gloo' and c['world_size'] == 2 and len(c['ranks_devices']) == 2 and c['ranks_devices'][0].startswith('0:cuda:0')
 	assert 3.4e6 < c['bucket_bytes'] < 4.0e6 and c['allreduce_us_per_step'] > 0
+	# the MLP weights' part of the bucket (3.47 MB) went out inside the backward in every step of the run
+	assert 3.4e6 < c['early_prefix_bytes'] < c['bucket_bytes'] and c['steps_with_early_prefix'] >= 3 + 1
 	assert c['distinct_devices'] == 1   # (both ranks share device 0 in this test; the driver's run must show N)
 	assert len(lines[0]) < 4096

@@ -135,15 +135,20 @@ def _dp_worker(rank, world, port, n_verts, q):
 				getattr(model, k).data.copy_(lat[k])
 	fd.broadcast_parameters([p for p in model.parameters() if p.is_floating_point()])
 	params = [p for p in model.parameters() if p.requires_grad]
-	bucket = fd.GradBucket(params)
-	assert bucket.arena
+	# the MLP weights' part of the bucket leaves INSIDE the backward (GradBucket.arm_early: when autograd accumulates the first trunk weight,
+	# behind the MLP's last weight-gradient kernel), the latent tables' part behind it: same averaged gradients as one collective
+	mlp_w = [p for seq in (model.base, model.mlp_disp, model.mlp_col) for p in seq.parameters()]
+	bucket = fd.GradBucket(params, early=mlp_w)
+	bucket.arm_early(model.base[0].weight)
+	assert bucket.arena and 3.4e6 < bucket.n_early * 4 < bucket.numel * 4
 	lo, hi = fd.shard_range(n_total, rank, world)
 	idx = torch.arange(lo, hi, device=dev)
 	batch = dict(shapevec_train=model.shapevec[idx], texvec_train=model.texvec[idx], posevec_train=model.posevec[idx], reg_train=model.reg[idx])
 	res = model.get_meshes_from_batch(batch, is_train=True)
 	loss = ((res['verts'] ** 2).sum() + (res['col'] ** 2).sum()) / (hi - lo)   # a batch mean, as every FIND loss
 	loss.backward()
-	in_arena = sum(int(p.grad is not None and p.grad.data_ptr() == v.data_ptr()) for p, v in zip(params, bucket.views))
+	in_arena = sum(int(p.grad is not None and p.grad.data_ptr() == v.data_ptr()) for p, v in zip(bucket.params, bucket.views))
+	assert bucket.early_issued == 1, 'the weights\' part of the bucket did not go out inside the backward'
 	bucket.allreduce_()
 	torch.cuda.synchronize()
 	grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).cpu()

@@ -111,11 +111,11 @@ def bench_render(n_feet, n_views, size, want_image, cpu=None):
 			   ms_fwd=ms_f, ms_fwd_bwd=ms_fb, vertices_views_per_s=n_feet * 6890 * n_views / (ms_fb * 1e-3), mpix_per_s_fwd=px / ms_f / 1e3,
 			   bytes_algorithmic=alg, achieved_GBs_fwd=alg / (ms_f * 1e-3) / 1e9, hbm_frac_fwd=alg / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			   pixel_face_tests=tests, tests_per_s_fwd=tests / (ms_f * 1e-3), silhouette_candidates=cands, pixels_over_K=over_px,
-			   band_list_bytes=12 * raster_counts.last_flags[26], lane_efficiency=cands / max(tests, 1),
-			   second_sweep_pixels=raster_counts.last_flags[4], band_candidates=raster_counts.last_flags[26], second_sweep_pairs=raster_counts.last_flags[29], pool_entries=raster_counts.last_flags[6],
+			   candidate_list_bytes=8 * cands, lane_efficiency=cands / max(tests, 1),
+			   tiles_left_early=raster_counts.last_flags[26], tie_fixup_pixels=raster_counts.last_flags[7], pool_entries=raster_counts.last_flags[6],
 			   hbm_traffic_bytes_fwd_launch=RASTER_TRAFFIC_C3['raster_kernel'] if (size == 256 and n_feet == 16 and n_views == 4 and not want_image) else None,
-			   bound='VALU (pixel x face fragment math; lists in depth order let a wave leave when its pixels hold their K nearest; the K-nearest rule from per-band '
-					 'counts and products, the crossing band of the pixels over K re-evaluated as compacted (pixel, face) pairs); HBM floor of the fused output %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
+			   bound='VALU (pixel x face fragment math; lists in depth order let a wave leave when its pixels hold their K nearest), then HBM traffic of the '
+					 'per-pixel candidate lists (8 B per candidate, written once, read ~3x by the K-nearest pass); HBM floor of the fused output %.1f us' % (alg / (HBM_PEAK_GBS * 1e9) * 1e6))
 	if cpu:
 		dt = cpu('render', verts=verts[:1].cpu().numpy(), faces=f.numpy(), colors=cols[:1].cpu().numpy(), R=R[:1].numpy(), T=T[:1].numpy(), size=size,
 				 want_image=want_image)

@@ -24,7 +24,9 @@ m = su['mwl'].model
 bucket = None
 if mode == 'dp':
 	fdist.broadcast_parameters([p for p in m.parameters() if p.is_floating_point()])
-	bucket = fdist.GradBucket([p for p in m.parameters() if p.requires_grad])
+	# (as bench.py's ranks: the MLP weights' part of the bucket leaves inside the backward, the latent tables' part behind it)
+	bucket = fdist.GradBucket([p for p in m.parameters() if p.requires_grad], early=[p for seq in (m.base, m.mlp_disp, m.mlp_col) for p in seq.parameters()])
+	bucket.arm_early(m.base[0].weight)
 opt, mwl, opts, flags, batches = su['opt'], su['mwl'], su['opts'], su['flags'], su['batches']
 from find_amd.train_utils import sample_latent_vectors
 state = dict(i=0)
@@ -35,7 +37,8 @@ def step():
 	loss, _ = mwl(b, 0, opts, **flags)
 	loss.backward()
 	if bucket is not None:
-		bucket.allreduce_()
+		bucket.allreduce_(async_op=True)
+		bucket.wait()
 	opt.step()
 import ctypes
 from find_amd import _lib
@@ -46,6 +49,7 @@ print(f'{mode}: hardware-queue groups [caller, Q, T1, T2, R] = {list(g)}', flush
 for rep in range(2):
 	print(f'{mode}: {run.timed(step, steps, 10):.3f} ms/step', flush=True)
 if bucket is not None:
+	print(f'{mode}: the weights\' part of the bucket ({bucket.n_early * 4} of {bucket.numel * 4} bytes) left inside the backward in {bucket.early_issued} steps', flush=True)
 	bucket.close()
 if mode in ('dp', 'pg_only'):
 	torch.distributed.destroy_process_group()

@@ -10,7 +10,7 @@ import sys
 
 O = sys.argv[1]
 evals = float(sys.argv[2]) if len(sys.argv) > 2 else None
-KERNELS = ('raster_kernel', 'bin_kernel', 'sil_bwd_kernel', 'face_setup_kernel')
+KERNELS = ('raster_kernel', 'bin_kernel', 'sil_bwd_kernel', 'tie_fix_kernel', 'face_setup_kernel')
 dur = collections.defaultdict(list)
 for f in glob.glob(O + '/trace/*/*kernel_trace.csv'):
 	for r in csv.DictReader(open(f)):
