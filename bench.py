@@ -58,7 +58,7 @@ MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 GEMM_TRAFFIC_BYTES = 242.9e6
 GEMM5_TRAFFIC_BYTES = 227.1e6
 GEMM5_C5_TRAFFIC_BYTES = None   # (gemm5 at the C5 shape, 16 x 50 002 rows: no PMC pass taken; at the headline shape 1.005 x algorithmic, profiles/r01_traffic_pmc_summary.txt)
-GEMM7_TRAFFIC_BYTES = 222.8e6   # bf16x3 gemm7 at the headline shape: 2 x 56 265.5 KB (FETCH_SIZE, gfx950 correction) + 110 240 KB (WRITE_SIZE), profiles/r04_gemm7_pmc_summary.txt
+GEMM7_TRAFFIC_BYTES = 228.1e6   # bf16x3 gemm7 at the headline shape: (2 x 56 269.0 (FETCH_SIZE, gfx950 correction) + 110 240.0 (WRITE_SIZE)) KiB x 1024, profiles/r04_gemm7_pmc_summary.txt
 
 
 def dtype_label():

@@ -1,11 +1,16 @@
 """ctypes binding of libfind_hip.so (include/find_hip.h).  There is NO fallback: if the HIP library is
-missing or a call fails, a RuntimeError is raised."""
+missing or a call fails, a RuntimeError is raised.
+
+FIND_DIAG=1 in the environment loads libfind_hip_diag.so instead -- the laboratory build of the same sources (include/find_hip_diag.h:
+fault reproducers, superseded kernels, timers, wrong-result ablation bits).  Only tools/ do that; tests, bench.py and
+__graft_entry__ run the product."""
 import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'lib', 'libfind_hip.so')
+DIAG = os.environ.get('FIND_DIAG', '0') not in ('', '0')
+LIB_PATH = os.path.join(_PKG, 'lib', 'libfind_hip_diag.so' if DIAG else 'libfind_hip.so')
 MAX_LAYERS = 8
 ABI_VERSION = 2
 
@@ -52,12 +57,12 @@ PROTOTYPES = {
 	'find_build_arch': (c_char_p, []),
 	'find_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
 	'find_ctx_destroy': (c_int, [_P]),
-	'find_debug_stream_groups': (c_int, [_P, _P, _P]),
+	'find_ctx_stream_groups': (c_int, [_P, _P, _P]),
 	'find_ctx_stream_beside': (c_int, [_P, _P, _P, c_int32, c_int32, _P]),
 	'find_ctx_set': (c_int, [_P, c_char_p, _I]),
 	'find_ctx_get': (c_int, [_P, c_char_p, POINTER(c_int64)]),
 	'find_ctx_join': (c_int, [_P, _P]),
-	'find_debug_raster_ablate': (c_int, [_I]),
+	'find_render_switches': (c_int, [_I]),
 	'find_mlp_ws_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I, c_int]),
 	'find_mlp_fwd': (c_int, [_P, POINTER(MlpParams), _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, c_int, _P]),
 	'find_mlp_bwd_scratch_bytes': (c_int64, [POINTER(MlpParams), _I, _I, _I]),
@@ -104,6 +109,10 @@ PROTOTYPES = {
 	'find_render_bwd': (c_int, [POINTER(RenderParams), _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
 	'find_render_flags': (c_int, [_P, _P, _P]),
 }
+# include/find_hip_diag.h: what libfind_hip_diag.so exports on top
+DIAG_PROTOTYPES = {
+	'find_debug_raster_ablate': (c_int, [_I]),
+}
 
 
 def lib():
@@ -119,7 +128,7 @@ def lib():
 	# process ends up with device pointers of one runtime handed to the other and every launch fails ("no ROCm-capable device").
 	import torch  # noqa: F401
 	L = ctypes.CDLL(LIB_PATH)
-	for name, (res, args) in PROTOTYPES.items():
+	for name, (res, args) in list(PROTOTYPES.items()) + (list(DIAG_PROTOTYPES.items()) if DIAG else []):
 		try:
 			fn = getattr(L, name)
 		except AttributeError as e:
@@ -134,7 +143,7 @@ def lib():
 	for kv in filter(None, os.environ.get('FIND_TUNING', '').split(',')):
 		k, v = kv.split('=')
 		if k.strip() == 'raster_ablate':   # process-wide, not a context knob: takes effect now
-			check(L.find_debug_raster_ablate(int(v)), 'find_debug_raster_ablate')
+			_raster_switches(L, int(v))
 		else:
 			_TUNING_DEFAULTS[k.strip()] = int(v)
 	return L
@@ -163,7 +172,7 @@ def ctx(device=None):
 		check(L.find_ctx_create(idx, ctypes.byref(h)), 'find_ctx_create')
 		for k, v in _TUNING_DEFAULTS.items():
 			if k == 'raster_ablate':
-				check(L.find_debug_raster_ablate(v), 'find_debug_raster_ablate')
+				_raster_switches(L, v)
 			else:
 				check(L.find_ctx_set(h, k.encode(), v), f'find_ctx_set({k})')
 		_ctx[idx] = h
@@ -176,7 +185,7 @@ def set_tuning(key, value, device=None):
 	L = lib()
 	value = int(value)
 	if key == 'raster_ablate':
-		check(L.find_debug_raster_ablate(value), 'find_debug_raster_ablate')
+		_raster_switches(L, value)
 		return
 	if device is not None:
 		check(L.find_ctx_set(ctx(device), key.encode(), value), f'find_ctx_set({key})')
@@ -187,6 +196,15 @@ def set_tuning(key, value, device=None):
 	for h in _ctx.values():
 		check(L.find_ctx_set(h, key.encode(), value), f'find_ctx_set({key})')
 	_TUNING_DEFAULTS[key] = value
+
+
+def _raster_switches(L, bits):
+	"""The process-wide switches of the rasteriser / the Chamfer search: the product takes the result-preserving bits (find_render_switches)
+	and refuses the rest; the laboratory build takes every bit (find_debug_raster_ablate)."""
+	if DIAG:
+		check(L.find_debug_raster_ablate(bits), 'find_debug_raster_ablate')
+	else:
+		check(L.find_render_switches(bits), 'find_render_switches')
 
 
 def get_tuning(key, device=None):

@@ -1,4 +1,6 @@
-"""Build libfind_hip.so (gfx950) in-tree with hipcc.  `python -m find_amd.build [-j N] [--force]`."""
+"""Build the two libraries (gfx950) in-tree with hipcc: libfind_hip.so, the product, and libfind_hip_diag.so, the same sources with -DFIND_DIAG
+(fault reproducers, superseded A/B kernels, timers, wrong-result ablation bits: include/find_hip_diag.h) for tools/.
+`python -m find_amd.build [-j N] [--force] [--no-diag]`."""
 import os
 import subprocess
 import sys
@@ -10,7 +12,9 @@ CSRC = os.path.join(PKG, 'csrc')
 INCLUDE = os.path.join(ROOT, 'include')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'libfind_hip.so')
+LIB_DIAG = os.path.join(LIBDIR, 'libfind_hip_diag.so')
 OBJDIR = os.path.join(LIBDIR, 'obj')
+OBJDIR_DIAG = os.path.join(LIBDIR, 'obj_diag')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INCLUDE, '-I' + CSRC] + os.environ.get('FIND_EXTRA_HIPCC_FLAGS', '').split()
 
@@ -25,8 +29,15 @@ def _deps_mtime():
 	return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build(force=False, jobs=4, verbose=True):
-	"""Compile every csrc/*.hip for gfx950 and link libfind_hip.so.  Incremental on mtimes."""
+def build(force=False, jobs=4, verbose=True, diag=True):
+	"""Compile every csrc/*.hip for gfx950 and link libfind_hip.so (and, with diag, libfind_hip_diag.so).  Incremental on mtimes."""
+	lib = _build_one(LIB, OBJDIR, [], force, jobs, verbose)
+	if diag:
+		_build_one(LIB_DIAG, OBJDIR_DIAG, ['-DFIND_DIAG'], force, jobs, verbose)
+	return lib
+
+
+def _build_one(LIB, OBJDIR, extra, force, jobs, verbose):
 	os.makedirs(OBJDIR, exist_ok=True)
 	hdr_m = _deps_mtime()
 	todo, objs = [], []
@@ -38,7 +49,7 @@ def build(force=False, jobs=4, verbose=True):
 
 	def cc(job):
 		src, obj = job
-		cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+		cmd = [HIPCC] + FLAGS + extra + ['-c', src, '-o', obj]
 		if verbose:
 			print('[find_amd.build]', ' '.join(cmd), flush=True)
 		r = subprocess.run(cmd, capture_output=True, text=True)
@@ -62,4 +73,4 @@ if __name__ == '__main__':
 	j = 4
 	if '-j' in sys.argv:
 		j = int(sys.argv[sys.argv.index('-j') + 1])
-	print(build(force='--force' in sys.argv, jobs=j))
+	print(build(force='--force' in sys.argv, jobs=j, diag='--no-diag' not in sys.argv))

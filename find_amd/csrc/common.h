@@ -12,7 +12,22 @@
 namespace find {
 
 void set_error(const char* fmt, ...);
-extern int g_raster_ablate;  // profiling only (render.hip; find_debug_raster_ablate)
+extern int g_raster_ablate;  // render.hip / geom.hip switches (find_render_switches; the diagnostics build's find_debug_raster_ablate)
+
+// Product and laboratory are two libraries built from the same sources (find_amd/build.py): libfind_hip.so carries the kernels the path runs
+// and the switches that leave results unchanged; libfind_hip_diag.so (-DFIND_DIAG, include/find_hip_diag.h) adds the fault reproducers, the
+// superseded A/B kernels, the per-workgroup timers and the ablation bits under which results are WRONG.  Device code asks through
+// FIND_ABL / FIND_DBG, which are compile-time 0 / nullptr in the product, so none of that code is in its code objects.
+#ifdef FIND_DIAG
+#define FIND_DIAG_ON 1
+#else
+#define FIND_DIAG_ON 0
+#endif
+#define FIND_ABL(bits, mask) (FIND_DIAG_ON && ((bits) & (mask)))
+#define FIND_DBG(ptr) (FIND_DIAG_ON ? (ptr) : nullptr)
+// result-preserving switches, settable in both builds
+constexpr int MLP_SWITCHES = 16 | 32 | 128;              // "ablate": no s_setprio in gemm4, every column block in the Fourier dW, 32-row fused tiles
+constexpr int RASTER_SWITCHES = 8 | 16 | 256 | 512 | 1024;  // no early exit, unsorted tile lists, tiny list pool; Chamfer: all pairs / grid from 64 points
 
 inline int check_launch(const char* what) {
 	hipError_t e = hipGetLastError();

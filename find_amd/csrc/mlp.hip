@@ -136,7 +136,8 @@ struct find_ctx {
 	int num_cus = 256;
 	int lds_bytes = 160 * 1024;   // largest dynamic LDS one workgroup may ask for on this device
 	// knobs (find_hip.h: find_ctx_set)
-	int ablate = 0;
+	int ablate = 0;               // switches; the product accepts MLP_SWITCHES only (common.h), the diagnostics build every bit
+	int x3_abl = 0;               // diagnostics build: ablation variant of gemm6 / gemm7 (tools/ablate_x3.py)
 	unsigned long long* dbg = nullptr;
 	unsigned long long* dw2_verify = nullptr;   // diagnosis (tools/probe_lds_fault.py): log buffer of dw2_kernel's stage verification
 	int64_t gemm4_min_units = 1024;
@@ -392,6 +393,7 @@ static int launch_gemm5(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, 
 	return launch_gemm5_t<EPI_NONE>(c, a, feet, s);
 }
 
+#ifdef FIND_DIAG   // gemm6 (weight planes in LDS), superseded by gemm7: kept in the diagnostics build for A/B runs ("gemm7" = 0)
 template <int EPI>
 static int launch_gemm6_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
 	int lds = 0;
@@ -402,7 +404,7 @@ static int launch_gemm6_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	constexpr int G = 8 * (8 / G6_NI);  // the column groups of a row range sit 8 blocks apart (same XCD)
 	const int grid = std::max(G, (c->num_cus / G) * G);
 	if constexpr (EPI == EPI_BIAS_RELU) {
-		const int abl = (c->ablate >> 5) & 7;   // profiling only (tools/ablate_x3.py)
+		const int abl = c->x3_abl & 7;   // profiling only (tools/ablate_x3.py)
 		if (abl) {
 #define FIND_G6_ABL(N) case N: { FIND_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm6_kernel<EPI, N>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes), "hipFuncSetAttribute"); \
 			hipLaunchKernelGGL((gemm6_kernel<EPI, N>), dim3(grid), dim3(GEMM6_NW * 64), lds, s, a); return FIND_OK; }
@@ -413,6 +415,7 @@ static int launch_gemm6_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	hipLaunchKernelGGL((gemm6_kernel<EPI>), dim3(grid), dim3(GEMM6_NW * 64), lds, s, a);
 	return FIND_OK;
 }
+#endif
 
 template <int EPI>
 static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
@@ -422,8 +425,9 @@ static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	const int grid = std::max(16, (c->num_cus / 16) * 16);   // the two column halves of a row range sit 8 blocks apart (same XCD)
+#ifdef FIND_DIAG
 	if constexpr (EPI == EPI_BIAS_RELU) {
-		const int abl = (c->ablate >> 5) & 15;   // profiling only (tools/ablate_x3.py)
+		const int abl = c->x3_abl & 15;   // profiling only (tools/ablate_x3.py)
 		if (abl) {
 #define FIND_G7_ABL(N) case N: { FIND_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm7_kernel<EPI, N>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes), "hipFuncSetAttribute"); \
 			hipLaunchKernelGGL((gemm7_kernel<EPI, N>), dim3(grid), dim3(GEMM7_NW * 64), lds, s, a); return FIND_OK; }
@@ -431,6 +435,7 @@ static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 #undef FIND_G7_ABL
 		}
 	}
+#endif
 	hipLaunchKernelGGL((gemm7_kernel<EPI>), dim3(grid), dim3(GEMM7_NW * 64), lds, s, a);
 	return FIND_OK;
 }
@@ -441,11 +446,13 @@ static int launch_gemm7(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, 
 	return launch_gemm7_t<EPI_NONE>(c, a, feet, s);
 }
 
+#ifdef FIND_DIAG
 static int launch_gemm6(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (epi == EPI_BIAS_RELU) return launch_gemm6_t<EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK) return launch_gemm6_t<EPI_MASK>(c, a, feet, s);
 	return launch_gemm6_t<EPI_NONE>(c, a, feet, s);
 }
+#endif
 
 static int launch_gemm3(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (epi == EPI_BIAS_RELU) return launch_gemm3_t<64, EPI_BIAS_RELU>(c, a, feet, s);
@@ -472,7 +479,10 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	const bool k256 = b.nseg == 1 && b.nchunk == 8;
 	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
 	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s);
-	if (c->x3 && k256 && units >= c->gemm6_min_units) return c->gemm7 ? launch_gemm7(c, epi, b, feet, s) : launch_gemm6(c, epi, b, feet, s);
+#ifdef FIND_DIAG
+	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
+#endif
+	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm7(c, epi, b, feet, s);
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
 	return launch_gemm3(c, epi, b, feet, s);
@@ -954,15 +964,20 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			nmain = (int)(feet * spf);
 			int lds = 0;
 			if (c->dw_lds_free == 0) FIND_TRY(prepare_kernel(c, K_DW2, &dw2_kernel, DW2_LDS, &lds));
+#ifdef FIND_DIAG
 			if (c->dw_lds_free == 3) FIND_TRY(prepare_kernel(c, K_DW2_REPRO, &dw2_repro_kernel, DW2_LDS, &lds));
+#endif
 			Dw2Args d2;
 			memset(&d2, 0, sizeof(d2));
 			d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
 			d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = b.pw; d2.pb = pbuf;
-			d2.dbg = c->dw2_verify;   // diagnosis: verify every published ring stage (tools/probe_lds_fault.py)
+			d2.dbg = FIND_DBG(c->dw2_verify);   // diagnosis: verify every published ring stage (tools/probe_lds_fault.py)
+#ifdef FIND_DIAG   // the reproducers of the co-residence fault
 			if (c->dw_lds_free == 3) hipLaunchKernelGGL(dw2_repro_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
 			else if (c->dw_lds_free == 2) hipLaunchKernelGGL(dw4_wide_kernel, dim3((unsigned)nmain), dim3(256), 0, s, d2);
-			else if (c->dw_lds_free == 1) hipLaunchKernelGGL(dw4_kernel, dim3((unsigned)nmain), dim3(512), 0, s, d2);
+			else
+#endif
+			if (c->dw_lds_free == 1) hipLaunchKernelGGL(dw4_kernel, dim3((unsigned)nmain), dim3(512), 0, s, d2);
 			else hipLaunchKernelGGL(dw2_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d2);
 			FIND_LAUNCH_CHECK("dw2_kernel");
 		}
@@ -1615,9 +1630,9 @@ static int stream_groups(hipStream_t const* st, int n, hipEvent_t ea, hipEvent_t
 	return FIND_OK;
 }
 
-extern "C" int find_debug_stream_groups(find_ctx* c, void* caller_stream, int32_t* groups) {
-	FIND_TRY(check_ctx(c, "find_debug_stream_groups"));
-	FIND_REQUIRE(groups != nullptr, "find_debug_stream_groups: groups is NULL");
+extern "C" int find_ctx_stream_groups(find_ctx* c, void* caller_stream, int32_t* groups) {
+	FIND_TRY(check_ctx(c, "find_ctx_stream_groups"));
+	FIND_REQUIRE(groups != nullptr, "find_ctx_stream_groups: groups is NULL");
 	hipStream_t st[1 + N_SIDE];
 	st[0] = reinterpret_cast<hipStream_t>(caller_stream);
 	for (int k = 0; k < N_SIDE; ++k) st[1 + k] = c->side[k];
@@ -1750,21 +1765,32 @@ extern "C" int find_ctx_destroy(find_ctx* c) {
 namespace {
 struct Knob { const char* key; int find_ctx::*field; int64_t lo, hi; };
 const Knob KNOBS[] = {
-	{"ablate", &find_ctx::ablate, INT32_MIN, INT32_MAX}, {"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
+#ifdef FIND_DIAG
+	{"gemm7", &find_ctx::gemm7, 0, 1}, {"x3_abl", &find_ctx::x3_abl, 0, 15},
+#endif
+	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, 3}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"gemm7", &find_ctx::gemm7, 0, 1}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
 };
 }  // namespace
 
 extern "C" int find_ctx_set(find_ctx* c, const char* key, int64_t value) {
 	FIND_REQUIRE(c != nullptr && key != nullptr, "find_ctx_set: NULL argument");
+#ifdef FIND_DIAG
 	if (strcmp(key, "dbg") == 0) {  // device pointer to >= 4 * grid uint64 (profiling only)
 		c->dbg = reinterpret_cast<unsigned long long*>(value);
 		return FIND_OK;
 	}
 	if (strcmp(key, "dw2_verify") == 0) {  // device pointer to 8 + 64 * 8 uint64 (diagnosis only)
 		c->dw2_verify = reinterpret_cast<unsigned long long*>(value);
+		return FIND_OK;
+	}
+#endif
+	if (strcmp(key, "ablate") == 0) {
+		FIND_REQUIRE(value >= 0 && value <= INT32_MAX && (FIND_DIAG_ON || (value & ~(int64_t)find::MLP_SWITCHES) == 0),
+		             "find_ctx_set: ablate = %lld has bits outside the result-preserving switches 0x%x (the others exist in libfind_hip_diag.so only)", (long long)value, find::MLP_SWITCHES);
+		c->ablate = (int)value;
 		return FIND_OK;
 	}
 	if (strcmp(key, "gemm4_min_units") == 0) {
@@ -1790,13 +1816,23 @@ extern "C" int find_ctx_get(const find_ctx* c, const char* key, int64_t* value) 
 	if (strcmp(key, "device") == 0) { *value = c->device; return FIND_OK; }
 	if (strcmp(key, "events_per_call_max") == 0) { *value = c->events_per_call_max; return FIND_OK; }
 	if (strcmp(key, "gemm4_min_units") == 0) { *value = c->gemm4_min_units; return FIND_OK; }
+	if (strcmp(key, "ablate") == 0) { *value = c->ablate; return FIND_OK; }
+	if (strcmp(key, "diag") == 0) { *value = FIND_DIAG_ON; return FIND_OK; }
 	for (const Knob& k : KNOBS)
 		if (strcmp(key, k.key) == 0) { *value = c->*(k.field); return FIND_OK; }
 	set_error("find_ctx_get: unknown key %s", key);
 	return FIND_EINVAL;
 }
 
-extern "C" int find_debug_raster_ablate(int64_t bits) {
+extern "C" int find_render_switches(int64_t bits) {
+	FIND_REQUIRE(bits >= 0 && (bits & ~(int64_t)find::RASTER_SWITCHES) == 0, "find_render_switches: bits 0x%llx outside the result-preserving switches 0x%x", (unsigned long long)bits, find::RASTER_SWITCHES);
 	find::g_raster_ablate = (int)bits;
 	return FIND_OK;
 }
+
+#ifdef FIND_DIAG
+extern "C" int find_debug_raster_ablate(int64_t bits) {   // every bit, also those under which the render is wrong (include/find_hip_diag.h)
+	find::g_raster_ablate = (int)bits;
+	return FIND_OK;
+}
+#endif

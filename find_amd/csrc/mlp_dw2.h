@@ -41,6 +41,7 @@ struct Dw2Args {
 constexpr int DW2_STAGE = 2 * 16 * 1024;                // dZ rows then X rows
 constexpr int DW2_LDS = 3 * DW2_STAGE + 4 * 256 * 4;    // + bias reduction scratch
 
+#ifdef FIND_DIAG
 // Diagnosis of the LDS co-residence fault (mlp.hip): thread t compares bytes [128 t, 128 t + 128) of a published stage (16 dZ rows then 16 X
 // rows of 1 KB) with the same bytes read straight from HBM.  Log layout (uint64): [0] mismatching 16-byte pieces, [1] stages checked by
 // thread 0, [2] stages checked by workgroups whose LDS base is not 0, then up to 64 records of 8 words:
@@ -82,6 +83,7 @@ __device__ __noinline__ void dw2_verify_stage(unsigned long long* log, const cha
 		}
 	}
 }
+#endif
 
 __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,14 +187,18 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 			const int ahead = issued - (consumed + 2);
 			mfma_step(a0, b0);
 			// (diagnosis) the stage this wave has just consumed must still hold chunk c: stage index + 8 in the log
+#ifdef FIND_DIAG
 			if (g.dbg) dw2_verify_stage(g.dbg, sb, zb + (int64_t)c * 4096, xb + (int64_t)c * 4096, nullptr, nullptr, split, c, cs + 8);
+#endif
 			if (more) {
 				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 				if (ahead <= 0) FIND_WAIT_VMCNT(0);
 				else FIND_WAIT_VMCNT(8);
 				__builtin_amdgcn_s_barrier();
+#ifdef FIND_DIAG
 				if (g.dbg) dw2_verify_stage(g.dbg, nsb, zb + (int64_t)(c + 1) * 4096, xb + (int64_t)(c + 1) * 4096, c >= 2 ? zb + (int64_t)(c - 2) * 4096 : nullptr,
 											c >= 2 ? xb + (int64_t)(c - 2) * 4096 : nullptr, split, c + 1, ns);
+#endif
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			mfma_ja(a1, b1, 0);
@@ -268,8 +274,10 @@ __global__ __launch_bounds__(256, 1) void dw2_kernel(const Dw2Args g) {
 	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 312 registers by itself: the fault's victim (see the macro); with all 512, 0 wrong tensors in 450 stress passes
 	dw2_body(g, blockIdx.x);
 }
+#ifdef FIND_DIAG
 // The kernel as round 1 had it (312 registers, foreign waves fit beside it): the reproducer of the fault ("dw_lds_free" = 3), nothing else.
 __global__ __launch_bounds__(256, 1) void dw2_repro_kernel(const Dw2Args g) { dw2_body(g, blockIdx.x); }
+#endif
 
 // Several weight gradients of the same geometry in ONE launch (blockIdx.y = job): the small calls -- batch 1, the texture samples --
 // have eleven 256 x 256 weight gradients of 54 workgroups each; launched one by one they neither fill the chip nor overlap well.

@@ -143,9 +143,11 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 }
 
 __global__ __launch_bounds__(512) void dw4_kernel(const Dw2Args g) { dw4_body<2>(g, blockIdx.x); }
+#ifdef FIND_DIAG
 // (diagnosis, "dw_lds_free" = 2: dw2's register shape without its LDS ring -- four waves, one per SIMD, 128 x 128 tiles, 328 registers with 256
 // accumulators in AGPRs.  It shows the fault of dw2 without any LDS in the kernel: what matters is a wave above 256 registers, mlp_kernels.h)
 __global__ __launch_bounds__(256, 1) void dw4_wide_kernel(const Dw2Args g) { dw4_body<4>(g, blockIdx.x); }
+#endif
 
 // Several weight gradients of the same geometry in ONE launch (blockIdx.y = job), as dw2_group_kernel.
 __global__ __launch_bounds__(512) void dw4_group_kernel(const Dw2Group grp) {

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 			const float* const wfrag1 = Wc1 + li * FW_LD + lh * 4;
 #define FUSED_CHUNK(PAR, c_)                                                                                                   \
 			do {                                                                                                               \
-				if (!(g.ablate & 1)) { if (PAR) FUSED_W_LOAD(wb, pf_w, pf_ldw, pf_c); else FUSED_W_LOAD(wa, pf_w, pf_ldw, pf_c); }   \
+				if (!FIND_ABL(g.ablate, 1)) { if (PAR) FUSED_W_LOAD(wb, pf_w, pf_ldw, pf_c); else FUSED_W_LOAD(wa, pf_w, pf_ldw, pf_c); }   \
 				pf_advance();                                                                                                  \
 				__builtin_amdgcn_sched_barrier(0); /* the prefetch is issued BEFORE the MFMAs (else it sinks next to its store) */ \
 				const float* xa = xa0 + (s.src_kind == FS_SRC_PE ? ((c_) & 7) : (c_)) * 32;                                    \
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 					}                                                                                                          \
 					__builtin_amdgcn_sched_barrier(0);                                                                         \
 					const float4 b = fb[cur];                                                                                  \
-					if (!(g.ablate & 2)) {                                                                                     \
+					if (!FIND_ABL(g.ablate, 2)) {                                                                                     \
 						_Pragma("unroll") for (int rt = 0; rt < NT; ++rt) {                                                    \
 							const float4 a = fa[cur][rt];                                                                      \
 							acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[rt], 0, 0, 0);                        \
@@ -235,10 +235,10 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 				}                                                                                                              \
 				/* chunk k + 1 (requested one iteration ago) moves into the stage chunk k - 1 has left; the ring is private to */ \
 				/* the wave, whose LDS operations complete in order: no barrier */                                              \
-				if (!(g.ablate & 1)) { if (PAR) FUSED_W_STORE(wa, Wc0); else FUSED_W_STORE(wb, Wc1); }                          \
+				if (!FIND_ABL(g.ablate, 1)) { if (PAR) FUSED_W_STORE(wa, Wc0); else FUSED_W_STORE(wb, Wc1); }                          \
 			} while (0)
 			for (int c = 0; c < nchunk; c += 2) {
-				if (s.src_kind == FS_SRC_PE && (c & 7) == 0 && !(g.ablate & 8)) {
+				if (s.src_kind == FS_SRC_PE && (c & 7) == 0 && !FIND_ABL(g.ablate, 8)) {
 					// regenerate the X tile with the Fourier features of k-tile c / 8; a thread fills 16 columns of one row
 					if (c > 0) __syncthreads();   // the previous k-tile has been consumed by every wave
 					const int seg = tid & 15;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 				FUSED_CHUNK(1, c + 1);
 			}
 #undef FUSED_CHUNK
-			if (s.keep || (g.ablate & 4)) continue;
+			if (s.keep || FIND_ABL(g.ablate, 4)) continue;
 
 			// ---- epilogue: bias + ReLU / mask, store to HBM, hand the tile to the next step through LDS
 			__syncthreads();   // every wave has multiplied its last chunk: nobody reads X any more

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 				setup = false;
 			}
 
-			if (s.src_kind == FS_SRC_PE && (c & 15) == 0 && !(g.ablate & 8)) {
+			if (s.src_kind == FS_SRC_PE && (c & 15) == 0 && !FIND_ABL(g.ablate, 8)) {
 				// regenerate the tile with the Fourier features of k-tile c / 16; a thread fills 16 columns of one row
 				if (c > 0) lds_barrier();   // the previous k-tile has been consumed by every wave
 				// The padded order (mlp_kernels.h: pe_value) alternates 32-column chunks: sin of 32 features, cos of the SAME 32, ..., then
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 			if (c < nsteps) continue;
 
 			// ---- the step's last k-step is through
-			if (!s.keep && !(g.ablate & 4)) {
+			if (!s.keep && !FIND_ABL(g.ablate, 4)) {
 				// epilogue: lane (row li of block rt, half lh) holds columns wave * 32 + 8 q + 4 lh .. + 3 in acc[rt][4 q .. 4 q + 3]
 				lds_barrier();   // every wave has multiplied its last step: nobody reads the tile any more
 				const int n0 = wave * 32 + 4 * lh;

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, FIND_GEMM3_MIN_WGS) void gemm3_kernel(const Ge
 	const int64_t a_foot_stride = g.a_foot_stride;
 	const int lda = g.lda, ldw = g.ldw, ldy = g.ldy, V = g.V, nchunk = g.nchunk, tpf = g.tiles_per_foot;
 	const int NC = g.nseg * g.nchunk;
-	const int ablate = g.ablate;
-	unsigned long long* const dbg = g.dbg;
+	const int ablate = FIND_DIAG_ON ? g.ablate : 0;   // (bits 1, 2: diagnostics build only)
+	unsigned long long* const dbg = FIND_DBG(g.dbg);
 
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;

@@ -61,6 +61,7 @@ __device__ __forceinline__ void split3(const float4& lo, const float4& hi, bf16x
 	p3 = __builtin_bit_cast(bf16x8, u32x4{q0.p3, q1.p3, q2.p3, q3.p3});
 }
 
+#ifdef FIND_DIAG   // (the kernel itself: diagnostics build only, "gemm7" = 0; the product keeps this header's split helpers)
 // ABL: profiling only (tools/ablate_x3.py): 1 = no split arithmetic, 2 = no LDS fragment reads after a unit's first, 4 = no A loads after the
 // prologue -- compile-time, so that the measured loop keeps its basic blocks
 template <int EPI, int ABL = 0>
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(GEMM6_NW * 64) void gemm6_kernel(const Gemm2Args g)
 		cur = nxt; foot = nfoot; v0 = nv0;
 	}
 }
+#endif
 
 }  // namespace mlp
 }  // namespace find

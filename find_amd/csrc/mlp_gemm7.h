@@ -80,7 +80,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	};
 	auto unit_rsrc = [&](int uu) -> __amdgpu_buffer_rsrc_t {
 		// (a unit past the end of the range: size 0, every load comes back as zeros; so do the rows past the end of a foot)
-		const int ua = (g.ablate & 512) ? u0 : uu;   // profiling only: every unit reads the range's first rows (served by L2)
+		const int ua = FIND_ABL(g.ablate, 512) ? u0 : uu;   // profiling only: every unit reads the range's first rows (served by L2)
 		const int foot = ua / upf;
 		const int v0 = (ua - foot * upf) * 32;
 		const int valid = uu < u1 ? min(32, V - v0) : 0;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 
 	int cb = 0;
 	unsigned long long t_bar = 0, t_loop = 0;
-	const unsigned long long t_start = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long t_start = FIND_DBG(g.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
 
 	// lane (row i16 of block rb, quarter h4) holds columns col0 + 4 h4 .. + 3 of its row in the four registers of acc[rb]
 	f32x4 acc[2];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	};
 	struct OutTile { __amdgpu_buffer_rsrc_t y, m; };
 	auto out_tile = [&](int uq) -> OutTile {
-		const int uu = (g.ablate & 1024) ? u0 : uq;   // profiling only: every unit's block goes to the range's first rows
+		const int uu = FIND_ABL(g.ablate, 1024) ? u0 : uq;   // profiling only: every unit's block goes to the range's first rows
 		const int foot = uu / upf;
 		const int v0 = (uu - foot * upf) * 32;
 		const int nbytes = min(32, V - v0) * ldy * 4;
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	// Unit u: multiply it (buffer cb).  Under its 96 MFMAs: split and store unit u + 1 from `slot` (one PAIR of values per k-step: nine
 	// VALU instructions against twelve MFMAs), refill `slot` with unit u + 3, store the previous unit's blocks (`first`: there is none).
 	auto unit_body = [&](int u, u4 (&slot)[4], bool first) {
-		const unsigned long long tb0 = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+		const unsigned long long tb0 = FIND_DBG(g.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
 		lds_barrier();   // unit u is complete in buffer cb; nobody reads buffer cb ^ 1 (unit u - 1) any more (the loads in flight stay in flight)
-		const unsigned long long tb1 = g.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+		const unsigned long long tb1 = FIND_DBG(g.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
 		const char* buf = smem + cb * G7_BUF;
 		char* other = smem + (cb ^ 1) * G7_BUF;
 		const __amdgpu_buffer_rsrc_t rs2 = unit_rsrc(u + 3);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		}
-		if (g.dbg) {   // profiling only (tools/prof_x3.py, FIND_DBG): ticks of wave 0 at the barrier / in the k loop
+		if (FIND_DBG(g.dbg)) {   // profiling only (tools/prof_x3.py, FIND_DBG): ticks of wave 0 at the barrier / in the k loop
 			const unsigned long long te1 = __builtin_amdgcn_s_memtime();
 			t_bar += tb1 - tb0; t_loop += te1 - tb1;
 		}
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		}
 		store_block(last, 0); store_block(last, 1);
 	}
-	if (g.dbg && tid == 0) {
+	if (FIND_DBG(g.dbg) && tid == 0) {
 		g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - t_start;
 		g.dbg[blockIdx.x * 4 + 1] = t_bar; g.dbg[blockIdx.x * 4 + 2] = 0; g.dbg[blockIdx.x * 4 + 3] = t_loop;
 	}

@@ -634,7 +634,7 @@ __device__ __forceinline__ void bin_tile(const TileArgs& a, uint32_t* src, int* 
 		}
 		return cnt;
 	};
-	if (!(a.ablate & 32)) n = scan([&](uint32_t e, int pos) { if (pos < BIN_CAP) src[pos] = e; });
+	if (!FIND_ABL(a.ablate, 32)) n = scan([&](uint32_t e, int pos) { if (pos < BIN_CAP) src[pos] = e; });
 	if (n == 0) {
 		// nothing can touch this tile: its outputs are the background
 		if (lane == 0) a.tinfo[t_id] = make_int2(0, 0);
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 			}
 			// a pixel that holds its K nearest (and its colour) in front of everything from this batch on needs nothing more
 			const bool fin = !in_img || ((!want_sil || c_lt >= K) && (!want_rgb || bz < front));
-			const bool need = (early ? !fin : in_img) && !(a.ablate & 4);
+			const bool need = (early ? !fin : in_img) && !FIND_ABL(a.ablate, 4);
 			// What is still to come AFTER this batch lies behind the lower edge of the next batch's first slab.  The candidates seen so far
 			// come from faces of slabs up to that one, so none lies two slabs behind the old edge: when the edge moves by one slab, those
 			// within a slab of the old one are now in front, the rest are within a slab of the new one; by more, all are in front.
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 				const bool inb_a = need & (px <= bx4.z) & (px >= bx4.x) & (py <= by4.z) & (py >= by4.x);
 				const bool inb_b = two & need & (px <= bx4.w) & (px >= bx4.y) & (py <= by4.w) & (py >= by4.y);
 				if (__ballot(inb_a | inb_b) == 0ull) continue;
-				if (a.ablate & 64) n_eval += two ? 2 : 1;
+				if (FIND_ABL(a.ablate, 64)) n_eval += two ? 2 : 1;
 				Frag2 fr2;
 				eval_pair(blk, px, py, &fr2);   // (every lane: the ones outside the bboxes compute along and are masked out below)
 				const float2 fid = *reinterpret_cast<const float2*>(blk + 54);   // the two face indices
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 						if (cand) {
 							const float prob = silhouette_prob(f_inside ? -f_dist : f_dist, inv_sigma);
 							alpha *= (1.0f - prob);
-							if (cnt < KN_CAP && !(a.ablate & 1)) {
+							if (cnt < KN_CAP && !FIND_ABL(a.ablate, 1)) {
 								const int slot = cnt & (RING - 1);
 								ring_z[slot][tid] = f_pzc; ring_q[slot][tid] = 1.0f - prob;
 								if (slot == RING - 1) flush_ring(cnt - (RING - 1), RING);
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 			// a wave that left early has candidates it never looked at behind `front`: its pixels hold >= K in front of it, and the bound
 			// handed to the backward must keep those out even when the pixel holds exactly K
 			if (stopped && in_img) thr = front;
-			const bool over = in_img && cnt > K && !(a.ablate & 2);
+			const bool over = in_img && cnt > K && !FIND_ABL(a.ablate, 2);
 			const unsigned long long ov_all = __ballot(over);
 			if (ov_all) {
 				// (no fence: every lane reads back only the list it wrote itself -- same thread, same addresses, program order.  An
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 			}
 		}
 
-		if (a.ablate & 64) {  // diagnostics: [24] (pixel, face) tests issued (64-lane slots, in units of 64), [25] silhouette candidates (units of 64)
+		if (FIND_ABL(a.ablate, 64)) {  // diagnostics: [24] (pixel, face) tests issued (64-lane slots, in units of 64), [25] silhouette candidates (units of 64)
 			int te = n_eval, tc = in_img ? cnt : 0;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) { te += __shfl_xor(te, d, 64); tc += __shfl_xor(tc, d, 64); }

@@ -51,10 +51,10 @@ const char* find_build_arch(void);
 typedef struct find_ctx find_ctx;
 int find_ctx_create(int device, find_ctx** out);
 int find_ctx_destroy(find_ctx* ctx);
-/* Diagnosis: which of the context's four side streams share a hardware queue with `caller_stream` or with each other (HIP maps streams
+/* Which of the context's four side streams share a hardware queue with `caller_stream` or with each other (HIP maps streams
  * onto GPU_MAX_HW_QUEUES queues in creation order; two streams on one queue run in order).  groups[0] = 0 is the caller's stream,
  * groups[1 + k] side stream k; equal numbers = same queue.  Synchronises the streams it probes (~0.3 ms per probe). */
-int find_debug_stream_groups(find_ctx* ctx, void* caller_stream, int32_t* groups /* [5] */);
+int find_ctx_stream_groups(find_ctx* ctx, void* caller_stream, int32_t* groups /* [5] */);
 /* A second stream for the CALLER's own concurrent work (find_amd.model_with_loss: the Chamfer term beside the texture term's MLP pass, the
  * GT render beside the predicted one) that fits the context's stream layout: *index = the first of the n candidate streams that runs beside
  * `caller_stream` AND shares the hardware queue of side stream `role` (0 = Q, 1 = T1, 2 = T2, 3 = R), -1 if none does.  With four hardware
@@ -165,8 +165,11 @@ int64_t find_linear_wgrad_scratch_bytes(int64_t n_feet);
 int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_feet, int64_t n_pts, float* dw, float* db,
 					  void* scratch, int64_t scratch_bytes, void* stream);
 
-/* Tuning / profiling knobs of a context (no reference counterpart).  Results do not depend on any knob except "mlp_f16",
- * "dw_lds_free" = 2 / 3 (the fault they reproduce), the summation order of "reduce_exclusive" = 2 and the ablation bits.
+/* Tuning knobs of a context (no reference counterpart).  Results do not depend on any knob except "mlp_f16" (the precision, below) and the
+ * summation order of "reduce_exclusive" = 2.  The laboratory -- fault reproducers, superseded kernels kept for A/B runs, per-workgroup timers
+ * and the ablation bits under which results are WRONG -- is not in this library: find_amd/build.py builds it from the same sources with
+ * -DFIND_DIAG as libfind_hip_diag.so, whose additional keys and entry point include/find_hip_diag.h declares.  Read-only key "diag": 0 here,
+ * 1 there.
  *   "gemm4_min_units" launches with at least this many 32-row x 128-column units use the W-resident kernel on column halves (default 1024)
  *   "gemm4_small"     ... and launches of at least this many 32-row units use it on column quarters (default 64; 0 = never);
  *                     anything smaller, and the two-segment trunk-output gradient, runs on the LDS-DMA ring kernel (gemm3)
@@ -178,7 +181,7 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "reduce_stream"   1 = slab reduces of the large head layers on their own stream, two alternating slab sets; default 0 (behind their
  *                     weight-gradient launch: measured 0.6 - 0.9 % faster since the weight gradients use no LDS)
  *   "bind_streams"    1 (default) = the first call that forks picks the four side streams among a dozen candidates by probing which
- *                     hardware queue each one shares (see find_debug_stream_groups); 0 = keep them as created
+ *                     hardware queue each one shares (see find_ctx_stream_groups); 0 = keep them as created
  *   "r_queue"         which side stream's hardware queue the slab-reduce stream shares: 0 = Q, 1 = T1, 2 = T2 (default, measured best)
  *   "defer_join"      1 = the NEXT find_mlp_bwd, if it is a small per-foot call (the fused-chain path: the texture pass of a train_3d step),
  *                     returns with its weight-gradient kernels still running on the context's side streams; its latent gradients are
@@ -192,7 +195,6 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *                     2 = bf16x3 (find_mlp_params.precision 3: fp32-faithful, gemm7_kernel / dw6_kernel)
  *   "gemm5_min_units" in fp16 mode, launches of fewer 32-row units than this stay on the fp32 kernels (default 1024)
  *   "gemm6_min_units" the same threshold for the bf16x3 kernels (default 1024)
- *   "gemm7"           bf16x3 Linear kernel: 1 = gemm7 (weights in registers, activations through LDS; default), 0 = gemm6 (weight planes in LDS)
  *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
  *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped
  *                     launch + one grouped reduce; 0 = one launch per layer at every size
@@ -201,26 +203,20 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "dw6_wgs"         workgroups (= 256 x 256 slabs) of a dw6_kernel launch: 0 (default) = one per CU, half that inside a backward whose side
  *                     streams are on (it runs beside the next layer's dX GEMM; half the slabs are half the reduce's traffic)
  *   "dw_lds_free"     kernel of the 256 x 256 weight gradients: 1 = dw4_kernel (operands straight from global memory, no LDS, <= 256
- *                     registers; default), 0 = dw2_kernel (LDS-DMA ring, the whole register file of its SIMDs claimed).  2 / 3 =
- *                     dw4_wide_kernel / dw2_repro_kernel: waves of 328 / 312 registers, the reproducers of the co-residence fault
- *                     (mlp.hip: wrong weight-gradient elements whenever waves of another kernel share their SIMD) -- diagnosis only
+ *                     registers; default), 0 = dw2_kernel (LDS-DMA ring, the whole register file of its SIMDs claimed)
  *   "lds_exclusive"   1 = the LDS-DMA ring kernels reserve their CU's whole LDS: round 1's containment of that fault, which turned out
  *                     to be about registers; default 0
- *   "reduce_exclusive" diagnosis of the same fault: 1 = the slab-reduce kernels reserve their CU's whole LDS; 2 = they use no LDS and are
- *                     slow, so that they stay resident beside later weight-gradient kernels (the stress configuration: with
- *                     "dw_lds_free" = 2 or 3 every backward pass has wrong elements); default 0
- *   "ablate", "dbg"   profiling switches of the GEMM kernels ("ablate" bits in fused_chain_kernel: 1 no W staging, 2 no MFMAs, 4 no
- *                     epilogue, 8 no Fourier features -- results are WRONG with any of these set; bits with unchanged results: 16 no
- *                     s_setprio in gemm4, 32 every column block in the Fourier layer's weight gradient, 128 fused chains always on
- *                     32-row tiles); "dbg" = device pointer to per-workgroup timers
+ *   "reduce_exclusive" the stress test's hook for that fault (tests/test_gpu_mlp.py): 1 = the slab-reduce kernels reserve their CU's whole LDS;
+ *                     2 = they use no LDS and are slow, so that they stay resident beside later weight-gradient kernels; default 0
+ *   "ablate"          switches that leave results unchanged (the tests compare them): 16 no s_setprio in gemm4 / gemm7, 32 every column block in
+ *                     the Fourier layer's weight gradient, 128 fused chains always on 32-row tiles.  Any other bit is refused here.
  * The Python binding applies FIND_TUNING="key=value,..." from the environment to every context it creates. */
 
-/* Process-wide profiling switch of the rasteriser (diagnosis only; bits 1, 2, 4 and 32 make the render WRONG):
- * bits 1 no candidate lists, 2 no K-nearest pass, 4 no fragment math, 32 no bbox scan in the binning pass, 64 statistics in the flags;
- * bits with unchanged results (tests/test_gpu_render.py compares them): 8 no early exit of finished pixels / tiles, 16 tile lists left in
- * face order (no depth-slab sort), 256 a list pool of 512 entries per image (tiles without room scan the faces themselves);
- * and of find_chamfer_fwd's neighbour search: 512 all pairs at every size, 1024 the uniform grid from 64 points per cloud on (geom.hip). */
-int find_debug_raster_ablate(int64_t bits);
+/* Process-wide switches of the rasteriser and of find_chamfer_fwd's neighbour search, all with unchanged results (tests/test_gpu_render.py,
+ * tests/test_gpu_geom.py compare them): 8 no early exit of finished pixels / tiles, 16 tile lists left in face order (no depth-slab sort),
+ * 256 a list pool of 512 entries per image (tiles without room scan the faces themselves); Chamfer: 512 all pairs at every size, 1024 the
+ * uniform grid from 64 points per cloud on (geom.hip).  Any other bit is refused (FIND_EINVAL). */
+int find_render_switches(int64_t bits);
 /* ------------------------------------------------------------------------------------------------
  * Latent-table lookup.  Replaces LatentVector.__getitem__ with a tensor of indices (src/model/model.py:131-152;
  * call sites src/model/model.py:360-372 get_meshes_from_batch) and the index_put its autograd runs backward.

@@ -410,6 +410,19 @@ def test_context_reports_the_device_and_keeps_its_knobs():
 		_lib.set_tuning('no_such_knob', 1)
 	with pytest.raises(RuntimeError, match='out of range'):
 		_lib.set_tuning('bwd_streams', 7)
+	# the laboratory's keys and wrong-result bits exist in libfind_hip_diag.so only (include/find_hip_diag.h)
+	assert _lib.get_tuning('diag') == 0
+	for key in ('gemm7', 'x3_abl', 'dbg', 'dw2_verify'):
+		with pytest.raises(RuntimeError, match='unknown key'):
+			_lib.set_tuning(key, 0)
+	with pytest.raises(RuntimeError, match='out of range'):
+		_lib.set_tuning('dw_lds_free', 2)
+	for bits in (1, 2, 4, 8, 512, 1024, 64):
+		with pytest.raises(RuntimeError, match='result-preserving'):
+			_lib.set_tuning('ablate', bits)
+	_lib.set_tuning('ablate', 16 | 32 | 128)
+	assert _lib.get_tuning('ablate') == 176
+	_lib.set_tuning('ablate', 0)
 	# a second context on the same device is independent of the first
 	h = ctypes.c_void_p()
 	_lib.check(L.find_ctx_create(torch.cuda.current_device(), ctypes.byref(h)), 'find_ctx_create')
@@ -638,7 +651,7 @@ def test_side_streams_are_bound_to_queues_beside_the_callers():
 		finally:
 			_lib._ctx[torch.cuda.current_device()] = prev
 		g = (ctypes.c_int32 * 5)()
-		_lib.check(L.find_debug_stream_groups(h, _lib.current_stream(torch.device('cuda')), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+		_lib.check(L.find_ctx_stream_groups(h, _lib.current_stream(torch.device('cuda')), ctypes.cast(g, ctypes.c_void_p)), 'find_ctx_stream_groups')
 		caller, q, t1, t2, r = list(g)
 		assert caller == 0
 		assert len({caller, q, t1, t2}) == 4, list(g)
@@ -650,7 +663,7 @@ def test_side_streams_are_bound_to_queues_beside_the_callers():
 
 def test_stream_beside_picks_a_stream_on_the_asked_hardware_queue():
 	"""find_ctx_stream_beside (what ModelWithLoss's second stream is chosen with): among a dozen candidate streams the one returned runs
-	beside the caller's stream and shares the hardware queue of the asked side stream -- checked against find_debug_stream_groups with the
+	beside the caller's stream and shares the hardware queue of the asked side stream -- checked against find_ctx_stream_groups with the
 	candidate put in the caller's place --; bad arguments are refused; ModelWithLoss's own pick sits on Q's queue."""
 	import ctypes
 	from find_amd import _lib
@@ -666,16 +679,16 @@ def test_stream_beside_picks_a_stream_on_the_asked_hardware_queue():
 		_lib.check(L.find_ctx_stream_beside(h, ctypes.c_void_p(main.cuda_stream), arr, len(cands), role, ctypes.byref(idx)), 'find_ctx_stream_beside')
 		assert 0 <= idx.value < len(cands), (role, idx.value)   # (twelve streams over four hardware queues: every queue is met)
 		g = (ctypes.c_int32 * 5)()
-		_lib.check(L.find_debug_stream_groups(h, ctypes.c_void_p(cands[idx.value].cuda_stream), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+		_lib.check(L.find_ctx_stream_groups(h, ctypes.c_void_p(cands[idx.value].cuda_stream), ctypes.cast(g, ctypes.c_void_p)), 'find_ctx_stream_groups')
 		assert g[1 + role] == g[0], (role, list(g))                 # the candidate (group 0 here) shares side stream `role`'s queue
 		g2 = (ctypes.c_int32 * 5)()
-		_lib.check(L.find_debug_stream_groups(h, ctypes.c_void_p(main.cuda_stream), ctypes.cast(g2, ctypes.c_void_p)), 'find_debug_stream_groups')
+		_lib.check(L.find_ctx_stream_groups(h, ctypes.c_void_p(main.cuda_stream), ctypes.cast(g2, ctypes.c_void_p)), 'find_ctx_stream_groups')
 		assert g2[1 + role] != g2[0]                                 # ... which is not the caller's
 	assert L.find_ctx_stream_beside(h, ctypes.c_void_p(main.cuda_stream), arr, len(cands), 9, ctypes.byref(idx)) != 0
 	assert L.find_ctx_stream_beside(h, ctypes.c_void_p(main.cuda_stream), None, len(cands), 0, ctypes.byref(idx)) != 0
 	side = _second_stream(dev)
 	g = (ctypes.c_int32 * 5)()
-	_lib.check(L.find_debug_stream_groups(h, ctypes.c_void_p(side.cuda_stream), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+	_lib.check(L.find_ctx_stream_groups(h, ctypes.c_void_p(side.cuda_stream), ctypes.cast(g, ctypes.c_void_p)), 'find_ctx_stream_groups')
 	assert g[1] == g[0], list(g)   # Q's queue
 	torch.cuda.synchronize()
 

@@ -118,6 +118,32 @@ def test_c_abi_exports_every_declared_symbol():
 	assert ctypes.sizeof(_lib.RenderParams) == 21 * 4
 
 
+def test_the_product_library_carries_no_laboratory_code():
+	"""include/find_hip_diag.h declares what only libfind_hip_diag.so (-DFIND_DIAG) has: the product exports none of it, holds none of the
+	reproducer / superseded kernels in its code objects, and refuses the switches under which results are wrong -- before any HIP call."""
+	import subprocess
+	from find_amd import _lib
+	assert not _lib.DIAG and _lib.LIB_PATH.endswith('libfind_hip.so')
+	hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'find_hip_diag.h')).read(), flags=re.S)
+	extra = set(re.findall(r'\b(find_[a-z0-9_]+)\s*\(', hdr))
+	assert extra == set(_lib.DIAG_PROTOTYPES) and extra
+	L = _lib.lib()
+	for name in extra:
+		assert not hasattr(L, name), name
+	diag = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), 'libfind_hip_diag.so'))
+	for name in list(_lib.PROTOTYPES) + list(extra):
+		assert hasattr(diag, name), name
+	kernels = lambda path: subprocess.run(['strings', path], capture_output=True, text=True).stdout
+	lab = ('gemm6_kernel', 'dw4_wide_kernel', 'dw2_repro_kernel', 'dw2_verify_stage')
+	prod, dg = kernels(_lib.LIB_PATH), kernels(diag._name)
+	for k in lab:
+		assert k not in prod and k in dg, k
+	for bits in (1, 2, 4, 32, 64, 8 | 1):
+		assert L.find_render_switches(bits) == -1 and b'result-preserving' in L.find_last_error()
+	for bits in (8, 16, 256, 512, 1024, 0):
+		assert L.find_render_switches(bits) == 0
+
+
 def test_error_reporting_without_gpu():
 	"""Argument validation happens before any launch, so it can be exercised on the CPU-only builder."""
 	from find_amd import _lib

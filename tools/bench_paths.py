@@ -49,14 +49,18 @@ def views(m, seed=7):
 
 
 # HBM-side bytes per forward launch of raster_kernel / per launch of sil_bwd_kernel at the C3 shape, rocprofv3 --pmc FETCH_SIZE (x2, the
-# gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r03_raster_pmc.txt)
-RASTER_TRAFFIC_C3 = {'raster_kernel': 2 * 511493.6 * 1024 + 533171.5 * 1024, 'sil_bwd_kernel': 2 * 96658.4 * 1024 + 83899.6 * 1024}   # profiles/r03_raster_pmc.txt
+# gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE in separate passes (tools/prof_raster.sh -> profiles/r05_raster_pmc.txt)
+RASTER_TRAFFIC_C3 = {'raster_kernel': 2 * 649308.6 * 1024 + 616660.7 * 1024, 'sil_bwd_kernel': 2 * 118954.5 * 1024 + 83899.9 * 1024}   # profiles/r05_raster_pmc.txt
 
 
 def raster_counts(verts, fc, Rc, Tc, params):
-	"""(pixel x face tests issued, silhouette candidates) of one forward render: the rasteriser's diagnostic counters (ablation bit 64)."""
+	"""(pixel x face tests issued, silhouette candidates) of one forward render: the rasteriser's diagnostic counters (ablation bit 64, which
+	only the laboratory build has: run with FIND_DIAG=1; the product library yields no counts)."""
 	import ctypes
 	from find_amd import _lib
+	if not _lib.DIAG:
+		raster_counts.last_flags = [None] * 64
+		return None, None, None
 	from find_amd._lib import check, current_stream, ptr
 	from find_amd.functional import _faces_i32, _ws
 	L = _lib.lib()
@@ -110,8 +114,8 @@ def bench_render(n_feet, n_views, size, want_image, cpu=None):
 	out = dict(path=f'render+{"phong+" if want_image else ""}silhouette fwd+bwd', workload=f'{n_feet} feet x {n_views} views @{size}^2, V=6890 F={F}',
 			   ms_fwd=ms_f, ms_fwd_bwd=ms_fb, vertices_views_per_s=n_feet * 6890 * n_views / (ms_fb * 1e-3), mpix_per_s_fwd=px / ms_f / 1e3,
 			   bytes_algorithmic=alg, achieved_GBs_fwd=alg / (ms_f * 1e-3) / 1e9, hbm_frac_fwd=alg / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
-			   pixel_face_tests=tests, tests_per_s_fwd=tests / (ms_f * 1e-3), silhouette_candidates=cands, pixels_over_K=over_px,
-			   candidate_list_bytes=8 * cands, lane_efficiency=cands / max(tests, 1),
+			   pixel_face_tests=tests, tests_per_s_fwd=None if tests is None else tests / (ms_f * 1e-3), silhouette_candidates=cands, pixels_over_K=over_px,
+			   candidate_list_bytes=None if cands is None else 8 * cands, lane_efficiency=None if cands is None else cands / max(tests, 1),
 			   tiles_left_early=raster_counts.last_flags[26], tie_fixup_pixels=raster_counts.last_flags[7], pool_entries=raster_counts.last_flags[6],
 			   hbm_traffic_bytes_fwd_launch=RASTER_TRAFFIC_C3['raster_kernel'] if (size == 256 and n_feet == 16 and n_views == 4 and not want_image) else None,
 			   bound='VALU (pixel x face fragment math; lists in depth order let a wave leave when its pixels hold their K nearest), then HBM traffic of the '

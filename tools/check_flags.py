@@ -1,5 +1,6 @@
 """Count pixels with more than faces_per_pixel silhouette candidates at C3 / C4-share sizes (find_render_flags)."""
 import os, sys, ctypes
+os.environ.setdefault('FIND_DIAG', '1')   # laboratory build (include/find_hip_diag.h): this tool uses what the product library does not carry
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from find_amd import functional_render as FR, synthetic, _lib

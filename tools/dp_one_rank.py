@@ -44,7 +44,7 @@ import ctypes
 from find_amd import _lib
 g = (ctypes.c_int32 * 5)()
 step(); torch.cuda.synchronize()
-_lib.check(_lib.lib().find_debug_stream_groups(_lib.ctx(run.dev), _lib.current_stream(run.dev), ctypes.cast(g, ctypes.c_void_p)), 'find_debug_stream_groups')
+_lib.check(_lib.lib().find_ctx_stream_groups(_lib.ctx(run.dev), _lib.current_stream(run.dev), ctypes.cast(g, ctypes.c_void_p)), 'find_ctx_stream_groups')
 print(f'{mode}: hardware-queue groups [caller, Q, T1, T2, R] = {list(g)}', flush=True)
 for rep in range(2):
 	print(f'{mode}: {run.timed(step, steps, 10):.3f} ms/step', flush=True)

@@ -1,6 +1,7 @@
 """Where the time of fused_chain_kernel goes: forward chain at batch 1 (6890 rows, no grad) under the kernel's ablation bits
 (find_ctx knob "ablate": 1 no W staging, 2 no MFMAs, 4 no epilogue, 8 no Fourier features).  python tools/fused_micro.py"""
 import os, sys
+os.environ.setdefault('FIND_DIAG', '1')   # laboratory build (include/find_hip_diag.h): this tool uses what the product library does not carry
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from find_amd import _lib, synthetic

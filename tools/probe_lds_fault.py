@@ -2,6 +2,7 @@
 ring stage with the same bytes in HBM and logs the mismatching 16-byte pieces with the workgroup's HW_REG_LDS_ALLOC (LDS base / size),
 HW_ID and whether the piece still holds what the stage held three chunks ago.  python tools/probe_lds_fault.py [passes] [lds_exclusive]"""
 import os, sys
+os.environ.setdefault('FIND_DIAG', '1')   # laboratory build (include/find_hip_diag.h): this tool uses what the product library does not carry
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

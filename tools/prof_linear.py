@@ -3,6 +3,7 @@
 Usage: python3 tools/prof_linear.py [iters] [n_feet] [n_pts] [mode] [ablate]   mode 4 = gemm4 (default routing), 3 = gemm3 for every size"""
 import ctypes
 import os
+os.environ.setdefault('FIND_DIAG', '1')   # laboratory build (include/find_hip_diag.h): this tool uses what the product library does not carry
 import sys
 
 import torch

@@ -4,6 +4,7 @@ time per launch of find_linear_relu_fwd at a given shape and the error of each a
 Usage: python3 tools/prof_x3.py [iters] [n_feet] [n_pts]"""
 import ctypes
 import os
+os.environ.setdefault('FIND_DIAG', '1')   # laboratory build (include/find_hip_diag.h): this tool uses what the product library does not carry
 import sys
 
 import torch
