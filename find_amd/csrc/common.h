@@ -74,6 +74,17 @@ struct Carver {
 // (__syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: in a loop that keeps global loads in flight across iterations -- the
 // prefetch of a software pipeline -- it drains them at every barrier and exposes the whole memory latency once per iteration: a quarter
 // of gemm7's time and more of dw6's before this.)
+// Buffer stores of more than 64 bits go out WITHOUT an SGPR offset (the offset is folded into the VGPR one).  gfx950 reads the data registers
+// of such a store after it has issued: a VALU instruction right behind it that overwrites one of them corrupts the stored dword -- 0.11 % of
+// the stores under a backed-up memory pipeline with an SGPR offset, 21 % without (tools/store_hazard_probe.hip; one wait state cures both).
+// LLVM's hazard recognizer inserts that wait state only for the form without an SGPR offset (GCNHazardRecognizer::createsVALUHazard follows
+// the ISA manual's rule), so that is the form to emit; tools/check_store_hazard.py lints the built code objects for the unprotected one
+// (tests/test_host_api.py runs it).  Found in round 5: gemm7's masked-dX stores, single elements wrong, differently from run to run.
+typedef unsigned find_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_b128(find_u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voff, int off) {
+	__builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff + off, 0, 0);
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Wave-level sum over 64 lanes (result valid in every lane).

@@ -958,7 +958,10 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			spf = 1;
 			if (cpf16 > 0) {
 				const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
-				cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(c->dw2_min_cps, cpf16));  // few, long runs: slab traffic
+				// few, long runs (slab traffic) -- unless that leaves CUs without a workgroup: a launch of few rows (the head's first-layer gradient
+				// over the foot-summed dZ of a shared template: 6890 rows = 54 runs of 8 chunks, 86 us) is bounded by its longest run, not by slabs
+				const int floor_cps = (feet * cpf16 < (int64_t)c->dw2_min_cps * c->num_cus) ? std::min(2, c->dw2_min_cps) : c->dw2_min_cps;
+				cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(floor_cps, cpf16));
 				spf = (int)cdiv(cpf16, cps2);
 			}
 			nmain = (int)(feet * spf);

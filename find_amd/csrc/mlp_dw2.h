@@ -259,7 +259,7 @@ __device__ __forceinline__ void dw2_body(const Dw2Args& g, const int split) {
 				// (value copies: __builtin_bit_cast on a vector-element lvalue reads element 0)
 				const float f0 = acc[ja][0][r], f1 = acc[ja][1][r], f2 = acc[ja][2][r], f3 = acc[ja][3][r];
 				v.x = __float_as_uint(f0); v.y = __float_as_uint(f1); v.z = __float_as_uint(f2); v.w = __float_as_uint(f3);
-				__builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, nrow * 1024, 0);
+				store_b128(v, rsrc, voff, nrow * 1024);
 			}
 	}
 	if (pb) {

@@ -129,7 +129,7 @@ __device__ __forceinline__ void dw4_body(const Dw2Args& g, const int split) {
 					u32x4 v;
 					const float f0 = acc[ja][0][r], f1 = acc[ja][1][r], f2 = acc[ja][2 % NB][r], f3 = acc[ja][3 % NB][r];
 					v.x = __float_as_uint(f0); v.y = __float_as_uint(f1); v.z = __float_as_uint(f2); v.w = __float_as_uint(f3);
-					__builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, nrow * 1024, 0);
+					store_b128(v, rsrc, voff, nrow * 1024);
 				}
 			}
 	}

@@ -316,9 +316,8 @@ __global__ __launch_bounds__(512, 2) void fused6_kernel(const FusedArgs g) {
 					if (s.dst) {
 #pragma unroll
 						for (int q = 0; q < 4; ++q)
-							__builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[rt][4 * q]), __float_as_uint(acc[rt][4 * q + 1]), __float_as_uint(acc[rt][4 * q + 2]),
-																		 __float_as_uint(acc[rt][4 * q + 3])},
-																   drs, voff + q * 32, rt * 32 * W * 4, 0);
+							store_b128(u32x4{__float_as_uint(acc[rt][4 * q]), __float_as_uint(acc[rt][4 * q + 1]), __float_as_uint(acc[rt][4 * q + 2]), __float_as_uint(acc[rt][4 * q + 3])},
+									   drs, voff + q * 32, rt * 32 * W * 4);
 					}
 					if (s.to_lds) {
 #pragma unroll

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			if constexpr (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
 			if constexpr (EPI == EPI_MASK) v[e] = (__uint_as_float(mv[rb][e]) > 0.f) ? v[e] : 0.f;
 		}
-		__builtin_amdgcn_raw_buffer_store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4, 0);
+		store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4);   // (no SGPR offset: common.h)
 	};
 	auto mm = [&](const bf16x8& w, const bf16x8& x, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0); };
 

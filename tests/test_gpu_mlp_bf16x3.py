@@ -179,14 +179,17 @@ def test_backward_matches_reference_golden_under_bf16x3(every_size, golden_main,
 	assert n >= 20
 
 
-@pytest.mark.parametrize('n_feet,n_verts,shared', [(16, 6890, True), (16, 1000, False)])
+@pytest.mark.parametrize('n_feet,n_verts,shared', [(16, 6890, True), (16, 1000, False), (8, 6890, True), (6, 6890, True), (32, 6890, True)])
 def test_bf16x3_backward_is_bit_reproducible(n_feet, n_verts, shared):
-	"""No float atomics and a fixed split geometry: two passes of the same forward + backward give bit-identical outputs and gradients --
+	"""No float atomics and a fixed split geometry: repeated passes of the same forward + backward give bit-identical outputs and gradients --
 	the headline's main pass (gemm7 / dw6, the trunk on 32-row fused6 tiles) and the texture pass's shape (64-row fused6 tiles, grouped weight
 	gradients); the slab reduces are deterministic, the chains' LDS tile changes hands behind barriers only (tools/check_determinism.py is
-	the long version: 100 - 200 passes)."""
+	the long version: 100 - 200 passes).  8, 6 and 32 feet: row ranges of gemm7 with an even unit count -- where round 5 found single dX
+	elements changing from run to run (a 128-bit buffer store whose data register the next VALU instruction overwrote: csrc/common.h
+	store_b128, tools/store_hazard_probe.hip; a data-parallel rank of the headline holds 8 feet)."""
 	a = _run_model(n_feet, n_verts, shared, 'bf16x3')
-	b = _run_model(n_feet, n_verts, shared, 'bf16x3')
-	assert torch.equal(a[0], b[0])
-	for n in a[1]:
-		assert torch.equal(a[1][n], b[1][n]), n
+	for _ in range(3 if n_feet != 16 else 1):
+		b = _run_model(n_feet, n_verts, shared, 'bf16x3')
+		assert torch.equal(a[0], b[0])
+		for n in a[1]:
+			assert torch.equal(a[1][n], b[1][n]), n
