@@ -635,11 +635,14 @@ __device__ __forceinline__ void apply_L(Q qv, const int32_t* __restrict__ faces,
 	*rowsum = quad_sum(rs);
 }
 
-constexpr int SMOOTH_VPB = 256;   // vertices per block: 1024 threads = 256 quads
+// vertices per block: 256 threads = 64 quads.  (Small blocks on purpose: inside a training step these launches run beside the Chamfer
+// search / the texture pass's trailing weight-gradient kernels, and a 16-wave block found room on a CU only when one of theirs retired --
+// the forward took 100 us beside nn_kernel against 18 us alone.)
+constexpr int SMOOTH_VPB = 64;
 
 // forward per vertex: lap = (L V)_i * nw_i - V_i; block partial sums of |lap| and of the half edge-length sums.
 // Saves nw_i (rowsum>0 ? 1/rowsum : rowsum) and u_i = lap_i/|lap_i| scaled later in backward.
-__global__ __launch_bounds__(1024) void smooth_fwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+__global__ __launch_bounds__(256) void smooth_fwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
 														   const float* __restrict__ fw, const int32_t* __restrict__ vf_off,
 														   const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
 														   const int32_t* __restrict__ nbr_idx, int n_verts, int n_faces,
@@ -670,13 +673,13 @@ __global__ __launch_bounds__(1024) void smooth_fwd_kernel(const float* __restric
 			lapdir_out[o * 3 + 0] = lap.x * inv; lapdir_out[o * 3 + 1] = lap.y * inv; lapdir_out[o * 3 + 2] = lap.z * inv;
 		}
 	}
-	__shared__ float red[2][16];
+	__shared__ float red[2][4];
 	const float a = wave_sum(lap_n), b = wave_sum(edge_s);
 	if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
 	__syncthreads();
 	if (threadIdx.x < 2) {
 		float sum = 0.f;
-		for (int w = 0; w < 16; ++w) sum += red[threadIdx.x][w];
+		for (int w = 0; w < 4; ++w) sum += red[threadIdx.x][w];
 		partial[((int64_t)m * gridDim.x + blockIdx.x) * 2 + threadIdx.x] = sum;
 	}
 }
@@ -699,9 +702,6 @@ __global__ void smooth_finalize_kernel(const float* __restrict__ partial, int n_
 
 // backward: with u_i = g_lap/(V N) * lapdir_i and q_i = nw_i * u_i:   dV_i = (L q)_i - u_i  +  g_edge/(E N) * 2 * sum_j (v_i - v_j)
 // (q is formed where it is read -- nw_j and lapdir_j instead of a stored q_j: one launch and one (N, V, 3) buffer less)
-// (256-thread blocks: inside a training step this launch runs beside the texture pass's trailing weight-gradient kernels, and a 16-wave
-// block found room on a CU only when one of theirs retired -- 150 us in the step against 20 us alone)
-constexpr int SMOOTH_BWD_VPB = 64;
 __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
 														   const float* __restrict__ fw, const int32_t* __restrict__ vf_off,
 														   const int32_t* __restrict__ vf_items, const int32_t* __restrict__ nbr_off,
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float* __restrict
 														   const float* __restrict__ g_lap, float s_edge, float s_lap, int n_meshes, int n_verts,
 														   int n_faces, int n_edges, float* __restrict__ d_verts) {
 	const int m = blockIdx.y;
-	const int i = blockIdx.x * SMOOTH_BWD_VPB + ((int)threadIdx.x >> 2), t = threadIdx.x & 3;
+	const int i = blockIdx.x * SMOOTH_VPB + ((int)threadIdx.x >> 2), t = threadIdx.x & 3;
 	const bool live = i < n_verts;
 	const float* vp = verts + (int64_t)m * n_verts * 3;
 	const float* nwp = nw + (int64_t)m * n_verts;
@@ -1212,7 +1212,7 @@ static int smooth_fwd_body(const char* who, const float* verts, const int32_t* f
 	if (ws_bytes < w.bytes) { set_error("%s: workspace too small", who); return FIND_EWORKSPACE; }
 	hipStream_t s = (hipStream_t)stream;
 	hipLaunchKernelGGL(cot_weights_kernel, dim3((unsigned)cdiv(n_faces, 256), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, (int)n_verts, (int)n_faces, w.fw);
-	hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(1024), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off,
+	hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)w.nblk, (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off,
 					   nbr_idx, (int)n_verts, (int)n_faces, w.nw, w.lapdir, w.partial);
 	hipLaunchKernelGGL(smooth_finalize_kernel, dim3(1), dim3(64), 0, s, w.partial, (int)n_meshes, w.nblk, (int)n_verts, (int)n_edges, loss_edge, loss_lap,
 					   w_edge, w_lap, loss_sum);
@@ -1229,7 +1229,7 @@ static int smooth_bwd_body(const char* who, const float* verts, const int32_t* f
 	carve_smooth(n_meshes, n_verts, n_faces, ws, &w);
 	if (ws_bytes < w.bytes) { set_error("%s: workspace too small", who); return FIND_EWORKSPACE; }
 	hipStream_t s = (hipStream_t)stream;
-	hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)cdiv(n_verts, SMOOTH_BWD_VPB), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off, nbr_idx,
+	hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)cdiv(n_verts, SMOOTH_VPB), (unsigned)n_meshes), dim3(256), 0, s, verts, faces, w.fw, vf_off, vf_items, nbr_off, nbr_idx,
 					   w.nw, w.lapdir, g_edge, g_lap, s_edge, s_lap, (int)n_meshes, (int)n_verts, (int)n_faces, (int)n_edges, d_verts);
 	FIND_LAUNCH_CHECK(who);
 	return FIND_OK;
