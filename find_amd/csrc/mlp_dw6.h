@@ -15,6 +15,11 @@
 //   * two chunk buffers (2 x 48 KB): the chunk after the one being multiplied is loaded, split and stored under the MFMAs; one
 //     barrier per chunk.
 // Rows past the end of a foot are zero-filled at load time (no tail path): chunks_per_foot = ceil(V / 16).
+// Where the time goes (round 5, same box, find_linear_wgrad at 16 x 6890 rows incl. the 20-us slab reduce): 101.5 us as is; without the
+// split arithmetic 85.5; without the LDS plane writes 93.6; without the loads 89.7; without the barrier 97.4; without the fragment reads of
+// the k loop 102.4; with all of that gone -- MFMAs, prologue and slab epilogue only -- 83.5.  A loop of nothing but these MFMAs runs at
+// 16 - 17.6 us per 1000 (tools/mfma_bf16_mix.hip: the clock under bf16 MFMA load is 1.8 - 2.0 GHz, not the 2.4 the 2.5 PFLOP/s peak is
+// quoted at), i.e. 44 us for the 2592 of a workgroup here: the kernel's loop is at ~0.7 of what the pipe sustains, 0.40 of the quoted peak.
 #pragma once
 #include "mlp_dw3.h"
 #include "mlp_gemm6.h"
@@ -118,6 +123,16 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 		// the run's last chunk -- so that the instruction order can be prescribed: while the matrix pipe runs the 24 products of column
 		// block tj, the wave splits and stores column e = tj of the NEXT chunk's rows (`set`: in registers for the last two chunks), then
 		// refills `set` with the chunk three ahead.
+		// The split of one column (e) of the wave's eight staged rows -- four row pairs, three pieces each -- cut into twelve stages of four
+		// instructions (piece k of pair jj: round what is left to bf16, take it off): one stage goes behind every PAIR of MFMAs, fenced
+		// by sched_barrier, so that the matrix pipe never waits for a run of VALU work.  (Round 4 left the placement to
+		// sched_group_barrier hints; the compiler clustered 18-MFMA and 50-VALU runs and the pipe sat idle during the latter: 43 % busy.)
+		struct ColSplit { f32x2 r[4]; u32x4 p[3]; float t; };
+		auto cs_stage = [&](ColSplit& c, int jj, int k) {
+			const unsigned qv = __builtin_bit_cast(unsigned, __builtin_convertvector(c.r[jj], bf16x2));
+			c.p[k][jj] = qv;
+			if (k < 2) c.r[jj] = c.r[jj] - f32x2{__uint_as_float(qv << 16), __uint_as_float(qv & 0xffff0000u)};
+		};
 		auto chunk_body = [&](int q, u4 (&set)[8]) {
 			const char* buf = smem + cb * DW6_BUF;
 			char* other = smem + (cb ^ 1) * DW6_BUF;   // its readers finished before the last barrier
@@ -126,33 +141,37 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 #pragma unroll
 			for (int i = 0; i < 4; ++i) { a1[i] = frag(buf, za, i, 0); a2[i] = frag(buf, za, i, 1); a3[i] = frag(buf, za, i, 2); }
 			b1[0] = frag(buf, xa, 0, 0); b2[0] = frag(buf, xa, 0, 1); b3[0] = frag(buf, xa, 0, 2);
-			FIND_DW6_WAIT(set, 8);   // (behind this chunk's eight loads: the eight of the chunk after it)
-			__builtin_amdgcn_sched_group_barrier(0x100, 15, 0);
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int tj = 0; tj < 4; ++tj) {
 				const int cu = tj & 1, nx = cu ^ 1;
-				if (tj + 1 < 4) { b1[nx] = frag(buf, xa, tj + 1, 0); b2[nx] = frag(buf, xa, tj + 1, 1); b3[nx] = frag(buf, xa, tj + 1, 2); }
-				store_part(other, set, tj, keep);
-				// smallest terms first
+				ColSplit c;
 #pragma unroll
-				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ti], b1[cu], acc[ti][tj], 0, 0, 0);
+				for (int jj = 0; jj < 4; ++jj) c.r[jj] = f32x2{comp(set[2 * jj], tj), comp(set[2 * jj + 1], tj)};
+				c.t = 0.f;
 #pragma unroll
-				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ti], b3[cu], acc[ti][tj], 0, 0, 0);
+				for (int sl = 0; sl < 12; ++sl) {
+					// MFMAs 2 sl, 2 sl + 1 of the 24: product group g (smallest terms first), row block ti
 #pragma unroll
-				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ti], b2[cu], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ti], b1[cu], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ti], b2[cu], acc[ti][tj], 0, 0, 0);
-#pragma unroll
-				for (int ti = 0; ti < 4; ++ti) acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ti], b1[cu], acc[ti][tj], 0, 0, 0);
-				if (tj + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-				for (int i = 0; i < 24; ++i) {
-					__builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-					__builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+					for (int h = 0; h < 2; ++h) {
+						const int m = 2 * sl + h, gq = m >> 2, ti = m & 3;
+						const bf16x8& av = (gq == 0) ? a3[ti] : ((gq == 2 || gq == 3) ? a2[ti] : a1[ti]);
+						const bf16x8& bv = (gq == 0 || gq == 3 || gq == 5) ? b1[cu] : ((gq == 2 || gq == 4) ? b2[cu] : b3[cu]);
+						acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ti][tj], 0, 0, 0);
+					}
+					if (sl == 1 && tj + 1 < 4) { b1[nx] = frag(buf, xa, tj + 1, 0); b2[nx] = frag(buf, xa, tj + 1, 1); b3[nx] = frag(buf, xa, tj + 1, 2); }
+					cs_stage(c, sl & 3, sl >> 2);
+					if (sl < 8) c.t += comp(set[sl], tj);   // (the bias sums: the dZ values as loaded, rows in order)
+					__builtin_amdgcn_sched_barrier(0);
 				}
-				__builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+				{
+					char* dst = other + wbase_h + (((c4 + tj) ^ (lane & 7)) * 32);
+					*reinterpret_cast<u32x4*>(dst) = c.p[0];
+					*reinterpret_cast<u32x4*>(dst + DW6_PLANE) = c.p[1];
+					*reinterpret_cast<u32x4*>(dst + 2 * DW6_PLANE) = c.p[2];
+					if (tj == 0) bsum.x += keep * c.t; else if (tj == 1) bsum.y += keep * c.t; else if (tj == 2) bsum.z += keep * c.t; else bsum.w += keep * c.t;
+				}
+				__builtin_amdgcn_sched_barrier(0);
 			}
 			load_chunk(min(q + 3, q1 - 1), set);   // three chunks ahead: consumed two iterations from now
 			lds_barrier();   // (not __syncthreads: that would wait for the loads just issued)

@@ -8,6 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from find_amd import _lib  # noqa: E402
+if os.environ.get('FIND_LIB'):   # a library variant under test
+	_lib.LIB_PATH = os.environ['FIND_LIB']
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_feet = int(sys.argv[2]) if len(sys.argv) > 2 else 16
