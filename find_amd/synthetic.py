@@ -36,7 +36,44 @@ def ellipsoid_mesh(rings, segs, axes=(0.12, 0.045, 0.04)):
 	return torch.from_numpy(verts.astype(np.float32)), torch.tensor(faces, dtype=torch.int64)
 
 
+# Which triangulation the generators below use.  'latlong' (default; what every round's numbers and every test were taken on): a
+# latitude-longitude grid -- its two poles are vertices of valence `segs` (82 on the template, 100 on the GT scans), and on a 256^2 render
+# the hundred-odd slivers around a pole put 2 - 3 thousand faces into single 8 x 8 tiles.  'uniform': a Fibonacci sphere triangulated by its
+# convex hull (valence 5 - 7 everywhere, the same V and F = 2 V - 4): what a decimated scan or FIND's own template looks like to a rasteriser.
+# bench.py reports the render configurations on both (records *_uniform_meshes).
+MESH_KIND = 'latlong'
+
+
+def uniform_sphere_mesh(n_verts):
+	"""Unit sphere with n_verts near-uniformly spread vertices (Fibonacci lattice), triangulated by its convex hull: F = 2 V - 4 faces,
+	outward orientation.  Returns verts (V,3) float32, faces (F,3) int64."""
+	from scipy.spatial import ConvexHull
+	i = np.arange(n_verts) + 0.5
+	z = 1.0 - 2.0 * i / n_verts
+	r = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+	ph = i * (math.pi * (3.0 - math.sqrt(5.0)))
+	v = np.stack([r * np.cos(ph), r * np.sin(ph), z], -1)
+	f = ConvexHull(v).simplices.astype(np.int64)
+	n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+	flip = (n * v[f[:, 0]]).sum(-1) < 0
+	f[flip] = f[flip][:, [0, 2, 1]]
+	f = f[np.lexsort((f[:, 2], f[:, 1], f[:, 0]))]
+	assert f.shape[0] == 2 * n_verts - 4
+	return torch.from_numpy(v.astype(np.float32)), torch.from_numpy(f)
+
+
+def sphere_mesh(n_verts):
+	"""Unit sphere of MESH_KIND with n_verts vertices."""
+	if MESH_KIND == 'uniform':
+		return uniform_sphere_mesh(n_verts)
+	rings, segs = TEMPLATE_GRIDS[n_verts]
+	return ellipsoid_mesh(rings, segs, axes=(1.0, 1.0, 1.0))
+
+
 def template(n_verts=6890):
+	if MESH_KIND == 'uniform':
+		v, f = uniform_sphere_mesh(n_verts)
+		return v * torch.tensor([0.12, 0.045, 0.04]), f
 	rings, segs = TEMPLATE_GRIDS[n_verts]
 	return ellipsoid_mesh(rings, segs)
 
@@ -73,8 +110,7 @@ def gt_feet(n_feet, n_verts=10002, seed=0, device='cuda'):
 	"""Per-foot GT scans: ellipsoid with axes scaled U(0.9,1.1) plus three low-frequency sinusoidal bumps (3 mm),
 	per-vertex RGB.  Returns verts (N,V,3), faces (F,3) int64 (shared topology), colours (N,V,3)."""
 	rng = np.random.RandomState(seed)
-	rings, segs = TEMPLATE_GRIDS[n_verts]
-	base, faces = ellipsoid_mesh(rings, segs, axes=(1.0, 1.0, 1.0))
+	base, faces = sphere_mesh(n_verts)
 	base = base.numpy()
 	verts, cols = [], []
 	for _ in range(n_feet):
