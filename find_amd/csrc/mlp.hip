@@ -127,7 +127,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -174,6 +174,8 @@ struct find_ctx {
 	int next = 0;
 	int events_per_call_max = 0;
 	bool attr_done[K_COUNT] = {};
+	int act16 = 1;                // knob: in the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large
+	                              // shared-template shapes (use_act16): those layers are HBM-bound, and the matrix pipe rounds them to fp16 anyway
 	int defer_join = 0;           // knob, read by the next find_mlp_bwd: leave the weight-gradient side streams running behind the call (find_hip.h)
 	hipEvent_t pend_ev[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};   // end of the deferred work on each side stream
 	bool pend[N_SIDE] = {};       // side stream k carries deferred work nobody has waited for yet
@@ -375,19 +377,26 @@ static int launch_gemm4(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, 
 	return launch_gemm4_t<EPI_NONE, NI>(c, a, feet, s);
 }
 
-template <int EPI>
+template <int EPI, bool H16 = false>
 static int launch_gemm5_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
 	int lds = 0;
-	const int rc = prepare_kernel(c, K_GEMM5_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2), &gemm5_kernel<EPI>, GEMM5_LDS, &lds);
+	const int id = H16 ? (EPI == EPI_BIAS_RELU ? K_GEMM5_RELU_H : K_GEMM5_MASK_H) : K_GEMM5_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2);
+	const int rc = prepare_kernel(c, id, &gemm5_kernel<EPI, H16>, GEMM5_LDS, &lds);
 	if (rc != FIND_OK) return rc;
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
 	const int grid = (int)std::min<int64_t>(c->num_cus, cdiv(a.ntiles, GEMM5_NW));
-	hipLaunchKernelGGL((gemm5_kernel<EPI>), dim3(grid), dim3(GEMM5_NW * 64), lds, s, a);
+	hipLaunchKernelGGL((gemm5_kernel<EPI, H16>), dim3(grid), dim3(GEMM5_NW * 64), lds, s, a);
 	return FIND_OK;
 }
 
-static int launch_gemm5(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+static int launch_gemm5(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s, bool h16) {
+	if (h16) {   // fp16-stored A / y / mask (act16): the two epilogues the heads' hidden layers use
+		if (epi == EPI_BIAS_RELU) return launch_gemm5_t<EPI_BIAS_RELU, true>(c, a, feet, s);
+		if (epi == EPI_MASK) return launch_gemm5_t<EPI_MASK, true>(c, a, feet, s);
+		set_error("launch_gemm5: no fp16-stored variant of this epilogue");
+		return FIND_EINVAL;
+	}
 	if (epi == EPI_BIAS_RELU) return launch_gemm5_t<EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK) return launch_gemm5_t<EPI_MASK>(c, a, feet, s);
 	return launch_gemm5_t<EPI_NONE>(c, a, feet, s);
@@ -478,7 +487,8 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	const int64_t units = cdiv(a.V, 32) * feet;
 	const bool k256 = b.nseg == 1 && b.nchunk == 8;
 	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
-	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s);
+	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s, a.h16 != 0);
+	FIND_REQUIRE(!a.h16, "launch_gemm: an fp16-stored layer reached a kernel that reads fp32 (act16 and the kernel selection disagree)");
 #ifdef FIND_DIAG
 	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
 #endif
@@ -585,8 +595,9 @@ static GemmArgs gemm_args_zero() {
 
 // Linear + ReLU forward:  y = relu(x @ w^T + bias[foot])
 static int linear_fwd(find_ctx* c, const float* x, int64_t x_foot_stride, const float* w, int ldw, const float* bias,
-					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s) {
+					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
 	GemmArgs a = gemm_args_zero();
+	a.h16 = h16;
 	a.a0 = x; a.a_foot_stride = x_foot_stride; a.lda = W;
 	a.w0 = w; a.ldw = ldw; a.nchunk = W / KC;
 	a.bias = bias; a.bias_foot_stride = bias_foot_stride;
@@ -599,6 +610,14 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 	int64_t s0 = std::max<int64_t>(1, std::min<int64_t>(cpf, cdiv(target, n_feet)));
 	*cps = (int)cdiv(cpf, s0);
 	*spf = (int)cdiv(cpf, *cps);
+}
+
+// act16: the opt-in fp16 mode STORES the heads' hidden activations (w.D / w.C) and their gradients (b.dzD / b.dzC) as fp16 when every
+// kernel that touches them is one of the HBM-bound large-shape kernels: a template shared by more than one foot (bias_relu_bcast ->
+// gemm5 -> head_out forward; head_out_bwd -> dw3 / gemm5 / footsum backward) with enough rows for gemm5.  Forward and backward of a
+// call evaluate this with the same arguments (the "act16" / "gemm5_min_units" knobs must not change in between).
+static bool use_act16(const find_ctx* c, bool f16, bool shared, int64_t n_feet, int64_t V) {
+	return f16 && c->act16 && shared && n_feet > 1 && cdiv(V, 32) * n_feet >= c->gemm5_min_units;
 }
 
 static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 == 1); }
@@ -686,6 +705,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 
 	// 4. heads (model.py:439-440); the trunk rows are shared by every foot when d.shared
+	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
 	const float* hl = w.H[p->n_trunk - 1];
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 	// first layer of a head.  Shared template: every foot multiplies the SAME trunk rows, so  H W^T  is formed once on V rows
@@ -701,9 +721,10 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_NONE, a, 1, st));
 			}
 			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, st, hp, bias,
-							   bstride, (int)n_feet, V, out);
+							   bstride, (int)n_feet, V, out, a16 ? 1 : 0);
 			return FIND_OK;
 		}
+		FIND_REQUIRE(!a16, "find_mlp_fwd: act16 without a shared template");
 		return linear_fwd(c, hl, hl_stride, w0, W, bias, bstride, out, V, n_feet, st);
 	};
 	// 5. final 256->3 layers + tanh scalings (model.py:444-449), one launch per head
@@ -718,6 +739,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		h.avg_col = p->avg_col;
 		h.rows = d.rows_h;
 		h.head0 = head;
+		h.x_half = a16 ? 1 : 0;
 		const unsigned gx = (unsigned)std::min<int64_t>(cdiv(d.rows_h, 32), 2048);
 		hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 1), dim3(256), 0, st, h);
 	};
@@ -731,12 +753,12 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 	if (disp) {
 		FIND_TRY(head_first(w.wd0, bias_d0, bstride_d, w.D[0], w.hp, s));
-		for (int i = 1; i < p->n_disp; ++i) FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s));
+		for (int i = 1; i < p->n_disp; ++i) FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s, a16));
 		head_out(0, s);
 	}
 	if (col) {
 		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], (sc != s || (fused && disp)) ? w.hp2 : w.hp, sc));
-		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc));
+		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc, a16));
 		head_out(1, sc);
 	}
 	FIND_LAUNCH_CHECK("head layers");
@@ -907,7 +929,7 @@ static int reduce_lds(find_ctx* c) {
 // tiles go out on stream s; the slab reduce follows on s, or -- reduce_side >= 0 -- on that side stream of the fork, ordered behind s.
 static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
-					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1) {
+					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1, bool h16 = false) {
 	auto reduce_stream = [&]() -> hipStream_t {
 		if (!fk || !fk->on || reduce_side < 0 || s_side < 0 || reduce_side == s_side) return s;
 		fk->chain(s_side, reduce_side);
@@ -924,12 +946,14 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			spf = (int)cdiv(cpf64, cps3);
 			nmain = (int)(feet * spf);
 			int lds = 0;
-			FIND_TRY(prepare_kernel(c, K_DW3, &dw3_kernel, DW3_LDS, &lds));
+			if (h16) FIND_TRY(prepare_kernel(c, K_DW3_H, &dw3_h16_kernel, DW3_LDS, &lds));
+			else FIND_TRY(prepare_kernel(c, K_DW3, &dw3_kernel, DW3_LDS, &lds));
 			Dw3Args d3;
 			memset(&d3, 0, sizeof(d3));
 			d3.dz = dz; d3.dz_foot_stride = V * W; d3.x = x; d3.x_foot_stride = x_foot_stride;
 			d3.V = (int)V; d3.chunks_per_foot = cpf64; d3.spf = spf; d3.cps = cps3; d3.pw = b.pw; d3.pb = pbuf;
-			hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);
+			if (h16) hipLaunchKernelGGL(dw3_h16_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);   // (dz and x fp16-stored: act16)
+			else hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);
 			FIND_LAUNCH_CHECK("dw3_kernel");
 		} else if (c->x3 && cdiv(V, 32) * feet >= c->gemm6_min_units) {
 			// bf16x3: 16-row chunks, rows past the end of a foot zero-filled by the kernel; few, long runs (slab traffic)
@@ -1093,8 +1117,9 @@ static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 }
 
 // masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
-static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s) {
+static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
 	GemmArgs a = gemm_args_zero();
+	a.h16 = h16;
 	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
 	a.w0 = wt; a.ldw = W; a.nchunk = W / KC;
 	a.mask = mask; a.mask_foot_stride = V * W;
@@ -1170,6 +1195,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
+	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
 	int cd = 0, cc = 0;  // current dZ buffer per head
 	{
 		HeadOutBwdArgs h;
@@ -1182,6 +1208,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		h.pw[0] = b.pwo[0]; h.pw[1] = b.pwo[1];
 		h.pb[0] = b.pbo[0]; h.pb[1] = b.pbo[1];
 		h.rows = d.rows_h;
+		h.half = a16 ? 1 : 0;
 		hipLaunchKernelGGL(head_out_bwd_kernel, dim3((unsigned)b.nblk_out, 2), dim3(256), 0, s, h);
 		HeadOutReduceArgs hr;
 		memset(&hr, 0, sizeof(hr));
@@ -1236,8 +1263,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			if (want_d) head_chain(p->n_disp, w.D, b.dzD, b.Dt, cd);
 			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		} else {
-			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzD[cd], b.Dt[l], w.D[l - 1], b.dzD[cd + 1], V, n_feet, s)); cd += 1; }
-			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzC[cc], b.Ct[l], w.C[l - 1], b.dzC[cc + 1], V, n_feet, s)); cc += 1; }
+			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzD[cd], b.Dt[l], w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16)); cd += 1; }
+			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzC[cc], b.Ct[l], w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16)); cc += 1; }
 		}
 		struct Job { const float* dz; float* ps; float* S; const float* w0; int ld0; const float* lat; int L; float* glat; };
 		const Job jobs[2] = {{b.dzD[cd], b.pS, b.Sd, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, g->lat_disp},
@@ -1245,7 +1272,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		for (int h = 0; h < 2; ++h) {
 			if (!(h == 0 ? want_d : want_c)) continue;
 			const Job& j = jobs[h];
-			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, j.dz, (int)n_feet, (int)V, (float*)nullptr, j.ps);
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, j.dz, (int)n_feet, (int)V, (float*)nullptr, j.ps, a16 ? 1 : 0);
 			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, s, j.ps, b.nblk_fs, (int)n_feet, j.S);
 			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)n_feet), dim3(256), 0, s, j.w0, j.ld0, j.lat, j.L, j.S, (int)n_feet, j.glat,
 							   (float*)nullptr, (float*)nullptr);
@@ -1315,7 +1342,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				// the weight gradients stay behind on the side streams: the latent gradients -- an OUTPUT autograd hands to whatever comes
 				// next -- are formed on the caller's stream, from per-foot column sums of their own (no slab reduce to wait for)
 				float* ps = (gw == g->disp_w) ? b.pS : b.pS2;
-				hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur_last], (int)n_feet, (int)V, (float*)nullptr, ps);
+				hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur_last], (int)n_feet, (int)V, (float*)nullptr, ps, 0);
 				hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, s, ps, b.nblk_fs, (int)n_feet, S);
 				hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0], (float*)nullptr);
 				FIND_LAUNCH_CHECK("latent gradients (deferred join)");
@@ -1371,12 +1398,12 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				BwdWs bk = b;
 				bk.pw = b.pw_t[si ? 3 : 0]; bk.pb = b.pb_t[si ? 3 : 0];
 				fk.wait(Q, set_free[si]);
-				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R));
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R, a16));
 				set_free[si] = fk.mark(R);
 			} else {
-				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q)));
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16));
 			}
-			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s));
+			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s, a16));
 			cur += 1;
 		}
 		float* db_late = nullptr;
@@ -1386,7 +1413,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			// (Measured and dropped: the foot sum on the head's side stream, the caller's stream going straight on to the other head's dX
 			// chain and waiting for the sums in step 4 -- 3.49 against 3.38 ms per train_3d step: the HBM-bound pass beside the dX GEMMs
 			// costs them more than the wait it removes.)
-			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps);
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps, a16 ? 1 : 0);
 			// the foot-summed first layer is a small launch: its own side stream and slab set, so that it does not queue behind the
 			// large weight-gradient launches on Q.  The per-foot column sums go there too: only the latent / bias gradients read them.
 			fk.fork_to(side);
@@ -1774,7 +1801,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 

@@ -35,8 +35,11 @@ constexpr int DW3_OPER = 256 * 128;            // one operand of one chunk in LD
 constexpr int DW3_BUF = 2 * DW3_OPER;          // dZ then X
 constexpr int DW3_LDS = 2 * DW3_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 135 168 B
 
-__global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) {
+// H16 ("act16", mlp.hip): both operands are STORED as fp16 (strides in elements as before): 8 bytes per thread and row instead of 16.
+template <bool H16>
+__device__ __forceinline__ void dw3_body(const Dw3Args& g) {
 	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 432 registers by itself (256 fp32 accumulators in AGPRs): see the macro
+	constexpr int ES = H16 ? 2 : 4;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* red = reinterpret_cast<float*>(smem + 2 * DW3_BUF);
 
@@ -52,8 +55,17 @@ __global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) {
 	const int q1 = min(q0 + g.cps, g.chunks_per_foot);
 	float* const pw = g.pw + (int64_t)split * 65536;
 	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
-	const float* const zfoot = g.dz + (int64_t)foot * g.dz_foot_stride;
-	const float* const xfoot = g.x + (int64_t)foot * g.x_foot_stride;
+	const char* const zfoot = reinterpret_cast<const char*>(g.dz) + (int64_t)foot * g.dz_foot_stride * ES;
+	const char* const xfoot = reinterpret_cast<const char*>(g.x) + (int64_t)foot * g.x_foot_stride * ES;
+	auto ld4 = [](const char* base, int64_t elem) -> float4 {
+		if constexpr (H16) {
+			typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+			const h4 h = *reinterpret_cast<const h4*>(base + elem * 2);
+			return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+		} else {
+			return *reinterpret_cast<const float4*>(base + elem * 4);
+		}
+	};
 
 	f32x16 acc[4][4];
 #pragma unroll
@@ -76,8 +88,8 @@ __global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) {
 				const int row = r0 + 8 * (wave + 4 * u) + j;
 				const bool ok = row < g.V;
 				const int rc = ok ? row : g.V - 1;
-				const float4 z = *reinterpret_cast<const float4*>(zfoot + (int64_t)rc * 256 + c4);
-				const float4 x = *reinterpret_cast<const float4*>(xfoot + (int64_t)rc * 256 + c4);
+				const float4 z = ld4(zfoot, (int64_t)rc * 256 + c4);
+				const float4 x = ld4(xfoot, (int64_t)rc * 256 + c4);
 				st[0][u][j] = ok ? z : make_float4(0.f, 0.f, 0.f, 0.f);
 				st[1][u][j] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
 			}
@@ -125,6 +137,77 @@ __global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) {
 		}
 	};
 
+	if constexpr (H16) {
+		// fp16-stored operands: a chunk is half the registers, so TWO chunks are kept in flight (as dw6 does) -- with one, the memory pipeline
+		// idles while a chunk is transposed into LDS and the launch reads at ~3 TB/s; the halves go to LDS as they are (no conversion)
+		typedef unsigned u2 __attribute__((ext_vector_type(2)));
+		u2 hs[2][2][2][8];   // [set][operand][u][row j]: the thread's four columns of a row as two dwords
+		auto load_h = [&](int q, u2 (&set)[2][2][8]) {
+			const int r0 = q * 64;
+#pragma unroll
+			for (int u = 0; u < 2; ++u)
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int row = r0 + 8 * (wave + 4 * u) + j;
+					const bool ok = row < g.V;
+					const int rc = ok ? row : g.V - 1;
+					const u2 z = *reinterpret_cast<const u2*>(zfoot + ((int64_t)rc * 256 + c4) * 2);
+					const u2 x = *reinterpret_cast<const u2*>(xfoot + ((int64_t)rc * 256 + c4) * 2);
+					set[0][u][j] = ok ? z : u2{0u, 0u};
+					set[1][u][j] = ok ? x : u2{0u, 0u};
+				}
+		};
+		auto store_h = [&](char* buf, const u2 (&set)[2][2][8]) {
+#pragma unroll
+			for (int op = 0; op < 2; ++op)
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+					const int slot = (wave + 4 * u) ^ (lane & 7);
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						u32x4 v;   // rows 2 jj, 2 jj + 1 of column e as one dword
+#pragma unroll
+						for (int jj = 0; jj < 4; ++jj) {
+							const unsigned a0 = (e < 2) ? set[op][u][2 * jj].x : set[op][u][2 * jj].y, a1 = (e < 2) ? set[op][u][2 * jj + 1].x : set[op][u][2 * jj + 1].y;
+							v[jj] = (e & 1) ? ((a0 >> 16) | (a1 & 0xffff0000u)) : ((a0 & 0xffffu) | (a1 << 16));
+						}
+						*reinterpret_cast<u32x4*>(buf + op * DW3_OPER + (c4 + e) * 128 + slot * 16) = v;
+					}
+				}
+			if (pb) {
+				typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+				for (int u = 0; u < 2; ++u)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						const unsigned wlo = set[0][u][j].x, whi = set[0][u][j].y;   // (value copies: __builtin_bit_cast on a vector-element lvalue reads element 0)
+						const h2 lo = __builtin_bit_cast(h2, wlo), hi = __builtin_bit_cast(h2, whi);
+						bsum.x += (float)lo[0]; bsum.y += (float)lo[1]; bsum.z += (float)hi[0]; bsum.w += (float)hi[1];
+					}
+			}
+		};
+		if (q0 < q1) {
+			load_h(q0, hs[0]);
+			load_h(min(q0 + 1, q1 - 1), hs[1]);
+			store_h(smem, hs[0]);
+			load_h(min(q0 + 2, q1 - 1), hs[0]);
+			__syncthreads();
+			int cb = 0;
+			// chunk q is in LDS buffer cb; `set` holds chunk q + 1 (stored under this chunk's MFMAs), then takes chunk q + 3.  (A repeated
+			// load re-reads the run's last chunk; a repeated store goes to the buffer nobody reads any more.)
+			auto body = [&](int q, u2 (&set)[2][2][8]) {
+				multiply(smem + cb * DW3_BUF);
+				if (q + 1 < q1) store_h(smem + (cb ^ 1) * DW3_BUF, set);
+				load_h(min(q + 3, q1 - 1), set);
+				__syncthreads();
+				cb ^= 1;
+			};
+			for (int q = q0; q < q1; q += 2) {
+				body(q, hs[1]);
+				if (q + 1 < q1) body(q + 1, hs[0]);
+			}
+		}
+	} else
 	if (q0 < q1) {
 		load_chunk(q0);
 		store_chunk(smem);
@@ -161,6 +244,9 @@ __global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) {
 		pb[tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
 	}
 }
+
+__global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) { dw3_body<false>(g); }
+__global__ __launch_bounds__(256, 1) void dw3_h16_kernel(const Dw3Args g) { dw3_body<true>(g); }
 
 }  // namespace mlp
 }  // namespace find

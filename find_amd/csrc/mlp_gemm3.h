@@ -26,6 +26,10 @@ __device__ __forceinline__ const float* uniform_ptr(const float* p) {
 	return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
 }
 
+__device__ __forceinline__ char* uniform_ptr(const char* p) {
+	return const_cast<char*>(reinterpret_cast<const char*>(uniform_ptr(reinterpret_cast<const float*>(p))));
+}
+
 // 4 LDS-DMA instructions: lanes fetch 16 B from base + off_i, landing at LDS [dst + i*1024, +1024)
 __device__ __forceinline__ void dma4(const float* base, unsigned dst, unsigned o0, unsigned o1, unsigned o2, unsigned o3) {
 	unsigned keep;

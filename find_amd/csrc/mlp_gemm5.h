@@ -32,8 +32,14 @@ __device__ __forceinline__ f16x8 pack_f16x8(const float4& lo, const float4& hi) 
 	return v;
 }
 
-template <int EPI>
+// H16 ("act16", mlp.hip): A, y and the mask are STORED as fp16 (ld in elements as before): the lane's 16 k-values of a chunk are its two
+// MFMA operands as they lie in memory, the epilogue writes / tests 2-byte elements -- half the HBM bytes of a layer that is bound by them.
+template <int EPI, bool H16 = false>
 __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g) {
+	constexpr int ES = H16 ? 2 : 4;          // bytes per stored element of A / y / mask
+	constexpr int CH = 32 * ES;              // bytes of a 32-k chunk of one row
+	constexpr int NQ = CH / 2 / 16;          // 16-byte pieces of a lane's half chunk: 4 (fp32) or 2 (fp16)
+	typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -45,23 +51,24 @@ __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g)
 	const int u1 = (int)((int64_t)(blockIdx.x + 1) * g.ntiles / gridDim.x);
 	if (u0 >= u1) return;
 
-	auto unit_rows = [&](int uu, int& foot, int& v0) -> const float4* {
+	auto unit_rows = [&](int uu, int& foot, int& v0) -> const char* {
 		foot = uu / upf;
 		v0 = (uu - foot * upf) * 32;
 		const int row = min(v0 + li, V - 1);  // rows past the end of a foot re-read its last row (never stored)
-		return reinterpret_cast<const float4*>(g.a0 + (int64_t)foot * g.a_foot_stride + (int64_t)row * lda + fh * 16);
+		return reinterpret_cast<const char*>(g.a0) + ((int64_t)foot * g.a_foot_stride + (int64_t)row * lda + fh * 16) * ES;
 	};
+	auto piece = [](const char* base, int chunk, int q) -> u32x4g { return *reinterpret_cast<const u32x4g*>(base + chunk * CH + q * 16); };
 
 	// the first A chunks are on their way while W is converted
 	int u = u0 + wave;
 	const bool active = u < u1;
 	int foot = 0, v0 = 0;
-	const float4* cur = unit_rows(active ? u : u0, foot, v0);
-	float4 areg[4][4];
+	const char* cur = unit_rows(active ? u : u0, foot, v0);
+	u32x4g areg[4][NQ];
 #pragma unroll
 	for (int c = 0; c < GEMM4_PD; ++c)
 #pragma unroll
-		for (int q = 0; q < 4; ++q) areg[c][q] = cur[c * 8 + q];
+		for (int q = 0; q < NQ; ++q) areg[c][q] = piece(cur, c, q);
 
 	// ---- prologue: W (256, ldw) fp32 -> LDS fp16; item = (row n, 8-k group): 8192 items over 512 threads
 	{
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g)
 		int nfoot = foot, nv0 = v0;
 		// (no next unit: the run-ahead loads re-read chunks 5..7 of this unit -- lines the wave has just fetched, served by L2 -- instead
 		// of pulling chunks 0..2 in from HBM a second time: 24 MB per launch at the C2 shape, profiles/r01_traffic_pmc_summary.txt)
-		const float4* nxt = (u + GEMM5_NW < u1) ? unit_rows(u + GEMM5_NW, nfoot, nv0) : cur + (8 - GEMM4_PD) * 8;
+		const char* nxt = (u + GEMM5_NW < u1) ? unit_rows(u + GEMM5_NW, nfoot, nv0) : cur + (8 - GEMM4_PD) * CH;
 
 		f32x16 acc[8];
 #pragma unroll
@@ -98,14 +105,15 @@ __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g)
 		for (int c = 0; c < 8; ++c) {
 			{  // A prefetch: chunk c+PD of this unit, or chunk c+PD-8 of the wave's next unit
 				const int pc = c + GEMM4_PD;
-				const float4* src = (pc < 8) ? cur + pc * 8 : nxt + (pc - 8) * 8;
 #pragma unroll
-				for (int q = 0; q < 4; ++q) areg[pc & 3][q] = src[q];
+				for (int q = 0; q < NQ; ++q) areg[pc & 3][q] = (pc < 8) ? piece(cur, pc, q) : piece(nxt, pc - 8, q);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int m = 0; m < 2; ++m) {
-				const f16x8 a = pack_f16x8(areg[c & 3][2 * m], areg[c & 3][2 * m + 1]);
+				f16x8 a;
+				if constexpr (H16) a = __builtin_bit_cast(f16x8, areg[c & 3][m]);
+				else a = pack_f16x8(__builtin_bit_cast(float4, areg[c & 3][2 * m]), __builtin_bit_cast(float4, areg[c & 3][2 * m + 1]));
 				f16x8 bf[8];
 #pragma unroll
 				for (int ni = 0; ni < 8; ++ni) bf[ni] = load_b(c, m, ni);
@@ -117,13 +125,13 @@ __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g)
 		// ---- epilogue (as gemm4): element (r, lane) of block ni = row (r&3) + 8(r>>2) + 4fh, column 32ni + li
 		{
 			const int valid_rows = min(32, V - v0);
-			float* ytile = g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy;
-			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ytile)), 0, valid_rows * ldy * 4, 0x00020000);
-			const int voff = ((4 * fh) * ldy + li) * 4;
+			char* ytile = reinterpret_cast<char*>(g.y) + ((int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy) * ES;
+			const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(static_cast<const char*>(ytile)), 0, valid_rows * ldy * ES, 0x00020000);
+			const int voff = ((4 * fh) * ldy + li) * ES;
 			__amdgpu_buffer_rsrc_t msrc = rsrc;
 			if constexpr (EPI == EPI_MASK) {
-				const float* mtile = g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy;
-				msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(mtile)), 0, valid_rows * ldy * 4, 0x00020000);
+				const char* mtile = reinterpret_cast<const char*>(g.mask) + ((int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy) * ES;
+				msrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(mtile), 0, valid_rows * ldy * ES, 0x00020000);
 			}
 #pragma unroll
 			for (int ni = 0; ni < 8; ++ni) {
@@ -132,15 +140,18 @@ __global__ __launch_bounds__(GEMM5_NW * 64) void gemm5_kernel(const Gemm2Args g)
 				float mv[16];
 				if constexpr (EPI == EPI_MASK) {
 #pragma unroll
-					for (int r = 0; r < 16; ++r)
-						mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0));
+					for (int r = 0; r < 16; ++r) {
+						if constexpr (H16) mv[r] = (float)(short)__builtin_amdgcn_raw_buffer_load_b16(msrc, voff + ((r & 3) * ldy + ni * 32) * ES, (8 * (r >> 2) * ldy) * ES, 0);   // (the sign is all that is asked)
+						else mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(msrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0));
+					}
 				}
 #pragma unroll
 				for (int r = 0; r < 16; ++r) {
 					float val = acc[ni][r];
 					if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val + bv, 0.f);
 					if constexpr (EPI == EPI_MASK) val = (mv[r] > 0.f) ? val : 0.f;
-					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0);
+					if constexpr (H16) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)val), rsrc, voff + ((r & 3) * ldy + ni * 32) * ES, (8 * (r >> 2) * ldy) * ES, 0);
+					else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsrc, voff + ((r & 3) * ldy + ni * 32) * 4, (8 * (r >> 2) * ldy) * 4, 0);
 				}
 			}
 		}

@@ -90,6 +90,7 @@ struct GemmArgs {
 	int64_t y_foot_stride;
 	int ldy;
 	int V;                  // rows per foot
+	int h16;                // host side only (launch_gemm): a0, y and mask are fp16-STORED tensors (act16: gemm5_kernel<EPI, true>)
 };
 
 enum { AMODE_MAT = 0, AMODE_PE = 1 };
@@ -402,12 +403,28 @@ __global__ __launch_bounds__(256) void zero_many_kernel(const ZeroArgs a) {
 // One pass over dZ0 (n_feet, V, 256) produces  zsum[v] = sum_b dZ0[b,v]  and partial per-foot column sums.
 constexpr int FS_ROWS = 16;  // rows of v per block
 constexpr int FS_FEET = 16;  // feet per round: that many independent 16-byte loads in flight per thread
+// fp16-STORED tensors of the opt-in fp16 mode ("act16", mlp.hip): the heads' hidden activations and their gradients at the large
+// shared-template shapes live in HBM as fp16 -- the matrix pipe rounds them to fp16 anyway, and those layers are bound by HBM.  Four
+// consecutive elements of such a tensor (or of an fp32 one: `half` is uniform) as a float4, and back.
+typedef _Float16 find_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_any(const void* base, int64_t elem, int half) {
+	if (half) {
+		const find_h4 h = *reinterpret_cast<const find_h4*>(reinterpret_cast<const _Float16*>(base) + elem);
+		return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+	}
+	return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+}
+__device__ __forceinline__ void st4_any(void* base, int64_t elem, int half, const float4& v) {
+	if (half) *reinterpret_cast<find_h4*>(reinterpret_cast<_Float16*>(base) + elem) = find_h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+	else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
+}
+
 // grid (ceil(V/16), 4): block = 16 rows x 64 columns; thread (row r = tid>>4, column group cg = tid&15) walks the feet.
 // (An LDS-free variant -- one wave per 16 columns, the 16 rows summed by shuffles, so that it could share CUs with the ring kernels
 // that claim the whole LDS -- made the step slower, 2.30 against 2.26 ms: 64-byte row segments and the interference cost more than
 // the wait for a CU.)
 __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ dz, int n_feet, int V, float* __restrict__ zsum,
-													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */) {
+													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */, int dz_half) {
 	__shared__ __attribute__((aligned(16))) float red[4][FS_FEET][64];
 	const int cg = threadIdx.x & 15, r = threadIdx.x >> 4, wave = threadIdx.x >> 6;
 	const int v = blockIdx.x * FS_ROWS + r;
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 		float4 x[FS_FEET];
 #pragma unroll
 		for (int bb = 0; bb < FS_FEET; ++bb)
-			x[bb] = (live && bb < nb) ? *reinterpret_cast<const float4*>(dz + ((int64_t)(b0 + bb) * V + v) * 256 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+			x[bb] = (live && bb < nb) ? ld4_any(dz, ((int64_t)(b0 + bb) * V + v) * 256 + c0, dz_half) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 		for (int bb = 0; bb < FS_FEET; ++bb) {
 			zs.x += x[bb].x; zs.y += x[bb].y; zs.z += x[bb].z; zs.w += x[bb].w;
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, in
 // once per group instead of once per foot; the writes are the traffic: n_feet * V * 1 KB).
 constexpr int BCAST_FEET = 4;
 __global__ __launch_bounds__(256) void bias_relu_bcast_kernel(const float* __restrict__ P, const float* __restrict__ bias, int64_t bias_foot_stride,
-															   int n_feet, int64_t V, float* __restrict__ out) {
+															   int n_feet, int64_t V, float* __restrict__ out, int out_half) {
 	const int64_t per_foot = V * (W / 4);
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= per_foot) return;
@@ -604,7 +621,7 @@ __global__ __launch_bounds__(256) void bias_relu_bcast_kernel(const float* __res
 		const float4 b = *reinterpret_cast<const float4*>(bias + foot * bias_foot_stride + c4 * 4);
 		float4 o;
 		o.x = fmaxf(p.x + b.x, 0.f); o.y = fmaxf(p.y + b.y, 0.f); o.z = fmaxf(p.z + b.z, 0.f); o.w = fmaxf(p.w + b.w, 0.f);
-		reinterpret_cast<float4*>(out)[foot * per_foot + r] = o;
+		st4_any(out, (foot * per_foot + r) * 4, out_half, o);
 	}
 }
 
@@ -621,6 +638,7 @@ struct HeadOutArgs {
 	const float* avg_col; // or null
 	int64_t rows;
 	int head0;            // head of blockIdx.y == 0 (the two heads can be launched separately, grid.y = 1)
+	int x_half;           // x is stored as fp16 (act16)
 };
 
 // 16 lanes per row (4 rows per wave, 2 row groups in flight): lane part p holds columns 4p + 64i, i = 0..3.
@@ -650,7 +668,7 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) 
 			const int64_t row = r0 + u * 4 + sub;
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
-				xv[u][i] = (row < g.rows) ? *reinterpret_cast<const float4*>(x + row * W + part * 4 + 64 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+				xv[u][i] = (row < g.rows) ? ld4_any(x, row * W + part * 4 + 64 * i, g.x_half) : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
@@ -685,6 +703,7 @@ struct HeadOutBwdArgs {
 	float* pw[2];          // [gridDim.x][3][256]
 	float* pb[2];          // [gridDim.x][4]
 	int64_t rows;
+	int half;              // y and dy are stored as fp16 (act16)
 };
 
 __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs g) {
@@ -711,7 +730,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const int64_t row = r0 + u;
-			yv[u] = (row < g.rows) ? *reinterpret_cast<const float4*>(y + row * W + lane * 4) : make_float4(0, 0, 0, 0);
+			yv[u] = (row < g.rows) ? ld4_any(y, row * W + lane * 4, g.half) : make_float4(0, 0, 0, 0);
 		}
 		// the U*3 output gradients of these rows are computed once (lanes 0..U*3-1: one tanh each) and broadcast
 		float dmine = 0.f;
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 			o.y = (yv[u].y > 0.f) ? d0 * w0.y + d1 * w1.y + d2 * w2.y : 0.f;
 			o.z = (yv[u].z > 0.f) ? d0 * w0.z + d1 * w1.z + d2 * w2.z : 0.f;
 			o.w = (yv[u].w > 0.f) ? d0 * w0.w + d1 * w1.w + d2 * w2.w : 0.f;
-			*reinterpret_cast<float4*>(dy + row * W + lane * 4) = o;
+			st4_any(dy, row * W + lane * 4, g.half, o);
 			aw0.x += d0 * yv[u].x; aw0.y += d0 * yv[u].y; aw0.z += d0 * yv[u].z; aw0.w += d0 * yv[u].w;
 			aw1.x += d1 * yv[u].x; aw1.y += d1 * yv[u].y; aw1.z += d1 * yv[u].z; aw1.w += d1 * yv[u].w;
 			aw2.x += d2 * yv[u].x; aw2.y += d2 * yv[u].y; aw2.z += d2 * yv[u].z; aw2.w += d2 * yv[u].w;

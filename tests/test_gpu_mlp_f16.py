@@ -182,6 +182,29 @@ def test_c5_dense_template_fp16_as_configured():
 	print(f'C5 fp16 vs fp32: outputs {d:.2e}, worst gradient deviation {worst:.2e} of the tensor maximum')
 
 
+def test_fp16_stored_activations_agree_with_fp32_stored_ones():
+	"""Inside the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large shared-template shapes
+	("act16" knob, csrc/mlp.hip use_act16; BASELINE configs[4] is bound by these bytes).  The matrix pipe rounds the same values to fp16 when
+	they are read as fp32, so switching the storage changes little: outputs within 2e-5, every gradient within 5e-3 of its tensor's largest
+	entry of the act16 = 0 result -- and not nothing (the 3-wide output layers and the bias / latent sums now see rounded values)."""
+	from find_amd import functional as F
+	from find_amd import _lib
+	prev = F.set_mlp_precision('fp16')
+	try:
+		out_a, g_a = _run_model(16, 6890, True)
+		_lib.set_tuning('act16', 0)
+		out_b, g_b = _run_model(16, 6890, True)
+	finally:
+		_lib.set_tuning('act16', 1)
+		F.set_mlp_precision(prev)
+	d = (out_a - out_b).abs().max().item()
+	assert 0.0 < d < 2e-5, d
+	for n in g_b:
+		scale = max(1e-6, g_b[n].abs().max().item())
+		assert torch.isfinite(g_a[n]).all(), n
+		assert (g_a[n] - g_b[n]).abs().max().item() < 5e-3 * scale, (n, (g_a[n] - g_b[n]).abs().max().item() / scale)
+
+
 def test_two_models_in_one_process_may_differ_in_precision():
 	"""find_mlp_params.precision travels with each call: a model pinned to fp16 and a model pinned to fp32 interleave their passes,
 	and the fp32 one stays bit-identical to a run without any fp16 model around (the precision is no longer process-wide state)."""
