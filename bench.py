@@ -793,7 +793,8 @@ def c2_record(run, steps, warmup, n_verts=None, fp16=False, with_cpu=False, dp_o
 def c3_record_uniform_meshes(run, steps, warmup, c4=False):
 	"""The C3 / C4 step on uniformly triangulated meshes (find_amd.synthetic.MESH_KIND = 'uniform': valence 5 - 7 everywhere) instead of the
 	latitude-longitude grids all other numbers are taken on, whose poles put thousands of sliver faces into single tiles: what the
-	rasteriser's time is on meshes shaped like FIND's template and decimated scans.  Extra information, not the configuration's number."""
+	rasteriser's time is on meshes shaped like FIND's template and decimated scans.  Extra information, not the configuration's number:
+	tools/c3_uniform.py prints it beside the configuration's own (not a record of the bench line)."""
 	from find_amd import synthetic
 	prev = synthetic.MESH_KIND
 	synthetic.MESH_KIND = 'uniform'
@@ -1153,9 +1154,6 @@ def main():
 			add('c3', brief(c3_record(run, 20, 3, with_cpu)))
 			note('record c4_rank_share')
 			add('c4_rank_share', brief(c3_record(run, 10, 3, False, c4=True)))
-			note('record c3 / c4 on uniform triangulations')
-			add('c3_uniform_meshes', brief(c3_record_uniform_meshes(run, 20, 3)))
-			add('c4_rank_share_uniform_meshes', brief(c3_record_uniform_meshes(run, 10, 3, c4=True)))
 			note('record c5')
 			add('c5_fp32', brief(c2_record(run, 10, 3, n_verts=50002), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed'))
 			add('c5_fp16', brief(c2_record(run, 10, 3, n_verts=50002, fp16=True), 'step_tflops_executed'))

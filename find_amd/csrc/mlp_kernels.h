@@ -641,6 +641,18 @@ struct HeadOutArgs {
 	int x_half;           // x is stored as fp16 (act16)
 };
 
+// Sum over the 16 lanes of a DPP row, in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- VALU-only, and bit for
+// bit the xor-1, 2, 4, 8 butterfly it replaces (after the quad steps the four lanes of a quad hold one value, so the mirror pairings add
+// the same partner sums).  The butterfly through __shfl_xor was 24 ds_bpermute per 8 rows: the LDS pipe, not HBM, bounded the kernel
+// once its input was fp16-stored.
+__device__ __forceinline__ float row16_sum(float t) {
+	t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0xB1, 0xF, 0xF, false));
+	t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, false));
+	t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x141, 0xF, 0xF, false));
+	t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x140, 0xF, 0xF, false));
+	return t;
+}
+
 // 16 lanes per row (4 rows per wave, 2 row groups in flight): lane part p holds columns 4p + 64i, i = 0..3.
 __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) {
 	const int head = blockIdx.y + g.head0;
@@ -679,8 +691,7 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) 
 				float t = 0.f;
 #pragma unroll
 				for (int i = 0; i < 4; ++i) t += xv[u][i].x * wv[c][i].x + xv[u][i].y * wv[c][i].y + xv[u][i].z * wv[c][i].z + xv[u][i].w * wv[c][i].w;
-				t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-				sc[c] = t;
+				sc[c] = row16_sum(t);
 			}
 			if (part < 3 && row < g.rows) {
 				const float zz = (part == 0 ? sc[0] : (part == 1 ? sc[1] : sc[2])) + bc;
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 #pragma unroll
 		for (int u = 0; u < U; ++u)
 #pragma unroll
-			for (int c = 0; c < 3; ++c) d[u][c] = __shfl(dmine, u * 3 + c, 64);
+			for (int c = 0; c < 3; ++c) d[u][c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dmine), u * 3 + c));   // (bits, not the value: readlane converts a float argument)
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const int64_t row = r0 + u;
