@@ -174,6 +174,11 @@ struct find_ctx {
 	int next = 0;
 	int events_per_call_max = 0;
 	bool attr_done[K_COUNT] = {};
+	// how the last forward calls that saved a workspace stored the heads' activations (act16): the backward of a workspace follows its
+	// forward's decision even if a knob was turned in between (ring of the last 16; a workspace not found falls back to the rule)
+	struct Act16Note { const void* ws; bool a16; };
+	Act16Note act16_notes[16] = {};
+	int act16_next = 0;
 	int act16 = 1;                // knob: in the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large
 	                              // shared-template shapes (use_act16): those layers are HBM-bound, and the matrix pipe rounds them to fp16 anyway
 	int defer_join = 0;           // knob, read by the next find_mlp_bwd: leave the weight-gradient side streams running behind the call (find_hip.h)
@@ -615,9 +620,18 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 // act16: the opt-in fp16 mode STORES the heads' hidden activations (w.D / w.C) and their gradients (b.dzD / b.dzC) as fp16 when every
 // kernel that touches them is one of the HBM-bound large-shape kernels: a template shared by more than one foot (bias_relu_bcast ->
 // gemm5 -> head_out forward; head_out_bwd -> dw3 / gemm5 / footsum backward) with enough rows for gemm5.  Forward and backward of a
-// call evaluate this with the same arguments (the "act16" / "gemm5_min_units" knobs must not change in between).
+// call agree on it through a note the forward leaves in the context (note_act16), so a knob turned in between cannot split them.
 static bool use_act16(const find_ctx* c, bool f16, bool shared, int64_t n_feet, int64_t V) {
 	return f16 && c->act16 && shared && n_feet > 1 && cdiv(V, 32) * n_feet >= c->gemm5_min_units;
+}
+static void note_act16(find_ctx* c, const void* ws, bool a16) {
+	for (auto& n : c->act16_notes) if (n.ws == ws) { n.a16 = a16; return; }
+	c->act16_notes[c->act16_next] = find_ctx::Act16Note{ws, a16};
+	c->act16_next = (c->act16_next + 1) & 15;
+}
+static bool noted_act16(const find_ctx* c, const void* ws, bool by_rule) {
+	for (const auto& n : c->act16_notes) if (n.ws == ws) return n.a16;
+	return by_rule;
 }
 
 static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 == 1); }
@@ -628,6 +642,8 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	hipStream_t s = fk.s;
 	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
+	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
+	note_act16(c, w.D[0], a16);   // (every forward leaves its note, keyed by the workspace's first head buffer: the backward follows it)
 
 	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers
 	{
@@ -705,7 +721,6 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 
 	// 4. heads (model.py:439-440); the trunk rows are shared by every foot when d.shared
-	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
 	const float* hl = w.H[p->n_trunk - 1];
 	const int64_t hl_stride = d.shared ? 0 : V * W;
 	// first layer of a head.  Shared template: every foot multiplies the SAME trunk rows, so  H W^T  is formed once on V rows
@@ -1195,7 +1210,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
-	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
+	const bool a16 = noted_act16(c, w.D[0], use_act16(c, c->f16, d.shared, n_feet, V));   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
 	int cd = 0, cc = 0;  // current dZ buffer per head
 	{
 		HeadOutBwdArgs h;

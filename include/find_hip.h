@@ -197,7 +197,7 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *   "act16"           in fp16 mode only: 1 (default) = the heads' hidden activations and their gradients are STORED as fp16 inside the
  *                     call's workspace / scratch when a template is shared by more than one foot and the heads have >= "gemm5_min_units"
  *                     units (the matrix pipe rounds these values to fp16 anyway; BASELINE.json configs[4] is bound by their bytes); 0 = fp32
- *                     storage.  Must not change between a find_mlp_fwd and its find_mlp_bwd (nor may "gemm5_min_units")
+ *                     storage.  (A find_mlp_bwd follows what the find_mlp_fwd of its workspace did, also if a knob was turned in between.)
  *   "gemm6_min_units" the same threshold for the bf16x3 kernels (default 1024)
  *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
  *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped

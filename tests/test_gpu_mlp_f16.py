@@ -63,8 +63,8 @@ def test_linear_relu_fp16_operands_exact(fp16_mode, n_feet, n_pts):
 	assert 1e-4 < np.abs(got - full).max() < 5e-2
 
 
-def _run_model(n_feet, n_verts, shared, backward_precision=None):
-	"""backward_precision: run the BACKWARD of every MLP call in this arithmetic whatever the forward ran in (the precision code saved on the
+def _run_model(n_feet, n_verts, shared, backward_precision=None, between=None):
+	"""between: called after the forward, before the backward (a knob turned in between).  backward_precision: run the BACKWARD of every MLP call in this arithmetic whatever the forward ran in (the precision code saved on the
 	autograd node is replaced): same saved activations, hence the same ReLU masks, on both sides of a comparison."""
 	from find_amd import synthetic
 	dev = torch.device('cuda:0')
@@ -95,6 +95,8 @@ def _run_model(n_feet, n_verts, shared, backward_precision=None):
 				hit += 1
 			todo.extend(f for f, _ in fn.next_functions)
 		assert hit >= 1
+	if between is not None:
+		between()
 	(out * wgt).sum().backward()
 	torch.cuda.synchronize()
 	grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
@@ -197,6 +199,16 @@ def test_fp16_stored_activations_agree_with_fp32_stored_ones():
 	finally:
 		_lib.set_tuning('act16', 1)
 		F.set_mlp_precision(prev)
+	# a knob turned between a forward and its backward does not split them: the backward follows the note its forward left in the context
+	try:
+		F.set_mlp_precision('fp16')
+		out_c, g_c = _run_model(16, 6890, True, between=lambda: _lib.set_tuning('act16', 0))
+	finally:
+		_lib.set_tuning('act16', 1)
+		F.set_mlp_precision(prev)
+	assert torch.equal(out_c, out_a)
+	for n in g_a:
+		assert torch.equal(g_c[n], g_a[n]), n
 	d = (out_a - out_b).abs().max().item()
 	assert 0.0 < d < 2e-5, d
 	for n in g_b:

@@ -6,6 +6,7 @@ for w in ${*:-fp16}; do
   flag=""; [ $w = fp16 ] && flag="--fp16"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5$w -- python3 $R/bench.py --c5 $flag --steps 10 --warmup 3 --no-cpu-baseline > $O/c5${w}_line.json 2> $O/c5$w.err
   python3 $R/tools/step_stats.py $O/c5$w/*/*kernel_trace.csv head_out_fwd_kernel 6 > $O/c5${w}_step_stats.csv
+  python3 $R/tools/step_timeline.py $O/c5$w/*/*kernel_trace.csv head_out_reduce_kernel 3 > $O/c5${w}_step_timeline.txt
   head -30 $O/c5${w}_step_stats.csv | cut -c1-170; tail -1 $O/c5${w}_step_stats.csv
   rm -rf $O/c5$w/
 done
