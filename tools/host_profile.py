@@ -1,5 +1,5 @@
-"""Where the host's time goes in one batch-1 train_3d step (the step is host-bound there): cProfile over 200 eager steps, the 45 most
-expensive functions by own time, then by cumulative time.  python tools/host_profile.py [steps]"""
+"""Where the host's time goes in one train_3d step (batch 1: the step is host-bound; batch 16: the host is within 10 % of the GPU): cProfile
+over 200 eager steps, the 45 most expensive functions by own time, then by cumulative time.  python tools/host_profile.py [steps] [batch]"""
 import cProfile
 import os
 import pstats
@@ -9,8 +9,9 @@ import torch
 import bench
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 run = bench.Run(1)
-step = bench.train3d_setup(run, n_items=4, batch_size=1, stage='net', labels=True, seed=0)['step']
+step = bench.train3d_setup(run, n_items=max(4, batch), batch_size=batch, stage='net', labels=batch == 1, seed=0, dp=False)['step']
 from find_amd.train_utils import backward_on_this_thread
 with backward_on_this_thread():   # (as Trainer / bench run it; the backward's Python functions then show in the profile)
 	for _ in range(30):
