@@ -97,13 +97,20 @@ class GradBucket:
 		only if every early slot was handed to a backward kernel this step (else the prefix travels with the rest, as before)."""
 		if self.n_early == 0 or self._hook is not None:
 			return
-		trigger._find_hooks_are_stream_safe = True   # (find_amd.functional: this hook reads gradients only behind the stream's own work; deferred joins stay allowed)
+		trigger._find_hooks_are_stream_safe = True   # (find_amd.functional: this hook joins deferred weight-gradient work itself before it reads the arena, so deferred joins stay allowed)
 
 		def fire(_p):
 			if self._early is not None or not (dist.is_available() and dist.is_initialized()):
 				return
 			if not all(self.taken[:self.n_early_params]):
 				return
+			if self.arena:
+				# weight-gradient work a deferred find_mlp_bwd left on the context's side streams (functional: defer_join) writes the arena
+				# too: the current stream -- and with it the collective issued behind it -- waits for it first.  (In FIND's step the main
+				# pass's backward has joined it before this hook runs; a graph in which the deferred pass is the trigger's only feeder has not.)
+				from . import functional
+				if functional._DEFERRED:
+					functional._join_deferred()
 			avg = dist.get_backend(self.group) == 'nccl'
 			work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
 			self._early = (work, None if avg else dist.get_world_size(self.group))

@@ -1,10 +1,26 @@
 """GPU side of the data-parallel step: the gradient arena -- backward kernels writing straight into the flat
 all-reduce bucket -- and the RCCL collective itself on a one-rank `nccl` group (the multi-rank arithmetic is covered on CPU with
 `gloo`, tests/test_distributed_cpu.py)."""
+import os
+import queue
 import socket
 
 import pytest
 import torch
+
+
+def _collect(q, procs, n, timeout=500):
+	"""n results from the workers' queue -- or an immediate failure when a worker has died (not a 500-second wait for its answer)."""
+	import time
+	out, t0 = [], time.time()
+	while len(out) < n:
+		try:
+			out.append(q.get(timeout=2))
+		except queue.Empty:
+			dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+			assert not dead, f'a worker exited with code {dead[0]}'
+			assert time.time() - t0 < timeout, 'timed out waiting for the workers'
+	return out
 
 pytestmark = pytest.mark.gpu
 
@@ -174,7 +190,7 @@ def test_two_ranks_of_the_find_model_equal_one_process_on_16_feet():
 	procs = [ctx.Process(target=_dp_worker, args=(r, world, port, n_verts, q)) for r in range(world)]
 	for p in procs:
 		p.start()
-	res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+	res = sorted(_collect(q, procs, world), key=lambda t: t[0])
 	for p in procs:
 		p.join(timeout=120)
 		assert p.exitcode == 0
@@ -250,3 +266,111 @@ def test_one_rank_rccl_step_keeps_the_stream_layout_and_the_step_time():
 		if ratio < 1.05:
 			break
 	assert ratio < 1.05, (res, ratio)
+
+
+def _train3d_grads(lo, hi, n_total, n_verts, gt_verts, bucket_early):
+	"""Gradients of ONE train_3d.yaml network-stage step (chamf + smooth + texture: TWO MLP passes, the texture pass's weight gradients
+	deferred on the side streams and folded into the main pass's) on the feet [lo, hi) of n_total, with fixed sampler draws."""
+	import sys
+	sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+	from test_gpu_train3d import FixedDraws
+	from find_amd import distributed as fd
+	from find_amd import synthetic
+	from find_amd.model_with_loss import ModelWithLoss
+	from find_amd.opts import Opts
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.train_utils import backward_on_this_thread, sample_latent_vectors
+	dev = torch.device('cuda:0')
+	opts = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True, use_pose_code=True)
+	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=n_total, val_size=2,
+						shapevec_size=100, texvec_size=100, posevec_size=100, template_mesh_loc=None)
+	g = torch.Generator().manual_seed(1234)
+	with torch.no_grad():
+		mwl.model.mlp_disp[-1].weight.copy_(torch.randn(mwl.model.mlp_disp[-1].weight.shape, generator=g) * 0.01)
+		mwl.model.mlp_disp[-1].bias.copy_(torch.randn(3, generator=g) * 0.01)
+	mwl = mwl.to(dev)
+	m = mwl.model
+	v, f = synthetic.template(n_verts)
+	m.set_template(v.to(dev), f.to(dev))
+	lat = synthetic.latents(n_total, seed=5, device=dev)
+	with torch.no_grad():
+		for k in ('shapevec', 'texvec', 'posevec', 'reg'):
+			getattr(m, k).data.copy_(lat[k])
+	gv, gf, gc = synthetic.gt_feet(n_total, gt_verts, seed=3, device=dev)
+	gc = gc.clamp(0.05, 0.95)
+	F_gt, F_t = gf.shape[0], f.shape[0]
+	gd = torch.Generator().manual_seed(9)
+	full = [(torch.randint(0, F_gt, (n_total, 5000), generator=gd), torch.rand(n_total, 5000, 2, generator=gd)),
+			(torch.randint(0, F_t, (n_total, 5000), generator=gd), torch.rand(n_total, 5000, 2, generator=gd)),
+			(torch.randint(0, F_gt, (n_total, 1000), generator=gd), torch.rand(n_total, 1000, 2, generator=gd))]
+	draws = [(a[lo:hi].to(torch.int32).to(dev), b[lo:hi].to(dev)) for a, b in full]
+	params = [p for p in m.parameters() if p.requires_grad]
+	bucket = None
+	if bucket_early:
+		mlp_w = [p for seq in (m.base, m.mlp_disp, m.mlp_col) for p in seq.parameters()]
+		bucket = fd.GradBucket(params, early=mlp_w)
+		bucket.arm_early(m.base[0].weight)
+	batch = dict(mesh=Meshes(gv[lo:hi].contiguous(), gf, TexturesVertex(gc[lo:hi].contiguous())), idx=torch.arange(lo, hi, device=dev),
+				 name=[f'{i:04d}' for i in range(lo, hi)])
+	batch.update(sample_latent_vectors(batch, m.latent_vectors_train))
+	with FixedDraws(draws), backward_on_this_thread():
+		loss, _ = mwl(batch, 0, opts, chamf=True, smooth=True, texture=True)
+		loss.backward()
+	if bucket is not None:
+		assert bucket.early_issued == 1, 'the MLP weights\' part of the bucket did not leave inside the backward'
+		bucket.allreduce_()
+	torch.cuda.synchronize()
+	grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).cpu()
+	if bucket is not None:
+		bucket.close()
+	return grads, [tuple(p.shape) for p in params]
+
+
+def _train3d_worker(rank, world, port, n_verts, gt_verts, q):
+	import os
+	os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+	import torch.distributed as dist
+	from find_amd import distributed as fd
+	torch.cuda.set_device(0)
+	fd.init_from_env(backend='gloo')
+	lo, hi = fd.shard_range(16, rank, world)
+	grads, _ = _train3d_grads(lo, hi, 16, n_verts, gt_verts, bucket_early=True)
+	q.put((rank, grads.numpy().copy()))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_of_the_two_pass_training_step_equal_one_process():
+	"""The step the headline times, data-parallel: chamf + smooth + texture on 2 x 8 feet, the MLP weights' part of the gradient bucket
+	all-reduced INSIDE the backward (GradBucket.arm_early), against one process on the 16 feet with the same sampler draws.  The step
+	runs the MLP twice; the texture pass's weight gradients are still running on the side streams when its backward node returns and the
+	main pass's backward adds its own to them -- the early collective must come behind both (an all-reduce that left after the first
+	would average half a gradient and have the other half added on top: a factor-of-two error in every MLP weight)."""
+	import torch.multiprocessing as mp
+	n_verts, gt_verts, world = 1002, 1002, 2
+	ctx = mp.get_context('spawn')
+	q = ctx.Queue()
+	s = socket.socket()
+	s.bind(('127.0.0.1', 0))
+	port = s.getsockname()[1]
+	s.close()
+	procs = [ctx.Process(target=_train3d_worker, args=(r, world, port, n_verts, gt_verts, q)) for r in range(world)]
+	for p in procs:
+		p.start()
+	res = sorted(_collect(q, procs, world), key=lambda t: t[0])
+	for p in procs:
+		p.join(timeout=120)
+		assert p.exitcode == 0
+	ga, gb = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+	assert torch.equal(ga, gb), 'both ranks hold the same averaged gradient'
+	want, shapes = _train3d_grads(0, 16, 16, n_verts, gt_verts, bucket_early=False)
+	o = 0
+	for sh in shapes:
+		n = int(torch.tensor(sh).prod()) if sh else 1
+		g, w = ga[o:o + n], want[o:o + n]
+		o += n
+		scale = max(1e-8, w.abs().max().item())
+		err = (g - w).abs().max().item() / scale
+		# fp32 sums in a different order (two half batches, then their mean); the texture loss's mean runs over the masked samples of the batch
+		assert err < 2e-4, (sh, err)
