@@ -27,7 +27,7 @@ extern int g_raster_ablate;  // render.hip / geom.hip switches (find_render_swit
 #define FIND_DBG(ptr) (FIND_DIAG_ON ? (ptr) : nullptr)
 // result-preserving switches, settable in both builds
 constexpr int MLP_SWITCHES = 16 | 32 | 128;              // "ablate": no s_setprio in gemm4, every column block in the Fourier dW, 32-row fused tiles
-constexpr int RASTER_SWITCHES = 8 | 16 | 256 | 512 | 1024;  // no early exit, unsorted tile lists, tiny list pool; Chamfer: all pairs / grid from 64 points
+constexpr int RASTER_SWITCHES = 8 | 16 | 256 | 512 | 1024 | 2048 | 4096;  // no early exit, unsorted tile lists, tiny list pool; Chamfer: all pairs / grid from 64 points; 2048 / 4096: band / list rasteriser at every size
 
 inline int check_launch(const char* what) {
 	hipError_t e = hipGetLastError();

@@ -42,6 +42,7 @@ constexpr int KU = 16;            // list entries in flight per lane in the K-ne
 constexpr int KN_CAP = 4096;      // silhouette candidates kept per pixel for the K-nearest rule (more: unresolved, flags[1]); the pole of a 10 002-vertex lat-long scan @256^2 collects ~2000
 constexpr int RING = 8;           // candidates a lane collects in LDS before it writes them out: 2 x 32 contiguous bytes per flush
 constexpr int RASTER_WGS = 1024;  // persistent rasteriser workgroups (4 independent waves each); each owns 256 x KN_CAP x 8 B of scratch
+constexpr int64_t BAND_MIN_PIXELS = 384 * 384;   // images of at least this many pixels go through raster_band_kernel (find_render_fwd)
 constexpr int BIN_CAP = 2048;     // list entries a binning wave keeps (and sorts) in LDS; a longer list goes out in face order, without the early exit
 constexpr int N_SLABS = 255;      // depth slabs per image (8 bits of a list entry; the other 24 are the face index)
 constexpr int N_QUEUES = 24;      // tile queues by log2(list length), the longest lists first
@@ -120,7 +121,8 @@ static void carve(const find_render_params* rp, int64_t n_meshes, int64_t n_view
 	o->tie_face = c.take<int32_t>(px);
 	o->n_tiles = n_img * cdiv(rp->image_w, T8) * cdiv(rp->image_h, T8);
 	o->raster_wgs = std::min<int64_t>(cdiv(o->n_tiles, 4), RASTER_WGS);
-	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256);
+	// (raster_kernel: 256 x KN_CAP x 8 B per workgroup; raster_band_kernel, render_band.h: 4 waves x 3 x KN_CAP x 64 x 4 B -- the larger)
+	o->scratch = c.take<float2>(o->raster_wgs * KN_CAP * 256 * 3 / 2);
 	o->tinfo = c.take<int2>(o->n_tiles);
 	// a face of ~1 pixel with the silhouette's blur margin touches ~4.5 tiles at 256^2 and ~10 at 512^2; a tile that finds the pool
 	// full is rasterised from the face arrays directly (slower, never wrong)
@@ -1165,6 +1167,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 	}
 }
 
+#include "render_band.h"
+
+
 // Phong shading + softmax blend (K = 1) of every pixel's nearest inside fragment, the user-visible pix_to_face / zbuf, and the
 // barycentrics the RGB backward reads: one thread per pixel of the tiles that have a list (the others got their background from bin_kernel).
 __global__ __launch_bounds__(256) void shade_kernel(const TileArgs a) {
@@ -1751,7 +1756,20 @@ extern "C" int find_render_fwd(const find_render_params* rp, const float* verts,
 	ra.tb = w.tb; ra.zinfo = w.zinfo; ra.tinfo = w.tinfo; ra.F = F; ra.tiles_x = tiles_x; ra.tiles_per_img = tiles_per_img; ra.pool_cap = w.pool_cap;
 	ra.mask = mask; ra.p2f_ws = a.p2f_ws; ra.frag_ws = w.frag; ra.flags = w.flags; ra.qn = w.qn; ra.zthr = w.zthr; ra.alpha_ws = w.alpha;
 	ra.scratch = w.scratch; ra.fix = w.fix; ra.ablate = a.ablate;
-	if (mask && a.p2f_ws) hipLaunchKernelGGL((raster_kernel<true, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
+	// Which rasteriser: the list-free band kernel (render_band.h) from BAND_MIN_PIXELS pixels per image on, the candidate-list kernel below
+	// (switch bits 2048 / 4096 of find_render_switches force the band / the list kernel at every size: tests and A/B runs)
+	const bool band = (a.ablate & 2048) || (!(a.ablate & 4096) && (int64_t)H * W >= BAND_MIN_PIXELS);
+	if (band) {
+		RasterBandArgs rb;
+		memset(&rb, 0, sizeof(rb));
+		rb.sil_blur_radius = ra.sil_blur_radius; rb.sil_sigma = ra.sil_sigma; rb.sil_faces_per_pixel = ra.sil_faces_per_pixel; rb.image_h = H; rb.image_w = W;
+		rb.tb = ra.tb; rb.zinfo = ra.zinfo; rb.tinfo = ra.tinfo; rb.F = ra.F; rb.tiles_x = ra.tiles_x; rb.tiles_per_img = ra.tiles_per_img; rb.pool_cap = ra.pool_cap;
+		rb.mask = ra.mask; rb.p2f_ws = ra.p2f_ws; rb.frag_ws = ra.frag_ws; rb.flags = ra.flags; rb.qn = ra.qn; rb.zthr = ra.zthr; rb.alpha_ws = ra.alpha_ws;
+		rb.tie_face = w.tie_face; rb.scratch = reinterpret_cast<float*>(w.scratch); rb.ablate = ra.ablate;
+		if (mask && a.p2f_ws) hipLaunchKernelGGL((raster_band_kernel<true, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, rb, w.recs, w.pool, w.order);
+		else if (mask) hipLaunchKernelGGL((raster_band_kernel<true, false>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, rb, w.recs, w.pool, w.order);
+		else hipLaunchKernelGGL((raster_band_kernel<false, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, rb, w.recs, w.pool, w.order);
+	} else if (mask && a.p2f_ws) hipLaunchKernelGGL((raster_kernel<true, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
 	else if (mask) hipLaunchKernelGGL((raster_kernel<true, false>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
 	else hipLaunchKernelGGL((raster_kernel<false, true>), dim3((unsigned)w.raster_wgs), dim3(256), 0, s, ra, w.recs, w.pool, w.order);
 	if (a.p2f_ws) hipLaunchKernelGGL(shade_kernel, dim3((unsigned)cdiv(n_img * H * W, 256)), dim3(256), 0, s, a);

@@ -219,7 +219,9 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
 /* Process-wide switches of the rasteriser and of find_chamfer_fwd's neighbour search, all with unchanged results (tests/test_gpu_render.py,
  * tests/test_gpu_geom.py compare them): 8 no early exit of finished pixels / tiles, 16 tile lists left in face order (no depth-slab sort),
  * 256 a list pool of 512 entries per image (tiles without room scan the faces themselves); Chamfer: 512 all pairs at every size, 1024 the
- * uniform grid from 64 points per cloud on (geom.hip).  Any other bit is refused (FIND_EINVAL). */
+ * uniform grid from 64 points per cloud on (geom.hip); 2048 / 4096 the band / the candidate-list rasteriser at every image size (default: the
+ * band kernel from 384^2 pixels on, csrc/render_band.h -- the two agree in everything but the last bits of the alpha products).  Any other bit
+ * is refused (FIND_EINVAL). */
 int find_render_switches(int64_t bits);
 /* ------------------------------------------------------------------------------------------------
  * Latent-table lookup.  Replaces LatentVector.__getitem__ with a tensor of indices (src/model/model.py:131-152;

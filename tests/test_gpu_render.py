@@ -11,6 +11,22 @@ import torch
 from oracle import camera_ref, render_ref
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=['list', 'band'])
+def rasteriser(request):
+	"""Every test of this file runs on BOTH forward rasterisers: raster_kernel (candidate lists: what find_render_fwd picks below 384^2) and
+	raster_band_kernel (csrc/render_band.h, the list-free K-nearest rule: from 384^2 on) -- the switch bits 4096 / 2048 of
+	find_render_switches force one at every size."""
+	from find_amd import _lib
+	global RASTER_BASE
+	RASTER_BASE = 2048 if request.param == 'band' else 4096
+	_lib.set_tuning('raster_ablate', RASTER_BASE)
+	yield request.param
+	_lib.set_tuning('raster_ablate', 0)
+
+
+RASTER_BASE = 0
 TOL = 1e-4
 GRAD_TOL = 1e-4   # gradients relative to the tensor's largest entry; measured on MI355X: silhouette 1e-5, Phong image 1e-6 .. 1.3e-5
 
@@ -419,7 +435,7 @@ def test_early_exit_and_list_order_change_nothing():
 	params = FR.make_params(96)
 	out = {}
 	for bits in (0, 8, 16, 256):
-		_lib.set_tuning('raster_ablate', bits)
+		_lib.set_tuning('raster_ablate', bits | RASTER_BASE)
 		try:
 			vg = verts.clone().requires_grad_(True)
 			mask, image, p2f, zbuf = FR.render(vg, cols, f.cuda(), R.cuda(), T.cuda(), params, want_image=True, want_frags=True)
@@ -427,7 +443,7 @@ def test_early_exit_and_list_order_change_nothing():
 			((mask - gt) ** 2).mean().backward()
 			out[bits] = (mask.detach().clone(), image.detach().clone(), p2f.clone(), zbuf.clone(), vg.grad.clone())
 		finally:
-			_lib.set_tuning('raster_ablate', 0)
+			_lib.set_tuning('raster_ablate', RASTER_BASE)
 	m0, i0, p0, z0, g0 = out[0]
 	assert float((m0 > 0.5).float().mean()) > 0.05
 	for bits in (8, 16, 256):

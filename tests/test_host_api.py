@@ -141,7 +141,7 @@ def test_the_product_library_carries_no_laboratory_code():
 		assert k not in prod and k in dg, k
 	for bits in (1, 2, 4, 32, 64, 8 | 1):
 		assert L.find_render_switches(bits) == -1 and b'result-preserving' in L.find_last_error()
-	for bits in (8, 16, 256, 512, 1024, 0):
+	for bits in (8, 16, 256, 512, 1024, 2048, 4096, 0):
 		assert L.find_render_switches(bits) == 0
 
 
