@@ -38,6 +38,23 @@ def code_objects(lib, tmp):
 	return sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if 'amdgcn' in f)
 
 
+def scan(ins, out, stats):
+	"""ins: [(kernel, instruction text)] in program order.  Appends (kernel, store, next instruction) for every wide store with an SGPR
+	offset whose data registers the very next instruction of the same kernel writes."""
+	for i, (k, l) in enumerate(ins):
+		m = WIDE.match(l)
+		if not m:
+			continue
+		stats['wide_stores'] += 1
+		soff = m.group(6)
+		if not soff.startswith('s') and soff not in ('m0',):
+			continue   # immediate / "off" offset: the compiler's own hazard handling applies
+		stats['sgpr_offset'] += 1
+		data = set(range(int(m.group(2)), int(m.group(3)) + 1))
+		if i + 1 < len(ins) and ins[i + 1][0] == k and (_writes(ins[i + 1][1]) & data):
+			out.append((k, l.strip(), ins[i + 1][1].strip()))
+
+
 def hazards(lib):
 	"""[(kernel, store line, next line)] for every unprotected wide store in the library's gfx950 code objects."""
 	out = []
@@ -54,18 +71,7 @@ def hazards(lib):
 					continue
 				if l.startswith('\t') or l.startswith('  '):
 					ins.append((kernel, l.split('//')[0].rstrip()))
-			for i, (k, l) in enumerate(ins):
-				m = WIDE.match(l)
-				if not m:
-					continue
-				stats['wide_stores'] += 1
-				soff = m.group(6)
-				if not soff.startswith('s') and soff not in ('m0',):
-					continue   # immediate / "off" offset: the compiler's own hazard handling applies
-				stats['sgpr_offset'] += 1
-				data = set(range(int(m.group(2)), int(m.group(3)) + 1))
-				if i + 1 < len(ins) and ins[i + 1][0] == k and (_writes(ins[i + 1][1]) & data):
-					out.append((k, l.strip(), ins[i + 1][1].strip()))
+			scan(ins, out, stats)
 	return out, stats
 
 
