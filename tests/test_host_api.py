@@ -167,6 +167,8 @@ def test_no_wide_buffer_store_has_its_data_overwritten_by_the_next_instruction()
 	assert found(['\tbuffer_store_dwordx4 v[32:35], v77, s[20:23], 0 offen', '\tv_lshlrev_b32_e32 v32, 16, v49']) == 0
 	assert found(['\tbuffer_store_dwordx2 v[32:33], v77, s[20:23], s40 offen', '\tv_lshlrev_b32_e32 v32, 16, v49']) == 0
 	assert found([st128, '\tv_cmp_lt_f32_e32 vcc, 0, v32']) == 0   # (a read of the data, not a write)
+	assert found([st128, '\tv_accvgpr_write_b32 a32, v1']) == 0    # (another register file)
+	assert found(['\tbuffer_store_dwordx4 a[32:35], v77, s[20:23], s40 offen', '\tv_accvgpr_write_b32 a33, v1']) == 1
 	for lib in (_lib.LIB_PATH, os.path.join(os.path.dirname(_lib.LIB_PATH), 'libfind_hip_diag.so')):
 		hz, st = check_store_hazard.hazards(lib)
 		assert st['wide_stores'] >= 20, st      # (the lint saw the kernels)

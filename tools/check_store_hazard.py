@@ -11,21 +11,22 @@ import sys
 import tempfile
 
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-WIDE = re.compile(r'^\s*(buffer_store_dwordx[34]|buffer_store_format_xyzw?|tbuffer_store_format_xyzw?)\s+v\[(\d+):(\d+)\],\s*([^,]+),\s*([^,]+),\s*(\S+)')
+WIDE = re.compile(r'^\s*(buffer_store_dwordx[34]|buffer_store_format_xyzw?|tbuffer_store_format_xyzw?)\s+([va])\[(\d+):(\d+)\],\s*([^,]+),\s*([^,]+),\s*(\S+)')
 
 
 def _regs(tok):
-	m = re.match(r'[va]\[(\d+):(\d+)\]', tok)
+	"""(file, numbers) of a vector register operand: 'v' = VGPRs, 'a' = accumulation registers (a store may read its data from either)."""
+	m = re.match(r'([va])\[(\d+):(\d+)\]', tok)
 	if m:
-		return set(range(int(m.group(1)), int(m.group(2)) + 1))
-	m = re.match(r'v(\d+)$', tok)
-	return {int(m.group(1))} if m else set()
+		return {(m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)}
+	m = re.match(r'([va])(\d+)$', tok)
+	return {(m.group(1), int(m.group(2)))} if m else set()
 
 
 def _writes(line):
-	"""VGPRs a VALU instruction writes (first operand; v_cmp* / v_readlane etc. write none)."""
+	"""Vector registers a VALU / matrix instruction writes (first operand; v_cmp* / v_readlane etc. write none)."""
 	t = line.split('//')[0].strip()
-	if not t.startswith('v_') or t.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane', 'v_nop', 'v_accvgpr_write', 'v_mfma', 'v_smfmac')):
+	if not t.startswith('v_') or t.startswith(('v_cmp', 'v_readlane', 'v_readfirstlane', 'v_nop')):
 		return set()
 	ops = re.split(r'[ ,]+', t)
 	return _regs(ops[1]) if len(ops) > 1 else set()
@@ -46,11 +47,11 @@ def scan(ins, out, stats):
 		if not m:
 			continue
 		stats['wide_stores'] += 1
-		soff = m.group(6)
+		soff = m.group(7)
 		if not soff.startswith('s') and soff not in ('m0',):
 			continue   # immediate / "off" offset: the compiler's own hazard handling applies
 		stats['sgpr_offset'] += 1
-		data = set(range(int(m.group(2)), int(m.group(3)) + 1))
+		data = {(m.group(2), r) for r in range(int(m.group(3)), int(m.group(4)) + 1)}
 		if i + 1 < len(ins) and ins[i + 1][0] == k and (_writes(ins[i + 1][1]) & data):
 			out.append((k, l.strip(), ins[i + 1][1].strip()))
 
