@@ -643,7 +643,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
-	note_act16(c, w.D[0], a16);   // (every forward leaves its note, keyed by the workspace's first head buffer: the backward follows it)
+	note_act16(c, w.fbd, a16);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
 
 	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers
 	{
@@ -1210,7 +1210,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
-	const bool a16 = noted_act16(c, w.D[0], use_act16(c, c->f16, d.shared, n_feet, V));   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
+	const bool a16 = noted_act16(c, w.fbd, use_act16(c, c->f16, d.shared, n_feet, V));   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
 	int cd = 0, cc = 0;  // current dZ buffer per head
 	{
 		HeadOutBwdArgs h;
