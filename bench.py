@@ -61,6 +61,9 @@ GEMM5_C5_TRAFFIC_BYTES = None   # (gemm5 at the C5 shape, 16 x 50 002 rows: no P
 GEMM7_TRAFFIC_BYTES = 228.1e6   # bf16x3 gemm7 at the headline shape: (2 x 56 269.0 (FETCH_SIZE, gfx950 correction) + 110 240.0 (WRITE_SIZE)) KiB x 1024, profiles/r04_gemm7_pmc_summary.txt
 
 
+OWN_STREAM = os.environ.get('FIND_BENCH_STREAM', '0') != '0'
+
+
 def dtype_label():
 	"""Arithmetic type of the path as configured, as a token ('f32' also when the large layers' fp32 products are formed as bf16x3: DTYPE_NOTE)."""
 	from find_amd import functional as FF
@@ -217,7 +220,14 @@ class Run:
 		"""_timed() with the backward passes on this thread, as find_amd.trainer.Trainer runs its loops (train_utils.backward_on_this_thread:
 		autograd's worker thread costs the host 0.5 ms per step and made the eager loop host-bound; FIND_AUTOGRAD_THREADS=1 for torch's default)."""
 		from find_amd.train_utils import backward_on_this_thread
-		with backward_on_this_thread():
+		import contextlib
+		own = None
+		if OWN_STREAM:
+			# the loop on a stream of the bench's own, as find_amd.trainer.Trainer runs its loops (not HIP's legacy default stream, with which
+			# every blocking stream of the process -- the context's CU-masked side streams are of that kind -- synchronises implicitly)
+			own = self.__dict__.setdefault('_own_stream', torch.cuda.Stream(device=self.dev))
+			torch.cuda.synchronize()
+		with backward_on_this_thread(), (torch.cuda.stream(own) if own is not None else contextlib.nullcontext()):
 			return self._timed(step, steps, warmup, prime)
 
 	def _timed(self, step, steps, warmup, prime=True):

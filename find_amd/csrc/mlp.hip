@@ -169,6 +169,11 @@ struct find_ctx {
 	bool side_bound = false;      // the side streams have been chosen against the hardware queue of a caller's stream (bind_side_streams)
 	int bind_streams = 1;         // knob: 0 = keep the side streams as created
 	int r_queue = 2;              // knob: the side stream (0 = Q, 1 = T1, 2 = T2) whose hardware queue the slab-reduce stream R shares
+	int cu_reserve = 0;           // knob: CUs per XCD the side streams may NOT use (hipExtStreamCreateWithCUMask): the short kernels on the caller's
+	                              // stream -- the loss-side chain the main backward waits for -- then always find a free CU beside the side streams'
+	                              // long weight-gradient workgroups.  Takes effect when the side streams are bound (first fork).  Masked streams are
+	                              // BLOCKING streams (HIP offers no other kind with a mask): only for callers on a non-default stream
+	int side_cus = 256;           // CUs a side stream may use (num_cus - 8 cu_reserve once bound): what the weight-gradient launches are sized for
 	hipEvent_t ev[N_EVENTS];
 	int n_events = 0;
 	int next = 0;
@@ -951,12 +956,13 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 		return fk->stream(reduce_side);
 	};
 	float* pbuf = (db || S) ? b.pb : nullptr;
+	const int cus = (fk && fk->on) ? c->side_cus : c->num_cus;   // (the side streams may be confined to a part of the chip: cu_reserve)
 	if (!pos) {
 		int nmain, spf;
 		if (c->f16) {
 			// opt-in fp16 mode: 64-row chunks, rows past the end of a foot zero-filled by the kernel
 			const int cpf64 = (int)cdiv(V, 64);
-			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf64, cdiv(c->num_cus, feet)));
+			const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf64, cdiv(cus, feet)));
 			const int cps3 = (int)std::max<int64_t>(cdiv(cpf64, want), std::min<int>(4, cpf64));  // at least 256 rows per slab (the small launches are slab-bound)
 			spf = (int)cdiv(cpf64, cps3);
 			nmain = (int)(feet * spf);
@@ -996,10 +1002,10 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			int cps2 = 1;
 			spf = 1;
 			if (cpf16 > 0) {
-				const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(c->num_cus, feet)));
+				const int want = (int)std::max<int64_t>(1, std::min<int64_t>(cpf16, cdiv(cus, feet)));
 				// few, long runs (slab traffic) -- unless that leaves CUs without a workgroup: a launch of few rows (the head's first-layer gradient
 				// over the foot-summed dZ of a shared template: 6890 rows = 54 runs of 8 chunks, 86 us) is bounded by its longest run, not by slabs
-				const int floor_cps = (feet * cpf16 < (int64_t)c->dw2_min_cps * c->num_cus) ? std::min(2, c->dw2_min_cps) : c->dw2_min_cps;
+				const int floor_cps = (feet * cpf16 < (int64_t)c->dw2_min_cps * cus) ? std::min(2, c->dw2_min_cps) : c->dw2_min_cps;
 				cps2 = (int)std::max<int64_t>(cdiv(cpf16, want), std::min<int>(floor_cps, cpf16));
 				spf = (int)cdiv(cpf16, cps2);
 			}
@@ -1039,7 +1045,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	const bool lds_free = c->dw_pe_lds_free != 0 && p->pe_size >= 32;
 	const int nkt_launch = lds_free ? (int)cdiv(p->pe_size, 128) : nkt;
 	int spf, cps;
-	split_policy(feet, V, &spf, &cps, std::min<int64_t>(128, std::max<int64_t>(16, c->dw_pe_target / nkt_launch)));
+	split_policy(feet, V, &spf, &cps, std::min<int64_t>(128, std::max<int64_t>(16, std::min(c->dw_pe_target, cus) / nkt_launch)));
 	DwArgs a;
 	memset(&a, 0, sizeof(a));
 	a.dz = dz; a.dz_foot_stride = V * W;
@@ -1089,7 +1095,7 @@ static void group_geometry(const find_ctx* c, int cpf16, int64_t feet, int jobs,
 		const int cps = (int)cdiv(cpf16, s);
 		if ((int)cdiv(cpf16, cps) != s || (cps < 2 && s > 1)) continue;   // (same geometry as a smaller s; single-chunk splits)
 		const int64_t wgs = feet * s * std::max(jobs, 1);
-		const double cost = (double)cdiv(wgs, c->num_cus) * (cps * 3.6 + 6.0) + wgs * 0.06;
+		const double cost = (double)cdiv(wgs, c->side_cus) * (cps * 3.6 + 6.0) + wgs * 0.06;
 		if (cost < best) { best = cost; take(s); }
 	}
 }
@@ -1716,15 +1722,35 @@ extern "C" int find_ctx_stream_beside(find_ctx* c, void* caller_stream, void* co
 // chooses its side streams among a dozen candidates by probing (once per context, ~20 ms).
 namespace find {
 namespace mlp {
+// a side-stream candidate: non-blocking, or -- cu_reserve -- confined to the CUs the mask leaves (bit i of the mask = CU i / 8 of XCD i % 8,
+// the driver's order on multi-XCD parts: clearing the low 8 R bits takes R CUs from every XCD)
+static hipError_t create_side_stream(find_ctx* c, hipStream_t* out) {
+	if (c->cu_reserve <= 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+	uint32_t mask[16] = {};
+	const int ncu = std::min(c->num_cus, 512), lo = std::min(8 * c->cu_reserve, ncu - 8);
+	for (int i = lo; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+	return hipExtStreamCreateWithCUMask(out, (uint32_t)((ncu + 31) / 32), mask);
+}
+
 static int bind_side_streams(find_ctx* c, hipStream_t caller) {
 	c->side_bound = true;   // (one attempt: a failure below keeps the streams as created)
 	constexpr int N_CAND = 12;
 	hipStream_t st[1 + N_CAND];
 	st[0] = caller;
 	int n = 1;
+	if (c->cu_reserve > 0) {
+		// the streams find_ctx_create made carry no mask: replace them
+		for (int k = 0; k < N_SIDE; ++k) {
+			hipStream_t m = nullptr;
+			if (create_side_stream(c, &m) != hipSuccess) { set_error("find_ctx: hipExtStreamCreateWithCUMask failed"); return FIND_ELAUNCH; }
+			(void)hipStreamDestroy(c->side[k]);
+			c->side[k] = m;
+		}
+		c->side_cus = c->num_cus - std::min(8 * c->cu_reserve, c->num_cus - 8);
+	}
 	for (int k = 0; k < N_SIDE; ++k) st[n++] = c->side[k];
 	for (; n < 1 + N_CAND; ++n)
-		if (hipStreamCreateWithFlags(&st[n], hipStreamNonBlocking) != hipSuccess) break;
+		if (create_side_stream(c, &st[n]) != hipSuccess) break;
 	int g[1 + N_CAND];
 	int rc = stream_groups(st, n, c->ev[0], c->ev[1], g);
 	int pick[N_SIDE] = {-1, -1, -1, -1};
@@ -1782,6 +1808,7 @@ extern "C" int find_ctx_create(int device, find_ctx** out) {
 	int v = 0;
 	if ((e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return fail("CU count", e);
 	c->num_cus = v > 0 ? v : 256;
+	c->side_cus = c->num_cus;
 	if ((e = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device)) != hipSuccess) return fail("LDS size", e);
 	c->lds_bytes = v;
 	for (int i = 0; i < N_SIDE; ++i)
@@ -1816,7 +1843,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 
@@ -1856,6 +1883,7 @@ extern "C" int find_ctx_set(find_ctx* c, const char* key, int64_t value) {
 extern "C" int find_ctx_get(const find_ctx* c, const char* key, int64_t* value) {
 	FIND_REQUIRE(c != nullptr && key != nullptr && value != nullptr, "find_ctx_get: NULL argument");
 	if (strcmp(key, "num_cus") == 0) { *value = c->num_cus; return FIND_OK; }
+	if (strcmp(key, "side_cus") == 0) { *value = c->side_cus; return FIND_OK; }
 	if (strcmp(key, "pending") == 0) { *value = (c->pend[0] || c->pend[1] || c->pend[2] || c->pend[3]) ? 1 : 0; return FIND_OK; }
 	if (strcmp(key, "lds_bytes") == 0) { *value = c->lds_bytes; return FIND_OK; }
 	if (strcmp(key, "device") == 0) { *value = c->device; return FIND_OK; }

@@ -64,8 +64,13 @@ class GradBucket:
 		if not early:
 			self.n_early = 0
 		self._early = None      # (work, divisor) of the prefix collective issued inside this step's backward
+		self._early_void = False   # that collective was overtaken (a second backward, a stale step): its result is dropped, the prefix travels again
+		self._stage = None      # the prefix is averaged in a COPY: the arena (= the live .grad tensors) is only written at wait(), when the
+		                        # step has shown that nothing else touched those gradients in between
+		self._task = None       # autograd graph task the `taken` flags belong to
 		self._hook = None
 		self.early_issued = 0   # steps in which the prefix went out early (diagnostics / tests)
+		self.early_dropped = 0  # early collectives whose result had to be dropped (diagnostics / tests)
 		self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
 		self.views = [self._view(i) for i in range(len(self.params))]
 		self.taken = [False] * len(self.params)
@@ -80,7 +85,14 @@ class GradBucket:
 
 	def take(self, i, shape, device):
 		"""Arena request from a backward kernel wrapper: a FRESH view of slot i (autograd adopts a gradient tensor only when nothing
-		else references it), or None when the slot was handed out already this step or still backs a live .grad."""
+		else references it), or None when the slot was handed out already in this backward pass or still backs a live .grad."""
+		from . import functional
+		task = functional._graph_task_id()
+		if task != self._task:
+			# a new backward() call: the flags of the last one are history (a step that ended without allreduce_() must not leave them set --
+			# the next step's hook would take a stale arena for a complete one); a slot that still backs a live .grad stays refused below
+			self._task = task
+			self.taken = [False] * len(self.params)
 		p = self.params[i]
 		if self.taken[i] or tuple(shape) != tuple(p.shape) or device != self.flat.device:
 			return None
@@ -93,27 +105,46 @@ class GradBucket:
 	def arm_early(self, trigger):
 		"""Issue the all-reduce of the early prefix when autograd has accumulated `trigger` -- a parameter every backward node that writes an
 		early gradient feeds (FIND: `base[0].weight`, which both MLP passes of a step reach: its AccumulateGrad node runs after the last of
-		them has returned, i.e. behind its last weight-gradient kernel on the stream).  The collective reads the arena, not `.grad`: it goes out
-		only if every early slot was handed to a backward kernel this step (else the prefix travels with the rest, as before)."""
+		them has returned, i.e. behind its last weight-gradient kernel on the stream).  The collective reads the arena, not `.grad`, and
+		averages a COPY of the prefix: it goes out only if every early slot was handed to a backward kernel in this pass (else the prefix
+		travels with the rest, as before), and its result reaches the gradients in wait() only if allreduce_() finds every early .grad still
+		being its arena slot and no second backward() in between -- otherwise it is dropped and the prefix travels with the rest."""
 		if self.n_early == 0 or self._hook is not None:
 			return
 		trigger._find_hooks_are_stream_safe = True   # (find_amd.functional: this hook joins deferred weight-gradient work itself before it reads the arena, so deferred joins stay allowed)
+		t_index = next(i for i, p in enumerate(self.params) if p is trigger)
 
 		def fire(_p):
-			if self._early is not None or not (dist.is_available() and dist.is_initialized()):
+			if not (dist.is_available() and dist.is_initialized()):
+				return
+			if self._early is not None:
+				# an early collective nobody consumed: a second backward() before allreduce_() (micro-batches) or a step that never called
+				# allreduce_() -- what it averaged is not what the gradients are now
+				self._early_void = True
 				return
 			if not all(self.taken[:self.n_early_params]):
 				return
+			g = trigger.grad
+			if g is None or g.data_ptr() != self.views[t_index].data_ptr():
+				return   # (autograd summed into a tensor of its own: a second MLP pass that could not fold into the arena)
 			if self.arena:
+				from . import functional
 				# weight-gradient work a deferred find_mlp_bwd left on the context's side streams (functional: defer_join) writes the arena
 				# too: the current stream -- and with it the collective issued behind it -- waits for it first.  (In FIND's step the main
 				# pass's backward has joined it before this hook runs; a graph in which the deferred pass is the trigger's only feeder has not.)
-				from . import functional
 				if functional._DEFERRED:
 					functional._join_deferred()
+				# ... and so does the fold of an MLP pass that ran on a stream of its own (model_with_loss.TEXTURE_STREAM): it adds into the
+				# parked slots on THAT stream and reports no gradient, so autograd has not ordered this hook behind it (ADVICE r5)
+				for s in functional._CROSS_STREAMS:
+					torch.cuda.current_stream(s.device).wait_stream(s)
+			if self._stage is None:
+				self._stage = torch.empty(self.n_early, dtype=torch.float32, device=self.flat.device)
+			self._stage.copy_(self.flat[:self.n_early])
 			avg = dist.get_backend(self.group) == 'nccl'
-			work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+			work = dist.all_reduce(self._stage, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
 			self._early = (work, None if avg else dist.get_world_size(self.group))
+			self._early_void = False
 			self.early_issued += 1
 		self._hook = trigger.register_post_accumulate_grad_hook(fire)
 
@@ -131,11 +162,22 @@ class GradBucket:
 		enqueueing work that does not read the gradients and calls wait() before the optimiser step (RCCL runs the collective on its own
 		stream behind everything the current stream held at the call; wait() makes the current stream wait for it, the host never blocks)."""
 		self.taken = [False] * len(self.params)
+		self._task = None
 		self._pending = None
 		early, self._early = self._early, None
+		void, self._early_void = self._early_void, False
 		if not (dist.is_available() and dist.is_initialized()):
 			return
 		world = dist.get_world_size(self.group)
+		if early is not None:
+			# the prefix is on its way -- valid only if every early gradient still IS its arena slot (a pass that did not fold, a hook that
+			# replaced .grad) and no second backward() ran since it left
+			ok = not void and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+								  for p, v in zip(self.params[:self.n_early_params], self.views[:self.n_early_params]))
+			if not ok:
+				early[0].wait()   # (collectives of a group complete in issue order: finish it, drop what it averaged)
+				early = None
+				self.early_dropped += 1
 		missing, src, dst = [], [], []
 		lo = self.n_early_params if early is not None else 0   # (the early prefix is on its way already: every one of its slots came out of the arena)
 		for p, v in list(zip(self.params, self.views))[lo:]:
@@ -164,7 +206,8 @@ class GradBucket:
 		if early is not None:
 			early[0].wait()
 			if early[1] is not None:
-				self.flat[:self.n_early].div_(early[1])
+				self._stage.div_(early[1])
+			self.flat[:self.n_early].copy_(self._stage)   # (the early gradients ARE these slots: checked in allreduce_)
 		if work is not None:
 			work.wait()
 			if div is not None:

@@ -47,7 +47,12 @@ OVERLAP_GT_RENDER = os.environ.get('FIND_OVERLAP_GT_RENDER', '1') != '0'
 OVERLAP_CHAMFER = os.environ.get('FIND_OVERLAP_CHAMFER', '1') != '0'
 # the texture term (GT surface samples -> colour field -> masked MSE: a chain of its own, it reads nothing of the main pass) on the second
 # stream from the START of the step, beside the main pass; FIND_TEXTURE_STREAM=0 turns it off
-TEXTURE_STREAM = os.environ.get('FIND_TEXTURE_STREAM', '0') != '0'
+# = 2: the texture term on a THIRD stream, forked behind the main pass's forward -- its forward beside the Chamfer term's (as on the main stream),
+# but its BACKWARD (autograd replays a node on its forward's stream) beside the main pass's backward instead of in front of it: the texture
+# pass's dX chain and weight gradients (0.37 ms of the step when they sit between the loss glue and the main pass's backward) fill the small-kernel
+# stretches of the main chain.  Measured in round 6 and NOT the default: 1.93-2.05 ms against 1.81-1.83 on the same box (tools/ab_env.sh) -- kernels
+# that run beside each other on this chip slow each other by what the overlap gains; only less matrix-pipe time helps
+TEXTURE_STREAM = int(os.environ.get('FIND_TEXTURE_STREAM', '0'))
 # the GT scans' surface samples drawn before the main pass, beside it (ModelWithLoss.forward); FIND_PRESAMPLE_GT=0: inside the loss terms, as the reference orders them
 PRESAMPLE_GT = os.environ.get('FIND_PRESAMPLE_GT', '1') != '0'
 LAZY_COLOURS = os.environ.get('FIND_LAZY_COLOURS', '1') != '0'       # switch for A/B runs and for the bench record with the reference's eager colour head
@@ -87,6 +92,36 @@ def _second_stream(device):
 		torch.cuda.synchronize(device)
 	pick = cands[max(0, index.value)]
 	_SECOND_STREAMS[device] = pick
+	return pick
+
+
+_THIRD_STREAMS = {}
+
+
+def _third_stream(device):
+	"""A stream beside the caller's AND beside _second_stream: on the hardware queue of the context's T2 stream (idle in the forward; in the
+	backward it carries the Fourier layer's weight gradient, which the texture pass's own chain forks and therefore never waits behind)."""
+	s = _THIRD_STREAMS.get(device)
+	if s is not None:
+		return s
+	import ctypes
+	from . import _lib
+	second = _second_stream(device)
+	main = torch.cuda.current_stream(device)
+	cands = [torch.cuda.Stream(device=device) for _ in range(12)]
+	arr = (ctypes.c_void_p * len(cands))(*[c.cuda_stream for c in cands])
+	index = ctypes.c_int32(-1)
+	with torch.cuda.device(device):
+		torch.cuda.synchronize(device)
+		for role in (int(os.environ.get('FIND_THIRD_STREAM_ROLE', '2')), 1, 2):
+			_lib.check(_lib.lib().find_ctx_stream_beside(_lib.ctx(), ctypes.c_void_p(main.cuda_stream), arr, len(cands), role, ctypes.byref(index)), 'find_ctx_stream_beside')
+			if index.value >= 0:
+				break
+		torch.cuda.synchronize(device)
+	pick = cands[max(0, index.value)]
+	if pick is second:
+		pick = cands[(max(0, index.value) + 1) % len(cands)]
+	_THIRD_STREAMS[device] = pick
 	return pick
 
 
@@ -238,7 +273,8 @@ class ModelWithLoss(nn.Module):
 		# pipe) and the other way round -- forward and, since autograd replays a node on its forward's stream, backward.
 		early = {}
 		tex_side = None
-		if (TEXTURE_STREAM and texture and supervise_3d and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()):
+		st.gt_chamf = st.gt_tex = None
+		if (TEXTURE_STREAM == 1 and texture and supervise_3d and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()):
 			tex_side = _second_stream(dev)
 			main = torch.cuda.current_stream(dev)
 			tex_side.wait_stream(main)   # (the latent rows of the batch were gathered on this stream)
@@ -248,7 +284,6 @@ class ModelWithLoss(nn.Module):
 		# The surface samples of the GT scans (Chamfer: 5000 per scan; texture: 1000 with colours) depend on the batch alone: drawn HERE, before
 		# the main pass and -- outside a capture -- on the second stream beside it (round 5: they used to sit between the main pass and the
 		# texture term's MLP pass, three short launches each on a chip the nearest-neighbour search was filling: 60 us for a 7-us kernel).
-		st.gt_chamf = st.gt_tex = None
 		pre_ev = None
 		if PRESAMPLE_GT and supervise_3d and (chamf or texture) and tex_side is None and 'mesh' in batch:
 			with_side = dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
@@ -283,22 +318,31 @@ class ModelWithLoss(nn.Module):
 		if (OVERLAP_CHAMFER and tex_side is None and dev is not None and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
 				and any(t.flag == 'chamf' for t in active) and any(t.flag == 'texture' for t in active)):
 			aside = _second_stream(dev)
-		for term in active:
+		third = None
+		if (TEXTURE_STREAM == 2 and aside is not None and any(t.needs_3d and t.flag != 'texture' for t in active)):
+			third = _third_stream(dev)
+		# (issue order = reverse backward order: with a third stream the texture term goes first, so that the loss-side chain the main pass's
+		# backward waits for -- smoothness, Chamfer, registration -- is the first thing the backward pass enqueues)
+		order = sorted(active, key=lambda t: t.flag != 'texture') if third is not None else active
+		got = {}
+		for term in order:
 			if term.key in early:
-				raw[term.key] = early[term.key]
-			elif aside is not None and term.flag == 'chamf':
+				got[term.key] = early[term.key]
+			elif (aside is not None and term.flag == 'chamf') or (third is not None and term.flag == 'texture'):
+				side = aside if term.flag == 'chamf' else third
 				main = torch.cuda.current_stream(dev)
-				aside.wait_stream(main)
-				with torch.cuda.stream(aside):
-					raw[term.key] = getattr(self, term.fn)(st)
-				raw[term.key].record_stream(main)   # allocated on the second stream, read on this one
+				side.wait_stream(main)
+				with torch.cuda.stream(side):
+					got[term.key] = getattr(self, term.fn)(st)
+				got[term.key].record_stream(main)   # allocated on the side stream, read on this one
 			else:
-				raw[term.key] = getattr(self, term.fn)(st)
+				got[term.key] = getattr(self, term.fn)(st)
+		for term in active:   # (reported, and summed, in the registry's order whatever the issue order was)
+			raw[term.key] = got[term.key]
 			weights.append(float(getattr(opts, term.weight)))
-		if aside is not None:
-			torch.cuda.current_stream(dev).wait_stream(aside)
-		if tex_side is not None:
-			torch.cuda.current_stream(dev).wait_stream(tex_side)
+		for side in (aside, third, tex_side):
+			if side is not None:
+				torch.cuda.current_stream(dev).wait_stream(side)
 		if save_renders:
 			self._save_renders(st, render_dir)
 		# losses[k] = raw * opts.weight_k, loss = sum(losses.values())   (model.py:1157-1163): one launch for all terms (find_weighted_terms_*)

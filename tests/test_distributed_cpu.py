@@ -101,3 +101,132 @@ def test_single_process_bucket_is_a_noop():
 	(p * 2).sum().backward()
 	GradBucket([p]).allreduce_()
 	assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+# ------------------------------------------------------------------------------------------------ early prefix (GradBucket.arm_early)
+class _ArenaLinear(torch.autograd.Function):
+	"""x @ w.T + b whose backward asks find_amd.functional for its gradient buffers, as the HIP wrappers do (the bucket's arena protocol)."""
+
+	@staticmethod
+	def forward(ctx, x, w, b):
+		ctx.save_for_backward(x, w, b)
+		return x @ w.t() + b
+
+	@staticmethod
+	def backward(ctx, g):
+		from find_amd import functional as FN
+		x, w, b = ctx.saved_tensors
+		gw, gb = FN._grads_like([w, b])
+		gw.copy_(g.t() @ x)
+		gb.copy_(g.sum(0))
+		return g @ w, gw, gb
+
+
+def _early_model(seed):
+	torch.manual_seed(seed)
+	w1, b1 = torch.nn.Parameter(torch.randn(5, 6) * 0.3), torch.nn.Parameter(torch.randn(5) * 0.1)
+	w2, b2 = torch.nn.Parameter(torch.randn(3, 5) * 0.3), torch.nn.Parameter(torch.randn(3) * 0.1)
+	table = torch.nn.Parameter(torch.randn(8, 3) * 0.1)   # a latent table: not part of the early prefix
+	return [w1, b1, w2, b2], table
+
+
+def _early_loss(ws, table, X, Y, lo, hi):
+	w1, b1, w2, b2 = ws
+	h = torch.relu(_ArenaLinear.apply(X[lo:hi], w1, b1))
+	return ((_ArenaLinear.apply(h, w2, b2) + table[lo:hi] - Y[lo:hi]) ** 2).mean()
+
+
+def _early_worker(rank, world, port, q):
+	os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+	torch.set_num_threads(1)
+	from find_amd import distributed as fd
+	fd.init_from_env(backend='gloo')
+	ws, table = _early_model(7)
+	params = ws + [table]
+	g = torch.Generator().manual_seed(0)
+	X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+	lo, hi = fd.shard_range(8, rank, world)
+	bucket = fd.GradBucket(params, arena=True, early=ws)
+	bucket.arm_early(ws[0])
+	assert bucket.params[:4] == ws and bucket.n_early == sum((p.numel() + 3) & ~3 for p in ws)
+	out = {}
+
+	def grads():
+		return torch.cat([p.grad.reshape(-1) for p in params]).numpy().copy()
+
+	# A: one backward per step -- the prefix leaves inside the backward, the table's part in allreduce_()
+	_early_loss(ws, table, X, Y, lo, hi).backward()
+	assert bucket.early_issued == 1 and bucket._early is not None
+	local = torch.cat([p.grad.reshape(-1) for p in ws]).clone()   # (the arena is not written before wait(): still this rank's own gradient)
+	bucket.allreduce_(async_op=True)
+	assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ws]), local)
+	bucket.wait()
+	assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+	out['A'] = grads()
+	# B: two backward() calls before allreduce_() (micro-batches): the early collective of the first is overtaken and dropped
+	for p in params:
+		p.grad = None
+	mid = (lo + hi) // 2
+	(_early_loss(ws, table, X, Y, lo, mid) * 0.5).backward()
+	(_early_loss(ws, table, X, Y, mid, hi) * 0.5).backward()
+	assert bucket.early_issued == 2 and bucket._early_void
+	bucket.allreduce_()
+	assert bucket.early_dropped == 1
+	out['B'] = grads()
+	# C: a step that never calls allreduce_() (its early collective goes stale), then a normal one
+	for p in params:
+		p.grad = None
+	(_early_loss(ws, table, X, Y, lo, hi) * 3.0).backward()
+	assert bucket.early_issued == 3
+	for p in params:
+		p.grad = None
+	_early_loss(ws, table, X, Y, lo, hi).backward()
+	assert bucket.early_issued == 3 and bucket._early_void   # (the stale one is still unconsumed: this pass must not fire, and must not trust it)
+	bucket.allreduce_()
+	assert bucket.early_dropped == 2
+	out['C'] = grads()
+	# D: ... and the step after that takes the early path again
+	for p in params:
+		p.grad = None
+	_early_loss(ws, table, X, Y, lo, hi).backward()
+	assert bucket.early_issued == 4
+	bucket.allreduce_()
+	assert bucket.early_dropped == 2
+	out['D'] = grads()
+	# E: a gradient that is not its arena slot when allreduce_() looks (here: replaced by a clone) voids the early result as well
+	for p in params:
+		p.grad = None
+	_early_loss(ws, table, X, Y, lo, hi).backward()
+	ws[2].grad = ws[2].grad.clone()
+	bucket.allreduce_()
+	assert bucket.early_dropped == 3
+	out['E'] = grads()
+	q.put((rank, out))
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+def test_early_prefix_equals_one_collective_equals_single_process():
+	"""GradBucket(early=...) + arm_early on gloo, world 2: prefix inside the backward + remainder == the full-batch gradient of one process;
+	the cases ADVICE r5 names (second backward before allreduce_, a step without allreduce_, a .grad that left the arena) drop the early
+	result and still give the right average."""
+	world = 2
+	ctx = mp.get_context('spawn')
+	q = ctx.Queue()
+	port = _free_port()
+	procs = [ctx.Process(target=_early_worker, args=(r, world, port, q)) for r in range(world)]
+	for p in procs:
+		p.start()
+	res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+	for p in procs:
+		p.join(timeout=60)
+		assert p.exitcode == 0
+	ws, table = _early_model(7)
+	g = torch.Generator().manual_seed(0)
+	X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+	_early_loss(ws, table, X, Y, 0, 8).backward()   # (no bucket in this process: _grads_like hands out plain tensors)
+	ref = torch.cat([p.grad.reshape(-1) for p in ws + [table]])
+	for case in 'ABCDE':
+		a, b = torch.from_numpy(res[0][1][case]), torch.from_numpy(res[1][1][case])
+		assert torch.equal(a, b), f'case {case}: the ranks disagree'
+		assert torch.allclose(a, ref, atol=1e-6), (case, (a - ref).abs().max())
