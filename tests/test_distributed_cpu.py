@@ -161,7 +161,7 @@ def _early_worker(rank, world, port, q):
 	bucket.allreduce_(async_op=True)
 	assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ws]), local)
 	bucket.wait()
-	assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+	assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params[:4], bucket.views[:4]))   # (the table's gradient is autograd's own tensor: copy path)
 	out['A'] = grads()
 	# B: two backward() calls before allreduce_() (micro-batches): the early collective of the first is overtaken and dropped
 	for p in params:
@@ -217,7 +217,7 @@ def test_early_prefix_equals_one_collective_equals_single_process():
 	procs = [ctx.Process(target=_early_worker, args=(r, world, port, q)) for r in range(world)]
 	for p in procs:
 		p.start()
-	res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+	res = sorted([q.get(timeout=60) for _ in range(world)], key=lambda t: t[0])
 	for p in procs:
 		p.join(timeout=60)
 		assert p.exitcode == 0
