@@ -6,7 +6,6 @@
 #include "mlp_gemm5.h"
 #include "mlp_gemm6.h"
 #include "mlp_gemm7.h"
-#include "mlp_gemm8.h"
 #include "mlp_dw3.h"
 #include "mlp_dw6.h"
 #include "mlp_gemm4.h"
@@ -128,7 +127,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_GEMM8_RELU, K_GEMM8_MASK, K_GEMM8_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -154,7 +153,6 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int gemm6_min_units = 1024;
 	int gemm7 = 1;                // bf16x3 Linear kernel: 1 = gemm7 (W in registers, activations through LDS), 0 = gemm6 (W planes in LDS; kept for A/B)
-	int gemm8 = 0;                // knob: bf16x3 Linear kernel of the large launches: 1 = gemm8 (32 columns x half of K per wave: half the LDS fragment reads), 0 = gemm7
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which
 	                              // round 2 showed to be about registers, not LDS (see "Co-residence" below); off by default now
@@ -461,33 +459,6 @@ static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	return FIND_OK;
 }
 
-template <int EPI>
-static int launch_gemm8_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
-	int lds = 0;
-	const int rc = prepare_kernel(c, K_GEMM8_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2), &gemm8_kernel<EPI>, GEMM8_LDS, &lds);
-	if (rc != FIND_OK) return rc;
-	a.tiles_per_foot = (int)cdiv(a.V, 32);
-	a.ntiles = (int)(a.tiles_per_foot * feet);
-	const int grid = std::max(16, (c->num_cus / 16) * 16);   // the two column halves of a row range sit 8 blocks apart (same XCD)
-	if constexpr (EPI == EPI_BIAS_RELU) {
-		const int var = c->gemm8 - 1;
-		if (var > 0) {
-#define FIND_G8_VAR(N) case N: { FIND_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<EPI, N>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes), "hipFuncSetAttribute"); \
-			hipLaunchKernelGGL((gemm8_kernel<EPI, N>), dim3(grid), dim3(GEMM8_NW * 64), lds, s, a); return FIND_OK; }
-			switch (var) { FIND_G8_VAR(1) FIND_G8_VAR(2) FIND_G8_VAR(3) FIND_G8_VAR(4) FIND_G8_VAR(5) FIND_G8_VAR(6) FIND_G8_VAR(7) }
-#undef FIND_G8_VAR
-		}
-	}
-	hipLaunchKernelGGL((gemm8_kernel<EPI>), dim3(grid), dim3(GEMM8_NW * 64), lds, s, a);
-	return FIND_OK;
-}
-
-static int launch_gemm8(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
-	if (epi == EPI_BIAS_RELU) return launch_gemm8_t<EPI_BIAS_RELU>(c, a, feet, s);
-	if (epi == EPI_MASK) return launch_gemm8_t<EPI_MASK>(c, a, feet, s);
-	return launch_gemm8_t<EPI_NONE>(c, a, feet, s);
-}
-
 static int launch_gemm7(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (epi == EPI_BIAS_RELU) return launch_gemm7_t<EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK) return launch_gemm7_t<EPI_MASK>(c, a, feet, s);
@@ -531,7 +502,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 #ifdef FIND_DIAG
 	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
 #endif
-	if (c->x3 && k256 && units >= c->gemm6_min_units) return c->gemm8 ? launch_gemm8(c, epi, b, feet, s) : launch_gemm7(c, epi, b, feet, s);
+	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm7(c, epi, b, feet, s);
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
 	return launch_gemm3(c, epi, b, feet, s);
@@ -1872,7 +1843,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"gemm8", &find_ctx::gemm8, 0, 8}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 
