@@ -153,6 +153,7 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int gemm6_min_units = 1024;
 	int gemm7 = 1;                // bf16x3 Linear kernel: 1 = gemm7 (W in registers, activations through LDS), 0 = gemm6 (W planes in LDS; kept for A/B)
+	int direct_w = 1;             // knob: bf16x3 kernels read the model's weights themselves (transposed / Fourier order) instead of repacked copies (0: A/B)
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which
 	                              // round 2 showed to be about registers, not LDS (see "Co-residence" below); off by default now
@@ -490,7 +491,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	memset(&b, 0, sizeof(b));
 	b.a0 = a.a0; b.a1 = a.a1; b.nseg = a.nbase; b.a_foot_stride = a.a_foot_stride; b.lda = a.lda;
 	b.pos = a.pos; b.pos_foot_stride = a.pos_foot_stride; b.Bm = a.Bm; b.pe = a.pe;
-	b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk;
+	b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk; b.w_tr = a.w_tr;
 	b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
 	b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = c->ablate; b.dbg = c->dbg;
 	if (amode == AMODE_PE) return launch_gemm2_pe(c, b, feet, s);
@@ -503,10 +504,24 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
 #endif
 	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm7(c, epi, b, feet, s);
+	FIND_REQUIRE(!a.w_tr, "launch_gemm: an untransposed weight reached a kernel that cannot read it (gemm7_direct and the kernel selection disagree)");
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
 	return launch_gemm3(c, epi, b, feet, s);
 }
+
+// a K = 256, one-segment launch of this many rows per foot goes to gemm7 (launch_gemm's rule): its dX form may then read the model's weight
+// itself (Gemm2Args::w_tr) instead of a transposed copy
+static bool gemm7_direct(const find_ctx* c, int64_t V, int64_t feet) {
+	const int64_t units = cdiv(V, 32) * feet;
+#ifdef FIND_DIAG
+	if (!c->gemm7) return false;
+#endif
+	return c->direct_w && c->x3 && !(c->f16 && units >= c->gemm5_min_units) && units >= c->gemm6_min_units;
+}
+// a fused chain of this call will run on fused6_kernel (chain_prepare's rule): split_w_kernel reads every weight once anyway, in whatever
+// order the step asks for (FusedStep::wmode) -- no repack launch in front of the chain
+static bool chain_direct(const find_ctx* c) { return c->direct_w && c->x3 && c->fused6; }
 
 // ---- fused chains (mlp_fused.h): one launch takes every 32-row tile through a list of layers
 struct Chain {
@@ -514,6 +529,7 @@ struct Chain {
 	int nt = 1;             // 32-row blocks per tile (chain_prepare)
 	bool x3 = false;        // runs on fused6_kernel: its weights have been split (chain_prepare)
 	bool prepared = false;
+	int in_dim = 3;         // of the Fourier layer (wmode 2)
 	Chain() { memset(&a, 0, sizeof(a)); }
 	FusedStep& add() { return a.step[a.n_steps++]; }
 	bool full(int more) const { return a.n_steps + more > FUSED_MAX_STEPS; }
@@ -548,7 +564,7 @@ static int chain_prepare(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStr
 			const FusedStep& st = ch.a.step[i];
 			if (st.kind != FS_GEMM) continue;
 			const int n = 2 * st.nchunk;
-			sa.job[sa.njobs++] = SplitWJob{st.w, st.ldw, n, sa.total};
+			sa.job[sa.njobs++] = SplitWJob{st.w, st.ldw, n, sa.total, st.wmode, ch.a.pe, ch.in_dim};
 			sa.total += n;
 			maxn = std::max(maxn, n);
 		}
@@ -561,6 +577,9 @@ static int chain_prepare(find_ctx* c, Chain& ch, int64_t V, int64_t feet, hipStr
 			ch.x3 = true;
 		}
 	}
+	if (!ch.x3)
+		for (int i = 0; i < ch.a.n_steps; ++i)
+			FIND_REQUIRE(ch.a.step[i].kind != FS_GEMM || ch.a.step[i].wmode == 0, "find_mlp: a chain with weights in model order did not get its bf16x3 kernel (chain_direct and chain_prepare disagree)");
 	return FIND_OK;
 }
 
@@ -650,8 +669,12 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
 	note_act16(c, w.fbd, a16);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
 
-	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers
-	{
+	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers.  Not for a bf16x3 chain that carries the
+	// whole call (or everything up to the heads' broadcast first layers): its weight split reads the model's tensors directly (round 6: this
+	// launch sat in front of both MLP passes of a training step, 8 - 20 us each on the critical path)
+	const bool fused_early = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	const bool direct = fused_early && chain_direct(c);
+	if (!direct) {
 		RepackArgs ra;
 		memset(&ra, 0, sizeof(ra));
 		ra.njobs = 3;
@@ -677,13 +700,18 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	FIND_LAUNCH_CHECK("latent_bias_kernel");
 
 	// 3 (+ 4, 5 for small calls). trunk (model.py:421-426); layer 0 generates the Fourier features on the fly
-	const bool fused = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	const bool fused = fused_early;
 	const bool fused_heads = fused && !(d.shared && n_feet > 1);   // per-foot rows: the heads are as small as the trunk
 	if (fused) {
 		Chain ch;
-		ch.a.pos = pos; ch.a.pos_foot_stride = V * 3; ch.a.Bm = p->B; ch.a.pe = p->pe_size;
+		ch.a.pos = pos; ch.a.pos_foot_stride = V * 3; ch.a.Bm = p->B; ch.a.pe = p->pe_size; ch.in_dim = p->in_dim;
+		const float* const wd0 = direct ? p->disp_w[0] : w.wd0;
+		const float* const wc0 = direct ? p->col_w[0] : w.wc0;
+		const int ldd0 = direct ? ld_d0 : W, ldc0 = direct ? ld_c0 : W;
 		{
-			FusedStep& s0 = ch.gemm(w.w0p, KP0, (d.nchunk0 + 1) & ~1);   // even chunk counts (the padding columns of w0p are zeros)
+			// even chunk counts (the padding columns of w0p are zeros; wmode 2 reads them as zeros)
+			FusedStep& s0 = direct ? ch.gemm(p->trunk_w[0], p->in_dim + 2 * p->pe_size, (d.nchunk0 + 1) & ~1) : ch.gemm(w.w0p, KP0, (d.nchunk0 + 1) & ~1);
+			s0.wmode = direct ? 2 : 0;
 			s0.src_kind = FS_SRC_PE; s0.relu = 1; s0.bias = p->trunk_b[0]; s0.dst = w.H[0]; s0.to_lds = 1;
 		}
 		for (int i = 1; i < p->n_trunk; ++i) {
@@ -693,12 +721,12 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		const float* hlast = w.H[p->n_trunk - 1];
 		if (!fused_heads) {
 			// shared template: the first layer of each head is H W0^T on the V template rows (bias + ReLU are broadcast per foot below)
-			if (disp) { FusedStep& st = ch.gemm(w.wd0, W, W / KC); st.dst = w.hp; }
-			if (col) { FusedStep& st = ch.gemm(w.wc0, W, W / KC); st.dst = disp ? w.hp2 : w.hp; }
+			if (disp) { FusedStep& st = ch.gemm(wd0, ldd0, W / KC); st.dst = w.hp; }
+			if (col) { FusedStep& st = ch.gemm(wc0, ldc0, W / KC); st.dst = disp ? w.hp2 : w.hp; }
 		} else {
-			auto head = [&](int which, float* const* act, int nl, const float* w0, const float* b0, int64_t bstride, const float* const* hw, const float* const* hb,
+			auto head = [&](int which, float* const* act, int nl, const float* w0, int ld0, const float* b0, int64_t bstride, const float* const* hw, const float* const* hb,
 							float* z, float* out, bool reload) {
-				FusedStep& f0 = ch.gemm(w0, W, W / KC, reload ? hlast : nullptr);
+				FusedStep& f0 = ch.gemm(w0, ld0, W / KC, reload ? hlast : nullptr);
 				f0.relu = 1; f0.bias = b0; f0.bias_foot_stride = (int)bstride; f0.dst = act[0]; f0.to_lds = 1;
 				for (int i = 1; i < nl; ++i) {
 					FusedStep& st = ch.gemm(hw[i], W, W / KC);
@@ -708,8 +736,8 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				o.kind = FS_OUT; o.w = hw[nl]; o.bias = hb[nl]; o.dst = out; o.dst2 = z; o.head = (unsigned char)which;
 				o.aux = which ? p->avg_col : nullptr;
 			};
-			if (disp) head(0, w.D, p->n_disp, w.wd0, bias_d0, bstride_d, p->disp_w, p->disp_b, w.zd, disp, false);
-			if (col) head(1, w.C, p->n_col, w.wc0, bias_c0, bstride_c, p->col_w, p->col_b, w.zc, col, disp != nullptr);
+			if (disp) head(0, w.D, p->n_disp, wd0, ldd0, bias_d0, bstride_d, p->disp_w, p->disp_b, w.zd, disp, false);
+			if (col) head(1, w.C, p->n_col, wc0, ldc0, bias_c0, bstride_c, p->col_w, p->col_b, w.zc, col, disp != nullptr);
 		}
 		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, w.w6, chain_w6_bytes(p)));
 		if (fused_heads) return FIND_OK;
@@ -1138,11 +1166,11 @@ static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 }
 
 // masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
-static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
+static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, int ldw, int w_tr, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
 	GemmArgs a = gemm_args_zero();
 	a.h16 = h16;
 	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
-	a.w0 = wt; a.ldw = W; a.nchunk = W / KC;
+	a.w0 = wt; a.ldw = ldw; a.w_tr = w_tr; a.nchunk = W / KC;
 	a.mask = mask; a.mask_foot_stride = V * W;
 	a.y = y; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
 	return launch_gemm(c, AMODE_MAT, EPI_MASK, a, feet, s);
@@ -1198,18 +1226,35 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	zero_flush();
 	if (mrc != FIND_OK) return mrc;
 
-	// 1. transposed weights for the dX GEMMs (a frozen network's backward stops at the heads' first layers: only their later layers)
+	// 1. transposed weights for the dX GEMMs (a frozen network's backward stops at the heads' first layers: only their later layers) --
+	// where the kernel that will run the layer cannot read the model's weight itself: bf16x3 chains (split_w_kernel, FusedStep::wmode 1) and
+	// gemm7 (Gemm2Args::w_tr) can, so a bf16x3 training step transposes nothing (round 6: this launch was 10 - 12 us in front of each of the
+	// step's two MLP backward passes)
+	const bool fused_b = use_fused(c, V, d.feet_t) && p->pe_size > 0;
+	const bool small_chain = fused_b && !d.shared;                 // the whole dX chain is one fused launch (also the frozen network's head chains)
+	const bool t_heads = !(small_chain ? chain_direct(c) : gemm7_direct(c, V, n_feet));                 // layers >= 1 of the heads
+	const bool t_trunk = !(fused_b ? chain_direct(c) : gemm7_direct(c, V, d.feet_t));                   // trunk layers >= 1
+	const bool t_first = !(fused_b && chain_direct(c));                                                  // the heads' first layers (two-operand sum: gemm3 outside a chain)
+	struct WT { const float* w; int ld; int tr; };
+	auto wt_of = [&](bool need_t, const float* orig, int ld_orig, const float* transposed) -> WT { return need_t ? WT{transposed, W, 0} : WT{orig, ld_orig, 1}; };
+	auto wt_D = [&](int l) -> WT { return l == 0 ? wt_of(t_first, p->disp_w[0], ld_d0, b.Dt[0]) : wt_of(t_heads, p->disp_w[l], W, b.Dt[l]); };
+	auto wt_C = [&](int l) -> WT { return l == 0 ? wt_of(t_first, p->col_w[0], ld_c0, b.Ct[0]) : wt_of(t_heads, p->col_w[l], W, b.Ct[l]); };
+	auto wt_T = [&](int l) -> WT { return wt_of(t_trunk, p->trunk_w[l], W, b.Tt[l]); };
 	{
 		RepackArgs ra;
 		memset(&ra, 0, sizeof(ra));
 		int n = 0;
 		if (!frozen) {
-			for (int i = 1; i < p->n_trunk; ++i) ra.job[n++] = RepackJob{p->trunk_w[i], b.Tt[i], W, W, W, 0, W, 1, 0, 0};
-			ra.job[n++] = RepackJob{p->disp_w[0], b.Dt[0], W, W, ld_d0, 0, W, 1, 0, 0};
-			ra.job[n++] = RepackJob{p->col_w[0], b.Ct[0], W, W, ld_c0, 0, W, 1, 0, 0};
+			if (t_trunk) for (int i = 1; i < p->n_trunk; ++i) ra.job[n++] = RepackJob{p->trunk_w[i], b.Tt[i], W, W, W, 0, W, 1, 0, 0};
+			if (t_first) {
+				ra.job[n++] = RepackJob{p->disp_w[0], b.Dt[0], W, W, ld_d0, 0, W, 1, 0, 0};
+				ra.job[n++] = RepackJob{p->col_w[0], b.Ct[0], W, W, ld_c0, 0, W, 1, 0, 0};
+			}
 		}
-		for (int i = 1; i < p->n_disp; ++i) ra.job[n++] = RepackJob{p->disp_w[i], b.Dt[i], W, W, W, 0, W, 1, 0, 0};
-		for (int i = 1; i < p->n_col; ++i) ra.job[n++] = RepackJob{p->col_w[i], b.Ct[i], W, W, W, 0, W, 1, 0, 0};
+		if (t_heads) {
+			for (int i = 1; i < p->n_disp; ++i) ra.job[n++] = RepackJob{p->disp_w[i], b.Dt[i], W, W, W, 0, W, 1, 0, 0};
+			for (int i = 1; i < p->n_col; ++i) ra.job[n++] = RepackJob{p->col_w[i], b.Ct[i], W, W, W, 0, W, 1, 0, 0};
+		}
 		ra.njobs = n;
 		if (n > 0) hipLaunchKernelGGL(repack_kernel, dim3(64, n), dim3(256), 0, s, ra);
 		FIND_LAUNCH_CHECK("repack_kernel(T)");
@@ -1237,7 +1282,12 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		hr.dw[0] = act_d ? g->disp_w[p->n_disp] : nullptr; hr.db[0] = g->disp_b[p->n_disp];
 		hr.dw[1] = act_c ? g->col_w[p->n_col] : nullptr; hr.db[1] = g->col_b[p->n_col];
 		hr.nblk = b.nblk_out;
-		if (!frozen) hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(1024), 0, s, hr);
+		// (the 3-wide layers' dW / db feed nothing of the dX chain: their reduce goes to a side stream like every other weight gradient --
+		// it used to sit between head_out_bwd and the first dX GEMM of both backward passes of a step, 10 - 14 us each)
+		if (!frozen) {
+			fk.fork_to(T2);
+			hipLaunchKernelGGL(head_out_reduce_kernel, dim3(12, 2), dim3(1024), 0, fk.stream(T2), hr);
+		}
 		FIND_LAUNCH_CHECK("head_out_bwd");
 	}
 
@@ -1249,17 +1299,20 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	// put together HERE, so that its weights are split (chain_prepare) before the large kernels fill the chip.
 	Chain tch;
 	if (fused && !frozen && d.shared) {
-		const float* Wt[2]; int nb = 0;
-		if (act_d) Wt[nb++] = b.Dt[0];
-		if (act_c) Wt[nb++] = b.Ct[0];
+		WT Wt[2]; int nb = 0;
+		if (act_d) Wt[nb++] = wt_D(0);
+		if (act_c) Wt[nb++] = wt_C(0);
 		for (int i = 0; i < nb; ++i) {
-			FusedStep& st = tch.gemm(Wt[i], W, W / KC, hl /* patched below: the head's foot-summed first-layer dZ */);
+			FusedStep& st = tch.gemm(Wt[i].w, Wt[i].ld, W / KC, hl /* patched below: the head's foot-summed first-layer dZ */);
+			st.wmode = (unsigned char)Wt[i].tr;
 			st.accum = i > 0;
 			if (i + 1 < nb) { st.keep = 1; continue; }
 			st.mask = 1; st.aux = hl; st.dst = b.dzT[0]; st.to_lds = 1;
 		}
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			FusedStep& st = tch.gemm(b.Tt[l], W, W / KC);
+			const WT t = wt_T(l);
+			FusedStep& st = tch.gemm(t.w, t.ld, W / KC);
+			st.wmode = (unsigned char)t.tr;
 			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[p->n_trunk - l]; st.to_lds = 1;
 		}
 		FIND_TRY(chain_prepare(c, tch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
@@ -1273,19 +1326,21 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		if (fused && !d.shared) {
 			Chain ch;
 			int nsteps = 0;
-			auto head_chain = [&](int nl, float* const* act, float* const* dzbuf, float* const* wt, int& cur) {
+			auto head_chain = [&](int nl, float* const* act, float* const* dzbuf, bool colour, int& cur) {
 				for (int l = nl - 1; l >= 1; --l) {
-					FusedStep& st = ch.gemm(wt[l], W, W / KC, cur == 0 ? dzbuf[0] : nullptr);
+					const WT t = colour ? wt_C(l) : wt_D(l);
+					FusedStep& st = ch.gemm(t.w, t.ld, W / KC, cur == 0 ? dzbuf[0] : nullptr);
+					st.wmode = (unsigned char)t.tr;
 					st.mask = 1; st.aux = act[l - 1]; st.dst = dzbuf[cur + 1]; st.to_lds = 1;
 					cur += 1; nsteps += 1;
 				}
 			};
-			if (want_c) head_chain(p->n_col, w.C, b.dzC, b.Ct, cc);
-			if (want_d) head_chain(p->n_disp, w.D, b.dzD, b.Dt, cd);
+			if (want_c) head_chain(p->n_col, w.C, b.dzC, true, cc);
+			if (want_d) head_chain(p->n_disp, w.D, b.dzD, false, cd);
 			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		} else {
-			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzD[cd], b.Dt[l], w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16)); cd += 1; }
-			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { FIND_TRY(linear_bwd_dx(c, b.dzC[cc], b.Ct[l], w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16)); cc += 1; }
+			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { const WT t = wt_D(l); FIND_TRY(linear_bwd_dx(c, b.dzD[cd], t.w, t.ld, t.tr, w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16)); cd += 1; }
+			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { const WT t = wt_C(l); FIND_TRY(linear_bwd_dx(c, b.dzC[cc], t.w, t.ld, t.tr, w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16)); cc += 1; }
 		}
 		struct Job { const float* dz; float* ps; float* S; const float* w0; int ld0; const float* lat; int L; float* glat; };
 		const Job jobs[2] = {{b.dzD[cd], b.pS, b.Sd, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, g->lat_disp},
@@ -1307,22 +1362,25 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		// side streams (round-robin, one slab set per stream)
 		Chain ch;
 		int cd2 = 0, cc2 = 0;
-		auto head_chain = [&](int nl, float* const* act, float* const* dzbuf, float* const* wt, int& cur) {
+		auto head_chain = [&](int nl, float* const* act, float* const* dzbuf, bool colour, int& cur) {
 			for (int l = nl - 1; l >= 1; --l) {
-				FusedStep& st = ch.gemm(wt[l], W, W / KC, cur == 0 ? dzbuf[0] : nullptr);
+				const WT t = colour ? wt_C(l) : wt_D(l);
+				FusedStep& st = ch.gemm(t.w, t.ld, W / KC, cur == 0 ? dzbuf[0] : nullptr);
+				st.wmode = (unsigned char)t.tr;
 				st.mask = 1; st.aux = act[l - 1]; st.dst = dzbuf[cur + 1]; st.to_lds = 1;
 				cur += 1;
 			}
 		};
-		if (act_c) head_chain(p->n_col, w.C, b.dzC, b.Ct, cc2);
-		if (act_d) head_chain(p->n_disp, w.D, b.dzD, b.Dt, cd2);
+		if (act_c) head_chain(p->n_col, w.C, b.dzC, true, cc2);
+		if (act_d) head_chain(p->n_disp, w.D, b.dzD, false, cd2);
 		{
 			// gradient wrt the trunk output: both heads summed in one accumulator, then masked by the trunk's last activation
-			const float* A[2]; const float* Wt[2]; int nb = 0;
-			if (act_d) { A[nb] = b.dzD[cd2]; Wt[nb] = b.Dt[0]; ++nb; }
-			if (act_c) { A[nb] = b.dzC[cc2]; Wt[nb] = b.Ct[0]; ++nb; }
+			const float* A[2]; WT Wt[2]; int nb = 0;
+			if (act_d) { A[nb] = b.dzD[cd2]; Wt[nb] = wt_D(0); ++nb; }
+			if (act_c) { A[nb] = b.dzC[cc2]; Wt[nb] = wt_C(0); ++nb; }
 			for (int i = 0; i < nb; ++i) {
-				FusedStep& st = ch.gemm(Wt[i], W, W / KC, A[i]);
+				FusedStep& st = ch.gemm(Wt[i].w, Wt[i].ld, W / KC, A[i]);
+				st.wmode = (unsigned char)Wt[i].tr;
 				st.accum = i > 0;
 				if (i + 1 < nb) { st.keep = 1; continue; }
 				st.mask = 1; st.aux = hl; st.dst = b.dzT[0]; st.to_lds = 1;
@@ -1330,7 +1388,9 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		}
 		int ct2 = 0;
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
-			FusedStep& st = ch.gemm(b.Tt[l], W, W / KC);
+			const WT t = wt_T(l);
+			FusedStep& st = ch.gemm(t.w, t.ld, W / KC);
+			st.wmode = (unsigned char)t.tr;
 			st.mask = 1; st.aux = w.H[l - 1]; st.dst = b.dzT[ct2 + 1]; st.to_lds = 1;
 			ct2 += 1;
 		}
@@ -1405,7 +1465,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	// the dX chain) goes to the side streams; every layer's dZ has its own buffer, so the dX chain on the caller's stream never waits.
 	int big_toggle = 0;
 	hipEvent_t set_free[2] = {nullptr, nullptr};   // fires when the slab set's previous reduce (on R) has read it
-	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, float* const* wt, float* const* gw, float* const* gb,
+	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, bool colour, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
 		for (int l = nl - 1; l >= 1; --l) {
 			fk.fork_to(Q);
@@ -1424,7 +1484,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			} else {
 				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16));
 			}
-			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], wt[l], act[l - 1], dzbuf[cur + 1], V, n_feet, s, a16));
+			const WT t = colour ? wt_C(l) : wt_D(l);
+			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, act[l - 1], dzbuf[cur + 1], V, n_feet, s, a16));
 			cur += 1;
 		}
 		float* db_late = nullptr;
@@ -1460,8 +1521,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		}
 		return FIND_OK;
 	};
-	if (act_d) FIND_TRY(head_bwd(p->n_disp, w.D, b.dzD, cd, b.Dt, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS, T1));
-	if (act_c) FIND_TRY(head_bwd(p->n_col, w.C, b.dzC, cc, b.Ct, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2, T2));
+	if (act_d) FIND_TRY(head_bwd(p->n_disp, w.D, b.dzD, cd, false, g->disp_w, g->disp_b, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, b.Sd, g->lat_disp, b.zsD, b.pS, T1));
+	if (act_c) FIND_TRY(head_bwd(p->n_col, w.C, b.dzC, cc, true, g->col_w, g->col_b, p->col_w[0], ld_c0, lat_col, p->lat_col, b.Sc, g->lat_col, b.zsC, b.pS2, T2));
 
 	// 4 + 5.  gradient wrt the trunk output -- both heads (and, for a shared trunk, every foot) summed in the K loop -- and the trunk's
 	// dX chain.  With few trunk rows (the shared template) all of it is one fused launch; the weight gradients follow on T1 / T2.
@@ -1515,7 +1576,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			bk.pw = b.pw_t[k]; bk.pb = b.pb_t[k];
 			fk.fork_to(k);
 			FIND_TRY(weight_grad(c, &fk, b.dzT[ct], w.H[l - 1], V * W, nullptr, 0, p, 1, d.feet_t, V, bk, g->trunk_w[l], W, W, 0, g->trunk_b[l], nullptr, fk.stream(k)));
-			FIND_TRY(linear_bwd_dx(c, b.dzT[ct], b.Tt[l], w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s));
+			const WT t = wt_T(l);
+			FIND_TRY(linear_bwd_dx(c, b.dzT[ct], t.w, t.ld, t.tr, w.H[l - 1], b.dzT[ct + 1], V, d.feet_t, s));
 			ct += 1;
 		}
 	}
@@ -1843,7 +1905,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 

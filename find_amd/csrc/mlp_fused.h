@@ -52,6 +52,9 @@ struct FusedStep {
 	unsigned char accum;  // 1: start from the previous step's accumulators
 	unsigned char to_lds; // 1: the result becomes the X tile of the next step
 	unsigned char head;   // OUT: 0 = displacement (0.1 tanh), 1 = colour (0.5 (1 + tanh))
+	unsigned char wmode;  // GEMM, bf16x3 chains only (split_w_kernel reads the weights once per call anyway): 0 = w as described above; 1 = w is the
+	                      // layer's weight as the MODEL holds it and the step multiplies by its transpose (a dX step: W_eff[n][k] = w[k * ldw + n]);
+	                      // 2 = w is base.0.weight in the reference's column order, read through the padded Fourier order (pe_col_to_orig)
 };
 
 constexpr int FUSED_MAX_STEPS = 26;

@@ -32,7 +32,7 @@ constexpr int fused6_lds(int nt) { return 3 * f6_plane(nt) + 3 * 256 * 4; }   //
 constexpr int64_t F6_STEP_BYTES = 3 * 64 * 16;                // one wave's operands of one 16-k step: three planes x 1 KB
 
 // ---- weights -> fragment-ordered bf16 planes (once per chain launch)
-struct SplitWJob { const float* w; int ldw; int nsteps; int cum; };
+struct SplitWJob { const float* w; int ldw; int nsteps; int cum; int mode; int pe; int in_dim; };   // mode: FusedStep::wmode
 struct SplitWArgs {
 	SplitWJob job[FUSED_MAX_STEPS];
 	int njobs;
@@ -46,9 +46,24 @@ __global__ __launch_bounds__(256) void split_w_kernel(const SplitWArgs g) {
 	const int lane = idx & 63, s = (idx >> 6) % j.nsteps, nb = (idx >> 6) / j.nsteps;
 	if (nb >= 8) return;
 	// MFMA row operand of step s: lane (n = lane & 31, half = lane >> 5) holds W[32 nb + n][16 s + 8 half .. + 8]
-	const float4* src = reinterpret_cast<const float4*>(j.w + (int64_t)(nb * 32 + (lane & 31)) * j.ldw + s * 16 + (lane >> 5) * 8);
+	const int n = nb * 32 + (lane & 31), k0 = s * 16 + (lane >> 5) * 8;
+	float4 lo, hi;
+	if (j.mode == 0) {
+		const float4* src = reinterpret_cast<const float4*>(j.w + (int64_t)n * j.ldw + k0);
+		lo = src[0]; hi = src[1];
+	} else {
+		// the weights as the model holds them: transposed (a dX step; the 32 lanes of a half read 32 consecutive floats of a row) or through
+		// the Fourier layer's padded column order -- what repack_kernel used to materialise first, one launch per call on the step's critical path
+		float v[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			if (j.mode == 1) v[i] = j.w[(int64_t)(k0 + i) * j.ldw + n];
+			else { const int ko = pe_col_to_orig(k0 + i, j.pe, j.in_dim); v[i] = ko >= 0 ? j.w[(int64_t)n * j.ldw + ko] : 0.f; }
+		}
+		lo = make_float4(v[0], v[1], v[2], v[3]); hi = make_float4(v[4], v[5], v[6], v[7]);
+	}
 	bf16x8 p1, p2, p3;
-	split3(src[0], src[1], p1, p2, p3);
+	split3(lo, hi, p1, p2, p3);
 	u32x4* d = g.dst + ((int64_t)nb * g.total + j.cum + s) * 192 + lane;
 	d[0] = __builtin_bit_cast(u32x4, p1);
 	d[64] = __builtin_bit_cast(u32x4, p2);

@@ -36,6 +36,7 @@ struct Gemm2Args {
 	const float* w0;        // (256, ldw) K-contiguous weight of segment 0
 	const float* w1;
 	int ldw;
+	int w_tr;               // gemm7 only: w0 is the layer's weight as the model holds it, the launch multiplies by its transpose (W_eff[n][k] = w0[k * ldw + n])
 	int nchunk;             // 32-wide K chunks per segment
 	const float* bias;      // EPI_BIAS_RELU
 	int64_t bias_foot_stride;

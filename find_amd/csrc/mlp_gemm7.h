@@ -58,9 +58,18 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	bf16x8 B1[8], B2[8], B3[8];
 	{
 		const float4* wrow = reinterpret_cast<const float4*>(g.w0 + (int64_t)(col0 + i16) * g.ldw + h4 * 8);
+		const float* wcol = g.w0 + (int64_t)(h4 * 8) * g.ldw + col0 + i16;   // (w_tr: the dX launches read the model's weight itself -- no transposed copy)
 #pragma unroll
 		for (int s = 0; s < 8; ++s) {
-			split3(wrow[s * 8], wrow[s * 8 + 1], B1[s], B2[s], B3[s]);
+			float4 lo, hi;
+			if (g.w_tr) {
+				const float* q = wcol + (int64_t)(s * 32) * g.ldw;
+				lo = make_float4(q[0], q[g.ldw], q[2 * (int64_t)g.ldw], q[3 * (int64_t)g.ldw]);
+				hi = make_float4(q[4 * (int64_t)g.ldw], q[5 * (int64_t)g.ldw], q[6 * (int64_t)g.ldw], q[7 * (int64_t)g.ldw]);
+			} else {
+				lo = wrow[s * 8]; hi = wrow[s * 8 + 1];
+			}
+			split3(lo, hi, B1[s], B2[s], B3[s]);
 			asm volatile("" : "+a"(B1[s]));
 			asm volatile("" : "+a"(B2[s]));
 			asm volatile("" : "+a"(B3[s]));

@@ -81,6 +81,7 @@ struct GemmArgs {
 	const float* w0;        // (256, ldw), K contiguous
 	const float* w1;
 	int ldw;
+	int w_tr;               // host side (launch_gemm): w0 is untransposed and the launch goes to gemm7, which reads it transposed (linear_bwd_dx)
 	int nchunk;             // 32-wide K chunks per segment
 	const float* bias;      // EPI_BIAS_RELU: (.., 256)
 	int64_t bias_foot_stride;

@@ -64,14 +64,17 @@ class GradBucket:
 		if not early:
 			self.n_early = 0
 		self._early = None      # (work, divisor) of the prefix collective issued inside this step's backward
-		self._early_void = False   # that collective was overtaken (a second backward, a stale step): its result is dropped, the prefix travels again
-		self._stage = None      # the prefix is averaged in a COPY: the arena (= the live .grad tensors) is only written at wait(), when the
-		                        # step has shown that nothing else touched those gradients in between
 		self._task = None       # autograd graph task the `taken` flags belong to
 		self._hook = None
 		self.early_issued = 0   # steps in which the prefix went out early (diagnostics / tests)
 		self.early_dropped = 0  # early collectives whose result had to be dropped (diagnostics / tests)
 		self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+		# (per-slot constants of take(): it runs once per gradient tensor and backward pass -- 40 times per FIND step -- on the host's critical path)
+		self._shapes = [tuple(p.shape) for p in self.params]
+		self._strides = [tuple(p.contiguous().stride()) if p.dim() else () for p in self.params]
+		self._ptrs = [self.flat.data_ptr() + 4 * o for o in self.offsets]
+		from . import functional as _fn
+		self._task_id = _fn._graph_task_id
 		self.views = [self._view(i) for i in range(len(self.params))]
 		self.taken = [False] * len(self.params)
 		self.arena = p0.is_cuda if arena is None else arena
@@ -80,35 +83,45 @@ class GradBucket:
 			functional.register_grad_arena(self, self.params)
 
 	def _view(self, i):
-		p = self.params[i]
-		return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+		return self.flat.as_strided(self._shapes[i], self._strides[i], self.offsets[i])   # (one op: slice + view were two)
 
 	def take(self, i, shape, device):
 		"""Arena request from a backward kernel wrapper: a FRESH view of slot i (autograd adopts a gradient tensor only when nothing
 		else references it), or None when the slot was handed out already in this backward pass or still backs a live .grad."""
-		from . import functional
-		task = functional._graph_task_id()
+		task = self._task_id()
 		if task != self._task:
 			# a new backward() call: the flags of the last one are history (a step that ended without allreduce_() must not leave them set --
 			# the next step's hook would take a stale arena for a complete one); a slot that still backs a live .grad stays refused below
 			self._task = task
 			self.taken = [False] * len(self.params)
-		p = self.params[i]
-		if self.taken[i] or tuple(shape) != tuple(p.shape) or device != self.flat.device:
+			if self._early is not None:
+				# ... and so is an early collective nobody consumed.  It averaged the arena IN PLACE.  If the gradients it averaged are gone
+				# (zero_grad: a step that never called allreduce_()), it is dropped -- behind its completion: this pass's kernels write the
+				# same slots.  If they are still the parameters' .grad, this is a second backward() of the same step (micro-batches): it
+				# would accumulate into gradients that are half-way through a collective -- refused, loudly (ADVICE r5)
+				live = [q for q, v in zip(self.params[:self.n_early_params], self.views[:self.n_early_params]) if q.grad is not None and q.grad.data_ptr() == v.data_ptr()]
+				if live:
+					raise RuntimeError('find_amd.distributed.GradBucket: backward() called again before allreduce_() while the early part of the bucket '
+									   '(arm_early) is being all-reduced: gradient accumulation over several backward passes needs a bucket without `early`')
+				self._early[0].wait()
+				self._early = None
+				self.early_dropped += 1
+		if self.taken[i] or shape != self._shapes[i] or device != self.flat.device:
 			return None
-		g = p.grad
-		if g is not None and g.data_ptr() == self.views[i].data_ptr():
+		g = self.params[i].grad
+		if g is not None and g.data_ptr() == self._ptrs[i]:
 			return None
 		self.taken[i] = True
-		return self._view(i)
+		return self.flat.as_strided(self._shapes[i], self._strides[i], self.offsets[i])
 
 	def arm_early(self, trigger):
 		"""Issue the all-reduce of the early prefix when autograd has accumulated `trigger` -- a parameter every backward node that writes an
 		early gradient feeds (FIND: `base[0].weight`, which both MLP passes of a step reach: its AccumulateGrad node runs after the last of
-		them has returned, i.e. behind its last weight-gradient kernel on the stream).  The collective reads the arena, not `.grad`, and
-		averages a COPY of the prefix: it goes out only if every early slot was handed to a backward kernel in this pass (else the prefix
-		travels with the rest, as before), and its result reaches the gradients in wait() only if allreduce_() finds every early .grad still
-		being its arena slot and no second backward() in between -- otherwise it is dropped and the prefix travels with the rest."""
+		them has returned, i.e. behind its last weight-gradient kernel on the stream).  The collective averages the arena prefix in place: it
+		goes out only if every early slot was handed to a backward kernel in this pass and the trigger's .grad IS its slot (else the prefix
+		travels with the rest, as before).  allreduce_() checks that every early .grad still is its slot -- a pass that could not fold its
+		gradients into the arena leaves them elsewhere: the prefix then travels again, from the real gradients --; a step that never reaches
+		allreduce_() has its early collective dropped by the next backward, and a second backward() of the same step is refused (take())."""
 		if self.n_early == 0 or self._hook is not None:
 			return
 		trigger._find_hooks_are_stream_safe = True   # (find_amd.functional: this hook joins deferred weight-gradient work itself before it reads the arena, so deferred joins stay allowed)
@@ -117,12 +130,7 @@ class GradBucket:
 		def fire(_p):
 			if not (dist.is_available() and dist.is_initialized()):
 				return
-			if self._early is not None:
-				# an early collective nobody consumed: a second backward() before allreduce_() (micro-batches) or a step that never called
-				# allreduce_() -- what it averaged is not what the gradients are now
-				self._early_void = True
-				return
-			if not all(self.taken[:self.n_early_params]):
+			if self._early is not None or not all(self.taken[:self.n_early_params]):
 				return
 			g = trigger.grad
 			if g is None or g.data_ptr() != self.views[t_index].data_ptr():
@@ -138,13 +146,9 @@ class GradBucket:
 				# parked slots on THAT stream and reports no gradient, so autograd has not ordered this hook behind it
 				for s in functional._CROSS_STREAMS:
 					torch.cuda.current_stream(s.device).wait_stream(s)
-			if self._stage is None:
-				self._stage = torch.empty(self.n_early, dtype=torch.float32, device=self.flat.device)
-			self._stage.copy_(self.flat[:self.n_early])
 			avg = dist.get_backend(self.group) == 'nccl'
-			work = dist.all_reduce(self._stage, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+			work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
 			self._early = (work, None if avg else dist.get_world_size(self.group))
-			self._early_void = False
 			self.early_issued += 1
 		self._hook = trigger.register_post_accumulate_grad_hook(fire)
 
@@ -165,17 +169,16 @@ class GradBucket:
 		self._task = None
 		self._pending = None
 		early, self._early = self._early, None
-		void, self._early_void = self._early_void, False
 		if not (dist.is_available() and dist.is_initialized()):
 			return
 		world = dist.get_world_size(self.group)
 		if early is not None:
-			# the prefix is on its way -- valid only if every early gradient still IS its arena slot (a pass that did not fold, a hook that
-			# replaced .grad) and no second backward() ran since it left
-			ok = not void and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
-								  for p, v in zip(self.params[:self.n_early_params], self.views[:self.n_early_params]))
+			# the prefix is on its way -- valid only if every early gradient still IS its arena slot (a pass that did not fold into the
+			# arena, a hook that replaced .grad: the real gradients then sit elsewhere and are copied into the slots below)
+			ok = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+					 for p, v in zip(self.params[:self.n_early_params], self.views[:self.n_early_params]))
 			if not ok:
-				early[0].wait()   # (collectives of a group complete in issue order: finish it, drop what it averaged)
+				early[0].wait()   # (finish it first: the copies below overwrite what it averaged)
 				early = None
 				self.early_dropped += 1
 		missing, src, dst = [], [], []
@@ -206,8 +209,7 @@ class GradBucket:
 		if early is not None:
 			early[0].wait()
 			if early[1] is not None:
-				self._stage.div_(early[1])
-			self.flat[:self.n_early].copy_(self._stage)   # (the early gradients ARE these slots: checked in allreduce_)
+				self.flat[:self.n_early].div_(early[1])
 		if work is not None:
 			work.wait()
 			if div is not None:

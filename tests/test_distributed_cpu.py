@@ -157,49 +157,54 @@ def _early_worker(rank, world, port, q):
 	# A: one backward per step -- the prefix leaves inside the backward, the table's part in allreduce_()
 	_early_loss(ws, table, X, Y, lo, hi).backward()
 	assert bucket.early_issued == 1 and bucket._early is not None
-	local = torch.cat([p.grad.reshape(-1) for p in ws]).clone()   # (the arena is not written before wait(): still this rank's own gradient)
 	bucket.allreduce_(async_op=True)
-	assert torch.equal(torch.cat([p.grad.reshape(-1) for p in ws]), local)
 	bucket.wait()
 	assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params[:4], bucket.views[:4]))   # (the table's gradient is autograd's own tensor: copy path)
 	out['A'] = grads()
-	# B: two backward() calls before allreduce_() (micro-batches): the early collective of the first is overtaken and dropped
+	# B: a second backward() before allreduce_() (micro-batches) would accumulate into gradients that are being all-reduced: refused, loudly
 	for p in params:
 		p.grad = None
 	mid = (lo + hi) // 2
 	(_early_loss(ws, table, X, Y, lo, mid) * 0.5).backward()
-	(_early_loss(ws, table, X, Y, mid, hi) * 0.5).backward()
-	assert bucket.early_issued == 2 and bucket._early_void
-	bucket.allreduce_()
-	assert bucket.early_dropped == 1
-	out['B'] = grads()
-	# C: a step that never calls allreduce_() (its early collective goes stale), then a normal one
-	for p in params:
-		p.grad = None
-	(_early_loss(ws, table, X, Y, lo, hi) * 3.0).backward()
-	assert bucket.early_issued == 3
+	assert bucket.early_issued == 2
+	try:
+		(_early_loss(ws, table, X, Y, mid, hi) * 0.5).backward()
+		raise AssertionError('the second backward() of a step with an early prefix in flight was not refused')
+	except RuntimeError as e:
+		assert 'arm_early' in str(e)
+	# C: ... and that step never calls allreduce_(): its early collective goes stale; the next backward drops it, behind its completion
 	for p in params:
 		p.grad = None
 	_early_loss(ws, table, X, Y, lo, hi).backward()
-	assert bucket.early_issued == 3 and bucket._early_void   # (the stale one is still unconsumed: this pass must not fire, and must not trust it)
+	assert bucket.early_dropped == 1 and bucket.early_issued == 3
 	bucket.allreduce_()
-	assert bucket.early_dropped == 2
 	out['C'] = grads()
-	# D: ... and the step after that takes the early path again
+	# D: the step after that takes the early path again
 	for p in params:
 		p.grad = None
 	_early_loss(ws, table, X, Y, lo, hi).backward()
 	assert bucket.early_issued == 4
 	bucket.allreduce_()
-	assert bucket.early_dropped == 2
+	assert bucket.early_dropped == 1
 	out['D'] = grads()
-	# E: a gradient that is not its arena slot when allreduce_() looks (here: replaced by a clone) voids the early result as well
+	# E: a gradient that is not its arena slot when allreduce_() looks (here: replaced by a clone of the LOCAL gradient, taken before the
+	# collective could touch it -- gloo's work runs on the calling thread's queue: wait first, then restore) makes the prefix travel again
 	for p in params:
 		p.grad = None
+	bucket._hook.remove(); bucket._hook = None      # (take the local gradients without the early collective ...)
 	_early_loss(ws, table, X, Y, lo, hi).backward()
-	ws[2].grad = ws[2].grad.clone()
+	local = [p.grad.clone() for p in ws]
+	for p in params:
+		p.grad = None
+	bucket.taken = [False] * len(bucket.params); bucket._task = None
+	bucket.arm_early(ws[0])                          # (... then the real thing)
+	_early_loss(ws, table, X, Y, lo, hi).backward()
+	assert bucket.early_issued == 5
+	bucket._early[0].wait()
+	for p, g in zip(ws, local):
+		p.grad = g                                   # every early .grad now lives outside the arena, as after a pass that could not fold
 	bucket.allreduce_()
-	assert bucket.early_dropped == 3
+	assert bucket.early_dropped == 2
 	out['E'] = grads()
 	q.put((rank, out))
 	dist.barrier()
@@ -208,8 +213,8 @@ def _early_worker(rank, world, port, q):
 
 def test_early_prefix_equals_one_collective_equals_single_process():
 	"""GradBucket(early=...) + arm_early on gloo, world 2: prefix inside the backward + remainder == the full-batch gradient of one process;
-	the cases ADVICE r5 names (second backward before allreduce_, a step without allreduce_, a .grad that left the arena) drop the early
-	result and still give the right average."""
+	of the cases ADVICE r5 names, a second backward before allreduce_ is refused, a step without allreduce_ has its early collective
+	dropped, a .grad that left the arena makes the prefix travel again -- and the average is right after each."""
 	world = 2
 	ctx = mp.get_context('spawn')
 	q = ctx.Queue()
@@ -226,7 +231,7 @@ def test_early_prefix_equals_one_collective_equals_single_process():
 	X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
 	_early_loss(ws, table, X, Y, 0, 8).backward()   # (no bucket in this process: _grads_like hands out plain tensors)
 	ref = torch.cat([p.grad.reshape(-1) for p in ws + [table]])
-	for case in 'ABCDE':
+	for case in 'ACDE':
 		a, b = torch.from_numpy(res[0][1][case]), torch.from_numpy(res[1][1][case])
 		assert torch.equal(a, b), f'case {case}: the ranks disagree'
 		assert torch.allclose(a, ref, atol=1e-6), (case, (a - ref).abs().max())

@@ -48,6 +48,20 @@ _lib.check(_lib.lib().find_ctx_stream_groups(_lib.ctx(run.dev), _lib.current_str
 print(f'{mode}: hardware-queue groups [caller, Q, T1, T2, R] = {list(g)}', flush=True)
 for rep in range(2):
 	print(f'{mode}: {run.timed(step, steps, 10):.3f} ms/step', flush=True)
+# host enqueue time of a step with an empty queue (is this mode host-bound?)
+if os.environ.get('FIND_DP_HOST', '0') != '0':
+	import time
+	from find_amd.train_utils import backward_on_this_thread
+	with backward_on_this_thread():
+		ts = []
+		for _ in range(40):
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			step()
+			ts.append(time.perf_counter() - t0)
+		torch.cuda.synchronize()
+	ts.sort()
+	print(f'{mode}: host enqueue per step (empty queue): median {ts[len(ts) // 2] * 1e3:.3f} ms, min {ts[0] * 1e3:.3f} ms', flush=True)
 if bucket is not None:
 	print(f'{mode}: the weights\' part of the bucket ({bucket.n_early * 4} of {bucket.numel * 4} bytes) left inside the backward in {bucket.early_issued} steps', flush=True)
 	bucket.close()

@@ -7,6 +7,9 @@ import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 run = bench.Run(1)
 step = bench.train3d_setup(run, bench.N_FEET, bench.N_FEET, stage='net', labels=False, seed=0)['step']
+from find_amd.train_utils import backward_on_this_thread
+_ctx = backward_on_this_thread()   # as bench.Run.timed and Trainer run their loops (FIND_AUTOGRAD_THREADS=1: torch's worker thread)
+_ctx.__enter__()
 for _ in range(40):
 	step()
 ts = []
@@ -30,4 +33,4 @@ for _ in range(steps):
 torch.cuda.synchronize()
 pr.disable()
 print(f'==== by tottime (per step: divide by {steps})')
-pstats.Stats(pr).sort_stats('tottime').print_stats(32)
+pstats.Stats(pr).sort_stats('tottime').print_stats(45)
