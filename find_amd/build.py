@@ -29,8 +29,12 @@ def _deps_mtime():
 	return max(os.path.getmtime(h) for h in hdrs)
 
 
+LAST_COMPILED = []   # objects the last build() call compiled (what a caller may report: __graft_entry__.build)
+
+
 def build(force=False, jobs=4, verbose=True, diag=True):
 	"""Compile every csrc/*.hip for gfx950 and link libfind_hip.so (and, with diag, libfind_hip_diag.so).  Incremental on mtimes."""
+	del LAST_COMPILED[:]
 	lib = _build_one(LIB, OBJDIR, [], force, jobs, verbose)
 	if diag:
 		_build_one(LIB_DIAG, OBJDIR_DIAG, ['-DFIND_DIAG'], force, jobs, verbose)
@@ -59,6 +63,7 @@ def _build_one(LIB, OBJDIR, extra, force, jobs, verbose):
 	if todo:
 		with ThreadPoolExecutor(max_workers=jobs) as ex:
 			list(ex.map(cc, todo))
+		LAST_COMPILED.extend(os.path.relpath(obj, ROOT) for _, obj in todo)
 	if todo or not os.path.exists(LIB):
 		cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
 		if verbose:

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			// The further a wave is into its unit, the lower its priority: the two waves of a SIMD then SHARE the matrix pipe.  (The
 			// arbiter prefers the older wave: without this, wave w ran its k loop at full speed and waited at the barrier -- a quarter of the
 			// kernel's time -- while wave w + 4 ran the rest of its own alone, with every stall of a lone wave exposed.)
-			if (h == 0 && !(g.ablate & 16)) {
+			if (h == 0 && !FIND_ABL(g.ablate, 16)) {   // (the switch exists in the laboratory build only)
 				if (row == 0) __builtin_amdgcn_s_setprio(3);
 				else if (row == 1) __builtin_amdgcn_s_setprio(2);
 				else if (row == 2) __builtin_amdgcn_s_setprio(1);

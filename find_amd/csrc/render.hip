@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterArgs a, const F
 							}
 							++cnt;
 							c_lt += f_pzc < front ? 1 : 0;
-							c_a += (f_pzc >= front) & (f_pzc < front1) ? 1 : 0;
+							c_a += ((f_pzc >= front) & (f_pzc < front1)) ? 1 : 0;
 							c_b += f_pzc >= front1 ? 1 : 0;
 							z_lo = fminf(z_lo, f_pzc); z_hi = fmaxf(z_hi, f_pzc);  // depth range of the candidates (bounds of the radix search)
 						}

@@ -1,7 +1,9 @@
 """torch.autograd binding of the HIP renderer (find_render_fwd / find_render_bwd).  GPU only, no fallback."""
 import atexit
+import contextlib
 import ctypes
 import math
+import os
 import warnings
 
 import torch
@@ -38,10 +40,25 @@ def make_params(image_size=256, faces_per_pixel=100, background=(1., 1., 1.), li
 # that hits either case is REPORTED: the two counters travel to a pinned host slot behind the launch and are looked at when they have
 # arrived -- at the next render call, in check_render_flags(), at an epoch boundary of find_amd.trainer.Trainer, or when the interpreter
 # exits -- so the check costs no synchronisation.  FLAG_POLICY:
-#   'warn'   (default) warnings.warn with the description of the render: a close-up visualisation must not end a training run;
-#   'strict' the same look-up raises RuntimeError (in whichever later call finds the counters);   'async' = 'strict' (rounds 1-2 name)
+#   'strict' (default since round 6: a wrong image is an error) the look-up raises RuntimeError, in whichever later call finds the
+#            counters;   'async' = 'strict' (rounds 1-2 name)
+#   'warn'   warnings.warn with the description of the render -- what find_amd.trainer.Trainer runs its epochs under (flag_policy('warn')):
+#            a close-up visualisation render must not end a training run at an arbitrary later call;
 #   'sync'   wait for the counters and raise in the same call (tests);   'ignore' no bookkeeping at all.
-FLAG_POLICY = 'warn'
+FLAG_POLICY = os.environ.get('FIND_RENDER_FLAG_POLICY', 'strict')
+
+
+@contextlib.contextmanager
+def flag_policy(policy):
+	"""Renders issued inside the block are watched under `policy` (each render carries the policy of its own call to the look-up)."""
+	global FLAG_POLICY
+	if policy not in ('strict', 'async', 'warn', 'sync', 'ignore'):
+		raise ValueError(f'flag_policy: {policy!r}')
+	prev, FLAG_POLICY = FLAG_POLICY, policy
+	try:
+		yield
+	finally:
+		FLAG_POLICY = prev
 _RING = 64
 _pending = []   # (event, slot, description, policy at the time of the render)
 _slots = None   # one pinned int32[_RING][2] buffer, reused: slot i is free when no pending entry holds it

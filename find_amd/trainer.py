@@ -17,6 +17,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
+from . import functional_render as FR
 from .train_utils import backward_on_this_thread, batch_to_device, sample_latent_vectors
 
 
@@ -99,6 +100,9 @@ class Trainer:
 		# accumulation to the stream its node was created on, and a capture that meets a node of another stream (kept alive by any loss
 		# or latent row of an eager step) does not survive hipStreamEndCapture (find_amd.graph.GraphedStep: stream).
 		self._stream = None
+		# what a render that meets an unclipped face or an overfull pixel does inside this Trainer's epochs (functional_render.FLAG_POLICY:
+		# 'strict' everywhere else): warn and go on -- a training run must not end on a close-up visualisation render
+		self.render_flag_policy = 'warn'
 
 	def sample_latent_vectors(self, batch, latent_vectors=None):
 		return sample_latent_vectors(batch, self.latent_vectors_train if latent_vectors is None else latent_vectors)
@@ -140,10 +144,10 @@ class Trainer:
 	def _epoch_done(self):
 		if self._stream is not None:
 			torch.cuda.current_stream(self.device).wait_stream(self._stream)
-		# the render watchdog's counters of this epoch (functional_render.FLAG_POLICY: a warning per bad render by default): the epoch's
-		# losses were read on the host just before, so they have all arrived
-		from . import functional_render as FR
-		FR.check_render_flags(wait=True)
+		# the render watchdog's counters of this epoch (a warning per bad render: Trainer.render_flag_policy; outside a Trainer a bad
+		# render is an error, functional_render.FLAG_POLICY): the epoch's losses were read on the host just before, so they have all arrived
+		with FR.flag_policy(self.render_flag_policy):
+			FR.check_render_flags(wait=True)
 
 	def _graphed_step(self, optims, latent_vectors, model_kwargs):
 		from .graph import GraphedStep
@@ -172,7 +176,7 @@ class Trainer:
 		step_per_epoch = bool(getattr(self.opts, 'step_per_epoch', False))
 		stream = self._step_stream()
 		n_steps = 0
-		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), backward_on_this_thread():
+		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), backward_on_this_thread(), FR.flag_policy(self.render_flag_policy):
 			[o.zero_grad() for o in self.optims]
 			for _ in range(self.n_repeat):
 				for batch in self.train_loader:
@@ -216,7 +220,7 @@ class Trainer:
 		self.last_mode = 'graph' if gs is not None else 'eager'
 		captures0 = self._captures()
 		stream = self._step_stream()
-		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), backward_on_this_thread():
+		with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), backward_on_this_thread(), FR.flag_policy(self.render_flag_policy):
 			for batch in self.val_loader:
 				if gs is not None:
 					loss, loss_dict = gs(batch_to_device(batch, self.device), epoch)

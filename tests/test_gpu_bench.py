@@ -102,3 +102,26 @@ def test_two_rank_bench_path_runs_end_to_end_on_one_gpu():
 	assert 3.4e6 < c['early_prefix_bytes'] < c['bucket_bytes'] and c['steps_with_early_prefix'] >= 3 + 1
 	assert c['distinct_devices'] == 1   # (both ranks share device 0 in this test; the driver's run must show N)
 	assert len(lines[0]) < 4096
+
+
+def test_eight_rank_bench_path_runs_end_to_end_on_one_gpu():
+	"""The driver's scaling bench ends at `--gpus 8`: eight ranks once, all on device 0 over gloo (FIND_BENCH_SHARE_GPU=1) -- the port choice,
+	the store's time-outs with eight children starting at different moments, the broadcast, eight arena buckets, the cross-rank "go on" of
+	the priming phase, MAX-over-ranks timing, one line from rank 0 with a `collective` block that saw eight ranks (the
+	1 -> 8 curve itself is the driver's to measure: eight processes time-slicing one GPU say nothing about throughput)."""
+	env = dict(os.environ, FIND_BENCH_SHARE_GPU='1')
+	for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+		env.pop(k, None)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--no-records', '--no-prime'],
+					   capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr[-3000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith('{')]
+	assert len(lines) == 1, r.stdout[-2000:]
+	d = json.loads(lines[0])
+	assert d['n_gpus'] == 8 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp8'
+	assert abs(d['value'] - 8 * 16 * 6890 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+	c = d['collective']
+	assert c['world_size'] == 8 and len(c['ranks_devices']) == 8 and c['distinct_devices'] == 1
+	assert [x.split(':')[0] for x in c['ranks_devices']] == [str(i) for i in range(8)]
+	assert c['steps_with_early_prefix'] >= 2 + 1
+	assert len(lines[0]) < 4096
