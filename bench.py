@@ -475,7 +475,7 @@ def train3d_workload(n_feet, stage, labels, frozen=False):
 def train3d_cpu(mwl, gt, stage='net', sample_feet=1):
 	"""Oracle composition of the same step (tests/test_gpu_pipeline.py::test_train_3d_loss_set_matches_oracle) on `sample_feet` feet,
 	without the optimiser update."""
-	from oracle import geom_ref, mlp_ref
+	from oracle import compose_ref, geom_ref, mlp_ref
 	gv, gf, gc = gt
 	m = mwl.model
 	nf = sample_feet
@@ -491,20 +491,13 @@ def train3d_cpu(mwl, gt, stage='net', sample_feet=1):
 		return torch.multinomial(areas, n, replacement=True, generator=g), torch.rand(verts.shape[0], n, 2, generator=g)
 
 	def one():
+		# (oracle.compose_ref.train3d_losses: the reference's ModelWithLoss.forward composition, pinned to the reference's own by
+		# tests/test_oracle_pins.py; the draws as PyTorch3D's sampler makes them: multinomial over face areas + uniform (u, v))
 		t0 = time.perf_counter()
-		res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
-		fi, uv = draws(gvc, gfc, 5000)
-		gt_s = geom_ref.sample_points(gvc, gfc, fi, uv)
-		fi, uv = draws(res['verts'].detach(), tf, 5000)
-		pr_s = geom_ref.sample_points(res['verts'], tf, fi, uv)
-		total = geom_ref.chamfer_distance(pr_s, gt_s) * 10000.
+		dr = dict(gt=draws(gvc, gfc, 5000), pred=lambda v: draws(v, tf, 5000))
 		if stage == 'net':
-			total = total + geom_ref.mesh_smoothness(res['verts'], tf) * 1000.
-			fi, uv = draws(gvc, gfc, 1000)
-			tx_p, tx_c = geom_ref.sample_points(gvc, gfc, fi, uv, attr=gcc)
-			col = mlp_ref.mlp_forward(sd, B, tx_p, lat['shapevec'], lat['texvec'], lat['posevec'])['col']
-			mask = (tx_c < 1).any(dim=-1, keepdim=True).expand(-1, -1, 3)
-			total = total + (torch.nn.functional.mse_loss(col, tx_c, reduction='none') * mask).mean()
+			dr['tex'] = draws(gvc, gfc, 1000)
+		total, _ = compose_ref.train3d_losses(sd, B, tv, tf, lat, gvc, gfc, gcc, dr, chamf=True, smooth=stage == 'net', texture=stage == 'net')
 		total.backward()
 		return time.perf_counter() - t0
 

@@ -57,22 +57,12 @@ def test_headline_step_batch16_full_size_matches_oracle():
 		  for k, v in m.state_dict().items()}
 	lat = {k: b[f'{k}_train'].detach().cpu().clone().requires_grad_(True) for k in ('shapevec', 'texvec', 'posevec', 'reg')}
 	B, tv, tf = m.encoder[0]._B, m.template_verts.data.cpu(), m.template_faces.data[0].cpu().long()
-	res = mlp_ref.get_meshes_verts(sd, B, tv, lat['shapevec'], lat['reg'], lat['texvec'], lat['posevec'])
 	gvc, gfc, gcc = gv.cpu(), gf.cpu(), gc.cpu()
-	gt_s = geom_ref.sample_points(gvc, gfc, fi_gt, uv_gt)
-	pr_s = geom_ref.sample_points(res['verts'], tf, fi_pr, uv_pr)
-	n = gvc.shape[0]
-	edges = geom_ref.unique_edges(tf)
-	l_ch = sum(geom_ref.chamfer_distance(pr_s[i:i + 1], gt_s[i:i + 1]) for i in range(n)) / n        # batch 'mean' of per-cloud terms
-	l_sm = sum(geom_ref.mesh_smoothness(res['verts'][i:i + 1], tf, edges) for i in range(n)) / n
-	tx_p, tx_c = geom_ref.sample_points(gvc, gfc, fi_tx, uv_tx, attr=gcc)
-	col = mlp_ref.mlp_forward(sd, B, tx_p, lat['shapevec'], lat['texvec'], lat['posevec'])['col']
-	mask = (tx_c < 1).any(dim=-1, keepdim=True).expand(-1, -1, 3)
-	l_tx = (torch.nn.functional.mse_loss(col, tx_c, reduction='none') * mask).mean()
-	ref = {'loss_chamf': l_ch * 10000., 'loss_smooth': l_sm * 1000., 'loss_tex': l_tx * 1.}   # opts.py:97-99
+	# (oracle.compose_ref.train3d_losses: the composition tests/test_oracle_pins.py holds to the reference's own ModelWithLoss.forward)
+	from oracle import compose_ref
+	rl, ref = compose_ref.train3d_losses(sd, B, tv, tf, lat, gvc, gfc, gcc, dict(gt=(fi_gt, uv_gt), pred=(fi_pr, uv_pr), tex=(fi_tx, uv_tx)), per_foot=True)
 	for k in ref:
 		assert abs(losses[k].item() - ref[k].item()) < TOL * max(1.0, abs(ref[k].item())), (k, losses[k].item(), ref[k].item())
-	rl = sum(ref.values())
 	assert abs(loss.item() - rl.item()) < TOL * max(1.0, abs(rl.item()))
 	rl.backward()
 	worst = {}

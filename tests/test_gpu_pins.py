@@ -115,3 +115,93 @@ def test_reference_checkpoint_on_the_gpu():
 	assert list(a['state_dict']) == list(b['state_dict']) and a['params'] == b['params']
 	for k in a['state_dict']:
 		assert torch.equal(a['state_dict'][k], b['state_dict'][k]), k
+
+
+def test_model_with_loss_equals_the_reference_model_with_loss():
+	"""find_amd.ModelWithLoss.forward on the GPU against what the REFERENCE's ModelWithLoss.forward returned for the same weights, latent tables,
+	scans, sampler draws and flags (tests/golden/make_golden_composition.py ran src/model/model.py:1001-1163 for real, its PyTorch3D calls backed
+	by the oracle): the loss dict -- keys in the reference's order --, the total, gradients of every MLP weight and latent table, for the
+	network-stage flags (Opts.net_train_kwargs), the registration stage with a GT cut-off, a validation step with the z cut-off on both
+	clouds, a scan whose 3-D supervision is withheld (total is the python int 0) and the texture term alone."""
+	import sys
+	sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+	from test_gpu_train3d import FixedDraws
+	from find_amd.model_with_loss import ModelWithLoss
+	from find_amd.opts import Opts
+	from find_amd.structures import Meshes, TexturesVertex
+	from find_amd.train_utils import sample_latent_vectors
+	z = np.load(os.path.join(GOLD, 'composition.npz'))
+	dev = torch.device('cuda')
+	lab = {k[len('labels/'):]: [str(s) for s in z[k]] for k in z.files if k.startswith('labels/')}
+	opts = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True, use_pose_code=True, use_latent_labels=True)
+	mwl = ModelWithLoss(opts=opts, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=3, val_size=3, shapevec_size=100,
+						texvec_size=100, posevec_size=100, template_mesh_loc=None, latent_labels=lab)
+	m = mwl.model
+	m.set_template(torch.from_numpy(z['sd/template_verts'])[0], torch.from_numpy(z['sd/template_faces'])[0])
+	m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}, strict=True)
+	assert torch.equal(m.encoder[0]._B, torch.from_numpy(z['B']))
+	mwl = mwl.to(dev)
+	m = mwl.model
+	gv, gf, gc = (torch.from_numpy(z[f'gt/{k}']).to(dev) for k in ('verts', 'faces', 'colours'))
+	feet, names = [str(s) for s in z['batch/feet']], [str(s) for s in z['batch/names']]
+	feet_val, names_val = [str(s) for s in z['batch/feet_val']], [str(s) for s in z['batch/names_val']]
+	params = dict(mwl.named_parameters())
+	for name in z['cases']:
+		flags = {}
+		for f in z[f'case/{name}/flags']:
+			k, v = str(f).split('=')
+			flags[k] = {'True': True, 'False': False, 'None': None}.get(v, None if v == 'None' else v)
+			if k == 'gt_z_cutoff' and v != 'None':
+				flags[k] = float(v)
+		val = flags.get('is_train', True) is False
+		idx = [int(i) for i in z[f'case/{name}/idx']]
+		ft, nm = (feet_val, names_val) if val else (feet, names)
+		b = dict(mesh=Meshes(gv[idx].contiguous(), gf, TexturesVertex(gc[idx].contiguous())), idx=torch.tensor(idx, device=dev), name=[nm[i] for i in idx],
+				 shape=[ft[i] for i in idx], tex=[ft[i] for i in idx], pose=[nm[i] for i in idx], reg=[nm[i] for i in idx])
+		b.update(sample_latent_vectors(b, m.latent_vectors_val if val else m.latent_vectors_train))
+		n_draws = int(z[f'case/{name}/n_draws'])
+		dr = [(torch.from_numpy(z[f'case/{name}/draw/{i}/face_idx']).to(dev), torch.from_numpy(z[f'case/{name}/draw/{i}/uv']).to(dev)) for i in range(n_draws)]
+		# FixedDraws hands out (GT / Chamfer, prediction / Chamfer, GT / texture); the reference drew in the order GT, prediction, texture
+		if n_draws == 3:
+			draws = dr
+		elif n_draws == 2:
+			draws = [dr[0], dr[1], None]
+		elif n_draws == 1:
+			draws = [None, None, dr[0]]
+		else:
+			draws = [None, None, None]
+		for k, v in (dict(s.split('=') for s in z[f'case/{name}/opts'])).items():
+			setattr(opts, k, int(v))
+		for p in mwl.parameters():
+			p.grad = None
+		try:
+			with FixedDraws(draws):
+				loss, losses = mwl(b, 0, opts, **flags)
+		finally:
+			opts.restrict_3d_n_train = None
+		assert list(losses) == [str(s) for s in z[f'case/{name}/loss_keys']], (name, list(losses))
+		if f'case/{name}/loss_is_python_zero' in z.files:
+			assert not torch.is_tensor(loss) and loss == 0
+			continue
+		for k, v in losses.items():
+			want = float(z[f'case/{name}/losses/{k}'])
+			assert abs(v.item() - want) < TOL * max(1.0, abs(want)), (name, k, v.item(), want)
+		assert abs(loss.item() - float(z[f'case/{name}/loss'])) < TOL * max(1.0, abs(loss.item()))
+		loss.backward()
+		seen = 0
+		for key in z.files:
+			if not key.startswith(f'case/{name}/grad/'):
+				continue
+			k = key[len(f'case/{name}/grad/'):]
+			want = z[key]
+			if np.abs(want).max() == 0:
+				assert params[k].grad is None or params[k].grad.abs().max().item() == 0, (name, k)
+				continue
+			got = params[k].grad.detach().cpu().numpy()
+			got = got if got.size <= 4096 else got.reshape(-1)[::17]
+			assert np.abs(got - want).max() < TOL * max(1e-3, np.abs(want).max()), (name, k, np.abs(got - want).max(), np.abs(want).max())
+			seen += 1
+		assert seen >= 4, (name, seen)
+		have = {k for k, p in params.items() if p.grad is not None and p.grad.abs().max().item() > 0}
+		want_keys = {key[len(f'case/{name}/grad/'):] for key in z.files if key.startswith(f'case/{name}/grad/') and np.abs(z[key]).max() > 0}
+		assert have == want_keys, (name, have ^ want_keys)

@@ -104,3 +104,110 @@ def test_reference_checkpoint_loads():
 	m2 = NeuralDisplacementField.load(path, device='cpu', opts=Opts(dont_load_latents=True), train_size=7, val_size=1)
 	assert m2.shapevec.data.shape == (7, 100) and float(m2.shapevec.data.abs().max()) == 0.0
 	assert torch.equal(m2.base[2].weight, raw['state_dict']['base.2.weight'])
+
+
+# ------------------------------------------------------------------------------------------------ the composition of a training step
+def _composition_case(z, name):
+	"""Inputs of one case of composition.npz for oracle.compose_ref.train3d_losses: state dict with gradients on, this batch's latent rows
+	(gathered from the tables, so that the tables' gradients come out), scans, draws, flags."""
+	val = any(f == 'is_train=False' for f in z[f'case/{name}/flags'])
+	sfx = '_val' if val else ''
+	sd = {k[3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith('sd/')}
+	for k, v in sd.items():
+		if v.is_floating_point() and (k.split('.')[0] in ('base', 'mlp_disp', 'mlp_col') or k.endswith('.data')):
+			v.requires_grad_(True)
+	idx = torch.from_numpy(z[f'case/{name}/idx'])
+	rows = {k: torch.from_numpy(z[f"case/{name}/rows/{k}_{'val' if val else 'train'}"]) for k in ('shapevec', 'texvec', 'posevec', 'reg')}
+	lat = {k: sd[f'{k}{sfx}.data'][rows[k]] for k in rows}
+	flags = dict(f.split('=') for f in z[f'case/{name}/flags'])
+	n_draws = int(z[f'case/{name}/n_draws'])
+	dr = [(torch.from_numpy(z[f'case/{name}/draw/{i}/face_idx']).long(), torch.from_numpy(z[f'case/{name}/draw/{i}/uv'])) for i in range(n_draws)]
+	on = {k: flags.get(k, 'False') == 'True' for k in ('chamf', 'smooth', 'texture')}
+	draws, i = {}, 0
+	if on['chamf'] and n_draws:   # DisplacementLoss samples the GT cloud first, then the prediction (losses.py:63,67); the texture term comes last
+		draws['gt'], draws['pred'] = dr[0], dr[1]
+		i = 2
+	if on['texture'] and n_draws:
+		draws['tex'] = dr[i]
+	gzc = flags.get('gt_z_cutoff', 'None')
+	return dict(sd=sd, lat=lat, idx=idx, draws=draws, on=on, use_z_cutoff=flags.get('use_z_cutoff') == 'True', gt_z_cutoff=None if gzc == 'None' else float(gzc),
+				supervise_3d=n_draws > 0 or not any(on.values()), sfx=sfx)
+
+
+def test_oracle_composition_equals_the_reference_model_with_loss():
+	"""oracle.compose_ref.train3d_losses -- the composition tests/test_gpu_fullsize.py, tests/test_gpu_pipeline.py and bench.py's cpu_baseline
+	check the HIP path against -- held to what the reference's OWN ModelWithLoss.forward / get_meshes_from_batch / loss classes return
+	(tests/golden/make_golden_composition.py ran them: src/model/model.py:1001-1163, :455-504, src/model/losses.py:22-99): losses, total,
+	gradients of every MLP weight and latent table, for the network-stage flags, the registration stage with a GT cut-off, a validation step
+	with the z cut-off on both clouds, a scan whose 3-D supervision is withheld, and a single term."""
+	from oracle import compose_ref
+	z = np.load(os.path.join(GOLD, 'composition.npz'))
+	assert list(z['opts/net_train_kwargs_true']) == ['chamf', 'smooth', 'texture']
+	weights = dict(loss_chamf=float(z['opts/weight_chamf']), loss_smooth=float(z['opts/weight_smooth']), loss_tex=float(z['opts/weight_tex']))
+	assert weights == compose_ref.DEFAULT_WEIGHTS
+	B = torch.from_numpy(z['B'])
+	gv, gf, gc = (torch.from_numpy(z[f'gt/{k}']) for k in ('verts', 'faces', 'colours'))
+	for name in z['cases']:
+		c = _composition_case(z, name)
+		sd = c['sd']
+		total, losses = compose_ref.train3d_losses(sd, B, sd['template_verts'], sd['template_faces'][0], c['lat'], gv[c['idx']], gf, gc[c['idx']], c['draws'],
+													 chamf=c['on']['chamf'], smooth=c['on']['smooth'], texture=c['on']['texture'], use_z_cutoff=c['use_z_cutoff'],
+													 gt_z_cutoff=c['gt_z_cutoff'], supervise_3d=c['supervise_3d'], weights=weights)
+		assert list(losses) == list(z[f'case/{name}/loss_keys']), name
+		if f'case/{name}/loss_is_python_zero' in z.files:
+			assert total == 0 and not torch.is_tensor(total) and not losses   # sum({}.values()): the trainer's `if loss == 0: continue` relies on it
+			continue
+		for k, v in losses.items():
+			want = float(z[f'case/{name}/losses/{k}'])
+			assert abs(v.item() - want) < 2e-5 * max(1.0, abs(want)), (name, k, v.item(), want)
+		assert abs(total.item() - float(z[f'case/{name}/loss'])) < 2e-5 * max(1.0, abs(total.item()))
+		total.backward()
+		seen = 0
+		for key in z.files:
+			if not key.startswith(f'case/{name}/grad/model.'):
+				continue
+			k = key[len(f'case/{name}/grad/model.'):]
+			want = z[key]
+			got = sd[k].grad.numpy()
+			got = got if got.size <= 4096 else got.reshape(-1)[::17]
+			assert np.abs(got - want).max() < 1e-5 * max(1e-3, np.abs(want).max()), (name, k, np.abs(got - want).max(), np.abs(want).max())
+			seen += 1
+		assert seen >= 4, (name, seen)
+		# ... and nothing else got a gradient (e.g. the displacement head under the texture term alone)
+		have = {k for k, v in sd.items() if v.grad is not None and v.grad.abs().max() > 0}
+		want_keys = {key[len(f'case/{name}/grad/model.'):] for key in z.files if key.startswith(f'case/{name}/grad/model.') and np.abs(z[key]).max() > 0}
+		assert have == want_keys, (name, have ^ want_keys)
+
+
+def test_host_side_helpers_equal_the_reference_functions():
+	"""find_amd's copies of the small host-side functions around the step against what the reference's own return (composition.npz):
+	Opts.net_train_kwargs / default weights (src/train/opts.py:97-100,207-215), sample_latent_vectors with label-addressed tables
+	(src/train/trainer.py:29-46), get_pose_code (src/data/dataset.py:88-109)."""
+	from find_amd import dataset as D
+	from find_amd.model import NeuralDisplacementField
+	from find_amd.opts import Opts
+	from find_amd.train_utils import sample_latent_vectors
+	z = np.load(os.path.join(GOLD, 'composition.npz'))
+	opts = Opts(chamf_loss=True, smooth_loss=True, texture_loss=True, use_pose_code=True, use_latent_labels=True)
+	ntk = opts.net_train_kwargs()
+	assert sorted(ntk) == list(z['opts/net_train_kwargs_keys']) and sorted(k for k, v in ntk.items() if v) == list(z['opts/net_train_kwargs_true'])
+	for k in ('weight_chamf', 'weight_smooth', 'weight_tex', 'weight_pix', 'weight_sil'):
+		assert float(getattr(opts, k)) == float(z[f'opts/{k}']), k
+	assert (opts.gt_z_cutoff is None) == bool(z['opts/gt_z_cutoff_is_none']) and opts.num_views == int(z['opts/num_views'])
+	import json
+	lookup = {(int(k) if k.isdigit() else k): v for k, v in json.loads(str(z['pose/lookup_json'])).items()}
+	for i in range(int(z['pose/n'])):
+		names = [str(s) for s in z[f'pose/{i}/names']]
+		np.testing.assert_array_equal(np.asarray(D.get_pose_code(names, dict(POSE_VECTOR=lookup)), np.float64), z[f'pose/{i}/code'])
+	lab = {k[len('labels/'):]: [str(s) for s in z[k]] for k in z.files if k.startswith('labels/')}
+	m = NeuralDisplacementField(template_mesh_loc=None, device='cpu', use_shapevec=True, use_texvec=True, use_posevec=True, train_size=3, val_size=3,
+								shapevec_size=100, texvec_size=100, posevec_size=100, latent_labels=lab)
+	m.set_template(torch.from_numpy(z['sd/template_verts'])[0], torch.from_numpy(z['sd/template_faces'])[0])   # (as Model.load's configure_template: the template sizes the buffers)
+	m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}, strict=True)   # same keys and shapes as the reference's
+	feet, names = [str(s) for s in z['batch/feet']], [str(s) for s in z['batch/names']]
+	idx = [2, 0]
+	b = dict(idx=torch.tensor(idx), name=[names[i] for i in idx], shape=[feet[i] for i in idx], tex=[feet[i] for i in idx], pose=[names[i] for i in idx],
+			 reg=[names[i] for i in idx])
+	got = sample_latent_vectors(b, m.latent_vectors_train)
+	for k in ('shapevec_train', 'texvec_train', 'posevec_train', 'reg_train'):
+		np.testing.assert_array_equal(got[k].detach().numpy(), z[f'slv/{k}'])
