@@ -188,20 +188,26 @@ def test_model_with_loss_equals_the_reference_model_with_loss():
 			assert abs(v.item() - want) < TOL * max(1.0, abs(want)), (name, k, v.item(), want)
 		assert abs(loss.item() - float(z[f'case/{name}/loss'])) < TOL * max(1.0, abs(loss.item()))
 		loss.backward()
-		seen = 0
+		# gradients against the reference's code run in float64 on the same draws (the fixture's yardstick run); the bound is the north star's
+		# 1e-4 of the tensor's largest entry, or twice the distance of the reference's OWN fp32 gradients from those float64 values where that
+		# is larger (it is not, in this fixture: <= 1.5e-5).  The draws are free of nearest-neighbour near-ties (make_golden_composition.py).
+		seen, worst = 0, (0.0, '')
 		for key in z.files:
-			if not key.startswith(f'case/{name}/grad/'):
+			if not key.startswith(f'case/{name}/grad64/'):
 				continue
-			k = key[len(f'case/{name}/grad/'):]
+			k = key[len(f'case/{name}/grad64/'):]
 			want = z[key]
 			if np.abs(want).max() == 0:
 				assert params[k].grad is None or params[k].grad.abs().max().item() == 0, (name, k)
 				continue
-			got = params[k].grad.detach().cpu().numpy()
+			got = params[k].grad.detach().cpu().numpy().astype(np.float64)
 			got = got if got.size <= 4096 else got.reshape(-1)[::17]
-			assert np.abs(got - want).max() < TOL * max(1e-3, np.abs(want).max()), (name, k, np.abs(got - want).max(), np.abs(want).max())
+			err = np.abs(got - want).max() / max(1e-3, np.abs(want).max())
+			assert err < max(TOL, 2.0 * float(z[f'case/{name}/ref_fp32_error/{k}'])), (name, k, err, float(z[f'case/{name}/ref_fp32_error/{k}']))
+			worst = max(worst, (float(err), k))
 			seen += 1
 		assert seen >= 4, (name, seen)
+		print(f'composition case {name}: worst gradient error {worst[0]:.1e} of the tensor maximum ({worst[1]}); nearest-neighbour gap of the draws >= {float(z[f"case/{name}/nn_min_relative_gap"]):.1e}')
 		have = {k for k, p in params.items() if p.grad is not None and p.grad.abs().max().item() > 0}
 		want_keys = {key[len(f'case/{name}/grad/'):] for key in z.files if key.startswith(f'case/{name}/grad/') and np.abs(z[key]).max() > 0}
 		assert have == want_keys, (name, have ^ want_keys)
