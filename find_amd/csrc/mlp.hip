@@ -127,7 +127,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -153,6 +153,7 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int gemm6_min_units = 1024;
 	int gemm7 = 1;                // bf16x3 Linear kernel: 1 = gemm7 (W in registers, activations through LDS), 0 = gemm6 (W planes in LDS; kept for A/B)
+	int dw6_group = 1;            // knob: grouped weight gradients of bf16x3 calls on dw6_group_kernel (0: dw4_group, fp32 MFMA)
 	int direct_w = 1;             // knob: bf16x3 kernels read the model's weights themselves (transposed / Fourier order) instead of repacked copies (0: A/B)
 	int mlp_f16 = 0;              // default precision of calls that do not name one
 	int lds_exclusive = 0;        // 1 = the LDS-DMA ring kernels reserve the whole LDS of their CU: round 1's containment of the co-residence fault, which
@@ -1101,11 +1102,13 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 // Grouped weight gradients of a small call: every 256 x 256 layer's dW / db (and per-foot column sums) in ONE dw2 launch + ONE slab reduce.
 struct WgradGroup {
 	Dw2Group d;
+	Dw6Group d6;        // the same jobs for dw6_group_kernel (bf16x3 calls)
+	bool x3 = false;
 	ReduceWGroup r;
 	int n = 0, nmain = 0;
 	int live_jobs = 0;   // jobs this launch will really carry (a call that skips a head has fewer than the workspace reserves): what the geometry is sized for
 	int64_t feet = 0;
-	WgradGroup() { memset(&d, 0, sizeof(d)); memset(&r, 0, sizeof(r)); }
+	WgradGroup() { memset(&d, 0, sizeof(d)); memset(&d6, 0, sizeof(d6)); memset(&r, 0, sizeof(r)); }
 };
 
 // Splits per foot of a grouped weight gradient.  A workgroup owns a whole 256 x 256 tile over `cps` 16-row chunks (3.4 us of MFMA issue
@@ -1130,8 +1133,10 @@ static void group_geometry(const find_ctx* c, int cpf16, int64_t feet, int jobs,
 
 static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const float* dz, const float* x, int64_t x_foot_stride, int64_t feet, int64_t V,
 						   float* dw, int ld_out, float* db, float* S) {
-	FIND_REQUIRE(G.n < b.grp_jobs && G.n < DW2_MAX_JOBS, "find_mlp_bwd: too many grouped weight gradients");
-	const int cpf16 = (int)(V / 16);
+	FIND_REQUIRE(G.n < b.grp_jobs && G.n < DW2_MAX_JOBS && G.n < DW6_MAX_JOBS, "find_mlp_bwd: too many grouped weight gradients");
+	// bf16x3 calls: dw6_group_kernel (16-row chunks, rows past a foot's end zero-filled by the loads: ceil); the others dw4_group (tail rows folded)
+	G.x3 = c->x3 && c->dw6_group && c->dw_lds_free == 1;
+	const int cpf16 = G.x3 ? (int)cdiv(V, 16) : (int)(V / 16);
 	int spf = 1, cps2 = 1;
 	if (cpf16 > 0) group_geometry(c, cpf16, feet, G.live_jobs > 0 ? G.live_jobs : b.grp_jobs, b.grp_slabs, &spf, &cps2);
 	const int nmain = (int)(feet * spf);
@@ -1141,6 +1146,9 @@ static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const flo
 	Dw2Args& d2 = G.d.job[G.n];
 	d2.dz = dz; d2.dz_foot_stride = V * W; d2.x = x; d2.x_foot_stride = x_foot_stride;
 	d2.chunks_per_foot = cpf16; d2.tail_rows = (int)(V % 16); d2.spf = spf; d2.cps = cps2; d2.pw = pw; d2.pb = (db || S) ? pb : nullptr;
+	Dw3Args& d6 = G.d6.job[G.n];
+	d6.dz = dz; d6.dz_foot_stride = V * W; d6.x = x; d6.x_foot_stride = x_foot_stride;
+	d6.V = (int)V; d6.chunks_per_foot = cpf16; d6.spf = spf; d6.cps = cps2; d6.pw = pw; d6.pb = d2.pb;
 	ReduceWArgs& r = G.r.job[G.n];
 	r.pw = pw; r.nsplit = nmain; r.Kp = 256; r.out = dw; r.ld_out = ld_out; r.K_valid = W;
 	r.pb = d2.pb; r.n_feet = (int)feet; r.spf = spf; r.db = db; r.S = S;
@@ -1152,7 +1160,11 @@ static int wgrad_group_add(find_ctx* c, WgradGroup& G, const BwdWs& b, const flo
 
 static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 	if (G.n == 0) return FIND_OK;
-	if (c->dw_lds_free == 1 || c->dw_lds_free == 2) {
+	if (G.x3) {
+		int lds = 0;
+		FIND_TRY(prepare_kernel(c, K_DW6G, &dw6_group_kernel, DW6_LDS, &lds));
+		hipLaunchKernelGGL(dw6_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(256), lds, s, G.d6);
+	} else if (c->dw_lds_free == 1 || c->dw_lds_free == 2) {
 		hipLaunchKernelGGL(dw4_group_kernel, dim3((unsigned)G.nmain, (unsigned)G.n), dim3(512), 0, s, G.d);
 	} else {
 		int lds = 0;
@@ -1905,7 +1917,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 

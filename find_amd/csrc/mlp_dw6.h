@@ -32,8 +32,7 @@ constexpr int DW6_OPER = 3 * DW6_PLANE;         // 24 KB
 constexpr int DW6_BUF = 2 * DW6_OPER;           // dZ then X: 48 KB
 constexpr int DW6_LDS = 2 * DW6_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 102 400 B
 
-__global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
-	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 256 fp32 accumulators in AGPRs + ~150 VGPRs: more than 256 registers (see the macro)
+__device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* red = reinterpret_cast<float*>(smem + 2 * DW6_BUF);
 
@@ -42,7 +41,6 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wn = wave >> 1, wk = wave & 1;
 	const int li = lane & 31, fh = lane >> 5;
-	const int split = blockIdx.x;
 	const int foot = split / g.spf;
 	const int sidx = split - foot * g.spf;
 	const int q0 = sidx * g.cps;
@@ -203,6 +201,26 @@ __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 		__syncthreads();
 		pb[tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
 	}
+}
+
+__global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
+	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 256 fp32 accumulators in AGPRs + ~150 VGPRs: more than 256 registers (see the macro)
+	dw6_body(g, blockIdx.x);
+}
+
+// Several weight gradients of the same geometry in ONE launch (blockIdx.y = job), as dw4_group_kernel: the 256 x 256 layers of a small call
+// (the texture samples' seven, the shared trunk's four) in bf16x3 arithmetic -- 6/16 of dw4_group's matrix-pipe time, which is what counts
+// for kernels that run BESIDE the step's other matrix-pipe work (round 6; fp32 dw4_group: `dw_lds_free` path of the other precisions).
+constexpr int DW6_MAX_JOBS = 24;
+struct Dw6Group { Dw3Args job[DW6_MAX_JOBS]; };
+__global__ __launch_bounds__(256, 1) void dw6_group_kernel(const Dw6Group grp) {
+	FIND_CLAIM_WHOLE_REGISTER_FILE();
+	const int j = blockIdx.y;
+	Dw3Args g;   // (fields copied one by one: a reference into the kernel-argument array makes the compiler copy the array to scratch)
+	g.dz = grp.job[j].dz; g.dz_foot_stride = grp.job[j].dz_foot_stride; g.x = grp.job[j].x; g.x_foot_stride = grp.job[j].x_foot_stride;
+	g.V = grp.job[j].V; g.chunks_per_foot = grp.job[j].chunks_per_foot; g.spf = grp.job[j].spf; g.cps = grp.job[j].cps;
+	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb;
+	dw6_body(g, blockIdx.x);
 }
 
 }  // namespace mlp
