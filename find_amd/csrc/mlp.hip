@@ -3,6 +3,7 @@
 #include "mlp_dw2.h"
 #include "mlp_dw4.h"
 #include "mlp_dwpe.h"
+#include "mlp_dwpe6.h"
 #include "mlp_gemm5.h"
 #include "mlp_gemm6.h"
 #include "mlp_gemm7.h"
@@ -153,6 +154,7 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int gemm6_min_units = 1024;
 	int gemm7 = 1;                // bf16x3 Linear kernel: 1 = gemm7 (W in registers, activations through LDS), 0 = gemm6 (W planes in LDS; kept for A/B)
+	int dwpe6 = 1;                // knob: the Fourier layer's weight gradient of bf16x3 calls on dwpe6_kernel (0: dwpe_kernel, fp32 MFMA)
 	int dw6_group = 1;            // knob: grouped weight gradients of bf16x3 calls on dw6_group_kernel (0: dw4_group, fp32 MFMA)
 	int direct_w = 1;             // knob: bf16x3 kernels read the model's weights themselves (transposed / Fourier order) instead of repacked copies (0: A/B)
 	int mlp_f16 = 0;              // default precision of calls that do not name one
@@ -1084,7 +1086,11 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	a.pw = b.pw; a.pb = pbuf;
 	a.all_blocks = (c->ablate & 32) ? 1 : 0;
 	const int nsplit = (int)(feet * spf);
-	if (lds_free) hipLaunchKernelGGL(dwpe_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
+	if (lds_free && c->x3 && c->dwpe6) {   // bf16x3 calls: the sin / cos columns on the bf16 matrix pipe, the x, y, z columns and the bias sums beside them
+		hipLaunchKernelGGL(dwpe6_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
+		hipLaunchKernelGGL(dwxyz_kernel, dim3((unsigned)nsplit), dim3(256), 0, s, a);
+	}
+	else if (lds_free) hipLaunchKernelGGL(dwpe_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
 	else hipLaunchKernelGGL((dw_kernel<AMODE_PE>), dim3((unsigned)nkt, (unsigned)nsplit), dim3(512), 0, s, a);
 	FIND_LAUNCH_CHECK("dw_kernel");
 	ReduceWArgs r;
@@ -1917,7 +1923,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 
