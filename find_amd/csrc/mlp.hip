@@ -1088,7 +1088,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	const int nsplit = (int)(feet * spf);
 	if (lds_free && c->x3 && c->dwpe6) {   // bf16x3 calls: the sin / cos columns on the bf16 matrix pipe, the x, y, z columns and the bias sums beside them
 		hipLaunchKernelGGL(dwpe6_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
-		hipLaunchKernelGGL(dwxyz_kernel, dim3((unsigned)nsplit), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(dwxyz_kernel, dim3((unsigned)nsplit), dim3(1024), 0, s, a);
 	}
 	else if (lds_free) hipLaunchKernelGGL(dwpe_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
 	else hipLaunchKernelGGL((dw_kernel<AMODE_PE>), dim3((unsigned)nkt, (unsigned)nsplit), dim3(512), 0, s, a);

@@ -135,10 +135,11 @@ __device__ __forceinline__ void dwpe6_body(const DwArgs& g, const int kt, const 
 }
 
 // The x, y, z columns of dW0 and the bias gradient: column n of dZ against (x, y, z, 1) over the rows of a run -- 4 of the 515 columns,
-// plain fp32 FMAs; dwpe_kernel folds them into two of its waves, which dwpe6's register budget has no room for.  grid (n_feet * spf) x 256
-// threads (thread = output row n: a row of dZ is one contiguous KB per step); writes the same slab columns / bias rows as dwpe_kernel.
-__global__ __launch_bounds__(256) void dwxyz_kernel(const DwArgs g) {
-	const int split = blockIdx.x, n = threadIdx.x;
+// plain fp32 FMAs; dwpe_kernel folds them into two of its waves, which dwpe6's register budget has no room for.  grid (n_feet * spf) x 1024
+// threads (four row groups x 256 output rows n: a row of dZ is one contiguous KB per load); writes the same slab columns / bias rows as dwpe_kernel.
+__global__ __launch_bounds__(1024) void dwxyz_kernel(const DwArgs g) {
+	__shared__ float red[4][4][256];
+	const int split = blockIdx.x, n = threadIdx.x & 255, grp = threadIdx.x >> 8;   // four row groups of 256 columns: rows grp, grp + 4, ...
 	const int foot = split / g.spf;
 	const int sidx = split - foot * g.spf;
 	const int cpf = (g.V - g.v_begin + 31) / 32;
@@ -148,20 +149,30 @@ __global__ __launch_bounds__(256) void dwxyz_kernel(const DwArgs g) {
 	const int nrows = max(min(g.v_begin + q1 * 32, g.V) - r0, 0);
 	const float* zp = g.dz + (int64_t)foot * g.dz_foot_stride + (int64_t)r0 * 256 + n;
 	const float* pp = g.pos + (int64_t)foot * g.pos_foot_stride + (int64_t)r0 * 3;
-	float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};   // two chains (even / odd rows), summed at the end
-	int r = 0;
-	for (; r + 1 < nrows; r += 2) {
-		const float a = zp[(int64_t)r * 256], b = zp[(int64_t)(r + 1) * 256];
-		s0[0] = fmaf(a, pp[r * 3], s0[0]); s0[1] = fmaf(a, pp[r * 3 + 1], s0[1]); s0[2] = fmaf(a, pp[r * 3 + 2], s0[2]); s0[3] += a;
-		s1[0] = fmaf(b, pp[r * 3 + 3], s1[0]); s1[1] = fmaf(b, pp[r * 3 + 4], s1[1]); s1[2] = fmaf(b, pp[r * 3 + 5], s1[2]); s1[3] += b;
+	float sx = 0.f, sy = 0.f, sz = 0.f, sb = 0.f;
+	int r = grp;
+	for (; r + 12 < nrows; r += 16) {   // four rows of this group per turn: their loads are independent
+		float a[4], x[4], y[4], z[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int rr = r + 4 * u;
+			a[u] = zp[(int64_t)rr * 256]; x[u] = pp[rr * 3]; y[u] = pp[rr * 3 + 1]; z[u] = pp[rr * 3 + 2];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { sx = fmaf(a[u], x[u], sx); sy = fmaf(a[u], y[u], sy); sz = fmaf(a[u], z[u], sz); sb += a[u]; }
 	}
-	if (r < nrows) {
+	for (; r < nrows; r += 4) {
 		const float a = zp[(int64_t)r * 256];
-		s0[0] = fmaf(a, pp[r * 3], s0[0]); s0[1] = fmaf(a, pp[r * 3 + 1], s0[1]); s0[2] = fmaf(a, pp[r * 3 + 2], s0[2]); s0[3] += a;
+		sx = fmaf(a, pp[r * 3], sx); sy = fmaf(a, pp[r * 3 + 1], sy); sz = fmaf(a, pp[r * 3 + 2], sz); sb += a;
 	}
-	float* q = g.pw + (int64_t)split * 256 * g.Kp + (int64_t)n * g.Kp + (g.pe >> 4) * 32;   // x, y, z: the first three columns of the last chunk
-	q[0] = s0[0] + s1[0]; q[1] = s0[1] + s1[1]; q[2] = s0[2] + s1[2];
-	if (g.pb != nullptr) g.pb[(int64_t)split * 256 + n] = s0[3] + s1[3];
+	red[grp][0][n] = sx; red[grp][1][n] = sy; red[grp][2][n] = sz; red[grp][3][n] = sb;
+	__syncthreads();
+	if (grp == 0) {
+		float* q = g.pw + (int64_t)split * 256 * g.Kp + (int64_t)n * g.Kp + (g.pe >> 4) * 32;   // x, y, z: the first three columns of the last chunk
+#pragma unroll
+		for (int c = 0; c < 3; ++c) q[c] = (red[0][c][n] + red[1][c][n]) + (red[2][c][n] + red[3][c][n]);
+		if (g.pb != nullptr) g.pb[(int64_t)split * 256 + n] = (red[0][3][n] + red[1][3][n]) + (red[2][3][n] + red[3][3][n]);
+	}
 }
 
 // grid (ceil(pe / 128), n_feet * spf) as dwpe_kernel.  pe >= 32.

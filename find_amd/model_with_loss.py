@@ -55,6 +55,7 @@ OVERLAP_CHAMFER = os.environ.get('FIND_OVERLAP_CHAMFER', '1') != '0'
 TEXTURE_STREAM = int(os.environ.get('FIND_TEXTURE_STREAM', '0'))
 # the GT scans' surface samples drawn before the main pass, beside it (ModelWithLoss.forward); FIND_PRESAMPLE_GT=0: inside the loss terms, as the reference orders them
 PRESAMPLE_GT = os.environ.get('FIND_PRESAMPLE_GT', '1') != '0'
+TEXTURE_FIRST = os.environ.get('FIND_TEXTURE_FIRST', '0') != '0'     # experiment: the texture term issued before the Chamfer term (ModelWithLoss.forward); measured SLOWER (1.69 against 1.63 ms)
 LAZY_COLOURS = os.environ.get('FIND_LAZY_COLOURS', '1') != '0'       # switch for A/B runs and for the bench record with the reference's eager colour head
 _SECOND_STREAMS = {}
 
@@ -324,6 +325,15 @@ class ModelWithLoss(nn.Module):
 		# (issue order = reverse backward order: with a third stream the texture term goes first, so that the loss-side chain the main pass's
 		# backward waits for -- smoothness, Chamfer, registration -- is the first thing the backward pass enqueues)
 		order = sorted(active, key=lambda t: t.flag != 'texture') if third is not None else active
+		# Experiment (round 6, FIND_TEXTURE_FIRST=1; off): the texture term ISSUED before the Chamfer term, the second stream forked by an
+		# event.  Under the tracer the texture pass's 5-us weight split waits 84 us for a CU behind the nearest-neighbour search's 1280
+		# workgroups; untraced -- the host far ahead of the GPU -- the reordering costs 60 us per step (1.69 against 1.63 ms, three
+		# alternating runs each): the traced timeline is not the untraced one.
+		fork_ev = None
+		if aside is not None and third is None and TEXTURE_FIRST:
+			order = sorted(active, key=lambda t: {'texture': 0, 'chamf': 1}.get(t.flag, 2))
+			fork_ev = torch.cuda.Event()
+			fork_ev.record(torch.cuda.current_stream(dev))
 		got = {}
 		for term in order:
 			if term.key in early:
@@ -331,7 +341,10 @@ class ModelWithLoss(nn.Module):
 			elif (aside is not None and term.flag == 'chamf') or (third is not None and term.flag == 'texture'):
 				side = aside if term.flag == 'chamf' else third
 				main = torch.cuda.current_stream(dev)
-				side.wait_stream(main)
+				if fork_ev is not None:
+					side.wait_event(fork_ev)
+				else:
+					side.wait_stream(main)
 				with torch.cuda.stream(side):
 					got[term.key] = getattr(self, term.fn)(st)
 				got[term.key].record_stream(main)   # allocated on the side stream, read on this one
