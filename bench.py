@@ -57,8 +57,28 @@ MAC_TRUNK_FWD = 515 * 256 + 4 * 256 * 256
 # fp16-mode gemm5 (profiles/r01_traffic_pmc_summary.txt): 2 x 57.10 MB + 112.9 MB.
 GEMM_TRAFFIC_BYTES = 242.9e6
 GEMM5_TRAFFIC_BYTES = 227.1e6
-GEMM5_C5_TRAFFIC_BYTES = None   # (gemm5 at the C5 shape, 16 x 50 002 rows: no PMC pass taken; at the headline shape 1.005 x algorithmic, profiles/r01_traffic_pmc_summary.txt)
-GEMM7_TRAFFIC_BYTES = 228.1e6   # bf16x3 gemm7 at the headline shape: (2 x 56 269.0 (FETCH_SIZE, gfx950 correction) + 110 240.0 (WRITE_SIZE)) KiB x 1024, profiles/r04_gemm7_pmc_summary.txt
+
+
+def pmc_traffic(stem, kernel):
+	"""(HBM-side bytes per launch of `kernel`, file name) from the NEWEST committed profiles/rNN_<stem>.txt: the FETCH_SIZE / WRITE_SIZE averages
+	(KiB per launch, separate rocprofv3 --pmc passes) of the kernel's section, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- the gfx950 fetch
+	correction of MI355X_MICROARCH.md.  (None, None) when no such file or section exists: the figure on the line is then null, never a constant
+	from an older round (the kernel's store path had changed under a hard-coded number)."""
+	import glob
+	import re
+	for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_{stem}.txt')), reverse=True):
+		vals, section = {}, None
+		for ln in open(path):
+			m = re.match(r'==\s*(\S+?):?\s*$', ln.strip()) or re.match(r'==\s*(\S+)\s', ln.strip())
+			if ln.startswith('=='):
+				section = m.group(1).rstrip(':') if m else None
+				continue
+			m = re.match(r'\s*(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+avg=\s*([0-9.]+)', ln)
+			if m and section is not None and kernel in section and m.group(1) not in vals:
+				vals[m.group(1)] = float(m.group(2))
+		if len(vals) == 2:
+			return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, os.path.basename(path)
+	return None, None
 
 
 OWN_STREAM = os.environ.get('FIND_BENCH_STREAM', '0') != '0'
@@ -624,7 +644,10 @@ def dominant_roofline(device, fp16=False, n_verts=None):
 		# gemm5 is bound by its streams
 		return {'bound': 'hbm', 'kernel': f'find::mlp::gemm5_kernel<1> (Linear 256->256 + bias + ReLU over {rows} rows, fp16 MFMA operands, fp32 tensors in HBM)',
 				'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS, 'avg_kernel_ms': kms,
-				'bytes_per_launch': nbytes, 'traffic': GEMM5_TRAFFIC_BYTES if n_verts == 6890 else (GEMM5_C5_TRAFFIC_BYTES if n_verts == 50002 else None), 'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
+				'bytes_per_launch': nbytes, 'traffic': GEMM5_TRAFFIC_BYTES if n_verts == 6890 else (pmc_traffic('gemm5_c5_pmc_summary', 'gemm5_kernel')[0] if n_verts == 50002 else None),
+				'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): '
+								+ ('profiles/r01_traffic_pmc_summary.txt' if n_verts == 6890 else f"profiles/{pmc_traffic('gemm5_c5_pmc_summary', 'gemm5_kernel')[1]}"),
+				'mfma_tflops': kflops / (kms * 1e-3) / 1e12}
 	ach = kflops / (kms * 1e-3) / 1e12
 	if FF.get_mlp_precision() == 'bf16x3':
 		# six bf16 products per fp32 multiply-accumulate: the flops the matrix pipe EXECUTES are 6 x the layer's
@@ -633,8 +656,9 @@ def dominant_roofline(device, fp16=False, n_verts=None):
 				'achieved': ex, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex / PEAK_BF16_MFMA_TFLOPS,
 				'avg_kernel_ms': kms, 'flops_per_launch': 6.0 * kflops, 'flops_per_launch_fp32_equivalent': kflops,
 				'fp32_equivalent_tflops': ach, 'x_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
-				'hbm_gbs_algorithmic': gbs, 'frac_of_hbm_peak': gbs / PEAK_HBM_GBS, 'traffic': GEMM7_TRAFFIC_BYTES if N_VERTS == 6890 else None,
-				'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r04_gemm7_pmc_summary.txt; algorithmic 226.0e6',
+				'hbm_gbs_algorithmic': gbs, 'frac_of_hbm_peak': gbs / PEAK_HBM_GBS, 'traffic': pmc_traffic('gemm7_pmc_summary', 'gemm7_kernel')[0] if n_verts == 6890 else None,
+				'traffic_note': 'HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), read from '
+								f"profiles/{pmc_traffic('gemm7_pmc_summary', 'gemm7_kernel')[1]}; algorithmic 226.0e6",
 				'note': 'achieved / peak count the bf16 products the matrix pipe executes (6 per fp32 multiply-accumulate); fp32_equivalent_tflops is the layer\'s own '
 						'2*rows*256*256 flop count over the same time -- above the fp32 MFMA peak (x_fp32_mfma_peak), which the round-3 kernel (gemm4, records.fp32_mfma) sat at 0.80 of'}
 	return {'bound': 'mfma', 'kernel': f'find::mlp::gemm4_kernel<1, 4, 8> (Linear 256->256 + bias + ReLU over {rows} rows, fp32 MFMA)',

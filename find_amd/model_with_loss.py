@@ -56,6 +56,7 @@ TEXTURE_STREAM = int(os.environ.get('FIND_TEXTURE_STREAM', '0'))
 # the GT scans' surface samples drawn before the main pass, beside it (ModelWithLoss.forward); FIND_PRESAMPLE_GT=0: inside the loss terms, as the reference orders them
 PRESAMPLE_GT = os.environ.get('FIND_PRESAMPLE_GT', '1') != '0'
 TEXTURE_FIRST = os.environ.get('FIND_TEXTURE_FIRST', '0') != '0'     # experiment: the texture term issued before the Chamfer term (ModelWithLoss.forward); measured SLOWER (1.69 against 1.63 ms)
+TEX_BWD_LATE = os.environ.get('FIND_TEX_BWD_LATE', '0') != '0'       # experiment: the texture term's backward behind the loss-side chain's (ModelWithLoss.forward); no gain measured (1.70-1.73 against 1.68-1.70 ms)
 LAZY_COLOURS = os.environ.get('FIND_LAZY_COLOURS', '1') != '0'       # switch for A/B runs and for the bench record with the reference's eager colour head
 _SECOND_STREAMS = {}
 
@@ -350,6 +351,16 @@ class ModelWithLoss(nn.Module):
 				got[term.key].record_stream(main)   # allocated on the side stream, read on this one
 			else:
 				got[term.key] = getattr(self, term.fn)(st)
+		if TEX_BWD_LATE and 'loss_tex' in got and st.res is not None:
+			# Backward order (round 6): autograd runs ready nodes by descending sequence number, i.e. in reverse order of creation -- the
+			# texture term, created last, first.  Its MLP backward leaves ~110 us of weight-gradient work on the side streams, and the short
+			# kernels of the loss-side chain that follow (smoothness, Chamfer, sampling backward -> d verts, which the main pass's backward
+			# waits for) then crawl beside it: 409 us from the start of the backward to d verts against ~215 for the two chains alone
+			# (tools/r6_phases.py, untraced).  The texture term's first backward node gets a sequence number just above the registration
+			# node's instead: the loss-side chain runs first, on an empty chip, then the texture pass's chain, then registration.
+			tex_fn, verts_fn = got['loss_tex'].grad_fn, st.res['verts'].grad_fn if torch.is_tensor(st.res.get('verts')) else None
+			if tex_fn is not None and verts_fn is not None and hasattr(tex_fn, '_set_sequence_nr'):
+				tex_fn._set_sequence_nr(verts_fn._sequence_nr() + 1)
 		for term in active:   # (reported, and summed, in the registry's order whatever the issue order was)
 			raw[term.key] = got[term.key]
 			weights.append(float(getattr(opts, term.weight)))
