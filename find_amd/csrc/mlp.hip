@@ -792,7 +792,8 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		h.head0 = head;
 		h.x_half = a16 ? 1 : 0;
 		const unsigned gx = (unsigned)std::min<int64_t>(cdiv(d.rows_h, 32), 2048);
-		hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 1), dim3(256), 0, st, h);
+		if (a16) hipLaunchKernelGGL(head_out_fwd_h16_kernel, dim3(gx, 1), dim3(256), 0, st, h);   // (fp16-stored activations: on the fp16 matrix pipe)
+		else hipLaunchKernelGGL(head_out_fwd_kernel, dim3(gx, 1), dim3(256), 0, st, h);
 	};
 	// The heads are independent after the trunk.  With both active, the colour head runs on a side stream: its bandwidth-bound
 	// pieces (the bias + ReLU broadcast, the 3-wide output layer: no LDS, so they can share CUs with the W-resident GEMMs) then
@@ -1086,7 +1087,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	a.pw = b.pw; a.pb = pbuf;
 	a.all_blocks = (c->ablate & 32) ? 1 : 0;
 	const int nsplit = (int)(feet * spf);
-	if (lds_free && c->x3 && c->dwpe6) {   // bf16x3 calls: the sin / cos columns on the bf16 matrix pipe, the x, y, z columns and the bias sums beside them
+	if (lds_free && (c->x3 || c->f16) && c->dwpe6) {   // bf16x3 calls (and the opt-in fp16 mode, whose Fourier layer keeps fp32-class arithmetic): the sin / cos columns on the bf16 matrix pipe, the x, y, z columns and the bias sums beside them
 		hipLaunchKernelGGL(dwpe6_kernel, dim3((unsigned)nkt_launch, (unsigned)nsplit), dim3(512), 0, s, a);
 		hipLaunchKernelGGL(dwxyz_kernel, dim3((unsigned)nsplit), dim3(1024), 0, s, a);
 	}
@@ -1366,7 +1367,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		for (int h = 0; h < 2; ++h) {
 			if (!(h == 0 ? want_d : want_c)) continue;
 			const Job& j = jobs[h];
-			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, j.dz, (int)n_feet, (int)V, (float*)nullptr, j.ps, a16 ? 1 : 0);
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs * 4), dim3(256), 0, s, j.dz, (int)n_feet, (int)V, (float*)nullptr, j.ps, a16 ? 1 : 0);
 			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, s, j.ps, b.nblk_fs, (int)n_feet, j.S);
 			hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)n_feet), dim3(256), 0, s, j.w0, j.ld0, j.lat, j.L, j.S, (int)n_feet, j.glat,
 							   (float*)nullptr, (float*)nullptr);
@@ -1441,7 +1442,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				// the weight gradients stay behind on the side streams: the latent gradients -- an OUTPUT autograd hands to whatever comes
 				// next -- are formed on the caller's stream, from per-foot column sums of their own (no slab reduce to wait for)
 				float* ps = (gw == g->disp_w) ? b.pS : b.pS2;
-				hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur_last], (int)n_feet, (int)V, (float*)nullptr, ps, 0);
+				hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs * 4), dim3(256), 0, s, dzbuf[cur_last], (int)n_feet, (int)V, (float*)nullptr, ps, 0);
 				hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, s, ps, b.nblk_fs, (int)n_feet, S);
 				hipLaunchKernelGGL(latent_grad_kernel, dim3((unsigned)(n_feet + W)), dim3(256), 0, s, w0full, ld0, lat, L, S, (int)n_feet, glat, gw[0], (float*)nullptr);
 				FIND_LAUNCH_CHECK("latent gradients (deferred join)");
@@ -1513,7 +1514,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			// (Measured and dropped: the foot sum on the head's side stream, the caller's stream going straight on to the other head's dX
 			// chain and waiting for the sums in step 4 -- 3.49 against 3.38 ms per train_3d step: the HBM-bound pass beside the dX GEMMs
 			// costs them more than the wait it removes.)
-			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs, 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps, a16 ? 1 : 0);
+			hipLaunchKernelGGL(footsum_kernel, dim3((unsigned)b.nblk_fs * 4), dim3(256), 0, s, dzbuf[cur], (int)n_feet, (int)V, zs, ps, a16 ? 1 : 0);
 			// the foot-summed first layer is a small launch: its own side stream and slab set, so that it does not queue behind the
 			// large weight-gradient launches on Q.  The per-foot column sums go there too: only the latent / bias gradients read them.
 			fk.fork_to(side);

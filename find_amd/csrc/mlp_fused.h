@@ -167,8 +167,7 @@ __global__ __launch_bounds__(512, 2) void fused_chain_kernel(const FusedArgs g) 
 					p1 += x.x * b.x + x.y * b.y + x.z * b.z + x.w * b.w;
 					p2 += x.x * c.x + x.y * c.y + x.z * c.z + x.w * c.w;
 				}
-#pragma unroll
-				for (int d = 1; d < 16; d <<= 1) { p0 += __shfl_xor(p0, d, 64); p1 += __shfl_xor(p1, d, 64); p2 += __shfl_xor(p2, d, 64); }
+				p0 = row16_sum(p0); p1 = row16_sum(p1); p2 = row16_sum(p2);   // (DPP: bit for bit the xor-1, 2, 4, 8 butterfly through ds_bpermute it replaces)
 				if (seg < 3 && row < valid) {
 					const float zz = (seg == 0 ? p0 : (seg == 1 ? p1 : p2)) + s.bias[seg];
 					const float t = tanhf(zz);

@@ -420,7 +420,19 @@ __device__ __forceinline__ void st4_any(void* base, int64_t elem, int half, cons
 	else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
 }
 
-// grid (ceil(V/16), 4): block = 16 rows x 64 columns; thread (row r = tid>>4, column group cg = tid&15) walks the feet.
+// v + its three counterparts 16, 32 and 48 lanes away (the four 16-lane rows of a wave), in every lane: gfx950's v_permlane16_swap /
+// v_permlane32_swap on two copies of the value -- VALU only, and bit for bit the xor-16, xor-32 butterfly through __shfl_xor it replaces
+// (128 ds_bpermute per thread and round of feet: the LDS pipe, not HBM, bounded footsum_kernel -- 2.4 TB/s at the C5 shape, round 6).
+__device__ __forceinline__ float rows4_sum(float v) {
+	const unsigned u = __float_as_uint(v);
+	const auto p = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // rows (0, 1, 2, 3) -> (0, 0, 2, 2) and (1, 1, 3, 3)
+	const float t = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+	const unsigned w = __float_as_uint(t);
+	const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);     // lower half twice, upper half twice
+	return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// grid (4 ceil(V/16)): block = 16 rows x 64 columns (row block blockIdx.x / 4, column quarter blockIdx.x % 4); thread (row r = tid>>4, column group cg = tid&15) walks the feet.
 // (An LDS-free variant -- one wave per 16 columns, the 16 rows summed by shuffles, so that it could share CUs with the ring kernels
 // that claim the whole LDS -- made the step slower, 2.30 against 2.26 ms: 64-byte row segments and the interference cost more than
 // the wait for a CU.)
@@ -428,8 +440,11 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 													   float* __restrict__ pS /* [gridDim.x][n_feet][256] */, int dz_half) {
 	__shared__ __attribute__((aligned(16))) float red[4][FS_FEET][64];
 	const int cg = threadIdx.x & 15, r = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-	const int v = blockIdx.x * FS_ROWS + r;
-	const int c0 = blockIdx.y * 64 + cg * 4;
+	// (the four column quarters of the same 16 rows are CONSECUTIVE workgroups: with the quarter in blockIdx.y a launch read one 128-byte
+	// quarter of every 512-byte fp16 row, then the next quarter a whole grid later -- a quarter of every DRAM row per visit: 2.3 TB/s at C5)
+	const int blk = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+	const int v = blk * FS_ROWS + r;
+	const int c0 = quarter * 64 + cg * 4;
 	const bool live = v < V;
 	float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
 	for (int b0 = 0; b0 < n_feet; b0 += FS_FEET) {
@@ -443,14 +458,13 @@ __global__ __launch_bounds__(256) void footsum_kernel(const float* __restrict__ 
 			zs.x += x[bb].x; zs.y += x[bb].y; zs.z += x[bb].z; zs.w += x[bb].w;
 			// per-foot column sums: the 4 rows of this wave by shuffles (lanes 16 apart), the 4 waves through LDS
 			float4 a = x[bb];
-			a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
-			a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
+			a.x = rows4_sum(a.x); a.y = rows4_sum(a.y); a.z = rows4_sum(a.z); a.w = rows4_sum(a.w);
 			if ((threadIdx.x & 63) < 16) *reinterpret_cast<float4*>(&red[wave][bb][cg * 4]) = a;
 		}
 		__syncthreads();
 		for (int i = threadIdx.x; i < nb * 64; i += 256) {
 			const int bb = i >> 6, c = i & 63;
-			pS[((int64_t)blockIdx.x * n_feet + b0 + bb) * 256 + blockIdx.y * 64 + c] = (red[0][bb][c] + red[1][bb][c]) + (red[2][bb][c] + red[3][bb][c]);
+			pS[((int64_t)blk * n_feet + b0 + bb) * 256 + quarter * 64 + c] = (red[0][bb][c] + red[1][bb][c]) + (red[2][bb][c] + red[3][bb][c]);
 		}
 		__syncthreads();
 	}
@@ -704,6 +718,73 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const HeadOutArgs g) 
 	}
 }
 
+// The same for fp16-STORED activations (act16, the opt-in fp16 mode at the large shared-template shapes) on the fp16 matrix pipe: a row of
+// x is 512 B, and the fp32 kernel above spends more instructions converting, multiplying and DPP-summing a row than the memory system
+// needs to deliver it (2.8 TB/s at the C5 shape, round 6).  Here a wave takes 16-row blocks: x is the MFMA's row operand AS IT LIES IN
+// MEMORY (v_mfma_f32_16x16x32_f16: lane (row l % 16, k quarter l / 16) loads 16 bytes = 8 consecutive k), W the column operand, split
+// into an fp16 pair hi + lo of 16 w (exact to 2^-22 |w|; the factor keeps lo out of the fp16 subnormals) held in registers for the whole
+// run -- 16 MFMAs and 8 loads per block and lane, four blocks in flight.  fp32 accumulation; the three live columns of the 16 x 16
+// result (lanes l % 16 < 3, four rows each) go through the same bias / tanh epilogue.
+typedef _Float16 find_h8 __attribute__((ext_vector_type(8)));
+typedef float find_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void head_out_fwd_h16_kernel(const HeadOutArgs g) {
+	const int head = blockIdx.y + g.head0;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const _Float16* x = reinterpret_cast<const _Float16*>(head ? g.x[1] : g.x[0]);
+	const float* w = head ? g.w[1] : g.w[0];
+	const float* b = head ? g.b[1] : g.b[0];
+	float* z = head ? g.z[1] : g.z[0];
+	float* out = head ? g.out[1] : g.out[0];
+	if (out == nullptr) return;
+	const int m = lane & 15, kq = lane >> 4;
+	const int ch = m < 3 ? m : 0;
+	find_h8 wh[8], wl[8];
+#pragma unroll
+	for (int s = 0; s < 8; ++s)
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const float v = m < 3 ? 16.0f * w[ch * W + 32 * s + 8 * kq + j] : 0.f;
+			const _Float16 hi = (_Float16)v;
+			wh[s][j] = hi;
+			wl[s][j] = (_Float16)(v - (float)hi);
+		}
+	const float bc = b[ch];
+	const float av = (head && g.avg_col) ? g.avg_col[ch] : 0.f;
+	constexpr int U = 4;
+	const int64_t nblk = (g.rows + 15) >> 4;
+	for (int64_t b0 = ((int64_t)blockIdx.x * 4 + wave) * U; b0 < nblk; b0 += (int64_t)gridDim.x * 4 * U) {
+		find_h8 xa[U][8];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int64_t row = min((b0 + u) * 16 + m, g.rows - 1);   // (rows past the end re-read the last row: never stored)
+			const find_h8* p = reinterpret_cast<const find_h8*>(x + row * W + 8 * kq);
+#pragma unroll
+			for (int s = 0; s < 8; ++s) xa[u][s] = p[4 * s];
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			find_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int s = 0; s < 8; ++s) {
+				acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[u][s], wl[s], acc, 0, 0, 0);   // (small terms first)
+				acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[u][s], wh[s], acc, 0, 0, 0);
+			}
+			if (m < 3) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int64_t row = (b0 + u) * 16 + 4 * kq + i;
+					if (row < g.rows) {
+						const float zz = acc[i] * 0.0625f + bc;
+						const float t = tanhf(zz);
+						if (z) z[row * 3 + m] = zz;
+						out[row * 3 + m] = head ? (av + 0.5f * (1.0f + t)) : 0.1f * t;
+					}
+				}
+			}
+		}
+	}
+}
+
 // Backward of the final layers: dz = g * act'(z);  dY[row][k] = (sum_c dz_c W[c][k]) * (Y[row][k] > 0);
 // partial dW[c][k] = sum_rows dz_c * Y[row][k], partial db[c] = sum_rows dz_c   (per workgroup slabs).
 struct HeadOutBwdArgs {
@@ -718,7 +799,8 @@ struct HeadOutBwdArgs {
 	int half;              // y and dy are stored as fp16 (act16)
 };
 
-__global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs g) {
+template <int U>   // rows in flight per wave: 4, or 8 for fp16-stored tensors (half the bytes per row: twice the rows for the same bytes in flight)
+__device__ __forceinline__ void head_out_bwd_body(const HeadOutBwdArgs& g) {
 	const int head = blockIdx.y;
 	const float* gout = head ? g.gout[1] : g.gout[0];
 	if (gout == nullptr) return;
@@ -735,7 +817,6 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 	const float scale = head ? 0.5f : 0.1f;
 	float4 aw0 = make_float4(0, 0, 0, 0), aw1 = aw0, aw2 = aw0;
 	float ab0 = 0.f, ab1 = 0.f, ab2 = 0.f;
-	constexpr int U = 4;  // rows in flight per wave
 	for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * U; r0 < g.rows; r0 += (int64_t)gridDim.x * 4 * U) {
 		float4 yv[U];
 		float d[U][3];
@@ -785,6 +866,10 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs 
 	for (int c = 0; c < 3; ++c)
 		pw[((int64_t)blockIdx.x * 3 + c) * 256 + k] = red[0][c][k] + red[1][c][k] + red[2][c][k] + red[3][c][k];
 	if (k < 3) pb[(int64_t)blockIdx.x * 4 + k] = redb[0][k] + redb[1][k] + redb[2][k] + redb[3][k];
+}
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(const HeadOutBwdArgs g) {
+	if (g.half) head_out_bwd_body<8>(g);
+	else head_out_bwd_body<4>(g);
 }
 
 // grid (12, 2 heads) x 1024 threads: block handles 64 of the 768 dW outputs, the partial range cut 16 ways, LDS-combined.
