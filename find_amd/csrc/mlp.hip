@@ -112,15 +112,12 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 		if (save || !pt[i & 1]) pt[i & 1] = c.take<float>(d.rows_t * W);
 		o->H[i] = pt[i & 1];
 	}
-	// (a shared template's head activations may be stored as three bf16 planes -- 6 bytes per element, use_planes: room for that whichever
-	// arithmetic the call ends up in: this function does not see the context's default precision)
-	const int64_t act_elems = (d.shared && d.n_feet > 1) ? d.rows_h * W * 3 / 2 : d.rows_h * W;
 	for (int i = 0; i < p->n_disp; ++i) {
-		if (save || !pd[i & 1]) pd[i & 1] = c.take<float>(act_elems);
+		if (save || !pd[i & 1]) pd[i & 1] = c.take<float>(d.rows_h * W);
 		o->D[i] = pd[i & 1];
 	}
 	for (int i = 0; i < p->n_col; ++i) {
-		if (save || !pc[i & 1]) pc[i & 1] = c.take<float>(act_elems);
+		if (save || !pc[i & 1]) pc[i & 1] = c.take<float>(d.rows_h * W);
 		o->C[i] = pc[i & 1];
 	}
 	o->bytes = c.off;
@@ -131,7 +128,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_GEMM7P_RELU, K_GEMM7P_RELU_Y, K_GEMM7P_MASK, K_GEMM7P_MASK_Y, K_DW6P, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -157,7 +154,6 @@ struct find_ctx {
 	int gemm5_min_units = 1024;
 	int gemm6_min_units = 1024;
 	int gemm7 = 1;                // bf16x3 Linear kernel: 1 = gemm7 (W in registers, activations through LDS), 0 = gemm6 (W planes in LDS; kept for A/B)
-	int act_planes = 1;           // knob: bf16x3 calls store the heads' hidden activations and their gradients as three bf16 planes at the large shared-template shapes (use_planes)
 	int dwpe6 = 1;                // knob: the Fourier layer's weight gradient of bf16x3 calls on dwpe6_kernel (0: dwpe_kernel, fp32 MFMA)
 	int dw6_group = 1;            // knob: grouped weight gradients of bf16x3 calls on dw6_group_kernel (0: dw4_group, fp32 MFMA)
 	int direct_w = 1;             // knob: bf16x3 kernels read the model's weights themselves (transposed / Fourier order) instead of repacked copies (0: A/B)
@@ -189,7 +185,7 @@ struct find_ctx {
 	bool attr_done[K_COUNT] = {};
 	// how the last forward calls that saved a workspace stored the heads' activations (act16): the backward of a workspace follows its
 	// forward's decision even if a knob was turned in between (ring of the last 16; a workspace not found falls back to the rule)
-	struct Act16Note { const void* ws; bool a16; bool planes; };
+	struct Act16Note { const void* ws; bool a16; };
 	Act16Note act16_notes[16] = {};
 	int act16_next = 0;
 	int act16 = 1;                // knob: in the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large
@@ -467,25 +463,6 @@ static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	return FIND_OK;
 }
 
-// gemm7 with activations / outputs / masks stored as bf16 planes (mlp_gemm7.h: PL_A, PL_Y, PL_M): the four combinations a head's hidden
-// layers use -- forward: planes in, planes or fp32 (the last hidden layer) out; backward: planes in, mask from planes, planes or fp32 out
-template <int EPI, bool PY, bool PM>
-static int launch_gemm7_planes_t(find_ctx* c, int kid, Gemm2Args a, int64_t feet, hipStream_t s) {
-	int lds = 0;
-	const int rc = prepare_kernel(c, kid, &gemm7_kernel<EPI, 0, true, PY, PM>, GEMM7_LDS, &lds);
-	if (rc != FIND_OK) return rc;
-	a.tiles_per_foot = (int)cdiv(a.V, 32);
-	a.ntiles = (int)(a.tiles_per_foot * feet);
-	const int grid = std::max(16, (c->num_cus / 16) * 16);
-	hipLaunchKernelGGL((gemm7_kernel<EPI, 0, true, PY, PM>), dim3(grid), dim3(GEMM7_NW * 64), lds, s, a);
-	return FIND_OK;
-}
-static int launch_gemm7_planes(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s, int pl_a, int pl_y, int pl_m) {
-	FIND_REQUIRE(pl_a && ((epi == EPI_BIAS_RELU && !pl_m) || (epi == EPI_MASK && pl_m)), "launch_gemm7_planes: unsupported combination (epi %d, planes a %d y %d m %d)", epi, pl_a, pl_y, pl_m);
-	if (epi == EPI_BIAS_RELU) return pl_y ? launch_gemm7_planes_t<EPI_BIAS_RELU, true, false>(c, K_GEMM7P_RELU_Y, a, feet, s) : launch_gemm7_planes_t<EPI_BIAS_RELU, false, false>(c, K_GEMM7P_RELU, a, feet, s);
-	return pl_y ? launch_gemm7_planes_t<EPI_MASK, true, true>(c, K_GEMM7P_MASK_Y, a, feet, s) : launch_gemm7_planes_t<EPI_MASK, false, true>(c, K_GEMM7P_MASK, a, feet, s);
-}
-
 static int launch_gemm7(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
 	if (epi == EPI_BIAS_RELU) return launch_gemm7_t<EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK) return launch_gemm7_t<EPI_MASK>(c, a, feet, s);
@@ -517,7 +494,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	memset(&b, 0, sizeof(b));
 	b.a0 = a.a0; b.a1 = a.a1; b.nseg = a.nbase; b.a_foot_stride = a.a_foot_stride; b.lda = a.lda;
 	b.pos = a.pos; b.pos_foot_stride = a.pos_foot_stride; b.Bm = a.Bm; b.pe = a.pe;
-	b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk; b.w_tr = a.w_tr; b.a_plane = a.a_plane; b.y_plane = a.y_plane;
+	b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk; b.w_tr = a.w_tr;
 	b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
 	b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = c->ablate; b.dbg = c->dbg;
 	if (amode == AMODE_PE) return launch_gemm2_pe(c, b, feet, s);
@@ -529,9 +506,8 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 #ifdef FIND_DIAG
 	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
 #endif
-	if (c->x3 && k256 && units >= c->gemm6_min_units) return (a.pl_a || a.pl_y || a.pl_m) ? launch_gemm7_planes(c, epi, b, feet, s, a.pl_a, a.pl_y, a.pl_m) : launch_gemm7(c, epi, b, feet, s);
+	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm7(c, epi, b, feet, s);
 	FIND_REQUIRE(!a.w_tr, "launch_gemm: an untransposed weight reached a kernel that cannot read it (gemm7_direct and the kernel selection disagree)");
-	FIND_REQUIRE(!(a.pl_a || a.pl_y || a.pl_m), "launch_gemm: a layer stored as bf16 planes reached a kernel that reads fp32 (use_planes and the kernel selection disagree)");
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
 	return launch_gemm3(c, epi, b, feet, s);
@@ -651,10 +627,9 @@ static GemmArgs gemm_args_zero() {
 
 // Linear + ReLU forward:  y = relu(x @ w^T + bias[foot])
 static int linear_fwd(find_ctx* c, const float* x, int64_t x_foot_stride, const float* w, int ldw, const float* bias,
-					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false, int pl_a = 0, int pl_y = 0) {
+					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
 	GemmArgs a = gemm_args_zero();
 	a.h16 = h16;
-	a.pl_a = pl_a; a.pl_y = pl_y; a.a_plane = a.y_plane = feet * V * 512;   // (planes: [plane][all rows of the tensor][256] bf16)
 	a.a0 = x; a.a_foot_stride = x_foot_stride; a.lda = W;
 	a.w0 = w; a.ldw = ldw; a.nchunk = W / KC;
 	a.bias = bias; a.bias_foot_stride = bias_foot_stride;
@@ -676,22 +651,10 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 static bool use_act16(const find_ctx* c, bool f16, bool shared, int64_t n_feet, int64_t V) {
 	return f16 && c->act16 && shared && n_feet > 1 && cdiv(V, 32) * n_feet >= c->gemm5_min_units;
 }
-// "planes" (round 6): in a bf16x3 call of the same large shared-template shapes the heads' hidden activations (all but each head's last)
-// and the gradients that meet them (all but each head's first-layer dZ) are stored as their three bf16 planes -- exact (p1 + p2 + p3 == a),
-// 6 bytes per element: gemm7 and dw6 then read MFMA operands as stored instead of splitting every element in every consumer
-// (mlp_gemm7.h: PL_A / PL_Y / PL_M, mlp_dw6.h: dw6_planes_kernel; bias_relu_bcast and head_out_bwd write planes).  Needs at least two
-// hidden layers per head; forward and backward agree through the same note as act16.
-static bool use_planes(const find_ctx* c, const find_mlp_params* p, bool shared, int64_t n_feet, int64_t V) {
-	return c->x3 && c->act_planes && shared && n_feet > 1 && p->n_disp >= 2 && p->n_col >= 2 && gemm7_direct(c, V, n_feet);
-}
-static void note_act16(find_ctx* c, const void* ws, bool a16, bool planes = false) {
-	for (auto& n : c->act16_notes) if (n.ws == ws) { n.a16 = a16; n.planes = planes; return; }
-	c->act16_notes[c->act16_next] = find_ctx::Act16Note{ws, a16, planes};
+static void note_act16(find_ctx* c, const void* ws, bool a16) {
+	for (auto& n : c->act16_notes) if (n.ws == ws) { n.a16 = a16; return; }
+	c->act16_notes[c->act16_next] = find_ctx::Act16Note{ws, a16};
 	c->act16_next = (c->act16_next + 1) & 15;
-}
-static bool noted_planes(const find_ctx* c, const void* ws, bool by_rule) {
-	for (const auto& n : c->act16_notes) if (n.ws == ws) return n.planes;
-	return by_rule;
 }
 static bool noted_act16(const find_ctx* c, const void* ws, bool by_rule) {
 	for (const auto& n : c->act16_notes) if (n.ws == ws) return n.a16;
@@ -707,9 +670,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
-	const bool planes = use_planes(c, p, d.shared, n_feet, V);
-	note_act16(c, w.fbd, a16, planes);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
-	const int64_t plane_bytes = d.rows_h * 512;
+	note_act16(c, w.fbd, a16);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
 
 	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers.  Not for a bf16x3 chain that carries the
 	// whole call (or everything up to the heads' broadcast first layers): its weight split reads the model's tensors directly (round 6: this
@@ -811,7 +772,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_NONE, a, 1, st));
 			}
 			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, st, hp, bias,
-							   bstride, (int)n_feet, V, out, planes ? 2 : (a16 ? 1 : 0), plane_bytes);
+							   bstride, (int)n_feet, V, out, a16 ? 1 : 0);
 			return FIND_OK;
 		}
 		FIND_REQUIRE(!a16, "find_mlp_fwd: act16 without a shared template");
@@ -844,13 +805,12 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 	if (disp) {
 		FIND_TRY(head_first(w.wd0, bias_d0, bstride_d, w.D[0], w.hp, s));
-		// (planes: every hidden activation but the head's last -- which the 3-wide output layer reads -- is stored as bf16 planes)
-		for (int i = 1; i < p->n_disp; ++i) FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s, a16, planes, planes && i < p->n_disp - 1));
+		for (int i = 1; i < p->n_disp; ++i) FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s, a16));
 		head_out(0, s);
 	}
 	if (col) {
 		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], (sc != s || (fused && disp)) ? w.hp2 : w.hp, sc));
-		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc, a16, planes, planes && i < p->n_col - 1));
+		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc, a16));
 		head_out(1, sc);
 	}
 	FIND_LAUNCH_CHECK("head layers");
@@ -960,9 +920,8 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	for (int i = 1; i < p->n_trunk; ++i) o->Tt[i] = c.take<float>((int64_t)W * W);
 	for (int i = 0; i < p->n_disp; ++i) o->Dt[i] = c.take<float>((int64_t)W * W);
 	for (int i = 0; i < p->n_col; ++i) o->Ct[i] = c.take<float>((int64_t)W * W);
-	const int64_t dz_elems = (d.shared && d.n_feet > 1) ? d.rows_h * W * 3 / 2 : d.rows_h * W;   // (bf16 planes: carve_fwd)
-	for (int i = 0; i < std::max(p->n_disp, 1); ++i) o->dzD[i] = c.take<float>(dz_elems);
-	for (int i = 0; i < std::max(p->n_col, 1); ++i) o->dzC[i] = c.take<float>(dz_elems);
+	for (int i = 0; i < std::max(p->n_disp, 1); ++i) o->dzD[i] = c.take<float>(d.rows_h * W);
+	for (int i = 0; i < std::max(p->n_col, 1); ++i) o->dzC[i] = c.take<float>(d.rows_h * W);
 	for (int i = 0; i < std::max(p->n_trunk, 1); ++i) o->dzT[i] = c.take<float>(d.rows_t * W);
 	int spf, cps;
 	split_policy(d.n_feet, d.V, &spf, &cps);
@@ -1022,7 +981,7 @@ static int reduce_lds(find_ctx* c) {
 // tiles go out on stream s; the slab reduce follows on s, or -- reduce_side >= 0 -- on that side stream of the fork, ordered behind s.
 static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
-					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1, bool h16 = false, bool planes = false) {
+					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1, bool h16 = false) {
 	auto reduce_stream = [&]() -> hipStream_t {
 		if (!fk || !fk->on || reduce_side < 0 || s_side < 0 || reduce_side == s_side) return s;
 		fk->chain(s_side, reduce_side);
@@ -1030,7 +989,6 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 	};
 	float* pbuf = (db || S) ? b.pb : nullptr;
 	const int cus = (fk && fk->on) ? c->side_cus : c->num_cus;   // (the side streams may be confined to a part of the chip: cu_reserve)
-	FIND_REQUIRE(!planes || (!pos && !c->f16 && c->x3 && cdiv(V, 32) * feet >= c->gemm6_min_units), "find_mlp_bwd: operands stored as bf16 planes reached a weight-gradient kernel that reads fp32 (use_planes and the kernel selection disagree)");
 	if (!pos) {
 		int nmain, spf;
 		if (c->f16) {
@@ -1067,13 +1025,7 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			memset(&d6, 0, sizeof(d6));
 			d6.dz = dz; d6.dz_foot_stride = V * W; d6.x = x; d6.x_foot_stride = x_foot_stride;
 			d6.V = (int)V; d6.chunks_per_foot = cpf16; d6.spf = spf; d6.cps = cps6; d6.pw = b.pw; d6.pb = pbuf;
-			if (planes) {   // both operands stored as bf16 planes (use_planes): no split, the rows regrouped by permutes
-				FIND_TRY(prepare_kernel(c, K_DW6P, &dw6_planes_kernel, DW6_LDS, &lds));
-				d6.dz_plane = d6.x_plane = feet * V * 512;
-				hipLaunchKernelGGL(dw6_planes_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);
-			} else {
-				hipLaunchKernelGGL(dw6_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);
-			}
+			hipLaunchKernelGGL(dw6_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);
 			FIND_LAUNCH_CHECK("dw6_kernel");
 		} else {
 			// LDS-DMA kernel: every foot's rows cut into spf contiguous runs of 16-row chunks, the <= 15 leftover rows
@@ -1233,11 +1185,9 @@ static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 }
 
 // masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
-static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, int ldw, int w_tr, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false,
-						 int pl_a = 0, int pl_y = 0, int pl_m = 0) {
+static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, int ldw, int w_tr, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
 	GemmArgs a = gemm_args_zero();
 	a.h16 = h16;
-	a.pl_a = pl_a; a.pl_y = pl_y; a.pl_m = pl_m; a.a_plane = a.y_plane = feet * V * 512;
 	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
 	a.w0 = wt; a.ldw = ldw; a.w_tr = w_tr; a.nchunk = W / KC;
 	a.mask = mask; a.mask_foot_stride = V * W;
@@ -1331,8 +1281,6 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
 	const bool a16 = noted_act16(c, w.fbd, use_act16(c, c->f16, d.shared, n_feet, V));   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
-	const bool planes = noted_planes(c, w.fbd, use_planes(c, p, d.shared, n_feet, V));   // (... or as bf16 planes: every dZ but each head's first-layer one follows)
-	const int64_t plane_bytes = d.rows_h * 512;
 	int cd = 0, cc = 0;  // current dZ buffer per head
 	{
 		HeadOutBwdArgs h;
@@ -1346,7 +1294,6 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		h.pb[0] = b.pbo[0]; h.pb[1] = b.pbo[1];
 		h.rows = d.rows_h;
 		h.half = a16 ? 1 : 0;
-		h.dy_planes = planes ? 1 : 0; h.plane_bytes = plane_bytes;
 		hipLaunchKernelGGL(head_out_bwd_kernel, dim3((unsigned)b.nblk_out, 2), dim3(256), 0, s, h);
 		HeadOutReduceArgs hr;
 		memset(&hr, 0, sizeof(hr));
@@ -1411,8 +1358,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			if (want_d) head_chain(p->n_disp, w.D, b.dzD, false, cd);
 			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		} else {
-			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { const WT t = wt_D(l); FIND_TRY(linear_bwd_dx(c, b.dzD[cd], t.w, t.ld, t.tr, w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16, planes, planes && l > 1, planes)); cd += 1; }
-			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { const WT t = wt_C(l); FIND_TRY(linear_bwd_dx(c, b.dzC[cc], t.w, t.ld, t.tr, w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16, planes, planes && l > 1, planes)); cc += 1; }
+			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { const WT t = wt_D(l); FIND_TRY(linear_bwd_dx(c, b.dzD[cd], t.w, t.ld, t.tr, w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16)); cd += 1; }
+			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { const WT t = wt_C(l); FIND_TRY(linear_bwd_dx(c, b.dzC[cc], t.w, t.ld, t.tr, w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16)); cc += 1; }
 		}
 		struct Job { const float* dz; float* ps; float* S; const float* w0; int ld0; const float* lat; int L; float* glat; };
 		const Job jobs[2] = {{b.dzD[cd], b.pS, b.Sd, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, g->lat_disp},
@@ -1551,13 +1498,13 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				BwdWs bk = b;
 				bk.pw = b.pw_t[si ? 3 : 0]; bk.pb = b.pb_t[si ? 3 : 0];
 				fk.wait(Q, set_free[si]);
-				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R, a16, planes));
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R, a16));
 				set_free[si] = fk.mark(R);
 			} else {
-				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16, planes));
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16));
 			}
 			const WT t = colour ? wt_C(l) : wt_D(l);
-			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, act[l - 1], dzbuf[cur + 1], V, n_feet, s, a16, planes, planes && l > 1, planes));
+			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, act[l - 1], dzbuf[cur + 1], V, n_feet, s, a16));
 			cur += 1;
 		}
 		float* db_late = nullptr;
@@ -1977,7 +1924,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"act_planes", &find_ctx::act_planes, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
 };
 }  // namespace
 

@@ -29,7 +29,6 @@ struct Dw3Args {
 	int cps;                 // 64-row chunks per split
 	float* pw;               // [n_feet*spf][256][256]
 	float* pb;               // [n_feet*spf][256] or nullptr
-	int64_t dz_plane, x_plane;   // dw6_planes_kernel: bytes between the three bf16 planes of dz / of x (both point at plane 0; foot strides in elements)
 };
 
 constexpr int DW3_OPER = 256 * 128;            // one operand of one chunk in LDS: 256 columns x 64 rows fp16

@@ -32,12 +32,6 @@ constexpr int DW6_OPER = 3 * DW6_PLANE;         // 24 KB
 constexpr int DW6_BUF = 2 * DW6_OPER;           // dZ then X: 48 KB
 constexpr int DW6_LDS = 2 * DW6_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 102 400 B
 
-// PL ("planes", round 6; mlp.hip: use_planes): both operands are STORED as their three bf16 planes ([plane][row][256] bf16; g.dz / g.x point
-// at plane 0, planes g.dz_plane / g.x_plane bytes apart).  Nothing is split here: a lane loads the 8 bytes (four columns) of each of its
-// eight rows in each plane and regroups them -- one v_perm_b32 per word -- into the same [column'][16 rows] LDS words; the twelve stages of a
-// column between the MFMA pairs are one permute each (150 -> ~50 VALU instructions per chunk and wave, + 4 per word in the two waves that
-// sum the bias gradient: the pieces widened and added in fp32 -- another summation order than the fp32-stored path's, nothing else).
-template <bool PL>
 __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* red = reinterpret_cast<float*>(smem + 2 * DW6_BUF);
@@ -55,9 +49,7 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
 	// staging role of this wave: operand sop (0 = dZ, 1 = X), row group srg (rows 8 srg .. +7 of a chunk)
 	const int sop = wave >> 1, srg = wave & 1;
-	const float* const sfoot = PL ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(sop == 0 ? g.dz : g.x) + (int64_t)foot * (sop == 0 ? g.dz_foot_stride : g.x_foot_stride) * 2)
-								  : (sop == 0 ? g.dz + (int64_t)foot * g.dz_foot_stride : g.x + (int64_t)foot * g.x_foot_stride);
-	const int64_t splane = sop == 0 ? g.dz_plane : g.x_plane;
+	const float* const sfoot = sop == 0 ? g.dz + (int64_t)foot * g.dz_foot_stride : g.x + (int64_t)foot * g.x_foot_stride;
 
 	f32x16 acc[4][4];
 #pragma unroll
@@ -75,38 +67,15 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	// Buffer loads: the descriptor's size is the foot's valid bytes, so rows past its end come back as zeros from the bounds check.
 	typedef unsigned u4 __attribute__((ext_vector_type(4)));
 	typedef int i4 __attribute__((ext_vector_type(4)));
-	typedef unsigned u2 __attribute__((ext_vector_type(2)));
-	// fp32: set[j] = the float4 of row j.  Planes: set[2 p + (j >> 2)] component pair (j & 3) ... kept simple: set[6 * (j >> 2) + ...] below
-	constexpr int NSET = PL ? 12 : 8;   // planes: 8 rows x 3 planes x 8 bytes = 12 16-byte registers (rows j, j + 4 of a plane share one)
-	u4 st[2][NSET];
+	u4 st[2][8];
 	const int c4 = lane * 4;
-	const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(sfoot)), 0, PL ? g.V * 512 : g.V * 1024, 0x00020000);
-	const __amdgpu_buffer_rsrc_t srsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(sfoot) + (PL ? splane : 0)))), 0, PL ? g.V * 512 : 0, 0x00020000);
-	const __amdgpu_buffer_rsrc_t srsrc3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(reinterpret_cast<const float*>(reinterpret_cast<const char*>(sfoot) + (PL ? 2 * splane : 0)))), 0, PL ? g.V * 512 : 0, 0x00020000);
-	auto load_chunk = [&](int q, u4 (&set)[NSET]) {
+	const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(sfoot)), 0, g.V * 1024, 0x00020000);
+	auto load_chunk = [&](int q, u4 (&set)[8]) {
 		const int r0 = q * 16 + 8 * srg;
-		if constexpr (PL) {
-			// plane p, row j: 8 bytes (columns 4 lane .. + 3); set[4 p + (j >> 1)] holds rows j (x, y) and j + 1 (z, w) for even j
 #pragma unroll
-			for (int p = 0; p < 3; ++p)
-#pragma unroll
-				for (int j = 0; j < 8; j += 2) {
-					const __amdgpu_buffer_rsrc_t& rs = p == 0 ? srsrc : (p == 1 ? srsrc2 : srsrc3);
-					const u2 a = __builtin_amdgcn_raw_buffer_load_b64(rs, c4 * 2, (r0 + j) * 512, 0);
-					const u2 b = __builtin_amdgcn_raw_buffer_load_b64(rs, c4 * 2, (r0 + j + 1) * 512, 0);
-					set[4 * p + (j >> 1)] = u4{a.x, a.y, b.x, b.y};
-				}
-		} else {
-#pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				set[j] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, c4 * 4, (r0 + j) * 1024, 0);
-			}
+		for (int j = 0; j < 8; ++j) {
+			set[j] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, c4 * 4, (r0 + j) * 1024, 0);
 		}
-	};
-	// planes: the LDS word (rows 2 jj, 2 jj + 1) of column e, plane p, from set[4 p + jj] = {row 2jj: (c0|c1, c2|c3), row 2jj+1: (c0|c1, c2|c3)}
-	auto pl_word = [](const u4& v, int e) -> unsigned {
-		const unsigned lo = (e < 2) ? v.x : v.y, hi = (e < 2) ? v.z : v.w;   // the word holding column e of the even row, of the odd row
-		return __builtin_amdgcn_perm(hi, lo, (e & 1) ? 0x07060302u : 0x05040100u);
 	};
 #define FIND_DW6_WAIT(set, n) ((void)0)
 	auto comp = [](const u4& v, int e) -> float { return __uint_as_float(e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w))); };
@@ -115,24 +84,8 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	// halves in place the fragment reads cost 9.6 cycles and the writes 16, swapped 7.6 - 8.0 and 13.2; conflict-free reads are 7.2)
 	const int wbase_h = sop * DW6_OPER + (srg ^ ((lane >> 2) & 1)) * 16;   // column 4 lane + e: bit 4 = bit 2 of the lane
 	// one column (e) of the staged rows: split, write the three planes; the bias sums count a chunk once (keep = 0 for a repeated store)
-	// the two bf16 of a word, summed in fp32 (v_dot2_f32_bf16 with (1, 1) would be one instruction -- and rounds: 3e-3 of a bias gradient)
-	auto pair_sum = [](unsigned wv) -> float { return __uint_as_float(wv << 16) + __uint_as_float(wv & 0xffff0000u); };
-	auto store_part = [&](char* buf, const u4 (&st)[NSET], int e, float keep) {
+	auto store_part = [&](char* buf, const u4 (&st)[8], int e, float keep) {
 		u32x4 p1, p2, p3;
-		if constexpr (PL) {
-			float t = 0.f;
-#pragma unroll
-			for (int jj = 0; jj < 4; ++jj) {
-				p1[jj] = pl_word(st[jj], e); p2[jj] = pl_word(st[4 + jj], e); p3[jj] = pl_word(st[8 + jj], e);
-				t += pair_sum(p1[jj]); t += pair_sum(p2[jj]); t += pair_sum(p3[jj]);
-			}
-			char* dst = buf + wbase_h + (((c4 + e) ^ (lane & 7)) * 32);
-			*reinterpret_cast<u32x4*>(dst) = p1;
-			*reinterpret_cast<u32x4*>(dst + DW6_PLANE) = p2;
-			*reinterpret_cast<u32x4*>(dst + 2 * DW6_PLANE) = p3;
-			if (e == 0) bsum.x += keep * t; else if (e == 1) bsum.y += keep * t; else if (e == 2) bsum.z += keep * t; else bsum.w += keep * t;
-			return;
-		}
 #pragma unroll
 		for (int jj = 0; jj < 4; ++jj) {
 			const Split2 s = split_pair(f32x2{comp(st[2 * jj], e), comp(st[2 * jj + 1], e)});
@@ -178,7 +131,7 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 			c.p[k][jj] = qv;
 			if (k < 2) c.r[jj] = c.r[jj] - f32x2{__uint_as_float(qv << 16), __uint_as_float(qv & 0xffff0000u)};
 		};
-		auto chunk_body = [&](int q, u4 (&set)[NSET]) {
+		auto chunk_body = [&](int q, u4 (&set)[8]) {
 			const char* buf = smem + cb * DW6_BUF;
 			char* other = smem + (cb ^ 1) * DW6_BUF;   // its readers finished before the last barrier
 			const float keep = (q + 1 < q1) ? bias_w : 0.f;
@@ -191,10 +144,8 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 			for (int tj = 0; tj < 4; ++tj) {
 				const int cu = tj & 1, nx = cu ^ 1;
 				ColSplit c;
-				if constexpr (!PL) {
 #pragma unroll
-					for (int jj = 0; jj < 4; ++jj) c.r[jj] = f32x2{comp(set[2 * jj], tj), comp(set[2 * jj + 1], tj)};
-				}
+				for (int jj = 0; jj < 4; ++jj) c.r[jj] = f32x2{comp(set[2 * jj], tj), comp(set[2 * jj + 1], tj)};
 				c.t = 0.f;
 #pragma unroll
 				for (int sl = 0; sl < 12; ++sl) {
@@ -207,15 +158,8 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 						acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[ti][tj], 0, 0, 0);
 					}
 					if (sl == 1 && tj + 1 < 4) { b1[nx] = frag(buf, xa, tj + 1, 0); b2[nx] = frag(buf, xa, tj + 1, 1); b3[nx] = frag(buf, xa, tj + 1, 2); }
-					if constexpr (PL) {
-						// stage sl: plane sl >> 2, row pair sl & 3: one permute regroups the pair's word; the bias sums take it as it is
-						const unsigned wv = pl_word(set[4 * (sl >> 2) + (sl & 3)], tj);
-						c.p[sl >> 2][sl & 3] = wv;
-						c.t += pair_sum(wv);
-					} else {
-						cs_stage(c, sl & 3, sl >> 2);
-						if (sl < 8) c.t += comp(set[sl], tj);   // (the bias sums: the dZ values as loaded, rows in order)
-					}
+					cs_stage(c, sl & 3, sl >> 2);
+					if (sl < 8) c.t += comp(set[sl], tj);   // (the bias sums: the dZ values as loaded, rows in order)
 					__builtin_amdgcn_sched_barrier(0);
 				}
 				{
@@ -261,11 +205,7 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 
 __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 256 fp32 accumulators in AGPRs + ~150 VGPRs: more than 256 registers (see the macro)
-	dw6_body<false>(g, blockIdx.x);
-}
-__global__ __launch_bounds__(256, 1) void dw6_planes_kernel(const Dw3Args g) {   // both operands stored as bf16 planes (dw6_body<true>)
-	FIND_CLAIM_WHOLE_REGISTER_FILE();
-	dw6_body<true>(g, blockIdx.x);
+	dw6_body(g, blockIdx.x);
 }
 
 // Several weight gradients of the same geometry in ONE launch (blockIdx.y = job), as dw4_group_kernel: the 256 x 256 layers of a small call
@@ -280,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void dw6_group_kernel(const Dw6Group grp) {
 	g.dz = grp.job[j].dz; g.dz_foot_stride = grp.job[j].dz_foot_stride; g.x = grp.job[j].x; g.x_foot_stride = grp.job[j].x_foot_stride;
 	g.V = grp.job[j].V; g.chunks_per_foot = grp.job[j].chunks_per_foot; g.spf = grp.job[j].spf; g.cps = grp.job[j].cps;
 	g.pw = grp.job[j].pw; g.pb = grp.job[j].pb;
-	dw6_body<false>(g, blockIdx.x);
+	dw6_body(g, blockIdx.x);
 }
 
 }  // namespace mlp

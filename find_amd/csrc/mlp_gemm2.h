@@ -36,7 +36,6 @@ struct Gemm2Args {
 	const float* w0;        // (256, ldw) K-contiguous weight of segment 0
 	const float* w1;
 	int ldw;
-	int64_t a_plane, y_plane;   // gemm7 planes modes (PL_A / PL_Y): bytes between the three bf16 planes of the activation operand / of the output
 	int w_tr;               // gemm7 only: w0 is the layer's weight as the model holds it, the launch multiplies by its transpose (W_eff[n][k] = w0[k * ldw + n])
 	int nchunk;             // 32-wide K chunks per segment
 	const float* bias;      // EPI_BIAS_RELU

@@ -38,13 +38,7 @@ constexpr int GEMM7_NW = 8;
 
 // ABL: profiling only (tools/ablate_x3.py; results are wrong under every bit): 1 = no split / LDS writes, 2 = no fragment reads after a unit's
 // first, 4 = no activation loads after the prologue, 8 = no stores
-// PL_A / PL_Y / PL_M ("planes", round 6; mlp.hip: use_planes): the activation operand, the output, the ReLU mask are STORED as their three
-// bf16 planes ([plane][row][256] bf16, 512 B per row and plane; plane stride a_plane / y_plane bytes) instead of fp32: the split is exact
-// (p1 + p2 + p3 == a), so nothing changes numerically -- but an element is then split ONCE, by the epilogue that produces it (36 VALU
-// instructions per unit and wave), instead of by every consumer (this kernel's two column halves: 72 per unit and wave each, and dw6), and
-// this kernel's staging becomes six 16-byte loads + six 16-byte LDS writes per thread and unit with no arithmetic at all (tools/ablate_x3.py:
-// without the split arithmetic and plane writes 60 of gemm7's 82 us).  The mask is the sign of plane 0 (8 bytes per lane instead of 16).
-template <int EPI, int ABL = 0, bool PL_A = false, bool PL_Y = false, bool PL_M = false>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args g) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x;
@@ -85,8 +79,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	// ---- staging: thread (wave w, lane l) loads the float4 at columns 4 l .. 4 l + 3 of rows 8 r + w, r = 0 .. 3, of a unit
 	typedef unsigned u4 __attribute__((ext_vector_type(4)));
 	typedef unsigned u2 __attribute__((ext_vector_type(2)));
-	constexpr int NS = PL_A ? 6 : 4;
-	u4 st[2][NS];   // two units in flight: a load is consumed two units later (HBM latency under load is 1-2 us, a unit takes ~1.5 us)
+	u4 st[2][4];   // two units in flight: a load is consumed two units later (HBM latency under load is 1-2 us, a unit takes ~1.5 us)
 	// (Tried: issuing the activation loads through inline asm with hand-counted s_waitcnt vmcnt(N), because the compiler starts every unit
 	// with vmcnt(0) -- it cannot count the loads in flight across the unit loop's back edge.  2 us here, and WRONG RESULTS in dw6, where the
 	// allocator moved such a register before its wait: a load the compiler does not know about is not safe.  The loads stay visible.)
@@ -94,32 +87,18 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	auto make_srd = [&](const float* base, int nbytes) -> __amdgpu_buffer_rsrc_t {
 		return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(base)), 0, nbytes, 0x00020000);
 	};
-	struct UnitSrc { __amdgpu_buffer_rsrc_t p[PL_A ? 3 : 1]; };
-	auto unit_rsrc = [&](int uu) -> UnitSrc {
+	auto unit_rsrc = [&](int uu) -> __amdgpu_buffer_rsrc_t {
 		// (a unit past the end of the range: size 0, every load comes back as zeros; so do the rows past the end of a foot)
 		const int ua = FIND_ABL(g.ablate, 512) ? u0 : uu;   // profiling only: every unit reads the range's first rows (served by L2)
 		const int foot = ua / upf;
 		const int v0 = (ua - foot * upf) * 32;
 		const int valid = uu < u1 ? min(32, V - v0) : 0;
-		UnitSrc r;
-		if constexpr (PL_A) {
-			const char* base = reinterpret_cast<const char*>(g.a0) + ((int64_t)foot * V + v0) * 512;
-#pragma unroll
-			for (int p = 0; p < 3; ++p) r.p[p] = make_srd(reinterpret_cast<const float*>(base + p * g.a_plane), valid * 512);
-		} else {
-			r.p[0] = make_srd(g.a0 + (int64_t)foot * g.a_foot_stride + (int64_t)v0 * lda, valid * lda * 4);
-		}
-		return r;
+		return make_srd(g.a0 + (int64_t)foot * g.a_foot_stride + (int64_t)v0 * lda, valid * lda * 4);
 	};
 	const int lvoff = lane * 16;
 	auto vm_load = [&](u4& dst, const __amdgpu_buffer_rsrc_t& srd, int voff, int soff) { dst = __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, 0); };
 #define FIND_VM_WAIT(reg, n) ((void)0)
-	// fp32 staging: slot r = the thread's float4 of row 8 r + wave.  Planes: slot 2 p + t = 16 bytes (8 columns) of plane p, row
-	// 2 wave + 16 t + (lane >> 5): a wave load covers two whole rows of a plane (1 KB contiguous).
-	auto load_row = [&](const UnitSrc& rs, u4 (&slot)[NS], int r) {
-		if constexpr (PL_A) vm_load(slot[r], rs.p[r >> 1], lvoff, (2 * wave + 16 * (r & 1)) * 512);
-		else vm_load(slot[r], rs.p[0], lvoff, (8 * r + wave) * lda * 4);
-	};
+	auto load_row = [&](const __amdgpu_buffer_rsrc_t& rs, u4 (&slot)[4], int r) { vm_load(slot[r], rs, lvoff, (8 * r + wave) * lda * 4); };
 	// Row 8 r + w of a unit goes to LDS as the thread's four values of every plane, one 8-byte word per plane.  The split of its two
 	// pairs is cut into pieces (RowSplit::stage) that the k loop places between its MFMAs.
 	struct RowSplit {
@@ -139,13 +118,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	auto write_plane = [&](char* buf, const RowSplit& q, int r, int k) {
 		*reinterpret_cast<u2*>(buf + wbase + r * (8 * G7_ROW) + k * G7_PLANE) = u2{q.p[0][k], q.p[1][k]};
 	};
-	// planes: slot r goes to LDS as it is (the LDS tile IS three row-major planes)
-	const int pbase = (2 * wave + (lane >> 5)) * G7_ROW + (lane & 31) * 16;
-	auto put_plane_slot = [&](char* buf, const u4 (&slot)[NS], int r) {
-		*reinterpret_cast<u4*>(buf + pbase + (r >> 1) * G7_PLANE + (r & 1) * (16 * G7_ROW)) = slot[r];
-	};
-	auto store_row = [&](char* buf, const u4 (&slot)[NS], int r) {   // (the prologue's unit: all at once)
-		if constexpr (PL_A) { put_plane_slot(buf, slot, r); return; }
+	auto store_row = [&](char* buf, const u4 (&slot)[4], int r) {   // (the prologue's unit: all at once)
 		RowSplit q;
 		q.begin(slot[r]);
 #pragma unroll
@@ -168,17 +141,17 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	};
 	{
 		load_bias(u0);
-		const UnitSrc r0 = unit_rsrc(u0);
+		const __amdgpu_buffer_rsrc_t r0 = unit_rsrc(u0);
 #pragma unroll
-		for (int r = 0; r < NS; ++r) load_row(r0, st[0], r);
-		const UnitSrc r1 = unit_rsrc(u0 + 1);
+		for (int r = 0; r < 4; ++r) load_row(r0, st[0], r);
+		const __amdgpu_buffer_rsrc_t r1 = unit_rsrc(u0 + 1);
 #pragma unroll
-		for (int r = 0; r < NS; ++r) load_row(r1, st[1], r);
+		for (int r = 0; r < 4; ++r) load_row(r1, st[1], r);
 #pragma unroll
-		for (int r = 0; r < NS; ++r) { FIND_VM_WAIT(st[0][r], 4); store_row(smem, st[0], r); }   // (the loads of unit u0 + 1 may stay in flight)
-		const UnitSrc r2 = unit_rsrc(u0 + 2);
+		for (int r = 0; r < 4; ++r) { FIND_VM_WAIT(st[0][r], 4); store_row(smem, st[0], r); }   // (the four loads of unit u0 + 1 may stay in flight)
+		const __amdgpu_buffer_rsrc_t r2 = unit_rsrc(u0 + 2);
 #pragma unroll
-		for (int r = 0; r < NS; ++r) load_row(r2, st[0], r);
+		for (int r = 0; r < 4; ++r) load_row(r2, st[0], r);
 	}
 
 	int cb = 0;
@@ -196,41 +169,20 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		}
 		acc[0] = t; acc[1] = t;
 	};
-	struct OutTile { __amdgpu_buffer_rsrc_t y, m, y2, y3; };
+	struct OutTile { __amdgpu_buffer_rsrc_t y, m; };
 	auto out_tile = [&](int uq) -> OutTile {
 		const int uu = FIND_ABL(g.ablate, 1024) ? u0 : uq;   // profiling only: every unit's block goes to the range's first rows
 		const int foot = uu / upf;
 		const int v0 = (uu - foot * upf) * 32;
 		const int nbytes = min(32, V - v0) * ldy * 4;
-		const int pbytes = min(32, V - v0) * 512;
 		OutTile t;
-		if constexpr (PL_Y) {
-			char* base = reinterpret_cast<char*>(g.y) + ((int64_t)foot * V + v0) * 512;
-			t.y = make_srd(reinterpret_cast<const float*>(base), pbytes);
-			t.y2 = make_srd(reinterpret_cast<const float*>(base + g.y_plane), pbytes);
-			t.y3 = make_srd(reinterpret_cast<const float*>(base + 2 * g.y_plane), pbytes);
-		} else {
-			t.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy)), 0, nbytes, 0x00020000);
-			t.y2 = t.y; t.y3 = t.y;
-		}
+		t.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy)), 0, nbytes, 0x00020000);
 		t.m = t.y;
-		if constexpr (EPI == EPI_MASK) {
-			if constexpr (PL_M) t.m = make_srd(reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.mask) + ((int64_t)foot * V + v0) * 512), pbytes);   // plane 0: the sign
-			else t.m = make_srd(g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy, nbytes);
-		}
+		if constexpr (EPI == EPI_MASK) t.m = make_srd(g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy, nbytes);
 		return t;
 	};
 	const int ovoff = (i16 * ldy + col0 + 4 * h4) * 4;
-	const int opoff = i16 * 512 + (col0 + 4 * h4) * 2;   // the same four columns of a row in a plane
 	u4 mv[2];
-	auto load_mask = [&](const OutTile& t, int rb) {
-		if constexpr (PL_M) {
-			const u2 m2 = __builtin_amdgcn_raw_buffer_load_b64(t.m, opoff, rb * 16 * 512, 0);
-			mv[rb] = u4{m2.x << 16, m2.x & 0xffff0000u, m2.y << 16, m2.y & 0xffff0000u};   // the four bf16 first pieces as floats: same sign and zero-ness as the values
-		} else {
-			vm_load(mv[rb], t.m, ovoff, rb * 16 * ldy * 4);
-		}
-	};
 	auto store_block = [&](const OutTile& t, int rb) {
 		float v[4];
 #pragma unroll
@@ -239,34 +191,26 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			if constexpr (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
 			if constexpr (EPI == EPI_MASK) v[e] = (__uint_as_float(mv[rb][e]) > 0.f) ? v[e] : 0.f;
 		}
-		if constexpr (PL_Y) {
-			// the block leaves as its three planes: 8 bytes each (64-bit stores: outside the store-data hazard of common.h)
-			const Split2 q0 = split_pair(f32x2{v[0], v[1]}), q1 = split_pair(f32x2{v[2], v[3]});
-			__builtin_amdgcn_raw_buffer_store_b64(u2{q0.p1, q1.p1}, t.y, opoff, rb * 16 * 512, 0);
-			__builtin_amdgcn_raw_buffer_store_b64(u2{q0.p2, q1.p2}, t.y2, opoff, rb * 16 * 512, 0);
-			__builtin_amdgcn_raw_buffer_store_b64(u2{q0.p3, q1.p3}, t.y3, opoff, rb * 16 * 512, 0);
-		} else {
-			store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4);   // (no SGPR offset: common.h)
-		}
+		store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4);   // (no SGPR offset: common.h)
 	};
 	auto mm = [&](const bf16x8& w, const bf16x8& x, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0); };
 
 	// Unit u: multiply it (buffer cb).  Under its 96 MFMAs: split and store unit u + 1 from `slot` (one PAIR of values per k-step: nine
 	// VALU instructions against twelve MFMAs), refill `slot` with unit u + 3, store the previous unit's blocks (`first`: there is none).
-	auto unit_body = [&](int u, u4 (&slot)[NS], bool first) {
+	auto unit_body = [&](int u, u4 (&slot)[4], bool first) {
 		const unsigned long long tb0 = FIND_DBG(g.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
 		lds_barrier();   // unit u is complete in buffer cb; nobody reads buffer cb ^ 1 (unit u - 1) any more (the loads in flight stay in flight)
 		const unsigned long long tb1 = FIND_DBG(g.dbg) ? __builtin_amdgcn_s_memtime() : 0ull;
 		const char* buf = smem + cb * G7_BUF;
 		char* other = smem + (cb ^ 1) * G7_BUF;
-		const UnitSrc rs2 = unit_rsrc(u + 3);
+		const __amdgpu_buffer_rsrc_t rs2 = unit_rsrc(u + 3);
 		const OutTile prev = out_tile(first ? u : u - 1);
 		pend[0] = acc[0]; pend[1] = acc[1];
 		init_acc();
 		load_bias(u + 1);
 		if constexpr (EPI == EPI_MASK) {
-			load_mask(prev, 0);
-			load_mask(prev, 1);
+			vm_load(mv[0], prev.m, ovoff, 0);
+			vm_load(mv[1], prev.m, ovoff, 16 * ldy * 4);
 		}
 		bf16x8 a1[2][2], a2[2][2], a3[2][2];   // [buffer][row block]
 #pragma unroll
@@ -294,15 +238,15 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			// VMEM operations behind the load of slot[row] when it is needed (buffer loads and stores complete in order): the rest of its own
 			// unit's, those of the unit after it and this unit's so far -- at least 7 in every unit of the pipeline (10-11 in the steady
 			// state: two units of loads stay in flight)
-			if constexpr (!PL_A) { if (h == 0 && !(ABL & 1)) { FIND_VM_WAIT(slot[row], 7); q.begin(slot[row]); } }
+			if (h == 0 && !(ABL & 1)) { FIND_VM_WAIT(slot[row], 7); q.begin(slot[row]); }
 			// smallest terms first
 			mm(B1[s], a3[cu][0], acc[0]); mm(B1[s], a3[cu][1], acc[1]);
-			if constexpr (!(ABL & 1) && !PL_A) q.stage(h, 0);
+			if constexpr (!(ABL & 1)) q.stage(h, 0);
 			__builtin_amdgcn_sched_barrier(0);
 			mm(B3[s], a1[cu][0], acc[0]); mm(B3[s], a1[cu][1], acc[1]);
 			__builtin_amdgcn_sched_barrier(0);
 			mm(B2[s], a2[cu][0], acc[0]); mm(B2[s], a2[cu][1], acc[1]);
-			if constexpr (!(ABL & 1) && !PL_A) q.stage(h, 1);
+			if constexpr (!(ABL & 1)) q.stage(h, 1);
 			__builtin_amdgcn_sched_barrier(0);
 			mm(B1[s], a2[cu][0], acc[0]); mm(B1[s], a2[cu][1], acc[1]);
 			if (h == 1 && !first && s >= 4 && !(ABL & 8)) {
@@ -311,13 +255,10 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			}
 			__builtin_amdgcn_sched_barrier(0);
 			mm(B2[s], a1[cu][0], acc[0]); mm(B2[s], a1[cu][1], acc[1]);
-			if constexpr (!(ABL & 1) && !PL_A) q.stage(h, 2);
+			if constexpr (!(ABL & 1)) q.stage(h, 2);
 			__builtin_amdgcn_sched_barrier(0);
 			mm(B1[s], a1[cu][0], acc[0]); mm(B1[s], a1[cu][1], acc[1]);
-			if constexpr (PL_A) {
-				// planes: slot s of unit u + 1 goes to LDS as it is, then refills with unit u + 3 (k-steps 0 .. 5: six slots)
-				if (s < 6) { put_plane_slot(other, slot, s); load_row(rs2, slot, s); }
-			} else if (h == 1) {
+			if (h == 1) {
 				if constexpr (!(ABL & 1)) { write_plane(other, q, row, 0); write_plane(other, q, row, 1); write_plane(other, q, row, 2); }
 				if constexpr (!(ABL & 4)) load_row(rs2, slot, row);   // unit u + 3: on its way for two units
 			}
@@ -338,8 +279,9 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		const OutTile last = out_tile(u1 - 1);
 		pend[0] = acc[0]; pend[1] = acc[1];
 		if constexpr (EPI == EPI_MASK) {
-			load_mask(last, 0);
-			load_mask(last, 1);
+			vm_load(mv[0], last.m, ovoff, 0);
+			vm_load(mv[1], last.m, ovoff, 16 * ldy * 4);
+			FIND_VM_WAIT(mv[0], 0); FIND_VM_WAIT(mv[1], 0);
 		}
 		store_block(last, 0); store_block(last, 1);
 	}

@@ -81,8 +81,6 @@ struct GemmArgs {
 	const float* w0;        // (256, ldw), K contiguous
 	const float* w1;
 	int ldw;
-	int pl_a, pl_y, pl_m;   // host side (launch_gemm -> gemm7): the activation operand / the output / the mask are stored as bf16 planes (mlp.hip: use_planes)
-	int64_t a_plane, y_plane;   // ... bytes between their planes
 	int w_tr;               // host side (launch_gemm): w0 is untransposed and the launch goes to gemm7, which reads it transposed (linear_bwd_dx)
 	int nchunk;             // 32-wide K chunks per segment
 	const float* bias;      // EPI_BIAS_RELU: (.., 256)
@@ -417,29 +415,6 @@ __device__ __forceinline__ float4 ld4_any(const void* base, int64_t elem, int ha
 	}
 	return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
 }
-// "planes" (round 6; mlp.hip: use_planes): an fp32 tensor stored as its three bf16 planes, [plane][row][256] bf16: a = p1 + p2 + p3 EXACTLY
-// (p1 = bf16(a), p2 = bf16(a - p1), p3 = bf16(a - p1 - p2), round to nearest: mlp_gemm6.h), so the bf16x3 matrix kernels read their
-// operands as stored and nothing changes numerically.  Four consecutive elements -> 8 bytes in each plane.
-__device__ __forceinline__ unsigned find_bf16_rn(float x) {   // round to nearest even, as v_cvt_pk_bf16_f32 (finite inputs)
-	const unsigned u = __float_as_uint(x);
-	return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void st4_planes(void* base, int64_t plane_bytes, int64_t elem, const float4& v) {
-	const float a[4] = {v.x, v.y, v.z, v.w};
-	unsigned p[3][4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		float r = a[i];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			p[k][i] = find_bf16_rn(r);
-			r -= __uint_as_float(p[k][i] << 16);
-		}
-	}
-	char* q = reinterpret_cast<char*>(base) + elem * 2;
-#pragma unroll
-	for (int k = 0; k < 3; ++k) *reinterpret_cast<uint2*>(q + k * plane_bytes) = make_uint2(p[k][0] | (p[k][1] << 16), p[k][2] | (p[k][3] << 16));
-}
 __device__ __forceinline__ void st4_any(void* base, int64_t elem, int half, const float4& v) {
 	if (half) *reinterpret_cast<find_h4*>(reinterpret_cast<_Float16*>(base) + elem) = find_h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
 	else *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
@@ -647,7 +622,7 @@ __global__ __launch_bounds__(256) void latent_grad_kernel(const float* Wfull, in
 // once per group instead of once per foot; the writes are the traffic: n_feet * V * 1 KB).
 constexpr int BCAST_FEET = 4;
 __global__ __launch_bounds__(256) void bias_relu_bcast_kernel(const float* __restrict__ P, const float* __restrict__ bias, int64_t bias_foot_stride,
-															   int n_feet, int64_t V, float* __restrict__ out, int out_half /* 0 fp32, 1 fp16, 2 bf16 planes */, int64_t plane_bytes) {
+															   int n_feet, int64_t V, float* __restrict__ out, int out_half) {
 	const int64_t per_foot = V * (W / 4);
 	const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= per_foot) return;
@@ -661,8 +636,7 @@ __global__ __launch_bounds__(256) void bias_relu_bcast_kernel(const float* __res
 		const float4 b = *reinterpret_cast<const float4*>(bias + foot * bias_foot_stride + c4 * 4);
 		float4 o;
 		o.x = fmaxf(p.x + b.x, 0.f); o.y = fmaxf(p.y + b.y, 0.f); o.z = fmaxf(p.z + b.z, 0.f); o.w = fmaxf(p.w + b.w, 0.f);
-		if (out_half == 2) st4_planes(out, plane_bytes, (foot * per_foot + r) * 4, o);
-		else st4_any(out, (foot * per_foot + r) * 4, out_half, o);
+		st4_any(out, (foot * per_foot + r) * 4, out_half, o);
 	}
 }
 
@@ -823,8 +797,6 @@ struct HeadOutBwdArgs {
 	float* pb[2];          // [gridDim.x][4]
 	int64_t rows;
 	int half;              // y and dy are stored as fp16 (act16)
-	int dy_planes;         // dy is stored as bf16 planes (use_planes); y stays fp32
-	int64_t plane_bytes;
 };
 
 template <int U>   // rows in flight per wave: 4, or 8 for fp16-stored tensors (half the bytes per row: twice the rows for the same bytes in flight)
@@ -876,8 +848,7 @@ __device__ __forceinline__ void head_out_bwd_body(const HeadOutBwdArgs& g) {
 			o.y = (yv[u].y > 0.f) ? d0 * w0.y + d1 * w1.y + d2 * w2.y : 0.f;
 			o.z = (yv[u].z > 0.f) ? d0 * w0.z + d1 * w1.z + d2 * w2.z : 0.f;
 			o.w = (yv[u].w > 0.f) ? d0 * w0.w + d1 * w1.w + d2 * w2.w : 0.f;
-			if (g.dy_planes) st4_planes(dy, g.plane_bytes, row * W + lane * 4, o);
-			else st4_any(dy, row * W + lane * 4, g.half, o);
+			st4_any(dy, row * W + lane * 4, g.half, o);
 			aw0.x += d0 * yv[u].x; aw0.y += d0 * yv[u].y; aw0.z += d0 * yv[u].z; aw0.w += d0 * yv[u].w;
 			aw1.x += d1 * yv[u].x; aw1.y += d1 * yv[u].y; aw1.z += d1 * yv[u].z; aw1.w += d1 * yv[u].w;
 			aw2.x += d2 * yv[u].x; aw2.y += d2 * yv[u].y; aw2.z += d2 * yv[u].z; aw2.w += d2 * yv[u].w;
