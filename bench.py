@@ -817,27 +817,15 @@ def c2_record(run, steps, warmup, n_verts=None, fp16=False, with_cpu=False, dp_o
 
 
 # ------------------------------------------------------------------------------------------------ C3 / C4 (BASELINE configs[2], [3])
-def c3_record_uniform_meshes(run, steps, warmup, c4=False):
-	"""The C3 / C4 step on uniformly triangulated meshes (find_amd.synthetic.MESH_KIND = 'uniform': valence 5 - 7 everywhere) instead of the
-	latitude-longitude grids all other numbers are taken on, whose poles put thousands of sliver faces into single tiles: what the
-	rasteriser's time is on meshes shaped like FIND's template and decimated scans.  Extra information, not the configuration's number:
-	tools/c3_uniform.py prints it beside the configuration's own (not a record of the bench line)."""
-	from find_amd import synthetic
-	prev = synthetic.MESH_KIND
-	synthetic.MESH_KIND = 'uniform'
-	try:
-		rec = c3_record(run, steps, warmup, False, c4=c4)
-	finally:
-		synthetic.MESH_KIND = prev
-	rec['config']['workload'] += '; UNIFORM triangulations (Fibonacci-sphere hulls) instead of the latitude-longitude grids of the configuration\'s own record'
-	return rec
-
-
-def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=False):
+def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=False, mesh='uniform'):
 	"""BASELINE.json configs[2] (and, with c4=True, the per-rank share of configs[3]: 16 of the 128 feet, 4 views @512^2, silhouette + pixel +
 	Chamfer losses).  configs[2]: a batch of 16 feet x 4 views @256^2 with the silhouette render loss, end to end -- MLP query,
 	registration, GT and predicted renders (the GT is re-rendered every step, as the reference does), silhouette loss, backward
-	through rasteriser and MLP, optimiser step."""
+	through rasteriser and MLP, optimiser step.
+	mesh: the triangulation of template and GT scans (find_amd.synthetic.MESH_KIND).  'uniform' (the record `c3` / `c4_rank_share`): Fibonacci-
+	sphere hulls, valence 5 - 7 everywhere -- what FIND's template and decimated scans look like to a rasteriser.  'latlong' (the records
+	`*_latlong_stress`): latitude-longitude grids whose two poles put thousands of sliver faces into single tiles -- the binning's worst case,
+	and what rounds 1 - 5 quoted as the configuration's number."""
 	import numpy as np
 	from find_amd import distributed as fdist
 	from find_amd import optim, synthetic
@@ -848,10 +836,14 @@ def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=F
 	if c4:
 		size = 512
 	opts = Opts(sil_loss=True, pix_loss=c4, chamf_loss=c4, num_views=n_views)
-	mwl = make_mwl(dev, n_feet, opts, size=size)
-	m = mwl.model
-	fill_latents(m, n_feet, run.rank, dev)
-	gv, gf, gc = synthetic.gt_feet(n_feet, N_GT_VERTS, seed=run.rank, device=dev)
+	prev_kind, synthetic.MESH_KIND = synthetic.MESH_KIND, mesh
+	try:
+		mwl = make_mwl(dev, n_feet, opts, size=size)
+		m = mwl.model
+		fill_latents(m, n_feet, run.rank, dev)
+		gv, gf, gc = synthetic.gt_feet(n_feet, N_GT_VERTS, seed=run.rank, device=dev)
+	finally:
+		synthetic.MESH_KIND = prev_kind
 	batch = dict(mesh=Meshes(gv, gf, TexturesVertex(gc.clamp(0.05, 0.95))), idx=torch.arange(n_feet, device=dev), name=[f'{i:04d}' for i in range(n_feet)])
 	np.random.seed(7)
 	R, T = mwl.rdr.sample_views(nviews=n_views, dist_mean=0.3, dist_std=0, elev_min=-90, elev_max=90, azim_min=-90, azim_max=90)
@@ -875,8 +867,9 @@ def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=F
 
 	ms = run.timed(step, steps, warmup)
 	cfg = {'workload': f'{"C4 rank share" if c4 else "C3"}: {n_feet} feet x {n_views} views @{size}^2 per GPU, {N_VERTS}-vertex template, {N_GT_VERTS}-vertex GT '
-					   f'scans re-rendered every step, {"sil+pix+chamf losses" if c4 else "silhouette loss"}, backward through rasteriser + MLP, Adam step',
-		   'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{run.world}'}
+					   f'scans re-rendered every step, {"sil+pix+chamf losses" if c4 else "silhouette loss"}, backward through rasteriser + MLP, Adam step; '
+					   + ('uniform triangulations (Fibonacci-sphere hulls, F = 2V - 4)' if mesh == 'uniform' else 'latitude-longitude grids (pole slivers: binning stress case)'),
+		   'mesh': mesh, 'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{run.world}'}
 	out = line(run.world * n_feet * N_VERTS * n_views / (ms * 1e-3), ms, run, steps, warmup, cfg)
 	if bucket is not None:
 		bucket.close()
@@ -1077,6 +1070,7 @@ def main():
 	ap.add_argument('--c3', action='store_true', help='instead of the headline line: BASELINE configs[2] end to end (16 feet x 4 views @256^2, silhouette render loss)')
 	ap.add_argument('--c5', action='store_true', help='BASELINE configs[4] geometry: the C2 workload on the 50 002-vertex dense template (fp32 unless --fp16)')
 	ap.add_argument('--fp16', action='store_true', help="opt-in reduced precision (find_amd.functional.set_mlp_precision('fp16')): the 256->256 layers on the fp16 matrix pipe with fp32 accumulation -- BASELINE configs[4] with --c5; NOT the parity path, never the default line")
+	ap.add_argument('--mesh', default='uniform', choices=('uniform', 'latlong'), help='--c3 / --c4: triangulation of template and scans (latlong: the pole-sliver stress case)')
 	ap.add_argument('--c4', action='store_true', help='per-rank share of BASELINE configs[3]: 16 feet x 4 views @512^2, silhouette + pixel + Chamfer losses')
 	ap.add_argument('--dp-overhead', action='store_true', help='diagnostic: run the C2 step on ONE GPU through the data-parallel code path (one-rank RCCL group, gradient bucket + all-reduce)')
 	ap.add_argument('--subpaths', action='store_true', help='instead of the headline line: one JSON line per render / Chamfer / smoothness sub-path (SURVEY 8d), CPU oracle timed beside each')
@@ -1108,7 +1102,7 @@ def main():
 			emit(out)
 		return run.finish()
 	if args.c3 or args.c4:
-		out = c3_record(run, args.steps, args.warmup, with_cpu, c4=args.c4)
+		out = c3_record(run, args.steps, args.warmup, with_cpu, c4=args.c4, mesh=args.mesh)
 		if run.rank == 0:
 			emit(out)
 		return run.finish()
@@ -1181,6 +1175,9 @@ def main():
 			add('c3', brief(c3_record(run, 20, 3, with_cpu)))
 			note('record c4_rank_share')
 			add('c4_rank_share', brief(c3_record(run, 10, 3, False, c4=True)))
+			note('records *_latlong_stress')
+			add('c3_latlong_stress', brief(c3_record(run, 20, 3, False, mesh='latlong')))
+			add('c4_rank_share_latlong_stress', brief(c3_record(run, 10, 3, False, c4=True, mesh='latlong')))
 			note('record c5')
 			add('c5_fp32', brief(c2_record(run, 10, 3, n_verts=50002), 'step_tflops_executed', 'step_frac_of_fp32_mfma_peak_executed'))
 			add('c5_fp16', brief(c2_record(run, 10, 3, n_verts=50002, fp16=True), 'step_tflops_executed'))

@@ -40,7 +40,7 @@ def ellipsoid_mesh(rings, segs, axes=(0.12, 0.045, 0.04)):
 # latitude-longitude grid -- its two poles are vertices of valence `segs` (82 on the template, 100 on the GT scans), and on a 256^2 render
 # the hundred-odd slivers around a pole put 2 - 3 thousand faces into single 8 x 8 tiles.  'uniform': a Fibonacci sphere triangulated by its
 # convex hull (valence 5 - 7 everywhere, the same V and F = 2 V - 4): what a decimated scan or FIND's own template looks like to a rasteriser.
-# bench.py reports the render configurations on both (records *_uniform_meshes).
+# bench.py reports the render configurations on both: 'uniform' is the record c3 / c4_rank_share, 'latlong' the records *_latlong_stress.
 MESH_KIND = 'latlong'
 
 

@@ -62,7 +62,7 @@ def test_the_drivers_exact_command_gives_one_short_parsable_line():
 	for k in ('value', 'unit', 'cores', 'kind', 'sample'):
 		assert k in d['cpu_baseline'], k
 	assert len(d['config']['workload']) <= 200 and 'records_error' not in d
-	names = {'train3d_b16_eager_colour_head', 'fp32_mfma', 'train3d_b1', 'train3d_b1_graph', 'c2', 'c3', 'c4_rank_share', 'c5_fp32', 'c5_fp16'}
+	names = {'train3d_b16_eager_colour_head', 'fp32_mfma', 'train3d_b1', 'train3d_b1_graph', 'c2', 'c3', 'c4_rank_share', 'c3_latlong_stress', 'c4_rank_share_latlong_stress', 'c5_fp32', 'c5_fp16'}
 	assert names <= set(d['records']), sorted(d['records'])
 	assert all(len(v) == 2 and v[0] > 0 and v[1] > 0 for v in d['records'].values())
 	full = json.load(open(os.path.join(ROOT, d['records_file'])))
