@@ -12,6 +12,7 @@ finishes in a second or two and reach the full configurations by composition; he
 
 Bounds: floats 1e-4 (gradients relative to the tensor's largest entry); index maps exact or a proven edge tie; the K-nearest silhouette
 outside float64-proved depth ties at the K-th place, as tests/test_gpu_render.py does."""
+import json
 import os
 import sys
 import types
@@ -206,6 +207,14 @@ def _assert_grad(errs, order, what):
 	e64, e32o, e32, e64_pinned, n_unpinned, n = errs
 	report = dict(hip_vs_float64=e64, hip_vs_float64_where_fp32_pins=e64_pinned, entries_fp32_does_not_pin=n_unpinned, entries=n, hip_vs_fp32_oracle=e32,
 				  fp32_oracle_vs_float64=e32o, fp32_summation_order_term=order)
+	print('measured', what, report)
+	try:   # kept beside the GPU run's other outputs (profiles/rNN_measured_bounds.jsonl is a copy of it)
+		d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+		if os.path.isdir(d):
+			with open(os.path.join(d, 'measured_bounds.jsonl'), 'a') as f:
+				f.write(json.dumps(dict(test=what, **{k: float(v) for k, v in report.items()})) + '\n')
+	except OSError:
+		pass
 	assert e64_pinned < TOL and e64 < 5e-4 and n_unpinned < 1e-3 * n, (what, report)
 
 
