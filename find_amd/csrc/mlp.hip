@@ -128,7 +128,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_GEMM5_RELU_V, K_GEMM5_MASK_V, K_DW3_V, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -185,9 +185,10 @@ struct find_ctx {
 	bool attr_done[K_COUNT] = {};
 	// how the last forward calls that saved a workspace stored the heads' activations (act16): the backward of a workspace follows its
 	// forward's decision even if a knob was turned in between (ring of the last 16; a workspace not found falls back to the rule)
-	struct Act16Note { const void* ws; bool a16; };
+	struct Act16Note { const void* ws; bool a16; bool fold; };
 	Act16Note act16_notes[16] = {};
 	int act16_next = 0;
+	int bcast_fold = 1;           // knob: inside act16 the broadcast first head layer's output is formed by its readers instead of stored (use_fold)
 	int act16 = 1;                // knob: in the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large
 	                              // shared-template shapes (use_act16): those layers are HBM-bound, and the matrix pipe rounds them to fp16 anyway
 	int defer_join = 0;           // knob, read by the next find_mlp_bwd: leave the weight-gradient side streams running behind the call (find_hip.h)
@@ -391,21 +392,25 @@ static int launch_gemm4(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, 
 	return launch_gemm4_t<EPI_NONE, NI>(c, a, feet, s);
 }
 
-template <int EPI, bool H16 = false>
+template <int EPI, bool H16 = false, bool VIRT = false>
 static int launch_gemm5_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {
 	int lds = 0;
-	const int id = H16 ? (EPI == EPI_BIAS_RELU ? K_GEMM5_RELU_H : K_GEMM5_MASK_H) : K_GEMM5_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2);
-	const int rc = prepare_kernel(c, id, &gemm5_kernel<EPI, H16>, GEMM5_LDS, &lds);
+	const int id = VIRT ? (EPI == EPI_BIAS_RELU ? K_GEMM5_RELU_V : K_GEMM5_MASK_V)
+				 : H16 ? (EPI == EPI_BIAS_RELU ? K_GEMM5_RELU_H : K_GEMM5_MASK_H) : K_GEMM5_RELU + (EPI == EPI_BIAS_RELU ? 0 : EPI == EPI_MASK ? 1 : 2);
+	const int rc = prepare_kernel(c, id, &gemm5_kernel<EPI, H16, VIRT>, VIRT ? GEMM5_LDS_VIRT : GEMM5_LDS, &lds);
 	if (rc != FIND_OK) return rc;
 	a.tiles_per_foot = (int)cdiv(a.V, 32);
 	a.ntiles = (int)(a.tiles_per_foot * feet);
+	a.tile_major = VIRT ? 1 : 0;   // the feet of a tile side by side: the shared product behind the virtual operand is read from HBM once
 	const int grid = (int)std::min<int64_t>(c->num_cus, cdiv(a.ntiles, GEMM5_NW));
-	hipLaunchKernelGGL((gemm5_kernel<EPI, H16>), dim3(grid), dim3(GEMM5_NW * 64), lds, s, a);
+	hipLaunchKernelGGL((gemm5_kernel<EPI, H16, VIRT>), dim3(grid), dim3(GEMM5_NW * 64), lds, s, a);
 	return FIND_OK;
 }
 
 static int launch_gemm5(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s, bool h16) {
 	if (h16) {   // fp16-stored A / y / mask (act16): the two epilogues the heads' hidden layers use
+		if (epi == EPI_BIAS_RELU && a.va_bias) return launch_gemm5_t<EPI_BIAS_RELU, true, true>(c, a, feet, s);   // (bcast_fold: mlp_gemm5.h)
+		if (epi == EPI_MASK && a.vm_bias) return launch_gemm5_t<EPI_MASK, true, true>(c, a, feet, s);
 		if (epi == EPI_BIAS_RELU) return launch_gemm5_t<EPI_BIAS_RELU, true>(c, a, feet, s);
 		if (epi == EPI_MASK) return launch_gemm5_t<EPI_MASK, true>(c, a, feet, s);
 		set_error("launch_gemm5: no fp16-stored variant of this epilogue");
@@ -497,12 +502,14 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	b.w0 = a.w0; b.w1 = a.w1; b.ldw = a.ldw; b.nchunk = a.nchunk; b.w_tr = a.w_tr;
 	b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
 	b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = c->ablate; b.dbg = c->dbg;
+	b.va_bias = a.va_bias; b.va_bias_stride = a.va_bias_stride; b.vm_bias = a.vm_bias; b.vm_bias_stride = a.vm_bias_stride;
 	if (amode == AMODE_PE) return launch_gemm2_pe(c, b, feet, s);
 	const int64_t units = cdiv(a.V, 32) * feet;
 	const bool k256 = b.nseg == 1 && b.nchunk == 8;
 	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
 	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s, a.h16 != 0);
 	FIND_REQUIRE(!a.h16, "launch_gemm: an fp16-stored layer reached a kernel that reads fp32 (act16 and the kernel selection disagree)");
+	FIND_REQUIRE(!a.va_bias && !a.vm_bias, "launch_gemm: a virtual operand reached a kernel that cannot form it (bcast_fold and the kernel selection disagree)");
 #ifdef FIND_DIAG
 	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
 #endif
@@ -627,9 +634,11 @@ static GemmArgs gemm_args_zero() {
 
 // Linear + ReLU forward:  y = relu(x @ w^T + bias[foot])
 static int linear_fwd(find_ctx* c, const float* x, int64_t x_foot_stride, const float* w, int ldw, const float* bias,
-					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
+					  int64_t bias_foot_stride, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false, const float* va_bias = nullptr,
+					  int64_t va_bias_stride = 0) {
 	GemmArgs a = gemm_args_zero();
 	a.h16 = h16;
+	a.va_bias = va_bias; a.va_bias_stride = va_bias_stride;   // (then x is the shared fp32 product and x_foot_stride 0: bcast_fold)
 	a.a0 = x; a.a_foot_stride = x_foot_stride; a.lda = W;
 	a.w0 = w; a.ldw = ldw; a.nchunk = W / KC;
 	a.bias = bias; a.bias_foot_stride = bias_foot_stride;
@@ -651,14 +660,18 @@ static void split_policy(int64_t n_feet, int64_t V, int* spf, int* cps, int64_t 
 static bool use_act16(const find_ctx* c, bool f16, bool shared, int64_t n_feet, int64_t V) {
 	return f16 && c->act16 && shared && n_feet > 1 && cdiv(V, 32) * n_feet >= c->gemm5_min_units;
 }
-static void note_act16(find_ctx* c, const void* ws, bool a16) {
-	for (auto& n : c->act16_notes) if (n.ws == ws) { n.a16 = a16; return; }
-	c->act16_notes[c->act16_next] = find_ctx::Act16Note{ws, a16};
+// bcast_fold (round 6): inside act16 the output of a head's broadcast first layer, h1 = fp16(relu(P[v] + bias[foot])), is never stored: its
+// three readers (the second layer's forward GEMM, the ReLU mask of that layer's dX GEMM, the x operand of its weight gradient) form it from the
+// V x 256 product P (w.hp / w.hp2, kept until the backward) and the bias rows -- gemm5_kernel<.., VIRT>, dw3_h16v_kernel.  Needs a second hidden layer.
+static bool use_fold(const find_ctx* c, bool a16, const find_mlp_params* p) { return a16 && c->bcast_fold && p->n_disp >= 2 && p->n_col >= 2; }
+static void note_act16(find_ctx* c, const void* ws, bool a16, bool fold) {
+	for (auto& n : c->act16_notes) if (n.ws == ws) { n.a16 = a16; n.fold = fold; return; }
+	c->act16_notes[c->act16_next] = find_ctx::Act16Note{ws, a16, fold};
 	c->act16_next = (c->act16_next + 1) & 15;
 }
-static bool noted_act16(const find_ctx* c, const void* ws, bool by_rule) {
-	for (const auto& n : c->act16_notes) if (n.ws == ws) return n.a16;
-	return by_rule;
+static int noted_act16(const find_ctx* c, const void* ws, bool by_rule, bool fold_by_rule) {   // bit 0: act16, bit 1: bcast_fold
+	for (const auto& n : c->act16_notes) if (n.ws == ws) return (n.a16 ? 1 : 0) | (n.fold ? 2 : 0);
+	return (by_rule ? 1 : 0) | (fold_by_rule ? 2 : 0);
 }
 
 static bool call_f16(const find_ctx* c, const find_mlp_params* p) { return p->precision == 2 || (p->precision == 0 && c->mlp_f16 == 1); }
@@ -670,7 +683,8 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
-	note_act16(c, w.fbd, a16);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
+	const bool fold = use_fold(c, a16, p);
+	note_act16(c, w.fbd, a16, fold);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
 
 	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers.  Not for a bf16x3 chain that carries the
 	// whole call (or everything up to the heads' broadcast first layers): its weight split reads the model's tensors directly (round 6: this
@@ -725,7 +739,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 		if (!fused_heads) {
 			// shared template: the first layer of each head is H W0^T on the V template rows (bias + ReLU are broadcast per foot below)
 			if (disp) { FusedStep& st = ch.gemm(wd0, ldd0, W / KC); st.dst = w.hp; }
-			if (col) { FusedStep& st = ch.gemm(wc0, ldc0, W / KC); st.dst = disp ? w.hp2 : w.hp; }
+			if (col) { FusedStep& st = ch.gemm(wc0, ldc0, W / KC); st.dst = (disp || fold) ? w.hp2 : w.hp; }
 		} else {
 			auto head = [&](int which, float* const* act, int nl, const float* w0, int ld0, const float* b0, int64_t bstride, const float* const* hw, const float* const* hb,
 							float* z, float* out, bool reload) {
@@ -771,6 +785,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				a.y = hp; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
 				FIND_TRY(launch_gemm(c, AMODE_MAT, EPI_NONE, a, 1, st));
 			}
+			if (fold) return FIND_OK;   // (the second layer reads hp and the bias rows itself)
 			hipLaunchKernelGGL(bias_relu_bcast_kernel, dim3((unsigned)cdiv(V * (W / 4), 256), (unsigned)cdiv(n_feet, BCAST_FEET)), dim3(256), 0, st, hp, bias,
 							   bstride, (int)n_feet, V, out, a16 ? 1 : 0);
 			return FIND_OK;
@@ -805,12 +820,20 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 	if (disp) {
 		FIND_TRY(head_first(w.wd0, bias_d0, bstride_d, w.D[0], w.hp, s));
-		for (int i = 1; i < p->n_disp; ++i) FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s, a16));
+		for (int i = 1; i < p->n_disp; ++i) {
+			if (i == 1 && fold) FIND_TRY(linear_fwd(c, w.hp, 0, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s, a16, bias_d0, bstride_d));
+			else FIND_TRY(linear_fwd(c, w.D[i - 1], V * W, p->disp_w[i], W, p->disp_b[i], 0, w.D[i], V, n_feet, s, a16));
+		}
 		head_out(0, s);
 	}
 	if (col) {
-		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], (sc != s || (fused && disp)) ? w.hp2 : w.hp, sc));
-		for (int i = 1; i < p->n_col; ++i) FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc, a16));
+		// (bcast_fold: the products stay until the backward -- the colour head's is ALWAYS hp2, the other head's hp)
+		float* const hpc = (fold || sc != s || (fused && disp)) ? w.hp2 : w.hp;
+		FIND_TRY(head_first(w.wc0, bias_c0, bstride_c, w.C[0], hpc, sc));
+		for (int i = 1; i < p->n_col; ++i) {
+			if (i == 1 && fold) FIND_TRY(linear_fwd(c, hpc, 0, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc, a16, bias_c0, bstride_c));
+			else FIND_TRY(linear_fwd(c, w.C[i - 1], V * W, p->col_w[i], W, p->col_b[i], 0, w.C[i], V, n_feet, sc, a16));
+		}
 		head_out(1, sc);
 	}
 	FIND_LAUNCH_CHECK("head layers");
@@ -981,7 +1004,9 @@ static int reduce_lds(find_ctx* c) {
 // tiles go out on stream s; the slab reduce follows on s, or -- reduce_side >= 0 -- on that side stream of the fork, ordered behind s.
 static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, int64_t x_foot_stride, const float* pos, int64_t pos_foot_stride,
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
-					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1, bool h16 = false) {
+					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1, bool h16 = false,
+					   const float* vx_bias = nullptr, int64_t vx_bias_stride = 0) {   // (vx_bias: bcast_fold -- x is the shared product P, the operand relu(P[v] + vx_bias[foot]))
+	FIND_REQUIRE(!vx_bias || (h16 && c->f16 && !pos), "weight_grad: a virtual operand outside the fp16-stored path (bcast_fold and the kernel selection disagree)");
 	auto reduce_stream = [&]() -> hipStream_t {
 		if (!fk || !fk->on || reduce_side < 0 || s_side < 0 || reduce_side == s_side) return s;
 		fk->chain(s_side, reduce_side);
@@ -999,13 +1024,16 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			spf = (int)cdiv(cpf64, cps3);
 			nmain = (int)(feet * spf);
 			int lds = 0;
-			if (h16) FIND_TRY(prepare_kernel(c, K_DW3_H, &dw3_h16_kernel, DW3_LDS, &lds));
+			if (vx_bias) FIND_TRY(prepare_kernel(c, K_DW3_V, &dw3_h16v_kernel, DW3_LDS, &lds));
+			else if (h16) FIND_TRY(prepare_kernel(c, K_DW3_H, &dw3_h16_kernel, DW3_LDS, &lds));
 			else FIND_TRY(prepare_kernel(c, K_DW3, &dw3_kernel, DW3_LDS, &lds));
 			Dw3Args d3;
 			memset(&d3, 0, sizeof(d3));
 			d3.dz = dz; d3.dz_foot_stride = V * W; d3.x = x; d3.x_foot_stride = x_foot_stride;
 			d3.V = (int)V; d3.chunks_per_foot = cpf64; d3.spf = spf; d3.cps = cps3; d3.pw = b.pw; d3.pb = pbuf;
-			if (h16) hipLaunchKernelGGL(dw3_h16_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);   // (dz and x fp16-stored: act16)
+			d3.xbias = vx_bias; d3.xbias_stride = vx_bias_stride;
+			if (vx_bias) hipLaunchKernelGGL(dw3_h16v_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);   // (x formed from the shared product: bcast_fold)
+			else if (h16) hipLaunchKernelGGL(dw3_h16_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);   // (dz and x fp16-stored: act16)
 			else hipLaunchKernelGGL(dw3_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d3);
 			FIND_LAUNCH_CHECK("dw3_kernel");
 		} else if (c->x3 && cdiv(V, 32) * feet >= c->gemm6_min_units) {
@@ -1185,12 +1213,15 @@ static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 }
 
 // masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
-static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, int ldw, int w_tr, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false) {
+// (vm_bias: bcast_fold -- mask is the shared fp32 product P and the layer's output was relu(P[v] + vm_bias[foot]))
+static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, int ldw, int w_tr, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false,
+						 const float* vm_bias = nullptr, int64_t vm_bias_stride = 0) {
 	GemmArgs a = gemm_args_zero();
 	a.h16 = h16;
 	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
 	a.w0 = wt; a.ldw = ldw; a.w_tr = w_tr; a.nchunk = W / KC;
-	a.mask = mask; a.mask_foot_stride = V * W;
+	a.mask = mask; a.mask_foot_stride = vm_bias ? 0 : V * W;
+	a.vm_bias = vm_bias; a.vm_bias_stride = vm_bias_stride;
 	a.y = y; a.y_foot_stride = V * W; a.ldy = W; a.V = (int)V;
 	return launch_gemm(c, AMODE_MAT, EPI_MASK, a, feet, s);
 }
@@ -1280,7 +1311,16 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	}
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
-	const bool a16 = noted_act16(c, w.fbd, use_act16(c, c->f16, d.shared, n_feet, V));   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
+	const bool a16_rule = use_act16(c, c->f16, d.shared, n_feet, V);
+	const int note16 = noted_act16(c, w.fbd, a16_rule, use_fold(c, a16_rule, p));
+	const bool a16 = (note16 & 1) != 0;   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
+	const bool fold = (note16 & 2) != 0;  // (... and did not store w.D[0] / w.C[0] at all: their readers form them from w.hp / w.hp2 and the bias rows)
+	struct Virt { const float* P; const float* bias; int64_t bstride; };
+	auto virt = [&](bool colour, int l) -> Virt {   // the input of head layer l (l >= 1): virtual for l == 1 under bcast_fold
+		if (!fold || l != 1) return Virt{nullptr, nullptr, 0};
+		if (colour) return (p->lat_col > 0) ? Virt{w.hp2, w.fbc, W} : Virt{w.hp2, p->col_b[0], 0};
+		return (p->lat_disp > 0) ? Virt{w.hp, w.fbd, W} : Virt{w.hp, p->disp_b[0], 0};
+	};
 	int cd = 0, cc = 0;  // current dZ buffer per head
 	{
 		HeadOutBwdArgs h;
@@ -1358,8 +1398,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			if (want_d) head_chain(p->n_disp, w.D, b.dzD, false, cd);
 			if (nsteps > 0) FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		} else {
-			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { const WT t = wt_D(l); FIND_TRY(linear_bwd_dx(c, b.dzD[cd], t.w, t.ld, t.tr, w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16)); cd += 1; }
-			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { const WT t = wt_C(l); FIND_TRY(linear_bwd_dx(c, b.dzC[cc], t.w, t.ld, t.tr, w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16)); cc += 1; }
+			if (want_d) for (int l = p->n_disp - 1; l >= 1; --l) { const WT t = wt_D(l); const Virt v = virt(false, l); FIND_TRY(linear_bwd_dx(c, b.dzD[cd], t.w, t.ld, t.tr, v.P ? v.P : w.D[l - 1], b.dzD[cd + 1], V, n_feet, s, a16, v.bias, v.bstride)); cd += 1; }
+			if (want_c) for (int l = p->n_col - 1; l >= 1; --l) { const WT t = wt_C(l); const Virt v = virt(true, l); FIND_TRY(linear_bwd_dx(c, b.dzC[cc], t.w, t.ld, t.tr, v.P ? v.P : w.C[l - 1], b.dzC[cc + 1], V, n_feet, s, a16, v.bias, v.bstride)); cc += 1; }
 		}
 		struct Job { const float* dz; float* ps; float* S; const float* w0; int ld0; const float* lat; int L; float* glat; };
 		const Job jobs[2] = {{b.dzD[cd], b.pS, b.Sd, p->disp_w[0], ld_d0, lat_disp, p->lat_disp, g->lat_disp},
@@ -1487,6 +1527,9 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, bool colour, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
 		for (int l = nl - 1; l >= 1; --l) {
+			const Virt v = virt(colour, l);
+			const float* const xin = v.P ? v.P : act[l - 1];
+			const int64_t xin_stride = v.P ? 0 : V * W;
 			fk.fork_to(Q);
 			// the large layers alternate between two slab sets and hand their slab reduce to stream R: the reduce (LDS-using, so
 			// it only gets a CU when a ring kernel's workgroup retires) no longer sits between two dw2 launches on Q
@@ -1498,13 +1541,13 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				BwdWs bk = b;
 				bk.pw = b.pw_t[si ? 3 : 0]; bk.pb = b.pb_t[si ? 3 : 0];
 				fk.wait(Q, set_free[si]);
-				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R, a16));
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], xin, xin_stride, nullptr, 0, p, 1, n_feet, V, bk, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), Q, R, a16, v.bias, v.bstride));
 				set_free[si] = fk.mark(R);
 			} else {
-				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], act[l - 1], V * W, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16));
+				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], xin, xin_stride, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16, v.bias, v.bstride));
 			}
 			const WT t = colour ? wt_C(l) : wt_D(l);
-			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, act[l - 1], dzbuf[cur + 1], V, n_feet, s, a16));
+			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, xin, dzbuf[cur + 1], V, n_feet, s, a16, v.bias, v.bstride));
 			cur += 1;
 		}
 		float* db_late = nullptr;
@@ -1924,7 +1967,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1},
 };
 }  // namespace
 

@@ -29,6 +29,8 @@ struct Dw3Args {
 	int cps;                 // 64-row chunks per split
 	float* pw;               // [n_feet*spf][256][256]
 	float* pb;               // [n_feet*spf][256] or nullptr
+	const float* xbias;      // dw3_h16v_kernel (bcast_fold): x is the shared fp32 product P (x_foot_stride 0) and the operand is
+	int64_t xbias_stride;    // fp16(relu(P[v] + xbias[foot])) -- what bias_relu_bcast would have stored, formed on the way in
 };
 
 constexpr int DW3_OPER = 256 * 128;            // one operand of one chunk in LDS: 256 columns x 64 rows fp16
@@ -36,8 +38,9 @@ constexpr int DW3_BUF = 2 * DW3_OPER;          // dZ then X
 constexpr int DW3_LDS = 2 * DW3_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 135 168 B
 
 // H16 ("act16", mlp.hip): both operands are STORED as fp16 (strides in elements as before): 8 bytes per thread and row instead of 16.
-template <bool H16>
+template <bool H16, bool VX = false>
 __device__ __forceinline__ void dw3_body(const Dw3Args& g) {
+	static_assert(!VX || H16, "dw3_body: the virtual operand exists beside fp16-stored gradients only");
 	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 432 registers by itself (256 fp32 accumulators in AGPRs): see the macro
 	constexpr int ES = H16 ? 2 : 4;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,7 +59,7 @@ __device__ __forceinline__ void dw3_body(const Dw3Args& g) {
 	float* const pw = g.pw + (int64_t)split * 65536;
 	float* const pb = g.pb ? g.pb + (int64_t)split * 256 : nullptr;
 	const char* const zfoot = reinterpret_cast<const char*>(g.dz) + (int64_t)foot * g.dz_foot_stride * ES;
-	const char* const xfoot = reinterpret_cast<const char*>(g.x) + (int64_t)foot * g.x_foot_stride * ES;
+	const char* const xfoot = reinterpret_cast<const char*>(g.x) + (int64_t)foot * g.x_foot_stride * (VX ? 4 : ES);
 	auto ld4 = [](const char* base, int64_t elem) -> float4 {
 		if constexpr (H16) {
 			typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -142,7 +145,11 @@ __device__ __forceinline__ void dw3_body(const Dw3Args& g) {
 		// idles while a chunk is transposed into LDS and the launch reads at ~3 TB/s; the halves go to LDS as they are (no conversion)
 		typedef unsigned u2 __attribute__((ext_vector_type(2)));
 		u2 hs[2][2][2][8];   // [set][operand][u][row j]: the thread's four columns of a row as two dwords
-		auto load_h = [&](int q, u2 (&set)[2][2][8]) {
+		// VX: the x operand arrives as fp32 products; they stay raw in flight (xs) and become relu(P + bias) -> fp16 when the chunk is stored
+		float4 xs[VX ? 2 : 1][2][VX ? 8 : 1];
+		float4 xb = make_float4(0.f, 0.f, 0.f, 0.f);
+		if constexpr (VX) xb = *reinterpret_cast<const float4*>(g.xbias + (int64_t)foot * g.xbias_stride + c4);
+		auto load_h = [&](int q, u2 (&set)[2][2][8], int si) {
 			const int r0 = q * 64;
 #pragma unroll
 			for (int u = 0; u < 2; ++u)
@@ -152,12 +159,30 @@ __device__ __forceinline__ void dw3_body(const Dw3Args& g) {
 					const bool ok = row < g.V;
 					const int rc = ok ? row : g.V - 1;
 					const u2 z = *reinterpret_cast<const u2*>(zfoot + ((int64_t)rc * 256 + c4) * 2);
-					const u2 x = *reinterpret_cast<const u2*>(xfoot + ((int64_t)rc * 256 + c4) * 2);
 					set[0][u][j] = ok ? z : u2{0u, 0u};
-					set[1][u][j] = ok ? x : u2{0u, 0u};
+					if constexpr (VX) {
+						// (rows past the end of a foot: dZ is zero there, whatever x is)
+						xs[si][u][j] = *reinterpret_cast<const float4*>(xfoot + ((int64_t)rc * 256 + c4) * 4);
+					} else {
+						const u2 x = *reinterpret_cast<const u2*>(xfoot + ((int64_t)rc * 256 + c4) * 2);
+						set[1][u][j] = ok ? x : u2{0u, 0u};
+					}
 				}
 		};
-		auto store_h = [&](char* buf, const u2 (&set)[2][2][8]) {
+		auto store_h = [&](char* buf, u2 (&set)[2][2][8], int si) {
+			if constexpr (VX) {
+				typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+				for (int u = 0; u < 2; ++u)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						const float4 v = xs[si][u][j];
+						h2v lo, hi;
+						lo[0] = (_Float16)fmaxf(v.x + xb.x, 0.f); lo[1] = (_Float16)fmaxf(v.y + xb.y, 0.f);
+						hi[0] = (_Float16)fmaxf(v.z + xb.z, 0.f); hi[1] = (_Float16)fmaxf(v.w + xb.w, 0.f);
+						set[1][u][j] = u2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+					}
+			}
 #pragma unroll
 			for (int op = 0; op < 2; ++op)
 #pragma unroll
@@ -187,24 +212,24 @@ __device__ __forceinline__ void dw3_body(const Dw3Args& g) {
 			}
 		};
 		if (q0 < q1) {
-			load_h(q0, hs[0]);
-			load_h(min(q0 + 1, q1 - 1), hs[1]);
-			store_h(smem, hs[0]);
-			load_h(min(q0 + 2, q1 - 1), hs[0]);
+			load_h(q0, hs[0], 0);
+			load_h(min(q0 + 1, q1 - 1), hs[1], 1);
+			store_h(smem, hs[0], 0);
+			load_h(min(q0 + 2, q1 - 1), hs[0], 0);
 			__syncthreads();
 			int cb = 0;
 			// chunk q is in LDS buffer cb; `set` holds chunk q + 1 (stored under this chunk's MFMAs), then takes chunk q + 3.  (A repeated
 			// load re-reads the run's last chunk; a repeated store goes to the buffer nobody reads any more.)
-			auto body = [&](int q, u2 (&set)[2][2][8]) {
+			auto body = [&](int q, u2 (&set)[2][2][8], int si) {
 				multiply(smem + cb * DW3_BUF);
-				if (q + 1 < q1) store_h(smem + (cb ^ 1) * DW3_BUF, set);
-				load_h(min(q + 3, q1 - 1), set);
+				if (q + 1 < q1) store_h(smem + (cb ^ 1) * DW3_BUF, set, si);
+				load_h(min(q + 3, q1 - 1), set, si);
 				__syncthreads();
 				cb ^= 1;
 			};
 			for (int q = q0; q < q1; q += 2) {
-				body(q, hs[1]);
-				if (q + 1 < q1) body(q + 1, hs[0]);
+				body(q, hs[1], 1);
+				if (q + 1 < q1) body(q + 1, hs[0], 0);
 			}
 		}
 	} else
@@ -247,6 +272,7 @@ __device__ __forceinline__ void dw3_body(const Dw3Args& g) {
 
 __global__ __launch_bounds__(256, 1) void dw3_kernel(const Dw3Args g) { dw3_body<false>(g); }
 __global__ __launch_bounds__(256, 1) void dw3_h16_kernel(const Dw3Args g) { dw3_body<true>(g); }
+__global__ __launch_bounds__(256, 1) void dw3_h16v_kernel(const Dw3Args g) { dw3_body<true, true>(g); }
 
 }  // namespace mlp
 }  // namespace find

@@ -48,6 +48,11 @@ struct Gemm2Args {
 	int V;                  // rows per foot
 	int tiles_per_foot;
 	int ntiles;
+	const float* va_bias;   // gemm5_kernel<.., VIRT>: bias rows of the virtual A operand relu(a0[v] + va_bias[foot]) (mlp_gemm5.h)
+	int64_t va_bias_stride;
+	const float* vm_bias;   // ... of the virtual ReLU mask (mask = the shared fp32 product)
+	int64_t vm_bias_stride;
+	int tile_major;         // gemm5: unit = tile * n_feet + foot instead of foot * tiles_per_foot + tile
 	int ablate;             // profiling only: bit0 skip DMA issue, bit1 skip epilogue stores, bit2 skip MFMAs
 	unsigned long long* dbg; // profiling only: per-workgroup [total, wait+barrier, epilogue, lgkm-wait] shader cycles (wave 0)
 };

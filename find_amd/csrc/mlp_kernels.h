@@ -92,6 +92,10 @@ struct GemmArgs {
 	int ldy;
 	int V;                  // rows per foot
 	int h16;                // host side only (launch_gemm): a0, y and mask are fp16-STORED tensors (act16: gemm5_kernel<EPI, true>)
+	const float* va_bias;   // bcast_fold: a0 is the shared fp32 product P and the operand is relu(P[v] + va_bias[foot]) (gemm5_kernel<.., VIRT>)
+	int64_t va_bias_stride;
+	const float* vm_bias;   // bcast_fold: mask is P and the mask is P[v] + vm_bias[foot]
+	int64_t vm_bias_stride;
 };
 
 enum { AMODE_MAT = 0, AMODE_PE = 1 };

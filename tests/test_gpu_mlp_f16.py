@@ -217,6 +217,30 @@ def test_fp16_stored_activations_agree_with_fp32_stored_ones():
 		assert (g_a[n] - g_b[n]).abs().max().item() < 5e-3 * scale, (n, (g_a[n] - g_b[n]).abs().max().item() / scale)
 
 
+@pytest.mark.parametrize('n_feet,n_verts', [(16, 6890), (5, 6890), (4, 10002)])
+def test_broadcast_layer_formed_by_its_readers_equals_the_stored_one(n_feet, n_verts):
+	"""bcast_fold (csrc/mlp.hip use_fold, mlp_gemm5.h VIRT, dw3_h16v_kernel): inside act16 the output of a head's broadcast first layer,
+	fp16(relu(P[v] + bias[foot])), is not stored -- the second layer's forward GEMM, the ReLU mask of its dX GEMM and the x operand of its
+	weight gradient form it from the V x 256 product and the bias rows.  Same add, same max, same rounding, same summation order everywhere:
+	outputs and every gradient are BIT-IDENTICAL to the stored path; a knob turned between forward and backward does not split them."""
+	from find_amd import functional as F
+	from find_amd import _lib
+	prev = F.set_mlp_precision('fp16')
+	try:
+		assert _lib.get_tuning('bcast_fold') == 1
+		out_a, g_a = _run_model(n_feet, n_verts, True)
+		out_c, g_c = _run_model(n_feet, n_verts, True, between=lambda: _lib.set_tuning('bcast_fold', 0))
+		out_b, g_b = _run_model(n_feet, n_verts, True)   # (the knob is still 0: the stored path)
+	finally:
+		_lib.set_tuning('bcast_fold', 1)
+		F.set_mlp_precision(prev)
+	assert torch.equal(out_a, out_b) and torch.equal(out_c, out_a)
+	for n in g_b:
+		assert torch.isfinite(g_a[n]).all(), n
+		assert torch.equal(g_a[n], g_b[n]), (n, (g_a[n] - g_b[n]).abs().max().item() / max(1e-30, g_b[n].abs().max().item()))
+		assert torch.equal(g_c[n], g_a[n]), n
+
+
 def test_two_models_in_one_process_may_differ_in_precision():
 	"""find_mlp_params.precision travels with each call: a model pinned to fp16 and a model pinned to fp32 interleave their passes,
 	and the fp32 one stays bit-identical to a run without any fp16 model around (the precision is no longer process-wide state)."""
