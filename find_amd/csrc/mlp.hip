@@ -128,7 +128,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_GEMM5_RELU_V, K_GEMM5_MASK_V, K_DW3_V, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_GEMM5_RELU_V, K_GEMM5_MASK_V, K_DW3_V, K_GEMM7_RELU_V, K_GEMM7_MASK_V, K_DW6_V, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -468,7 +468,20 @@ static int launch_gemm7_t(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s)
 	return FIND_OK;
 }
 
+template <int EPI>
+static int launch_gemm7_virt(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {   // (bcast_fold: mlp_gemm7.h VIRT)
+	int lds = 0;
+	FIND_TRY(prepare_kernel(c, EPI == EPI_BIAS_RELU ? K_GEMM7_RELU_V : K_GEMM7_MASK_V, &gemm7_kernel<EPI, 0, true>, GEMM7_LDS, &lds));
+	a.tiles_per_foot = (int)cdiv(a.V, 32);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	const int grid = std::max(16, (c->num_cus / 16) * 16);
+	hipLaunchKernelGGL((gemm7_kernel<EPI, 0, true>), dim3(grid), dim3(GEMM7_NW * 64), lds, s, a);
+	return FIND_OK;
+}
+
 static int launch_gemm7(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_BIAS_RELU && a.va_bias) return launch_gemm7_virt<EPI_BIAS_RELU>(c, a, feet, s);
+	if (epi == EPI_MASK && a.vm_bias) return launch_gemm7_virt<EPI_MASK>(c, a, feet, s);
 	if (epi == EPI_BIAS_RELU) return launch_gemm7_t<EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK) return launch_gemm7_t<EPI_MASK>(c, a, feet, s);
 	return launch_gemm7_t<EPI_NONE>(c, a, feet, s);
@@ -509,11 +522,11 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	// (gemm5 keeps the whole W per workgroup, so 216 units occupy 27 CUs: 22 us against 13 us for gemm4 on column quarters)
 	if (c->f16 && k256 && units >= c->gemm5_min_units) return launch_gemm5(c, epi, b, feet, s, a.h16 != 0);
 	FIND_REQUIRE(!a.h16, "launch_gemm: an fp16-stored layer reached a kernel that reads fp32 (act16 and the kernel selection disagree)");
-	FIND_REQUIRE(!a.va_bias && !a.vm_bias, "launch_gemm: a virtual operand reached a kernel that cannot form it (bcast_fold and the kernel selection disagree)");
 #ifdef FIND_DIAG
-	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) return launch_gemm6(c, epi, b, feet, s);
+	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) { FIND_REQUIRE(!a.va_bias && !a.vm_bias, "launch_gemm: gemm6 forms no virtual operand"); return launch_gemm6(c, epi, b, feet, s); }
 #endif
 	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm7(c, epi, b, feet, s);
+	FIND_REQUIRE(!a.va_bias && !a.vm_bias, "launch_gemm: a virtual operand reached a kernel that cannot form it (bcast_fold and the kernel selection disagree)");
 	FIND_REQUIRE(!a.w_tr, "launch_gemm: an untransposed weight reached a kernel that cannot read it (gemm7_direct and the kernel selection disagree)");
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
@@ -663,7 +676,18 @@ static bool use_act16(const find_ctx* c, bool f16, bool shared, int64_t n_feet, 
 // bcast_fold (round 6): inside act16 the output of a head's broadcast first layer, h1 = fp16(relu(P[v] + bias[foot])), is never stored: its
 // three readers (the second layer's forward GEMM, the ReLU mask of that layer's dX GEMM, the x operand of its weight gradient) form it from the
 // V x 256 product P (w.hp / w.hp2, kept until the backward) and the bias rows -- gemm5_kernel<.., VIRT>, dw3_h16v_kernel.  Needs a second hidden layer.
-static bool use_fold(const find_ctx* c, bool a16, const find_mlp_params* p) { return a16 && c->bcast_fold && p->n_disp >= 2 && p->n_col >= 2; }
+// The same in the default bf16x3 arithmetic (fp32-stored activations): gemm7_kernel<.., VIRT>, dw6v_kernel -- wherever the heads' hidden
+// layers of a shared template go to gemm7 / dw6 (launch_gemm's and weight_grad's rule).
+static bool use_fold(const find_ctx* c, bool a16, bool shared, int64_t n_feet, int64_t V, const find_mlp_params* p) {
+	if (!c->bcast_fold || p->n_disp < 2 || p->n_col < 2) return false;
+	if (a16) return true;
+	const int64_t units = cdiv(V, 32) * n_feet;
+	bool x3_large = c->x3 && !c->f16 && shared && n_feet > 1 && units >= c->gemm6_min_units;
+#ifdef FIND_DIAG
+	x3_large = x3_large && c->gemm7;
+#endif
+	return x3_large;
+}
 static void note_act16(find_ctx* c, const void* ws, bool a16, bool fold) {
 	for (auto& n : c->act16_notes) if (n.ws == ws) { n.a16 = a16; n.fold = fold; return; }
 	c->act16_notes[c->act16_next] = find_ctx::Act16Note{ws, a16, fold};
@@ -683,7 +707,7 @@ static int mlp_fwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	const int64_t V = d.V, n_feet = d.n_feet;
 	const int ld_d0 = W + p->lat_disp, ld_c0 = W + p->lat_col;
 	const bool a16 = use_act16(c, c->f16, d.shared, n_feet, V);
-	const bool fold = use_fold(c, a16, p);
+	const bool fold = use_fold(c, a16, d.shared, n_feet, V, p);
 	note_act16(c, w.fbd, a16, fold);   // (every forward leaves its note, keyed by a buffer every workspace has: the backward follows it)
 
 	// 1. repack: layer-0 weight into padded PE order; main blocks of the two head input layers.  Not for a bf16x3 chain that carries the
@@ -1006,7 +1030,8 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 					   const find_mlp_params* p, int nkt, int64_t feet, int64_t V, const BwdWs& b, float* dw, int ld_out,
 					   int k_valid, int pe_map, float* db, float* S, hipStream_t s, int s_side = -1, int reduce_side = -1, bool h16 = false,
 					   const float* vx_bias = nullptr, int64_t vx_bias_stride = 0) {   // (vx_bias: bcast_fold -- x is the shared product P, the operand relu(P[v] + vx_bias[foot]))
-	FIND_REQUIRE(!vx_bias || (h16 && c->f16 && !pos), "weight_grad: a virtual operand outside the fp16-stored path (bcast_fold and the kernel selection disagree)");
+	FIND_REQUIRE(!vx_bias || (!pos && ((h16 && c->f16) || (!c->f16 && c->x3 && cdiv(V, 32) * feet >= c->gemm6_min_units))),
+				 "weight_grad: a virtual operand reached a kernel that cannot form it (bcast_fold and the kernel selection disagree)");
 	auto reduce_stream = [&]() -> hipStream_t {
 		if (!fk || !fk->on || reduce_side < 0 || s_side < 0 || reduce_side == s_side) return s;
 		fk->chain(s_side, reduce_side);
@@ -1048,12 +1073,15 @@ static int weight_grad(find_ctx* c, Fork* fk, const float* dz, const float* x, i
 			spf = (int)cdiv(cpf16, cps6);
 			nmain = (int)(feet * spf);
 			int lds = 0;
-			FIND_TRY(prepare_kernel(c, K_DW6, &dw6_kernel, DW6_LDS, &lds));
+			if (vx_bias) FIND_TRY(prepare_kernel(c, K_DW6_V, &dw6v_kernel, DW6_LDS, &lds));
+			else FIND_TRY(prepare_kernel(c, K_DW6, &dw6_kernel, DW6_LDS, &lds));
 			Dw3Args d6;
 			memset(&d6, 0, sizeof(d6));
 			d6.dz = dz; d6.dz_foot_stride = V * W; d6.x = x; d6.x_foot_stride = x_foot_stride;
 			d6.V = (int)V; d6.chunks_per_foot = cpf16; d6.spf = spf; d6.cps = cps6; d6.pw = b.pw; d6.pb = pbuf;
-			hipLaunchKernelGGL(dw6_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);
+			d6.xbias = vx_bias; d6.xbias_stride = vx_bias_stride;
+			if (vx_bias) hipLaunchKernelGGL(dw6v_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);   // (x formed from the shared product: bcast_fold)
+			else hipLaunchKernelGGL(dw6_kernel, dim3((unsigned)nmain), dim3(256), lds, s, d6);
 			FIND_LAUNCH_CHECK("dw6_kernel");
 		} else {
 			// LDS-DMA kernel: every foot's rows cut into spf contiguous runs of 16-row chunks, the <= 15 leftover rows
@@ -1312,7 +1340,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 
 	// 2. final layers: dz of the last hidden layer of each head + dW/db of the 3-wide layers
 	const bool a16_rule = use_act16(c, c->f16, d.shared, n_feet, V);
-	const int note16 = noted_act16(c, w.fbd, a16_rule, use_fold(c, a16_rule, p));
+	const int note16 = noted_act16(c, w.fbd, a16_rule, use_fold(c, a16_rule, d.shared, n_feet, V, p));
 	const bool a16 = (note16 & 1) != 0;   // (the forward stored w.D / w.C as fp16: b.dzD / b.dzC follow)
 	const bool fold = (note16 & 2) != 0;  // (... and did not store w.D[0] / w.C[0] at all: their readers form them from w.hp / w.hp2 and the bias rows)
 	struct Virt { const float* P; const float* bias; int64_t bstride; };

@@ -32,6 +32,10 @@ constexpr int DW6_OPER = 3 * DW6_PLANE;         // 24 KB
 constexpr int DW6_BUF = 2 * DW6_OPER;           // dZ then X: 48 KB
 constexpr int DW6_LDS = 2 * DW6_BUF + 4 * 256 * 4;  // double buffer + bias reduction scratch = 102 400 B
 
+// VX ("bcast_fold", mlp.hip): the X operand is not stored -- the waves that stage it read the shared V x 256 product (g.x, foot stride 0) and
+// form relu(product + xbias[foot]) in front of the split (one packed add and two max per row pair; branch-free: the waves that stage dZ
+// add zero and clamp at -inf).
+template <bool VX = false>
 __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	float* red = reinterpret_cast<float*>(smem + 2 * DW6_BUF);
@@ -69,6 +73,19 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 	typedef int i4 __attribute__((ext_vector_type(4)));
 	u4 st[2][8];
 	const int c4 = lane * 4;
+	float xb[4] = {0.f, 0.f, 0.f, 0.f};
+	float xlo = -INFINITY;
+	if constexpr (VX) {
+		if (sop == 1) {
+			const float4 b4 = *reinterpret_cast<const float4*>(g.xbias + (int64_t)foot * g.xbias_stride + c4);
+			xb[0] = b4.x; xb[1] = b4.y; xb[2] = b4.z; xb[3] = b4.w;
+			xlo = 0.f;
+		}
+	}
+	auto virt = [&](f32x2 v, int e) -> f32x2 {
+		if constexpr (VX) { v = v + f32x2{xb[e], xb[e]}; v = f32x2{fmaxf(v[0], xlo), fmaxf(v[1], xlo)}; }
+		return v;
+	};
 	const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(sfoot)), 0, g.V * 1024, 0x00020000);
 	auto load_chunk = [&](int q, u4 (&set)[8]) {
 		const int r0 = q * 16 + 8 * srg;
@@ -88,7 +105,7 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 		u32x4 p1, p2, p3;
 #pragma unroll
 		for (int jj = 0; jj < 4; ++jj) {
-			const Split2 s = split_pair(f32x2{comp(st[2 * jj], e), comp(st[2 * jj + 1], e)});
+			const Split2 s = split_pair(virt(f32x2{comp(st[2 * jj], e), comp(st[2 * jj + 1], e)}, e));
 			p1[jj] = s.p1; p2[jj] = s.p2; p3[jj] = s.p3;
 		}
 		char* dst = buf + wbase_h + (((c4 + e) ^ (lane & 7)) * 32);
@@ -145,7 +162,7 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 				const int cu = tj & 1, nx = cu ^ 1;
 				ColSplit c;
 #pragma unroll
-				for (int jj = 0; jj < 4; ++jj) c.r[jj] = f32x2{comp(set[2 * jj], tj), comp(set[2 * jj + 1], tj)};
+				for (int jj = 0; jj < 4; ++jj) c.r[jj] = virt(f32x2{comp(set[2 * jj], tj), comp(set[2 * jj + 1], tj)}, tj);
 				c.t = 0.f;
 #pragma unroll
 				for (int sl = 0; sl < 12; ++sl) {
@@ -206,6 +223,10 @@ __device__ __forceinline__ void dw6_body(const Dw3Args& g, const int split) {
 __global__ __launch_bounds__(256, 1) void dw6_kernel(const Dw3Args g) {
 	FIND_CLAIM_WHOLE_REGISTER_FILE();   // 256 fp32 accumulators in AGPRs + ~150 VGPRs: more than 256 registers (see the macro)
 	dw6_body(g, blockIdx.x);
+}
+__global__ __launch_bounds__(256, 1) void dw6v_kernel(const Dw3Args g) {   // (bcast_fold: X formed from the shared product)
+	FIND_CLAIM_WHOLE_REGISTER_FILE();
+	dw6_body<true>(g, blockIdx.x);
 }
 
 // Several weight gradients of the same geometry in ONE launch (blockIdx.y = job), as dw4_group_kernel: the 256 x 256 layers of a small call

@@ -38,8 +38,14 @@ constexpr int GEMM7_NW = 8;
 
 // ABL: profiling only (tools/ablate_x3.py; results are wrong under every bit): 1 = no split / LDS writes, 2 = no fragment reads after a unit's
 // first, 4 = no activation loads after the prologue, 8 = no stores
-template <int EPI, int ABL = 0>
+// VIRT ("bcast_fold", mlp.hip): the layer behind a head's broadcast first layer forms that layer's output h1 = relu(P[v] + bias[foot]) itself
+// instead of reading n_feet x V x 1 KB of it from HBM -- from the V x 256 product P (a0 / mask with foot stride 0: L2) and the foot's bias
+// row: EPI_BIAS_RELU: the A operand, two packed adds and four max per staged row in front of its split (g.va_bias); EPI_MASK: the ReLU
+// mask of the epilogue (g.vm_bias).  Bit for bit the values bias_relu_bcast_kernel would have stored.
+template <int EPI, int ABL = 0, bool VIRT = false>
 __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args g) {
+	static_assert(!VIRT || EPI != EPI_NONE, "gemm7_kernel: a virtual operand needs the epilogue it belongs to");
+	constexpr bool VA = VIRT && EPI == EPI_BIAS_RELU, VM = VIRT && EPI == EPI_MASK;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
@@ -108,6 +114,14 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			r[0] = f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
 			r[1] = f32x2{__uint_as_float(v.z), __uint_as_float(v.w)};
 		}
+		// VA: the staged values are the shared product's; the operand is relu(product + the foot's bias)
+		__device__ __forceinline__ void begin_virtual(const u4& v, const u4& bias) {
+			begin(v);
+			r[0] = r[0] + f32x2{__uint_as_float(bias.x), __uint_as_float(bias.y)};
+			r[1] = r[1] + f32x2{__uint_as_float(bias.z), __uint_as_float(bias.w)};
+			r[0] = f32x2{fmaxf(r[0][0], 0.f), fmaxf(r[0][1], 0.f)};
+			r[1] = f32x2{fmaxf(r[1][0], 0.f), fmaxf(r[1][1], 0.f)};
+		}
 		// piece k of pair h: round what is left to bf16, take it off (4 instructions; the last piece is the rounding alone)
 		__device__ __forceinline__ void stage(int h, int k) {
 			p[h][k] = __builtin_bit_cast(unsigned, __builtin_convertvector(r[h], bf16x2));
@@ -118,9 +132,23 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	auto write_plane = [&](char* buf, const RowSplit& q, int r, int k) {
 		*reinterpret_cast<u2*>(buf + wbase + r * (8 * G7_ROW) + k * G7_PLANE) = u2{q.p[0][k], q.p[1][k]};
 	};
+	// VA: bias row (columns 4 lane .. + 3) of the foot whose unit is being split; VM: (columns col0 + 4 h4 .. + 3) of the foot whose block is being stored
+	u4 vab = {0u, 0u, 0u, 0u};
+	int vab_foot = -1;
+	auto virt_bias = [&](int uu, int col) {   // (wave-uniform branch; a foot changes every tiles_per_foot units)
+		if constexpr (VIRT) {
+			const int foot = min(uu, u1 - 1) / upf;
+			if (foot != vab_foot) {
+				const float* bp = VA ? g.va_bias + (int64_t)foot * g.va_bias_stride : g.vm_bias + (int64_t)foot * g.vm_bias_stride;
+				vab = __builtin_amdgcn_raw_buffer_load_b128(make_srd(bp, 256 * 4), col * 4, 0, 0);
+				vab_foot = foot;
+			}
+		}
+	};
 	auto store_row = [&](char* buf, const u4 (&slot)[4], int r) {   // (the prologue's unit: all at once)
 		RowSplit q;
-		q.begin(slot[r]);
+		if constexpr (VA) q.begin_virtual(slot[r], vab);
+		else q.begin(slot[r]);
 #pragma unroll
 		for (int k = 0; k < 3; ++k) { q.stage(0, k); q.stage(1, k); }
 #pragma unroll
@@ -147,6 +175,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		const __amdgpu_buffer_rsrc_t r1 = unit_rsrc(u0 + 1);
 #pragma unroll
 		for (int r = 0; r < 4; ++r) load_row(r1, st[1], r);
+		if constexpr (VA) virt_bias(u0, lane * 4);
 #pragma unroll
 		for (int r = 0; r < 4; ++r) { FIND_VM_WAIT(st[0][r], 4); store_row(smem, st[0], r); }   // (the four loads of unit u0 + 1 may stay in flight)
 		const __amdgpu_buffer_rsrc_t r2 = unit_rsrc(u0 + 2);
@@ -189,7 +218,8 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		for (int e = 0; e < 4; ++e) {
 			v[e] = pend[rb][e];
 			if constexpr (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
-			if constexpr (EPI == EPI_MASK) v[e] = (__uint_as_float(mv[rb][e]) > 0.f) ? v[e] : 0.f;
+			if constexpr (VM) v[e] = (__uint_as_float(mv[rb][e]) + __uint_as_float(vab[e]) > 0.f) ? v[e] : 0.f;
+			else if constexpr (EPI == EPI_MASK) v[e] = (__uint_as_float(mv[rb][e]) > 0.f) ? v[e] : 0.f;
 		}
 		store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4);   // (no SGPR offset: common.h)
 	};
@@ -208,6 +238,8 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		pend[0] = acc[0]; pend[1] = acc[1];
 		init_acc();
 		load_bias(u + 1);
+		if constexpr (VA) virt_bias(u + 1, lane * 4);                      // the unit split under this one's MFMAs
+		if constexpr (VM) virt_bias(first ? u : u - 1, col0 + 4 * h4);     // the unit whose blocks are stored under them
 		if constexpr (EPI == EPI_MASK) {
 			vm_load(mv[0], prev.m, ovoff, 0);
 			vm_load(mv[1], prev.m, ovoff, 16 * ldy * 4);
@@ -238,7 +270,11 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			// VMEM operations behind the load of slot[row] when it is needed (buffer loads and stores complete in order): the rest of its own
 			// unit's, those of the unit after it and this unit's so far -- at least 7 in every unit of the pipeline (10-11 in the steady
 			// state: two units of loads stay in flight)
-			if (h == 0 && !(ABL & 1)) { FIND_VM_WAIT(slot[row], 7); q.begin(slot[row]); }
+			if (h == 0 && !(ABL & 1)) {
+				FIND_VM_WAIT(slot[row], 7);
+				if constexpr (VA) q.begin_virtual(slot[row], vab);
+				else q.begin(slot[row]);
+			}
 			// smallest terms first
 			mm(B1[s], a3[cu][0], acc[0]); mm(B1[s], a3[cu][1], acc[1]);
 			if constexpr (!(ABL & 1)) q.stage(h, 0);
@@ -278,6 +314,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	{   // the last unit's blocks
 		const OutTile last = out_tile(u1 - 1);
 		pend[0] = acc[0]; pend[1] = acc[1];
+		if constexpr (VM) virt_bias(u1 - 1, col0 + 4 * h4);
 		if constexpr (EPI == EPI_MASK) {
 			vm_load(mv[0], last.m, ovoff, 0);
 			vm_load(mv[1], last.m, ovoff, 16 * ldy * 4);

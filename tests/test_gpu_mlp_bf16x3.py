@@ -179,6 +179,27 @@ def test_backward_matches_reference_golden_under_bf16x3(every_size, golden_main,
 	assert n >= 20
 
 
+@pytest.mark.parametrize('n_feet,n_verts', [(16, 6890), (5, 6890), (4, 10002), (3, 1002)])
+def test_broadcast_layer_formed_by_its_readers_equals_the_stored_one(every_size, n_feet, n_verts):
+	"""bcast_fold in the default arithmetic (csrc/mlp.hip use_fold; mlp_gemm7.h VIRT, dw6v_kernel): the output of a head's broadcast first
+	layer, relu(P[v] + bias[foot]), is not stored -- the second layer's forward GEMM, the ReLU mask of its dX GEMM and the X operand of its
+	weight gradient form it from the V x 256 product and the bias rows.  Same add, same max, same splits, same summation order: outputs and
+	every gradient BIT-IDENTICAL to the stored path (16 / 5 feet of the 6890-vertex template: a partial last unit per foot; 10 002 and
+	1002 vertices: other tile edges -- the latter through gemm7 only under the every_size fixture)."""
+	from find_amd import _lib
+	assert _lib.get_tuning('bcast_fold') == 1
+	out_a, g_a = _run_model(n_feet, n_verts, True, 'bf16x3')
+	try:
+		_lib.set_tuning('bcast_fold', 0)
+		out_b, g_b = _run_model(n_feet, n_verts, True, 'bf16x3')
+	finally:
+		_lib.set_tuning('bcast_fold', 1)
+	assert torch.equal(out_a, out_b)
+	for n in g_b:
+		assert torch.isfinite(g_a[n]).all(), n
+		assert torch.equal(g_a[n], g_b[n]), (n, (g_a[n] - g_b[n]).abs().max().item() / max(1e-30, g_b[n].abs().max().item()))
+
+
 @pytest.mark.parametrize('n_feet,n_verts,shared', [(16, 6890, True), (16, 1000, False), (8, 6890, True), (6, 6890, True), (32, 6890, True)])
 def test_bf16x3_backward_is_bit_reproducible(n_feet, n_verts, shared):
 	"""No float atomics and a fixed split geometry: repeated passes of the same forward + backward give bit-identical outputs and gradients --
