@@ -188,6 +188,7 @@ struct find_ctx {
 	struct Act16Note { const void* ws; bool a16; bool fold; };
 	Act16Note act16_notes[16] = {};
 	int act16_next = 0;
+	int group_head0 = 1;          // knob: a shared template's first head layers' weight gradients ride in the trunk's grouped launch (mlp_bwd_body)
 	int bcast_fold = 1;           // knob: inside act16 the broadcast first head layer's output is formed by its readers instead of stored (use_fold)
 	int act16 = 1;                // knob: in the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large
 	                              // shared-template shapes (use_act16): those layers are HBM-bound, and the matrix pipe rounds them to fp16 anyway
@@ -896,9 +897,10 @@ extern "C" int find_mlp_fwd(find_ctx* c, const find_mlp_params* p, const float* 
 	FIND_TRY(make_dims(p, pos_batch, n_feet, n_pts, &d));
 	FIND_TRY(check_weights(p));
 	FIND_REQUIRE(pos && ws, "find_mlp_fwd: pos/ws is NULL");
-	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_fwd: lat_disp pointer does not match params.lat_disp=%d", p->lat_disp);
-	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_fwd: lat_col pointer does not match params.lat_col=%d", p->lat_col);
 	FIND_REQUIRE(disp || col, "find_mlp_fwd: both outputs NULL");
+	// (the latents of a head the call does not evaluate may be NULL: nothing reads them)
+	FIND_REQUIRE(p->lat_disp == 0 ? lat_disp == nullptr : (lat_disp != nullptr || disp == nullptr), "find_mlp_fwd: lat_disp pointer does not match params.lat_disp=%d", p->lat_disp);
+	FIND_REQUIRE(p->lat_col == 0 ? lat_col == nullptr : (lat_col != nullptr || col == nullptr), "find_mlp_fwd: lat_col pointer does not match params.lat_col=%d", p->lat_col);
 	FIND_REQUIRE(p->precision >= 0 && p->precision <= 3, "find_mlp_fwd: params.precision must be 0 (context default), 1 (fp32 MFMA), 2 (fp16) or 3 (bf16x3), got %d", p->precision);
 	FwdWs w;
 	carve_fwd(p, d, save_for_bwd != 0, ws, &w);
@@ -1001,7 +1003,8 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	o->grp_pw = nullptr; o->grp_slabs = 0; o->grp_jobs = 0;
 	if (cdiv(d.V, 32) * d.feet_t <= GROUP_MAX_UNITS) {
 		// (a shared trunk groups its own layers only: the heads' layers there have n_feet times the rows and keep their own launches)
-		o->grp_jobs = d.shared ? (p->n_trunk - 1) : (p->n_trunk - 1) + p->n_disp + p->n_col;
+		// (round 6: ... and the heads' FIRST layers, whose foot-summed gradient has the trunk's V rows)
+		o->grp_jobs = d.shared ? (p->n_trunk - 1) + 2 : (p->n_trunk - 1) + p->n_disp + p->n_col;
 		o->grp_slabs = std::max<int64_t>(d.feet_t * (cdiv(d.V / 16, GROUP_MIN_CPS) + 1), std::min<int64_t>(d.feet_t * cdiv(d.V / 16, 2), 32));
 		if (o->grp_jobs > 0) o->grp_pw = c.take<float>((int64_t)o->grp_jobs * o->grp_slabs * ((int64_t)W * W + W));
 	}
@@ -1552,6 +1555,11 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	// the dX chain) goes to the side streams; every layer's dZ has its own buffer, so the dX chain on the caller's stream never waits.
 	int big_toggle = 0;
 	hipEvent_t set_free[2] = {nullptr, nullptr};   // fires when the slab set's previous reduce (on R) has read it
+	// The V-row weight gradients of a shared template's backward -- the trunk's layers and (round 6) the heads' first layers over the
+	// foot-summed dZ, which used to be a 50-70-us fp32-MFMA launch of its own per head -- travel in ONE grouped launch behind the trunk's dX chain.
+	WgradGroup G;
+	const bool grouped_v = fused && d.shared && !c->f16 && b.grp_pw != nullptr;
+	G.live_jobs = (p->n_trunk - 1) + (c->group_head0 ? (act_d ? 1 : 0) + (act_c ? 1 : 0) : 0);
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, bool colour, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
 		for (int l = nl - 1; l >= 1; --l) {
@@ -1597,7 +1605,8 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			if (L > 0) db_late = gb[0];
 			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, q0, S, (int)n_feet, gb[0]);
 			FIND_LAUNCH_CHECK("footsum");
-			FIND_TRY(weight_grad(c, &fk, zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0));
+			if (grouped_v && c->group_head0) FIND_TRY(wgrad_group_add(c, G, b, zs, hl, 0, 1, V, gw[0], ld0, nullptr, nullptr));
+			else FIND_TRY(weight_grad(c, &fk, zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0));
 		} else {
 			fk.fork_to(Q);
 			q0 = fk.stream(Q);
@@ -1623,8 +1632,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			if (ch.a.step[i].src_kind == FS_SRC_GLOBAL) { ch.a.step[i].src = (k == 0 && act_d) ? (d.shared ? b.zsD : b.dzD[cd]) : (d.shared ? b.zsC : b.dzC[cc]); ++k; }
 		FIND_TRY(launch_chain(c, ch, V, d.feet_t, s, b.w6, chain_w6_bytes(p)));
 		// the trunk's weight gradients: all their inputs exist now -- one grouped launch + one grouped reduce (fp32), as in the small-call path
-		const bool grouped = !c->f16 && b.grp_pw != nullptr;
-		WgradGroup G;
+		const bool grouped = grouped_v;
 		for (int l = p->n_trunk - 1; l >= 1; --l) {
 			if (grouped) {
 				FIND_TRY(wgrad_group_add(c, G, b, b.dzT[ct], w.H[l - 1], V * W, d.feet_t, V, g->trunk_w[l], W, g->trunk_b[l], nullptr));
@@ -1727,8 +1735,8 @@ extern "C" int find_mlp_bwd(find_ctx* c, const find_mlp_params* p, const float* 
 	FIND_TRY(make_dims(p, pos_batch, n_feet, n_pts, &d));
 	FIND_TRY(check_weights(p));
 	FIND_REQUIRE(pos && ws && scratch && g, "find_mlp_bwd: NULL argument");
-	FIND_REQUIRE((p->lat_disp == 0) == (lat_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
-	FIND_REQUIRE((p->lat_col == 0) == (lat_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
+	FIND_REQUIRE(p->lat_disp == 0 ? lat_disp == nullptr : (lat_disp != nullptr || d_disp == nullptr), "find_mlp_bwd: lat_disp pointer does not match params");
+	FIND_REQUIRE(p->lat_col == 0 ? lat_col == nullptr : (lat_col != nullptr || d_col == nullptr), "find_mlp_bwd: lat_col pointer does not match params");
 	FIND_REQUIRE(p->precision >= 0 && p->precision <= 3, "find_mlp_bwd: params.precision must be 0, 1, 2 or 3 (got %d)", p->precision);
 	{
 		// weight-gradient buffers: all of them (a head without an upstream gradient may leave its own out: nothing is written for it), or
@@ -1995,7 +2003,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1}, {"group_head0", &find_ctx::group_head0, 0, 1},
 };
 }  // namespace
 

@@ -154,9 +154,9 @@ class _MLP(torch.autograd.Function):
 		pos_batch, V, _ = pos.shape
 		n_feet = pos_batch
 		batches = set()
-		for name, lat, width in (('lat_disp', lat_disp, spec.lat_disp), ('lat_col', lat_col, spec.lat_col)):
+		for name, lat, width, bit in (('lat_disp', lat_disp, spec.lat_disp, 1), ('lat_col', lat_col, spec.lat_col, 2)):
 			if lat is None:
-				if width != 0:
+				if width != 0 and heads & bit:   # (the latents of a head this call does not evaluate may be left out)
 					raise RuntimeError(f'find_amd.mlp: {name} is missing but the head expects {width} latent columns')
 				continue
 			if lat.dim() != 2 or lat.shape[1] != width:

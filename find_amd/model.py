@@ -453,10 +453,11 @@ class NeuralDisplacementField(Model):
 			raise NotImplementedError('onnx_mode (web export) is out of scope')
 		if pos.dim() != 3 or pos.shape[-1] != self.input_dim:
 			raise ValueError(f'pos must be [B, V, {self.input_dim}], got {tuple(pos.shape)}')
-		lat_disp = self._cat_latents(shapevec, posevec)
-		lat_col = self._cat_latents(texvec)
-		got_d = 0 if lat_disp is None else lat_disp.shape[-1]
-		got_c = 0 if lat_col is None else lat_col.shape[-1]
+		# (a head `want` leaves out reads no latents: its concatenation -- a launch on the texture pass's critical chain -- is not formed)
+		lat_disp = self._cat_latents(shapevec, posevec) if 'disp' in want else None
+		lat_col = self._cat_latents(texvec) if 'col' in want else None
+		got_d = self._lat_disp if 'disp' not in want else (0 if lat_disp is None else lat_disp.shape[-1])
+		got_c = self._lat_col if 'col' not in want else (0 if lat_col is None else lat_col.shape[-1])
 		if got_d != self._lat_disp or got_c != self._lat_col:
 			raise RuntimeError(f'latent widths do not match the head input sizes: disp head expects {self._lat_disp} latent columns '
 							   f'(got {got_d}), col head expects {self._lat_col} (got {got_c}); cf. model.py:352,361')

@@ -133,7 +133,8 @@ typedef struct find_mlp_grads {
  * untouched, to find_mlp_bwd. */
 int64_t find_mlp_ws_bytes(const find_mlp_params* p, int64_t pos_batch, int64_t n_feet, int64_t n_pts, int save_for_bwd);
 
-/* pos (pos_batch, n_pts, 3); lat_disp (n_feet, lat_disp) or NULL; lat_col (n_feet, lat_col) or NULL;
+/* pos (pos_batch, n_pts, 3); lat_disp (n_feet, lat_disp) or NULL; lat_col (n_feet, lat_col) or NULL (NULL when params say the head takes no
+ * latents -- or when the call does not evaluate that head: disp / col NULL here, d_disp / d_col NULL in find_mlp_bwd);
  * out: disp (n_feet, n_pts, 3) = 0.1*tanh(.), col (n_feet, n_pts, 3) = 0.5*(1+tanh(.)) [+avg_col]. */
 int find_mlp_fwd(find_ctx* ctx, const find_mlp_params* p, const float* pos, int64_t pos_batch, int64_t n_feet, int64_t n_pts,
 				 const float* lat_disp, const float* lat_col, float* disp, float* col,
