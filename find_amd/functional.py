@@ -283,7 +283,17 @@ class _MLP(torch.autograd.Function):
 				cur.wait_event(pending[3])
 				_sync_at_end_of_backward(cur)
 			if both:
-				torch._foreach_add_([slots[i][0][slots[i][1]:slots[i][1] + grads[i].numel()].view(grads[i].shape) for i in both], [grads[i] for i in both])
+				# Both calls carved their gradients out of ONE flat buffer each, in the same order (_grads_like): where the tensors both
+				# have lie at the same offsets of the two buffers -- the trunk's, in front of either head's -- the sum is ONE contiguous add
+				# (the multi-tensor form it replaces ran 12 workgroups for 18 us at the end of the step and cost the host 35 us).  (The
+				# alignment gaps between slots are added too: nobody reads them.)
+				b0, g0 = slots[both[0]][0], grads[both[0]]._base
+				lo, hi = slots[both[0]][1], slots[both[-1]][1] + grads[both[-1]].numel()
+				if (FOLD_FLAT and g0 is not None and g0.dim() == 1 and b0.dim() == 1 and all(slots[i][0] is b0 and grads[i]._base is g0 and slots[i][1] == grads[i].storage_offset() for i in both)
+						and all(slots[both[k + 1]][1] - (slots[both[k]][1] + ((grads[both[k]].numel() + 3) & ~3)) == 0 for k in range(len(both) - 1))):
+					b0[lo:hi].add_(g0[lo:hi])
+				else:
+					torch._foreach_add_([slots[i][0][slots[i][1]:slots[i][1] + grads[i].numel()].view(grads[i].shape) for i in both], [grads[i] for i in both])
 			out = [None if slots[i] is not None else grads[i] for i in range(len(weights))]
 			return (None, None, g_lat_disp, g_lat_col, None, None, *out)
 		_PENDING_WGRADS.clear()
@@ -297,6 +307,7 @@ class _MLP(torch.autograd.Function):
 
 import os as _os
 DEFER_WGRAD_JOIN = _os.environ.get('FIND_DEFER_WGRADS', '1') != '0'   # switch for A/B runs
+FOLD_FLAT = _os.environ.get('FIND_FOLD_FLAT', '1') != '0'           # switch for A/B runs: the second pass's trunk gradients added with one contiguous add
 _DEFERRED = {}   # device -> tensors the side streams of a deferred find_mlp_bwd may still be using
 
 
