@@ -237,7 +237,7 @@ class ModelWithLoss(nn.Module):
 				if torch.is_tensor(t):
 					t.record_stream(main)
 			main.wait_stream(side)
-		if copy_mask_out:  # what the GT's slicing plane hides is hidden in the prediction too (model.py:1091-1094)
+		if copy_mask_out and not gt.get('nothing_hidden', False):  # what the GT's slicing plane hides is hidden in the prediction too (model.py:1091-1094)
 			hidden = gt['mask_out_masks']
 			# (the image is whitened only for a caller who looks at it: the pixel loss reads it through the mask, which is zero there)
 			if images and mask_image:

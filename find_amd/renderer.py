@@ -117,8 +117,12 @@ class FootRenderer(nn.Module):
 		if return_mask and not want_soft:  # hard mask from the image render (renderer.py:313)
 			mask = torch.any(renders < 1, dim=-1).float()
 
-		mask_out = torch.zeros((N, M, self.params.image_h, self.params.image_w), dtype=torch.bool, device=dev)
-		if mask_out_faces and (masked_faces is not None or uv_tex):
+		# (the all-False map costs a 16-MB fill @512^2: it is made where somebody hides faces or asks for the map, and `nothing_hidden` -- not in
+		# the reference -- tells ModelWithLoss that copying it into the prediction would change nothing)
+		hides = mask_out_faces and (masked_faces is not None or uv_tex)
+		mask_out = torch.zeros((N, M, self.params.image_h, self.params.image_w), dtype=torch.bool, device=dev) if (hides or return_mask_out_masks) else None
+		nothing_hidden = not hides
+		if hides:
 			img = torch.arange(N * M, device=dev, dtype=torch.int32).view(N, M, 1, 1)
 			local = torch.where(p2f >= 0, p2f - img * F, p2f)  # face count within the mesh (renderer.py:322-327)
 			for n in range(N):
@@ -129,6 +133,7 @@ class FootRenderer(nn.Module):
 					# UV indices all point at it; the first mesh without the marker ends the search, as the reference's `break`
 					vu, fu = tex.verts_uvs_padded()[n], tex.faces_uvs_padded()[n]
 					if not bool((vu[-1] == 0).all()):
+						nothing_hidden = nothing_hidden or n == 0
 						break
 					mf = torch.argwhere(torch.all(fu == vu.shape[0] - 1, dim=-1)).flatten()
 				mask_out[n] = torch.isin(local[n], mf.to(dev).to(local.dtype))
@@ -143,4 +148,5 @@ class FootRenderer(nn.Module):
 			out['mask'] = mask
 		if return_mask_out_masks:
 			out['mask_out_masks'] = mask_out
+			out['nothing_hidden'] = nothing_hidden
 		return out
