@@ -91,6 +91,7 @@ PROTOTYPES = {
 	'find_nn_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 	'find_sample_surface_ws_bytes': (c_int64, [_I, _I]),
 	'find_sample_surface_fwd': (c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+	'find_sample_surface_again': (c_int, [_P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
 	'find_chamfer_ws_bytes': (c_int64, [_I, _I, _I]),
 	'find_chamfer_fwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
 	'find_chamfer_bwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

@@ -1141,6 +1141,21 @@ extern "C" int find_sample_surface_fwd(const float* verts, const int32_t* faces,
 	return FIND_OK;
 }
 
+extern "C" int find_sample_surface_again(const float* verts, const int32_t* faces, int64_t faces_batch, const float* rnd, int64_t n_meshes, int64_t n_verts,
+										 int64_t n_faces, int64_t n_samples, int32_t* face_idx, float* uv, float* out, const float* attr, float* attr_out,
+										 const void* ws, int64_t ws_bytes, void* stream) {
+	FIND_REQUIRE(verts && faces && rnd && face_idx && uv && out && ws, "find_sample_surface_again: NULL argument");
+	FIND_REQUIRE((attr == nullptr) == (attr_out == nullptr), "find_sample_surface_again: attr and attr_out must both be given or both NULL");
+	FIND_REQUIRE(!bad_dims(n_meshes, n_samples) && !bad_dims(n_meshes, n_faces) && n_verts >= 1, "find_sample_surface_again: bad sizes");
+	FIND_REQUIRE(faces_batch == 1 || faces_batch == n_meshes, "find_sample_surface_again: faces_batch must be 1 or n_meshes");
+	if (ws_bytes < find_sample_surface_ws_bytes(n_meshes, n_faces)) { set_error("find_sample_surface_again: workspace too small"); return FIND_EWORKSPACE; }
+	const int64_t fstride = faces_batch == 1 ? 0 : n_faces * 3;
+	hipLaunchKernelGGL(sample_surface_kernel, dim3((unsigned)cdiv(n_samples, 256), (unsigned)n_meshes), dim3(256), 0, (hipStream_t)stream, verts, faces, fstride,
+					   (const float*)ws, rnd, (int)n_verts, (int)n_faces, (int)n_samples, face_idx, uv, out, attr, attr_out);
+	FIND_LAUNCH_CHECK("sample_surface (again)");
+	return FIND_OK;
+}
+
 extern "C" int find_masked_mse_fwd(const float* pred, const float* target, int64_t n_pts, float* loss, void* stream) {
 	FIND_REQUIRE(pred && target && loss, "find_masked_mse_fwd: NULL argument");
 	FIND_REQUIRE(n_pts >= 1 && n_pts < (1ll << 40), "find_masked_mse_fwd: bad sizes");

@@ -607,6 +607,11 @@ def sample_points(verts, faces, face_idx, uv, attr=None):
 	return _SamplePoints.apply(verts, faces, face_idx, uv, attr)
 
 
+CACHE_AREA_SUMS = _os.environ.get('FIND_CACHE_AREA_SUMS', '1') != '0'
+_AREA_SUMS = {}         # key -> (running area sums of the meshes, event behind the launch that wrote them)
+_AREA_SUM_OWNERS = {}   # key -> the tensors the key names
+
+
 class _SampleSurface(torch.autograd.Function):
 	"""sample_points_from_meshes with the face choice on the device: rnd (N,S,3) uniform draws [face, u, v] -> points (N,S,3)
 	[, attr samples], plus the chosen faces and (u,v) as non-differentiable outputs (find_sample_surface_fwd)."""
@@ -615,6 +620,7 @@ class _SampleSurface(torch.autograd.Function):
 	def forward(ctx, verts, faces, rnd, attr):
 		_require_gpu(verts, rnd, attr)
 		L = _lib.lib()
+		verts_in, faces_in = verts, faces
 		verts, rnd, attr = _c(verts), _c(rnd), _c(attr)
 		faces = _faces_i32(faces)
 		N, V, _ = verts.shape
@@ -628,9 +634,34 @@ class _SampleSurface(torch.autograd.Function):
 		aout = torch.empty_like(out) if attr is not None else None
 		face_idx = torch.empty(N, S, device=dev, dtype=torch.int32)
 		uv = torch.empty(N, S, 2, device=dev, dtype=torch.float32)
-		ws = _ws(L.find_sample_surface_ws_bytes(N, F), dev)
-		check(L.find_sample_surface_fwd(ptr(verts.detach()), ptr(faces), fb, ptr(rnd), N, V, F, S, ptr(face_idx), ptr(uv), ptr(out), ptr(attr), ptr(aout),
-										ptr(ws), ws.numel(), current_stream(dev)), 'find_sample_surface_fwd')
+		# A mesh that carries no gradient (a GT scan: sampled twice per training step, the same tensors step after step) keeps its running
+		# area sum: keyed by the tensors' storage AND version counters (an in-place torch op on either invalidates the entry), a handful of
+		# entries, ordered behind the stream that built them by an event.  (four launches per step.)
+		key = None
+		if CACHE_AREA_SUMS and not verts.requires_grad and not torch.cuda.is_current_stream_capturing():
+			key = (verts_in.data_ptr(), verts_in._version, faces_in.data_ptr(), faces_in._version, N, V, F, fb, dev.index)
+			hit = _AREA_SUMS.get(key)
+			if hit is not None:
+				ws, ev, made_on = hit
+				cur = current_stream(dev)
+				if cur.value != made_on:   # (a stream sees its own earlier work)
+					torch.cuda.current_stream(dev).wait_event(ev)
+				check(L.find_sample_surface_again(ptr(verts), ptr(faces), fb, ptr(rnd), N, V, F, S, ptr(face_idx), ptr(uv), ptr(out), ptr(attr), ptr(aout),
+												  ptr(ws), ws.numel(), current_stream(dev)), 'find_sample_surface_again')
+				key = False   # (the entry keeps `ws` alive: no record_stream)
+		if key is not False:
+			ws = _ws(L.find_sample_surface_ws_bytes(N, F), dev)
+			check(L.find_sample_surface_fwd(ptr(verts.detach()), ptr(faces), fb, ptr(rnd), N, V, F, S, ptr(face_idx), ptr(uv), ptr(out), ptr(attr), ptr(aout),
+											ptr(ws), ws.numel(), current_stream(dev)), 'find_sample_surface_fwd')
+			if key is not None:
+				ev = torch.cuda.Event()
+				ev.record(torch.cuda.current_stream(dev))
+				if len(_AREA_SUMS) >= 8:
+					_AREA_SUMS.pop(next(iter(_AREA_SUMS)))
+				_AREA_SUMS[key] = (ws, ev, current_stream(dev).value)
+				_AREA_SUM_OWNERS[key] = (verts_in, faces_in)   # (the keyed tensors stay alive with the entry: a freed and re-used address cannot alias it)
+				for k in [k for k in _AREA_SUM_OWNERS if k not in _AREA_SUMS]:
+					del _AREA_SUM_OWNERS[k]
 		ctx.save_for_backward(faces, face_idx, uv)
 		ctx.dims = (N, V, F, S, fb)
 		ctx.has_attr = attr is not None

@@ -292,6 +292,11 @@ int64_t find_sample_surface_ws_bytes(int64_t n_meshes, int64_t n_faces);
 int find_sample_surface_fwd(const float* verts, const int32_t* faces, int64_t faces_batch, const float* rnd, int64_t n_meshes,
 							int64_t n_verts, int64_t n_faces, int64_t n_samples, int32_t* face_idx, float* uv, float* out,
 							const float* attr, float* attr_out, void* ws, int64_t ws_bytes, void* stream);
+/* The same for a mesh whose running area sum is already in `ws`: left there by an earlier find_sample_surface_fwd on the SAME verts /
+ * faces (a GT scan is sampled twice per training step and does not change between steps: losses.py:39,63).  Only the search + gather run. */
+int find_sample_surface_again(const float* verts, const int32_t* faces, int64_t faces_batch, const float* rnd, int64_t n_meshes,
+							  int64_t n_verts, int64_t n_faces, int64_t n_samples, int32_t* face_idx, float* uv, float* out,
+							  const float* attr, float* attr_out, const void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Chamfer nearest neighbour (K=1, squared L2, brute force).

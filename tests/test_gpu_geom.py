@@ -190,6 +190,49 @@ def test_nn_packed_four_queries_per_lane():
 	assert (d.cpu() - rd).abs().max().item() < 1e-7
 
 
+def test_sample_surface_keeps_the_area_sums_of_meshes_without_gradient():
+	"""A mesh that carries no gradient (a GT scan) is sampled from its KEPT running area sum on later calls (find_sample_surface_again;
+	functional._AREA_SUMS): same samples as a fresh call for the same draws, other draws work, an in-place change of the vertices drops the
+	entry (the samples follow the new vertices), a mesh with gradient never enters the cache."""
+	from find_amd import functional as FN
+	verts, faces = _mesh(1002, n=3, seed=21)
+	v, f = verts.cuda(), faces.cuda()
+	rnd = torch.rand(3, 4000, 3, generator=torch.Generator().manual_seed(22)).cuda()
+	rnd2 = torch.rand(3, 700, 3, generator=torch.Generator().manual_seed(23)).cuda()
+	FN._AREA_SUMS.clear()
+	a = FN.sample_surface(v, f, rnd)
+	assert len(FN._AREA_SUMS) == 1
+	b = FN.sample_surface(v, f, rnd)            # from the kept sums
+	assert len(FN._AREA_SUMS) == 1
+	assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+	c = FN.sample_surface(v, f, rnd2)           # other draws, another sample count, on another stream
+	side = torch.cuda.Stream()
+	side.wait_stream(torch.cuda.current_stream())
+	with torch.cuda.stream(side):
+		c2 = FN.sample_surface(v, f, rnd2)
+	torch.cuda.current_stream().wait_stream(side)
+	assert torch.equal(c[0], c2[0]) and torch.equal(c[2], c2[2])
+	prev = FN.CACHE_AREA_SUMS
+	try:
+		FN.CACHE_AREA_SUMS = False
+		c3 = FN.sample_surface(v, f, rnd2)
+	finally:
+		FN.CACHE_AREA_SUMS = prev
+	assert torch.equal(c[0], c3[0]) and torch.equal(c[2], c3[2])
+	v[0, :, 0] *= 3.0                           # in place: the version counter moves, the entry no longer matches
+	d = FN.sample_surface(v, f, rnd)
+	try:
+		FN.CACHE_AREA_SUMS = False
+		d2 = FN.sample_surface(v, f, rnd)
+	finally:
+		FN.CACHE_AREA_SUMS = prev
+	assert torch.equal(d[0], d2[0]) and torch.equal(d[2], d2[2]) and not torch.equal(d[2][0], a[2][0])
+	n = len(FN._AREA_SUMS)
+	vg = v.clone().requires_grad_(True)
+	FN.sample_surface(vg, f, rnd)
+	assert len(FN._AREA_SUMS) == n
+
+
 def test_sample_surface_faces_follow_the_area_distribution():
 	"""find_sample_surface_fwd: the face of every sample is the one the float64 running sum of the oracle's areas assigns to the
 	sample's draw (mismatches only where the draw sits within rounding of a boundary), the points are the oracle's for those faces,
