@@ -868,7 +868,7 @@ def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=F
 	ms = run.timed(step, steps, warmup)
 	cfg = {'workload': f'{"C4 rank share" if c4 else "C3"}: {n_feet} feet x {n_views} views @{size}^2 per GPU, {N_VERTS}-vertex template, {N_GT_VERTS}-vertex GT '
 					   f'scans re-rendered every step, {"sil+pix+chamf losses" if c4 else "silhouette loss"}, backward through rasteriser + MLP, Adam step; '
-					   + ('uniform triangulations (Fibonacci-sphere hulls, F = 2V - 4)' if mesh == 'uniform' else 'latitude-longitude grids (pole slivers: binning stress case)'),
+					   + ('uniform triangulations (Fibonacci-sphere hulls, F = 2V - 4, vertices in Morton order)' if mesh == 'uniform' else 'latitude-longitude grids (pole slivers: binning stress case)'),
 		   'mesh': mesh, 'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{run.world}'}
 	out = line(run.world * n_feet * N_VERTS * n_views / (ms * 1e-3), ms, run, steps, warmup, cfg)
 	if bucket is not None:

@@ -42,6 +42,10 @@ def ellipsoid_mesh(rings, segs, axes=(0.12, 0.045, 0.04)):
 # convex hull (valence 5 - 7 everywhere, the same V and F = 2 V - 4): what a decimated scan or FIND's own template looks like to a rasteriser.
 # bench.py reports the render configurations on both: 'uniform' is the record c3 / c4_rank_share, 'latlong' the records *_latlong_stress.
 MESH_KIND = 'latlong'
+# Vertex / face order of the 'uniform' meshes: 'morton' (default: spatially coherent, below) or 'lattice' (the Fibonacci lattice's own
+# spiral order with faces sorted by their first vertex, as round 5 and the first half of round 6 generated them; FIND_UNIFORM_ORDER).
+import os as _os
+UNIFORM_ORDER = _os.environ.get('FIND_UNIFORM_ORDER', 'morton')
 
 
 def uniform_sphere_mesh(n_verts):
@@ -53,10 +57,25 @@ def uniform_sphere_mesh(n_verts):
 	r = np.sqrt(np.maximum(0.0, 1.0 - z * z))
 	ph = i * (math.pi * (3.0 - math.sqrt(5.0)))
 	v = np.stack([r * np.cos(ph), r * np.sin(ph), z], -1)
+	# Vertices in a spatially coherent order (Morton code of the position, 10 bits per axis), faces by their lowest vertex: neighbours in
+	# memory are neighbours in space, as in the meshes modelling tools and scan pipelines write (FIND's template, decimated scans) -- and
+	# as in the latitude-longitude grids.  The lattice's own order runs along a spiral: 64 consecutive faces then span a whole ring of the
+	# sphere, and a rasteriser's per-run bounding boxes (bin_kernel: runs of 64 faces) cull nothing -- round 6 measured bin_kernel at
+	# 1.8 x its latitude-longitude time on lattice-ordered meshes (profiles/r06_raster_pmc_uniform_*.txt, taken before this ordering).
+	q = np.clip(((v + 1.0) * 0.5 * 1023.0).astype(np.int64), 0, 1023)
+	code = np.zeros(n_verts, np.int64)
+	for bit in range(10):
+		for ax in range(3):
+			code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+	if UNIFORM_ORDER == 'morton':
+		v = v[np.argsort(code, kind='stable')]
 	f = ConvexHull(v).simplices.astype(np.int64)
 	n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
 	flip = (n * v[f[:, 0]]).sum(-1) < 0
 	f[flip] = f[flip][:, [0, 2, 1]]
+	if UNIFORM_ORDER == 'morton':
+		k = f.argmin(1)   # rotate every face so that its lowest vertex comes first (orientation unchanged)
+		f = np.stack([f[np.arange(len(f)), k], f[np.arange(len(f)), (k + 1) % 3], f[np.arange(len(f)), (k + 2) % 3]], -1)
 	f = f[np.lexsort((f[:, 2], f[:, 1], f[:, 0]))]
 	assert f.shape[0] == 2 * n_verts - 4
 	return torch.from_numpy(v.astype(np.float32)), torch.from_numpy(f)

@@ -6,6 +6,7 @@ from find_amd import functional_render as FR, synthetic
 from find_amd.cameras import look_at_view_transform
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 want_image = (sys.argv[2] != '0') if len(sys.argv) > 2 else True
+synthetic.MESH_KIND = os.environ.get('FIND_MESH_KIND', synthetic.MESH_KIND)   # 'uniform': pole-free triangulation
 v, f = synthetic.template(6890)
 g = torch.Generator().manual_seed(0)
 verts = (v[None] * (1 + 0.1 * torch.rand(16, 1, 3, generator=g))).cuda()

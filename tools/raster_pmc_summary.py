@@ -10,7 +10,8 @@ import sys
 
 O = sys.argv[1]
 evals = float(sys.argv[2]) if len(sys.argv) > 2 else None
-KERNELS = ('raster_kernel', 'bin_kernel', 'sil_bwd_kernel', 'tie_fix_kernel', 'face_setup_kernel')
+import os
+KERNELS = ('raster_kernel', 'raster_band_kernel', 'bin_kernel', 'sil_bwd_kernel', 'tie_fix_kernel', 'face_setup_kernel')
 dur = collections.defaultdict(list)
 for f in glob.glob(O + '/trace/*/*kernel_trace.csv'):
 	for r in csv.DictReader(open(f)):
@@ -24,7 +25,7 @@ for f in glob.glob(O + '/pmc_*/*/*counter_collection.csv'):
 			if k in r['Kernel_Name']:
 				cnt[k][r['Counter_Name']].append(float(r['Counter_Value']))
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in cnt.items()}
-print('# Rasteriser evidence at the C3 render shape (16 feet x 4 views @256^2, V=6890, F=13776, silhouette only), MI355X.')
+print(f"# Rasteriser evidence: 16 feet x 4 views @{os.environ.get('RENDER_SIZE', '256')}^2, V=6890, F=13776, silhouette only, {os.environ.get('FIND_MESH_KIND', 'latlong')} template, MI355X.")
 print('# Command: bash tools/prof_raster.sh <out> full; every figure below is computed by tools/raster_pmc_summary.py from the tables that follow.')
 for k in KERNELS:
 	if k not in dur and k not in avg:
@@ -43,7 +44,7 @@ for k in KERNELS:
 		line += ';'
 	if 'SQ_INSTS_VALU' in a:
 		line += f' SQ_INSTS_VALU {a["SQ_INSTS_VALU"] / 1e6:.1f} M wave-instructions'
-		if evals and k == 'raster_kernel':
+		if evals and k in ('raster_kernel', 'raster_band_kernel'):
 			line += f' = {a["SQ_INSTS_VALU"] / evals:.0f} per (wave, face) evaluation ({evals / 1e6:.2f} M evaluations)'
 		if 'GRBM_GUI_ACTIVE' in a:
 			cyc = a['GRBM_GUI_ACTIVE'] / 8   # summed over the 8 XCDs
