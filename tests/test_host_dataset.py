@@ -96,6 +96,50 @@ def test_right_feet_are_mirrored_and_caching_and_no_texture(foot3d):
 	assert ds[0]['textures'] is not None
 
 
+def test_spatial_order_relabels_a_scan_without_changing_it(foot3d):
+	"""Foot3DDataset(spatial_order=True) / dataset.spatial_order: the same surface in a spatially coherent memory order (the
+	rasteriser's binning pass) -- the set of (position, uv) corners of every triangle, the orientation and the keypoints' positions are those
+	of the file; the faces are sorted by their lowest vertex."""
+	from find_amd.dataset import Foot3DDataset, ScanStore, spatial_order
+	cfg, _ = foot3d
+	ScanStore.shared.clear()
+	plain = Foot3DDataset(cfg, device='cpu', is_train=True, train_and_val=True)
+	moved = Foot3DDataset(cfg, device='cpu', is_train=True, train_and_val=True, spatial_order=True)
+	assert len(plain) == len(moved) > 0
+	for i in range(len(plain)):
+		a, b = plain[i], moved[i]
+
+		def corners(item):
+			v, f = item['verts'].double(), item['faces']
+			uv = item['textures'].verts_uvs_padded()[0].double()[item['textures'].faces_uvs_padded()[0]]   # (F, 3, 2)
+			tri = torch.cat([v[f], uv], -1)                                                                  # (F, 3, 5)
+			# a triangle up to rotation of its corners: start at the lexicographically smallest corner
+			key = tri[..., 0] * 1e6 + tri[..., 1] * 1e3 + tri[..., 2]
+			k = key.argmin(1)
+			rows = torch.arange(tri.shape[0])
+			tri = torch.stack([tri[rows, k], tri[rows, (k + 1) % 3], tri[rows, (k + 2) % 3]], 1).reshape(-1, 15)
+			return tri[np.lexsort(tri.numpy().T[::-1])]
+
+		assert torch.allclose(corners(a), corners(b), atol=1e-7)   # (the centring subtracts a mean formed in another order)
+		fb = b['faces']
+		assert bool((fb[:, 0] <= fb[:, 1]).all() and (fb[:, 0] <= fb[:, 2]).all()) and bool((fb[1:, 0] >= fb[:-1, 0]).all())
+		if a['has_keypoints']:
+			assert torch.allclose(a["verts"][torch.as_tensor(a["kp_idxs"])], b["verts"][torch.as_tensor(b["kp_idxs"])], atol=1e-7)
+	# the utility alone: a permuted grid comes back with short runs
+	g = torch.Generator().manual_seed(0)
+	n = 24
+	ii, jj = torch.meshgrid(torch.arange(n), torch.arange(n), indexing='ij')
+	v = torch.stack([ii.flatten() * 0.01, jj.flatten() * 0.01, torch.zeros(n * n)], -1)
+	idx = lambda i, j: i * n + j
+	f = torch.tensor([[idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)] for i in range(n - 1) for j in range(n - 1)])
+	perm = torch.randperm(n * n, generator=g)
+	inv = torch.empty_like(perm); inv[perm] = torch.arange(n * n)
+	v2, f2, vertex_of, face_of, shift = spatial_order(v[perm], inv[f][torch.randperm(f.shape[0], generator=g)])
+	cen = v2[f2].mean(1)
+	run = [float((cen[k:k + 64].max(0).values - cen[k:k + 64].min(0).values).norm()) for k in range(0, f2.shape[0], 64)]
+	assert sum(run) / len(run) < 0.12   # (a 64-face patch of this grid is ~0.08 across; a random order spans the whole 0.33)
+
+
 def test_collator_builds_ragged_meshes_with_joined_uv_textures(foot3d):
 	from find_amd.dataset import BatchCollator, Foot3DDataset
 	cfg, _ = foot3d
