@@ -69,6 +69,7 @@ class GradBucket:
 		self.early_issued = 0   # steps in which the prefix went out early (diagnostics / tests)
 		self.early_dropped = 0  # early collectives whose result had to be dropped (diagnostics / tests)
 		self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
+		self._flat_early, self._flat_rest = self.flat[:self.n_early], self.flat[self.n_early:]
 		# (per-slot constants of take(): it runs once per gradient tensor and backward pass -- 40 times per FIND step -- on the host's critical path)
 		self._shapes = [tuple(p.shape) for p in self.params]
 		self._strides = [tuple(p.contiguous().stride()) if p.dim() else () for p in self.params]
@@ -82,8 +83,49 @@ class GradBucket:
 			from . import functional
 			functional.register_grad_arena(self, self.params)
 
+	def _comm(self):
+		"""(process group, its all-reduce options, whether the backend averages) -- looked up once: the c10d python wrapper around a collective
+		(argument checks, logging decorator, backend look-up) costs the host 15 us per call, and the data-parallel step is bound by its host."""
+		c = getattr(self, '_comm_cache', None)
+		if c is None:
+			from torch.distributed import distributed_c10d as c10d
+			pg = self.group if self.group is not None else c10d._get_default_group()
+			avg = dist.get_backend(self.group) == 'nccl'
+			opts = c10d.AllreduceOptions()
+			opts.reduceOp = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+			c = self._comm_cache = (pg, opts, avg)
+		return c
+
+	def _all_reduce_async(self, tensor):
+		pg, opts, avg = self._comm()
+		return pg.allreduce([tensor], opts), avg
+
 	def _view(self, i):
 		return self.flat.as_strided(self._shapes[i], self._strides[i], self.offsets[i])   # (one op: slice + view were two)
+
+	def take_many(self, slots, tensors):
+		"""take() for the slots of `tensors` at once (a backward kernel wrapper asks for a whole layer list: 26 calls of take() were 40 us of the
+		data-parallel step's host time)."""
+		first = True
+		out = []
+		flat, shapes, strides, offsets, ptrs, params = self.flat, self._shapes, self._strides, self.offsets, self._ptrs, self.params
+		for i, t in zip(slots, tensors):
+			if first:
+				v = self.take(i, t.shape, t.device)   # (the per-pass book-keeping runs here)
+				first = False
+				out.append(v)
+				continue
+			taken = self.taken
+			if taken[i] or t.shape != shapes[i] or t.device != flat.device:
+				out.append(None)
+				continue
+			g = params[i].grad
+			if g is not None and g.data_ptr() == ptrs[i]:
+				out.append(None)
+				continue
+			taken[i] = True
+			out.append(flat.as_strided(shapes[i], strides[i], offsets[i]))
+		return out
 
 	def take(self, i, shape, device):
 		"""Arena request from a backward kernel wrapper: a FRESH view of slot i (autograd adopts a gradient tensor only when nothing
@@ -146,8 +188,7 @@ class GradBucket:
 				# parked slots on THAT stream and reports no gradient, so autograd has not ordered this hook behind it
 				for s in functional._CROSS_STREAMS:
 					torch.cuda.current_stream(s.device).wait_stream(s)
-			avg = dist.get_backend(self.group) == 'nccl'
-			work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+			work, avg = self._all_reduce_async(self._flat_early)
 			self._early = (work, None if avg else dist.get_world_size(self.group))
 			self.early_issued += 1
 		self._hook = trigger.register_post_accumulate_grad_hook(fire)
@@ -193,9 +234,8 @@ class GradBucket:
 			torch._foreach_zero_([v for _, v in missing])
 		if src:
 			torch._foreach_copy_(dst, src)
-		avg = dist.get_backend(self.group) == 'nccl'   # RCCL averages in place; gloo has no AVG: sum, then divide
-		rest = self.flat[self.n_early:] if early is not None else self.flat
-		work = dist.all_reduce(rest, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True) if rest.numel() else None
+		rest = self._flat_rest if early is not None else self.flat
+		work, avg = self._all_reduce_async(rest) if rest.numel() else (None, self._comm()[2])   # RCCL averages in place; gloo has no AVG: sum, then divide
 		self._pending = (work, None if avg else world, src, dst, missing, early, rest)
 		if not async_op:
 			self.wait()

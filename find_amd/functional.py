@@ -61,12 +61,18 @@ def _grads_like(tensors):
 	out = [None] * len(tensors)
 	rest = []
 	if _GRAD_ARENA:
-		for i, t in enumerate(tensors):
-			ent = _GRAD_ARENA.get((t.data_ptr(), t.numel()))
+		ents = [_GRAD_ARENA.get((t.data_ptr(), t.numel())) for t in tensors]
+		b0 = next((e[0] for e in ents if e is not None), None)
+		if b0 is not None and all(e is not None and e[0] is b0 for e in ents):   # (the usual case: one bucket holds them all)
+			return _fill_rest(b0.take_many([e[1] for e in ents], tensors), tensors)
+		for i, (t, ent) in enumerate(zip(tensors, ents)):
 			out[i] = ent[0].take(ent[1], t.shape, t.device) if ent is not None else None
-	for i, t in enumerate(tensors):
-		if out[i] is None:
-			rest.append(i)
+	return _fill_rest(out, tensors)
+
+
+def _fill_rest(out, tensors):
+	"""Views of ONE fresh allocation for the entries of `out` that are still None."""
+	rest = [i for i, v in enumerate(out) if v is None]
 	if rest:
 		# 16-byte aligned slots (the slab reduce stores float4)
 		offs, n = [], 0
@@ -289,9 +295,10 @@ class _MLP(torch.autograd.Function):
 				# alignment gaps between slots are added too: nobody reads them.)
 				b0, g0 = slots[both[0]][0], grads[both[0]]._base
 				lo, hi = slots[both[0]][1], slots[both[-1]][1] + grads[both[-1]].numel()
-				if (FOLD_FLAT and g0 is not None and g0.dim() == 1 and b0.dim() == 1 and all(slots[i][0] is b0 and grads[i]._base is g0 and slots[i][1] == grads[i].storage_offset() for i in both)
+				shift = grads[both[0]].storage_offset() - lo   # (a data-parallel run parks the first call's gradients in the bucket's arena: another base, the same spacing)
+				if (FOLD_FLAT and g0 is not None and g0.dim() == 1 and b0.dim() == 1 and all(slots[i][0] is b0 and grads[i]._base is g0 and slots[i][1] + shift == grads[i].storage_offset() for i in both)
 						and all(slots[both[k + 1]][1] - (slots[both[k]][1] + ((grads[both[k]].numel() + 3) & ~3)) == 0 for k in range(len(both) - 1))):
-					b0[lo:hi].add_(g0[lo:hi])
+					b0[lo:hi].add_(g0[lo + shift:hi + shift])
 				else:
 					torch._foreach_add_([slots[i][0][slots[i][1]:slots[i][1] + grads[i].numel()].view(grads[i].shape) for i in both], [grads[i] for i in both])
 			out = [None if slots[i] is not None else grads[i] for i in range(len(weights))]
