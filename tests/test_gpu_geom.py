@@ -351,6 +351,15 @@ def test_masked_mse_vs_torch():
 	assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item())
 	assert (pg.grad.cpu() - pr.grad).abs().max().item() < 1e-6 * pr.grad.abs().max().item()
 	assert float(pg.grad[0, :100].abs().max()) == 0.0
+	# sizes that leave points past the last group of four, and tensors that do not start on a 16-byte boundary (the scalar path)
+	for n_pts, shift in ((1003, 0), (7, 0), (1, 0), (1001, 1), (16000, 0)):
+		pred = torch.rand(n_pts + shift, 3, generator=g)
+		gt = torch.rand(n_pts + shift, 3, generator=g) * 1.3
+		gt[::7] = 1.25
+		loss = FN.masked_mse(pred.cuda()[shift:][None], gt.cuda()[shift:][None])
+		mask = (gt[shift:] < 1).any(dim=-1, keepdim=True).expand(-1, 3)
+		ref = (torch.nn.functional.mse_loss(pred[shift:], gt[shift:], reduction='none') * mask).double().mean()
+		assert abs(loss.item() - ref.item()) < 2e-6 * abs(ref.item()) + 1e-12, (n_pts, shift, loss.item(), ref.item())
 
 
 def test_smoothness_loss_scalar_vs_oracle():
