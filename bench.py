@@ -628,9 +628,22 @@ def time_small_pass(device, n_pts, shared, iters=40, warm=20):
 
 
 # Time per step of the kernels that take the most of it INSIDE the headline step (rocprofv3 --kernel-trace of `bench.py --headline-only`, steps cut at
-# the optimiser kernel: profiles/r04_headline_step_stats.csv; several streams run side by side there, so these sum to more than the step).
-# time per step inside the headline step (profiles/r04_headline_step_stats.csv: us_per_step, all launches of the kernel in a step, side streams running)
-IN_STEP_US = {'fused6_kernel<2>': 249.6, 'dw6_kernel': 351.4, 'gemm7_kernel<2>': 221.8, 'fused6_kernel<1>': 130.0, 'gemm7_kernel<1>': 155.3, 'dwpe_kernel': 215.2, 'dw4_group_kernel': 200.2}
+# the optimiser kernel; several streams run side by side there, so these sum to more than the step): read from the newest committed
+# profiles/rNN_headline_step_stats.csv, as roofline.traffic is read from the newest PMC summary -- no figure typed into this file.
+def in_step_us(*needles):
+	"""us per step of all launches whose kernel name contains one of `needles`, and the file it came from; (None, None) without a file."""
+	import csv
+	import glob
+	files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_headline_step_stats.csv')))
+	if not files:
+		return None, None
+	tot, hit = 0.0, False
+	with open(files[-1]) as f:
+		for row in csv.DictReader(ln for ln in f if not ln.startswith('#')):
+			if any(n in row['kernel'] for n in needles):
+				tot += float(row['us_per_step'])
+				hit = True
+	return (tot if hit else None), os.path.basename(files[-1])
 
 
 def dominant_roofline(device, fp16=False, n_verts=None):
@@ -652,7 +665,7 @@ def dominant_roofline(device, fp16=False, n_verts=None):
 	if FF.get_mlp_precision() == 'bf16x3':
 		# six bf16 products per fp32 multiply-accumulate: the flops the matrix pipe EXECUTES are 6 x the layer's
 		ex = 6.0 * ach
-		return {'bound': 'mfma', 'kernel': f'find::mlp::gemm7_kernel<1, 0> (Linear 256->256 + bias + ReLU over {rows} rows; bf16x3: v_mfma_f32_16x16x32_bf16, fp32 accumulation)',
+		return {'bound': 'mfma', 'kernel': f'find::mlp::gemm7_kernel<1, 0, false> (Linear 256->256 + bias + ReLU over {rows} rows; bf16x3: v_mfma_f32_16x16x32_bf16, fp32 accumulation)',
 				'achieved': ex, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex / PEAK_BF16_MFMA_TFLOPS,
 				'avg_kernel_ms': kms, 'flops_per_launch': 6.0 * kflops, 'flops_per_launch_fp32_equivalent': kflops,
 				'fp32_equivalent_tflops': ach, 'x_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
@@ -687,12 +700,12 @@ def roofline_kernels(device, lin_ms):
 		e = {'kernel': name, 'what': what, 'flops_fp32_equivalent': flops32, 'isolated_us': us, 'fp32_equivalent_tflops': flops32 / (us * 1e-6) / 1e12,
 			 'executed_tflops': ex / (us * 1e-6) / 1e12, 'pipe': 'bf16 MFMA (bf16x3: 6 products per multiply-accumulate)' if executed_mul == 6.0 else 'fp32 MFMA',
 			 'frac': ex / (us * 1e-6) / 1e12 / (PEAK_BF16_MFMA_TFLOPS if executed_mul == 6.0 else PEAK_FP32_MFMA_TFLOPS),
-			 'in_step_us_per_step': IN_STEP_US.get(in_step_key)}
+			 'in_step_us_per_step': in_step_us(*in_step_key)[0], 'in_step_source': in_step_us(*in_step_key)[1]}
 		out.append(e)
 
-	entry('gemm7_kernel<1>' if x3 else 'gemm4_kernel<1,4,8>', f'Linear 256->256 + bias + ReLU over {rows} rows (forward; 2 launches per step)', L, lin_ms * 1e3, mul, 'gemm7_kernel<1>')
+	entry('gemm7_kernel<1>' if x3 else 'gemm4_kernel<1,4,8>', f'Linear 256->256 + bias + ReLU over {rows} rows (forward; 2 launches per step)', L, lin_ms * 1e3, mul, ('gemm7_kernel<1,',) if x3 else ('gemm4_kernel<1',))
 	wg_ms = time_wgrad_kernel(device)
-	entry(('dw6_kernel' if x3 else 'dw4_kernel') + ' + reduce_w_kernel', f'dW = dZ^T X over {rows} rows + its slab reduce (2 launches per step)', L, wg_ms * 1e3, mul, 'dw6_kernel')
+	entry(('dw6_kernel' if x3 else 'dw4_kernel') + ' + reduce_w_kernel', f'dW = dZ^T X over {rows} rows + its slab reduce (2 launches per step)', L, wg_ms * 1e3, mul, ('dw6_kernel', 'dw6v_kernel') if x3 else ('dw4_kernel',))
 	# the small calls run whole layer chains per launch (bf16x3: fused6_kernel on the bf16 pipe; fp32: fused_chain_kernel): time the call (the chain
 	# + the handful of small launches around it: repack, latent bias, weight split, head output)
 	r = N_FEET * 1000
@@ -702,11 +715,12 @@ def roofline_kernels(device, lin_ms):
 	f_ms, fb_ms = time_small_pass(device, 1000, shared=False)
 	chain = 'fused6_kernel<2>' if x3 else 'fused_chain_kernel<2>'
 	entry(chain + ' (forward call)', f'texture pass forward: {N_FEET} x 1000 per-foot points, Fourier layer + trunk + colour head in one launch (+ repack, latent bias, '
-		  'weight split, 3-wide output around it)', tex_fwd, f_ms * 1e3, mul, chain)
-	# the backward call mixes pipes under bf16x3 (dX chain: bf16x3; the grouped weight gradients dw4_group and the Fourier layer's dwpe: fp32 MFMA): priced
-	# against the fp32 MFMA peak in the layer's own flop count
-	entry(chain + ' + dw4_group + dwpe (backward call)', 'texture pass backward: dX chain in one launch' + (' (bf16x3)' if x3 else '') + ', seven weight gradients as one grouped '
-		  'launch and the Fourier layer\'s beside them (fp32 MFMA); frac = fp32-equivalent flops against the fp32 MFMA peak', tex_bwd, (fb_ms - f_ms) * 1e3, 1.0, chain)
+		  'weight split, 3-wide output around it)', tex_fwd, f_ms * 1e3, mul, (chain,))
+	# the backward call: dX chain in one launch, the seven weight gradients as one grouped launch (bf16x3: dw6_group) and the Fourier layer's beside
+	# them (dwpe6); since round 6 all of it on the bf16 pipe under bf16x3 -- priced as executed products against that pipe's peak
+	grp = ('dw6_group_kernel', 'dwpe6_kernel') if x3 else ('dw4_group_kernel', 'dwpe_kernel')
+	entry(chain + ' + ' + ' + '.join(grp) + ' (backward call)', 'texture pass backward: dX chain in one launch, seven weight gradients as one grouped launch and the '
+		  "Fourier layer's beside them (in_step: the grouped + Fourier weight-gradient kernels of BOTH passes of a step)", tex_bwd, (fb_ms - f_ms) * 1e3, mul, grp)
 	return out
 
 
