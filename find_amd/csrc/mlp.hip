@@ -128,7 +128,7 @@ static void carve_fwd(const find_mlp_params* p, const Dims& d, bool save, void* 
 
 // Per-device state of the MLP entry points (find_hip.h: find_ctx_create).  Nothing below is process-global.
 enum { K_GEMM2_PE = 0, K_GEMM3_RELU, K_GEMM3_MASK, K_GEMM3_NONE, K_GEMM4_4_RELU, K_GEMM4_4_MASK, K_GEMM4_4_NONE, K_GEMM4_2_RELU, K_GEMM4_2_MASK,
-	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_GEMM5_RELU_V, K_GEMM5_MASK_V, K_DW3_V, K_GEMM7_RELU_V, K_GEMM7_MASK_V, K_DW6_V, K_COUNT };
+	   K_GEMM4_2_NONE, K_GEMM5_RELU, K_GEMM5_MASK, K_GEMM5_NONE, K_GEMM6_RELU, K_GEMM6_MASK, K_GEMM6_NONE, K_GEMM7_RELU, K_GEMM7_MASK, K_GEMM7_NONE, K_DW2, K_DW3, K_DW6, K_DW6G, K_FUSED, K_FUSED2, K_FUSED6, K_FUSED6_2, K_DW2G, K_REDUCE, K_DW2_REPRO, K_GEMM5_RELU_H, K_GEMM5_MASK_H, K_DW3_H, K_GEMM5_RELU_V, K_GEMM5_MASK_V, K_DW3_V, K_GEMM7_RELU_V, K_GEMM7_MASK_V, K_DW6_V, K_GEMM7_MASK_VF, K_COUNT };
 constexpr int N_SIDE = 4;       // internal streams: 0 = q (large head layers' dW), 1 / 2 = first head layers + trunk layers, 3 = slab reduces
 constexpr int N_EVENTS = 512;   // event ring: an MLP call with 3 x 8 layers uses ~170; checked per call
 
@@ -188,6 +188,7 @@ struct find_ctx {
 	struct Act16Note { const void* ws; bool a16; bool fold; };
 	Act16Note act16_notes[16] = {};
 	int act16_next = 0;
+	int footsum_fold = 1;         // knob: the foot sums of a shared template's first-layer dZ are formed inside the dX GEMM that produces it (mlp_gemm7.h FSUM)
 	int group_head0 = 1;          // knob: a shared template's first head layers' weight gradients ride in the trunk's grouped launch (mlp_bwd_body)
 	int bcast_fold = 1;           // knob: inside act16 the broadcast first head layer's output is formed by its readers instead of stored (use_fold)
 	int act16 = 1;                // knob: in the opt-in fp16 mode the heads' hidden activations and their gradients are STORED as fp16 at the large
@@ -480,7 +481,29 @@ static int launch_gemm7_virt(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t
 	return FIND_OK;
 }
 
+// workgroup pairs of the folded-foot-sum launch: the usual count, but never so many that a pair's unit range is shorter than a tile's run of
+// feet (mlp_gemm7.h FSUM: a tile then has at most two partial sums); 0 = the shape does not qualify
+static int gemm7_fsum_pairs(const find_ctx* c, int64_t V, int64_t feet) {
+	const int64_t upf = cdiv(V, 32);
+	const int def = std::max(16, (c->num_cus / 16) * 16) / 2;
+	const int pairs = (int)std::min<int64_t>(def, (upf / 8) * 8);   // (the two column halves of a pair sit 8 blocks apart: pairs come in eights)
+	return (feet >= 2 && feet <= 64 && pairs >= 8) ? pairs : 0;
+}
+
+static int launch_gemm7_fsum(find_ctx* c, Gemm2Args a, int64_t feet, hipStream_t s) {   // (footsum_fold: mlp_gemm7.h FSUM)
+	const int pairs = gemm7_fsum_pairs(c, a.V, feet);
+	FIND_REQUIRE(pairs > 0, "launch_gemm7_fsum: shape does not qualify (footsum_fold and the kernel selection disagree)");
+	int lds = 0;
+	FIND_TRY(prepare_kernel(c, K_GEMM7_MASK_VF, &gemm7_kernel<EPI_MASK, 0, true, true>, GEMM7_LDS + 64 * 128 * 4, &lds));
+	a.tiles_per_foot = (int)cdiv(a.V, 32);
+	a.ntiles = (int)(a.tiles_per_foot * feet);
+	a.tile_major = 1;
+	hipLaunchKernelGGL((gemm7_kernel<EPI_MASK, 0, true, true>), dim3(2 * pairs), dim3(GEMM7_NW * 64), lds, s, a);
+	return FIND_OK;
+}
+
 static int launch_gemm7(find_ctx* c, int epi, const Gemm2Args& a, int64_t feet, hipStream_t s) {
+	if (epi == EPI_MASK && a.vm_bias && a.fs_out) return launch_gemm7_fsum(c, a, feet, s);
 	if (epi == EPI_BIAS_RELU && a.va_bias) return launch_gemm7_virt<EPI_BIAS_RELU>(c, a, feet, s);
 	if (epi == EPI_MASK && a.vm_bias) return launch_gemm7_virt<EPI_MASK>(c, a, feet, s);
 	if (epi == EPI_BIAS_RELU) return launch_gemm7_t<EPI_BIAS_RELU>(c, a, feet, s);
@@ -517,6 +540,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	b.bias = a.bias; b.bias_foot_stride = a.bias_foot_stride; b.mask = a.mask; b.mask_foot_stride = a.mask_foot_stride;
 	b.y = a.y; b.y_foot_stride = a.y_foot_stride; b.ldy = a.ldy; b.V = a.V; b.ablate = c->ablate; b.dbg = c->dbg;
 	b.va_bias = a.va_bias; b.va_bias_stride = a.va_bias_stride; b.vm_bias = a.vm_bias; b.vm_bias_stride = a.vm_bias_stride;
+	b.fs_out = a.fs_out; b.fs_slot_stride = a.fs_slot_stride; b.cs_out = a.cs_out;
 	if (amode == AMODE_PE) return launch_gemm2_pe(c, b, feet, s);
 	const int64_t units = cdiv(a.V, 32) * feet;
 	const bool k256 = b.nseg == 1 && b.nchunk == 8;
@@ -527,7 +551,7 @@ static int launch_gemm(find_ctx* c, int amode, int epi, const GemmArgs& a, int64
 	if (c->x3 && k256 && units >= c->gemm6_min_units && !c->gemm7) { FIND_REQUIRE(!a.va_bias && !a.vm_bias, "launch_gemm: gemm6 forms no virtual operand"); return launch_gemm6(c, epi, b, feet, s); }
 #endif
 	if (c->x3 && k256 && units >= c->gemm6_min_units) return launch_gemm7(c, epi, b, feet, s);
-	FIND_REQUIRE(!a.va_bias && !a.vm_bias, "launch_gemm: a virtual operand reached a kernel that cannot form it (bcast_fold and the kernel selection disagree)");
+	FIND_REQUIRE(!a.va_bias && !a.vm_bias && !a.fs_out, "launch_gemm: a virtual operand reached a kernel that cannot form it (bcast_fold / footsum_fold and the kernel selection disagree)");
 	FIND_REQUIRE(!a.w_tr, "launch_gemm: an untransposed weight reached a kernel that cannot read it (gemm7_direct and the kernel selection disagree)");
 	if (k256 && units * 2 >= c->gemm4_min_units) return launch_gemm4<4>(c, epi, b, feet, s);
 	if (k256 && c->gemm4_small && units >= c->gemm4_small) return launch_gemm4<2>(c, epi, b, feet, s);
@@ -542,6 +566,14 @@ static bool gemm7_direct(const find_ctx* c, int64_t V, int64_t feet) {
 	if (!c->gemm7) return false;
 #endif
 	return c->direct_w && c->x3 && !(c->f16 && units >= c->gemm5_min_units) && units >= c->gemm6_min_units;
+}
+// ... whatever the weight's orientation: the launch will go to gemm7 (launch_gemm's rule)
+static bool gemm7_direct_units(const find_ctx* c, int64_t V, int64_t feet) {
+	const int64_t units = cdiv(V, 32) * feet;
+#ifdef FIND_DIAG
+	if (!c->gemm7) return false;
+#endif
+	return c->x3 && !(c->f16 && units >= c->gemm5_min_units) && units >= c->gemm6_min_units;
 }
 // a fused chain of this call will run on fused6_kernel (chain_prepare's rule): split_w_kernel reads every weight once anyway, in whatever
 // order the step asks for (FusedStep::wmode) -- no repack launch in front of the chain
@@ -947,6 +979,8 @@ struct BwdWs {
 	float* Sc;
 	float* zsD;   // shared template: (V,256) sum over feet of the disp head's first-layer dZ
 	float* zsC;
+	float* fs1D;  // footsum_fold: the second partial sum of gemm7_kernel<.., FSUM> (the first lands in zsD / zsC)
+	float* fs1C;
 	float* pS;    // [nblk_fs][n_feet][256] partial per-foot column sums (disp head)
 	float* pS2;   // same for the colour head: the reduces run on the side stream, so the heads cannot share one
 	int nblk_fs;
@@ -993,8 +1027,10 @@ static void carve_bwd(const find_mlp_params* p, const Dims& d, void* scratch, Bw
 	if (d.shared) {
 		o->zsD = c.take<float>(d.V * W);
 		o->zsC = c.take<float>(d.V * W);
+		o->fs1D = c.take<float>(d.V * W);
+		o->fs1C = c.take<float>(d.V * W);
 	} else {
-		o->zsD = o->zsC = nullptr;
+		o->zsD = o->zsC = o->fs1D = o->fs1C = nullptr;
 	}
 	// (also without a shared template: the latents-only backward of a frozen network takes its per-foot column sums this way)
 	o->pS = c.take<float>((int64_t)o->nblk_fs * d.n_feet * W);
@@ -1246,9 +1282,10 @@ static int wgrad_group_launch(find_ctx* c, WgradGroup& G, hipStream_t s) {
 // masked dX:  y = (dz @ W) * (mask > 0), with W given pre-transposed
 // (vm_bias: bcast_fold -- mask is the shared fp32 product P and the layer's output was relu(P[v] + vm_bias[foot]))
 static int linear_bwd_dx(find_ctx* c, const float* dz, const float* wt, int ldw, int w_tr, const float* mask, float* y, int64_t V, int64_t feet, hipStream_t s, bool h16 = false,
-						 const float* vm_bias = nullptr, int64_t vm_bias_stride = 0) {
+						 const float* vm_bias = nullptr, int64_t vm_bias_stride = 0, float* fs_out = nullptr, int64_t fs_slot_stride = 0, float* cs_out = nullptr) {
 	GemmArgs a = gemm_args_zero();
 	a.h16 = h16;
+	a.fs_out = fs_out; a.fs_slot_stride = fs_slot_stride; a.cs_out = cs_out;   // (footsum_fold: y is then not written)
 	a.a0 = dz; a.a_foot_stride = V * W; a.lda = W;
 	a.w0 = wt; a.ldw = ldw; a.w_tr = w_tr; a.nchunk = W / KC;
 	a.mask = mask; a.mask_foot_stride = vm_bias ? 0 : V * W;
@@ -1562,6 +1599,7 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 	G.live_jobs = (p->n_trunk - 1) + (c->group_head0 ? (act_d ? 1 : 0) + (act_c ? 1 : 0) : 0);
 	auto head_bwd = [&](int nl, float* const* act, float* const* dzbuf, int& cur, bool colour, float* const* gw, float* const* gb,
 						const float* w0full, int ld0, const float* lat, int L, float* S, float* glat, float* zs, float* ps, int side) -> int {
+		int fsum_pairs = 0;
 		for (int l = nl - 1; l >= 1; --l) {
 			const Virt v = virt(colour, l);
 			const float* const xin = v.P ? v.P : act[l - 1];
@@ -1583,12 +1621,33 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 				FIND_TRY(weight_grad(c, &fk, dzbuf[cur], xin, xin_stride, nullptr, 0, p, 1, n_feet, V, b, gw[l], W, W, 0, gb[l], nullptr, fk.stream(Q), -1, -1, a16, v.bias, v.bstride));
 			}
 			const WT t = colour ? wt_C(l) : wt_D(l);
-			FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, xin, dzbuf[cur + 1], V, n_feet, s, a16, v.bias, v.bstride));
+			// footsum_fold: this dX GEMM's output is the broadcast layer's dZ, of which only sums are read (below): formed inside the GEMM
+			fsum_pairs = (l == 1 && v.P && !a16 && c->footsum_fold && zs != nullptr && gemm7_direct_units(c, V, n_feet)) ? gemm7_fsum_pairs(c, V, n_feet) : 0;
+			if (fsum_pairs > 0) {
+				float* const fs1 = colour ? b.fs1C : b.fs1D;
+				FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, xin, dzbuf[cur + 1], V, n_feet, s, a16, v.bias, v.bstride, zs, fs1 - zs, ps));
+			} else {
+				FIND_TRY(linear_bwd_dx(c, dzbuf[cur], t.w, t.ld, t.tr, xin, dzbuf[cur + 1], V, n_feet, s, a16, v.bias, v.bstride));
+			}
 			cur += 1;
 		}
 		float* db_late = nullptr;
 		hipStream_t q0;
-		if (d.shared) {
+		if (d.shared && fsum_pairs > 0) {
+			// (the two partial foot sums -> the foot sum; the per-foot column sums wait in `ps`, one block per workgroup pair of the GEMM)
+			const int64_t n4 = V * W / 4;
+			hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)cdiv(n4, 256)), dim3(256), 0, s, zs, colour ? b.fs1C : b.fs1D, n4);
+			fk.fork_to(side);
+			q0 = fk.stream(side);
+			hipLaunchKernelGGL(footsum_reduce_kernel, dim3((unsigned)n_feet, 4), dim3(1024), 0, q0, ps, fsum_pairs, (int)n_feet, S);
+			if (L > 0) db_late = gb[0];
+			else hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(256), 0, q0, S, (int)n_feet, gb[0]);
+			FIND_LAUNCH_CHECK("footsum (folded)");
+			BwdWs bk = b;
+			bk.pw = b.pw_t[side]; bk.pb = b.pb_t[side];
+			if (grouped_v && c->group_head0) FIND_TRY(wgrad_group_add(c, G, b, zs, hl, 0, 1, V, gw[0], ld0, nullptr, nullptr));
+			else FIND_TRY(weight_grad(c, &fk, zs, hl, 0, nullptr, 0, p, 1, 1, V, bk, gw[0], ld0, W, 0, nullptr, nullptr, q0));
+		} else if (d.shared) {
 			// every foot multiplies the same trunk rows: reduce dZ0 over feet first (one pass), then M = V GEMMs
 			// (Measured and dropped: the foot sum on the head's side stream, the caller's stream going straight on to the other head's dX
 			// chain and waiting for the sums in step 4 -- 3.49 against 3.38 ms per train_3d step: the HBM-bound pass beside the dX GEMMs
@@ -2003,7 +2062,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1}, {"group_head0", &find_ctx::group_head0, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1}, {"group_head0", &find_ctx::group_head0, 0, 1}, {"footsum_fold", &find_ctx::footsum_fold, 0, 1},
 };
 }  // namespace
 

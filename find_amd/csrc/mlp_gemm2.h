@@ -52,7 +52,10 @@ struct Gemm2Args {
 	int64_t va_bias_stride;
 	const float* vm_bias;   // ... of the virtual ReLU mask (mask = the shared fp32 product)
 	int64_t vm_bias_stride;
-	int tile_major;         // gemm5: unit = tile * n_feet + foot instead of foot * tiles_per_foot + tile
+	int tile_major;         // gemm5 / gemm7<.., FSUM>: unit = tile * n_feet + foot instead of foot * tiles_per_foot + tile
+	float* fs_out;          // gemm7<.., FSUM>: [2][V][ldy] sums over the feet (slot 0 + slot 1 = the sum: mlp_gemm7.h)
+	int64_t fs_slot_stride; // floats between the two slots
+	float* cs_out;          // gemm7<.., FSUM>: [workgroup pair][foot][256] per-foot column sums
 	int ablate;             // profiling only: bit0 skip DMA issue, bit1 skip epilogue stores, bit2 skip MFMAs
 	unsigned long long* dbg; // profiling only: per-workgroup [total, wait+barrier, epilogue, lgkm-wait] shader cycles (wave 0)
 };

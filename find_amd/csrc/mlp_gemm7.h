@@ -42,9 +42,19 @@ constexpr int GEMM7_NW = 8;
 // instead of reading n_feet x V x 1 KB of it from HBM -- from the V x 256 product P (a0 / mask with foot stride 0: L2) and the foot's bias
 // row: EPI_BIAS_RELU: the A operand, two packed adds and four max per staged row in front of its split (g.va_bias); EPI_MASK: the ReLU
 // mask of the epilogue (g.vm_bias).  Bit for bit the values bias_relu_bcast_kernel would have stored.
-template <int EPI, int ABL = 0, bool VIRT = false>
+// FSUM ("footsum_fold", mlp.hip; with the virtual mask only): the dX GEMM of a head's second layer produces dZ of the BROADCAST first layer,
+// of which the backward reads nothing but two sums -- over the feet (what the shared trunk receives) and, per foot, over the rows (what the
+// latent codes and the bias receive).  Both are formed here and dZ (n_feet x V x 1 KB) is never stored: units run TILE-major (consecutive
+// units = consecutive feet of the same 32 rows); a wave adds the masked blocks of a tile's feet in its registers (its 16 columns: no
+// exchange between waves) and stores the sum when the tile -- or the workgroup's unit range -- ends: slot 0 of g.fs_out for a run that
+// began at the tile's first foot, slot 1 for one that did not (every range holds at least n_feet units, so a tile has at most two runs; a
+// run that covers a whole tile writes zeros to slot 1); the per-foot column sums go through 16-lane DPP sums into an LDS table
+// [foot][this workgroup's 128 columns] (each wave its own columns, in unit order) and out to g.cs_out [range][foot][256] at the end.
+// Every sum in a fixed order: bit-reproducible.
+template <int EPI, int ABL = 0, bool VIRT = false, bool FSUM = false>
 __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args g) {
 	static_assert(!VIRT || EPI != EPI_NONE, "gemm7_kernel: a virtual operand needs the epilogue it belongs to");
+	static_assert(!FSUM || (VIRT && EPI == EPI_MASK), "gemm7_kernel: the folded foot sum belongs to the virtual-mask dX GEMM");
 	constexpr bool VA = VIRT && EPI == EPI_BIAS_RELU, VM = VIRT && EPI == EPI_MASK;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x;
@@ -59,6 +69,12 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	const int u0 = (int)((int64_t)pair * g.ntiles / npairs);
 	const int u1 = (int)((int64_t)(pair + 1) * g.ntiles / npairs);
 	if (u0 >= u1) return;
+	const int nf = g.ntiles / upf;   // feet
+	// unit -> (foot, first row): foot-major, or -- FSUM -- tile-major
+	auto decode = [&](int uu, int& foot, int& v0) {
+		if constexpr (FSUM) { const int t = uu / nf; foot = uu - t * nf; v0 = t * 32; }
+		else { foot = uu / upf; v0 = (uu - foot * upf) * 32; }
+	};
 
 	// ---- prologue: this wave's 16 rows of W, all of K, as MFMA row operands: lane (n = i16, quarter h4), k-step s: W[col0 + i16][32 s + 8 h4 .. +8]
 	bf16x8 B1[8], B2[8], B3[8];
@@ -96,8 +112,8 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	auto unit_rsrc = [&](int uu) -> __amdgpu_buffer_rsrc_t {
 		// (a unit past the end of the range: size 0, every load comes back as zeros; so do the rows past the end of a foot)
 		const int ua = FIND_ABL(g.ablate, 512) ? u0 : uu;   // profiling only: every unit reads the range's first rows (served by L2)
-		const int foot = ua / upf;
-		const int v0 = (ua - foot * upf) * 32;
+		int foot, v0;
+		decode(ua, foot, v0);
 		const int valid = uu < u1 ? min(32, V - v0) : 0;
 		return make_srd(g.a0 + (int64_t)foot * g.a_foot_stride + (int64_t)v0 * lda, valid * lda * 4);
 	};
@@ -137,7 +153,8 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	int vab_foot = -1;
 	auto virt_bias = [&](int uu, int col) {   // (wave-uniform branch; a foot changes every tiles_per_foot units)
 		if constexpr (VIRT) {
-			const int foot = min(uu, u1 - 1) / upf;
+			int foot, v0_unused;
+			decode(min(uu, u1 - 1), foot, v0_unused);
 			if (foot != vab_foot) {
 				const float* bp = VA ? g.va_bias + (int64_t)foot * g.va_bias_stride : g.vm_bias + (int64_t)foot * g.vm_bias_stride;
 				vab = __builtin_amdgcn_raw_buffer_load_b128(make_srd(bp, 256 * 4), col * 4, 0, 0);
@@ -201,17 +218,30 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	struct OutTile { __amdgpu_buffer_rsrc_t y, m; };
 	auto out_tile = [&](int uq) -> OutTile {
 		const int uu = FIND_ABL(g.ablate, 1024) ? u0 : uq;   // profiling only: every unit's block goes to the range's first rows
-		const int foot = uu / upf;
-		const int v0 = (uu - foot * upf) * 32;
+		int foot, v0;
+		decode(uu, foot, v0);
 		const int nbytes = min(32, V - v0) * ldy * 4;
 		OutTile t;
-		t.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy)), 0, nbytes, 0x00020000);
+		if constexpr (FSUM) {
+			// (no dZ store: y of this tile = slot 0 / 1 of the foot-sum output, chosen at flush time)
+			t.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(g.fs_out + (int64_t)v0 * ldy)), 0, nbytes, 0x00020000);
+		} else {
+			t.y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(g.y + (int64_t)foot * g.y_foot_stride + (int64_t)v0 * ldy)), 0, nbytes, 0x00020000);
+		}
 		t.m = t.y;
 		if constexpr (EPI == EPI_MASK) t.m = make_srd(g.mask + (int64_t)foot * g.mask_foot_stride + (int64_t)v0 * ldy, nbytes);
 		return t;
 	};
 	const int ovoff = (i16 * ldy + col0 + 4 * h4) * 4;
 	u4 mv[2];
+	// FSUM state: the running sum over the feet of the current tile (this wave's 16 columns x 32 rows), the column sums of the unit being
+	// finished, and what the unit being finished is (set by unit_body before its k loop)
+	f32x4 fs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+	float cst[4] = {0.f, 0.f, 0.f, 0.f};
+	int fs_first_foot = 0;     // foot the current run of this tile began with (0: slot 0)
+	int prev_foot = 0, prev_v0 = 0;   // foot / first row of the unit whose blocks store_block is finishing
+	bool prev_ends_run = false;
+	float* const cs_lds = reinterpret_cast<float*>(smem + GEMM7_LDS);   // [foot][128]: this workgroup's columns
 	auto store_block = [&](const OutTile& t, int rb) {
 		float v[4];
 #pragma unroll
@@ -221,7 +251,34 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			if constexpr (VM) v[e] = (__uint_as_float(mv[rb][e]) + __uint_as_float(vab[e]) > 0.f) ? v[e] : 0.f;
 			else if constexpr (EPI == EPI_MASK) v[e] = (__uint_as_float(mv[rb][e]) > 0.f) ? v[e] : 0.f;
 		}
-		store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4);   // (no SGPR offset: common.h)
+		if constexpr (FSUM) {
+			// (rows past the end of the template: their dZ rows were loaded as zeros, so v is zero there whatever the mask says)
+#pragma unroll
+			for (int e = 0; e < 4; ++e) { fs[rb][e] += v[e]; cst[e] = (rb == 0) ? v[e] : cst[e] + v[e]; }
+			if (rb == 1) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) {
+					const float c = row16_sum(cst[e]);   // the unit's 32 rows of column col0 + 4 h4 + e
+					if (i16 == 0) atomicAdd(&cs_lds[prev_foot * 128 + wave * 16 + 4 * h4 + e], c);   // (ds_add_f32; this wave alone owns these columns: unit order)
+				}
+				if (prev_ends_run) {
+					// (t.y: the tile's rows of slot 0, bounded at the template's last row; slot 1 lies g.fs_slot_stride floats further)
+					const __amdgpu_buffer_rsrc_t s1 = make_srd(g.fs_out + g.fs_slot_stride + (int64_t)prev_v0 * ldy, min(32, V - prev_v0) * ldy * 4);
+					const bool whole = fs_first_foot == 0 && prev_foot == nf - 1;   // the whole tile in one run: nobody else writes its slot 1
+#pragma unroll
+					for (int q = 0; q < 2; ++q) {
+						const u4 sum = u4{__float_as_uint(fs[q][0]), __float_as_uint(fs[q][1]), __float_as_uint(fs[q][2]), __float_as_uint(fs[q][3])};
+						if (fs_first_foot == 0) store_b128(sum, t.y, ovoff, q * 16 * ldy * 4);
+						else store_b128(sum, s1, ovoff, q * 16 * ldy * 4);
+						if (whole) store_b128(u4{0u, 0u, 0u, 0u}, s1, ovoff, q * 16 * ldy * 4);
+						fs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+					}
+					fs_first_foot = 0;   // (what follows a finished tile starts the next one; a finished range is followed by nothing)
+				}
+			}
+		} else {
+			store_b128(u4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, t.y, ovoff, rb * 16 * ldy * 4);   // (no SGPR offset: common.h)
+		}
 	};
 	auto mm = [&](const bf16x8& w, const bf16x8& x, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0); };
 
@@ -235,6 +292,12 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		char* other = smem + (cb ^ 1) * G7_BUF;
 		const __amdgpu_buffer_rsrc_t rs2 = unit_rsrc(u + 3);
 		const OutTile prev = out_tile(first ? u : u - 1);
+		if constexpr (FSUM) {
+			if (!first) {
+				decode(u - 1, prev_foot, prev_v0);
+				prev_ends_run = prev_foot == nf - 1;   // (the range's last unit is finished below the loop)
+			}
+		}
 		pend[0] = acc[0]; pend[1] = acc[1];
 		init_acc();
 		load_bias(u + 1);
@@ -306,6 +369,12 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 		}
 		cb ^= 1;
 	};
+	if constexpr (FSUM) {
+		int f0, v0_unused;
+		decode(u0, f0, v0_unused);
+		fs_first_foot = f0;
+		for (int k = lane; k < nf * 16; k += 64) cs_lds[(k >> 4) * 128 + wave * 16 + (k & 15)] = 0.f;   // (this wave's columns; its LDS operations run in order)
+	}
 	unit_body(u0, st[1], true);
 	for (int u = u0 + 1; u < u1; u += 2) {
 		unit_body(u, st[0], false);
@@ -313,6 +382,7 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 	}
 	{   // the last unit's blocks
 		const OutTile last = out_tile(u1 - 1);
+		if constexpr (FSUM) { decode(u1 - 1, prev_foot, prev_v0); prev_ends_run = true; }
 		pend[0] = acc[0]; pend[1] = acc[1];
 		if constexpr (VM) virt_bias(u1 - 1, col0 + 4 * h4);
 		if constexpr (EPI == EPI_MASK) {
@@ -321,6 +391,10 @@ __global__ __launch_bounds__(GEMM7_NW * 64, 1) void gemm7_kernel(const Gemm2Args
 			FIND_VM_WAIT(mv[0], 0); FIND_VM_WAIT(mv[1], 0);
 		}
 		store_block(last, 0); store_block(last, 1);
+	}
+	if constexpr (FSUM) {   // the per-foot column sums of this range: cs_out [range = pair][foot][256]
+		float* out = g.cs_out + (int64_t)pair * nf * 256 + ((b >> 3) & 1) * 128 + wave * 16;
+		for (int k = lane; k < nf * 16; k += 64) out[(k >> 4) * 256 + (k & 15)] = cs_lds[(k >> 4) * 128 + wave * 16 + (k & 15)];
 	}
 	if (FIND_DBG(g.dbg) && tid == 0) {
 		g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - t_start;

@@ -96,6 +96,9 @@ struct GemmArgs {
 	int64_t va_bias_stride;
 	const float* vm_bias;   // bcast_fold: mask is P and the mask is P[v] + vm_bias[foot]
 	int64_t vm_bias_stride;
+	float* fs_out;          // footsum_fold (with vm_bias): no y; the sum over feet goes to fs_out (+ fs_slot_stride: second partial), the per-foot
+	int64_t fs_slot_stride; // column sums to cs_out [workgroup pair][foot][256] (gemm7_kernel<.., FSUM>)
+	float* cs_out;
 };
 
 enum { AMODE_MAT = 0, AMODE_PE = 1 };
@@ -509,6 +512,16 @@ __global__ __launch_bounds__(1024) void footsum_reduce_kernel(const float* __res
 			for (int j = 0; j < i; ++j) t[j] += t[j + i];
 		S[(int64_t)f * 256 + n] = t[0];
 	}
+}
+
+// a += b (float4 granules): the two partial foot sums of gemm7_kernel<.., FSUM> -> the foot sum
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n4) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n4) return;
+	float4 x = reinterpret_cast<float4*>(a)[i];
+	const float4 y = reinterpret_cast<const float4*>(b)[i];
+	x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+	reinterpret_cast<float4*>(a)[i] = x;
 }
 
 // db[n] = sum_b S[b][n]
