@@ -188,6 +188,7 @@ struct find_ctx {
 	struct Act16Note { const void* ws; bool a16; bool fold; };
 	Act16Note act16_notes[16] = {};
 	int act16_next = 0;
+	int pe_on_t2 = 1;             // knob: the Fourier layer's weight gradient of a shared-template backward runs on T2 instead of behind dw6 on Q
 	int footsum_fold = 1;         // knob: the foot sums of a shared template's first-layer dZ are formed inside the dX GEMM that produces it (mlp_gemm7.h FSUM)
 	int group_head0 = 1;          // knob: a shared template's first head layers' weight gradients ride in the trunk's grouped launch (mlp_bwd_body)
 	int bcast_fold = 1;           // knob: inside act16 the broadcast first head layer's output is formed by its readers instead of stored (use_fold)
@@ -1738,9 +1739,18 @@ static int mlp_bwd_body(find_ctx* c, Fork& fk, const find_mlp_params* p, const D
 			ct += 1;
 		}
 	}
-	fk.fork_to(Q);
-	fk.wait(Q, set_free[0]);
-	FIND_TRY(weight_grad(c, &fk, b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(Q)));
+	if (fused && d.shared && fk.on && c->pe_on_t2) {
+		// (round 6: on Q the Fourier layer's weight gradient queued behind the last large layer's dw6 AND its slab reduce -- 60 us after the
+		// trunk's dX chain had produced its input, at the very end of the step; T2 is idle by then, and its slab set is the Fourier layer's size)
+		fk.fork_to(T2);
+		BwdWs bk = b;
+		bk.pw = b.pw_t[T2]; bk.pb = b.pb_t[T2];
+		FIND_TRY(weight_grad(c, &fk, b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, bk, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(T2)));
+	} else {
+		fk.fork_to(Q);
+		fk.wait(Q, set_free[0]);
+		FIND_TRY(weight_grad(c, &fk, b.dzT[ct], nullptr, 0, pos, V * 3, p, d.nkt0, d.feet_t, V, b, g->trunk_w[0], K0, 0, 1, g->trunk_b[0], nullptr, fk.stream(Q)));
+	}
 	FIND_LAUNCH_CHECK("find_mlp_bwd");
 	return FIND_OK;
 }
@@ -2062,7 +2072,7 @@ const Knob KNOBS[] = {
 	{"gemm4_small", &find_ctx::gemm4_small, 0, INT32_MAX},
 	{"dw_pe_target", &find_ctx::dw_pe_target, 16, INT32_MAX}, {"dw_pe_lds_free", &find_ctx::dw_pe_lds_free, 0, 1}, {"dw2_min_cps", &find_ctx::dw2_min_cps, 1, INT32_MAX},
 	{"bwd_streams", &find_ctx::bwd_streams, 0, 1}, {"fwd_streams", &find_ctx::fwd_streams, 0, 1}, {"reduce_stream", &find_ctx::reduce_stream, 0, 1},
-	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1}, {"group_head0", &find_ctx::group_head0, 0, 1}, {"footsum_fold", &find_ctx::footsum_fold, 0, 1},
+	{"gemm5_min_units", &find_ctx::gemm5_min_units, 0, INT32_MAX}, {"fused_max_units", &find_ctx::fused_max_units, 0, 1024}, {"fused6", &find_ctx::fused6, 0, 1}, {"dw6_wgs", &find_ctx::dw6_wgs, 0, 512}, {"bind_streams", &find_ctx::bind_streams, 0, 1}, {"direct_w", &find_ctx::direct_w, 0, 1}, {"dw6_group", &find_ctx::dw6_group, 0, 1}, {"dwpe6", &find_ctx::dwpe6, 0, 1}, {"r_queue", &find_ctx::r_queue, 0, 2}, {"cu_reserve", &find_ctx::cu_reserve, 0, 16}, {"group_spf", &find_ctx::group_spf, 0, 4096}, {"dw_lds_free", &find_ctx::dw_lds_free, 0, FIND_DIAG_ON ? 3 : 1}, {"reduce_exclusive", &find_ctx::reduce_exclusive, 0, 2}, {"mlp_f16", &find_ctx::mlp_f16, 0, 2}, {"gemm6_min_units", &find_ctx::gemm6_min_units, 0, INT32_MAX}, {"lds_exclusive", &find_ctx::lds_exclusive, 0, 1}, {"defer_join", &find_ctx::defer_join, 0, 1}, {"act16", &find_ctx::act16, 0, 1}, {"bcast_fold", &find_ctx::bcast_fold, 0, 1}, {"group_head0", &find_ctx::group_head0, 0, 1}, {"footsum_fold", &find_ctx::footsum_fold, 0, 1}, {"pe_on_t2", &find_ctx::pe_on_t2, 0, 1},
 };
 }  // namespace
 
