@@ -199,6 +199,16 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
  *                     call's workspace / scratch when a template is shared by more than one foot and the heads have >= "gemm5_min_units"
  *                     units (the matrix pipe rounds these values to fp16 anyway; BASELINE.json configs[4] is bound by their bytes); 0 = fp32
  *                     storage.  (A find_mlp_bwd follows what the find_mlp_fwd of its workspace did, also if a knob was turned in between.)
+ *   "bcast_fold"      1 (default) = with a template shared by several feet, the output relu(P[v] + bias[foot]) of a head's broadcast first layer is
+ *                     not stored: the second layer's forward GEMM, the ReLU mask of its dX GEMM and the x operand of its weight gradient form it
+ *                     from the V x 256 product P and the bias rows (bf16x3: gemm7_kernel / dw6v_kernel; fp16 mode inside "act16": gemm5_kernel /
+ *                     dw3_h16v_kernel).  Bit-identical to 0 (bias_relu_bcast_kernel materialises it).  The backward follows its forward's note
+ *   "footsum_fold"    1 (default; bf16x3, needs "bcast_fold") = the dX GEMM that produces that layer's gradient forms the two sums the backward reads
+ *                     of it -- over the feet, and per foot over the rows -- in its epilogue and stores no gradient tensor (gemm7_kernel<.., FSUM>);
+ *                     0 = footsum_kernel over the stored tensor.  Same sums in another order (~2e-7 of a gradient's largest entry), deterministic
+ *   "group_head0", "pe_on_t2", "direct_w", "dw6_group", "dwpe6"   scheduling / kernel-choice switches of the backward (A/B runs), all default 1:
+ *                     the first head layers' weight gradients in the trunk's grouped launch; the Fourier layer's weight gradient on T2; kernels read
+ *                     the model's weights without repacked copies; grouped bf16x3 weight gradients; the Fourier layer's on the bf16 pipe
  *   "gemm6_min_units" the same threshold for the bf16x3 kernels (default 1024)
  *   "fused_max_units" calls of at most this many 32-row units (0..1024, default 512) run whole layer chains -- the trunk, trunk + heads of a
  *                     per-foot pass, their dX chains -- in one launch of fused_chain_kernel, and the weight gradients of a chain as one grouped
