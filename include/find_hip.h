@@ -167,7 +167,7 @@ int find_linear_wgrad(find_ctx* ctx, const float* dz, const float* x, int64_t n_
 					  void* scratch, int64_t scratch_bytes, void* stream);
 
 /* Tuning knobs of a context (no reference counterpart).  Results do not depend on any knob except "mlp_f16" (the precision, below) and the
- * summation order of "reduce_exclusive" = 2.  The laboratory -- fault reproducers, superseded kernels kept for A/B runs, per-workgroup timers
+ * summation order of "reduce_exclusive" = 2, "footsum_fold", "group_head0" / "dw6_group" / "dwpe6" (which kernel sums a weight gradient).  The laboratory -- fault reproducers, superseded kernels kept for A/B runs, per-workgroup timers
  * and the ablation bits under which results are WRONG -- is not in this library: find_amd/build.py builds it from the same sources with
  * -DFIND_DIAG as libfind_hip_diag.so, whose additional keys and entry point include/find_hip_diag.h declares.  Read-only key "diag": 0 here,
  * 1 there.
