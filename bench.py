@@ -1074,7 +1074,7 @@ def main():
 	ap.add_argument('--steps', type=int, default=30)
 	ap.add_argument('--warmup', type=int, default=5)
 	ap.add_argument('--no-cpu-baseline', action='store_true')
-	ap.add_argument('--repeats', type=int, default=3, help='repetitions of the headline K-step timing; the median is reported, all are listed')
+	ap.add_argument('--repeats', type=int, default=5, help='repetitions of the headline K-step timing; the median is reported, all are listed (5: a host that hiccups during two of three repetitions moved a 1.53-ms step to 1.71)')
 	ap.add_argument('--no-prime', action='store_true', help='no untimed priming phase before the warm-up steps (Run.timed): measures a cold GPU')
 	ap.add_argument('--headline-only', action='store_true', help='only the timed headline loop (no records, no CPU leg, no isolated kernel loop): the command to put under rocprofv3')
 	ap.add_argument('--no-graph', action='store_true', help='skip the HIP-graph variant of the batch-1 record')
@@ -1131,7 +1131,7 @@ def main():
 	# ---- headline: train_3d.yaml network-stage step, 16 feet per GPU
 	note('headline')
 	su = train3d_setup(run, N_FEET, N_FEET, stage='net', labels=False, seed=run.rank)
-	# The headline's K-step timing is taken `--repeats` times (default 3; each: W warm-up steps, exactly K steps between barrier +
+	# The headline's K-step timing is taken `--repeats` times (default 5; each: W warm-up steps, exactly K steps between barrier +
 	# synchronize, the maximum over ranks) and the MEDIAN is reported, every repetition listed beside it (`ms_per_step_repeats`): a step whose
 	# host work is most of its GPU time is sensitive to whatever else the host does, and a run that drifts shows in the list.
 	ms_all = [run.timed(su['step'], args.steps, args.warmup, prime=(i == 0)) for i in range(max(1, args.repeats))]
