@@ -614,6 +614,22 @@ def sample_points(verts, faces, face_idx, uv, attr=None):
 	return _SamplePoints.apply(verts, faces, face_idx, uv, attr)
 
 
+class _NoCtx:
+	"""Stands in for an autograd context when a Function's forward is called directly (no input wants a gradient): takes the attributes
+	and calls a forward makes, keeps nothing."""
+	needs_input_grad = (False,) * 64
+
+	def save_for_backward(self, *tensors):
+		pass
+
+	def mark_non_differentiable(self, *tensors):
+		pass
+
+	def set_materialize_grads(self, value):
+		pass
+
+
+_NO_CTX = _NoCtx()
 CACHE_AREA_SUMS = _os.environ.get('FIND_CACHE_AREA_SUMS', '1') != '0'
 _AREA_SUMS = {}         # key -> (running area sums of the meshes, event behind the launch that wrote them)
 _AREA_SUM_OWNERS = {}   # key -> the tensors the key names
@@ -701,7 +717,12 @@ class _SampleSurface(torch.autograd.Function):
 def sample_surface(verts, faces, rnd, attr=None):
 	"""All of sample_points_from_meshes on the device given the uniform draws rnd (N,S,3) = [face draw, u, v]: faces ~ multinomial(area).
 	Returns (points (N,S,3), attr samples or None, face_idx (N,S) int32, uv (N,S,2))."""
-	r = _SampleSurface.apply(verts, faces, rnd, attr)
+	if torch.is_grad_enabled() and (verts.requires_grad or (attr is not None and attr.requires_grad)):
+		r = _SampleSurface.apply(verts, faces, rnd, attr)
+	else:
+		# nothing to differentiate (a GT scan, an evaluation): the same code without the autograd Function around it (its bookkeeping is
+		# 20 us of host time per call, twice per training step, on a step whose host time is what a slow host makes the step time)
+		r = _SampleSurface.forward(_NO_CTX, verts, faces, rnd, attr)
 	if attr is None:
 		return r[0], None, r[1], r[2]
 	return r
