@@ -880,13 +880,17 @@ def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=F
 		return loss
 
 	# (the median of three K-step timings, as the headline: one allocator stall inside a 20-step window once made a 4.8-ms step read 12.4)
+	def mallocs():
+		return torch.cuda.memory_stats(dev).get('num_device_alloc', 0) if dev.type == 'cuda' else 0
+	m0 = mallocs()
 	ms_all = [run.timed(step, steps, warmup, prime=(i == 0)) for i in range(3)]
 	ms = sorted(ms_all)[1]
+	n_malloc = mallocs() - m0   # (a timed window that has the caching allocator go to the driver reads milliseconds too long: reported)
 	cfg = {'workload': f'{"C4 rank share" if c4 else "C3"}: {n_feet} feet x {n_views} views @{size}^2 per GPU, {N_VERTS}-vertex template, {N_GT_VERTS}-vertex GT '
 					   f'scans re-rendered every step, {"sil+pix+chamf losses" if c4 else "silhouette loss"}, backward through rasteriser + MLP, Adam step; '
 					   + ('uniform triangulations (Fibonacci-sphere hulls, F = 2V - 4, vertices in Morton order)' if mesh == 'uniform' else 'latitude-longitude grids (pole slivers: binning stress case)'),
 		   'mesh': mesh, 'feet_per_gpu': n_feet, 'views': n_views, 'parallelism': f'dp{run.world}'}
-	out = line(run.world * n_feet * N_VERTS * n_views / (ms * 1e-3), ms, run, steps, warmup, cfg, ms_per_step_repeats=[round(x, 4) for x in ms_all])
+	out = line(run.world * n_feet * N_VERTS * n_views / (ms * 1e-3), ms, run, steps, warmup, cfg, ms_per_step_repeats=[round(x, 4) for x in ms_all], device_mallocs_in_timed_steps=n_malloc)
 	if bucket is not None:
 		bucket.close()
 	if with_cpu and run.world == 1 and not c4:
@@ -951,7 +955,7 @@ def brief(rec, *keys):
 	for k in keys:
 		if k in rec['config']:
 			out[k] = rec['config'][k]
-	for k in ('cpu_baseline', 'roofline', 'note'):
+	for k in ('cpu_baseline', 'roofline', 'note', 'ms_per_step_repeats', 'device_mallocs_in_timed_steps'):
 		if k in rec:
 			out[k] = rec[k]
 	if 'cpu_baseline' in out:
