@@ -665,7 +665,7 @@ def dominant_roofline(device, fp16=False, n_verts=None):
 	if FF.get_mlp_precision() == 'bf16x3':
 		# six bf16 products per fp32 multiply-accumulate: the flops the matrix pipe EXECUTES are 6 x the layer's
 		ex = 6.0 * ach
-		return {'bound': 'mfma', 'kernel': f'find::mlp::gemm7_kernel<1, 0, false> (Linear 256->256 + bias + ReLU over {rows} rows; bf16x3: v_mfma_f32_16x16x32_bf16, fp32 accumulation)',
+		return {'bound': 'mfma', 'kernel': f'find::mlp::gemm7_kernel<1, 0, false, false> (Linear 256->256 + bias + ReLU over {rows} rows; bf16x3: v_mfma_f32_16x16x32_bf16, fp32 accumulation)',
 				'achieved': ex, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ex / PEAK_BF16_MFMA_TFLOPS,
 				'avg_kernel_ms': kms, 'flops_per_launch': 6.0 * kflops, 'flops_per_launch_fp32_equivalent': kflops,
 				'fp32_equivalent_tflops': ach, 'x_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,

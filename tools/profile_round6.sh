@@ -19,7 +19,7 @@ for w in $what; do
     head -16 "$O/headline_steady_kernel_stats.csv" | cut -c1-150; tail -1 "$O/headline_step_stats.csv" ;;
   roofline)
     rocprofv3 --kernel-trace --stats --output-format csv -d "$O/roofline" -- python3 "$R/bench.py" --no-records --no-cpu-baseline > "$O/roofline_line.json" 2> "$O/roofline.err"
-    python3 "$R/tools/roofline_loop_stats.py" "$O"/roofline/*/*kernel_trace.csv "gemm7_kernel<1, 0, false>" > "$O/roofline_loop_kernel_stats.txt"; cat "$O/roofline_loop_kernel_stats.txt" ;;
+    python3 "$R/tools/roofline_loop_stats.py" "$O"/roofline/*/*kernel_trace.csv "gemm7_kernel<1, 0, false, false>" > "$O/roofline_loop_kernel_stats.txt"; cat "$O/roofline_loop_kernel_stats.txt" ;;
   dw6)
     export FIND_TUNING=mlp_f16=2
     rocprofv3 --kernel-trace --stats --output-format csv -d "$O/dw6" -- python3 "$R/tools/prof_wgrad.py" 100 16 6890 > "$O/dw6.log" 2>&1
