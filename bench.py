@@ -308,6 +308,12 @@ def note(msg):
 	print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
 
+def train_backward(loss):
+	"""loss.backward() as find_amd.trainer.Trainer issues it (train_utils.backward: the seed gradient from a cache instead of a fill launch)."""
+	from find_amd.train_utils import backward
+	backward(loss)
+
+
 def line(value, ms, run, steps, warmup, config, **extra):
 	config = dict(config, workload=short(config['workload'], 240))
 	out = {'metric': METRIC, 'value': value, 'unit': UNIT, 'n_gpus': run.world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms,
@@ -416,7 +422,7 @@ def train3d_setup(run, n_items, batch_size, stage='net', labels=False, seed=0, d
 		state['i'] += 1
 		b.update(sample_latent_vectors(b, vectors))
 		loss, _ = mwl(b, 0, opts, **flags)
-		loss.backward()
+		train_backward(loss)
 		if bucket is not None:
 			bucket.allreduce_(async_op=True)   # the latent tables' part (the weights' part left inside the backward: GradBucket.arm_early);
 			bucket.wait()                      # the optimiser needs both: the wait follows at once (stream-side dependency, the host does not block)
@@ -749,7 +755,7 @@ def build_step(device, seed, n_verts=None):
 					 reg_train=model.reg[idx])
 		res = model.get_meshes_from_batch(batch, is_train=True)
 		loss = (res['verts'] ** 2).sum() + (res['col'] ** 2).sum()
-		loss.backward()
+		train_backward(loss)
 		return loss
 
 	return model, params, step
@@ -771,7 +777,7 @@ def c2_cpu(sample_feet=2):
 		t0 = time.perf_counter()
 		res = mlp_ref.get_meshes_verts(sd, B, tv, lv['shapevec'], lv['reg'], lv['texvec'], lv['posevec'])
 		loss = (res['verts'] ** 2).sum() + (res['col'] ** 2).sum()
-		loss.backward()
+		train_backward(loss)
 		return time.perf_counter() - t0
 
 	best, cores, how = best_of_cpu(lambda: one_step(sample_feet))
@@ -872,7 +878,7 @@ def c3_record(run, steps, warmup, with_cpu, n_feet=16, n_views=4, size=256, c4=F
 		b = dict(batch)
 		b.update(sample_latent_vectors(b, m.latent_vectors_train))
 		loss, _ = mwl(b, 0, opts, sil=True, pix=c4, chamf=c4, render_foot=True, views=(R, T))
-		loss.backward()
+		train_backward(loss)
 		if bucket is not None:
 			bucket.allreduce_(async_op=True)   # issued behind the backward's last kernel; nothing else of the step is independent of the gradients,
 			bucket.wait()                      # so the wait follows at once (the host does not block: stream-side dependency)

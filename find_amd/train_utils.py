@@ -18,6 +18,19 @@ def backward_on_this_thread():
 	return torch.autograd.set_multithreading_enabled(False)
 
 
+_ONES = {}
+
+
+def backward(loss):
+	"""loss.backward() with the seed gradient taken from a per-device cache: autograd otherwise makes torch.ones_like(loss) per call -- one more
+	launch at the head of the backward pass, between kernels that wait for each other (Trainer, GraphedStep and bench.py call this)."""
+	one = _ONES.get((loss.device, loss.dtype))
+	if one is None:
+		import torch
+		one = _ONES[(loss.device, loss.dtype)] = torch.ones((), device=loss.device, dtype=loss.dtype)
+	loss.backward(gradient=one if loss.dim() == 0 else None)
+
+
 def batch_to_device(batch, device='cuda'):
 	return {k: (v.to(device) if hasattr(v, 'to') else v) for k, v in batch.items()}
 

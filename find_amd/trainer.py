@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import functional_render as FR
-from .train_utils import backward_on_this_thread, batch_to_device, sample_latent_vectors
+from .train_utils import backward, backward_on_this_thread, batch_to_device, sample_latent_vectors
 
 
 def pretty_print_loss(loss_key: str):
@@ -196,7 +196,7 @@ class Trainer:
 						# test also reads a tensor loss back to compare it with 0; a step whose terms are all exactly 0.0 is not skipped here.)
 						if not torch.is_tensor(loss):
 							continue
-						loss.backward()
+						backward(loss)
 						if not step_per_epoch:
 							[o.step() for o in self.optims]
 					log.add(loss, loss_dict)
@@ -230,7 +230,7 @@ class Trainer:
 					batch = batch_to_device(batch, self.device)
 					self.val_optim.zero_grad()
 					loss, loss_dict = self.model(batch, epoch, opts=self.opts, **model_kwargs)
-					loss.backward()
+					backward(loss)
 					self.val_optim.step()
 				log.add(loss, loss_dict)
 		self._epoch_done()
